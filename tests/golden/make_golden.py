@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by running the REFERENCE on CPU in the build container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference tree (/root/reference, read-only) is imported through _refshim; it
+never travels to the GPU box.  What is committed is data only: seeded inputs,
+captured random draws and the reference's outputs / gradients.  Random draws are
+captured by re-seeding torch's global generator and replaying the reference's
+own draw sequence (same calls, same order), which reproduces them exactly.
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refshim  # noqa: E402
+import recipe  # noqa: E402
+
+_refshim.install()
+
+from gans.augment.adaptive_augment import AdaptiveAugment  # noqa: E402
+from gans.coords import CoordBridge  # noqa: E402
+from gans.models import ops as rops  # noqa: E402
+from gans.models.builder import build_discriminator, build_generator  # noqa: E402
+from gans.models.loss import GANLoss  # noqa: E402
+from gans.models.ops.upfirdn2d.upfirdn2d import upfirdn2d_native  # noqa: E402
+
+torch.set_num_threads(8)
+F = torch.nn.functional
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (npy(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(d)} arrays")
+
+
+def sd_np(prefix, sd):
+    return {prefix + k: v for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------
+def golden_ops():
+    g = torch.Generator().manual_seed(0)
+    out = {}
+
+    # fused_leaky_relu CPU branch, fwd + 1st + 2nd order
+    x = torch.randn(2, 6, 5, 7, generator=g, requires_grad=True)
+    b = torch.randn(6, generator=g, requires_grad=True)
+    y = rops.fused_leaky_relu(x, b, 0.2, 2 ** 0.5)
+    gy = torch.randn(y.shape, generator=g, requires_grad=True)
+    gx, gb = torch.autograd.grad(y, [x, b], gy, create_graph=True)
+    ggx = torch.randn(gx.shape, generator=g)
+    (ggy,) = torch.autograd.grad(gx, gy, ggx)
+    out.update(flr_x=x, flr_b=b, flr_y=y, flr_gy=gy, flr_gx=gx, flr_gb=gb, flr_ggx=ggx, flr_ggy=ggy)
+
+    # upfirdn2d_native: the four ADA configurations (incl. negative pads) + a 2-D kernel
+    x = torch.randn(2, 1, 15, 18, generator=g)
+    k12 = torch.randn(12, generator=g)
+    k2d = torch.randn(3, 4, generator=g)
+    cases = {
+        "upx": (k12[None], (2, 1), (1, 1), (6, 5, 0, 0)),
+        "upy": (k12[:, None], (1, 2), (1, 1), (0, 0, 6, 5)),
+        "dnx": (k12[None], (1, 1), (2, 1), (-1, -1, 0, 0)),
+        "dny": (k12[:, None], (1, 1), (1, 2), (0, 0, -1, -1)),
+        "k2d": (k2d, (2, 3), (3, 2), (2, 1, 3, 0)),
+        "k2dneg": (k2d, (1, 1), (1, 1), (-1, 2, 1, -2)),
+    }
+    out["ufd_x"] = x
+    out["ufd_k12"] = k12
+    out["ufd_k2d"] = k2d
+    for name, (k, up, down, pad) in cases.items():
+        out[f"ufd_{name}_y"] = upfirdn2d_native(x, k, *up, *down, *pad)
+        out[f"ufd_{name}_cfg"] = np.array([*up, *down, *pad])
+
+    # Resample / BlurVH / Pad
+    x = torch.randn(2, 3, 6, 8, generator=g)
+    out["rs_x"] = x
+    for ring in (True, False):
+        r = int(ring)
+        out[f"rs_up2_ring{r}"] = rops.Resample(up=2, ring=ring)(x)
+        out[f"rs_down2_ring{r}"] = rops.Resample(down=2, ring=ring)(x)
+        out[f"rs_blur_ring{r}"] = rops.Resample(ring=ring)(x)
+        out[f"rs_blurvh_ring{r}"] = rops.BlurVH(ring=ring)(x)
+        out[f"rs_pad_ring{r}"] = rops.Pad((1, 2, 2, 1), ring=ring)(x)
+
+    # PixelNorm, EqualLR Linear, MinibatchStdDev
+    x = torch.randn(4, 16, generator=g)
+    out["pn_x"], out["pn_y"] = x, rops.PixelNorm()(x)
+    lin = rops.EqualLR(torch.nn.Linear(16, 8), gain=2 ** 0.5, lr_mul=0.01)
+    with torch.no_grad():
+        lin.module.weight.copy_(torch.randn(8, 16, generator=g) * 100)
+        lin.module.bias.copy_(torch.randn(8, generator=g))
+    out["eq_w"], out["eq_b"], out["eq_y"] = lin.module.weight, lin.module.bias, lin(x)
+    x = torch.randn(8, 6, 3, 5, generator=g)
+    out["mb_x"], out["mb_y"] = x, rops.MinibatchStdDev(group=4, features=1)(x)
+    out["mb_y2"] = rops.MinibatchStdDev(group=4, features=2)(x[:2])
+
+    # FourierFeature (ctor uses numpy + torch RNG)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    pe = rops.FourierFeature(resolution=np.array([8, 64]), basis_scale="random", num_freqs=512, L_offset=(3, -1))
+    ang = (torch.rand(1, 2, 4, 16, generator=g) * 2 - 1) * 3.1
+    out.update(pe_freqs=pe.freqs, pe_phase=pe.phase, pe_angle=ang, pe_y=pe(ang))
+
+    # ModConv2d: trunk flavour (demod, no bias) train/eval; head flavour (no demod, bias)
+    for tag, demod, bias, O, I in (("trunk", True, False, 12, 20), ("head", False, True, 1, 20)):
+        torch.manual_seed(5)
+        m = rops.ModConv2d(in_ch=I, out_ch=O, mod_ch=16, ksize=1, stride=1, padding=0, demod=demod, bias=bias, ema=True)
+        with torch.no_grad():
+            m.ema_var.fill_(0.7)
+            m.mod.module.bias.copy_(torch.randn(I, generator=g) * 0.3)
+            if bias:
+                m.bias.copy_(torch.randn(1, O, 1, 1, generator=g))
+        x = torch.randn(3, I, 4, 6, generator=g, requires_grad=True)
+        s = torch.randn(3, 16, generator=g, requires_grad=True)
+        out.update({f"mc_{tag}_x": x, f"mc_{tag}_s": s})
+        out.update(sd_np(f"mc_{tag}_sd.", copy.deepcopy(m.state_dict())))
+        m.eval()
+        out[f"mc_{tag}_y_eval"] = m(x, s)
+        m.train()
+        y = m(x, s)
+        out[f"mc_{tag}_y_train"] = y
+        out[f"mc_{tag}_ema_after"] = m.ema_var.clone()
+        gy = torch.randn(y.shape, generator=g)
+        params = dict(m.named_parameters())
+        grads = torch.autograd.grad(y, [x, s] + list(params.values()), gy)
+        out[f"mc_{tag}_gy"] = gy
+        out[f"mc_{tag}_gx"], out[f"mc_{tag}_gs"] = grads[0], grads[1]
+        for k, gv in zip(params.keys(), grads[2:]):
+            out[f"mc_{tag}_g.{k}"] = gv
+
+    # GumbelSigmoid (replay the uniform draw of RelaxedBernoulli.rsample)
+    logits = torch.randn(2, 1, 4, 6, generator=g)
+    torch.manual_seed(11)
+    y = rops.GumbelSigmoid(temperature=1.0)(logits)
+    torch.manual_seed(11)
+    u = torch.distributions.utils.clamp_probs(torch.rand(logits.shape))
+    out.update(gs_logits=logits, gs_u=u, gs_y=y)
+    save("ops.npz", out)
+
+
+# ----------------------------------------------------------------------------
+def golden_coords():
+    out = {}
+    cb = CoordBridge(num_ring=64, num_points=512, min_depth=1.45, max_depth=80.0,
+                     angle_file=_refshim.REFERENCE_ROOT + "/data/coords/kitti_raw.npy")
+    out["angle_64x512"] = cb.angle
+    # a small synthetic angle file exercises the ctor resampling without the 1 MB npy
+    rng = np.random.RandomState(0)
+    elev = np.linspace(0.035, -0.43, 16)[:, None] + rng.randn(16, 96) * 1e-3
+    azim = np.linspace(np.pi, -np.pi, 96, endpoint=False)[None, :] + rng.randn(16, 96) * 1e-3
+    small = np.stack([elev, azim], axis=-1).astype(np.float32)
+    tmp = "/tmp/_dgv2_small_angle.npy"
+    np.save(tmp, small)
+    cs = CoordBridge(num_ring=8, num_points=32, min_depth=1.45, max_depth=80.0, angle_file=tmp)
+    out["small_angle_file"] = small
+    out["small_angle"] = cs.angle
+    g = torch.Generator().manual_seed(1)
+    depth = torch.rand(2, 1, 8, 32, generator=g) * 90.0  # some beyond max_depth
+    depth[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 1.45, 80.0])
+    out["depth"] = depth
+    for src, tgts in {
+        "depth": ["inv_depth", "inv_depth_norm", "depth_norm", "point_map", "point_set"],
+        "depth_norm": ["depth", "inv_depth", "inv_depth_norm", "point_map"],
+        "inv_depth": ["inv_depth_norm", "depth", "depth_norm"],
+        "inv_depth_norm": ["inv_depth", "depth", "depth_norm", "point_map", "point_set"],
+    }.items():
+        x = depth if src == "depth" else cs.convert(depth, "depth", src)
+        out[f"src_{src}"] = x
+        for tgt in tgts:
+            out[f"cv_{src}__{tgt}"] = cs.convert(x.clone(), src, tgt)
+    pm = cs.convert(depth, "depth", "point_map")
+    for tgt in ["point_set", "depth", "depth_norm", "inv_depth", "inv_depth_norm"]:
+        out[f"cv_point_map__{tgt}"] = cs.convert(pm.clone(), "point_map", tgt)
+    save("coords.npz", out)
+
+
+# ----------------------------------------------------------------------------
+def capture_g_noise(B, shape_hw, seed):
+    """Replay SynthesisNetwork.forward's shift draw (dusty_v2.py:268-273) and the
+    Gumbel uniform draw (RelaxedBernoulli.rsample) for a given seed."""
+    torch.manual_seed(seed)
+    shifts = torch.zeros((B, 2))
+    shifts[:, 1].uniform_(0, 1)
+    shifts = shifts.mul(2 * np.pi)
+    u = torch.distributions.utils.clamp_probs(torch.rand(B, 1, *shape_hw))
+    return shifts[:, 1].clone(), u
+
+
+def capture_ada(A, B, H, W, seed):
+    torch.manual_seed(seed)
+    Gm = A.sample_affine(B, H, W)
+    Cm = A.sample_color(B)
+    return Gm, Cm
+
+
+def run_steps(G, D, A, angle, x_real, B, tag, out, seeds, gp_weight=16.0):
+    """One G step, one D step and one R1 step of gans/trainer.py:262-451 on the
+    reference modules, recording inputs, captured draws, outputs and gradients."""
+    H, W = angle.shape[2:]
+    crit = GANLoss("nsgan")
+    gen = torch.Generator().manual_seed(seeds[0])
+    z1 = torch.randn(B, G.synthesis_network.in_ch, generator=gen)
+    z2 = torch.randn(B, G.synthesis_network.in_ch, generator=gen)
+    out[f"{tag}z1"], out[f"{tag}z2"], out[f"{tag}x_real"] = z1, z2, x_real
+    out.update(sd_np(f"{tag}G0.", copy.deepcopy(G.state_dict())))
+    ang = angle.repeat_interleave(B, dim=0)
+
+    # ---- G step -----------------------------------------------------------
+    G.train().requires_grad_(True)
+    D.requires_grad_(False)
+    s_g, s_a = seeds[1], seeds[2]
+    shifts, u = capture_g_noise(B, (H, W), s_g)
+    torch.manual_seed(s_g)
+    o = G(z1, angle=ang)
+    Gm, Cm = capture_ada(A, B, H, W, s_a)
+    torch.manual_seed(s_a)
+    x_aug = A(o["image"])
+    y_fake = D(x_aug)
+    loss_G = crit(None, y_fake, "G")
+    params = dict(G.named_parameters())
+    grads = torch.autograd.grad(loss_G, list(params.values()), allow_unused=True)
+    out.update({f"{tag}gs_shifts": shifts, f"{tag}gs_u": u, f"{tag}gs_adaG": Gm, f"{tag}gs_adaC": Cm,
+                f"{tag}gs_image": o["image"], f"{tag}gs_image_orig": o["image_orig"],
+                f"{tag}gs_raydrop_logit": o["raydrop_logit"], f"{tag}gs_raydrop_mask": o["raydrop_mask"],
+                f"{tag}gs_x_aug": x_aug, f"{tag}gs_y_fake": y_fake, f"{tag}gs_loss": loss_G})
+    for k, gv in zip(params.keys(), grads):
+        if gv is not None:
+            out[f"{tag}gs_grad.{k}"] = gv
+    out.update(sd_np(f"{tag}G1buf.", {k: v.clone() for k, v in G.state_dict().items()
+                                      if k.endswith("ema_var") or k == "w_avg"}))
+
+    # ---- D step -----------------------------------------------------------
+    G.requires_grad_(False)
+    D.requires_grad_(True)
+    s_g, s_ar, s_af = seeds[3], seeds[4], seeds[5]
+    shifts, u = capture_g_noise(B, (H, W), s_g)
+    torch.manual_seed(s_g)
+    with torch.no_grad():
+        x_fake = G(z2, angle=ang)["image"]
+    Gr, Cr = capture_ada(A, B, H, W, s_ar)
+    torch.manual_seed(s_ar)
+    xr = A(x_real).detach()
+    Gf, Cf = capture_ada(A, B, H, W, s_af)
+    torch.manual_seed(s_af)
+    xf = A(x_fake).detach()
+    y_real, y_fake = D(xr), D(xf)
+    loss_D = crit(y_real, y_fake, "D")
+    dparams = dict(D.named_parameters())
+    dgrads = torch.autograd.grad(loss_D, list(dparams.values()))
+    out.update({f"{tag}ds_shifts": shifts, f"{tag}ds_u": u, f"{tag}ds_adaG_real": Gr, f"{tag}ds_adaC_real": Cr,
+                f"{tag}ds_adaG_fake": Gf, f"{tag}ds_adaC_fake": Cf, f"{tag}ds_x_fake": x_fake,
+                f"{tag}ds_xr_aug": xr, f"{tag}ds_y_real": y_real, f"{tag}ds_y_fake": y_fake, f"{tag}ds_loss": loss_D})
+    for k, gv in zip(dparams.keys(), dgrads):
+        out[f"{tag}ds_gradnorm.{k}"] = gv.norm()
+        out[f"{tag}ds_gradslice.{k}"] = gv.flatten()[:64].clone()
+
+    # ---- lazy R1 ------------------------------------------------------------
+    s_a = seeds[6]
+    Gm, Cm = capture_ada(A, B, H, W, s_a)
+    xin = x_real.detach().clone().requires_grad_(True)
+    torch.manual_seed(s_a)
+    y = D(A(xin))
+    (gx,) = torch.autograd.grad(y.sum(), xin, create_graph=True)
+    r1 = (gx ** 2).sum(dim=[1, 2, 3]).mean()
+    loss = (gp_weight / 2) * r1 + 0.0 * y.squeeze()[0]
+    rgrads = torch.autograd.grad(loss, list(dparams.values()), allow_unused=True)
+    out.update({f"{tag}r1_adaG": Gm, f"{tag}r1_adaC": Cm, f"{tag}r1_gradx": gx, f"{tag}r1_penalty": r1})
+    for k, gv in zip(dparams.keys(), rgrads):
+        if gv is not None:
+            out[f"{tag}r1_gradnorm.{k}"] = gv.norm()
+            out[f"{tag}r1_gradslice.{k}"] = gv.flatten()[:64].clone()
+    return out
+
+
+def synthetic_reals(cb, B, H, W, seed):
+    """SURVEY.md section 8d synthetic real batch through the reference's fetch_reals math."""
+    g = torch.Generator().manual_seed(seed)
+    depth = torch.rand(B, 1, H, W, generator=g) * (80 - 1.45) + 1.45
+    mask = (torch.rand(B, 1, H, W, generator=g) < 0.85).float()
+    x = cb.convert(depth, "depth", "inv_depth_norm") * 2.0 - 1.0
+    return mask * x + (1 - mask) * -1.0
+
+
+def golden_small():
+    cfg = _refshim.load_cfg()
+    gk = cfg.model.generator
+    gk.mapping_kwargs.update(in_ch=32, out_ch=32)
+    gk.synthesis_kwargs.update(in_ch=32, ch_base=4, ch_max=16, resolution=[16, 64], layers=[2, 2])
+    dk = cfg.model.discriminator.layer_kwargs
+    dk.update(ch_base=4, ch_max=16, resolution=[16, 64])
+    np.random.seed(0)
+    torch.manual_seed(0)
+    G = build_generator(gk)
+    D = build_discriminator(cfg.model.discriminator)
+    recipe.fill_state_dict(G.state_dict(), 7)
+    recipe.fill_state_dict(D.state_dict(), 8)
+    A = AdaptiveAugment(p_init=0.6, p_target=0.6, kimg=500, **cfg.training.augment.policy)
+    tmp = "/tmp/_dgv2_small_angle.npy"
+    cb = CoordBridge(num_ring=16, num_points=64, min_depth=1.45, max_depth=80.0, angle_file=tmp)
+    B = 4
+    out = {"angle": cb.angle}
+    out.update(sd_np("D0.", copy.deepcopy(D.state_dict())))
+    x_real = synthetic_reals(cb, B, 16, 64, 21)
+    run_steps(G, D, A, cb.angle, x_real, B, "", out, seeds=[100, 101, 102, 103, 104, 105, 106])
+    # eval forward with truncation
+    G.eval()
+    shifts, u = capture_g_noise(B, (16, 64), 0)  # eval: no shift draw -> replay only the gumbel draw
+    torch.manual_seed(55)
+    with torch.no_grad():
+        o = G(out["z1"], angle=cb.angle.repeat_interleave(B, 0), truncation_psi=0.7)
+    torch.manual_seed(55)
+    out["ev_u"] = torch.distributions.utils.clamp_probs(torch.rand(B, 1, 16, 64))
+    out["ev_image"], out["ev_raydrop_logit"] = o["image"], o["raydrop_logit"]
+    out.update(sd_np("Gev.", {k: v.clone() for k, v in G.state_dict().items() if k.endswith("ema_var") or k == "w_avg"}))
+    save("model_small.npz", out)
+
+
+def golden_full():
+    cfg = _refshim.load_cfg()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    G = build_generator(cfg.model.generator)
+    D = build_discriminator(cfg.model.discriminator)
+    recipe.fill_state_dict(G.state_dict(), 1234)
+    recipe.fill_state_dict(D.state_dict(), 4321)
+    cb = CoordBridge(num_ring=64, num_points=512, min_depth=1.45, max_depth=80.0,
+                     angle_file=_refshim.REFERENCE_ROOT + "/data/coords/kitti_raw.npy")
+    B = 2
+    H, W = 64, 512
+    out = {}
+    for k, v in G.state_dict().items():
+        if k.endswith(("pe.freqs", "pe.phase")):
+            out["G." + k] = v.clone()
+    A = AdaptiveAugment(p_init=0.6, p_target=0.6, kimg=500, **cfg.training.augment.policy)
+    gen = torch.Generator().manual_seed(9)
+    z = torch.randn(B, 512, generator=gen)
+    x_real = synthetic_reals(cb, B, H, W, 22)
+    ang = cb.angle.repeat_interleave(B, dim=0)
+    crit = GANLoss("nsgan")
+
+    G.train().requires_grad_(True)
+    D.requires_grad_(False)
+    shifts, u = capture_g_noise(B, (H, W), 201)
+    torch.manual_seed(201)
+    o = G(z, angle=ang)
+    Gm, Cm = capture_ada(A, B, H, W, 202)
+    torch.manual_seed(202)
+    x_aug = A(o["image"])
+    y_fake = D(x_aug)
+    loss_G = crit(None, y_fake, "G")
+    params = dict(G.named_parameters())
+    grads = torch.autograd.grad(loss_G, list(params.values()), allow_unused=True)
+    out.update(z=z, gs_shifts=shifts, gs_u=u, gs_adaG=Gm, gs_adaC=Cm,
+               gs_image_orig=o["image_orig"].half(), gs_raydrop_logit=o["raydrop_logit"].half(),
+               gs_x_aug_row=x_aug[:, :, 31].clone(), gs_y_fake=y_fake, gs_loss=loss_G)
+    for k, gv in zip(params.keys(), grads):
+        if gv is not None:
+            out[f"gs_gradnorm.{k}"] = gv.norm()
+            out[f"gs_gradslice.{k}"] = gv.flatten()[:32].clone()
+    for k, v in G.state_dict().items():
+        if k.endswith("ema_var"):
+            out["G1buf." + k] = v.clone()
+
+    G.requires_grad_(False)
+    D.requires_grad_(True)
+    Gr, Cr = capture_ada(A, B, H, W, 203)
+    torch.manual_seed(203)
+    xr = A(x_real).detach()
+    y_real = D(xr)
+    y_fake2 = D(x_aug.detach())
+    loss_D = crit(y_real, y_fake2, "D")
+    dparams = dict(D.named_parameters())
+    dgrads = torch.autograd.grad(loss_D, list(dparams.values()))
+    out.update(ds_adaG_real=Gr, ds_adaC_real=Cr, ds_y_real=y_real, ds_loss=loss_D)
+    for k, gv in zip(dparams.keys(), dgrads):
+        out[f"ds_gradnorm.{k}"] = gv.norm()
+        out[f"ds_gradslice.{k}"] = gv.flatten()[:32].clone()
+    out["x_real"] = x_real
+    save("model_full.npz", out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "coords", "small", "full"]
+    if "ops" in which:
+        golden_ops()
+    if "coords" in which:
+        golden_coords()
+    if "small" in which:
+        golden_small()
+    if "full" in which:
+        golden_full()

@@ -1,0 +1,34 @@
+"""Deterministic "weights by recipe" used on both sides of the full-size parity
+fixtures: tests/golden/make_golden.py fills the *reference* modules with it and
+the tests fill the oracle / HIP modules with it, so 40 M parameters never have to
+be committed.  PE freqs/phase (numpy RNG in the reference ctor) are committed
+instead."""
+import zlib
+
+import torch
+
+SKIP_SUFFIXES = ("pe.freqs", "pe.phase", "resample.kernel", "downsample.kernel", "blur_v.kernel", "blur_h.kernel",
+                 "raydrop_const")
+
+
+def fill_state_dict(sd, seed=1234):
+    """In sorted-key order, overwrite every entry (except fixed buffers) in place:
+    weights ~ N(0,1); biases ~ 0.1*N(0,1); ema_var ~ U(0.5,1.5); w_avg ~ 0.1*N(0,1).
+    The per-key generator seed is crc32(key) ^ seed so that the values do not depend
+    on which other keys exist."""
+    for key in sorted(sd.keys()):
+        if key.endswith(SKIP_SUFFIXES):
+            continue
+        t = sd[key]
+        g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ seed) & 0x7FFFFFFF)
+        if key.endswith("ema_var"):
+            v = torch.rand(t.shape, generator=g) + 0.5
+        elif key.endswith("bias") or key.endswith("w_avg"):
+            v = torch.randn(t.shape, generator=g) * 0.1
+        elif "mapping_network" in key:
+            v = torch.randn(t.shape, generator=g) * 100.0  # EqualLR lr_mul=0.01 init (common.py:173)
+        else:
+            v = torch.randn(t.shape, generator=g)
+        with torch.no_grad():
+            t.copy_(v.to(t.dtype))
+    return sd

@@ -1,0 +1,186 @@
+"""Pin the CPU oracle (oracle/) against golden vectors emitted by the reference
+itself (tests/golden/make_golden.py).  CPU only; this is what makes the oracle
+trustworthy as the checker for the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub_dict
+from oracle import augment, coords, model, ops, step
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    torch.testing.assert_close(a.float(), b.float(), rtol=rtol, atol=atol)
+
+
+def test_fused_leaky_relu_all_orders(g_ops):
+    x = g_ops["flr_x"].clone().requires_grad_(True)
+    b = g_ops["flr_b"].clone().requires_grad_(True)
+    gy = g_ops["flr_gy"].clone().requires_grad_(True)
+    y = ops.fused_leaky_relu(x, b)
+    close(y, g_ops["flr_y"])
+    gx, gb = torch.autograd.grad(y, [x, b], gy, create_graph=True)
+    close(gx, g_ops["flr_gx"])
+    close(gb, g_ops["flr_gb"])
+    (ggy,) = torch.autograd.grad(gx, gy, g_ops["flr_ggx"])
+    close(ggy, g_ops["flr_ggy"])
+
+
+@pytest.mark.parametrize("name", ["upx", "upy", "dnx", "dny", "k2d", "k2dneg"])
+def test_upfirdn2d(g_ops, name):
+    cfg = [int(v) for v in g_ops[f"ufd_{name}_cfg"]]
+    k12, k2d = g_ops["ufd_k12"], g_ops["ufd_k2d"]
+    k = {"upx": k12[None], "dnx": k12[None], "upy": k12[:, None], "dny": k12[:, None]}.get(name, k2d)
+    y = ops.upfirdn2d(g_ops["ufd_x"], k, up=cfg[0:2], down=cfg[2:4], pad=cfg[4:8])
+    close(y, g_ops[f"ufd_{name}_y"])
+
+
+@pytest.mark.parametrize("ring", [True, False])
+def test_resample_family(g_ops, ring):
+    x = g_ops["rs_x"]
+    r = int(ring)
+    close(ops.resample(x, up=2, ring=ring), g_ops[f"rs_up2_ring{r}"])
+    close(ops.resample(x, down=2, ring=ring), g_ops[f"rs_down2_ring{r}"])
+    close(ops.resample(x, ring=ring), g_ops[f"rs_blur_ring{r}"])
+    close(ops.blur_vh(x, ring), g_ops[f"rs_blurvh_ring{r}"])
+    close(ops.pad_ring(x, (1, 2, 2, 1), ring), g_ops[f"rs_pad_ring{r}"])
+
+
+def test_small_dense_ops(g_ops):
+    close(ops.pixel_norm(g_ops["pn_x"]), g_ops["pn_y"])
+    close(ops.equal_lr_linear(g_ops["pn_x"], g_ops["eq_w"], g_ops["eq_b"], gain=2 ** 0.5, lr_mul=0.01), g_ops["eq_y"])
+    close(ops.minibatch_stddev(g_ops["mb_x"], 4, 1), g_ops["mb_y"])
+    close(ops.minibatch_stddev(g_ops["mb_x"][:2], 4, 2), g_ops["mb_y2"])
+
+
+def test_fourier_feature(g_ops):
+    y = ops.fourier_feature(g_ops["pe_angle"], g_ops["pe_freqs"], g_ops["pe_phase"])
+    close(y, g_ops["pe_y"], atol=2e-4)  # |c| reaches ~1e3 rad: fp32 argument rounding
+    assert torch.equal(g_ops["pe_freqs"][:, 1], g_ops["pe_freqs"][:, 1].round())  # azimuth freqs are integers
+
+
+@pytest.mark.parametrize("tag,demod,bias", [("trunk", True, False), ("head", False, True)])
+def test_modconv(g_ops, tag, demod, bias):
+    sd = sub_dict(g_ops, f"mc_{tag}_sd.")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "ema_var"}
+    x = g_ops[f"mc_{tag}_x"].clone().requires_grad_(True)
+    s = g_ops[f"mc_{tag}_s"].clone().requires_grad_(True)
+    args = (leaves["weight"], leaves["mod.module.weight"], leaves["mod.module.bias"], sd["ema_var"])
+    b = leaves["bias"] if bias else None
+    y_eval, ema = ops.modconv(x, s, *args, bias=b, demod=demod, training=False)
+    close(y_eval, g_ops[f"mc_{tag}_y_eval"], atol=1e-4)
+    assert torch.equal(ema, sd["ema_var"])
+    y, ema = ops.modconv(x, s, *args, bias=b, demod=demod, training=True)
+    close(y, g_ops[f"mc_{tag}_y_train"], atol=1e-4)
+    close(ema, g_ops[f"mc_{tag}_ema_after"])
+    keys = list(leaves.keys())
+    grads = torch.autograd.grad(y, [x, s] + [leaves[k] for k in keys], g_ops[f"mc_{tag}_gy"])
+    close(grads[0], g_ops[f"mc_{tag}_gx"], atol=1e-4)
+    close(grads[1], g_ops[f"mc_{tag}_gs"], atol=1e-4)
+    for k, gv in zip(keys, grads[2:]):
+        close(gv, g_ops[f"mc_{tag}_g.{k}"], rtol=1e-4, atol=1e-4)
+
+
+def test_gumbel_sigmoid(g_ops):
+    close(ops.gumbel_sigmoid(g_ops["gs_logits"], g_ops["gs_u"]), g_ops["gs_y"])
+
+
+# ----------------------------------------------------------------------------
+def test_coords_angle_grid(g_coords):
+    a = coords.resample_angle_grid(g_coords["small_angle_file"].numpy(), 8, 32)
+    np.testing.assert_allclose(a, g_coords["small_angle"].numpy(), rtol=0, atol=2e-6)
+    assert g_coords["angle_64x512"].shape == (1, 2, 64, 512)
+    assert abs(float(g_coords["angle_64x512"].abs().max()) - 3.1354) < 1e-3  # SURVEY section 8c probe
+
+
+def test_coords_convert_all_pairs(g_coords):
+    angle = g_coords["small_angle"].numpy()
+    n = 0
+    for key, want in g_coords.items():
+        if not key.startswith("cv_"):
+            continue
+        src, tgt = key[3:].split("__")
+        x = g_coords["cv_depth__point_map"] if src == "point_map" else g_coords[f"src_{src}"]
+        got = coords.convert(x.numpy(), src, tgt, 1.45, 80.0, angle)
+        np.testing.assert_allclose(got, want.numpy(), rtol=1e-6, atol=1e-6, err_msg=key)
+        n += 1
+    assert n >= 20
+
+
+# ----------------------------------------------------------------------------
+def _ada(d, tag):
+    return {"G": d[f"{tag}adaG"], "C": d[f"{tag}adaC"]}
+
+
+def test_small_model_g_step(g_small):
+    d = g_small
+    sdG, sdD = sub_dict(d, "G0."), sub_dict(d, "D0.")
+    B = d["z1"].shape[0]
+    angle = d["angle"].repeat_interleave(B, 0)
+    loss, grads, bufs, ex = step.g_step(sdG, sdD, d["z1"], angle, d["gs_shifts"], d["gs_u"], ada=_ada(d, "gs_"))
+    close(ex["image"], d["gs_image"], atol=2e-5)
+    close(ex["x_aug"], d["gs_x_aug"], atol=5e-5)
+    close(ex["y_fake"], d["gs_y_fake"], rtol=1e-4, atol=1e-4)
+    close(loss, d["gs_loss"], rtol=1e-5)
+    ref = sub_dict(d, "gs_grad.")
+    assert set(k for k, v in grads.items() if v is not None) == set(ref.keys())
+    for k, gv in ref.items():
+        tol = 1e-3 * float(gv.abs().max()) + 1e-9
+        assert float((grads[k] - gv).abs().max()) <= tol, k
+    for k, v in sub_dict(d, "G1buf.").items():
+        close(bufs[k], v)
+
+
+def test_small_model_d_and_r1_step(g_small):
+    d = g_small
+    # G buffers at the D step are the ones left by the G step
+    sdG = dict(sub_dict(d, "G0."))
+    sdG.update(sub_dict(d, "G1buf."))
+    sdD = sub_dict(d, "D0.")
+    B = d["z2"].shape[0]
+    angle = d["angle"].repeat_interleave(B, 0)
+    loss, grads, _, ex = step.d_step(
+        sdG, sdD, d["z2"], angle, d["ds_shifts"], d["ds_u"], d["x_real"],
+        ada_real={"G": d["ds_adaG_real"], "C": d["ds_adaC_real"]},
+        ada_fake={"G": d["ds_adaG_fake"], "C": d["ds_adaC_fake"]})
+    close(ex["y_real"], d["ds_y_real"], rtol=1e-4, atol=1e-4)
+    close(ex["y_fake"], d["ds_y_fake"], rtol=1e-4, atol=1e-4)
+    close(loss, d["ds_loss"], rtol=1e-5)
+    for k, gv in sub_dict(d, "ds_gradslice.").items():
+        want_norm = float(d[f"ds_gradnorm.{k}"])
+        assert abs(float(grads[k].norm()) - want_norm) <= 1e-3 * want_norm + 1e-9, k
+        close(grads[k].flatten()[:64], gv, rtol=1e-3, atol=1e-3 * float(gv.abs().max()) + 1e-9)
+    r1, rgrads, ex = step.r1_step(sdD, d["x_real"], 16.0, ada=_ada(d, "r1_"))
+    close(ex["grad_x"], d["r1_gradx"], rtol=1e-3, atol=1e-3 * float(d["r1_gradx"].abs().max()))
+    close(r1, d["r1_penalty"], rtol=1e-4)
+    # bias gradients of R1 are second-order-only terms (fp32 cancellation noise in the
+    # reference itself), so the absolute floor is tied to the largest gradient norm.
+    top = max(float(v) for k, v in d.items() if k.startswith("r1_gradnorm."))
+    for k, gv in sub_dict(d, "r1_gradslice.").items():
+        want_norm = float(d[f"r1_gradnorm.{k}"])
+        assert abs(float(rgrads[k].norm()) - want_norm) <= 2e-3 * want_norm + 1e-5 * top, k
+
+
+def test_small_model_eval_truncation(g_small):
+    d = g_small
+    sdG = dict(sub_dict(d, "G0."))
+    sdG.update(sub_dict(d, "Gev."))
+    B = d["z1"].shape[0]
+    with torch.no_grad():
+        o, _ = model.generator(sdG, d["z1"], d["angle"].repeat_interleave(B, 0), training=False,
+                               gumbel_u=d["ev_u"], truncation_psi=0.7)
+    close(o["raydrop_logit"], d["ev_raydrop_logit"], atol=2e-5)
+    close(o["image"], d["ev_image"], atol=2e-5)
+
+
+def test_ada_fixed_max_padding_is_equivalent(g_small):
+    """A static (graph-capturable) padding >= the data-dependent one of get_padding gives the
+    same augmented image: the design premise of the fused HIP resampler."""
+    d = g_small
+    x = d["x_real"]
+    H, W = x.shape[2:]
+    want = augment.ada_forward(x, d["ds_adaG_real"], d["ds_adaC_real"])
+    got = augment.ada_forward(x, d["ds_adaG_real"], d["ds_adaC_real"], pads=(W - 1, W - 1, H - 1, H - 1))
+    close(got, want, atol=5e-5)
