@@ -1,0 +1,82 @@
+// Shared device helpers for libdgv2 (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dgv2.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define DGV2_WAVE 64
+
+template <int DT> struct dtype_of;
+template <> struct dtype_of<DGV2_F32> { typedef float type; };
+template <> struct dtype_of<DGV2_BF16> { typedef bf16_t type; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte vector of T: 4 floats or 8 bf16.
+template <typename T> struct vec16 {
+  static constexpr int N = 16 / sizeof(T);
+  union {
+    uint4 raw;
+    T e[16 / sizeof(T)];
+  };
+  __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  __device__ __forceinline__ float get(int i) const { return to_f32(e[i]); }
+  __device__ __forceinline__ void set(int i, float v) { e[i] = from_f32<T>(v); }
+};
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Floor division / modulo for possibly negative numerators (b > 0).
+__host__ __device__ __forceinline__ int floordiv(int a, int b) {
+  int q = a / b;
+  return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+__host__ __device__ __forceinline__ int floormod(int a, int b) {
+  int r = a % b;
+  return r < 0 ? r + b : r;
+}
+
+// wave-level sum (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+#define DGV2_RETURN_LAST()                 \
+  do {                                     \
+    hipError_t e__ = hipGetLastError();    \
+    return (int)e__;                       \
+  } while (0)
+
+#define DGV2_DISPATCH_DTYPE(dtype, ...)                      \
+  do {                                                       \
+    if ((dtype) == DGV2_F32) {                               \
+      typedef float T;                                       \
+      __VA_ARGS__;                                           \
+    } else if ((dtype) == DGV2_BF16) {                       \
+      typedef bf16_t T;                                      \
+      __VA_ARGS__;                                           \
+    } else {                                                 \
+      return DGV2_EINVAL;                                    \
+    }                                                        \
+  } while (0)
+
+static inline int grid_for(int64_t work, int block, int cap = 256 * 16) {
+  int64_t g = (work + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}

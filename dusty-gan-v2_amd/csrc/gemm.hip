@@ -1,0 +1,79 @@
+// Batched channel GEMMs: the contraction of the modulated 1x1 convolution and its gradients.
+// Reference: the grouped F.conv2d of ModConv2d.forward (gans/models/ops/style.py:105-118).
+#include "gemm_core.h"
+
+namespace {
+
+template <typename T, typename TY, int TO>
+int launch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
+                  int64_t wstride, hipStream_t st) {
+  constexpr int CE = 16 / sizeof(T);
+  DenseRowLoader<T> al{(const T*)w, wstride, I, O, I, (I % CE == 0) && (wstride % CE == 0) && aligned16(w)};
+  DenseRowLoader<T> bl{(const T*)x, (int64_t)P * ldx, ldx, P, I, (ldx % CE == 0) && aligned16(x)};
+  constexpr int YE = 16 / sizeof(TY);
+  StoreEpilogue<TY> epi{(TY*)y, (int64_t)P * ldy, ldy, O, P,
+                        (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & (4 * sizeof(TY) - 1)) == 0)};
+  (void)YE;
+  dim3 grid((P + 127) / 128, (O + TO - 1) / TO, B);
+  gemm_nn_kernel<T, TO, DenseRowLoader<T>, DenseRowLoader<T>, StoreEpilogue<TY>><<<grid, 256, 0, st>>>(al, bl, epi, I);
+  return 0;
+}
+
+template <typename T, typename TY>
+int dispatch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
+                    int64_t wstride, hipStream_t st) {
+  if (O <= 16) return launch_bmm_nn<T, TY, 16>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+  if (O <= 32) return launch_bmm_nn<T, TY, 32>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+  if (O <= 64) return launch_bmm_nn<T, TY, 64>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+  return launch_bmm_nn<T, TY, 128>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+}
+
+template <typename T, int TO, int TJ>
+int launch_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I, int O, int ldgy, int ldx,
+                  int ksplit, hipStream_t st) {
+  constexpr int CE = 16 / sizeof(T);
+  DenseKLoader<T> al{(const T*)gy, (int64_t)P * ldgy, ldgy, O, (ldgy % CE == 0) && aligned16(gy)};
+  DenseKLoader<T> bl{(const T*)x, (int64_t)P * ldx, ldx, I, (ldx % CE == 0) && aligned16(x)};
+  const int64_t klen = (((int64_t)P + ksplit - 1) / ksplit + 31) / 32 * 32;
+  dim3 grid((I + TJ - 1) / TJ, (O + TO - 1) / TO, B * ksplit);
+  gemm_tn_kernel<T, TO, TJ, DenseKLoader<T>, DenseKLoader<T>><<<grid, 256, 0, st>>>(al, bl, gw, O, I, P, klen, ksplit,
+                                                                                   (int64_t)O * I, I);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dgv2_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
+                           int64_t wstride, int dtype, int ydtype, void* stream) {
+  if (!y || !x || !w || B <= 0 || P <= 0 || I <= 0 || O <= 0 || ldx < I || ldy < O) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DGV2_F32 && ydtype == DGV2_F32)
+    dispatch_bmm_nn<float, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+  else if (dtype == DGV2_BF16 && ydtype == DGV2_BF16)
+    dispatch_bmm_nn<bf16_t, bf16_t>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+  else if (dtype == DGV2_BF16 && ydtype == DGV2_F32)
+    dispatch_bmm_nn<bf16_t, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+  else
+    return DGV2_EINVAL;
+  DGV2_RETURN_LAST();
+}
+
+extern "C" int dgv2_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I, int O, int ldgy, int ldx,
+                           int dtype, void* stream) {
+  if (!gw || !gy || !x || B <= 0 || P <= 0 || I <= 0 || O <= 0 || ldgy < O || ldx < I) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  // enough blocks to fill 256 CUs: split the pixel axis when (batch x tiles) is small
+  const int tiles = B * ((O + 63) / 64) * ((I + 127) / 128);
+  int ksplit = 1;
+  while (tiles * ksplit < 512 && P / (ksplit * 2) >= 512) ksplit *= 2;
+  if (ksplit > 1) {
+    hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)B * O * I, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  DGV2_DISPATCH_DTYPE(dtype, {
+    if (O <= 16) launch_bmm_tn<T, 16, 128>(gw, gy, x, B, P, I, O, ldgy, ldx, ksplit, st);
+    else if (O <= 32) launch_bmm_tn<T, 32, 128>(gw, gy, x, B, P, I, O, ldgy, ldx, ksplit, st);
+    else launch_bmm_tn<T, 64, 128>(gw, gy, x, B, P, I, O, ldgy, ldx, ksplit, st);
+  });
+  DGV2_RETURN_LAST();
+}

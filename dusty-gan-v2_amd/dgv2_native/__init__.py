@@ -1,0 +1,98 @@
+"""ctypes binding of libdgv2.so -- the C ABI declared in include/dgv2.h.
+
+This is the only place the host side touches the native library.  There is no
+fallback: if the shared object is missing the import fails loudly, and every
+entry point raises RuntimeError on a non-zero return code (the reference's
+TORCH_CHECK -> c10::Error -> RuntimeError convention,
+gans/models/ops/fused_act/fused_bias_act.cpp:10-16).
+
+Tensors are passed as raw device pointers; the launch goes to torch's CURRENT HIP
+stream of the calling thread, so the calls are captured by torch.cuda.graph like any
+ATen op (outputs are allocated by the caller from torch's caching allocator).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
+
+F32, BF16 = 0, 1
+ABI_VERSION = 1
+
+_c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> argument ctypes (return type is always int); mirrors include/dgv2.h one to one
+SIGNATURES = {
+    "dgv2_abi_version": [],
+    "dgv2_fused_bias_act": [_c_ptr] * 4 + [_c_i64] * 3 + [_c_int, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
+    "dgv2_bias_grad": [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr],
+    "dgv2_upfirdn2d": [_c_ptr] * 3 + [_c_int] * 15 + [_c_ptr],
+    "dgv2_resample": [_c_ptr] * 4 + [_c_int] * 19 + [_c_ptr],
+    "dgv2_fourier_feature": [_c_ptr] * 5 + [_c_int] * 8 + [_c_ptr],
+    "dgv2_downsample_angle": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr],
+    "dgv2_bmm_nn": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_int, _c_int, _c_ptr],
+    "dgv2_bmm_tn": [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr],
+    "dgv2_sum_squares": [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_ptr],
+    "dgv2_conv_fwd": [_c_ptr] * 3 + [_c_int] * 11 + [_c_ptr],
+    "dgv2_conv_dgrad": [_c_ptr] * 4 + [_c_int] * 11 + [_c_ptr],
+    "dgv2_conv_wgrad": [_c_ptr] * 3 + [_c_int] * 11 + [_c_ptr],
+    "dgv2_gen_tail_fwd": [_c_ptr] * 7 + [_c_int] * 3 + [_c_f32] * 3 + [_c_ptr],
+    "dgv2_gen_tail_bwd": [_c_ptr] * 11 + [_c_int] * 3 + [_c_f32] * 3 + [_c_ptr],
+    "dgv2_ada_apply": [_c_ptr] * 8 + [_c_int] * 5 + [_c_ptr],
+    "dgv2_coords_convert": [_c_ptr] * 4 + [_c_int] * 3 + [_c_f32] * 3 + [_c_int, _c_ptr],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()). "
+            "The MI355X path has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    got = lib.dgv2_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libdgv2.so ABI version {got}, binding expects {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f"dgv2: unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def check(*tensors):
+    """Mirror of the reference's CHECK_INPUT: device-resident and contiguous."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("dgv2: tensor must be a CUDA/HIP tensor (no CPU fallback)")
+        if not t.is_contiguous():
+            raise RuntimeError("dgv2: tensor must be contiguous")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")

@@ -1,0 +1,338 @@
+"""DUSty-v2 generator / discriminator for MI355X.
+
+Same constructor kwargs, forward signatures, output dicts and state-dict layout as the
+reference (gans/models/dusty_v2.py:13-396); the module tree below exists to hold the
+parameters under the reference's names, while `forward` drives the libdgv2 kernels on
+channels-last activations:
+
+  generator level:  FIR up-2 of h written next to the in-place positional encoding
+                    (no concat) -> modulated 1x1 conv as an MFMA batched GEMM -> fused bias+lrelu
+                    -> second modulated conv -> both heads as one 2-channel GEMM (fp32) ->
+                    skip accumulation; output stage (shift cancel, x0.25, tanh, Gumbel ray-drop)
+                    is one kernel.
+  discriminator:    BlurVH -> 1x1 stem -> 4 residual blocks of ring-padded implicit-GEMM convs
+                    (padding folded into addressing) with FIR blurs -> mbstd -> 3x3 -> Linear x2.
+
+Compute dtype: `num_fp16_layers` keeps its reference meaning (-1 = every conv layer in reduced
+precision, 0 = fp32, n = last n generator blocks / first n discriminator layers); the reduced
+precision here is bfloat16 storage with fp32 MFMA accumulation (the reference autocasts to fp16).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.modules.utils import _pair
+
+from . import base, dusty_v1, ops
+from .ops import native
+
+LOW = torch.bfloat16
+
+
+class MappingNetwork(nn.Sequential):
+    """reference: dusty_v2.py:13-29."""
+
+    def __init__(self, in_ch, out_ch, depth=2):
+        self.in_ch, self.out_ch, self.depth = in_ch, out_ch, depth
+        layers = [ops.PixelNorm()]
+        ch = in_ch
+        for _ in range(depth):
+            layers.append(nn.Sequential(
+                ops.EqualLR(nn.Linear(ch, out_ch), gain=math.sqrt(2), lr_mul=0.01),
+                nn.LeakyReLU(negative_slope=0.2),
+            ))
+            ch = out_ch
+        super().__init__(*layers)
+
+
+class Head(nn.Module):
+    """reference: dusty_v2.py:32-57.  All heads share the input, so they run as ONE GEMM whose
+    per-sample weight rows are the stacked head weights; output stays fp32 (dusty_v2.py:174-178)."""
+
+    def __init__(self, in_ch, mod_ch, out_ch):
+        super().__init__()
+        self.in_ch, self.mod_ch, self.out_ch = in_ch, mod_ch, out_ch
+        self.heads = nn.ModuleDict()
+        for o in out_ch:
+            if o["ch"] == 0:
+                continue
+            self.heads[o["name"]] = ops.ModConv2d(out_ch=o["ch"], in_ch=in_ch, mod_ch=mod_ch, ksize=1, stride=1,
+                                                  padding=0, demod=False, ema=True)
+
+    def forward_cl(self, x, style):
+        """x [B,H,W,C] -> fp32 [B,H,W,sum(ch)] (heads concatenated in dict order)."""
+        training = self.training
+        sumsq = native.sum_squares(x) if training else None
+        wbs, biases = [], []
+        for head in self.heads.values():
+            wbs.append(head.sample_weights(style, sumsq, x.numel()))
+            biases.append(head.bias.reshape(-1))
+        wb = torch.cat(wbs, dim=1)
+        y = native.mod_gemm(x, wb, torch.float32)
+        return y + torch.cat(biases).reshape(1, 1, 1, -1)
+
+    def forward(self, x, style):
+        y = ops.from_cl(self.forward_cl(ops.to_cl(x), style))
+        out, c = {}, 0
+        for name, head in self.heads.items():
+            out[name] = y[:, c:c + head.out_ch]
+            c += head.out_ch
+        return out
+
+
+class SynthesisBlock(nn.Module):
+    """reference: dusty_v2.py:60-183."""
+
+    def __init__(self, in_ch, mid_ch, out_ch, mod_ch, resolution, up=2, resample_dir="hw",
+                 resample_window=[1, 3, 3, 1], use_noise=True, use_pe=True, pe_type="random", pe_ch=512,
+                 pe_scale_offset=(3, -1), ring=True):
+        super().__init__()
+        if use_noise:
+            raise NotImplementedError("use_noise=True is off the dusty_v2.yaml path and not built")
+        if not use_pe:
+            raise NotImplementedError("blocks without positional encoding do not occur in dusty_v2")
+        self.use_pe, self.use_fp16 = use_pe, False
+        self.is_first = in_ch == 0
+        self.num_conv = 0
+        self.ring = ring
+        if up > 1:
+            self.resample = ops.Resample(up=up, window=resample_window, ring=ring, direction=resample_dir)
+            self.downsample = ops.Resample(down=up, window=resample_window, ring=ring, direction=resample_dir)
+        else:
+            self.resample = nn.Identity()
+            self.downsample = None
+        self.pe = ops.FourierFeature(resolution=resolution, basis_scale=pe_type, num_freqs=pe_ch,
+                                     L_offset=pe_scale_offset)
+        kw = dict(out_ch=mid_ch, mod_ch=mod_ch, ksize=1, stride=1, padding=0, bias=False, ema=True)
+        self.conv1 = ops.ModConv2d(in_ch=in_ch + self.pe.out_ch, **kw)
+        self.noise1 = None
+        self.bias_act1 = ops.FusedLeakyReLU(mid_ch)
+        self.num_conv += 1
+        if not self.is_first:
+            self.conv2 = ops.ModConv2d(in_ch=mid_ch, **kw)
+            self.noise2 = None
+            self.bias_act2 = ops.FusedLeakyReLU(mid_ch)
+            self.num_conv += 1
+        self.head = Head(mid_ch, mod_ch, out_ch)
+
+    @property
+    def compute_dtype(self):
+        return LOW if self.use_fp16 else torch.float32
+
+    def downsample_angle(self, angle, shift=None, batch=None):
+        """sin/cos -> FIR down-2 -> atan2 (reference: dusty_v2.py:135-140), one kernel."""
+        B = angle.shape[0] if batch is None else batch
+        return native.downsample_angle(angle.float().contiguous(), shift, self.downsample.kernel, B, self.ring)
+
+    def forward_cl(self, h, skip, ws, angle, shift, B):
+        """h [B,h,w,C] or None; skip fp32 [B,h,w,nheads] or None; ws = 3 style vectors [B,D];
+        angle fp32 [B or 1, 2, H, W] for this level; shift [B] added to the azimuth or None."""
+        dt = self.compute_dtype
+        spec = None if self.is_first else self.resample.spec
+        hin = None if h is None else h.to(dt)
+        x1 = native.up_cat_pe(hin, spec, angle, shift, self.pe.freqs2.contiguous(), self.pe.phase, dt, B)
+        h = self.bias_act1.forward_cl(self.conv1.forward_cl(x1, ws[0]))
+        nxt = 1
+        if not self.is_first:
+            h = self.bias_act2.forward_cl(self.conv2.forward_cl(h, ws[1]))
+            nxt = 2
+        o = self.head.forward_cl(h, ws[nxt])
+        if skip is not None:
+            o = o + self.resample.forward_cl(skip)
+        return h, o
+
+    def extra_repr(self):
+        return f"use_fp16={self.use_fp16}"
+
+
+class SynthesisNetwork(nn.Module):
+    """reference: dusty_v2.py:186-308."""
+
+    def __init__(self, in_ch, out_ch, ch_base=64, ch_max=512, resolution=(64, 256), ring=True,
+                 layers=[2, 2, 2, 2], num_fp16_layers=-1, use_noise=True, pe_type="random",
+                 pe_scale_offset=(3, -1), aug_coords=True, aug_coords_blitting=False, output_scale=1 / 4.0):
+        super().__init__()
+        self.in_ch, self.out_ch = in_ch, out_ch
+        self.resolution_out = np.array(_pair(resolution))
+        self.resolution_in = self.resolution_out // np.prod(layers)
+        self.layers = nn.ModuleList()
+        res = self.resolution_in.copy()
+        n = len(layers)
+
+        def ch(i):
+            return min(ch_base << (n - i), ch_max)
+
+        for i, scale in enumerate([1] + list(layers)):
+            res = res * scale
+            self.layers.append(SynthesisBlock(
+                in_ch=ch(i - 1) if i != 0 else 0, mid_ch=ch(i), out_ch=out_ch, mod_ch=in_ch,
+                resolution=res.copy(), up=scale, resample_window=[1, 3, 3, 1], use_noise=use_noise,
+                use_pe=scale > 1 or i == 0, pe_type=pe_type, pe_scale_offset=pe_scale_offset, ring=ring))
+        for i, m in enumerate(self.layers[::-1]):
+            if i < num_fp16_layers or num_fp16_layers == -1:
+                m.use_fp16 = True
+        self.num_styles = len(self.layers) * 2
+        self.aug_coords = aug_coords
+        self.aug_coords_blitting = aug_coords_blitting
+        self.output_scale = output_scale
+        self.head_names = [o["name"] for o in out_ch if o["ch"] != 0]
+        acts = {}
+        for o in out_ch:
+            a = o["act"]
+            acts[o["name"]] = nn.Identity() if a is None else (eval(a)() if isinstance(a, str) else a())
+        self.output_acts = nn.ModuleDict(acts)
+        if self.head_names != ["image", "raydrop_logit"] or not isinstance(self.output_acts["image"], nn.Tanh) \
+                or not isinstance(self.output_acts["raydrop_logit"], nn.Identity):
+            raise NotImplementedError("the fused output stage implements heads (image: tanh, raydrop_logit: id)")
+
+    def synthesize(self, ws, angle, shifts="auto"):
+        """Trunk of the network: returns (skip fp32 [B,H,W,2] before the output stage, shift or None).
+        shifts: "auto" draws the training-time azimuth shift (dusty_v2.py:267-274); a tensor injects it."""
+        B, N, _ = ws.shape
+        assert N == self.num_styles, f"{self.num_styles} != {N}"
+        shift = None
+        if isinstance(shifts, torch.Tensor):
+            shift = shifts.float().contiguous()
+        elif shifts == "auto" and self.training and self.aug_coords:
+            shift = torch.rand(B, device=ws.device)
+            if self.aug_coords_blitting:
+                W = int(self.resolution_out[1])
+                shift = (shift * W).round() / W
+            shift = shift * (2 * math.pi)
+        angle = angle.float().contiguous()
+        if angle.shape[0] not in (1, B):
+            raise RuntimeError(f"angle batch {angle.shape[0]} does not match style batch {B}")
+        # multi-scale angles, full resolution last; the shift enters at the finest level only
+        pyramid = [(angle, shift)]
+        a, s = angle, shift
+        for layer in self.layers[:0:-1]:
+            a = layer.downsample_angle(a, s, B if s is not None else None)
+            s = None
+            pyramid.insert(0, (a, None))
+        h, skip, i = None, None, 0
+        for layer, (a, s) in zip(self.layers, pyramid):
+            h, skip = layer.forward_cl(h, skip, (ws[:, i], ws[:, i + 1], ws[:, min(i + 2, N - 1)]), a, s, B)
+            i += layer.num_conv
+        return skip, shift
+
+    def forward(self, ws, angle, shifts="auto"):
+        skip, shift = self.synthesize(ws, angle, shifts)
+        u = torch.full((ws.shape[0], 1, *skip.shape[1:3]), 0.5, device=skip.device)
+        _, image, logit, _ = native.gen_tail(skip, shift, u, self.output_scale, 0.0, 1.0)
+        return {"image": image, "raydrop_logit": logit}
+
+
+class Generator(base.Generator):
+    """reference: dusty_v2.py:311-322 (+ base.Generator.forward, base.py:26-63)."""
+
+    def __init__(self, mapping_kwargs, synthesis_kwargs, measurement_kwargs):
+        super().__init__(
+            mapping_network=MappingNetwork(**mapping_kwargs),
+            synthesis_network=SynthesisNetwork(**synthesis_kwargs),
+            measurement_model=dusty_v1.RayDropModel(**measurement_kwargs),
+        )
+
+    def forward_synthesis(self, w, angle=None):
+        angle = self.angle if angle is None else angle
+        return self.synthesis_network(w, angle)
+
+    def forward(self, z, angle=None, style_mixing=False, truncation_psi=1.0, input_w=False, noise=None):
+        """Fused path: synthesis trunk + ONE output-stage kernel (shift cancel, scale, tanh, Gumbel
+        ray-drop).  `noise` optionally injects {"shifts": [B], "gumbel_u": [B,1,H,W]} (parity tests).
+        Falls back to the modular reference flow when forward hooks watch the GumbelSigmoid module."""
+        mm = self.measurement_model
+        if len(mm.gumbel_sigmoid._forward_hooks) > 0:
+            return super().forward(z, angle, style_mixing, truncation_psi, input_w)
+        w = z if input_w else self.forward_mapping(z, style_mixing)
+        assert w.ndim == 3
+        if self.training:
+            self.moving_average_w(w)
+        else:
+            w = self.truncation_trick(w, truncation_psi)
+        angle = self.angle if angle is None else angle
+        noise = noise or {}
+        skip, shift = self.synthesis_network.synthesize(w, angle, noise.get("shifts", "auto"))
+        B, H, W, _ = skip.shape
+        u = noise.get("gumbel_u")
+        u = native.gumbel_uniform((B, 1, H, W), skip.device) if u is None else u.float().contiguous()
+        image, image_orig, logit, mask = native.gen_tail(
+            skip, shift, u, self.synthesis_network.output_scale, float(mm.raydrop_const),
+            mm.gumbel_sigmoid.temperature)
+        return {"image": image, "raydrop_logit": logit, "w": w, "raydrop_mask": mask, "image_orig": image_orig}
+
+
+class ResidualBlock(nn.Module):
+    """reference: dusty_v2.py:325-345 (ring padding hard-coded)."""
+
+    def __init__(self, in_ch: int, out_ch: int):
+        super().__init__()
+        kw = dict(bias=False, ring=True, equal_lr=True)
+        self.conv1 = ops.Conv2d(in_ch, in_ch, 3, 1, 1, **kw)
+        self.bias_act1 = ops.FusedLeakyReLU(in_ch)
+        self.resample = ops.Resample(window=[1, 3, 3, 1], ring=True)
+        self.conv2 = ops.Conv2d(in_ch, out_ch, 3, 2, 1, **kw)
+        self.bias_act2 = ops.FusedLeakyReLU(out_ch)
+        self.skip = ops.Conv2d(in_ch, out_ch, 1, 2, 0, **kw)
+
+    def forward_cl(self, x):
+        h = self.bias_act1.forward_cl(self.conv1.forward_cl(x))
+        h = self.conv2.forward_cl(self.resample.forward_cl(h))
+        h = self.bias_act2.forward_cl(h)
+        s = self.skip.forward_cl(self.resample.forward_cl(x))
+        return (h + s) * (1.0 / math.sqrt(2))
+
+    def forward(self, x):
+        return ops.from_cl(self.forward_cl(ops.to_cl(x)))
+
+
+class _ClAdapter(nn.Module):
+    pass
+
+
+class Discriminator(nn.Module):
+    """reference: dusty_v2.py:348-396."""
+
+    def __init__(self, in_ch: int, ch_base: int = 32, ch_max: int = 512, mbdis_group: int = 4, mbdis_feat: int = 1,
+                 resolution=(64, 512), ring=True, num_fp16_layers=-1, pre_blur=True):
+        super().__init__()
+        res_in = _pair(256 if resolution is None else resolution)
+        n_down = int(np.log2(min(res_in) / 4))
+        res_out = tuple(map(lambda x: x >> n_down, res_in))
+
+        def ch(i):
+            return min(ch_base << i, ch_max)
+
+        kw = dict(bias=False, ring=ring, equal_lr=True)
+        self.num_fp16_layers = num_fp16_layers
+        c_in = in_ch * 2 if pre_blur else in_ch
+        layers = [ops.BlurVH(ring=ring)] if pre_blur else []
+        layers += [ops.Conv2d(c_in, ch(0), 1, 1, 0, **kw)]
+        layers += [ops.FusedLeakyReLU(ch(0))]
+        layers += [ResidualBlock(ch(i), ch(i + 1)) for i in range(n_down)]
+        self.layers = nn.Sequential(*layers)
+        self.epilogue = nn.Sequential(
+            ops.MinibatchStdDev(group=mbdis_group, features=mbdis_feat),
+            ops.Conv2d(ch(4) + mbdis_feat, ch(4), 3, 1, 1, **kw),
+            ops.FusedLeakyReLU(ch(4)),
+            nn.Flatten(),
+            ops.EqualLR(nn.Linear(ch(4) * int(np.prod(res_out)), ch(4), bias=False)),
+            ops.FusedLeakyReLU(ch(4)),
+            ops.EqualLR(nn.Linear(ch(4), 1)),
+        )
+
+    def forward(self, h):
+        """h [B,C,H,W] (C = 1 on the dusty_v2 path) -> logits [B,1]."""
+        x = ops.to_cl(h.float())
+        for i, layer in enumerate(self.layers):
+            low = (self.num_fp16_layers > i) or (self.num_fp16_layers == -1)
+            x = layer.forward_cl(x.to(LOW if low else torch.float32))
+        x = x.float()
+        mb, conv, act1, _, lin1, act2, lin2 = self.epilogue
+        cin = x.shape[3] + mb.features
+        cpad = (cin + 3) // 4 * 4  # 16-byte channel vectors for the fp32 implicit GEMM
+        x = mb.forward_cl(x, pad_to=cpad)
+        x = act1.forward_cl(conv.forward_cl(x, pad_in_to=cpad))
+        x = ops.from_cl(x).flatten(1)  # NCHW flatten order of the reference's nn.Flatten
+        x = act2.forward_cl(lin1(x))
+        return lin2(x)

@@ -1,0 +1,59 @@
+"""GAN objectives (reference: gans/models/loss.py:21-88).  Plain tensor math on [B,1] logits."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _rel(a, b):
+    return a - b.mean(0, keepdim=True)
+
+
+class GANLoss(nn.Module):
+    def __init__(self, metric: str, smoothing: float = 1.0):
+        super().__init__()
+        self.register_buffer("label_real", torch.tensor(1.0))
+        self.register_buffer("label_fake", torch.tensor(0.0))
+        self.metric = metric
+        self.smoothing = smoothing
+
+    def forward(self, pred_real, pred_fake, mode):
+        if mode == "G":
+            return self.loss_G(pred_real, pred_fake)
+        if mode == "D":
+            return self.loss_D(pred_real, pred_fake)
+        raise ValueError(mode)
+
+    def loss_D(self, pred_real, pred_fake):
+        m = self.metric
+        if m == "nsgan":
+            return F.softplus(-pred_real).mean() + F.softplus(pred_fake).mean()
+        if m == "wgan":
+            return -pred_real.mean() + pred_fake.mean()
+        if m == "lsgan":
+            return F.mse_loss(pred_real, torch.full_like(pred_real, self.smoothing)) + \
+                F.mse_loss(pred_fake, torch.zeros_like(pred_fake))
+        if m == "hinge":
+            return F.relu(1 - pred_real).mean() + F.relu(1 + pred_fake).mean()
+        if m == "ragan":
+            return F.softplus(-_rel(pred_real, pred_fake)).mean() + F.softplus(_rel(pred_fake, pred_real)).mean()
+        if m == "rahinge":
+            return F.relu(1 - _rel(pred_real, pred_fake)).mean() + F.relu(1 + _rel(pred_fake, pred_real)).mean()
+        if m == "ralsgan":
+            return ((_rel(pred_real, pred_fake) - 1.0) ** 2).mean() + ((_rel(pred_fake, pred_real) + 1.0) ** 2).mean()
+        raise NotImplementedError(m)
+
+    def loss_G(self, pred_real, pred_fake):
+        m = self.metric
+        if m == "nsgan":
+            return F.softplus(-pred_fake).mean()
+        if m in ("wgan", "hinge"):
+            return -pred_fake.mean()
+        if m == "lsgan":
+            return F.mse_loss(pred_fake, torch.ones_like(pred_fake))
+        if m == "ragan":
+            return F.softplus(_rel(pred_real, pred_fake)).mean() + F.softplus(-_rel(pred_fake, pred_real)).mean()
+        if m == "rahinge":
+            return F.relu(1 + _rel(pred_real, pred_fake)).mean() + F.relu(1 - _rel(pred_fake, pred_real)).mean()
+        if m == "ralsgan":
+            return ((_rel(pred_real, pred_fake) + 1.0) ** 2).mean() + ((_rel(pred_fake, pred_real) - 1.0) ** 2).mean()
+        raise NotImplementedError(m)

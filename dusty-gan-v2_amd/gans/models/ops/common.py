@@ -1,0 +1,211 @@
+"""Building blocks with the reference's names and state-dict layout
+(gans/models/ops/common.py), executed by libdgv2 kernels.
+
+Each module keeps the reference's NCHW `forward` for drop-in use and adds a
+channels-last `forward_cl` used by the fused generator / discriminator."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.modules.utils import _pair, _quadruple
+
+from . import native
+
+__all__ = ["Pad", "filter2d", "Resample", "BlurVH", "EqualLR", "Conv2d", "PixelNorm", "MinibatchStdDev",
+           "to_cl", "from_cl"]
+
+
+def to_cl(x):
+    """NCHW -> contiguous [B,H,W,C]."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def from_cl(x):
+    """[B,H,W,C] -> NCHW view."""
+    return x.permute(0, 3, 1, 2)
+
+
+class Pad(nn.Module):
+    """reference: common.py:10-24 (circular along W when ring, replicate along H)."""
+
+    def __init__(self, padding, ring=False, mode="replicate"):
+        super().__init__()
+        self.padding = _quadruple(padding)
+        self.horizontal = "circular" if ring else mode
+        self.vertical = mode
+
+    def forward(self, h):
+        left, right, top, bottom = self.padding
+        h = F.pad(h, (left, right, 0, 0), mode=self.horizontal)
+        return F.pad(h, (0, 0, top, bottom), mode=self.vertical)
+
+    def extra_repr(self):
+        return f"padding={self.padding}, horizontal={self.horizontal}, vertical={self.vertical}"
+
+
+class Resample(nn.Module):
+    """Ring-aware FIR up/down/blur (reference: common.py:45-135) -> dgv2_resample."""
+
+    def __init__(self, up=1, down=1, window=[1, 3, 3, 1], ring=True, normalize=True, direction="hw"):
+        super().__init__()
+        assert direction in ("h", "w", "hw")
+        self.up, self.down = _pair(up), _pair(down)
+        self.window, self.ring, self.direction = list(window), ring, direction
+        up_h = self.up[0] if "h" in direction else 1
+        up_w = self.up[1] if "w" in direction else 1
+        kernel = torch.tensor(window, dtype=torch.float32)
+        if normalize:
+            kernel = kernel / kernel.sum()
+        self.register_buffer("kernel", kernel * math.sqrt(up_h * up_w))
+        self.spec = native.ResampleSpec(list(window), self.up, self.down, ring, direction, normalize)
+
+    def forward_cl(self, x):
+        return native.resample(x, self.spec)
+
+    def forward(self, h):
+        return from_cl(self.forward_cl(to_cl(h)))
+
+    def extra_repr(self):
+        return f'filter_type={self.window}, up={self.up}, down={self.down}, direction="{self.direction}"'
+
+
+class BlurVH(nn.Module):
+    """reference: common.py:141-155."""
+
+    def __init__(self, window=[1, 2, 1], ring=True):
+        super().__init__()
+        self.blur_v = Resample(window=window, ring=ring, direction="h")
+        self.blur_h = Resample(window=window, ring=ring, direction="w")
+
+    def forward_cl(self, x):
+        return torch.cat([self.blur_v.forward_cl(x), self.blur_h.forward_cl(x)], dim=3)
+
+    def forward(self, x):
+        return from_cl(self.forward_cl(to_cl(x)))
+
+
+class EqualLR(nn.Module):
+    """Runtime weight scaling (reference: common.py:158-184).  Wraps nn.Linear or nn.Conv2d; the
+    wrapped module only stores the parameters -- the arithmetic is ours."""
+
+    def __init__(self, module, gain: float = 1.0, lr_mul=1.0):
+        super().__init__()
+        self.module = module
+        self.gain, self.lr_mul = gain, lr_mul
+        self.gain_ = gain * lr_mul
+        self.scale = 1.0 / math.sqrt(self.module.weight[0].numel())
+        nn.init.normal_(self.module.weight, 0.0, 1.0 / lr_mul)
+        if getattr(self.module, "bias", None) is not None:
+            nn.init.constant_(self.module.bias, 0.0)
+
+    def effective_weight(self):
+        return self.module.weight * (self.scale * self.gain_)
+
+    def forward(self, x):
+        if isinstance(self.module, nn.Linear):
+            y = F.linear(x, self.module.weight * self.scale)
+            if self.module.bias is not None:
+                y = y + self.module.bias
+            return y * self.gain_
+        raise RuntimeError("EqualLR(conv) is executed by ops.Conv2d on this build")
+
+    def extra_repr(self):
+        return f"gain={self.gain}, lr_mul={self.lr_mul}"
+
+
+class Conv2d(nn.Sequential):
+    """Pad + Conv2d + EqualLR (reference: common.py:187-210) -> dgv2_conv_* implicit GEMM with the
+    ring / replicate padding folded into the address computation."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, stride, padding, bias=True, ring=False, equal_lr=False,
+                 gain=1.0, lr_mul=1.0):
+        layers = []
+        if padding != 0:
+            layers += [Pad(padding=padding, ring=ring)]
+        conv = nn.Conv2d(in_ch, out_ch, kernel_size, stride, 0, bias=bias)
+        layers += [EqualLR(conv, gain, lr_mul) if equal_lr else conv]
+        super().__init__(*layers)
+        kh, kw = _pair(kernel_size)
+        self.geom = native.ConvGeom(kh, kw, _pair(stride)[0], int(padding), ring)
+        self.in_ch, self.out_ch = in_ch, out_ch
+
+    def _params(self):
+        last = self[len(self) - 1]
+        if isinstance(last, EqualLR):
+            return last.effective_weight(), last.module.bias, last.gain_
+        return last.weight, last.bias, 1.0
+
+    def forward_cl(self, x, pad_in_to=None):
+        w, b, gain = self._params()
+        w = w.permute(0, 2, 3, 1)  # [O,kh,kw,C]
+        if pad_in_to is not None and pad_in_to > w.shape[3]:
+            w = F.pad(w, (0, pad_in_to - w.shape[3]))
+        y = native.conv_ring(x, w.contiguous(), self.geom)
+        if b is not None:
+            y = y + (b * gain).to(y.dtype)
+        return y
+
+    def forward(self, x):
+        return from_cl(self.forward_cl(to_cl(x)))
+
+
+class PixelNorm(nn.Module):
+    """reference: common.py:213-223."""
+
+    def forward(self, x, alpha: float = 1e-8):
+        return x / x.pow(2.0).mean(dim=1, keepdim=True).add(alpha).sqrt()
+
+
+class MinibatchStdDev(nn.Module):
+    """reference: common.py:226-250 (group members are strided through the batch)."""
+
+    def __init__(self, group=4, features=1):
+        super().__init__()
+        self.group, self.features = group, features
+
+    def stat(self, x, channels_last):
+        """x float32; returns the per-sample statistic [B, features]."""
+        B = x.shape[0]
+        g = min(B, self.group)
+        if channels_last:  # [B,H,W,C]
+            H, W, C = x.shape[1:]
+            y = x.reshape(g, B // g, H, W, self.features, C // self.features)
+            sd = torch.sqrt(y.var(0, unbiased=False) + 1e-8)  # [m,H,W,F,C/F]
+            st = sd.mean(dim=(1, 2, 4))
+        else:  # [B,C,H,W]
+            C, H, W = x.shape[1:]
+            y = x.reshape(g, B // g, self.features, C // self.features, H, W)
+            sd = torch.sqrt(y.var(0, unbiased=False) + 1e-8)  # [m,F,C/F,H,W]
+            st = sd.mean(dim=(2, 3, 4))
+        return st.repeat(g, 1)
+
+    def forward(self, x, alpha: float = 1e-8):
+        B, C, H, W = x.shape
+        st = self.stat(x, False)
+        return torch.cat([x, st[:, :, None, None].expand(B, self.features, H, W)], dim=1)
+
+    def forward_cl(self, x, pad_to=None):
+        B, H, W, C = x.shape
+        st = self.stat(x, True)
+        parts = [x, st[:, None, None, :].expand(B, H, W, self.features)]
+        total = C + self.features
+        if pad_to is not None and pad_to > total:
+            parts.append(x.new_zeros(B, H, W, pad_to - total))
+        return torch.cat(parts, dim=3)
+
+    def extra_repr(self):
+        return f"group={self.group}, features={self.features}"
+
+
+def filter2d(x, kernel, gain=1):
+    """Separable blur with ring / replicate extension (reference: common.py:27-42); only used by
+    the warm-up blur of the trainer, which is off in configs/gans/dusty_v2.yaml (sigma 0)."""
+    assert kernel.ndim == 1
+    kernel = kernel / kernel.sum() * (gain ** 0.5)
+    k = len(kernel)
+    p0, p1 = k // 2, (k - 1) // 2
+    x = F.pad(x, (p0, p1, 0, 0), mode="circular")
+    x = F.pad(x, (0, 0, p0, p1), mode="replicate")
+    x = (x.unfold(3, k, 1) * kernel.to(x.dtype)).sum(-1)
+    return (x.unfold(2, k, 1) * kernel.to(x.dtype)).sum(-1)

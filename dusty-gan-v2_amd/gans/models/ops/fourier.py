@@ -1,0 +1,61 @@
+"""Fourier-feature positional encoding of the laser angles (reference:
+gans/models/ops/fourier.py:11-85).  Buffers `freqs` [F,2,1,1] and `phase` [F] keep the
+reference layout; the encoding itself is dgv2_fourier_feature."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import native
+from .common import from_cl
+
+__all__ = ["FourierFeature"]
+
+
+class FourierFeature(nn.Module):
+    def __init__(self, resolution, basis_scale="random", num_freqs=512, L_offset=(3, -1), mapping=False,
+                 mapping_ch=64):
+        super().__init__()
+        if mapping:
+            raise NotImplementedError("FourierFeature(mapping=True) is unused by dusty_v2 and not built")
+        self.resolution = resolution
+        self.L_h = int(np.ceil(np.log2(resolution[0]))) + L_offset[0]
+        self.L_w = int(np.ceil(np.log2(resolution[1]))) + L_offset[1]
+        band_h, band_w = 2 ** (self.L_h - 1), 2 ** (self.L_w - 1)
+        self.max_band = (band_h ** 2 + band_w ** 2) ** 0.5
+        n = num_freqs // 2
+        # same draw order as the reference ctor (fourier.py:32-40): torch uniform, numpy choice, torch rand
+        if basis_scale == "random":
+            freqs_h = torch.empty(n, 1).uniform_(-band_h, band_h)
+            cand = 2 ** np.arange(self.L_w)
+            cand = list(-cand) + [0] + list(cand)
+            freqs_w = torch.from_numpy(np.random.choice(cand, size=(n, 1)))
+            phase = torch.rand(n) * 2 * np.pi
+        elif basis_scale == "random_2":
+            freqs_h = torch.empty(n, 1).uniform_(-band_h, band_h)
+            cand = np.arange(band_w)
+            cand = list(-cand) + [0] + list(cand)
+            freqs_w = torch.from_numpy(np.random.choice(cand, size=(n, 1)))
+            phase = torch.rand(n) * 2 * np.pi
+        else:
+            raise ValueError(basis_scale)
+        freqs = torch.cat([freqs_h, freqs_w.to(freqs_h.dtype)], dim=-1)
+        self.register_buffer("freqs", freqs[..., None, None])
+        self.register_buffer("phase", phase)
+        self.basis_ch = self.out_ch = 2 * n
+        self.mapping = None
+
+    @property
+    def freqs2(self):
+        return self.freqs.reshape(-1, 2)
+
+    def encode_into(self, out, c0, angle, shift=None):
+        native.fourier_feature_into(out, c0, angle, shift, self.freqs2.contiguous(), self.phase)
+
+    def forward(self, angles, dtype=torch.float32):
+        B, _, H, W = angles.shape
+        out = torch.empty((B, H, W, self.out_ch), device=angles.device, dtype=dtype)
+        self.encode_into(out, 0, angles.float().contiguous())
+        return from_cl(out)
+
+    def extra_repr(self):
+        return f"shape={self.resolution}, num_freqs={self.basis_ch}, L=({self.L_h}, {self.L_w})"

@@ -1,0 +1,483 @@
+"""Autograd-aware wrappers around the libdgv2 C ABI (include/dgv2.h).
+
+Internal layout is channels-last: activations are contiguous [B, H, W, C] tensors in
+float32 (parity mode) or bfloat16 (throughput mode, fp32 accumulate).  Parameters
+stay float32 masters; weight gradients are produced in float32.
+
+Every op that sits on the discriminator side of the R1 penalty (gans/trainer.py:419-451
+of the reference) is closed under differentiation: linear ops pair a forward Function
+with its transpose, convolutions form the {fwd, dgrad, wgrad} triple, bias+lrelu reuses
+its masked form -- so double backward never leaves the HIP kernels.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+import dgv2_native as N
+
+_EPS_U = torch.finfo(torch.float32).eps
+
+
+def _dt(t):
+    return N.dtype_code(t)
+
+
+# ---------------------------------------------------------------------------------------
+# fused bias + leaky ReLU   (reference: gans/models/ops/fused_act/fused_act.py:20-109)
+# ---------------------------------------------------------------------------------------
+def _bias_act_raw(x, bias, ref, grad, alpha, scale, step_b, size_b):
+    N.check(x, bias, ref)
+    y = torch.empty_like(x)
+    N.call("dgv2_fused_bias_act", N.ptr(y), N.ptr(x), N.ptr(bias), N.ptr(ref), x.numel(), step_b, size_b,
+           3, grad, alpha, scale, _dt(x), N.stream())
+    return y
+
+
+class _BiasActBackward(Function):
+    @staticmethod
+    def forward(ctx, gy, out, has_bias, alpha, scale, step_b, size_b):
+        gy = gy.contiguous()
+        gx = _bias_act_raw(gy, None, out, 1, alpha, scale, step_b, size_b)
+        gb = None
+        if has_bias:
+            gb = torch.empty(size_b, device=gy.device, dtype=torch.float32)
+            N.call("dgv2_bias_grad", N.ptr(gb), N.ptr(gx), gx.numel(), step_b, size_b, _dt(gx), N.stream())
+            gb = gb.to(gy.dtype)
+        ctx.save_for_backward(out)
+        ctx.cfg = (alpha, scale, step_b, size_b)
+        return gx, gb
+
+    @staticmethod
+    def backward(ctx, ggx, ggb):
+        (out,) = ctx.saved_tensors
+        alpha, scale, step_b, size_b = ctx.cfg
+        ggb = None if ggb is None else ggb.contiguous().to(ggx.dtype)
+        ggy = _bias_act_raw(ggx.contiguous(), ggb, out, 1, alpha, scale, step_b, size_b)
+        return ggy, None, None, None, None, None, None
+
+
+class _BiasAct(Function):
+    @staticmethod
+    def forward(ctx, x, bias, alpha, scale, step_b):
+        x = x.contiguous()
+        size_b = 1 if bias is None else bias.numel()
+        out = _bias_act_raw(x, None if bias is None else bias.contiguous(), None, 0, alpha, scale, step_b, size_b)
+        ctx.save_for_backward(out)
+        ctx.cfg = (bias is not None, alpha, scale, step_b, size_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        (out,) = ctx.saved_tensors
+        has_bias, alpha, scale, step_b, size_b = ctx.cfg
+        gx, gb = _BiasActBackward.apply(gy, out, has_bias, alpha, scale, step_b, size_b)
+        return gx, gb, None, None, None
+
+
+def bias_act(x, bias=None, alpha=0.2, scale=math.sqrt(2.0), channels_last=True):
+    """y = lrelu(x + b_c) * scale.  channels_last: channel is the LAST dim of x, else dim 1."""
+    if bias is not None:
+        bias = bias.to(x.dtype)
+    step_b = 1 if (channels_last or x.ndim <= 2) else int(math.prod(x.shape[2:]))
+    return _BiasAct.apply(x, bias, float(alpha), float(scale), step_b)
+
+
+# ---------------------------------------------------------------------------------------
+# ring-aware FIR resampler   (reference: gans/models/ops/common.py:45-135)
+# ---------------------------------------------------------------------------------------
+class ResampleSpec:
+    """Static description of one Resample module: per-axis taps / up / down / p0 / p1."""
+
+    def __init__(self, window, up=(1, 1), down=(1, 1), ring=True, direction="hw", normalize=True):
+        k = len(window)
+        w = torch.tensor(window, dtype=torch.float32)
+        self.ring = bool(ring)
+        self.axes = []
+        for ax, name in enumerate("hw"):
+            if name in direction:
+                u, d = int(up[ax]), int(down[ax])
+                if u > 1:
+                    p0, p1 = (k - u + 1) // 2 + u - 1, (k - u) // 2
+                else:
+                    p0, p1 = (k - d + 1) // 2, (k - d) // 2
+                self.axes.append((k, u, d, p0, p1))
+            else:
+                self.axes.append((1, 1, 1, 0, 0))
+        up_h = self.axes[0][1]
+        up_w = self.axes[1][1]
+        taps = (w / w.sum() if normalize else w) * math.sqrt(up_h * up_w)
+        one = torch.ones(1)
+        self.taps_cpu = (taps if "h" in direction else one, taps if "w" in direction else one)
+        self._dev = {}
+
+    def taps(self, device):
+        if device not in self._dev:
+            self._dev[device] = tuple(t.to(device) for t in self.taps_cpu)
+        return self._dev[device]
+
+    def out_size(self, H, W):
+        out = []
+        for L, (k, u, d, p0, p1) in zip((H, W), self.axes):
+            full = L * u + p0 + p1 - k + 1
+            out.append((full + d - 1) // d)
+        return tuple(out)
+
+
+def _resample_raw(x, spec, adjoint, in_hw, out=None, ldy=None, ldx=None, C=None):
+    """x [B,h,w,ldx]; forward maps in_hw -> spec.out_size(in_hw); adjoint the other way."""
+    B = x.shape[0]
+    H, W = in_hw
+    Ho, Wo = spec.out_size(H, W)
+    ldx = x.shape[3] if ldx is None else ldx
+    C = ldx if C is None else C
+    oh, ow = (H, W) if adjoint else (Ho, Wo)
+    if out is None:
+        out = torch.empty((B, oh, ow, C), device=x.device, dtype=x.dtype)
+        ldy = C
+    th, tw = spec.taps(x.device)
+    (kh, uh, dh, p0h, _), (kw, uw, dw, p0w, _) = spec.axes
+    N.call("dgv2_resample", N.ptr(out), N.ptr(x), N.ptr(th), N.ptr(tw), B, H, W, C, Ho, Wo, ldx, ldy,
+           kh, uh, dh, p0h, kw, uw, dw, p0w, int(spec.ring), int(adjoint), _dt(x), N.stream())
+    return out
+
+
+class _Resample(Function):
+    @staticmethod
+    def forward(ctx, x, spec, adjoint, in_hw):
+        x = x.contiguous()
+        N.check(x)
+        ctx.cfg = (spec, adjoint, in_hw)
+        return _resample_raw(x, spec, adjoint, in_hw)
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, adjoint, in_hw = ctx.cfg
+        return _Resample.apply(g, spec, not adjoint, in_hw), None, None, None
+
+
+def resample(x, spec):
+    """x [B,H,W,C] channels-last."""
+    return _Resample.apply(x, spec, False, (x.shape[1], x.shape[2]))
+
+
+# ---------------------------------------------------------------------------------------
+# Fourier features / angle pyramid (no gradient: angles are inputs of the training path)
+# ---------------------------------------------------------------------------------------
+def fourier_feature_into(out, c0, angle, shift, freqs2, phase):
+    """Write cat(sin, cos) of the encoding into channels [c0, c0+2F) of `out` [B,H,W,ld]."""
+    B, H, W, ld = out.shape
+    F = phase.numel()
+    N.check(out, angle, shift, freqs2, phase)
+    N.call("dgv2_fourier_feature", N.ptr(out), N.ptr(angle), N.ptr(shift), N.ptr(freqs2), N.ptr(phase),
+           B, angle.shape[0], H, W, F, ld, c0, _dt(out), N.stream())
+
+
+def downsample_angle(angle, shift, taps, B, ring=True):
+    Ba, _, H, W = angle.shape
+    N.check(angle, shift, taps)
+    out = torch.empty((B, 2, H // 2, W // 2), device=angle.device, dtype=torch.float32)
+    N.call("dgv2_downsample_angle", N.ptr(out), N.ptr(angle), N.ptr(shift), N.ptr(taps), B, Ba, H, W, int(ring),
+           N.stream())
+    return out
+
+
+def sum_squares(x, C=None):
+    """fp32 scalar: sum of squares of the first C channels of a channels-last tensor."""
+    ld = x.shape[-1]
+    C = ld if C is None else C
+    acc = torch.zeros((), device=x.device, dtype=torch.float32)
+    N.check(x)
+    N.call("dgv2_sum_squares", N.ptr(acc), N.ptr(x), x.numel() // ld, C, ld, _dt(x), N.stream())
+    return acc
+
+
+# ---------------------------------------------------------------------------------------
+# level input of the generator: FIR up-2 of h written next to the positional encoding
+# (reference: SynthesisBlock.forward, gans/models/dusty_v2.py:153-159 -- resample + cat)
+# ---------------------------------------------------------------------------------------
+class _UpCatPE(Function):
+    @staticmethod
+    def forward(ctx, h, spec, angle, shift, freqs2, phase, dtype, B):
+        F2 = 2 * phase.numel()
+        if h is None:
+            H, W = angle.shape[2:]
+            Cin = 0
+        else:
+            h = h.contiguous()
+            B = h.shape[0]
+            Cin = h.shape[3]
+            H, W = spec.out_size(h.shape[1], h.shape[2])
+        x1 = torch.empty((B, H, W, Cin + F2), device=angle.device, dtype=dtype)
+        if h is not None:
+            _resample_raw(h, spec, False, (h.shape[1], h.shape[2]), out=x1, ldy=Cin + F2)
+        fourier_feature_into(x1, Cin, angle, shift, freqs2, phase)
+        ctx.cfg = (spec, None if h is None else (h.shape[1], h.shape[2]), Cin)
+        return x1
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, in_hw, Cin = ctx.cfg
+        if in_hw is None:
+            return (None,) * 8
+        g = g.contiguous()
+        gh = _resample_raw(g, spec, True, in_hw, ldx=g.shape[3], C=Cin)
+        return gh, None, None, None, None, None, None, None
+
+
+def up_cat_pe(h, spec, angle, shift, freqs2, phase, dtype, B):
+    """[B,H,W,Cin+2F] = cat(FIR-up2(h), PE(angle (+shift on azimuth))) without a concat pass."""
+    return _UpCatPE.apply(h, spec, angle, shift, freqs2, phase, dtype, B)
+
+
+# ---------------------------------------------------------------------------------------
+# batched channel GEMM = contraction of the modulated 1x1 conv
+# (reference: grouped F.conv2d in ModConv2d.forward, gans/models/ops/style.py:105-118)
+# ---------------------------------------------------------------------------------------
+def _bmm_nn_raw(x3, w3, out_dtype):
+    """x3 [B,P,I]; w3 [Bw,O,I] (Bw = B or 1) same dtype -> [B,P,O]."""
+    B, P, I = x3.shape
+    Bw, O, _ = w3.shape
+    N.check(x3, w3)
+    y = torch.empty((B, P, O), device=x3.device, dtype=out_dtype)
+    N.call("dgv2_bmm_nn", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
+           _dt(x3), N.dtype_code(y), N.stream())
+    return y
+
+
+def _bmm_tn_raw(gy3, x3):
+    """gy3 [B,P,O], x3 [B,P,I] -> fp32 [B,O,I]."""
+    B, P, O = gy3.shape
+    I = x3.shape[2]
+    N.check(gy3, x3)
+    gw = torch.empty((B, O, I), device=x3.device, dtype=torch.float32)
+    N.call("dgv2_bmm_tn", N.ptr(gw), N.ptr(gy3), N.ptr(x3), B, P, I, O, O, I, _dt(x3), N.stream())
+    return gw
+
+
+class _ModGemm(Function):
+    """y[b,p,o] = sum_i x[b,p,i] w[b,o,i]; w is an fp32 master ([B,O,I] or shared [1,O,I])."""
+
+    @staticmethod
+    def forward(ctx, x, w, out_dtype):
+        shp = x.shape
+        x3 = x.contiguous().reshape(shp[0], -1, shp[-1])
+        wc = w.detach().to(x.dtype).contiguous()
+        y = _bmm_nn_raw(x3, wc, out_dtype)
+        ctx.save_for_backward(x3, wc)
+        ctx.cfg = (shp, w.shape[0] == 1)
+        return y.reshape(*shp[:-1], w.shape[1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x3, wc = ctx.saved_tensors
+        shp, shared = ctx.cfg
+        gy3 = gy.contiguous().reshape(x3.shape[0], -1, wc.shape[1]).to(x3.dtype)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = wc.transpose(1, 2).contiguous()
+            gx = _bmm_nn_raw(gy3, wt, x3.dtype).reshape(shp)
+        if ctx.needs_input_grad[1]:
+            if shared:
+                gw = _bmm_tn_raw(gy3.reshape(1, -1, gy3.shape[2]), x3.reshape(1, -1, x3.shape[2]))
+            else:
+                gw = _bmm_tn_raw(gy3, x3)
+        return gx, gw, None
+
+
+def mod_gemm(x, w, out_dtype=None):
+    return _ModGemm.apply(x, w, x.dtype if out_dtype is None else out_dtype)
+
+
+# ---------------------------------------------------------------------------------------
+# ring-padded dense convolution triple (reference: ops.Conv2d, common.py:187-210)
+# ---------------------------------------------------------------------------------------
+class ConvGeom:
+    def __init__(self, kh, kw, stride, pad, ring):
+        self.kh, self.kw, self.stride, self.pad, self.ring = kh, kw, stride, pad, int(bool(ring))
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
+
+
+def _conv_fwd_raw(x, w, g):
+    B, H, W, C = x.shape
+    O = w.shape[0]
+    Ho, Wo = g.out_hw(H, W)
+    N.check(x, w)
+    y = torch.empty((B, Ho, Wo, O), device=x.device, dtype=x.dtype)
+    N.call("dgv2_conv_fwd", N.ptr(y), N.ptr(x), N.ptr(w), B, H, W, C, O, g.kh, g.kw, g.stride, g.pad, g.ring,
+           _dt(x), N.stream())
+    return y
+
+
+def _conv_dgrad_raw(gy, w, g, xshape):
+    B, H, W, C = xshape
+    O = w.shape[0]
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    N.check(gy, wt)
+    gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
+    scratch = None
+    if g.pad > 0:
+        scratch = torch.empty((B, H + 2 * g.pad, W + 2 * g.pad, C), device=gy.device, dtype=gy.dtype)
+    N.call("dgv2_conv_dgrad", N.ptr(gx), N.ptr(scratch), N.ptr(gy), N.ptr(wt), B, H, W, C, O, g.kh, g.kw, g.stride,
+           g.pad, g.ring, _dt(gy), N.stream())
+    return gx
+
+
+def _conv_wgrad_raw(gy, x, g):
+    B, H, W, C = x.shape
+    O = gy.shape[3]
+    N.check(gy, x)
+    gw = torch.empty((O, g.kh, g.kw, C), device=x.device, dtype=torch.float32)
+    N.call("dgv2_conv_wgrad", N.ptr(gw), N.ptr(gy), N.ptr(x), B, H, W, C, O, g.kh, g.kw, g.stride, g.pad, g.ring,
+           _dt(x), N.stream())
+    return gw
+
+
+class _ConvFwd(Function):
+    @staticmethod
+    def forward(ctx, x, w, g):
+        x = x.contiguous()
+        wc = w.detach().to(x.dtype).contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.g = g
+        return _conv_fwd_raw(x, wc, g)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _ConvDgrad.apply(gy, w, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+class _ConvDgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, w, g, xshape):
+        gy = gy.contiguous()
+        wc = w.detach().to(gy.dtype).contiguous()
+        ctx.save_for_backward(gy, w)
+        ctx.g = g
+        return _conv_dgrad_raw(gy, wc, g, xshape)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g_gy = _ConvFwd.apply(ggx, w, ctx.g) if ctx.needs_input_grad[0] else None
+        g_w = _ConvWgrad.apply(gy, ggx, ctx.g) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w, None, None
+
+
+class _ConvWgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, x, g):
+        gy = gy.contiguous()
+        x = x.contiguous()
+        ctx.save_for_backward(gy, x)
+        ctx.g = g
+        return _conv_wgrad_raw(gy.to(x.dtype), x, g)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        g_gy = _ConvFwd.apply(x, ggw, ctx.g) if ctx.needs_input_grad[0] else None
+        g_x = _ConvDgrad.apply(gy, ggw, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[1] else None
+        return g_gy, g_x, None
+
+
+def conv_ring(x, w, geom):
+    """x [B,H,W,C]; w fp32 master in channels-last filter layout [O,kh,kw,C]."""
+    return _ConvFwd.apply(x, w, geom)
+
+
+# ---------------------------------------------------------------------------------------
+# generator output stage (reference: dusty_v2.py:290-306, dusty_v1.py:20-25, gumbel.py:23-29)
+# ---------------------------------------------------------------------------------------
+class _GenTail(Function):
+    @staticmethod
+    def forward(ctx, skip, shift, u, out_scale, raydrop_const, temperature):
+        skip = skip.contiguous()
+        B, H, W, _ = skip.shape
+        N.check(skip, shift, u)
+        outs = [torch.empty((B, 1, H, W), device=skip.device, dtype=torch.float32) for _ in range(4)]
+        image, image_orig, logit, mask = outs
+        N.call("dgv2_gen_tail_fwd", N.ptr(image), N.ptr(image_orig), N.ptr(logit), N.ptr(mask), N.ptr(skip),
+               N.ptr(shift), N.ptr(u), B, H, W, out_scale, raydrop_const, temperature, N.stream())
+        ctx.save_for_backward(image_orig, logit, mask, u, shift)
+        ctx.cfg = (out_scale, raydrop_const, temperature)
+        return image, image_orig, logit, mask
+
+    @staticmethod
+    def backward(ctx, g_image, g_image_orig, g_logit, g_mask):
+        image_orig, logit, mask, u, shift = ctx.saved_tensors
+        out_scale, raydrop_const, temperature = ctx.cfg
+        B, _, H, W = image_orig.shape
+        gs = [None if g is None else g.contiguous().float() for g in (g_image, g_image_orig, g_logit, g_mask)]
+        g_skip = torch.empty((B, H, W, 2), device=u.device, dtype=torch.float32)
+        scratch = torch.empty_like(g_skip) if shift is not None else None
+        N.call("dgv2_gen_tail_bwd", N.ptr(g_skip), N.ptr(scratch), N.ptr(gs[0]), N.ptr(gs[1]), N.ptr(gs[2]),
+               N.ptr(gs[3]), N.ptr(image_orig), N.ptr(logit), N.ptr(mask), N.ptr(u), N.ptr(shift), B, H, W,
+               out_scale, raydrop_const, temperature, N.stream())
+        return g_skip, None, None, None, None, None
+
+
+def gen_tail(skip, shift, u, out_scale=0.25, raydrop_const=-1.0, temperature=1.0):
+    """skip fp32 [B,H,W,2] -> (image, image_orig, raydrop_logit, raydrop_mask), each [B,1,H,W]."""
+    return _GenTail.apply(skip, shift, u, float(out_scale), float(raydrop_const), float(temperature))
+
+
+def gumbel_uniform(shape, device):
+    """Uniforms clamped like torch.distributions.utils.clamp_probs (RelaxedBernoulli.rsample)."""
+    return torch.rand(shape, device=device).clamp_(_EPS_U, 1.0 - _EPS_U)
+
+
+# ---------------------------------------------------------------------------------------
+# ADA separable operator (reference: gans/augment/adaptive_augment.py:471-545)
+# ---------------------------------------------------------------------------------------
+class _AdaApply(Function):
+    @staticmethod
+    def forward(ctx, x, Ay, kx, off, sgn, a, c, transpose):
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        N.check(x, Ay, kx, off, sgn, a, c)
+        y = torch.empty_like(x)
+        N.call("dgv2_ada_apply", N.ptr(y), N.ptr(x), N.ptr(Ay), N.ptr(kx), N.ptr(off), N.ptr(sgn), N.ptr(a),
+               N.ptr(c), B, H, W, kx.shape[1], int(transpose), N.stream())
+        ctx.save_for_backward(Ay, kx, off, sgn, a, c)
+        ctx.transpose = transpose
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        Ay, kx, off, sgn, a, c = ctx.saved_tensors
+        gx = _AdaApply.apply(g, Ay, kx, off, sgn, a, c, not ctx.transpose)
+        return gx, None, None, None, None, None, None, None
+
+
+def ada_apply(x, Ay, kx, off, sgn, a, c):
+    return _AdaApply.apply(x, Ay, kx, off, sgn, a, c, False)
+
+
+# ---------------------------------------------------------------------------------------
+def upfirdn2d_raw(x4, kernel, up, down, pad):
+    """x4 [major, H, W, minor] (reference extension ABI, upfirdn2d.cpp:17-31)."""
+    major, in_h, in_w, minor = x4.shape
+    kh, kw = kernel.shape
+    out_h = (in_h * up[1] + pad[2] + pad[3] - kh + down[1]) // down[1]
+    out_w = (in_w * up[0] + pad[0] + pad[1] - kw + down[0]) // down[0]
+    N.check(x4, kernel)
+    out = torch.empty((major, out_h, out_w, minor), device=x4.device, dtype=x4.dtype)
+    N.call("dgv2_upfirdn2d", N.ptr(out), N.ptr(x4), N.ptr(kernel), major, in_h, in_w, minor, kh, kw, up[0], up[1],
+           down[0], down[1], pad[0], pad[1], pad[2], pad[3], _dt(x4), N.stream())
+    return out
+
+
+def coords_convert(x, mode, min_depth, max_depth, angle=None, mask=None, raydrop_const=-1.0):
+    B, _, H, W = x.shape
+    x = x.contiguous().float()
+    N.check(x, angle, mask)
+    out = torch.empty((B, 3 if mode >= 2 else 1, H, W), device=x.device, dtype=torch.float32)
+    N.call("dgv2_coords_convert", N.ptr(out), N.ptr(x), N.ptr(mask), N.ptr(angle), B, H, W, float(min_depth),
+           float(max_depth), float(raydrop_const), mode, N.stream())
+    return out

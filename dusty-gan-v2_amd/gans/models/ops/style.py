@@ -1,0 +1,86 @@
+"""Modulated 1x1 convolution (reference: gans/models/ops/style.py:12-126).
+
+Parameter / buffer names and shapes match the reference (`weight` [1,O,I,k,k], `mod.module.*`,
+`bias` [1,O,1,1], `ema_var` []).  The per-sample weights are prepared with small fp32 tensor ops
+(autograd carries the chain into `weight` and the style Linear); the contraction -- the grouped
+conv of style.py:105-118 -- is the MFMA batched GEMM dgv2_bmm_nn / dgv2_bmm_tn."""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.modules.utils import _pair
+
+from . import native
+from .common import EqualLR, from_cl, to_cl
+
+__all__ = ["ModConv2d", "NoiseInjection"]
+
+
+class ModConv2d(nn.Module):
+    def __init__(self, in_ch, out_ch, mod_ch, ksize=3, stride=1, padding=1, demod=True, bias=True, gain=1.0,
+                 transposed=False, factorization_rank=None, ema=False, ema_decay=0.9989):
+        super().__init__()
+        self.in_ch, self.out_ch, self.mod_ch = in_ch, out_ch, mod_ch
+        self.ksize, self.stride, self.padding = _pair(ksize), _pair(stride), _pair(padding)
+        if self.ksize != (1, 1) or transposed or factorization_rank is not None:
+            raise NotImplementedError("only the 1x1 StyleGAN2-style modulated conv of dusty_v2 is built")
+        self.weight = nn.Parameter(torch.randn((1, out_ch, in_ch, *self.ksize)))
+        self.bias = nn.Parameter(torch.zeros((1, out_ch, 1, 1))) if bias else None
+        self.gain = gain
+        self.scale = 1.0 / np.sqrt(in_ch * np.prod(self.ksize))
+        self.mod = EqualLR(nn.Linear(mod_ch, in_ch), gain=1.0)
+        self.demod = demod
+        self.ema, self.ema_decay = ema, ema_decay
+        self.register_buffer("ema_var", torch.tensor(1.0))
+
+    def sample_weights(self, w_latent, sumsq=None, count=None):
+        """Per-sample weights [B,O,I] (fp32).  `sumsq`/`count`: sum of squares and element count of
+        the conv input, used for the input-magnitude EMA in training mode (style.py:98-103)."""
+        style = self.mod(w_latent.float())
+        weight = self.weight[0, :, :, 0, 0] * float(self.scale)
+        if self.demod:
+            weight = weight / weight.abs().max()
+            style = style / style.abs().amax(dim=1, keepdim=True)
+        wb = weight[None] * (style[:, None, :] + 1.0)
+        if self.demod:
+            wb = wb * torch.rsqrt(wb.square().sum(dim=2, keepdim=True) + 1e-8)
+        if self.ema:
+            if self.training and sumsq is not None:
+                with torch.no_grad():
+                    self.ema_var.lerp_(sumsq / count, 1 - self.ema_decay)
+            wb = wb / (torch.sqrt(self.ema_var) + 1e-8).detach().clone()
+        return wb
+
+    def forward_cl(self, x, w_latent, out_dtype=None):
+        sumsq = native.sum_squares(x) if (self.ema and self.training) else None
+        wb = self.sample_weights(w_latent, sumsq, x.numel())
+        y = native.mod_gemm(x, wb, out_dtype)
+        if self.bias is not None:
+            y = y + self.bias.reshape(1, 1, 1, -1).to(y.dtype)
+        if self.gain != 1.0:
+            y = y * self.gain
+        return y
+
+    def forward(self, x, style):
+        return from_cl(self.forward_cl(to_cl(x), style))
+
+    def extra_repr(self):
+        return (f"in_ch={self.in_ch}, out_ch={self.out_ch}, mod_ch={self.mod_ch}, ksize={self.ksize}, "
+                f"demod={self.demod}, gain={self.gain}")
+
+
+class NoiseInjection(nn.Module):
+    """reference: style.py:136-160 (unused by dusty_v2.yaml: use_noise false)."""
+
+    def __init__(self, ch: int = 1):
+        super().__init__()
+        self.ch = ch
+        self.weight = nn.Parameter(torch.zeros(1, self.ch, 1, 1))
+        self.fixed_noise = None
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        if self.fixed_noise is None:
+            noise = torch.randn((B, 1, H, W), device=x.device, dtype=x.dtype)
+        else:
+            noise = self.fixed_noise.expand(B, -1, -1, -1)
+        return x + self.weight * noise

@@ -1,0 +1,194 @@
+/*
+ * dgv2.h -- C ABI of libdgv2.so, the MI355X (gfx950) native kernels behind the
+ * dusty_v2 G+D training hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory;
+ *   - the CALLER allocates every output (so buffers can come from the host
+ *     framework's caching allocator and launches stay hipGraph-capturable);
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*);
+ *     nothing here allocates, synchronises or keeps mutable global state, so
+ *     entry points are re-entrant from the autograd thread;
+ *   - return value: 0 on success, a hipError_t value if the launch failed,
+ *     DGV2_EINVAL (-1) for invalid arguments;
+ *   - dtype: DGV2_F32 = 0, DGV2_BF16 = 1 (bf16 storage, fp32 accumulate);
+ *   - activations are channels-last: [B, H, W, C] ("pixels x channels").
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to
+ * the reference tree kazuto1011/dusty-gan-v2).
+ */
+#ifndef DGV2_H
+#define DGV2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGV2_F32 0
+#define DGV2_BF16 1
+#define DGV2_EINVAL (-1)
+
+/* Library/ABI version; bumped when a signature changes. */
+int dgv2_abi_version(void);
+
+/* ---------------------------------------------------------------------------
+ * fused bias + activation
+ * replaces: fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ *   gans/models/ops/fused_act/fused_bias_act.cpp:18-32,
+ *   gans/models/ops/fused_act/fused_bias_act_kernel.cu:19-105
+ * act: 1 = linear, 3 = leaky-ReLU.  grad: 0 = forward, 1 = first derivative
+ * (uses `ref` = forward OUTPUT), 2 = second derivative (zero).
+ * bias index = (i / step_b) % size_b; bias/ref may be NULL (= "empty tensor").
+ * ------------------------------------------------------------------------- */
+int dgv2_fused_bias_act(void* y, const void* x, const void* bias, const void* ref,
+                        int64_t size_x, int64_t step_b, int64_t size_b,
+                        int act, int grad, float alpha, float scale, int dtype, void* stream);
+
+/* Per-channel sum over everything else: gb[c] = sum_i x[i] with c = (i/step_b)%size_b.
+ * replaces: grad_input.sum(dim) in FusedLeakyReLUFunctionBackward.forward
+ *   (gans/models/ops/fused_act/fused_act.py:33-45).  gb is fp32 [size_b], overwritten. */
+int dgv2_bias_grad(float* gb, const void* x, int64_t size_x, int64_t step_b, int64_t size_b,
+                   int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * upfirdn2d
+ * replaces: upfirdn2d_op.upfirdn2d(input[major,H,W,minor], kernel[kh,kw],
+ *   up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+ *   gans/models/ops/upfirdn2d/upfirdn2d.cpp:17-31, upfirdn2d_kernel.cu:44-425
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh + down_y) / down_y (same for w);
+ * out is [major, out_h, out_w, minor], caller-allocated.  kernel is fp32.
+ * ------------------------------------------------------------------------- */
+int dgv2_upfirdn2d(void* out, const void* in, const float* kernel,
+                   int major, int in_h, int in_w, int minor, int kh, int kw,
+                   int up_x, int up_y, int down_x, int down_y,
+                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * ring-aware separable FIR resampler (channels-last)
+ * replaces: Resample.forward, gans/models/ops/common.py:105-135 (zero-insert +
+ *   F.pad + depthwise F.conv2d) and its autograd transpose.
+ * Per axis: out[n] = sum_i taps[i] * z[n*down + i - p0], z = zero-stuffed (x up)
+ * extension of the input; W extends circularly if ring else by replication, H by
+ * replication.  taps_h / taps_w: fp32 [kh] / [kw] (k <= 8; k = 1 with tap 1.0 = identity axis).
+ * adjoint = 0: forward, x [B,H,W,C] -> y [B,Ho,Wo,C];
+ * adjoint = 1: transpose, x is [B,Ho,Wo,C] (a gradient) -> y [B,H,W,C].
+ * H, W are always the forward INPUT size, Ho, Wo the forward OUTPUT size.
+ * y may be a channel slice of a wider tensor: ldy = channel stride (elements) of y
+ * per pixel, ldx likewise for x (pass C for dense).
+ * ------------------------------------------------------------------------- */
+int dgv2_resample(void* y, const void* x, const float* taps_h, const float* taps_w,
+                  int B, int H, int W, int C, int Ho, int Wo, int ldx, int ldy,
+                  int kh, int up_h, int down_h, int p0_h,
+                  int kw, int up_w, int down_w, int p0_w,
+                  int ring, int adjoint, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Fourier features (positional encoding of the laser angles)
+ * replaces: FourierFeature.forward, gans/models/ops/fourier.py:77-82
+ * angle fp32 [Ba, 2, H, W] (NCHW as in the module API; Ba = 1 broadcasts),
+ * shift fp32 [B] or NULL (added to the azimuth channel, dusty_v2.py:267-274),
+ * freqs fp32 [F, 2], phase fp32 [F];
+ * out [B, H, W, ld] channels-last, writes channels [c0, c0 + 2F): sin then cos.
+ * ------------------------------------------------------------------------- */
+int dgv2_fourier_feature(void* out, const float* angle, const float* shift,
+                         const float* freqs, const float* phase,
+                         int B, int Ba, int H, int W, int F, int ld, int c0, int dtype, void* stream);
+
+/* Angle pyramid step: sin/cos -> FIR down-2 (ring / replicate) -> atan2.
+ * replaces: SynthesisBlock.downsample_angle, gans/models/dusty_v2.py:135-140.
+ * in fp32 [Ba,2,H,W] (Ba = 1 broadcasts), shift fp32 [B] or NULL (added to the azimuth
+ * channel first) -> out fp32 [B,2,H/2,W/2] (NCHW, both channels are angles).  taps fp32 [4]. */
+int dgv2_downsample_angle(float* out, const float* in, const float* shift, const float* taps,
+                          int B, int Ba, int H, int W, int ring, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * batched channel GEMM = the contraction of the modulated 1x1 convolution
+ * replaces: F.conv2d(x[1,B*I,H,W], w[B*O,I,1,1], groups=B) in ModConv2d.forward,
+ *   gans/models/ops/style.py:105-118, and its autograd dgrad / wgrad.
+ *   nn:  y[b,p,o]  = sum_i x[b,p,i] * w[b,o,i]        (forward; dgrad with w^T)
+ *   tn:  gw[b,o,i] = sum_p gy[b,p,o] * x[b,p,i]       (wgrad, fp32 output)
+ * x [B,P,ldx] (first I channels used), w [B,O,I], y [B,P,ldy] (first O written).
+ * wstride = element stride between samples of w (0 = one weight shared by the batch).
+ * ydtype = dtype of y (DGV2_F32 allowed with bf16 inputs: the heads stay fp32, dusty_v2.py:174-178).
+ * ------------------------------------------------------------------------- */
+int dgv2_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O,
+                int ldx, int ldy, int64_t wstride, int dtype, int ydtype, void* stream);
+int dgv2_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I, int O,
+                int ldgy, int ldx, int dtype, void* stream);
+
+/* Sum of squares of the first C channels of x [N, ld] into acc[0] (fp32, ACCUMULATES).
+ * replaces: x.pow(2).mean() in ModConv2d.forward (style.py:100-101). */
+int dgv2_sum_squares(float* acc, const void* x, int64_t N, int C, int ld, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * dense convolution with ring padding (discriminator)
+ * replaces: ops.Conv2d = Pad(circular W / replicate H) + nn.Conv2d, via cuDNN/ATen
+ *   gans/models/ops/common.py:10-24,187-210, used at gans/models/dusty_v2.py:325-385
+ * x [B,H,W,C]; w [O,kh,kw,C] (channels-last filter); y [B,Ho,Wo,O];
+ * pad on every side, Ho = (H + 2*pad - kh)/stride + 1.
+ *   fwd  : y  = conv(pad(x), w)
+ *   dgrad: gx = pad^T(conv^T(gy, w))         (gx [B,H,W,C]; wt = w transposed to [C,kh,kw,O];
+ *          gxp_scratch [B,H+2pad,W+2pad,C] holds the padded-domain gradient, NULL if pad == 0)
+ *   wgrad: gw[o,ky,kx,c] = sum gy * pad(x)   (fp32 [O,kh,kw,C], overwritten)
+ * ------------------------------------------------------------------------- */
+int dgv2_conv_fwd(void* y, const void* x, const void* w, int B, int H, int W, int C, int O,
+                  int kh, int kw, int stride, int pad, int ring, int dtype, void* stream);
+int dgv2_conv_dgrad(void* gx, void* gxp_scratch, const void* gy, const void* wt,
+                    int B, int H, int W, int C, int O,
+                    int kh, int kw, int stride, int pad, int ring, int dtype, void* stream);
+int dgv2_conv_wgrad(float* gw, const void* gy, const void* x, int B, int H, int W, int C, int O,
+                    int kh, int kw, int stride, int pad, int ring, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * generator output stage: cancel the azimuth shift (circular bilinear shift),
+ * scale, tanh, Gumbel-sigmoid ray-drop mask, blend.
+ * replaces: dusty_v2.py:290-306 (affine_grid + grid_sample + *0.25 + tanh),
+ *   dusty_v1.py:20-25 (RayDropModel), ops/gumbel.py:23-29.
+ * skip fp32 [B,H,W,2] (ch0 image, ch1 raydrop_logit); shift fp32 [B] radians or NULL;
+ * u fp32 [B,H,W] uniforms in (0,1); outputs fp32 [B,H,W] each.
+ * backward: g_image, g_image_orig, g_logit, g_mask (any may be NULL) -> g_skip [B,H,W,2];
+ * scratch fp32 [B,H,W,2] is required when shift != NULL.
+ * ------------------------------------------------------------------------- */
+int dgv2_gen_tail_fwd(float* image, float* image_orig, float* logit, float* mask,
+                      const float* skip, const float* shift, const float* u,
+                      int B, int H, int W, float out_scale, float raydrop_const, float temperature,
+                      void* stream);
+int dgv2_gen_tail_bwd(float* g_skip, float* scratch, const float* g_image, const float* g_image_orig,
+                      const float* g_logit, const float* g_mask,
+                      const float* image_orig, const float* logit, const float* mask, const float* u,
+                      const float* shift, int B, int H, int W, float out_scale, float raydrop_const,
+                      float temperature, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * ADA resampler, separable operator form:
+ *   y[b] = a[b] * (Ay[b] @ x[b] @ Cx[b]^T) + c[b]
+ * replaces: AdaptiveAugment.forward geometric + colour stages,
+ *   gans/augment/adaptive_augment.py:471-545 (pad, 2x upfirdn2d, grid_sample,
+ *   2x upfirdn2d, colour affine).
+ * x, y fp32 [B,H,W]; Ay fp32 [B,H,H]; kx fp32 [B,K] circular taps:
+ *   (x Cx^T)[j] = sum_t kx[t] * x[(sgn*j + off + t) mod W], sgn[b] in {+1,-1}, off[b] int.
+ * transpose = 1 applies the adjoint (backward / used for double backward).
+ * ------------------------------------------------------------------------- */
+int dgv2_ada_apply(float* y, const float* x, const float* Ay, const float* kx, const int* off,
+                   const int* sgn, const float* a, const float* c, int B, int H, int W, int K,
+                   int transpose, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * range-image projection
+ * replaces: CoordBridge.convert / depth_to_point_map, gans/coords.py:88-185
+ * mode: 0 depth -> inv_depth_norm (the fetch_reals path, trainer.py:211-217, incl.
+ *         *2-1 and mask blend when mask != NULL), out [B,1,H,W];
+ *       1 inv_depth_norm -> depth, out [B,1,H,W];
+ *       2 inv_depth_norm -> point_map [B,3,H,W];  3 depth -> point_map.
+ * angle fp32 [1,2,H,W].
+ * ------------------------------------------------------------------------- */
+int dgv2_coords_convert(float* out, const float* in, const float* mask, const float* angle,
+                        int B, int H, int W, float min_depth, float max_depth, float raydrop_const,
+                        int mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGV2_H */

@@ -1,0 +1,354 @@
+"""Parity of every libdgv2 kernel (through the C ABI / ctypes binding) against the CPU oracle on
+the same seeded inputs.  fp32 mode: <= 1e-3 relative (north_star tolerance; most ops are ~1e-6).
+bf16 mode: integer-valued inputs make the MFMA results exact; random inputs use a stated bf16
+tolerance.  Run with `-m gpu` on an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub_dict
+from oracle import augment as o_aug
+from oracle import coords as o_coords
+from oracle import ops as o
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def cl(x):  # NCHW (cpu) -> channels-last on device
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(x):  # channels-last (device) -> NCHW cpu fp32
+    return x.permute(0, 3, 1, 2).float().cpu()
+
+
+def rel_err(got, want):
+    return float((got.double() - want.double()).abs().max() / (want.double().abs().max() + 1e-30))
+
+
+def assert_rel(got, want, tol, what=""):
+    e = rel_err(got, want)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from gans.models.ops import native
+    return native
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1.2e-2)])
+def test_bias_act_all_orders(nat, g_ops, dtype, tol):
+    x = g_ops["flr_x"].clone().requires_grad_(True)
+    b = g_ops["flr_b"].clone().requires_grad_(True)
+    gy = g_ops["flr_gy"].clone().requires_grad_(True)
+    # channel = dim 1 layout (reference API) and channels-last layout
+    for channels_last in (False, True):
+        xd = (cl(x.detach()) if channels_last else x.detach().to(DEV)).to(dtype).requires_grad_(True)
+        bd = b.detach().to(DEV).requires_grad_(True)
+        gyd = (cl(gy.detach()) if channels_last else gy.detach().to(DEV)).to(dtype).requires_grad_(True)
+        y = nat.bias_act(xd, bd, 0.2, math.sqrt(2), channels_last=channels_last)
+        gx, gb = torch.autograd.grad(y, [xd, bd], gyd, create_graph=True)
+        ggx = g_ops["flr_ggx"]
+        ggxd = (cl(ggx) if channels_last else ggx.to(DEV)).to(dtype)
+        (ggy,) = torch.autograd.grad(gx, gyd, ggxd)
+        back = nchw if channels_last else (lambda t: t.float().cpu())
+        assert_rel(back(y), g_ops["flr_y"], tol, "y")
+        assert_rel(back(gx), g_ops["flr_gx"], tol, "gx")
+        assert_rel(gb.float().cpu(), g_ops["flr_gb"], max(tol, 1e-5) * 4, "gb")
+        assert_rel(back(ggy), g_ops["flr_ggy"], tol, "ggy")
+
+
+def test_bias_act_large_vectorised(nat):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 16, 32, 64, generator=g)  # channels-last [B,H,W,C=64]
+    b = torch.randn(64, generator=g)
+    want = o.fused_leaky_relu(x.permute(0, 3, 1, 2), b).permute(0, 2, 3, 1)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+        y = nat.bias_act(x.to(DEV).to(dtype), b.to(DEV))
+        assert_rel(y.float().cpu(), want, tol)
+
+
+@pytest.mark.parametrize("ring", [True, False])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1.5e-2)])
+def test_resample_forward_and_adjoint(nat, g_ops, ring, dtype, tol):
+    from gans.models import ops as mops
+    x = g_ops["rs_x"]
+    r = int(ring)
+    mods = {"up2": mops.Resample(up=2, ring=ring), "down2": mops.Resample(down=2, ring=ring),
+            "blur": mops.Resample(ring=ring)}
+    for name, m in mods.items():
+        xd = cl(x).to(dtype).requires_grad_(True)
+        y = m.forward_cl(xd)
+        assert_rel(nchw(y), g_ops[f"rs_{name}_ring{r}"], tol, name)
+        # transpose (backward) and second-order (forward again) vs oracle autograd
+        xo = x.clone().requires_grad_(True)
+        kw = {"up2": dict(up=2), "down2": dict(down=2), "blur": {}}[name]
+        yo = o.resample(xo, ring=ring, **kw)
+        gy = torch.randn(yo.shape, generator=torch.Generator().manual_seed(5))
+        (gxo,) = torch.autograd.grad(yo, xo, gy)
+        gyd = cl(gy).to(dtype).requires_grad_(True)
+        (gx,) = torch.autograd.grad(y, xd, gyd, create_graph=True)
+        assert_rel(nchw(gx), gxo, tol, name + " adjoint")
+        (ggy,) = torch.autograd.grad(gx, gyd, xd.detach())
+        assert_rel(nchw(ggy), g_ops[f"rs_{name}_ring{r}"], 2 * tol, name + " double")
+    bv = mops.BlurVH(ring=ring).to(DEV)
+    assert_rel(nchw(bv.forward_cl(cl(x).to(dtype))), g_ops[f"rs_blurvh_ring{r}"], tol, "blurvh")
+
+
+def test_resample_odd_channels_and_strided_output(nat):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 6, 10, generator=g)  # C=5: scalar path
+    from gans.models import ops as mops
+    y = mops.Resample(up=2).forward_cl(cl(x))
+    assert_rel(nchw(y), o.resample(x, up=2), 1e-6)
+
+
+@pytest.mark.parametrize("name", ["upx", "upy", "dnx", "dny", "k2d", "k2dneg"])
+def test_upfirdn2d(nat, g_ops, name):
+    from gans.models.ops.upfirdn2d.upfirdn2d import upfirdn2d
+    cfg = [int(v) for v in g_ops[f"ufd_{name}_cfg"]]
+    k12, k2d = g_ops["ufd_k12"], g_ops["ufd_k2d"]
+    k = {"upx": k12[None], "dnx": k12[None], "upy": k12[:, None], "dny": k12[:, None]}.get(name, k2d)
+    x = g_ops["ufd_x"].to(DEV).requires_grad_(True)
+    y = upfirdn2d(x, k.to(DEV), up=cfg[0:2], down=cfg[2:4], pad=cfg[4:8])
+    assert_rel(y.cpu(), g_ops[f"ufd_{name}_y"], 1e-6, name)
+    xo = g_ops["ufd_x"].clone().requires_grad_(True)
+    yo = o.upfirdn2d(xo, k, up=cfg[0:2], down=cfg[2:4], pad=cfg[4:8])
+    gy = torch.randn(yo.shape, generator=torch.Generator().manual_seed(2))
+    (gxo,) = torch.autograd.grad(yo, xo, gy)
+    (gx,) = torch.autograd.grad(y, x, gy.to(DEV))
+    assert_rel(gx.cpu(), gxo, 1e-6, name + " grad")
+
+
+def test_fourier_feature_and_angle_pyramid(nat, g_ops):
+    from gans.models import ops as mops
+    ang, freqs, phase = g_ops["pe_angle"], g_ops["pe_freqs"], g_ops["pe_phase"]
+    out = torch.zeros(1, 4, 16, 520, device=DEV)
+    nat.fourier_feature_into(out, 8, ang.to(DEV), None, freqs.reshape(-1, 2).contiguous().to(DEV), phase.to(DEV))
+    got = nchw(out)
+    assert float(got[:, :8].abs().max()) == 0.0
+    assert float((got[:, 8:] - g_ops["pe_y"]).abs().max()) <= 3e-4  # |arg| ~ 1e3 rad in fp32
+    # per-sample shift on the azimuth + bf16 output
+    shift = torch.tensor([0.3, 2.9])
+    want = o.fourier_feature(ang.expand(2, -1, -1, -1) + torch.stack([torch.zeros(2), shift], 1)[:, :, None, None],
+                             freqs, phase)
+    out = torch.zeros(2, 4, 16, 512, device=DEV, dtype=torch.bfloat16)
+    nat.fourier_feature_into(out, 0, ang.to(DEV), shift.to(DEV), freqs.reshape(-1, 2).contiguous().to(DEV),
+                             phase.to(DEV))
+    assert float((nchw(out) - want).abs().max()) <= 5e-3
+    # angle pyramid
+    g = torch.Generator().manual_seed(3)
+    a = (torch.rand(2, 2, 8, 16, generator=g) * 2 - 1) * 3.0
+    blk = mops.Resample(down=2)
+    got = nat.downsample_angle(a.to(DEV), None, blk.kernel.to(DEV), 2, True).cpu()
+    from oracle import model as o_model
+    want = o_model.downsample_angle(a, True)
+    d = (got - want).abs()
+    d = torch.minimum(d, (2 * math.pi - d).abs())
+    assert float(d.max()) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+SHAPES = [(2, 300, 40, 24), (3, 129, 20, 1), (1, 64, 576, 32), (2, 257, 64, 130), (2, 128, 512, 256)]
+
+
+@pytest.mark.parametrize("B,P,I,O", SHAPES)
+def test_bmm_fp32_matches_fp64_reference(nat, B, P, I, O):
+    g = torch.Generator().manual_seed(B * 1000 + P)
+    x = torch.randn(B, P, I, generator=g)
+    w = torch.randn(B, O, I, generator=g)
+    gy = torch.randn(B, P, O, generator=g)
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = nat.mod_gemm(xd, wd)
+    gx, gw = torch.autograd.grad(y, [xd, wd], gy.to(DEV))
+    want = torch.einsum("bpi,boi->bpo", x.double(), w.double())
+    assert_rel(y.cpu(), want, 2e-6, "y")
+    assert_rel(gx.cpu(), torch.einsum("bpo,boi->bpi", gy.double(), w.double()), 2e-6, "gx")
+    assert_rel(gw.cpu(), torch.einsum("bpo,bpi->boi", gy.double(), x.double()), 5e-6, "gw")
+
+
+@pytest.mark.parametrize("B,P,I,O", SHAPES)
+def test_bmm_bf16_exact_on_integers_and_shared_weight(nat, B, P, I, O):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randint(-3, 4, (B, P, I), generator=g).float()
+    w = torch.randint(-3, 4, (1, O, I), generator=g).float()  # asymmetric, shared by the batch
+    gy = torch.randint(-2, 3, (B, P, O), generator=g).float()
+    xd = x.to(DEV).bfloat16().requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    y = nat.mod_gemm(xd, wd, torch.float32)
+    gx, gw = torch.autograd.grad(y, [xd, wd], gy.to(DEV))
+    assert torch.equal(y.cpu(), torch.einsum("bpi,oi->bpo", x, w[0]))
+    assert torch.equal(gx.float().cpu(), torch.einsum("bpo,oi->bpi", gy, w[0]))
+    assert torch.equal(gw.cpu()[0], torch.einsum("bpo,bpi->oi", gy, x))
+
+
+def test_bmm_bf16_random_tolerance(nat):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 500, 96, generator=g)
+    w = torch.randn(2, 48, 96, generator=g)
+    y = nat.mod_gemm(x.to(DEV).bfloat16(), w.to(DEV))
+    want = torch.einsum("bpi,boi->bpo", x.bfloat16().double(), w.bfloat16().double())
+    assert_rel(y.float().cpu(), want, 8e-3)
+
+
+# ---------------------------------------------------------------------------------------
+CONVS = [  # B, H, W, C, O, k, stride, pad, ring
+    (2, 8, 16, 8, 16, 3, 1, 1, True),
+    (2, 8, 16, 8, 24, 3, 2, 1, True),
+    (2, 8, 16, 12, 8, 1, 2, 0, True),
+    (3, 6, 10, 2, 32, 1, 1, 0, True),
+    (2, 4, 8, 20, 40, 3, 1, 1, False),
+    (1, 64, 32, 32, 32, 3, 1, 1, True),
+]
+
+
+def _conv_oracle(x, w, stride, pad, ring):
+    if pad:
+        x = o.pad_ring(x, (pad,) * 4, ring)
+    return torch.nn.functional.conv2d(x, w, None, stride)
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_triple_fp32(nat, cfg):
+    B, H, W, C, O, k, s, p, ring = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:5]))
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(O, C, k, k, generator=g, dtype=torch.float64, requires_grad=True)
+    y = _conv_oracle(x, w, s, p, ring)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64, requires_grad=True)
+    gx, gw = torch.autograd.grad(y, [x, w], gy, create_graph=True)
+    # second order: gradient of <gx, v> w.r.t. (gy, w)
+    v = torch.randn(gx.shape, generator=g, dtype=torch.float64)
+    ggy, gw2 = torch.autograd.grad((gx * v).sum(), [gy, w])
+
+    geom = nat.ConvGeom(k, k, s, p, ring)
+    xd = cl(x.detach().float()).requires_grad_(True)
+    wd = w.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    yd = nat.conv_ring(xd, wd, geom)
+    gyd = cl(gy.detach().float()).requires_grad_(True)
+    gxd, gwd = torch.autograd.grad(yd, [xd, wd], gyd, create_graph=True)
+    ggyd, gw2d = torch.autograd.grad((gxd * cl(v.float())).sum(), [gyd, wd])
+    assert_rel(nchw(yd), y.detach(), 5e-6, "y")
+    assert_rel(nchw(gxd), gx.detach(), 5e-6, "gx")
+    assert_rel(gwd.permute(0, 3, 1, 2).cpu(), gw.detach(), 1e-5, "gw")
+    assert_rel(nchw(ggyd), ggy, 1e-5, "ggy")
+    assert_rel(gw2d.permute(0, 3, 1, 2).cpu(), gw2, 1e-5, "gw (2nd order)")
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_bf16_exact_on_integers(nat, cfg):
+    B, H, W, C, O, k, s, p, ring = cfg
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(-2, 3, (B, C, H, W), generator=g).float().requires_grad_(True)
+    w = torch.randint(-2, 3, (O, C, k, k), generator=g).float().requires_grad_(True)
+    y = _conv_oracle(x, w, s, p, ring)
+    gy = torch.randint(-1, 2, y.shape, generator=g).float()
+    gx, gw = torch.autograd.grad(y, [x, w], gy)
+    geom = nat.ConvGeom(k, k, s, p, ring)
+    xd = cl(x.detach()).bfloat16().requires_grad_(True)
+    wd = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    yd = nat.conv_ring(xd, wd, geom)
+    gxd, gwd = torch.autograd.grad(yd, [xd, wd], cl(gy).bfloat16())
+    assert torch.equal(nchw(yd), y.detach())
+    assert torch.equal(nchw(gxd), gx)
+    assert torch.equal(gwd.permute(0, 3, 1, 2).cpu(), gw)
+
+
+# ---------------------------------------------------------------------------------------
+def test_gen_tail_forward_backward(nat):
+    g = torch.Generator().manual_seed(4)
+    B, H, W = 3, 6, 32
+    skip = torch.randn(B, 2, H, W, generator=g, requires_grad=True)
+    shift = torch.rand(B, generator=g) * 2 * math.pi
+    u = torch.rand(B, 1, H, W, generator=g).clamp(1e-6, 1 - 1e-6)
+    for use_shift in (True, False):
+        v = o.ring_shift(skip, shift) if use_shift else skip
+        v = v * 0.25
+        img0 = torch.tanh(v[:, 0:1])
+        logit = v[:, 1:2]
+        img, mask = o.raydrop_measure(img0, logit, u, -1.0, 1.0)
+        gi = torch.randn(img.shape, generator=g)
+        gl = torch.randn(img.shape, generator=g)
+        (gs,) = torch.autograd.grad([img, logit], skip, [gi, gl], retain_graph=True)
+        sd = cl(skip.detach()).requires_grad_(True)
+        image, image_orig, lg, m = nat.gen_tail(sd, shift.to(DEV) if use_shift else None, u.to(DEV), 0.25, -1.0, 1.0)
+        assert_rel(image.cpu(), img.detach(), 2e-6, "image")
+        assert_rel(image_orig.cpu(), img0.detach(), 2e-6, "image_orig")
+        assert_rel(lg.cpu(), logit.detach(), 2e-6, "logit")
+        assert torch.equal(m.cpu(), mask.detach().round())
+        (gsd,) = torch.autograd.grad([image, lg], sd, [gi.to(DEV), gl.to(DEV)])
+        assert_rel(nchw(gsd), gs, 1e-5, "g_skip")
+
+
+def test_ada_apply_matches_staged_oracle(nat, g_small):
+    from gans.augment.adaptive_augment import AdaptiveAugment
+    d = g_small
+    A = AdaptiveAugment(p_init=0.6, lr_flip=1, ud_flip=1, int_trans=1, iso_scale=1, frac_trans=1, brightness=1,
+                        contrast=1, luma_flip=1, hue=1, saturation=1).to(DEV)
+    for tag in ("ds_adaG_real", "gs_adaG", "ds_adaG_fake", "r1_adaG"):
+        G, C = d[tag], d[tag.replace("adaG", "adaC")]
+        x = d["x_real"].clone().requires_grad_(True)
+        want = o_aug.ada_forward(x, G, C)
+        gy = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
+        (gxo,) = torch.autograd.grad(want, x, gy)
+        xd = d["x_real"].to(DEV).requires_grad_(True)
+        gyd = gy.to(DEV).requires_grad_(True)
+        y = A(xd, draws={"G": G, "C": C})
+        assert_rel(y.cpu(), want.detach(), 5e-5, tag)
+        (gx,) = torch.autograd.grad(y, xd, gyd, create_graph=True)
+        assert_rel(gx.cpu(), gxo, 5e-5, tag + " grad")
+        (ggy,) = torch.autograd.grad(gx, gyd, xd.detach())  # double backward = forward without the offset
+        a, c = A.collapse_color(C)
+        assert_rel(ggy.cpu(), want.detach() - c[:, None, None, None], 1e-4, tag + " double")
+
+
+def test_ada_sampling_statistics(nat):
+    from gans.augment.adaptive_augment import AdaptiveAugment
+    torch.manual_seed(0)
+    A = AdaptiveAugment(p_init=0.5, lr_flip=1, ud_flip=1, int_trans=1, iso_scale=1, frac_trans=1, brightness=1,
+                        contrast=1, luma_flip=1, hue=1, saturation=1).to(DEV)
+    G = A.sample_affine(20000, 64, 512, DEV).cpu()
+    assert abs(float((G[:, 0, 0] < 0).float().mean()) - 0.25) < 0.02       # p * P(i = 1)
+    assert abs(float((G[:, 1, 1] < 0).float().mean()) - 0.25) < 0.02
+    assert float(G[:, 0, 1].abs().max()) == 0 and float(G[:, 1, 0].abs().max()) == 0
+    a, c = A.collapse_color(A.sample_color(20000, DEV))
+    assert 0.3 < float((a != 1).float().mean()) < 0.9
+    # p = 0: identity operators, output ~ input (SYM6 up/down reconstruction)
+    A.p.fill_(0.0)
+    x = torch.randn(4, 1, 16, 64, device=DEV)
+    assert_rel(A(x).cpu(), x.cpu(), 2e-3)
+
+
+def test_coords_convert(nat, g_coords):
+    from gans.coords import CoordBridge
+    cb = CoordBridge(8, 32, 1.45, 80.0, angle_array=g_coords["small_angle_file"].numpy()).to(DEV)
+    assert_rel(cb.angle.cpu(), g_coords["small_angle"], 1e-6, "angle grid")
+    n = 0
+    for key, want in g_coords.items():
+        if not key.startswith("cv_"):
+            continue
+        src, tgt = key[3:].split("__")
+        x = g_coords["cv_depth__point_map"] if src == "point_map" else g_coords[f"src_{src}"]
+        got = cb.convert(x.to(DEV), src, tgt).cpu()
+        assert_rel(got, want, 2e-6, key)
+        n += 1
+    assert n >= 20
+    depth = g_coords["depth"]
+    mask = (torch.rand(depth.shape, generator=torch.Generator().manual_seed(0)) < 0.85).float()
+    want = o_coords.fetch_reals(depth.numpy(), mask.numpy(), 1.45, 80.0)
+    assert_rel(cb.fetch_reals(depth.to(DEV), mask.to(DEV)).cpu(), torch.from_numpy(want), 2e-6, "fetch_reals")
+
+
+def test_sum_squares(nat):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 7, 9, 40, generator=g)
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        got = nat.sum_squares(x.to(DEV).to(dtype))
+        assert abs(float(got) - float(x.double().pow(2).sum())) <= tol * float(x.double().pow(2).sum())
+    got = nat.sum_squares(x.to(DEV), C=13)
+    assert abs(float(got) - float(x[..., :13].double().pow(2).sum())) <= 1e-5 * float(x.double().pow(2).sum())
