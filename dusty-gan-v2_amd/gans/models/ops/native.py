@@ -450,8 +450,9 @@ class _AdaApply(Function):
 
     @staticmethod
     def backward(ctx, g):
-        Ay, kx, off, sgn, a, c = ctx.saved_tensors
-        gx = _AdaApply.apply(g, Ay, kx, off, sgn, a, c, not ctx.transpose)
+        Ay, kx, off, sgn, a, _ = ctx.saved_tensors
+        # derivative of an affine map: the offset c never appears in (double) backward
+        gx = _AdaApply.apply(g, Ay, kx, off, sgn, a, None, not ctx.transpose)
         return gx, None, None, None, None, None, None, None
 
 

@@ -277,9 +277,9 @@ def test_gen_tail_forward_backward(nat):
         (gs,) = torch.autograd.grad([img, logit], skip, [gi, gl], retain_graph=True)
         sd = cl(skip.detach()).requires_grad_(True)
         image, image_orig, lg, m = nat.gen_tail(sd, shift.to(DEV) if use_shift else None, u.to(DEV), 0.25, -1.0, 1.0)
-        assert_rel(image.cpu(), img.detach(), 2e-6, "image")
-        assert_rel(image_orig.cpu(), img0.detach(), 2e-6, "image_orig")
-        assert_rel(lg.cpu(), logit.detach(), 2e-6, "logit")
+        assert_rel(image.cpu(), img.detach(), 1e-5, "image")
+        assert_rel(image_orig.cpu(), img0.detach(), 1e-5, "image_orig")
+        assert_rel(lg.cpu(), logit.detach(), 1e-5, "logit")
         assert torch.equal(m.cpu(), mask.detach().round())
         (gsd,) = torch.autograd.grad([image, lg], sd, [gi.to(DEV), gl.to(DEV)])
         assert_rel(nchw(gsd), gs, 1e-5, "g_skip")
