@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the dusty_v2 G+D training step on MI355X (BASELINE.json metric:
+range-images/sec for one G+D step, dusty_v2 64x512).
+
+    python bench.py --gpus 1 --steps 16 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full training iteration of gans/trainer.py: G step, D step, lazy R1 on every
+16th iteration, G_ema update, ADA p update every 4th iteration, Adam updates, gradient
+all-reduce over RCCL when N > 1.  Inputs are synthetic and resident in HBM (z ~ N(0,1), real
+range images from the synthetic depth generator).  Weak scaling: per-GPU batch fixed at 64.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dusty-gan-v2_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work per image, SURVEY.md section 8(d) (2 FLOP per MAC)
+GFLOP_PER_IMG_ITER = 47.7 + 27.0 / 16  # G step 17.6 + D step 29.5 + R1 (~27) amortised over 16
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--ada-p", type=float, default=0.6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    return ap.parse_args()
+
+
+def make_cfg(args, rank, world):
+    from gans.config import load_config
+    cfg = load_config()
+    n16 = -1 if args.dtype == "bf16" else 0
+    cfg.model.generator.synthesis_kwargs.num_fp16_layers = n16
+    cfg.model.discriminator.layer_kwargs.num_fp16_layers = n16
+    cfg.dataset.name = "synthetic"
+    cfg.training.rank = rank
+    cfg.training.num_gpus = world
+    cfg.training.batch_size = args.batch_per_gpu * world
+    cfg.training.batch_size_per_gpu = args.batch_per_gpu
+    cfg.training.augment.p_init = args.ada_p
+    cfg.training.warmup.fade_kimg = 0  # post-fade regime: no warm-up dropout / blur
+    cfg.training.resume = None
+    return cfg
+
+
+def cpu_baseline(batch, steps=2):
+    """The CPU oracle (oracle/step.py, a port of the reference's CPU path pinned by golden vectors)
+    timed on this host: full-size dusty_v2, fp32, one iteration = G step + D step, ADA at p=0.6."""
+    import numpy as np
+    from helpers import ada_from_cfg, build_models, full_cfg
+    from oracle import coords as o_coords
+    from oracle import step as o_step
+    import recipe
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = full_cfg()
+    G, D = build_models(cfg, "cpu")
+    sdG = recipe.fill_state_dict({k: v.clone() for k, v in G.state_dict().items()}, 1234)
+    sdD = recipe.fill_state_dict({k: v.clone() for k, v in D.state_dict().items()}, 4321)
+    A = ada_from_cfg(cfg, 0.6)
+    H, W = 64, 512
+    from gans.coords import synthetic_angle_grid
+    angle = torch.from_numpy(o_coords.resample_angle_grid(synthetic_angle_grid(64), H, W)).repeat(batch, 1, 1, 1)
+    g = torch.Generator().manual_seed(0)
+    depth = torch.rand(batch, 1, H, W, generator=g) * (80 - 1.45) + 1.45
+    mask = (torch.rand(batch, 1, H, W, generator=g) < 0.85).float()
+    x_real = torch.from_numpy(o_coords.fetch_reals(depth.numpy(), mask.numpy(), 1.45, 80.0))
+
+    def one():
+        z = torch.randn(batch, 512, generator=g)
+        sh = torch.rand(batch, generator=g) * 6.2831853
+        u = torch.rand(batch, 1, H, W, generator=g).clamp(1e-6, 1 - 1e-6)
+        ada = {"G": A.sample_affine(batch, H, W), "C": A.sample_color(batch)}
+        o_step.g_step(sdG, sdD, z, angle, sh, u, ada=ada)
+        o_step.d_step(sdG, sdD, z, angle, sh, u, x_real, ada_real=ada, ada_fake=ada)
+
+    one()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": batch / dt, "unit": "range-images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} iterations (G step + D step, fp32, B={batch}, ADA p=0.6, full-size dusty_v2 64x512) "
+                      f"of oracle/step.py after 1 warm-up; {dt:.2f} s/iteration"}
+
+
+def roofline_probe(args, reps=20):
+    """Roofline of the MFMA kernel north_star names: the modulated-conv contraction
+    gemm_nn_kernel (dgv2_bmm_nn) at the level-4 conv1 shape of the benchmarked batch
+    (B x 32768 pixels, I = 576, O = 32).  Timed live with HIP events on the launching stream.
+    Algorithmic FLOPs per launch = 2 * B * P * I * O (604 MMAC/img)."""
+    from gans.models.ops import native
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    B, P, I, O = args.batch_per_gpu, 64 * 512, 576, 32
+    x = torch.randn(B, P, I, device="cuda", dtype=dt)
+    w = torch.randn(B, O, I, device="cuda", dtype=dt)
+    for _ in range(3):
+        native._bmm_nn_raw(x, w, dt)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        native._bmm_nn_raw(x, w, dt)
+    e.record()
+    torch.cuda.synchronize()
+    sec = s.elapsed_time(e) * 1e-3 / reps
+    flops = 2.0 * B * P * I * O
+    bytes_ = (B * P * I + B * O * I + B * P * O) * x.element_size()
+    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+    return {"kernel": "gemm_nn_kernel (dgv2_bmm_nn, modconv level-4 conv1)", "bound": "mfma",
+            "achieved": flops / sec / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / peak,
+            "traffic": None, "avg_launch_us": sec * 1e6, "algorithmic_hbm_GBps": bytes_ / sec / 1e9}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    from gans.trainer import Trainer
+    from gans.utils import init_random_seed
+
+    init_random_seed(0, rank)
+    cfg = make_cfg(args, rank, world)
+    trainer = Trainer(cfg, sync_scalars=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: first call uses iteration 16 so that the lazy-R1 and ADA-update paths are also warm
+    it = 16
+    for _ in range(max(args.warmup, 1)):
+        trainer.step(it)
+        it += 1
+    it = 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(it)
+        it += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    imgs = args.steps * args.batch_per_gpu * world
+    value = imgs / dt
+
+    roof = roofline_probe(args) if rank == 0 else None
+
+    if rank == 0:
+        out = {
+            "metric": "range-images/sec (G+D step) on dusty_v2 64x512",
+            "value": value, "unit": "range-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[2]: configs/gans/dusty_v2.yaml full G+D train step "
+                                   "(G step + D step + lazy R1/16 + ADA + EMA + Adam), 64x512 synthetic",
+                       "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
+                       "parallelism": f"dp{world}", "ada_p": args.ada_p, "hip_graph": False},
+            "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

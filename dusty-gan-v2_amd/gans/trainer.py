@@ -1,0 +1,252 @@
+"""G+D training orchestration for MI355X (interface of the reference's gans/trainer.py:44-567:
+`Trainer(cfg)`, `.step(i)`, `.sample()`, `.save_checkpoint()`, same checkpoint keys).
+
+Sequence of one iteration = the reference's Trainer.step (:247-482): G step -> D step -> lazy R1
+every `lazy.gp` iterations -> G_ema update -> ADA p update every `lazy.ada` iterations -> scalars.
+What is different is the plumbing, chosen for MI355X:
+  * one process per GPU; gradients live in one flat fp32 buffer per model and are exchanged with
+    ONE all-reduce each (parallel.FlatGradSync) instead of DDP buckets; rank-0's mutable G
+    buffers travel as one packed broadcast; all logged scalars as one packed all-reduce;
+  * no per-iteration host synchronisation unless `sync_scalars` asks for Python floats;
+  * the angle grid is passed once ([1,2,H,W]) and broadcast inside the kernels instead of being
+    repeat_interleave'd to the batch (trainer.py:91-93);
+  * real batches: synthetic generator in HBM when no dataset is present (benchmarks).
+"""
+import copy
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from gans import parallel
+from gans.augment.adaptive_augment import AdaptiveAugment
+from gans.coords import CoordBridge, synthetic_angle_grid
+from gans.datasets.synthetic import SyntheticRangeImages
+from gans.models.builder import build_discriminator, build_generator
+from gans.models.loss import GANLoss
+from gans.models.ops.common import filter2d
+from gans.utils import set_requires_grad
+
+
+@torch.no_grad()
+def ema_inplace(ema_model, new_model, decay):
+    """reference: trainer.py:30-41 -- parameters lerp, buffers copied; foreach-batched."""
+    ep = [p for _, p in ema_model.named_parameters()]
+    np_ = [p for _, p in new_model.named_parameters()]
+    torch._foreach_mul_(ep, decay)
+    torch._foreach_add_(ep, np_, alpha=1 - decay)
+    eb = [b for _, b in ema_model.named_buffers()]
+    nb = [b for _, b in new_model.named_buffers()]
+    torch._foreach_copy_(eb, nb)
+
+
+class Trainer:
+    def __init__(self, cfg, sync_scalars=True):
+        self.cfg = cfg
+        self.rank = int(cfg.training.get("rank", 0))
+        self.num_gpus = int(cfg.training.get("num_gpus", 1))
+        local = int(os.environ.get("LOCAL_RANK", self.rank))
+        self.device = torch.device("cuda", local)
+        torch.cuda.set_device(self.device)
+        self.sync_scalars = sync_scalars
+        self.resolution = cfg.model.generator.synthesis_kwargs.resolution
+        self.B = int(cfg.training.get("batch_size_per_gpu", cfg.training.batch_size // self.num_gpus))
+        self.batch_size = int(cfg.training.batch_size)
+
+        # models (rank 0's initial weights are broadcast, as DDP's constructor does)
+        self.G = build_generator(cfg.model.generator).to(self.device)
+        self.D = build_discriminator(cfg.model.discriminator).to(self.device)
+        parallel.broadcast_module(self.G)
+        parallel.broadcast_module(self.D)
+        self.G_ema = copy.deepcopy(self.G).eval()
+        self.A = AdaptiveAugment(p_init=cfg.training.augment.p_init, p_target=cfg.training.augment.p_target,
+                                 kimg=cfg.training.augment.kimg, **cfg.training.augment.policy).to(self.device)
+        angle_file = f"data/coords/{cfg.dataset.name}.npy"
+        self.coord = CoordBridge(
+            num_ring=self.resolution[0], num_points=self.resolution[1], min_depth=cfg.dataset.min_depth,
+            max_depth=cfg.dataset.max_depth, angle_file=angle_file if os.path.exists(angle_file) else None,
+            angle_array=None if os.path.exists(angle_file) else synthetic_angle_grid(self.resolution[0]),
+        ).eval().to(self.device)
+        for m in (self.G, self.G_ema, self.D, self.A, self.coord):
+            m.requires_grad_(False)
+        self.g_sync = parallel.FlatGradSync(self.G)
+        self.d_sync = parallel.FlatGradSync(self.D)
+        self.ddp_models = (self.g_sync, self.d_sync)
+        self.auxin = {"angle": self.coord.angle}  # [1,2,H,W]; kernels broadcast it over the batch
+
+        # data
+        root = cfg.dataset.get("root", "")
+        if cfg.dataset.name != "synthetic" and os.path.isdir(root):
+            raise NotImplementedError("the KITTI loader is outside this round's scope (SURVEY.md section 8f); "
+                                      "use dataset.name=synthetic or remove dataset.root")
+        self.iter_train_loader = iter(SyntheticRangeImages(
+            self.resolution, cfg.dataset.min_depth, cfg.dataset.max_depth, self.B, self.device,
+            seed=cfg.random_seed + self.rank))
+
+        # losses and lazy-regularisation corrected Adam (reference: trainer.py:121-171)
+        self.adversarial_loss = GANLoss(cfg.training.gan_objective).to(self.device)
+        self.lazy_gp = int(cfg.training.lazy.gp)
+        self.lazy_ada = int(cfg.training.lazy.ada)
+        self.gp_weight = 0.0
+        ratio_G = ratio_D = 1.0
+        if cfg.training.loss.get("gp", 0) > 0.0:
+            self.gp_weight = float(cfg.training.loss.gp) * self.lazy_gp
+            ratio_D = self.lazy_gp / (self.lazy_gp + 1.0)
+        if cfg.training.loss.get("pl", 0) > 0.0:
+            raise NotImplementedError("path-length regularisation is disabled in dusty_v2.yaml (loss.pl: 0) and "
+                                      "its reference block is broken (SURVEY.md section 3B.4)")
+        lg, ld = cfg.training.lr.generator, cfg.training.lr.discriminator
+        self.optim_G = optim.Adam(self.G.parameters(), lr=lg.alpha * ratio_G,
+                                  betas=(float(lg.beta1) ** ratio_G, float(lg.beta2) ** ratio_G))
+        self.optim_D = optim.Adam(self.D.parameters(), lr=ld.alpha * ratio_D,
+                                  betas=(float(ld.beta1) ** ratio_D, float(ld.beta2) ** ratio_D))
+
+        # resume
+        self.start_iteration = 0
+        if cfg.training.get("resume") is not None:
+            sd = torch.load(cfg.training.resume, map_location="cpu", weights_only=False)
+            self.start_iteration = sd["step"] // self.batch_size
+            self.G.load_state_dict(sd["G"])
+            self.D.load_state_dict(sd["D"])
+            self.G_ema.load_state_dict(sd["G_ema"])
+            self.A.load_state_dict(sd["A"])
+            self.optim_G.load_state_dict(sd["optim_G"])
+            self.optim_D.load_state_dict(sd["optim_D"])
+            self.g_sync.rebind()
+            self.d_sync.rebind()
+
+        self.z_fixed = self.sample_z(self.B)
+        self.warmup_fade_kimg = cfg.training.warmup.fade_kimg * 1e3
+        self.blur_sigma = 0
+        self.dropout_ratio = 0
+        self.iters_to_imgs = lambda i: int(i * self.batch_size)
+
+    # ------------------------------------------------------------------ helpers
+    def sample_z(self, batch_size):
+        return torch.randn(batch_size, self.cfg.model.generator.mapping_kwargs.in_ch, device=self.device)
+
+    def fetch_reals(self, raw_batch):
+        """reference: trainer.py:211-217, fused into one kernel."""
+        mask = raw_batch["mask"].to(self.device)
+        x = self.coord.fetch_reals(raw_batch["depth"].to(self.device), mask, float(self.cfg.dataset.raydrop_const))
+        return {"image": x, "raydrop_mask": mask}
+
+    def set_warmup_params(self, iteration):
+        num_imgs = self.iters_to_imgs(iteration)
+        w = self.cfg.training.warmup
+        fade = max(1 - num_imgs / self.warmup_fade_kimg, 0) if self.warmup_fade_kimg > 0 else 0
+        self.blur_sigma = fade * w.blur_init_sigma
+        self.dropout_ratio = fade * w.dropout_init_ratio
+
+    def warmup(self, x):
+        """reference: trainer.py:234-245."""
+        blur_size = np.floor(self.blur_sigma * 3)
+        if blur_size > 0:
+            k = torch.arange(-blur_size, blur_size + 1, device=x.device)
+            x = filter2d(x, k.div(self.blur_sigma).square().neg().exp2())
+        if self.dropout_ratio > 0:
+            keep = (torch.rand_like(x) < (1 - self.dropout_ratio)).to(x.dtype)
+            x = keep * x + (1 - keep) * float(self.cfg.dataset.raydrop_const)
+        return x
+
+    # ------------------------------------------------------------------ sub-steps
+    def g_step(self, scalars):
+        set_requires_grad(self.G, True)
+        self.g_sync.zero()
+        parallel.sync_buffers(self.G)
+        z = self.sample_z(self.B)
+        x_fake = self.G(z, **self.auxin)["image"]
+        y_fake = self.D(self.A(self.warmup(x_fake)))
+        loss_gan = self.adversarial_loss(None, y_fake, "G")
+        (self.cfg.training.loss.gan * loss_gan).backward()
+        self.g_sync.all_reduce()
+        self.optim_G.step()
+        set_requires_grad(self.G, False)
+        scalars["loss/G/adversarial"] = loss_gan.detach()
+
+    def d_step(self, x_real, scalars):
+        set_requires_grad(self.D, True)
+        self.d_sync.zero()
+        parallel.sync_buffers(self.G)
+        z = self.sample_z(self.B)
+        with torch.no_grad():
+            x_fake = self.G(z, **self.auxin)["image"]
+            x_real_aug = self.A(self.warmup(x_real))
+            x_fake_aug = self.A(self.warmup(x_fake))
+        y_real = self.D(x_real_aug)
+        y_fake = self.D(x_fake_aug)
+        self.A.cumulate(y_real)
+        loss_gan = self.adversarial_loss(y_real, y_fake, "D")
+        (self.cfg.training.loss.gan * loss_gan).backward()
+        self.d_sync.all_reduce()
+        self.optim_D.step()
+        scalars["loss/D/output/real"] = y_real.mean().detach()
+        scalars["loss/D/output/fake"] = y_fake.mean().detach()
+        scalars["loss/D/adversarial"] = loss_gan.detach()
+
+    def r1_step(self, x_real, scalars):
+        """lazy R1 (reference: trainer.py:419-451): double backward through D and ADA."""
+        self.d_sync.zero()
+        x = x_real.detach().requires_grad_(True)
+        y_real = self.D(self.A(self.warmup(x)))
+        (grads,) = torch.autograd.grad(outputs=[y_real.sum()], inputs=[x], create_graph=True)
+        r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
+        loss = (self.gp_weight / 2) * r1 + 0.0 * y_real.squeeze()[0]
+        loss.backward()
+        self.d_sync.all_reduce()
+        self.optim_D.step()
+        scalars["loss/D/gradient_penalty"] = r1.detach()
+
+    def ema_decay(self, iteration):
+        ema_imgs = int(self.cfg.training.ema_kimg * 1e3)
+        if self.cfg.training.ema_rampup is not None:
+            ema_imgs = min(ema_imgs, iteration * self.batch_size * self.cfg.training.ema_rampup)
+        return 0.5 ** (self.batch_size / max(ema_imgs, 1e-8))
+
+    # ------------------------------------------------------------------ one iteration
+    def step(self, iteration):
+        self.G.train()
+        self.set_warmup_params(iteration)
+        scalars = {}
+        x_real = self.fetch_reals(next(self.iter_train_loader))["image"]
+
+        self.g_step(scalars)
+        self.d_step(x_real, scalars)
+        if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
+            self.r1_step(x_real, scalars)
+        set_requires_grad(self.D, False)
+
+        decay = self.ema_decay(iteration)
+        ema_inplace(self.G_ema, self.G, decay)
+        if iteration % self.lazy_ada == 0:
+            scalars["stats/ada_rt"] = self.A.update_p().reshape(())
+            scalars["stats/ada_p"] = self.A.p.detach().clone()
+
+        out = parallel.reduce_scalars(scalars)
+        if self.sync_scalars:
+            out = {k: v.cpu().item() for k, v in out.items()}
+        out["stats/ema_decay"] = decay
+        out["stats/warmup_blur_sigma"] = self.blur_sigma
+        out["stats/warmup_dropout_ratio"] = self.dropout_ratio
+        return out
+
+    @torch.no_grad()
+    def sample(self, ema=False):
+        model = self.G_ema if ema else self.G
+        model.eval()
+        return model(self.z_fixed, **self.auxin)
+
+    def validation(self):
+        raise NotImplementedError("FPD/KPD validation (PointNet features) is outside this round's scope")
+
+    def save_checkpoint(self, save_path, step):
+        """Same keys as the reference (trainer.py:551-567)."""
+        ckpt = {
+            "cfg": self.cfg, "step": step, "angle": self.coord.angle.detach().cpu(),
+            "G": self.G.state_dict(), "D": self.D.state_dict(), "G_ema": self.G_ema.state_dict(),
+            "A": self.A.state_dict(), "optim_G": self.optim_G.state_dict(), "optim_D": self.optim_D.state_dict(),
+        }
+        save_path.parent.mkdir(parents=True, exist_ok=True)
+        torch.save(ckpt, save_path)

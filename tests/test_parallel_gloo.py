@@ -1,0 +1,89 @@
+"""World-size-2 tests of the data-parallel plumbing on CPU (gloo): flat gradient all-reduce,
+packed buffer broadcast, packed scalar reduction, ADA statistics exchange, sampler sharding."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, tmp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{tmp}/init", world_size=world, rank=rank)
+    from gans import parallel
+    from gans.augment.adaptive_augment import AdaptiveAugment
+    from gans.models.builder import build_generator
+    from helpers import small_cfg
+
+    torch.manual_seed(rank)  # different init per rank on purpose
+    G = build_generator(small_cfg().model.generator)
+    parallel.broadcast_module(G)
+    w0 = G.state_dict()["synthesis_network.layers.1.conv1.weight"].clone()
+
+    sync = parallel.FlatGradSync(G)
+    for p in G.parameters():
+        assert p.grad.data_ptr() >= sync.flat.data_ptr()
+    sync.zero()
+    # fake local gradients: rank r contributes (r + 1) everywhere
+    for p in G.parameters():
+        p.grad.add_(float(rank + 1))
+    with sync.no_sync():
+        sync.all_reduce()
+    local_only = float(sync.flat[0])
+    sync.all_reduce()
+    averaged = float(sync.flat[0]), float(sync.flat[-1])
+
+    # mutable buffers: rank 0 wins
+    with torch.no_grad():
+        for b in parallel.mutable_buffers(G):
+            b.fill_(10.0 + rank)
+    parallel.sync_buffers(G)
+    bufs = [float(b.flatten()[0]) for b in parallel.mutable_buffers(G)]
+
+    sc = parallel.reduce_scalars({"a": torch.tensor(float(rank)), "b": torch.tensor(2.0 * rank + 1)})
+
+    A = AdaptiveAugment(p_init=0.0, p_target=0.6, kimg=1)
+    A.cumulate(torch.ones(4, 1) if rank == 0 else -torch.ones(4, 1))  # rt = 0 over both ranks
+    rt = float(A.update_p())
+    A.cumulate(torch.ones(4, 1))
+    A.update_p()  # rt = 1 on both -> p += 8 / 1000
+
+    q.put((rank, w0.sum().item(), local_only, averaged, bufs, {k: float(v) for k, v in sc.items()}, rt, float(A.p)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_plumbing():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = [ctx.Process(target=_worker, args=(r, world, tmp, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    (r0, r1) = res
+    assert r0[1] == r1[1]                                   # parameters broadcast from rank 0
+    assert r0[2] == 1.0 and r1[2] == 2.0                    # no_sync leaves local gradients alone
+    assert r0[3] == (1.5, 1.5) and r1[3] == (1.5, 1.5)      # mean over ranks of (1, 2)
+    assert set(r0[4]) == {10.0} and set(r1[4]) == {10.0}    # rank-0 buffers everywhere
+    assert r0[5] == r1[5] == {"a": 0.5, "b": 2.0}
+    assert r0[6] == r1[6] == 0.0 and r0[7] == r1[7] == pytest.approx(8 / 1000)
+
+
+def test_infinite_sampler_ranks_interleave_the_single_stream():
+    """With a shared seed, rank r of n yields every n-th element of the one-replica stream
+    (reference: gans/utils.py:238-271)."""
+    from gans.utils import InfiniteSampler
+    data = list(range(40))
+    one = iter(InfiniteSampler(data, rank=0, num_replicas=1, seed=3))
+    full = [next(one) for _ in range(60)]
+    for r in range(2):
+        it = iter(InfiniteSampler(data, rank=r, num_replicas=2, seed=3))
+        assert [next(it) for _ in range(30)] == full[r::2]
