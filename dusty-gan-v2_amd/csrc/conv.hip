@@ -9,13 +9,14 @@
 namespace {
 
 template <typename T, int TO>
-int launch_conv_fwd(void* y, const void* x, const void* w, const ConvGeom& g, hipStream_t st) {
+int launch_conv_fwd(void* y, const void* x, const void* w, const ConvGeom& g, const float* bias, int act,
+                    float alpha, float scale, hipStream_t st) {
   constexpr int CE = 16 / sizeof(T);
   const int K = g.kh * g.kw * g.C;
   const int npix = g.B * g.Ho * g.Wo;
   DenseRowLoader<T> al{(const T*)w, 0, K, g.O, K, (K % CE == 0) && aligned16(w)};
   Im2colFwdLoader<T> bl{(const T*)x, g, npix, K, (g.C % CE == 0) && aligned16(x)};
-  StoreEpilogue<T> epi{(T*)y, 0, g.O, g.O, npix, (g.O % 4 == 0) && aligned16(y)};
+  StoreEpilogue<T> epi{(T*)y, 0, g.O, g.O, npix, (g.O % 4 == 0) && aligned16(y), bias, act, alpha, scale};
   dim3 grid((npix + 127) / 128, (g.O + TO - 1) / TO, 1);
   gemm_nn_kernel<T, TO, DenseRowLoader<T>, Im2colFwdLoader<T>, StoreEpilogue<T>><<<grid, 256, 0, st>>>(al, bl, epi, K);
   return 0;
@@ -29,7 +30,7 @@ int launch_conv_dgrad(void* gxp, const void* gy, const void* wt, const ConvGeom&
   const int npix = g.B * Hp * Wp;
   DenseRowLoader<T> al{(const T*)wt, 0, K, g.C, K, (K % CE == 0) && aligned16(wt)};
   Im2colDgradLoader<T> bl{(const T*)gy, g, Hp, Wp, npix, K, (g.O % CE == 0) && aligned16(gy)};
-  StoreEpilogue<T> epi{(T*)gxp, 0, g.C, g.C, npix, (g.C % 4 == 0) && aligned16(gxp)};
+  StoreEpilogue<T> epi{(T*)gxp, 0, g.C, g.C, npix, (g.C % 4 == 0) && aligned16(gxp), nullptr, 0, 0.f, 1.f};
   dim3 grid((npix + 127) / 128, (g.C + TO - 1) / TO, 1);
   gemm_nn_kernel<T, TO, DenseRowLoader<T>, Im2colDgradLoader<T>, StoreEpilogue<T>><<<grid, 256, 0, st>>>(al, bl, epi, K);
   return 0;
@@ -124,15 +125,16 @@ ConvGeom make_geom(int B, int H, int W, int C, int O, int kh, int kw, int stride
 }  // namespace
 
 extern "C" int dgv2_conv_fwd(void* y, const void* x, const void* w, int B, int H, int W, int C, int O, int kh, int kw,
-                             int stride, int pad, int ring, int dtype, void* stream) {
+                             int stride, int pad, int ring, const float* bias, int act, float alpha, float scale,
+                             int dtype, void* stream) {
   const ConvGeom g = make_geom(B, H, W, C, O, kh, kw, stride, pad, ring);
-  if (!y || !x || !w || !geom_ok(g)) return DGV2_EINVAL;
+  if (!y || !x || !w || !geom_ok(g) || (act != 0 && act != 3)) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   DGV2_DISPATCH_DTYPE(dtype, {
-    if (O <= 16) launch_conv_fwd<T, 16>(y, x, w, g, st);
-    else if (O <= 32) launch_conv_fwd<T, 32>(y, x, w, g, st);
-    else if (O <= 64) launch_conv_fwd<T, 64>(y, x, w, g, st);
-    else launch_conv_fwd<T, 128>(y, x, w, g, st);
+    if (O <= 16) launch_conv_fwd<T, 16>(y, x, w, g, bias, act, alpha, scale, st);
+    else if (O <= 32) launch_conv_fwd<T, 32>(y, x, w, g, bias, act, alpha, scale, st);
+    else if (O <= 64) launch_conv_fwd<T, 64>(y, x, w, g, bias, act, alpha, scale, st);
+    else launch_conv_fwd<T, 128>(y, x, w, g, bias, act, alpha, scale, st);
   });
   DGV2_RETURN_LAST();
 }

@@ -6,13 +6,14 @@ namespace {
 
 template <typename T, typename TY, int TO>
 int launch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
-                  int64_t wstride, hipStream_t st) {
+                  int64_t wstride, const float* bias, int act, float alpha, float scale, hipStream_t st) {
   constexpr int CE = 16 / sizeof(T);
   DenseRowLoader<T> al{(const T*)w, wstride, I, O, I, (I % CE == 0) && (wstride % CE == 0) && aligned16(w)};
   DenseRowLoader<T> bl{(const T*)x, (int64_t)P * ldx, ldx, P, I, (ldx % CE == 0) && aligned16(x)};
   constexpr int YE = 16 / sizeof(TY);
   StoreEpilogue<TY> epi{(TY*)y, (int64_t)P * ldy, ldy, O, P,
-                        (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & (4 * sizeof(TY) - 1)) == 0)};
+                        (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & (4 * sizeof(TY) - 1)) == 0),
+                        bias, act, alpha, scale};
   (void)YE;
   dim3 grid((P + 127) / 128, (O + TO - 1) / TO, B);
   gemm_nn_kernel<T, TO, DenseRowLoader<T>, DenseRowLoader<T>, StoreEpilogue<TY>><<<grid, 256, 0, st>>>(al, bl, epi, I);
@@ -21,11 +22,11 @@ int launch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, in
 
 template <typename T, typename TY>
 int dispatch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
-                    int64_t wstride, hipStream_t st) {
-  if (O <= 16) return launch_bmm_nn<T, TY, 16>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
-  if (O <= 32) return launch_bmm_nn<T, TY, 32>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
-  if (O <= 64) return launch_bmm_nn<T, TY, 64>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
-  return launch_bmm_nn<T, TY, 128>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+                    int64_t wstride, const float* bias, int act, float alpha, float scale, hipStream_t st) {
+  if (O <= 16) return launch_bmm_nn<T, TY, 16>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st);
+  if (O <= 32) return launch_bmm_nn<T, TY, 32>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st);
+  if (O <= 64) return launch_bmm_nn<T, TY, 64>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st);
+  return launch_bmm_nn<T, TY, 128>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st);
 }
 
 template <typename T, int TO, int TJ>
@@ -44,15 +45,17 @@ int launch_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I,
 }  // namespace
 
 extern "C" int dgv2_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
-                           int64_t wstride, int dtype, int ydtype, void* stream) {
+                           int64_t wstride, const float* bias, int act, float alpha, float scale, int dtype,
+                           int ydtype, void* stream) {
   if (!y || !x || !w || B <= 0 || P <= 0 || I <= 0 || O <= 0 || ldx < I || ldy < O) return DGV2_EINVAL;
+  if (act != 0 && act != 3) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DGV2_F32 && ydtype == DGV2_F32)
-    dispatch_bmm_nn<float, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+    dispatch_bmm_nn<float, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st);
   else if (dtype == DGV2_BF16 && ydtype == DGV2_BF16)
-    dispatch_bmm_nn<bf16_t, bf16_t>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+    dispatch_bmm_nn<bf16_t, bf16_t>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st);
   else if (dtype == DGV2_BF16 && ydtype == DGV2_F32)
-    dispatch_bmm_nn<bf16_t, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, st);
+    dispatch_bmm_nn<bf16_t, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st);
   else
     return DGV2_EINVAL;
   DGV2_RETURN_LAST();

@@ -235,14 +235,28 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(ALoad al, BLoad bl, Epi ep
       epi(batch, m0 + mf * 16 + lc * 4, n0 + wave * 32 + nf * 16 + lr, acc[mf][nf]);
 }
 
-// Store epilogue: Y[batch][n][m..m+3] (channels-last), optional fp32 output for bf16 inputs.
+// Store epilogue: Y[batch][n][m..m+3] (channels-last), optional fp32 output for bf16 inputs, and
+// an optional fused "+ bias[m], leaky-ReLU, * scale" (the FusedLeakyReLU that follows every trunk
+// conv: gans/models/ops/fused_act/fused_bias_act_kernel.cu:19-65 case act=3, grad=0).
 template <typename TY> struct StoreEpilogue {
   TY* y;
   int64_t batch_stride;
   int ld, M, N;
   bool vec;
-  __device__ __forceinline__ void operator()(int batch, int m, int n, const f32x4& acc) const {
+  const float* bias;  // fp32 [M] or nullptr
+  int act;            // 0 = none, 3 = leaky ReLU
+  float alpha, scale;
+  __device__ __forceinline__ void operator()(int batch, int m, int n, f32x4 acc) const {
     if (n >= N || m >= M) return;
+    if (bias || act) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[r];
+        if (bias && m + r < M) v += bias[m + r];
+        if (act == 3) v = (v > 0.f ? v : v * alpha) * scale;
+        acc[r] = v;
+      }
+    }
     TY* p = y + batch * batch_stride + (int64_t)n * ld + m;
     if (vec && m + 3 < M) {
       if constexpr (sizeof(TY) == 4) {

@@ -171,3 +171,88 @@ extern "C" int dgv2_resample(void* y, const void* x, const float* taps_h, const 
   });
   DGV2_RETURN_LAST();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Table-driven variant: the per-axis sparse rows (index, coefficient, count) are geometry-only, so
+// the host builds them once per (spec, size, direction) and caches them on the device.  The kernel
+// is then pure streaming: one thread = one output pixel x one 16-byte channel vector, no LDS, no
+// barrier, 32-bit index math.  Tables: idx/coef [n_out, E] (row-major), cnt [n_out].
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void resample_tab_kernel(
+    T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
+    const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
+    const int* __restrict__ cnt_w, int Ew, int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w) {
+  constexpr int VN = VEC ? vec16<T>::N : 1;
+  const int cvecs = (C + VN - 1) / VN;
+  const int64_t total = (int64_t)B * out_h * out_w * cvecs;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(t % cvecs);
+    int64_t r = t / cvecs;
+    const int wo = (int)(r % out_w);
+    r /= out_w;
+    const int ho = (int)(r % out_h);
+    const int b = (int)(r / out_h);
+    const int nh = cnt_h[ho], nw = cnt_w[wo];
+    const int* ih = idx_h + ho * Eh;
+    const float* ch = coef_h + ho * Eh;
+    const int* iw = idx_w + wo * Ew;
+    const float* cw = coef_w + wo * Ew;
+    const T* xb = x + (int64_t)b * in_h * in_w * ldx + cv * VN;
+    float acc[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+    for (int a = 0; a < nh; ++a) {
+      const float fa = ch[a];
+      const T* xr = xb + (int64_t)ih[a] * in_w * ldx;
+      for (int c = 0; c < nw; ++c) {
+        const float cf = fa * cw[c];
+        const T* p = xr + iw[c] * ldx;
+        if (VEC) {
+          vec16<T> v;
+          v.load(p);
+#pragma unroll
+          for (int j = 0; j < VN; ++j) acc[j] += cf * v.get(j);
+        } else {
+          acc[0] += cf * to_f32(p[0]);
+        }
+      }
+    }
+    T* q = y + (((int64_t)b * out_h + ho) * out_w + wo) * ldy + cv * VN;
+    if (VEC) {
+      vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
+      o.store(q);
+    } else {
+      q[0] = from_f32<T>(acc[0]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const float* coef_h, const int* cnt_h,
+                                 int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew, int B,
+                                 int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w, int dtype,
+                                 void* stream) {
+  if (!y || !x || !idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w) return DGV2_EINVAL;
+  if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || Eh <= 0 || Ew <= 0) return DGV2_EINVAL;
+  if (ldx < C || ldy < C) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  DGV2_DISPATCH_DTYPE(dtype, {
+    constexpr int VN = vec16<T>::N;
+    const bool vec = (C % VN == 0) && (ldx % VN == 0) && (ldy % VN == 0) && aligned16(x) && aligned16(y);
+    const int64_t total = (int64_t)B * out_h * out_w * ((C + (vec ? VN : 1) - 1) / (vec ? VN : 1));
+    const int grid = grid_for(total, 256, 256 * 64);
+    if (vec)
+      resample_tab_kernel<T, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
+                                                        cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w);
+    else
+      resample_tab_kernel<T, false><<<grid, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
+                                                         cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w);
+  });
+  DGV2_RETURN_LAST();
+}

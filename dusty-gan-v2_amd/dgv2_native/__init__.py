@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -30,12 +30,13 @@ SIGNATURES = {
     "dgv2_bias_grad": [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr],
     "dgv2_upfirdn2d": [_c_ptr] * 3 + [_c_int] * 15 + [_c_ptr],
     "dgv2_resample": [_c_ptr] * 4 + [_c_int] * 19 + [_c_ptr],
+    "dgv2_resample_tab": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr],
     "dgv2_fourier_feature": [_c_ptr] * 5 + [_c_int] * 8 + [_c_ptr],
     "dgv2_downsample_angle": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr],
-    "dgv2_bmm_nn": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_int, _c_int, _c_ptr],
+    "dgv2_bmm_nn": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr],
     "dgv2_bmm_tn": [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr],
     "dgv2_sum_squares": [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_ptr],
-    "dgv2_conv_fwd": [_c_ptr] * 3 + [_c_int] * 11 + [_c_ptr],
+    "dgv2_conv_fwd": [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_conv_dgrad": [_c_ptr] * 4 + [_c_int] * 11 + [_c_ptr],
     "dgv2_conv_wgrad": [_c_ptr] * 3 + [_c_int] * 11 + [_c_ptr],
     "dgv2_gen_tail_fwd": [_c_ptr] * 7 + [_c_int] * 3 + [_c_f32] * 3 + [_c_ptr],

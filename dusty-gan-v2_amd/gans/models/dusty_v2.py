@@ -132,10 +132,10 @@ class SynthesisBlock(nn.Module):
         spec = None if self.is_first else self.resample.spec
         hin = None if h is None else h.to(dt)
         x1 = native.up_cat_pe(hin, spec, angle, shift, self.pe.freqs2.contiguous(), self.pe.phase, dt, B)
-        h = self.bias_act1.forward_cl(self.conv1.forward_cl(x1, ws[0]))
+        h = self.conv1.forward_cl(x1, ws[0], act=self.bias_act1)
         nxt = 1
         if not self.is_first:
-            h = self.bias_act2.forward_cl(self.conv2.forward_cl(h, ws[1]))
+            h = self.conv2.forward_cl(h, ws[1], act=self.bias_act2)
             nxt = 2
         o = self.head.forward_cl(h, ws[nxt])
         if skip is not None:
@@ -274,12 +274,15 @@ class ResidualBlock(nn.Module):
         self.conv2 = ops.Conv2d(in_ch, out_ch, 3, 2, 1, **kw)
         self.bias_act2 = ops.FusedLeakyReLU(out_ch)
         self.skip = ops.Conv2d(in_ch, out_ch, 1, 2, 0, **kw)
+        # blur followed by the stride-2 1x1 skip conv only ever reads even positions: evaluate the
+        # FIR directly at those (down=2 with the blur's pads), then a stride-1 1x1 conv
+        self.blur_down = native.ResampleSpec([1, 3, 3, 1], down=(2, 2), ring=True, pads=(2, 1))
+        self.skip_geom = native.ConvGeom(1, 1, 1, 0, True)
 
     def forward_cl(self, x):
-        h = self.bias_act1.forward_cl(self.conv1.forward_cl(x))
-        h = self.conv2.forward_cl(self.resample.forward_cl(h))
-        h = self.bias_act2.forward_cl(h)
-        s = self.skip.forward_cl(self.resample.forward_cl(x))
+        h = self.conv1.forward_cl(x, act=self.bias_act1)
+        h = self.conv2.forward_cl(self.resample.forward_cl(h), act=self.bias_act2)
+        s = self.skip.forward_cl(native.resample(x, self.blur_down), geom=self.skip_geom)
         return (h + s) * (1.0 / math.sqrt(2))
 
     def forward(self, x):
@@ -324,15 +327,30 @@ class Discriminator(nn.Module):
     def forward(self, h):
         """h [B,C,H,W] (C = 1 on the dusty_v2 path) -> logits [B,1]."""
         x = ops.to_cl(h.float())
-        for i, layer in enumerate(self.layers):
+        layers = list(self.layers)
+        i = 0
+        while i < len(layers):
             low = (self.num_fp16_layers > i) or (self.num_fp16_layers == -1)
-            x = layer.forward_cl(x.to(LOW if low else torch.float32))
+            x = x.to(LOW if low else torch.float32)
+            layer = layers[i]
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            if isinstance(layer, ops.Conv2d) and isinstance(nxt, ops.FusedLeakyReLU):
+                x = layer.forward_cl(x, act=nxt)  # stem conv + its bias/lrelu in one kernel
+                i += 2
+            else:
+                x = layer.forward_cl(x)
+                i += 1
         x = x.float()
         mb, conv, act1, _, lin1, act2, lin2 = self.epilogue
+        # The reference runs the epilogue in fp32.  With num_fp16_layers == -1 ("everything reduced")
+        # the 3x3 epilogue conv (303 MMAC/img) runs in bf16 with fp32 accumulation here; mbstd and the
+        # two Linear layers stay fp32.  See DESIGN.md section 4.
+        edt = LOW if self.num_fp16_layers == -1 else torch.float32
         cin = x.shape[3] + mb.features
-        cpad = (cin + 3) // 4 * 4  # 16-byte channel vectors for the fp32 implicit GEMM
+        vec = 8 if edt == LOW else 4
+        cpad = (cin + vec - 1) // vec * vec  # 16-byte channel vectors for the implicit GEMM
         x = mb.forward_cl(x, pad_to=cpad)
-        x = act1.forward_cl(conv.forward_cl(x, pad_in_to=cpad))
+        x = conv.forward_cl(x.to(edt), pad_in_to=cpad, act=act1).float()
         x = ops.from_cl(x).flatten(1)  # NCHW flatten order of the reference's nn.Flatten
         x = act2.forward_cl(lin1(x))
         return lin2(x)

@@ -136,15 +136,20 @@ class Conv2d(nn.Sequential):
             return last.effective_weight(), last.module.bias, last.gain_
         return last.weight, last.bias, 1.0
 
-    def forward_cl(self, x, pad_in_to=None):
+    def forward_cl(self, x, pad_in_to=None, act=None, geom=None):
+        """act: a FusedLeakyReLU module fused into the conv epilogue; geom overrides the stride
+        (used when the caller has already decimated the input)."""
         w, b, gain = self._params()
         w = w.permute(0, 2, 3, 1)  # [O,kh,kw,C]
         if pad_in_to is not None and pad_in_to > w.shape[3]:
             w = F.pad(w, (0, pad_in_to - w.shape[3]))
-        y = native.conv_ring(x, w.contiguous(), self.geom)
+        geom = self.geom if geom is None else geom
+        if act is not None and b is None and act.bias is not None:
+            return native.conv_ring_act(x, w.contiguous(), act.bias, geom, act.negative_slope, act.scale)
+        y = native.conv_ring(x, w.contiguous(), geom)
         if b is not None:
             y = y + (b * gain).to(y.dtype)
-        return y
+        return y if act is None else act.forward_cl(y)
 
     def forward(self, x):
         return from_cl(self.forward_cl(to_cl(x)))

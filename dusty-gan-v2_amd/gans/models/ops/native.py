@@ -43,7 +43,6 @@ class _BiasActBackward(Function):
         if has_bias:
             gb = torch.empty(size_b, device=gy.device, dtype=torch.float32)
             N.call("dgv2_bias_grad", N.ptr(gb), N.ptr(gx), gx.numel(), step_b, size_b, _dt(gx), N.stream())
-            gb = gb.to(gy.dtype)
         ctx.save_for_backward(out)
         ctx.cfg = (alpha, scale, step_b, size_b)
         return gx, gb
@@ -72,7 +71,7 @@ class _BiasAct(Function):
         (out,) = ctx.saved_tensors
         has_bias, alpha, scale, step_b, size_b = ctx.cfg
         gx, gb = _BiasActBackward.apply(gy, out, has_bias, alpha, scale, step_b, size_b)
-        return gx, gb, None, None, None
+        return gx, (None if gb is None else gb.to(gy.dtype)), None, None, None
 
 
 def bias_act(x, bias=None, alpha=0.2, scale=math.sqrt(2.0), channels_last=True):
@@ -87,9 +86,10 @@ def bias_act(x, bias=None, alpha=0.2, scale=math.sqrt(2.0), channels_last=True):
 # ring-aware FIR resampler   (reference: gans/models/ops/common.py:45-135)
 # ---------------------------------------------------------------------------------------
 class ResampleSpec:
-    """Static description of one Resample module: per-axis taps / up / down / p0 / p1."""
+    """Static description of one Resample module: per-axis taps / up / down / p0 / p1, plus the
+    cached sparse-row tables of the resampling matrix (forward) and of its transpose (adjoint)."""
 
-    def __init__(self, window, up=(1, 1), down=(1, 1), ring=True, direction="hw", normalize=True):
+    def __init__(self, window, up=(1, 1), down=(1, 1), ring=True, direction="hw", normalize=True, pads=None):
         k = len(window)
         w = torch.tensor(window, dtype=torch.float32)
         self.ring = bool(ring)
@@ -97,7 +97,9 @@ class ResampleSpec:
         for ax, name in enumerate("hw"):
             if name in direction:
                 u, d = int(up[ax]), int(down[ax])
-                if u > 1:
+                if pads is not None:
+                    p0, p1 = pads
+                elif u > 1:
                     p0, p1 = (k - u + 1) // 2 + u - 1, (k - u) // 2
                 else:
                     p0, p1 = (k - d + 1) // 2, (k - d) // 2
@@ -110,6 +112,7 @@ class ResampleSpec:
         one = torch.ones(1)
         self.taps_cpu = (taps if "h" in direction else one, taps if "w" in direction else one)
         self._dev = {}
+        self._tab = {}
 
     def taps(self, device):
         if device not in self._dev:
@@ -123,6 +126,47 @@ class ResampleSpec:
             out.append((full + d - 1) // d)
         return tuple(out)
 
+    @staticmethod
+    def _axis_rows(L, Lo, taps, k, up, down, p0, wrap, adjoint):
+        """Sparse rows of the 1-D resampling matrix R [Lo, L] (out[n] = sum_i taps[i] z[n*down+i-p0],
+        z zero-stuffed, ends extended circularly / by replication) or of its transpose."""
+
+        def ext(j):
+            return j % L if wrap else min(max(j, 0), L - 1)
+
+        rows = [[] for _ in range(L if adjoint else Lo)]
+        for n in range(Lo):
+            for i in range(k):
+                u = n * down + i - p0
+                if u % up != 0:
+                    continue
+                j = ext(u // up)
+                if adjoint:
+                    rows[j].append((n, float(taps[i])))
+                else:
+                    rows[n].append((j, float(taps[i])))
+        E = max(1, max(len(r) for r in rows))
+        idx = torch.zeros((len(rows), E), dtype=torch.int32)
+        coef = torch.zeros((len(rows), E), dtype=torch.float32)
+        cnt = torch.zeros(len(rows), dtype=torch.int32)
+        for r, ent in enumerate(rows):
+            cnt[r] = len(ent)
+            for e, (j, c) in enumerate(ent):
+                idx[r, e], coef[r, e] = j, c
+        return idx, coef, cnt, E
+
+    def tables(self, H, W, adjoint, device):
+        key = (H, W, bool(adjoint), str(device))
+        if key not in self._tab:
+            Ho, Wo = self.out_size(H, W)
+            tabs = []
+            for L, Lo, taps, (k, u, d, p0, _), wrap in zip((H, W), (Ho, Wo), self.taps_cpu, self.axes,
+                                                           (False, self.ring)):
+                idx, coef, cnt, E = self._axis_rows(L, Lo, taps.tolist(), k, u, d, p0, wrap, adjoint)
+                tabs.append((idx.to(device), coef.to(device), cnt.to(device), E))
+            self._tab[key] = tabs
+        return self._tab[key]
+
 
 def _resample_raw(x, spec, adjoint, in_hw, out=None, ldy=None, ldx=None, C=None):
     """x [B,h,w,ldx]; forward maps in_hw -> spec.out_size(in_hw); adjoint the other way."""
@@ -131,14 +175,14 @@ def _resample_raw(x, spec, adjoint, in_hw, out=None, ldy=None, ldx=None, C=None)
     Ho, Wo = spec.out_size(H, W)
     ldx = x.shape[3] if ldx is None else ldx
     C = ldx if C is None else C
+    ih, iw = (Ho, Wo) if adjoint else (H, W)
     oh, ow = (H, W) if adjoint else (Ho, Wo)
     if out is None:
         out = torch.empty((B, oh, ow, C), device=x.device, dtype=x.dtype)
         ldy = C
-    th, tw = spec.taps(x.device)
-    (kh, uh, dh, p0h, _), (kw, uw, dw, p0w, _) = spec.axes
-    N.call("dgv2_resample", N.ptr(out), N.ptr(x), N.ptr(th), N.ptr(tw), B, H, W, C, Ho, Wo, ldx, ldy,
-           kh, uh, dh, p0h, kw, uw, dw, p0w, int(spec.ring), int(adjoint), _dt(x), N.stream())
+    (ih_idx, ih_coef, ih_cnt, Eh), (iw_idx, iw_coef, iw_cnt, Ew) = spec.tables(H, W, adjoint, x.device)
+    N.call("dgv2_resample_tab", N.ptr(out), N.ptr(x), N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt), Eh,
+           N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew, B, C, ldx, ldy, ih, iw, oh, ow, _dt(x), N.stream())
     return out
 
 
@@ -234,14 +278,15 @@ def up_cat_pe(h, spec, angle, shift, freqs2, phase, dtype, B):
 # batched channel GEMM = contraction of the modulated 1x1 conv
 # (reference: grouped F.conv2d in ModConv2d.forward, gans/models/ops/style.py:105-118)
 # ---------------------------------------------------------------------------------------
-def _bmm_nn_raw(x3, w3, out_dtype):
-    """x3 [B,P,I]; w3 [Bw,O,I] (Bw = B or 1) same dtype -> [B,P,O]."""
+def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0):
+    """x3 [B,P,I]; w3 [Bw,O,I] (Bw = B or 1) same dtype -> [B,P,O]; optional fused
+    bias (fp32 [O]) + leaky-ReLU epilogue."""
     B, P, I = x3.shape
     Bw, O, _ = w3.shape
-    N.check(x3, w3)
+    N.check(x3, w3, bias)
     y = torch.empty((B, P, O), device=x3.device, dtype=out_dtype)
     N.call("dgv2_bmm_nn", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
-           _dt(x3), N.dtype_code(y), N.stream())
+           N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.stream())
     return y
 
 
@@ -289,6 +334,40 @@ def mod_gemm(x, w, out_dtype=None):
     return _ModGemm.apply(x, w, x.dtype if out_dtype is None else out_dtype)
 
 
+class _ModGemmAct(Function):
+    """lrelu(x @ w^T + b) * scale with the bias/activation fused into the GEMM epilogue
+    (reference: ModConv2d followed by FusedLeakyReLU, gans/models/dusty_v2.py:161-170)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, alpha, scale):
+        shp = x.shape
+        x3 = x.contiguous().reshape(shp[0], -1, shp[-1])
+        wc = w.detach().to(x.dtype).contiguous()
+        out = _bmm_nn_raw(x3, wc, x.dtype, bias.detach().float().contiguous(), 3, alpha, scale)
+        ctx.save_for_backward(x3, wc, out)
+        ctx.cfg = (shp, w.shape[0] == 1, alpha, scale, bias.numel())
+        return out.reshape(*shp[:-1], w.shape[1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x3, wc, out = ctx.saved_tensors
+        shp, shared, alpha, scale, size_b = ctx.cfg
+        gpre, gb = _BiasActBackward.apply(gy.contiguous().reshape(out.shape), out, True, alpha, scale, 1, size_b)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _bmm_nn_raw(gpre, wc.transpose(1, 2).contiguous(), x3.dtype).reshape(shp)
+        if ctx.needs_input_grad[1]:
+            if shared:
+                gw = _bmm_tn_raw(gpre.reshape(1, -1, gpre.shape[2]), x3.reshape(1, -1, x3.shape[2]))
+            else:
+                gw = _bmm_tn_raw(gpre, x3)
+        return gx, gw, gb, None, None
+
+
+def mod_gemm_act(x, w, bias, alpha=0.2, scale=math.sqrt(2.0)):
+    return _ModGemmAct.apply(x, w, bias, float(alpha), float(scale))
+
+
 # ---------------------------------------------------------------------------------------
 # ring-padded dense convolution triple (reference: ops.Conv2d, common.py:187-210)
 # ---------------------------------------------------------------------------------------
@@ -300,14 +379,14 @@ class ConvGeom:
         return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
 
 
-def _conv_fwd_raw(x, w, g):
+def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0):
     B, H, W, C = x.shape
     O = w.shape[0]
     Ho, Wo = g.out_hw(H, W)
-    N.check(x, w)
+    N.check(x, w, bias)
     y = torch.empty((B, Ho, Wo, O), device=x.device, dtype=x.dtype)
     N.call("dgv2_conv_fwd", N.ptr(y), N.ptr(x), N.ptr(w), B, H, W, C, O, g.kh, g.kw, g.stride, g.pad, g.ring,
-           _dt(x), N.stream())
+           N.ptr(bias), act, alpha, scale, _dt(x), N.stream())
     return y
 
 
@@ -389,6 +468,33 @@ class _ConvWgrad(Function):
 def conv_ring(x, w, geom):
     """x [B,H,W,C]; w fp32 master in channels-last filter layout [O,kh,kw,C]."""
     return _ConvFwd.apply(x, w, geom)
+
+
+class _ConvAct(Function):
+    """lrelu(conv(x, w) + b) * scale, bias/activation fused into the conv epilogue; the backward is
+    composed of differentiable Functions so R1's double backward stays on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, alpha, scale):
+        x = x.contiguous()
+        wc = w.detach().to(x.dtype).contiguous()
+        out = _conv_fwd_raw(x, wc, g, bias.detach().float().contiguous(), 3, alpha, scale)
+        ctx.save_for_backward(x, w, out)
+        ctx.cfg = (g, alpha, scale, bias.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, out = ctx.saved_tensors
+        g, alpha, scale, size_b = ctx.cfg
+        gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
+        gx = _ConvDgrad.apply(gpre, w, g, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gpre, x, g) if ctx.needs_input_grad[1] else None
+        return gx, gw, gb, None, None, None
+
+
+def conv_ring_act(x, w, bias, geom, alpha=0.2, scale=math.sqrt(2.0)):
+    return _ConvAct.apply(x, w, bias, geom, float(alpha), float(scale))
 
 
 # ---------------------------------------------------------------------------------------

@@ -50,15 +50,18 @@ class ModConv2d(nn.Module):
             wb = wb / (torch.sqrt(self.ema_var) + 1e-8).detach().clone()
         return wb
 
-    def forward_cl(self, x, w_latent, out_dtype=None):
+    def forward_cl(self, x, w_latent, out_dtype=None, act=None):
+        """act: a FusedLeakyReLU module whose bias + leaky-ReLU is fused into the GEMM epilogue."""
         sumsq = native.sum_squares(x) if (self.ema and self.training) else None
         wb = self.sample_weights(w_latent, sumsq, x.numel())
+        if act is not None and self.bias is None and self.gain == 1.0 and act.bias is not None:
+            return native.mod_gemm_act(x, wb, act.bias, act.negative_slope, act.scale)
         y = native.mod_gemm(x, wb, out_dtype)
         if self.bias is not None:
             y = y + self.bias.reshape(1, 1, 1, -1).to(y.dtype)
         if self.gain != 1.0:
             y = y * self.gain
-        return y
+        return y if act is None else act.forward_cl(y)
 
     def forward(self, x, style):
         return from_cl(self.forward_cl(to_cl(x), style))

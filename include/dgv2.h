@@ -84,6 +84,15 @@ int dgv2_resample(void* y, const void* x, const float* taps_h, const float* taps
                   int kw, int up_w, int down_w, int p0_w,
                   int ring, int adjoint, int dtype, void* stream);
 
+/* Table-driven form of the same operator (the hot-path entry): per axis the sparse rows of the
+ * resampling matrix, built once on the host per (spec, size, direction): idx/coef [n_out, E]
+ * row-major, cnt [n_out] valid entries per row.  y[b,ho,wo,:] = sum_a sum_c coef_h[ho,a] *
+ * coef_w[wo,c] * x[b, idx_h[ho,a], idx_w[wo,c], :].  Same reference lines as dgv2_resample. */
+int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const float* coef_h, const int* cnt_h,
+                      int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew,
+                      int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
+                      int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Fourier features (positional encoding of the laser angles)
  * replaces: FourierFeature.forward, gans/models/ops/fourier.py:77-82
@@ -112,9 +121,13 @@ int dgv2_downsample_angle(float* out, const float* in, const float* shift, const
  * x [B,P,ldx] (first I channels used), w [B,O,I], y [B,P,ldy] (first O written).
  * wstride = element stride between samples of w (0 = one weight shared by the batch).
  * ydtype = dtype of y (DGV2_F32 allowed with bf16 inputs: the heads stay fp32, dusty_v2.py:174-178).
+ * Fused epilogue (nn only): y = act(y + bias[o]) with bias fp32 [O] or NULL, act 0 = none /
+ * 3 = leaky-ReLU(alpha) * scale -- the FusedLeakyReLU that follows each trunk conv
+ * (fused_bias_act_kernel.cu:19-65), saving one pass over the activation.
  * ------------------------------------------------------------------------- */
 int dgv2_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O,
-                int ldx, int ldy, int64_t wstride, int dtype, int ydtype, void* stream);
+                int ldx, int ldy, int64_t wstride, const float* bias, int act, float alpha, float scale,
+                int dtype, int ydtype, void* stream);
 int dgv2_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I, int O,
                 int ldgy, int ldx, int dtype, void* stream);
 
@@ -128,13 +141,15 @@ int dgv2_sum_squares(float* acc, const void* x, int64_t N, int C, int ld, int dt
  *   gans/models/ops/common.py:10-24,187-210, used at gans/models/dusty_v2.py:325-385
  * x [B,H,W,C]; w [O,kh,kw,C] (channels-last filter); y [B,Ho,Wo,O];
  * pad on every side, Ho = (H + 2*pad - kh)/stride + 1.
- *   fwd  : y  = conv(pad(x), w)
+ *   fwd  : y  = conv(pad(x), w), optionally followed by the fused bias + leaky-ReLU epilogue
+ *          (bias fp32 [O] or NULL, act 0 / 3, alpha, scale) as in dgv2_bmm_nn
  *   dgrad: gx = pad^T(conv^T(gy, w))         (gx [B,H,W,C]; wt = w transposed to [C,kh,kw,O];
  *          gxp_scratch [B,H+2pad,W+2pad,C] holds the padded-domain gradient, NULL if pad == 0)
  *   wgrad: gw[o,ky,kx,c] = sum gy * pad(x)   (fp32 [O,kh,kw,C], overwritten)
  * ------------------------------------------------------------------------- */
 int dgv2_conv_fwd(void* y, const void* x, const void* w, int B, int H, int W, int C, int O,
-                  int kh, int kw, int stride, int pad, int ring, int dtype, void* stream);
+                  int kh, int kw, int stride, int pad, int ring,
+                  const float* bias, int act, float alpha, float scale, int dtype, void* stream);
 int dgv2_conv_dgrad(void* gx, void* gxp_scratch, const void* gy, const void* wt,
                     int B, int H, int W, int C, int O,
                     int kh, int kw, int stride, int pad, int ring, int dtype, void* stream);
