@@ -42,6 +42,41 @@ int launch_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I,
   return 0;
 }
 
+template <typename T, typename TY, int TO>
+int launch_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks, int O,
+                      const float* bias, int act, float alpha, float scale, hipStream_t st) {
+  const int K = Ka + Ks;
+  DenseRowLoader<T> al{(const T*)w, (int64_t)O * K, K, O, K, true};
+  ConcatRowLoader<T> bl{(const T*)xa, (int64_t)P * Ka, Ka, Ka, (const T*)xs, Ks, Ks, P};
+  StoreEpilogue<TY> epi{(TY*)y, (int64_t)P * O, O, O, P, (O % 4 == 0), bias, act, alpha, scale};
+  dim3 grid(B, (O + TO - 1) / TO, (P + 127) / 128);
+  gemm_nn_kernel<T, TO, DenseRowLoader<T>, ConcatRowLoader<T>, StoreEpilogue<TY>, true><<<grid, 256, 0, st>>>(al, bl, epi, K);
+  return 0;
+}
+
+template <typename T, typename TY>
+int dispatch_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks, int O,
+                        const float* bias, int act, float alpha, float scale, hipStream_t st) {
+  if (O <= 16) return launch_bmm_nn_cat<T, TY, 16>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st);
+  if (O <= 32) return launch_bmm_nn_cat<T, TY, 32>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st);
+  if (O <= 64) return launch_bmm_nn_cat<T, TY, 64>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st);
+  return launch_bmm_nn_cat<T, TY, 128>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st);
+}
+
+template <typename T, int TO, int TJ>
+int launch_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, int B, int P, int Ca, int Cs, int O,
+                      int ksplit, hipStream_t st) {
+  constexpr int CE = 16 / sizeof(T);
+  const int J = Ca + Cs;
+  DenseKLoader<T> al{(const T*)gy, (int64_t)P * O, O, O, (O % CE == 0) && aligned16(gy)};
+  ConcatKLoader<T> bl{(const T*)xa, (int64_t)P * Ca, Ca, Ca, (const T*)xs, Cs, Cs};
+  const int64_t klen = (((int64_t)P + ksplit - 1) / ksplit + 31) / 32 * 32;
+  dim3 grid((J + TJ - 1) / TJ, (O + TO - 1) / TO, B * ksplit);
+  gemm_tn_kernel<T, TO, TJ, DenseKLoader<T>, ConcatKLoader<T>><<<grid, 256, 0, st>>>(al, bl, gw, O, J, P, klen, ksplit,
+                                                                                  (int64_t)O * J, J);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int dgv2_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
@@ -77,6 +112,52 @@ extern "C" int dgv2_bmm_tn(float* gw, const void* gy, const void* x, int B, int 
     if (O <= 16) launch_bmm_tn<T, 16, 128>(gw, gy, x, B, P, I, O, ldgy, ldx, ksplit, st);
     else if (O <= 32) launch_bmm_tn<T, 32, 128>(gw, gy, x, B, P, I, O, ldgy, ldx, ksplit, st);
     else launch_bmm_tn<T, 64, 128>(gw, gy, x, B, P, I, O, ldgy, ldx, ksplit, st);
+  });
+  DGV2_RETURN_LAST();
+}
+
+// Level-input conv of the generator with the positional encoding kept batch-shared:
+//   y[b,p,o] = act( sum_{k<Ka} xa[b,p,k] w[b,o,k] + sum_{k<Ks} xs[p,k] w[b,o,Ka+k] + bias[o] )
+// xa = FIR-upsampled previous activation (per sample), xs = PE of the UNSHIFTED angle grid (one copy for
+// the whole batch; the per-sample azimuth shift is a rotation folded into w by the host, see
+// gans/models/dusty_v2.py).  Replaces cat(h, PE) + grouped conv (dusty_v2.py:153-161, style.py:105-118).
+extern "C" int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
+                               int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
+                               void* stream) {
+  if (!y || !xs || !w || (Ka > 0 && !xa) || B <= 0 || P <= 0 || Ka < 0 || Ks <= 0 || O <= 0) return DGV2_EINVAL;
+  if (act != 0 && act != 3) return DGV2_EINVAL;
+  const int ce = dtype == DGV2_BF16 ? 8 : 4;
+  if (Ka % ce || Ks % ce || !aligned16(xs) || (Ka > 0 && !aligned16(xa)) || !aligned16(w) || !aligned16(y))
+    return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DGV2_F32 && ydtype == DGV2_F32)
+    dispatch_bmm_nn_cat<float, float>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st);
+  else if (dtype == DGV2_BF16 && ydtype == DGV2_BF16)
+    dispatch_bmm_nn_cat<bf16_t, bf16_t>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st);
+  else
+    return DGV2_EINVAL;
+  DGV2_RETURN_LAST();
+}
+
+// Weight gradient of the above: gw[b,o,:] = sum_p gy[b,p,o] * [xa[b,p,:] | xs[p,:]]   (fp32 [B,O,Ka+Ks]).
+extern "C" int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, int B, int P, int Ka,
+                               int Ks, int O, int dtype, void* stream) {
+  if (!gw || !gy || !xs || (Ka > 0 && !xa) || B <= 0 || P <= 0 || Ka < 0 || Ks <= 0 || O <= 0) return DGV2_EINVAL;
+  const int ce = dtype == DGV2_BF16 ? 8 : 4;
+  if (Ka % ce || Ks % ce || !aligned16(xs) || (Ka > 0 && !aligned16(xa))) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int J = Ka + Ks;
+  const int tiles = B * ((O + 63) / 64) * ((J + 127) / 128);
+  int ksplit = 1;
+  while (tiles * ksplit < 512 && P / (ksplit * 2) >= 512) ksplit *= 2;
+  if (ksplit > 1) {
+    hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)B * O * J, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  DGV2_DISPATCH_DTYPE(dtype, {
+    if (O <= 16) launch_bmm_tn_cat<T, 16, 128>(gw, gy, xa, xs, B, P, Ka, Ks, O, ksplit, st);
+    else if (O <= 32) launch_bmm_tn_cat<T, 32, 128>(gw, gy, xa, xs, B, P, Ka, Ks, O, ksplit, st);
+    else launch_bmm_tn_cat<T, 64, 128>(gw, gy, xa, xs, B, P, Ka, Ks, O, ksplit, st);
   });
   DGV2_RETURN_LAST();
 }

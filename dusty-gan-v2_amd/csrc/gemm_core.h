@@ -60,6 +60,27 @@ template <typename T> struct DenseRowLoader {
   }
 };
 
+// Two-part K axis for the level-input conv of the generator: k < Ka comes from the per-sample
+// activation `a` [batch][rows][lda]; Ka <= k < Ka+Ks from a batch-SHARED tensor `s` [rows][lds]
+// (the positional encoding of the unshifted angle grid, see gemm.hip).  Ka % CE == 0 required.
+template <typename T> struct ConcatRowLoader {
+  const T* a;
+  int64_t a_batch_stride;
+  int lda, Ka;
+  const T* s;
+  int lds_, Ks;
+  int rows;
+  __device__ __forceinline__ uint4 load(int batch, int row, int kchunk) const {
+    constexpr int CE = 16 / sizeof(T);
+    const int k = kchunk * CE;
+    if (row >= rows) return make_uint4(0, 0, 0, 0);
+    if (k < Ka) return *reinterpret_cast<const uint4*>(a + batch * a_batch_stride + (int64_t)row * lda + k);
+    const int k2 = k - Ka;
+    if (k2 + CE <= Ks) return *reinterpret_cast<const uint4*>(s + (int64_t)row * lds_ + k2);
+    return make_uint4(0, 0, 0, 0);
+  }
+};
+
 struct ConvGeom {
   int B, H, W, C, O, Ho, Wo, kh, kw, stride, pad, ring;
 };
@@ -157,7 +178,7 @@ template <typename T> struct Im2colDgradLoader {
 // ds_read_b128 fragment reads of 16 consecutive rows hit 64 distinct banks.
 // Epilogue functor: epi(batch, m /*first of 4 consecutive channels*/, n /*pixel*/, f32x4 acc).
 // ----------------------------------------------------------------------------------------------
-template <typename T, int TO, class ALoad, class BLoad, class Epi>
+template <typename T, int TO, class ALoad, class BLoad, class Epi, bool BATCH_FAST = false>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(ALoad al, BLoad bl, Epi epi, int K) {
   constexpr int TP = 128;
   constexpr int MF = TO / 16;
@@ -170,9 +191,11 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(ALoad al, BLoad bl, Epi ep
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lc = lane >> 4;
-  const int batch = blockIdx.z;
+  // BATCH_FAST: consecutive blocks are the SAME pixel tile of different samples, so a batch-shared
+  // B operand (ConcatRowLoader) is fetched from HBM once and served from L2 to the other samples.
+  const int batch = BATCH_FAST ? blockIdx.x : blockIdx.z;
   const int m0 = blockIdx.y * TO;
-  const int n0 = blockIdx.x * TP;
+  const int n0 = (BATCH_FAST ? blockIdx.z : blockIdx.x) * TP;
   const int nk = (K + 4 * CE - 1) / (4 * CE);
 
   uint4 ra[ACH], rb[2];
@@ -295,6 +318,25 @@ template <typename T> struct DenseKLoader {
     for (int j = 0; j < CE; ++j)
       if (col + j < cols) v.e[j] = p[j];
     return v.raw;
+  }
+};
+
+// Column-concatenated operand for the TN engine: columns < Ca from the per-sample `a`, the rest from
+// the batch-shared `s` (positional encoding).  Ca % CE == 0 required.
+template <typename T> struct ConcatKLoader {
+  const T* a;
+  int64_t a_batch_stride;
+  int lda, Ca;
+  const T* s;
+  int lds_, Cs;
+  __device__ __forceinline__ uint4 load(int batch, int64_t k, int64_t K, int colchunk) const {
+    constexpr int CE = 16 / sizeof(T);
+    const int col = colchunk * CE;
+    if (k >= K) return make_uint4(0, 0, 0, 0);
+    if (col < Ca) return *reinterpret_cast<const uint4*>(a + batch * a_batch_stride + k * lda + col);
+    const int c2 = col - Ca;
+    if (c2 + CE <= Cs) return *reinterpret_cast<const uint4*>(s + k * lds_ + c2);
+    return make_uint4(0, 0, 0, 0);
   }
 };
 

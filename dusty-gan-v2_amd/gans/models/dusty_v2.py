@@ -125,14 +125,49 @@ class SynthesisBlock(nn.Module):
         B = angle.shape[0] if batch is None else batch
         return native.downsample_angle(angle.float().contiguous(), shift, self.downsample.kernel, B, self.ring)
 
+    def _conv1_shared_pe(self, hin, w_latent, angle, shift, B, dt):
+        """conv1 + bias + lrelu when the whole batch shares one angle grid (the training / sampling
+        case).  The reference encodes angle + shift_b per sample and concatenates 512 PE channels to
+        every sample's activation (dusty_v2.py:267-274,153-159): 90 % of conv1's input bytes.  The
+        azimuth frequencies are integers, so the shift is a per-frequency phase rotation
+            sin(c + d) = sin c cos d + cos c sin d,   cos(c + d) = cos c cos d - sin c sin d,
+        d = f_w * shift_b.  We encode the UNSHIFTED grid once for the batch and rotate the PE columns
+        of the per-sample weights instead: the PE operand is never materialised per sample."""
+        H, W = angle.shape[2:]
+        pe0 = torch.empty((1, H, W, self.pe.out_ch), device=angle.device, dtype=dt)
+        self.pe.encode_into(pe0, 0, angle)
+        hup = None if hin is None else self.resample.forward_cl(hin)
+        cin = 0 if hup is None else hup.shape[3]
+        conv = self.conv1
+        sumsq = None
+        if conv.training:
+            # sum of squares of cat(hup, PE): sin^2 + cos^2 = 1 per frequency pair
+            sumsq = torch.full((), float(self.pe.out_ch // 2) * B * H * W, device=angle.device)
+            if hup is not None:
+                sumsq = sumsq + native.sum_squares(hup)
+        wb = conv.sample_weights(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch))
+        if shift is not None:
+            nf = self.pe.out_ch // 2
+            d = shift[:, None] * self.pe.freqs2[:, 1][None, :]  # [B,F]
+            cd, sd = torch.cos(d)[:, None, :], torch.sin(d)[:, None, :]
+            w_s, w_c = wb[:, :, cin:cin + nf], wb[:, :, cin + nf:]
+            wb = torch.cat([wb[:, :, :cin], w_s * cd - w_c * sd, w_s * sd + w_c * cd], dim=2)
+        act = self.bias_act1
+        return native.mod_gemm_cat_act(hup, pe0, wb, act.bias, act.negative_slope, act.scale)
+
     def forward_cl(self, h, skip, ws, angle, shift, B):
         """h [B,h,w,C] or None; skip fp32 [B,h,w,nheads] or None; ws = 3 style vectors [B,D];
-        angle fp32 [B or 1, 2, H, W] for this level; shift [B] added to the azimuth or None."""
+        angle fp32 [B or 1, 2, H, W] for this level; shift [B]: azimuth shift still to be applied at
+        this level (None if absent or already folded into `angle`)."""
         dt = self.compute_dtype
         spec = None if self.is_first else self.resample.spec
         hin = None if h is None else h.to(dt)
-        x1 = native.up_cat_pe(hin, spec, angle, shift, self.pe.freqs2.contiguous(), self.pe.phase, dt, B)
-        h = self.conv1.forward_cl(x1, ws[0], act=self.bias_act1)
+        vec = 8 if dt == LOW else 4
+        if angle.shape[0] == 1 and (hin is None or hin.shape[3] % vec == 0):
+            h = self._conv1_shared_pe(hin, ws[0], angle, shift, B, dt)
+        else:
+            x1 = native.up_cat_pe(hin, spec, angle, shift, self.pe.freqs2.contiguous(), self.pe.phase, dt, B)
+            h = self.conv1.forward_cl(x1, ws[0], act=self.bias_act1)
         nxt = 1
         if not self.is_first:
             h = self.conv2.forward_cl(h, ws[1], act=self.bias_act2)
@@ -203,13 +238,23 @@ class SynthesisNetwork(nn.Module):
         angle = angle.float().contiguous()
         if angle.shape[0] not in (1, B):
             raise RuntimeError(f"angle batch {angle.shape[0]} does not match style batch {B}")
-        # multi-scale angles, full resolution last; the shift enters at the finest level only
-        pyramid = [(angle, shift)]
-        a, s = angle, shift
-        for layer in self.layers[:0:-1]:
-            a = layer.downsample_angle(a, s, B if s is not None else None)
-            s = None
-            pyramid.insert(0, (a, None))
+        # multi-scale angles, full resolution last
+        if angle.shape[0] == 1:
+            # shared grid: the pyramid is built once from the UNSHIFTED angles and every level applies
+            # the shift as a weight rotation (sin/cos -> FIR -> atan2 commutes with a constant shift)
+            pyramid = [(angle, shift)]
+            a = angle
+            for layer in self.layers[:0:-1]:
+                a = layer.downsample_angle(a, None, None)
+                pyramid.insert(0, (a, shift))
+        else:
+            # per-sample grids: the shift enters at the finest level and is baked into the pyramid
+            pyramid = [(angle, shift)]
+            a, s = angle, shift
+            for layer in self.layers[:0:-1]:
+                a = layer.downsample_angle(a, s, B if s is not None else None)
+                s = None
+                pyramid.insert(0, (a, None))
         h, skip, i = None, None, 0
         for layer, (a, s) in zip(self.layers, pyramid):
             h, skip = layer.forward_cl(h, skip, (ws[:, i], ws[:, i + 1], ws[:, min(i + 2, N - 1)]), a, s, B)

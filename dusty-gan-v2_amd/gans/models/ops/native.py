@@ -368,6 +368,49 @@ def mod_gemm_act(x, w, bias, alpha=0.2, scale=math.sqrt(2.0)):
     return _ModGemmAct.apply(x, w, bias, float(alpha), float(scale))
 
 
+class _ModGemmCatAct(Function):
+    """Level-input conv with a batch-shared positional encoding (dgv2_bmm_nn_cat / dgv2_bmm_tn_cat):
+    out = lrelu([xa | xs] @ w^T + b) * scale, xa [B,H,W,Ka] per sample (or None), xs [1,H,W,Ks] shared."""
+
+    @staticmethod
+    def forward(ctx, xa, xs, w, bias, alpha, scale):
+        B, O = w.shape[0], w.shape[1]
+        _, H, W_, Ks = xs.shape
+        Ka = 0 if xa is None else xa.shape[3]
+        xs = xs.contiguous()
+        xa = None if xa is None else xa.contiguous()
+        wc = w.detach().to(xs.dtype).contiguous()
+        bias32 = bias.detach().float().contiguous()
+        N.check(xa, xs, wc, bias32)
+        out = torch.empty((B, H, W_, O), device=xs.device, dtype=xs.dtype)
+        N.call("dgv2_bmm_nn_cat", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wc), B, H * W_, Ka, Ks, O, N.ptr(bias32),
+               3, alpha, scale, _dt(xs), _dt(xs), N.stream())
+        ctx.save_for_backward(xa, xs, wc, out)
+        ctx.cfg = (alpha, scale, Ka, Ks)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        xa, xs, wc, out = ctx.saved_tensors
+        alpha, scale, Ka, Ks = ctx.cfg
+        B, H, W_, O = out.shape
+        gpre, gb = _BiasActBackward.apply(gy.contiguous(), out, True, alpha, scale, 1, O)
+        gxa = gw = None
+        g3 = gpre.reshape(B, H * W_, O)
+        if xa is not None and ctx.needs_input_grad[0]:
+            wt = wc[:, :, :Ka].transpose(1, 2).contiguous()  # only the activation channels need a data gradient
+            gxa = _bmm_nn_raw(g3, wt, xa.dtype).reshape(xa.shape)
+        if ctx.needs_input_grad[2]:
+            gw = torch.empty((B, O, Ka + Ks), device=out.device, dtype=torch.float32)
+            N.call("dgv2_bmm_tn_cat", N.ptr(gw), N.ptr(g3), N.ptr(xa), N.ptr(xs), B, H * W_, Ka, Ks, O, _dt(xs),
+                   N.stream())
+        return gxa, None, gw, gb, None, None
+
+
+def mod_gemm_cat_act(xa, xs, w, bias, alpha=0.2, scale=math.sqrt(2.0)):
+    return _ModGemmCatAct.apply(xa, xs, w, bias, float(alpha), float(scale))
+
+
 # ---------------------------------------------------------------------------------------
 # ring-padded dense convolution triple (reference: ops.Conv2d, common.py:187-210)
 # ---------------------------------------------------------------------------------------

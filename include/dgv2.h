@@ -131,6 +131,20 @@ int dgv2_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int 
 int dgv2_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I, int O,
                 int ldgy, int ldx, int dtype, void* stream);
 
+/* Level-input conv of the generator with the positional encoding kept BATCH-SHARED:
+ *   y[b,p,o] = act( sum_{k<Ka} xa[b,p,k] w[b,o,k] + sum_{k<Ks} xs[p,k] w[b,o,Ka+k] + bias[o] )
+ * xa [B,P,Ka] = FIR-upsampled previous activation (NULL when Ka = 0), xs [P,Ks] = PE of the
+ * unshifted angle grid, ONE copy for the batch (the per-sample azimuth shift of dusty_v2.py:267-274
+ * is a per-frequency rotation folded into w by the host); w [B,O,Ka+Ks].  Ka, Ks multiples of the
+ * 16-byte vector.  replaces: torch.cat([h, pe]) + ModConv2d contraction + FusedLeakyReLU,
+ *   gans/models/dusty_v2.py:153-162, gans/models/ops/style.py:105-118.
+ * tn: gw[b,o,:] = sum_p gy[b,p,o] * [xa[b,p,:] | xs[p,:]]  (fp32 [B,O,Ka+Ks]). */
+int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
+                    int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
+                    void* stream);
+int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, int B, int P, int Ka, int Ks,
+                    int O, int dtype, void* stream);
+
 /* Sum of squares of the first C channels of x [N, ld] into acc[0] (fp32, ACCUMULATES).
  * replaces: x.pow(2).mean() in ModConv2d.forward (style.py:100-101). */
 int dgv2_sum_squares(float* acc, const void* x, int64_t N, int C, int ld, int dtype, void* stream);
