@@ -392,8 +392,8 @@ class Discriminator(nn.Module):
         # two Linear layers stay fp32.  See DESIGN.md section 4.
         edt = LOW if self.num_fp16_layers == -1 else torch.float32
         cin = x.shape[3] + mb.features
-        vec = 8 if edt == LOW else 4
-        cpad = (cin + vec - 1) // vec * vec  # 16-byte channel vectors for the implicit GEMM
+        vec = 32 if edt == LOW else 16
+        cpad = (cin + vec - 1) // vec * vec  # whole 64-byte K-steps for the direct conv engine
         x = mb.forward_cl(x, pad_to=cpad)
         x = conv.forward_cl(x.to(edt), pad_in_to=cpad, act=act1).float()
         x = ops.from_cl(x).flatten(1)  # NCHW flatten order of the reference's nn.Flatten

@@ -422,15 +422,82 @@ class ConvGeom:
         return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
 
 
+import ctypes as _ct
+
+
+def _kstep(t):
+    return 32 if t.dtype == torch.bfloat16 else 16
+
+
+def _conv_taps(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, ooff, taps, hzero, accumulate=False,
+               bias=None, act=0, alpha=0.2, scale=1.0):
+    """Direct halo-tile conv with a tap list (dgv2_conv_taps).  x [B,Hin,Win,Cin]; w3 [O,wtaps,Cin];
+    y [B,Hy,Wy,O]; taps: list of (dy, dx, widx)."""
+    B, Hin, Win, Cin = x.shape
+    O, wtaps, _ = w3.shape
+    _, Hy, Wy, _ = y.shape
+    arr = (_ct.c_int * (3 * len(taps)))(*[v for t in taps for v in t])
+    N.call("dgv2_conv_taps", N.ptr(y), N.ptr(x), N.ptr(w3), B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy, in_stride,
+           ioff[0], ioff[1], out_stride, ooff[0], ooff[1], len(taps), wtaps, arr, int(hzero), 1, int(accumulate),
+           N.ptr(bias), act, alpha, scale, _dt(x), N.stream())
+
+
+def _direct_ok(g, cin):
+    """The direct engine handles the discriminator's geometries: ring padding, 3x3/pad 1 or 1x1/pad 0,
+    stride 1 or 2, input channels a multiple of the K-step."""
+    return bool(g.ring) and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2) and cin
+
+
 def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0):
     B, H, W, C = x.shape
     O = w.shape[0]
     Ho, Wo = g.out_hw(H, W)
     N.check(x, w, bias)
     y = torch.empty((B, Ho, Wo, O), device=x.device, dtype=x.dtype)
+    if _direct_ok(g, C % _kstep(x) == 0):
+        taps = [(ky - g.pad, kx - g.pad, ky * g.kw + kx) for ky in range(g.kh) for kx in range(g.kw)]
+        _conv_taps(y, x, w.reshape(O, g.kh * g.kw, C), Ho, Wo, g.stride, (0, 0), 1, (0, 0), taps, False,
+                   bias=bias, act=act, alpha=alpha, scale=scale)
+        return y
     N.call("dgv2_conv_fwd", N.ptr(y), N.ptr(x), N.ptr(w), B, H, W, C, O, g.kh, g.kw, g.stride, g.pad, g.ring,
            N.ptr(bias), act, alpha, scale, _dt(x), N.stream())
     return y
+
+
+def _axis_taps_s2(parity):
+    """Stride-2, pad-1, 3-tap transpose along one axis for output parity `parity`:
+    list of (offset into gy, kernel index)."""
+    return [(0, 1)] if parity == 0 else [(1, 0), (0, 2)]
+
+
+def _conv_dgrad_direct(gy, wt3, g, xshape):
+    """Data gradient on the direct engine: gy [B,Ho,Wo,O], wt3 [C,kh*kw,O] -> gx [B,H,W,C].
+    Circular W padding transposes to a wrap of the gy coordinate; the replicate rows of the H padding
+    add one-row border terms (accumulate launches)."""
+    B, H, W, C = xshape
+    gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
+    k = g.kh
+    if k == 1:
+        _conv_taps(gx, gy, wt3, H, W, 1, (0, 0), 1, (0, 0), [(0, 0, 0)], True)
+        return gx
+    if g.stride == 1:
+        taps = [(1 - ky, 1 - kx, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+        _conv_taps(gx, gy, wt3, H, W, 1, (0, 0), 1, (0, 0), taps, True)
+        # replicate-padding rows: padded row -1 (-> h = 0) is read by ky = 0 of output row 0,
+        # padded row H (-> h = H-1) by ky = 2 of output row H-1
+        _conv_taps(gx, gy, wt3, 1, W, 1, (0, 0), 1, (0, 0), [(0, 1 - kx, kx) for kx in range(3)], True, True)
+        _conv_taps(gx, gy, wt3, 1, W, 1, (H - 1, 0), 1, (H - 1, 0), [(0, 1 - kx, 6 + kx) for kx in range(3)], True,
+                   True)
+        return gx
+    # stride 2: one launch per output parity class, only the taps that class can see
+    for ph in (0, 1):
+        for pw in (0, 1):
+            taps = [(dy, dx, ky * 3 + kx) for dy, ky in _axis_taps_s2(ph) for dx, kx in _axis_taps_s2(pw)]
+            _conv_taps(gx, gy, wt3, H // 2, W // 2, 1, (0, 0), 2, (ph, pw), taps, True)
+    for pw in (0, 1):  # padded row -1 (-> h = 0) is read by ky = 0 of output row 0
+        taps = [(0, dx, kx) for dx, kx in _axis_taps_s2(pw)]
+        _conv_taps(gx, gy, wt3, 1, W // 2, 1, (0, 0), 2, (0, pw), taps, True, True)
+    return gx
 
 
 def _conv_dgrad_raw(gy, w, g, xshape):
@@ -438,6 +505,9 @@ def _conv_dgrad_raw(gy, w, g, xshape):
     O = w.shape[0]
     wt = w.permute(3, 1, 2, 0).contiguous()
     N.check(gy, wt)
+    even = g.stride == 1 or (H % 2 == 0 and W % 2 == 0)
+    if _direct_ok(g, O % _kstep(gy) == 0) and even and not (g.kh == 1 and g.stride == 2):
+        return _conv_dgrad_direct(gy, wt.reshape(C, g.kh * g.kw, O), g, xshape)
     gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
     scratch = None
     if g.pad > 0:

@@ -170,6 +170,23 @@ int dgv2_conv_dgrad(void* gx, void* gxp_scratch, const void* gy, const void* wt,
 int dgv2_conv_wgrad(float* gw, const void* gy, const void* x, int B, int H, int W, int C, int O,
                     int kh, int kw, int stride, int pad, int ring, int dtype, void* stream);
 
+/* Direct (LDS halo-tile) convolution with a generic tap list -- the hot-path engine for the
+ * discriminator convs and their data gradients (same reference lines as dgv2_conv_*):
+ *   y[b, gh*out_stride+ooff_h, gw*out_stride+ooff_w, o] (=|+=) act( sum_t sum_c
+ *       x[b, H(gh*in_stride+ioff_h+dy_t), W(gw*in_stride+ioff_w+dx_t), c] * w[o, widx_t, c] + bias[o] )
+ * for gh < Hg, gw < Wg.  x [B,Hin,Win,Cin], w [O,wtaps,Cin], y [B,Hy,Wy,O].
+ * taps_host: HOST pointer to ntaps (<= 9) triples (dy, dx, widx).  H(): clamp (hzero = 0, replicate
+ * padding) or zero outside [0,Hin) (hzero = 1, gradients); W(): wrap (ring = 1) or clamp.
+ * forward conv: taps (ky-pad, kx-pad), in_stride = stride; stride-1 dgrad: taps (1-ky, 1-kx) on gy
+ * with transposed weights; stride-2 dgrad: one launch per output parity class (out_stride = 2);
+ * replicate-row border terms: one-row launches with accumulate = 1.
+ * Cin must be a multiple of 32 (bf16) / 16 (fp32). */
+int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int Hin, int Win, int Cin,
+                   int Hg, int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w,
+                   int out_stride, int ooff_h, int ooff_w, int ntaps, int wtaps, const int* taps_host,
+                   int hzero, int ring, int accumulate, const float* bias, int act, float alpha,
+                   float scale, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------
  * generator output stage: cancel the azimuth shift (circular bilinear shift),
  * scale, tanh, Gumbel-sigmoid ray-drop mask, blend.

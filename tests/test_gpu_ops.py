@@ -204,6 +204,12 @@ CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     (3, 6, 10, 2, 32, 1, 1, 0, True),
     (2, 4, 8, 20, 40, 3, 1, 1, False),
     (1, 64, 32, 32, 32, 3, 1, 1, True),
+    # direct halo-tile engine (C multiple of the K-step): partial tiles, odd O, both strides, 1x1
+    (2, 8, 40, 32, 24, 3, 1, 1, True),
+    (2, 8, 40, 32, 48, 3, 2, 1, True),
+    (1, 6, 36, 64, 32, 1, 1, 0, True),
+    (2, 4, 32, 64, 16, 3, 2, 1, True),
+    (1, 10, 70, 32, 130, 3, 1, 1, True),
 ]
 
 
