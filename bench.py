@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--ada-p", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
     ap.add_argument("--cpu-batch", type=int, default=4)
     return ap.parse_args()
 
@@ -58,6 +59,7 @@ def make_cfg(args, rank, world):
     cfg.training.augment.p_init = args.ada_p
     cfg.training.warmup.fade_kimg = 0  # post-fade regime: no warm-up dropout / blur
     cfg.training.resume = None
+    cfg.training.hip_graph = not args.no_graph
     return cfg
 
 
@@ -152,9 +154,10 @@ def main():
         torch.cuda.synchronize()
 
     # warm-up: first call uses iteration 16 so that the lazy-R1 and ADA-update paths are also warm
+    # (with hipGraphs every body needs 2 eager runs + 1 capture before it replays)
     it = 16
-    for _ in range(max(args.warmup, 1)):
-        trainer.step(it)
+    for _ in range(max(args.warmup, 1) + (3 if cfg.training.hip_graph else 0)):
+        trainer.step(16 if cfg.training.hip_graph else it)
         it += 1
     it = 1
     barrier()
@@ -182,7 +185,7 @@ def main():
             "config": {"workload": "configs[2]: configs/gans/dusty_v2.yaml full G+D train step "
                                    "(G step + D step + lazy R1/16 + ADA + EMA + Adam), 64x512 synthetic",
                        "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
-                       "parallelism": f"dp{world}", "ada_p": args.ada_p, "hip_graph": False},
+                       "parallelism": f"dp{world}", "ada_p": args.ada_p, "hip_graph": not args.no_graph},
             "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3,
             "roofline": roof,
         }

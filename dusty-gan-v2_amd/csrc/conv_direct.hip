@@ -210,8 +210,7 @@ extern "C" int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int 
   DGV2_DISPATCH_DTYPE(dtype, {
     if (O <= 16) rc = launch_direct<T, 16>(y, x, w, p, st);
     else if (O <= 32) rc = launch_direct<T, 32>(y, x, w, p, st);
-    else if (O <= 64) rc = launch_direct<T, 64>(y, x, w, p, st);
-    else rc = launch_direct<T, 128>(y, x, w, p, st);
+    else rc = launch_direct<T, 64>(y, x, w, p, st);  // TO = 64 keeps LDS <= 50 KB: 3 blocks/CU hide the staging latency
   });
   if (rc) return rc;
   DGV2_RETURN_LAST();

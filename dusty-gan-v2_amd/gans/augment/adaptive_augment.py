@@ -174,10 +174,9 @@ class AdaptiveAugment(torch.nn.Module):
     def sample_color(self, size, device="cpu"):
         """Same distribution as the reference's sample_color (:428-469); returns C [B,4,4]."""
         dev = device
-        eye = torch.eye(4, device=dev)[None].repeat(size, 1, 1)
+        v, vv, cross, eye3, eye4 = self._color_consts(dev)
+        eye = eye4[None].repeat(size, 1, 1)
         C = eye
-        v = torch.tensor([1.0, 1.0, 1.0, 0.0], device=dev) / math.sqrt(3)
-        vv = torch.outer(v, v)
 
         def apply(key, Cc):
             nonlocal C
@@ -200,8 +199,7 @@ class AdaptiveAugment(torch.nn.Module):
         if self.mul["hue"] > 0:
             th = (torch.rand(size, device=dev) * 2 - 1) * math.pi
             u = v[:3]
-            cross = torch.tensor([[0, -1, 1], [1, 0, -1], [-1, 1, 0]], device=dev, dtype=torch.float32) / math.sqrt(3)
-            rot = (torch.cos(th).view(-1, 1, 1) * torch.eye(3, device=dev) + torch.sin(th).view(-1, 1, 1) * cross
+            rot = (torch.cos(th).view(-1, 1, 1) * eye3 + torch.sin(th).view(-1, 1, 1) * cross
                    + (1 - torch.cos(th)).view(-1, 1, 1) * torch.outer(u, u))
             Cc = eye.clone()
             Cc[:, :3, :3] = rot
@@ -217,39 +215,44 @@ class AdaptiveAugment(torch.nn.Module):
         if key not in self._chain:
             M1y, Dy = _axis_chain_matrices(H, H - 1, "reflect")
             M1x, Dx = _axis_chain_matrices(W, W - 1, "circular")
-            self._chain[key] = tuple(t.to(device) for t in (M1y, Dy, M1x, Dx))
+            self._chain[key] = tuple(t.to(device) for t in (M1y, Dy, M1x, Dx, torch.tensor(SYM6)))
+        return self._chain[key]
+
+    def _color_consts(self, device):
+        key = ("color", str(device))
+        if key not in self._chain:
+            v = torch.tensor([1.0, 1.0, 1.0, 0.0]) / math.sqrt(3)
+            cross = torch.tensor([[0.0, -1, 1], [1, 0, -1], [-1, 1, 0]]) / math.sqrt(3)
+            self._chain[key] = tuple(t.to(device) for t in (v, torch.outer(v, v), cross, torch.eye(3), torch.eye(4)))
         return self._chain[key]
 
     @staticmethod
     def _sample_positions(G, H, W):
         """Source positions (in the padded, 2x upsampled image) of every grid_sample output row /
-        column: the affine_grid + unnormalisation of adaptive_augment.py:488-523 restricted to
-        one axis (the transform is diagonal).  Returns pos_y [B,2(H+6)], pos_x [B,2(W+6)]."""
-        B = G.shape[0]
+        column: the affine_grid + unnormalisation of adaptive_augment.py:488-523 restricted to one
+        axis (the transform is diagonal), written in closed form per axis:
+            G_inv: u -> a u + t, a = 1/s, t = -trans/s
+            S(2) . S(1/2) conjugation, T(-1/2) . T(1/2) conjugation, normalisation by in / out sizes.
+        No solver call and no host constants: capturable in a hipGraph.
+        Returns pos_y [B,2(H+6)], pos_x [B,2(W+6)]."""
         dev = G.device
         pad_k = len(SYM6) // 4
 
-        def S(sx, sy):
-            return torch.tensor([[sx, 0, 0], [0, sy, 0], [0, 0, 1.0]], device=dev)
-
-        def T(tx, ty):
-            return torch.tensor([[1.0, 0, tx], [0, 1.0, ty], [0, 0, 1.0]], device=dev)
+        def axis(s, trans, n_in, n_out):
+            a, t = 1.0 / s, -trans / s
+            A = a * (n_out / n_in)
+            Bc = (2.0 / n_in) * (0.5 * a + 2.0 * t - 0.5)
+            xn = (2 * torch.arange(n_out, device=dev, dtype=torch.float32) + 1) / n_out - 1
+            xs = A[:, None] * xn[None] + Bc[:, None]
+            return ((xs + 1) * n_in - 1) / 2
 
         in_h, in_w = (H + 2 * (H - 1)) * 2, (W + 2 * (W - 1)) * 2
         out_h, out_w = (H + pad_k * 2) * 2, (W + pad_k * 2) * 2
-        Gi = torch.inverse(G)
-        Gi = S(2, 2) @ Gi @ S(0.5, 0.5)
-        Gi = T(-0.5, -0.5) @ Gi @ T(0.5, 0.5)
-        Gi = S(2 / in_w, 2 / in_h) @ Gi @ S(out_w / 2, out_h / 2)
-        xn = (2 * torch.arange(out_w, device=dev, dtype=torch.float32) + 1) / out_w - 1
-        yn = (2 * torch.arange(out_h, device=dev, dtype=torch.float32) + 1) / out_h - 1
-        xs = Gi[:, 0, 0, None] * xn[None] + Gi[:, 0, 2, None]
-        ys = Gi[:, 1, 1, None] * yn[None] + Gi[:, 1, 2, None]
-        return ((ys + 1) * in_h - 1) / 2, ((xs + 1) * in_w - 1) / 2
+        return axis(G[:, 1, 1], G[:, 1, 2], in_h, out_h), axis(G[:, 0, 0], G[:, 0, 2], in_w, out_w)
 
     def build_operators(self, G, H, W):
         """G [B,3,3] (axis aligned) -> Ay [B,H,H], kx [B,KTAPS], off [B] int32, sgn [B] int32."""
-        M1y, Dy, M1x, Dx = self._chain_consts(H, W, G.device)
+        M1y, Dy, M1x, Dx, taps = self._chain_consts(H, W, G.device)
         pos_y, pos_x = self._sample_positions(G.float(), H, W)
         B = G.shape[0]
         # rows: dense.  S[q, m] = hat(pos(q) - m) is linear interpolation with zero padding.
@@ -261,7 +264,6 @@ class AdaptiveAugment(torch.nn.Module):
         q = 2 * j_ref + 1 + torch.arange(len(SYM6), device=G.device)
         grid_x = torch.arange(M1x.shape[0], device=G.device, dtype=torch.float32)
         Sx = torch.relu(1 - (pos_x[:, q, None] - grid_x[None, None, :]).abs())  # [B,12,2Lp]
-        taps = torch.tensor(SYM6, device=G.device)
         row = torch.einsum("i,bim->bm", taps, Sx @ M1x[None])  # Ax[j_ref, :]  [B,W]
         sgn = torch.where(G[:, 0, 0] < 0, -1, 1).to(torch.int32)
         # kappa[d] = Ax[j_ref, (d + sgn*j_ref) mod W]; keep KTAPS taps centred on the peak

@@ -11,6 +11,14 @@ class RayDropModel(nn.Module):
         super().__init__()
         self.gumbel_sigmoid = ops.GumbelSigmoid(temperature=gumbel_temperature, straight_through=True)
         self.register_buffer("raydrop_const", torch.tensor(float(raydrop_const)))
+        # host copy for kernel arguments (reading the buffer would be a device->host sync, which also
+        # breaks hipGraph capture); refreshed whenever a state dict is loaded
+        self.const_host = float(raydrop_const)
+        self.register_load_state_dict_post_hook(self._refresh_const)
+
+    @staticmethod
+    def _refresh_const(module, incompatible_keys):
+        module.const_host = float(module.raydrop_const)
 
     def forward(self, h):
         assert isinstance(h, dict) and ("image" in h) and ("raydrop_logit" in h)

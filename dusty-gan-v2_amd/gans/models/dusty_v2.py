@@ -302,7 +302,7 @@ class Generator(base.Generator):
         u = noise.get("gumbel_u")
         u = native.gumbel_uniform((B, 1, H, W), skip.device) if u is None else u.float().contiguous()
         image, image_orig, logit, mask = native.gen_tail(
-            skip, shift, u, self.synthesis_network.output_scale, float(mm.raydrop_const),
+            skip, shift, u, self.synthesis_network.output_scale, mm.const_host,
             mm.gumbel_sigmoid.temperature)
         return {"image": image, "raydrop_logit": logit, "w": w, "raydrop_mask": mask, "image_orig": image_orig}
 

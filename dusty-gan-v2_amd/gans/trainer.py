@@ -98,10 +98,16 @@ class Trainer:
             raise NotImplementedError("path-length regularisation is disabled in dusty_v2.yaml (loss.pl: 0) and "
                                       "its reference block is broken (SURVEY.md section 3B.4)")
         lg, ld = cfg.training.lr.generator, cfg.training.lr.discriminator
-        self.optim_G = optim.Adam(self.G.parameters(), lr=lg.alpha * ratio_G,
+        # hipGraph replay of the step bodies (training.hip_graph: true); Adam must then keep its step
+        # counters on the device
+        self.use_graphs = bool(cfg.training.get("hip_graph", False))
+        self._graphs, self._graph_warm = {}, {}
+        self._graph_pool = torch.cuda.graph_pool_handle() if self.use_graphs else None
+        self.optim_G = optim.Adam(self.G.parameters(), lr=lg.alpha * ratio_G, capturable=self.use_graphs,
                                   betas=(float(lg.beta1) ** ratio_G, float(lg.beta2) ** ratio_G))
-        self.optim_D = optim.Adam(self.D.parameters(), lr=ld.alpha * ratio_D,
+        self.optim_D = optim.Adam(self.D.parameters(), lr=ld.alpha * ratio_D, capturable=self.use_graphs,
                                   betas=(float(ld.beta1) ** ratio_D, float(ld.beta2) ** ratio_D))
+        self.x_real = torch.empty(self.B, 1, *self.resolution, device=self.device)  # static input of the graphs
 
         # resume
         self.start_iteration = 0
@@ -152,24 +158,23 @@ class Trainer:
         return x
 
     # ------------------------------------------------------------------ sub-steps
-    def g_step(self, scalars):
+    # Each sub-step is split into a forward/backward body (`*_fb`), the gradient all-reduce (eager,
+    # RCCL) and the optimizer body, so that the bodies can be replayed as hipGraphs while the
+    # collectives stay ordinary stream work between them.
+    def g_fb(self, scalars):
         set_requires_grad(self.G, True)
         self.g_sync.zero()
-        parallel.sync_buffers(self.G)
         z = self.sample_z(self.B)
         x_fake = self.G(z, **self.auxin)["image"]
         y_fake = self.D(self.A(self.warmup(x_fake)))
         loss_gan = self.adversarial_loss(None, y_fake, "G")
         (self.cfg.training.loss.gan * loss_gan).backward()
-        self.g_sync.all_reduce()
-        self.optim_G.step()
         set_requires_grad(self.G, False)
         scalars["loss/G/adversarial"] = loss_gan.detach()
 
-    def d_step(self, x_real, scalars):
+    def d_fb(self, x_real, scalars):
         set_requires_grad(self.D, True)
         self.d_sync.zero()
-        parallel.sync_buffers(self.G)
         z = self.sample_z(self.B)
         with torch.no_grad():
             x_fake = self.G(z, **self.auxin)["image"]
@@ -180,14 +185,13 @@ class Trainer:
         self.A.cumulate(y_real)
         loss_gan = self.adversarial_loss(y_real, y_fake, "D")
         (self.cfg.training.loss.gan * loss_gan).backward()
-        self.d_sync.all_reduce()
-        self.optim_D.step()
         scalars["loss/D/output/real"] = y_real.mean().detach()
         scalars["loss/D/output/fake"] = y_fake.mean().detach()
         scalars["loss/D/adversarial"] = loss_gan.detach()
 
-    def r1_step(self, x_real, scalars):
+    def r1_fb(self, x_real, scalars):
         """lazy R1 (reference: trainer.py:419-451): double backward through D and ADA."""
+        set_requires_grad(self.D, True)
         self.d_sync.zero()
         x = x_real.detach().requires_grad_(True)
         y_real = self.D(self.A(self.warmup(x)))
@@ -195,8 +199,6 @@ class Trainer:
         r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
         loss = (self.gp_weight / 2) * r1 + 0.0 * y_real.squeeze()[0]
         loss.backward()
-        self.d_sync.all_reduce()
-        self.optim_D.step()
         scalars["loss/D/gradient_penalty"] = r1.detach()
 
     def ema_decay(self, iteration):
@@ -205,17 +207,55 @@ class Trainer:
             ema_imgs = min(ema_imgs, iteration * self.batch_size * self.cfg.training.ema_rampup)
         return 0.5 ** (self.batch_size / max(ema_imgs, 1e-8))
 
+    # ------------------------------------------------------------------ hipGraph plumbing
+    def _graphs_usable(self):
+        # host-scheduled warm-up (blur / dropout ratios change every iteration) runs eagerly
+        return self.use_graphs and self.blur_sigma == 0 and self.dropout_ratio == 0
+
+    def _run(self, name, fn, *args):
+        """Run `fn(*args, scalars)` eagerly, or capture it once as a hipGraph and replay it.
+        Returns the dict of scalar tensors the body produced (static buffers under replay)."""
+        if not self._graphs_usable():
+            scalars = {}
+            fn(*args, scalars)
+            return scalars
+        if name not in self._graphs:
+            if self._graph_warm.get(name, 0) < 2:  # allocator / autotune warm-up before capture
+                self._graph_warm[name] = self._graph_warm.get(name, 0) + 1
+                scalars = {}
+                fn(*args, scalars)
+                return scalars
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            scalars = {}
+            with torch.cuda.graph(g, pool=self._graph_pool):
+                fn(*args, scalars)
+            self._graphs[name] = (g, scalars)
+        g, scalars = self._graphs[name]
+        g.replay()
+        return scalars
+
     # ------------------------------------------------------------------ one iteration
     def step(self, iteration):
         self.G.train()
         self.set_warmup_params(iteration)
         scalars = {}
-        x_real = self.fetch_reals(next(self.iter_train_loader))["image"]
+        self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
 
-        self.g_step(scalars)
-        self.d_step(x_real, scalars)
+        parallel.sync_buffers(self.G)
+        scalars.update(self._run("g_fb", self.g_fb))
+        self.g_sync.all_reduce()
+        self._run("g_opt", lambda sc: self.optim_G.step())
+
+        parallel.sync_buffers(self.G)
+        scalars.update(self._run("d_fb", self.d_fb, self.x_real))
+        self.d_sync.all_reduce()
+        self._run("d_opt", lambda sc: self.optim_D.step())
+
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
-            self.r1_step(x_real, scalars)
+            scalars.update(self._run("r1_fb", self.r1_fb, self.x_real))
+            self.d_sync.all_reduce()
+            self._run("d_opt", lambda sc: self.optim_D.step())
         set_requires_grad(self.D, False)
 
         decay = self.ema_decay(iteration)
