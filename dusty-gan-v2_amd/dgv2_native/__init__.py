@@ -37,6 +37,8 @@ SIGNATURES = {
     "dgv2_bmm_tn": [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr],
     "dgv2_bmm_nn_cat": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr],
     "dgv2_bmm_tn_cat": [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr],
+    "dgv2_mod_prep_fwd": [_c_ptr] * 8 + [_c_int] * 9 + [_c_ptr],
+    "dgv2_mod_prep_bwd": [_c_ptr] * 11 + [_c_int] * 8 + [_c_ptr],
     "dgv2_sum_squares": [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_ptr],
     "dgv2_conv_fwd": [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_conv_taps": [_c_ptr] * 3 + [_c_int] * 17 + [_c_ptr] + [_c_int] * 3 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int,

@@ -62,15 +62,10 @@ class Head(nn.Module):
 
     def forward_cl(self, x, style):
         """x [B,H,W,C] -> fp32 [B,H,W,sum(ch)] (heads concatenated in dict order)."""
-        training = self.training
-        sumsq = native.sum_squares(x) if training else None
-        wbs, biases = [], []
-        for head in self.heads.values():
-            wbs.append(head.sample_weights(style, sumsq, x.numel()))
-            biases.append(head.bias.reshape(-1))
-        wb = torch.cat(wbs, dim=1)
-        y = native.mod_gemm(x, wb, torch.float32)
-        return y + torch.cat(biases).reshape(1, 1, 1, -1)
+        sumsq = native.sum_squares(x) if self.training else None
+        mods = [head.prep_args(style, sumsq, x.numel()) for head in self.heads.values()]
+        bias = torch.cat([head.bias.reshape(-1) for head in self.heads.values()])
+        return native.mod_layer(x, None, mods, bias=bias, act=False, out_dtype=torch.float32)
 
     def forward(self, x, style):
         y = ops.from_cl(self.forward_cl(ops.to_cl(x), style))
@@ -145,6 +140,13 @@ class SynthesisBlock(nn.Module):
             sumsq = torch.full((), float(self.pe.out_ch // 2) * B * H * W, device=angle.device)
             if hup is not None:
                 sumsq = sumsq + native.sum_squares(hup)
+        act = self.bias_act1
+        if self.pe.out_ch == 512 and conv.in_ch <= 1024:
+            # weight preparation (+ rotation), contraction, bias and lrelu as one autograd node
+            mods = [conv.prep_args(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch))]
+            fw = self.pe.freqs2[:, 1].contiguous() if shift is not None else None
+            return native.mod_layer(hup, pe0, mods, bias=act.bias, act=True, alpha=act.negative_slope,
+                                    scale=act.scale, shift=shift, fw=fw, cin=cin)
         wb = conv.sample_weights(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch))
         if shift is not None:
             nf = self.pe.out_ch // 2
@@ -152,7 +154,6 @@ class SynthesisBlock(nn.Module):
             cd, sd = torch.cos(d)[:, None, :], torch.sin(d)[:, None, :]
             w_s, w_c = wb[:, :, cin:cin + nf], wb[:, :, cin + nf:]
             wb = torch.cat([wb[:, :, :cin], w_s * cd - w_c * sd, w_s * sd + w_c * cd], dim=2)
-        act = self.bias_act1
         return native.mod_gemm_cat_act(hup, pe0, wb, act.bias, act.negative_slope, act.scale)
 
     def forward_cl(self, h, skip, ws, angle, shift, B):
@@ -170,7 +171,10 @@ class SynthesisBlock(nn.Module):
             h = self.conv1.forward_cl(x1, ws[0], act=self.bias_act1)
         nxt = 1
         if not self.is_first:
-            h = self.conv2.forward_cl(h, ws[1], act=self.bias_act2)
+            a2 = self.bias_act2
+            sumsq = native.sum_squares(h) if self.conv2.training else None
+            h = native.mod_layer(h, None, [self.conv2.prep_args(ws[1], sumsq, h.numel())], bias=a2.bias, act=True,
+                                 alpha=a2.negative_slope, scale=a2.scale)
             nxt = 2
         o = self.head.forward_cl(h, ws[nxt])
         if skip is not None:
@@ -332,10 +336,6 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         return ops.from_cl(self.forward_cl(ops.to_cl(x)))
-
-
-class _ClAdapter(nn.Module):
-    pass
 
 
 class Discriminator(nn.Module):

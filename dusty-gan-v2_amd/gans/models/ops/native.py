@@ -701,3 +701,123 @@ def coords_convert(x, mode, min_depth, max_depth, angle=None, mask=None, raydrop
     N.call("dgv2_coords_convert", N.ptr(out), N.ptr(x), N.ptr(mask), N.ptr(angle), B, H, W, float(min_depth),
            float(max_depth), float(raydrop_const), mode, N.stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# One modulated-conv layer (or the stacked heads of a level) as a SINGLE autograd node:
+# weight preparation (dgv2_mod_prep_fwd) -> MFMA contraction with fused bias / lrelu -> and in backward
+# act-grad, data gradient, weight gradient, preparation backward (dgv2_mod_prep_bwd).
+# reference: ModConv2d.forward + FusedLeakyReLU, gans/models/ops/style.py:68-126, dusty_v2.py:161-170
+# ---------------------------------------------------------------------------------------
+class _ModLayer(Function):
+    @staticmethod
+    def forward(ctx, cfg, xa, xs, bias, shift, fw, *mods):
+        """cfg: dict(act=bool, alpha, scale, out_dtype, demod=[...], cin, F);
+        xa [B,H,W,Ka] per-sample input (or None), xs [1,H,W,Ks] batch-shared PE (or None);
+        bias fp32 [Otot] (or None); mods = (W_0, s_0, ev_0, W_1, s_1, ev_1, ...): weight [O_k,I] fp32,
+        style [B,I] fp32, ema_var scalar (value to use)."""
+        nm = len(mods) // 3
+        Ws = [mods[3 * k].detach().contiguous() for k in range(nm)]
+        Ss = [mods[3 * k + 1].detach().float().contiguous() for k in range(nm)]
+        Es = [mods[3 * k + 2].detach().float().reshape(1).clone() for k in range(nm)]
+        ref = xa if xa is not None else xs
+        dt = ref.dtype
+        B = Ss[0].shape[0]
+        I = Ws[0].shape[1]
+        Os = [w.shape[0] for w in Ws]
+        Otot = sum(Os)
+        H, W_ = ref.shape[1:3]
+        P = H * W_
+        dev = ref.device
+        wb = torch.empty((B, Otot, I), device=dev, dtype=dt)
+        rot = shift is not None and cfg["F"] > 0
+        saved_small = []
+        off = 0
+        for k in range(nm):
+            stats = torch.empty(2 + 2 * B, device=dev, dtype=torch.float32)
+            dsave = torch.empty((B, Os[k]), device=dev, dtype=torch.float32)
+            N.call("dgv2_mod_prep_fwd", N.ptr(wb), N.ptr(dsave), N.ptr(stats), N.ptr(Ws[k]), N.ptr(Ss[k]), N.ptr(Es[k]),
+                   N.ptr(shift) if rot else None, N.ptr(fw) if rot else None, B, Os[k], I, Otot, off,
+                   int(cfg["demod"][k]), cfg["cin"], cfg["F"] if rot else 0, _dt(wb), N.stream())
+            saved_small += [stats, dsave]
+            off += Os[k]
+        act = 3 if cfg["act"] else 0
+        bias32 = None if bias is None else bias.detach().float().contiguous()
+        odt = cfg["out_dtype"]
+        if xs is not None:
+            xs = xs.contiguous()
+            xa = None if xa is None else xa.contiguous()
+            Ka = 0 if xa is None else xa.shape[3]
+            out = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
+            N.check(xa, xs, wb, bias32)
+            N.call("dgv2_bmm_nn_cat", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3], Otot,
+                   N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs), N.stream())
+        else:
+            xa = xa.contiguous()
+            out = _bmm_nn_raw(xa.reshape(B, P, I), wb, odt, bias32, act, cfg["alpha"], cfg["scale"]).reshape(
+                B, H, W_, Otot)
+        ctx.cfg = dict(cfg, Os=Os, I=I, B=B, rot=rot, has_bias=bias is not None)
+        ctx.save_for_backward(xa, xs, wb, out if cfg["act"] else None, shift, fw, *Ws, *Ss, *Es, *saved_small)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        cfg = ctx.cfg
+        Os, I, B, rot = cfg["Os"], cfg["I"], cfg["B"], cfg["rot"]
+        nm = len(Os)
+        sv = ctx.saved_tensors
+        xa, xs, wb, out, shift, fw = sv[:6]
+        Ws, Ss, Es = sv[6:6 + nm], sv[6 + nm:6 + 2 * nm], sv[6 + 2 * nm:6 + 3 * nm]
+        small = sv[6 + 3 * nm:]
+        Otot = sum(Os)
+        dt = wb.dtype
+        gy = gy.contiguous()
+        H, W_ = gy.shape[1:3]
+        P = H * W_
+        gb = None
+        if cfg["act"]:
+            gpre, gb = _BiasActBackward.apply(gy, out, cfg["has_bias"], cfg["alpha"], cfg["scale"], 1, Otot)
+        else:
+            gpre = gy.to(dt)
+            if cfg["has_bias"]:
+                gb = torch.empty(Otot, device=gy.device, dtype=torch.float32)
+                N.call("dgv2_bias_grad", N.ptr(gb), N.ptr(gy), gy.numel(), 1, Otot, _dt(gy), N.stream())
+        g3 = gpre.reshape(B, P, Otot)
+        Ka = 0 if xa is None else xa.shape[3]
+        gxa = None
+        if xa is not None and ctx.needs_input_grad[1]:
+            wt = wb[:, :, :Ka].transpose(1, 2).contiguous()
+            gxa = _bmm_nn_raw(g3, wt, xa.dtype).reshape(xa.shape)
+        gwb = torch.empty((B, Otot, I), device=gy.device, dtype=torch.float32)
+        if xs is not None:
+            N.call("dgv2_bmm_tn_cat", N.ptr(gwb), N.ptr(g3), N.ptr(xa), N.ptr(xs), B, P, Ka, xs.shape[3], Otot,
+                   _dt(xs), N.stream())
+        else:
+            N.call("dgv2_bmm_tn", N.ptr(gwb), N.ptr(g3), N.ptr(xa.reshape(B, P, I)), B, P, I, Otot, Otot, I, _dt(xa),
+                   N.stream())
+        grads = []
+        off = 0
+        for k in range(nm):
+            gW = torch.empty((Os[k], I), device=gy.device, dtype=torch.float32)
+            gs = torch.empty((B, I), device=gy.device, dtype=torch.float32)
+            corr = torch.empty(1, device=gy.device, dtype=torch.float32)
+            N.call("dgv2_mod_prep_bwd", N.ptr(gW), N.ptr(gs), N.ptr(corr), N.ptr(gwb), N.ptr(Ws[k]), N.ptr(Ss[k]),
+                   N.ptr(small[2 * k]), N.ptr(small[2 * k + 1]), N.ptr(Es[k]), N.ptr(shift) if rot else None,
+                   N.ptr(fw) if rot else None, B, Os[k], I, Otot, off, int(cfg["demod"][k]), cfg["cin"],
+                   cfg["F"] if rot else 0, N.stream())
+            grads += [gW, gs, None]
+            off += Os[k]
+        return (None, gxa, None, gb, None, None, *grads)
+
+
+def mod_layer(xa, xs, mods, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=None, shift=None,
+              fw=None, cin=0):
+    """mods: list of (W [O,I] fp32, style [B,I] fp32, ema_var scalar tensor, demod flag)."""
+    ref = xa if xa is not None else xs
+    cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0,
+               out_dtype=ref.dtype if out_dtype is None else out_dtype, demod=[bool(m[3]) for m in mods], cin=int(cin),
+               F=0 if fw is None else int(fw.numel()))
+    flat = []
+    for W, s, ev, _ in mods:
+        flat += [W, s, ev]
+    return _ModLayer.apply(cfg, xa, xs, bias, shift, fw, *flat)

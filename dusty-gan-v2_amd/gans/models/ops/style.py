@@ -50,6 +50,15 @@ class ModConv2d(nn.Module):
             wb = wb / (torch.sqrt(self.ema_var) + 1e-8).detach().clone()
         return wb
 
+    def prep_args(self, w_latent, sumsq=None, count=None):
+        """(weight [O,I], style [B,I], ema_var, demod) for native.mod_layer, which fuses the whole
+        weight preparation; the input-magnitude EMA is updated here first (style.py:98-103)."""
+        style = self.mod(w_latent.float())
+        if self.ema and self.training and sumsq is not None:
+            with torch.no_grad():
+                self.ema_var.lerp_(sumsq / count, 1 - self.ema_decay)
+        return (self.weight[0, :, :, 0, 0], style, self.ema_var, self.demod)
+
     def forward_cl(self, x, w_latent, out_dtype=None, act=None):
         """act: a FusedLeakyReLU module whose bias + leaky-ReLU is fused into the GEMM epilogue."""
         sumsq = native.sum_squares(x) if (self.ema and self.training) else None

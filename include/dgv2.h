@@ -145,6 +145,22 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
 int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, int B, int P, int Ka, int Ks,
                     int O, int dtype, void* stream);
 
+/* Per-sample weights of the modulated conv, written directly as the GEMM operand, and the exact
+ * backward of that preparation (max-normalisations, modulation, demodulation, input-magnitude
+ * scaling, optional rotation of the positional-encoding columns by shift_b * fw).
+ * replaces: ModConv2d.forward weight path, gans/models/ops/style.py:72-103 (and its autograd).
+ * W fp32 [O,I]; s fp32 [B,I] (style after the affine); ema_var fp32 [1]; wb [B,Otot,I] (this layer's
+ * rows at [row_off, row_off+O)), dtype wb_dtype; stats fp32 [2+2B] and dsave fp32 [B,O] are produced
+ * by fwd and consumed by bwd; shift fp32 [B] / fw fp32 [F] or NULL (F must be 256, PE columns
+ * [cin, cin+2F)); I <= 1024.  bwd: G fp32 [B,Otot,I] -> gW fp32 [O,I], gs fp32 [B,I]; corr fp32 [1]. */
+int dgv2_mod_prep_fwd(void* wb, float* dsave, float* stats, const float* W, const float* s,
+                      const float* ema_var, const float* shift, const float* fw, int B, int O, int I,
+                      int Otot, int row_off, int demod, int cin, int F, int wb_dtype, void* stream);
+int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float* G, const float* W, const float* s,
+                      const float* stats, const float* dsave, const float* ema_var, const float* shift,
+                      const float* fw, int B, int O, int I, int Otot, int row_off, int demod, int cin,
+                      int F, void* stream);
+
 /* Sum of squares of the first C channels of x [N, ld] into acc[0] (fp32, ACCUMULATES).
  * replaces: x.pow(2).mean() in ModConv2d.forward (style.py:100-101). */
 int dgv2_sum_squares(float* acc, const void* x, int64_t N, int C, int ld, int dtype, void* stream);
