@@ -152,3 +152,89 @@ extern "C" int dgv2_bias_grad(float* gb, const void* x, int64_t size_x, int64_t 
   });
   DGV2_RETURN_LAST();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of bias + leaky-ReLU in ONE pass over the activation gradient (channels-last [rows, C]):
+//   gx = (ref > 0 ? gy : gy * alpha) * scale          (ref = forward output)
+//   gb[c] = sum_rows gx[:, c]
+// reference: FusedLeakyReLUFunctionBackward.forward, fused_act.py:22-45 = the act kernel (grad = 1)
+// followed by a separate grad_input.sum(dim) reduction that re-reads gx.
+// Thread t owns channel vector t % cvecs and row lane t / cvecs; partial sums stay in registers over the
+// grid-stride loop, meet in LDS, and leave as one fp32 atomic per channel per block.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(T* __restrict__ gx, float* __restrict__ gb,
+                                                           const T* __restrict__ gy, const T* __restrict__ ref,
+                                                           int64_t rows, int cvecs, float alpha, float scale) {
+  constexpr int VN = vec16<T>::N;
+  __shared__ float red[256 * VN];
+  const int tid = threadIdx.x;
+  const int lanes = 256 / cvecs;  // row lanes per block (cvecs divides 256)
+  const int cv = tid % cvecs, rl = tid / cvecs;
+  float acc[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+  const int64_t C = (int64_t)cvecs * VN;
+  constexpr int U = 4;  // rows in flight per thread (few blocks, so the loop itself must cover the latency)
+  const int64_t stride = (int64_t)gridDim.x * lanes;
+  for (int64_t r0 = (int64_t)blockIdx.x * lanes + rl; r0 < rows; r0 += stride * U) {
+    vec16<T> g[U], f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * stride;
+      if (r < rows) {
+        g[u].load(gy + r * C + cv * VN);
+        f[u].load(ref + r * C + cv * VN);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * stride;
+      if (r < rows) {
+        vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          const float v = (f[u].get(j) > 0.f ? g[u].get(j) : g[u].get(j) * alpha) * scale;
+          o.set(j, v);
+          acc[j] += o.get(j);  // sum what is actually stored (the reference sums the rounded gx)
+        }
+        o.store(gx + r * C + cv * VN);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VN; ++j) red[tid * VN + j] = acc[j];
+  __syncthreads();
+  // one thread per CHANNEL: a wave-instruction of atomics then covers 64 consecutive channels, and the
+  // grid is small -- same-address float atomics serialise at the memory side (~25 ns per instruction)
+  for (int c = tid; c < cvecs * VN; c += 256) {
+    const int v = c / VN, j = c - v * VN;
+    float s = 0.f;
+    for (int k = 0; k < lanes; ++k) s += red[(k * cvecs + v) * VN + j];
+    atomicAdd(&gb[c], s);
+  }
+}
+
+}  // namespace
+
+// gx [rows,C] and gb fp32 [C] from gy [rows,C] and the forward output ref [rows,C] (channels-last).
+// Returns DGV2_EINVAL when the shape does not fit the fused kernel (caller falls back to
+// dgv2_fused_bias_act + dgv2_bias_grad): C must be a multiple of the 16-byte vector with C/vec dividing 256.
+extern "C" int dgv2_bias_act_bwd(void* gx, float* gb, const void* gy, const void* ref, int64_t rows, int C,
+                                 float alpha, float scale, int dtype, void* stream) {
+  if (!gx || !gb || !gy || !ref || rows <= 0 || C <= 0) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int vn = dtype == DGV2_BF16 ? 8 : 4;
+  if (C % vn || 256 % (C / vn) || !aligned16(gx) || !aligned16(gy) || !aligned16(ref)) return DGV2_EINVAL;
+  hipError_t e = hipMemsetAsync(gb, 0, sizeof(float) * C, st);
+  if (e != hipSuccess) return (int)e;
+  const int cvecs = C / vn, lanes = 256 / cvecs;
+  int64_t want = rows / ((int64_t)lanes * 32);  // >= 32 rows per row-lane before adding blocks
+  const int grid = (int)(want < 32 ? 32 : (want > 256 ? 256 : want));
+  DGV2_DISPATCH_DTYPE(dtype, {
+    bias_act_bwd_kernel<T><<<grid, 256, 0, st>>>((T*)gx, gb, (const T*)gy, (const T*)ref, rows, cvecs, alpha, scale);
+  });
+  DGV2_RETURN_LAST();
+}

@@ -229,9 +229,9 @@ extern "C" int dgv2_sum_squares(float* acc, const void* x, int64_t N, int C, int
     constexpr int VN = vec16<T>::N;
     if (C % VN == 0 && ld % VN == 0 && aligned16(x)) {
       const int cvecs = C / VN;
-      sum_squares_vec_kernel<T><<<grid_for(N * cvecs, 256, 2048), 256, 0, st>>>(acc, (const T*)x, N, cvecs, ld);
+      sum_squares_vec_kernel<T><<<grid_for(N * cvecs, 256 * 8, 512), 256, 0, st>>>(acc, (const T*)x, N, cvecs, ld);
     } else {
-      sum_squares_kernel<T><<<grid_for(N * C, 256, 2048), 256, 0, st>>>(acc, (const T*)x, N, C, ld);
+      sum_squares_kernel<T><<<grid_for(N * C, 256 * 8, 512), 256, 0, st>>>(acc, (const T*)x, N, C, ld);
     }
   });
   DGV2_RETURN_LAST();

@@ -104,10 +104,15 @@ class EqualLR(nn.Module):
 
     def forward(self, x):
         if isinstance(self.module, nn.Linear):
-            y = F.linear(x, self.module.weight * self.scale)
-            if self.module.bias is not None:
-                y = y + self.module.bias
-            return y * self.gain_
+            # (x * scale) @ W^T + b as ONE hipBLASLt call (alpha = scale), output gain only if != 1
+            w, b = self.module.weight, self.module.bias
+            if b is not None and x.ndim == 2:
+                y = torch.addmm(b, x, w.t(), alpha=self.scale)
+            else:
+                y = F.linear(x, w) * self.scale
+                if b is not None:
+                    y = y + b
+            return y if self.gain_ == 1.0 else y * self.gain_
         raise RuntimeError("EqualLR(conv) is executed by ops.Conv2d on this build")
 
     def extra_repr(self):

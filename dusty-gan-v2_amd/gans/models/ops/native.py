@@ -38,11 +38,20 @@ class _BiasActBackward(Function):
     @staticmethod
     def forward(ctx, gy, out, has_bias, alpha, scale, step_b, size_b):
         gy = gy.contiguous()
-        gx = _bias_act_raw(gy, None, out, 1, alpha, scale, step_b, size_b)
         gb = None
-        if has_bias:
+        vn = 8 if gy.dtype == torch.bfloat16 else 4
+        if has_bias and step_b == 1 and size_b % vn == 0 and 256 % (size_b // vn) == 0:
+            # one pass: masked gradient and its per-channel sum
+            N.check(gy, out)
+            gx = torch.empty_like(gy)
             gb = torch.empty(size_b, device=gy.device, dtype=torch.float32)
-            N.call("dgv2_bias_grad", N.ptr(gb), N.ptr(gx), gx.numel(), step_b, size_b, _dt(gx), N.stream())
+            N.call("dgv2_bias_act_bwd", N.ptr(gx), N.ptr(gb), N.ptr(gy), N.ptr(out), gy.numel() // size_b, size_b,
+                   alpha, scale, _dt(gy), N.stream())
+        else:
+            gx = _bias_act_raw(gy, None, out, 1, alpha, scale, step_b, size_b)
+            if has_bias:
+                gb = torch.empty(size_b, device=gy.device, dtype=torch.float32)
+                N.call("dgv2_bias_grad", N.ptr(gb), N.ptr(gx), gx.numel(), step_b, size_b, _dt(gx), N.stream())
         ctx.save_for_backward(out)
         ctx.cfg = (alpha, scale, step_b, size_b)
         return gx, gb

@@ -52,6 +52,14 @@ int dgv2_fused_bias_act(void* y, const void* x, const void* bias, const void* re
 int dgv2_bias_grad(float* gb, const void* x, int64_t size_x, int64_t step_b, int64_t size_b,
                    int dtype, void* stream);
 
+/* Fused backward of bias + leaky-ReLU for channels-last activations: one pass produces
+ * gx = (ref > 0 ? gy : alpha*gy) * scale and gb[c] = sum_rows gx[:,c] (fp32 [C]).
+ * replaces: FusedLeakyReLUFunctionBackward.forward (act kernel + grad_input.sum), fused_act.py:22-45.
+ * Returns DGV2_EINVAL for shapes it does not cover (C % vec != 0 or (C/vec) not dividing 256);
+ * callers then use dgv2_fused_bias_act(grad=1) + dgv2_bias_grad. */
+int dgv2_bias_act_bwd(void* gx, float* gb, const void* gy, const void* ref, int64_t rows, int C,
+                      float alpha, float scale, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------
  * upfirdn2d
  * replaces: upfirdn2d_op.upfirdn2d(input[major,H,W,minor], kernel[kh,kw],
