@@ -74,6 +74,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     }                                                        \
   } while (0)
 
+// Zero-fill as an ordinary kernel node.  Every accumulate-by-atomics buffer in this library is cleared
+// with it instead of hipMemsetAsync: the launch is an ordinary kernel node under stream capture (memset
+// nodes replayed from hipGraphs were observed to misbehave on ROCm 7.0/7.2 for these small buffers).
+static __global__ void dgv2_zero_kernel(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t dgv2_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;  // all callers clear whole fp32 words
+  if (n == 0) return hipSuccess;
+  size_t g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  dgv2_zero_kernel<<<(int)g, 256, 0, st>>>(reinterpret_cast<uint32_t*>(p), n);
+  return hipGetLastError();
+}
+#define hipMemsetAsync(p, value, bytes, st) dgv2_zero_async((p), (bytes), (st))
+
 static inline int grid_for(int64_t work, int block, int cap = 256 * 16) {
   int64_t g = (work + block - 1) / block;
   if (g > cap) g = cap;

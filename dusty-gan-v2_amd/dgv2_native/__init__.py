@@ -44,6 +44,7 @@ SIGNATURES = {
     "dgv2_conv_fwd": [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_conv_taps": [_c_ptr] * 3 + [_c_int] * 17 + [_c_ptr] + [_c_int] * 3 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int,
                                                                                _c_ptr],
+    "dgv2_conv_wgrad_direct": [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr],
     "dgv2_conv_dgrad": [_c_ptr] * 4 + [_c_int] * 11 + [_c_ptr],
     "dgv2_conv_wgrad": [_c_ptr] * 3 + [_c_int] * 11 + [_c_ptr],
     "dgv2_gen_tail_fwd": [_c_ptr] * 7 + [_c_int] * 3 + [_c_f32] * 3 + [_c_ptr],

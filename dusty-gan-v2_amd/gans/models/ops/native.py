@@ -531,6 +531,12 @@ def _conv_wgrad_raw(gy, x, g):
     O = gy.shape[3]
     N.check(gy, x)
     gw = torch.empty((O, g.kh, g.kw, C), device=x.device, dtype=torch.float32)
+    small = C % 32 == 0 and C <= 64 and O % 8 == 0 and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0))
+    if small and g.stride in (1, 2) and (x.dtype == torch.bfloat16 or g.stride == 1):
+        # small-channel / large-image layers: halo-tile engine (input staged once for all nine taps)
+        N.call("dgv2_conv_wgrad_direct", N.ptr(gw), N.ptr(gy), N.ptr(x), B, H, W, C, O, g.kh, g.stride, g.pad,
+               g.ring, _dt(x), N.stream())
+        return gw
     N.call("dgv2_conv_wgrad", N.ptr(gw), N.ptr(gy), N.ptr(x), B, H, W, C, O, g.kh, g.kw, g.stride, g.pad, g.ring,
            _dt(x), N.stream())
     return gw

@@ -102,7 +102,6 @@ class Trainer:
         # counters on the device
         self.use_graphs = bool(cfg.training.get("hip_graph", False))
         self._graphs, self._graph_warm = {}, {}
-        self._graph_pool = torch.cuda.graph_pool_handle() if self.use_graphs else None
         self.optim_G = optim.Adam(self.G.parameters(), lr=lg.alpha * ratio_G, capturable=self.use_graphs,
                                   betas=(float(lg.beta1) ** ratio_G, float(lg.beta2) ** ratio_G))
         self.optim_D = optim.Adam(self.D.parameters(), lr=ld.alpha * ratio_D, capturable=self.use_graphs,
@@ -215,7 +214,8 @@ class Trainer:
     def _run(self, name, fn, *args):
         """Run `fn(*args, scalars)` eagerly, or capture it once as a hipGraph and replay it.
         Returns the dict of scalar tensors the body produced (static buffers under replay)."""
-        if not self._graphs_usable():
+        only = os.environ.get("DGV2_GRAPHS")  # debugging aid: comma list of bodies allowed to be graphs
+        if not self._graphs_usable() or (only is not None and name not in only.split(",")):
             scalars = {}
             fn(*args, scalars)
             return scalars
@@ -228,11 +228,16 @@ class Trainer:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             scalars = {}
-            with torch.cuda.graph(g, pool=self._graph_pool):
+            # one private memory pool per graph: the bodies are replayed in a different order than they
+            # were captured (lazy R1, shared optimizer graph), which a shared pool does not allow; HBM is
+            # not the constraint here (288 GB)
+            with torch.cuda.graph(g):
                 fn(*args, scalars)
             self._graphs[name] = (g, scalars)
         g, scalars = self._graphs[name]
         g.replay()
+        if os.environ.get("DGV2_GRAPH_SYNC"):  # debugging aid: serialise host and device after each replay
+            torch.cuda.synchronize()
         return scalars
 
     # ------------------------------------------------------------------ one iteration

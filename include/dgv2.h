@@ -194,6 +194,13 @@ int dgv2_conv_dgrad(void* gx, void* gxp_scratch, const void* gy, const void* wt,
 int dgv2_conv_wgrad(float* gw, const void* gy, const void* x, int B, int H, int W, int C, int O,
                     int kh, int kw, int stride, int pad, int ring, int dtype, void* stream);
 
+/* Direct (LDS halo-tile) weight gradient for the small-channel / large-image layers (same reference
+ * lines as dgv2_conv_wgrad): gw fp32 [O, k*k, C] = sum over pixels of gy [B,Ho,Wo,O] x padded x
+ * [B,H,W,C].  k in {1,3}, pad = (k-1)/2, stride in {1,2}, C % 32 == 0, O % vec == 0; bf16 or (fp32,
+ * stride 1).  Returns DGV2_EINVAL for anything else (use dgv2_conv_wgrad). */
+int dgv2_conv_wgrad_direct(float* gw, const void* gy, const void* x, int B, int H, int W, int C, int O,
+                           int k, int stride, int pad, int ring, int dtype, void* stream);
+
 /* Direct (LDS halo-tile) convolution with a generic tap list -- the hot-path engine for the
  * discriminator convs and their data gradients (same reference lines as dgv2_conv_*):
  *   y[b, gh*out_stride+ooff_h, gw*out_stride+ooff_w, o] (=|+=) act( sum_t sum_c
