@@ -369,8 +369,10 @@ class Discriminator(nn.Module):
             ops.EqualLR(nn.Linear(ch(4), 1)),
         )
 
-    def forward(self, h):
-        """h [B,C,H,W] (C = 1 on the dusty_v2 path) -> logits [B,1]."""
+    def forward(self, h, splits=1):
+        """h [B,C,H,W] (C = 1 on the dusty_v2 path) -> logits [B,1].  `splits` = number of independent
+        sub-batches stacked along dim 0 (minibatch statistics are computed per sub-batch), so that
+        D(real) and D(fake) of the discriminator step can share one pass over the weights."""
         x = ops.to_cl(h.float())
         layers = list(self.layers)
         i = 0
@@ -394,7 +396,7 @@ class Discriminator(nn.Module):
         cin = x.shape[3] + mb.features
         vec = 32 if edt == LOW else 16
         cpad = (cin + vec - 1) // vec * vec  # whole 64-byte K-steps for the direct conv engine
-        x = mb.forward_cl(x, pad_to=cpad)
+        x = mb.forward_cl(x, pad_to=cpad, splits=splits)
         x = conv.forward_cl(x.to(edt), pad_in_to=cpad, act=act1).float()
         x = ops.from_cl(x).flatten(1)  # NCHW flatten order of the reference's nn.Flatten
         x = act2.forward_cl(lin1(x))

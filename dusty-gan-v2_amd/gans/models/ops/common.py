@@ -174,30 +174,35 @@ class MinibatchStdDev(nn.Module):
         super().__init__()
         self.group, self.features = group, features
 
-    def stat(self, x, channels_last):
-        """x float32; returns the per-sample statistic [B, features]."""
+    def stat(self, x, channels_last, splits=1):
+        """x float32; returns the per-sample statistic [B, features].  `splits` > 1 treats the batch as
+        that many independent sub-batches (e.g. real | fake evaluated in one discriminator call)."""
         B = x.shape[0]
-        g = min(B, self.group)
+        S = splits
+        Bs = B // S
+        g = min(Bs, self.group)
+        m = Bs // g
+        F_ = self.features
         if channels_last:  # [B,H,W,C]
             H, W, C = x.shape[1:]
-            y = x.reshape(g, B // g, H, W, self.features, C // self.features)
-            sd = torch.sqrt(y.var(0, unbiased=False) + 1e-8)  # [m,H,W,F,C/F]
-            st = sd.mean(dim=(1, 2, 4))
+            y = x.reshape(S, g, m, H, W, F_, C // F_)
+            sd = torch.sqrt(y.var(1, unbiased=False) + 1e-8)  # [S,m,H,W,F,C/F]
+            st = sd.mean(dim=(2, 3, 5))
         else:  # [B,C,H,W]
             C, H, W = x.shape[1:]
-            y = x.reshape(g, B // g, self.features, C // self.features, H, W)
-            sd = torch.sqrt(y.var(0, unbiased=False) + 1e-8)  # [m,F,C/F,H,W]
-            st = sd.mean(dim=(2, 3, 4))
-        return st.repeat(g, 1)
+            y = x.reshape(S, g, m, F_, C // F_, H, W)
+            sd = torch.sqrt(y.var(1, unbiased=False) + 1e-8)  # [S,m,F,C/F,H,W]
+            st = sd.mean(dim=(3, 4, 5))
+        return st[:, None].expand(S, g, m, F_).reshape(B, F_)
 
     def forward(self, x, alpha: float = 1e-8):
         B, C, H, W = x.shape
         st = self.stat(x, False)
         return torch.cat([x, st[:, :, None, None].expand(B, self.features, H, W)], dim=1)
 
-    def forward_cl(self, x, pad_to=None):
+    def forward_cl(self, x, pad_to=None, splits=1):
         B, H, W, C = x.shape
-        st = self.stat(x, True)
+        st = self.stat(x, True, splits)
         parts = [x, st[:, None, None, :].expand(B, H, W, self.features)]
         total = C + self.features
         if pad_to is not None and pad_to > total:

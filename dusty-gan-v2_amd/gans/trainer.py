@@ -179,8 +179,10 @@ class Trainer:
             x_fake = self.G(z, **self.auxin)["image"]
             x_real_aug = self.A(self.warmup(x_real))
             x_fake_aug = self.A(self.warmup(x_fake))
-        y_real = self.D(x_real_aug)
-        y_fake = self.D(x_fake_aug)
+        # D(real) and D(fake) in ONE pass over the discriminator (minibatch-stddev per half), instead of
+        # the reference's two calls (trainer.py:391-392): same result, half the launches / weight reads
+        y = self.D(torch.cat([x_real_aug, x_fake_aug], dim=0), splits=2)
+        y_real, y_fake = y[:self.B], y[self.B:]
         self.A.cumulate(y_real)
         loss_gan = self.adversarial_loss(y_real, y_fake, "D")
         (self.cfg.training.loss.gan * loss_gan).backward()

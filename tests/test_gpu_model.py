@@ -143,6 +143,17 @@ def test_d_step_and_r1_gradients(models, g_small):
         assert abs(float(g.norm()) - want_norm) <= 2e-3 * want_norm + 1e-4 * top, k
 
 
+def test_discriminator_stacked_sub_batches(models, g_small):
+    """D(cat(real, fake), splits=2) == cat(D(real), D(fake)): the one-pass form used by the D step."""
+    cfg, G, D, A = models
+    d = g_small
+    load(G, D, d)
+    xr, xf = d["ds_xr_aug"].to(DEV), d["gs_x_aug"].to(DEV)
+    y2 = D(torch.cat([xr, xf]), splits=2)
+    assert rel(y2[:xr.shape[0]], d["ds_y_real"]) < 1e-3
+    assert rel(y2, torch.cat([D(xr), D(xf)])) < 1e-5
+
+
 def test_bf16_mode_tracks_fp32(g_small):
     """Throughput mode (bf16 storage, fp32 accumulate) against the golden fp32 result: stated
     tolerance 5e-2 of the output range for one forward, as expected from 8-bit mantissas."""
