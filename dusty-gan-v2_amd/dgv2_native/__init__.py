@@ -50,6 +50,8 @@ SIGNATURES = {
     "dgv2_gen_tail_fwd": [_c_ptr] * 7 + [_c_int] * 3 + [_c_f32] * 3 + [_c_ptr],
     "dgv2_gen_tail_bwd": [_c_ptr] * 11 + [_c_int] * 3 + [_c_f32] * 3 + [_c_ptr],
     "dgv2_ada_apply": [_c_ptr] * 8 + [_c_int] * 5 + [_c_ptr],
+    "dgv2_ada_sample": [_c_ptr] * 7 + [_c_int] * 3 + [_c_ptr],
+    "dgv2_ada_build": [_c_ptr] * 8 + [_c_int] * 4 + [_c_ptr],
     "dgv2_coords_convert": [_c_ptr] * 4 + [_c_int] * 3 + [_c_f32] * 3 + [_c_int, _c_ptr],
 }
 

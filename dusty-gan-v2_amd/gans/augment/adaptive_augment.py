@@ -290,8 +290,26 @@ class AdaptiveAugment(torch.nn.Module):
             raise NotImplementedError("ADA on this path handles 1-channel range images")
         dev = img.device
         with torch.no_grad():
-            G = self.sample_affine(B, H, W, dev) if draws is None else draws["G"].to(dev)
-            C = self.sample_color(B, dev) if draws is None else draws["C"].to(dev)
-            Ay, kx, off, sgn = self.build_operators(G, H, W)
-            a, c = self.collapse_color(C.float())
+            M1y, _, M1x, _, taps = self._chain_consts(H, W, dev)
+            if draws is None:
+                # sampling + colour collapse in one kernel, operators in two (dgv2_ada_sample / _build)
+                gaff, a, c = native.ada_sample(B, H, W, self.p.reshape(1), self.policy_vector(), dev)
+            else:
+                G = draws["G"].to(dev).float()
+                gaff = torch.stack([G[:, 0, 0], G[:, 0, 2], G[:, 1, 1], G[:, 1, 2]], dim=1).contiguous()
+                a, c = self.collapse_color(draws["C"].to(dev).float())
+            Ay, kx, off, sgn = native.ada_build(gaff, M1y, M1x, taps, H, W, KTAPS)
         return native.ada_apply(img.float(), Ay, kx, off, sgn, a, c)
+
+    def policy_vector(self):
+        m = self.mul
+        return [m["lr_flip"], m["ud_flip"], m["int_trans"], m["iso_scale"], m["frac_trans"], m["brightness"],
+                m["contrast"], m["luma_flip"], m["hue"], m["saturation"], self.h_trans_factor]
+
+    @torch.no_grad()
+    def sample_params(self, B, H, W, device):
+        """(G [B,3,3], a [B], c [B]) drawn by the fused sampler (the path `forward` uses)."""
+        gaff, a, c = native.ada_sample(B, H, W, self.p.reshape(1), self.policy_vector(), device)
+        G = torch.zeros(B, 3, 3, device=device)
+        G[:, 0, 0], G[:, 0, 2], G[:, 1, 1], G[:, 1, 2], G[:, 2, 2] = gaff[:, 0], gaff[:, 1], gaff[:, 2], gaff[:, 3], 1.0
+        return G, a, c

@@ -694,6 +694,33 @@ def ada_apply(x, Ay, kx, off, sgn, a, c):
     return _AdaApply.apply(x, Ay, kx, off, sgn, a, c, False)
 
 
+def ada_sample(B, H, W, p, policy, device):
+    """Draw the per-sample affine (sx, tx, sy, ty) and collapsed colour (a, c) of ADA in one kernel.
+    policy: 11 python floats (see dgv2_ada_sample).  Returns gaff [B,4], a [B], c [B]."""
+    u = torch.rand(B, 16, device=device)
+    n = torch.randn(B, 8, device=device)
+    gaff = torch.empty((B, 4), device=device, dtype=torch.float32)
+    a = torch.empty(B, device=device, dtype=torch.float32)
+    c = torch.empty(B, device=device, dtype=torch.float32)
+    pol = (_ct.c_float * 11)(*policy)
+    N.call("dgv2_ada_sample", N.ptr(gaff), N.ptr(a), N.ptr(c), N.ptr(u), N.ptr(n), N.ptr(p), pol, B, H, W, N.stream())
+    return gaff, a, c
+
+
+def ada_build(gaff, M1y, M1x, taps, H, W, K):
+    """Separable ADA operators from the affine parameters: Ay [B,H,H], kx [B,K], off [B], sgn [B]."""
+    B = gaff.shape[0]
+    dev = gaff.device
+    Ay = torch.empty((B, H, H), device=dev, dtype=torch.float32)
+    kx = torch.empty((B, K), device=dev, dtype=torch.float32)
+    off = torch.empty(B, device=dev, dtype=torch.int32)
+    sgn = torch.empty(B, device=dev, dtype=torch.int32)
+    N.check(gaff, M1y, M1x, taps)
+    N.call("dgv2_ada_build", N.ptr(Ay), N.ptr(kx), N.ptr(off), N.ptr(sgn), N.ptr(gaff), N.ptr(M1y), N.ptr(M1x),
+           N.ptr(taps), B, H, W, K, N.stream())
+    return Ay, kx, off, sgn
+
+
 # ---------------------------------------------------------------------------------------
 def upfirdn2d_raw(x4, kernel, up, down, pad):
     """x4 [major, H, W, minor] (reference extension ABI, upfirdn2d.cpp:17-31)."""

@@ -252,6 +252,19 @@ int dgv2_ada_apply(float* y, const float* x, const float* Ay, const float* kx, c
                    const int* sgn, const float* a, const float* c, int B, int H, int W, int K,
                    int transpose, void* stream);
 
+/* ADA random parameters and operator construction (three launches instead of ~160 tiny tensor ops).
+ * replaces: AdaptiveAugment.sample_affine / sample_color and the geometry set-up of forward,
+ *   gans/augment/adaptive_augment.py:386-469, 488-535.
+ * sample: u fp32 [B,16] uniforms, n fp32 [B,8] normals, p fp32 [1] (device); policy_host = HOST array of
+ *   11 floats (lr_flip, ud_flip, int_trans, iso_scale, frac_trans, brightness, contrast, luma_flip, hue,
+ *   saturation multipliers, h_trans_factor) -> gaff [B,4] = (sx, tx, sy, ty), a [B], c [B].
+ * build: gaff + chain constants M1y [2(3H-2),H], M1x [2(3W-2),W], taps [12] -> Ay [B,H,H], kx [B,K],
+ *   off [B], sgn [B] as consumed by dgv2_ada_apply. */
+int dgv2_ada_sample(float* gaff, float* a, float* c, const float* u, const float* n, const float* p,
+                    const float* policy_host, int B, int H, int W, void* stream);
+int dgv2_ada_build(float* Ay, float* kx, int* off, int* sgn, const float* gaff, const float* M1y,
+                   const float* M1x, const float* taps, int B, int H, int W, int K, void* stream);
+
 /* ---------------------------------------------------------------------------
  * range-image projection
  * replaces: CoordBridge.convert / depth_to_point_map, gans/coords.py:88-185

@@ -324,6 +324,27 @@ def test_ada_sampling_statistics(nat):
     assert float(G[:, 0, 1].abs().max()) == 0 and float(G[:, 1, 0].abs().max()) == 0
     a, c = A.collapse_color(A.sample_color(20000, DEV))
     assert 0.3 < float((a != 1).float().mean()) < 0.9
+    # the fused sampler (dgv2_ada_sample, the path forward() uses) draws from the same distributions
+    G2, a2, c2 = A.sample_params(20000, 64, 512, DEV)
+    G2, a2, c2 = G2.cpu(), a2.cpu(), c2.cpu()
+    assert abs(float((G2[:, 0, 0] < 0).float().mean()) - 0.25) < 0.02
+    assert abs(float((G2[:, 1, 1] < 0).float().mean()) - 0.25) < 0.02
+    for k in ((0, 2), (1, 2)):  # translations: same spread as the tensor-op sampler
+        assert abs(float(G2[:, k[0], k[1]].std()) / float(G[:, k[0], k[1]].std()) - 1) < 0.05
+    assert abs(float(G2[:, 1, 1].abs().log().std()) / float(G[:, 1, 1].abs().log().std()) - 1) < 0.05
+    assert abs(float(a2.mean()) - float(a.mean())) < 0.05 and abs(float(a2.std()) / float(a.std()) - 1) < 0.1
+    assert abs(float(c2.std()) / float(c.std()) - 1) < 0.1
+    # kernel-built operators == tensor-op-built operators for the same affine
+    Gs = G[:64].to(DEV)
+    Ay0, kx0, off0, sgn0 = A.build_operators(Gs, 16, 64)
+    M1y, _, M1x, _, taps = A._chain_consts(16, 64, DEV)
+    gaff = torch.stack([Gs[:, 0, 0], Gs[:, 0, 2], Gs[:, 1, 1], Gs[:, 1, 2]], 1).contiguous()
+    Ay1, kx1, off1, sgn1 = nat.ada_build(gaff, M1y, M1x, taps, 16, 64, kx0.shape[1])
+    assert torch.equal(sgn0.cpu(), sgn1.cpu())
+    assert_rel(Ay1.cpu(), Ay0.cpu(), 1e-5, "Ay")
+    same = off0.cpu() == off1.cpu()  # the peak can tie between two taps; compare where the window agrees
+    assert float(same.float().mean()) > 0.9
+    assert_rel(kx1.cpu()[same], kx0.cpu()[same], 1e-5, "kx")
     # p = 0: identity operators, output ~ input (SYM6 up/down reconstruction)
     A.p.fill_(0.0)
     x = torch.randn(4, 1, 16, 64, device=DEV)
