@@ -1,6 +1,6 @@
 // Direct (LDS halo-tile) convolution on the MFMA cores, channels-last, with a generic TAP LIST.
 //
-// One kernel covers every dense conv of the discriminator and their data gradients
+// One engine covers every dense conv of the discriminator and their data gradients
 // (reference: ops.Conv2d in gans/models/ops/common.py:187-210 at gans/models/dusty_v2.py:325-385,
 // and the cuDNN dgrad autograd would call):
 //   forward 3x3 / 1x1, stride 1 or 2      : taps (ky-1, kx-1), input coord = out * stride + d
@@ -11,10 +11,18 @@
 // Ring padding = wrap of the W coordinate while the halo tile is staged; H is clamped (forward,
 // replicate padding) or zero-filled (gradients).  Nothing padded is ever materialised.
 //
-// Block = 4 waves; tile = 4 x 32 output positions x TO output channels; wave w owns tile row w.
-// Per 64-byte channel chunk the input halo tile and the weight slab [TO][ntaps] are staged in LDS once
-// and reused by all taps (9x fewer global loads than an im2col gather); fragments are 16-byte
-// ds_read_b128 with the same (idx>>2)&3 XOR swizzle as gemm_core.h.
+// Two kernels:
+//   conv_pipe_kernel    the production path.  Block = 4 waves, tile = (4*RW) x 32 output positions x TO
+//                       channels, wave w owns RW tile rows.  A block walks `tpb` tiles along W and, per tile,
+//                       the Cin/32 (bf16) 64-byte channel chunks; that (tile, chunk) sequence is software
+//                       pipelined: the global loads of stage s+1 are issued into registers before the MFMA
+//                       loop of stage s and written to the (single) LDS buffer after it, so HBM/L2 latency,
+//                       MFMA work and the epilogue stores of consecutive stages overlap inside one block.
+//                       All per-slot address arithmetic is hoisted out of the stage loop.
+//   conv_direct_kernel  the simple synchronous version, kept as the fallback for geometries the pipelined
+//                       kernel's fixed register budget does not cover (very wide halos, Win < 32).
+// LDS images: input halo tile [pix][4 x 16 B] and weight slab [tap][TO][4 x 16 B], both with the
+// (row>>2)&3 XOR swizzle of gemm_core.h so every fragment is one conflict-free ds_read_b128.
 #include "gemm_core.h"
 
 namespace {
@@ -31,12 +39,218 @@ struct DConv {
   int dy[9], dx[9], widx[9];
   int dymin, dxmin, rows, cols;
   int hzero, ring, accumulate;
-  int ablate;  // benchmarking only (DGV2_ABLATE): 1 skip MFMA loop, 2 skip stores, 4 skip staging
+  int tpb;          // tiles per block along W (pipelined kernel)
+  float inv_cols;   // 1 / cols
   const float* bias;
   int act;
   float alpha, scale;
 };
 
+// Epilogue shared by both kernels: one accumulator fragment (16 channels x 16 positions) -> y.
+template <typename T>
+__device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, int o, f32x4 v) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (o + r >= p.O) continue;
+    float f = v[r];
+    if (p.accumulate) f += to_f32(row[o + r]);
+    if (p.bias) f += p.bias[o + r];
+    if (p.act == 3) f = (f > 0.f ? f : f * p.alpha) * p.scale;
+    v[r] = f;
+  }
+  if (o + 3 < p.O && (p.O & 3) == 0) {
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<f32x4*>(row + o) = v;
+    } else {
+      union { uint2 u; bf16_t e[4]; } pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pk.e[r] = (bf16_t)v[r];
+      *reinterpret_cast<uint2*>(row + o) = pk.u;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (o + r < p.O) row[o + r] = from_f32<T>(v[r]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined kernel.  NI = input-tile staging slots (16 B each) per thread, NW = weight slots.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int TO, int RW, int NI>
+__global__ __launch_bounds__(256, 2) void conv_pipe_kernel(T* __restrict__ y, const T* __restrict__ x,
+                                                           const T* __restrict__ w, DConv p) {
+  constexpr int CE = 16 / sizeof(T);
+  constexpr int MF = TO / 16, NF = 2 * RW, TH = 4 * RW;
+  constexpr int NW = (TO * 9 * 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  __shared__ int s_widx[9], s_tapoff[9];
+  const int npix = p.rows * p.cols;
+  uint4* lds_in = smem;
+  uint4* lds_w = smem + npix * 4;
+  const int n_in = npix * 4, n_w = TO * p.ntaps * 4;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lc = lane >> 4;
+  const int tiles_h = (p.Hg + TH - 1) / TH;
+  const int tiles_w = (p.Wg + DTW - 1) / DTW;
+  const int b = blockIdx.y / tiles_h;
+  const int h0 = (blockIdx.y % tiles_h) * TH;
+  const int o0 = blockIdx.z * TO;
+  const int tw0 = blockIdx.x * p.tpb;
+  const int ntile = min(p.tpb, tiles_w - tw0);
+  const T* xb = x + (int64_t)b * p.Hin * p.Win * p.Cin;
+  const int kchunk = 4 * CE;
+  const int nchunks = p.Cin / kchunk;
+
+  if (tid == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      s_widx[t] = p.widx[t];
+      s_tapoff[t] = (p.dy[t] - p.dymin) * p.cols + p.dx[t] - p.dxmin;
+    }
+  }
+  __syncthreads();
+
+  // ---- per-slot constants (once per block) ----
+  int woff[NW];   // element offset of the slot's 16 bytes in w at chunk 0, or -1
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int id = tid + j * 256;
+    const int t = id / (TO * 4), r = (id >> 2) & (TO - 1), ch = id & 3;
+    woff[j] = (id < n_w && o0 + r < p.O) ? ((o0 + r) * p.wtaps + s_widx[t < 9 ? t : 0]) * p.Cin + ch * CE : -1;
+  }
+  int ipos[NI];   // (iy << 16) | ix of the slot's pixel inside the halo tile
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int pix = (tid + j * 256) >> 2;
+    const int iy = (int)(((float)pix + 0.5f) * p.inv_cols);
+    ipos[j] = (iy << 16) | (pix - iy * p.cols);
+  }
+  int goff[NI];   // element offset inside image b of the slot's 16 bytes at chunk 0, or -1 (zero fill)
+  auto tile_offsets = [&](int tw) {
+    const int gh_base = h0 * p.in_stride + p.ioff_h + p.dymin;
+    const int gw_base = tw * DTW * p.in_stride + p.ioff_w + p.dxmin;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int id = tid + j * 256;
+      int gh = gh_base + (ipos[j] >> 16), gw = gw_base + (ipos[j] & 0xffff);
+      const bool zero = id >= n_in || (p.hzero && (gh < 0 || gh >= p.Hin));
+      gh = gh < 0 ? 0 : (gh >= p.Hin ? p.Hin - 1 : gh);
+      if (p.ring) {   // -Win <= gw < 4*Win (host-checked)
+        gw = gw < 0 ? gw + p.Win : gw;
+        gw = gw >= 2 * p.Win ? gw - 2 * p.Win : gw;
+        gw = gw >= p.Win ? gw - p.Win : gw;
+      } else {
+        gw = gw < 0 ? 0 : (gw >= p.Win ? p.Win - 1 : gw);
+      }
+      goff[j] = zero ? -1 : (gh * p.Win + gw) * p.Cin + (id & 3) * CE;
+    }
+  };
+
+  uint4 rin[NI], rwt[NW];
+  auto issue_in = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      rin[j] = make_uint4(0, 0, 0, 0);
+      if (goff[j] >= 0) rin[j] = *reinterpret_cast<const uint4*>(xb + goff[j] + c0);
+    }
+  };
+  auto issue_w = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      rwt[j] = make_uint4(0, 0, 0, 0);
+      if (woff[j] >= 0) rwt[j] = *reinterpret_cast<const uint4*>(w + woff[j] + c0);
+    }
+  };
+  // slot id -> swizzled LDS index; (pix>>2)&3 and (r>>2)&3 are both (id>>4)&3 (TO is a multiple of 16)
+  auto swz = [](int id) { return (id & ~3) | ((id & 3) ^ ((id >> 4) & 3)); };
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int bpix[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+    bpix[nf] = (wave * RW + (nf >> 1)) * p.in_stride * p.cols + ((nf & 1) * 16 + lr) * p.in_stride;
+  const int aswz = lc ^ ((lr >> 2) & 3);
+
+  // ---- pipeline over (tile, chunk) stages ----
+  tile_offsets(tw0);
+  issue_in(0);
+  issue_w(0);
+  int tile = 0, cc = 0;             // stage being computed
+  const int nstage = ntile * nchunks;
+  for (int s = 0; s < nstage; ++s) {
+    __syncthreads();                // every wave has finished reading stage s-1
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int id = tid + j * 256;
+      if (id < n_in) lds_in[swz(id)] = rin[j];
+    }
+    if (s == 0 || nchunks > 1) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int id = tid + j * 256;
+        if (id < n_w) lds_w[swz(id)] = rwt[j];
+      }
+    }
+    // prefetch stage s+1
+    int ntile_i = tile, ncc = cc + 1;
+    if (ncc == nchunks) { ncc = 0; ++ntile_i; }
+    if (s + 1 < nstage) {
+      if (ncc == 0) tile_offsets(tw0 + ntile_i);
+      issue_in(ncc * kchunk);
+      if (nchunks > 1) issue_w(ncc * kchunk);
+    }
+    __syncthreads();                // stage s visible in LDS
+
+    for (int t = 0; t < p.ntaps; ++t) {
+      uint4 a[MF], bb[NF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) a[mf] = lds_w[(t * TO + mf * 16 + lr) * 4 + aswz];
+      const int tapoff = s_tapoff[t];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int pix = bpix[nf] + tapoff;
+        bb[nf] = lds_in[pix * 4 + (lc ^ ((pix >> 2) & 3))];
+      }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) Mfma16<T>::run(acc[mf][nf], a[mf], bb[nf]);
+    }
+
+    if (cc == nchunks - 1) {        // tile finished: epilogue, reset accumulators
+      const int w0 = (tw0 + tile) * DTW;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int gh = h0 + wave * RW + (nf >> 1);
+        const int gw = w0 + (nf & 1) * 16 + lr;
+        if (gh < p.Hg && gw < p.Wg) {
+          const int yh = gh * p.out_stride + p.ooff_h, yw = gw * p.out_stride + p.ooff_w;
+          T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.O;
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            const int o = o0 + mf * 16 + lc * 4;
+            if (o < p.O) store_frag<T>(p, row, o, acc[mf][nf]);
+          }
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    tile = ntile_i; cc = ncc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synchronous fallback: 4 x 32 tile, stage -> barrier -> MFMA per chunk.
+// ---------------------------------------------------------------------------------------------
 template <typename T, int TO>
 __global__ __launch_bounds__(256) void conv_direct_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                           const T* __restrict__ w, DConv p) {
@@ -70,7 +284,6 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(T* __restrict__ y, con
   for (int cc = 0; cc < nchunks; ++cc) {
     const int c0 = cc * 4 * CE;
     __syncthreads();
-    if (!(p.ablate & 4))
     for (int id = tid; id < npix * 4; id += 256) {
       const int pix = id >> 2, ch = id & 3;
       const int iy = pix / p.cols, ix = pix - iy * p.cols;
@@ -83,7 +296,6 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(T* __restrict__ y, con
       if (!zero) v = *reinterpret_cast<const uint4*>(xb + ((int64_t)gh * p.Win + gw) * p.Cin + c0 + ch * CE);
       lds_in[pix * 4 + (ch ^ ((pix >> 2) & 3))] = v;
     }
-    if (!(p.ablate & 4))
     for (int id = tid; id < TO * p.ntaps * 4; id += 256) {
       const int r = id / (p.ntaps * 4);
       const int rem = id - r * (p.ntaps * 4);
@@ -94,7 +306,6 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(T* __restrict__ y, con
       lds_w[(r * p.ntaps + t) * 4 + (ch ^ ((r >> 2) & 3))] = v;
     }
     __syncthreads();
-    if (!(p.ablate & 1))
     for (int t = 0; t < p.ntaps; ++t) {
       uint4 a[MF], bb[2];
 #pragma unroll
@@ -118,7 +329,6 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(T* __restrict__ y, con
 
   const int gh = h0 + wave;
   if (gh >= p.Hg) return;
-  if ((p.ablate & 2) && acc[0][0][0] != 12345.678f) return;
   const int yh = gh * p.out_stride + p.ooff_h;
 #pragma unroll
   for (int nf = 0; nf < 2; ++nf) {
@@ -129,181 +339,15 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(T* __restrict__ y, con
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       const int o = o0 + mf * 16 + lc * 4;
-      if (o >= p.O) continue;
-      f32x4 v = acc[mf][nf];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (o + r >= p.O) continue;
-        float f = v[r];
-        if (p.accumulate) f += to_f32(row[o + r]);
-        if (p.bias) f += p.bias[o + r];
-        if (p.act == 3) f = (f > 0.f ? f : f * p.alpha) * p.scale;
-        v[r] = f;
-      }
-      if (o + 3 < p.O && (p.O & 3) == 0) {
-        if constexpr (sizeof(T) == 4) {
-          *reinterpret_cast<f32x4*>(row + o) = v;
-        } else {
-          union { uint2 u; bf16_t e[4]; } pk;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pk.e[r] = (bf16_t)v[r];
-          *reinterpret_cast<uint2*>(row + o) = pk.u;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (o + r < p.O) row[o + r] = from_f32<T>(v[r]);
-      }
+      if (o < p.O) store_frag<T>(p, row, o, acc[mf][nf]);
     }
-  }
-}
-
-// Weights-in-registers variant for the small-channel layers (Cin <= 2 K-steps, TO = 32): the A fragments
-// of every (chunk, tap) live in VGPRs for the whole block, which then walks TPB tiles along W staging only
-// the input halo tile.  Compared with the generic kernel this removes the weight slab from the per-tile
-// staging (it was larger than the input tile) and every LDS read of A.
-constexpr int WREG_TPB = 4;
-
-template <typename T, int NCH, int NT>
-__global__ __launch_bounds__(256) void conv_direct_wreg_kernel(T* __restrict__ y, const T* __restrict__ x,
-                                                               const T* __restrict__ w, DConv p) {
-  constexpr int CE = 16 / sizeof(T);
-  constexpr int TO = 32, MF = 2;
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-  const int npix = p.rows * p.cols;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int lr = lane & 15, lc = lane >> 4;
-  const int tiles_h = (p.Hg + DTH - 1) / DTH;
-  const int tiles_w = (p.Wg + DTW - 1) / DTW;
-  const int b = blockIdx.y / tiles_h;
-  const int h0 = (blockIdx.y % tiles_h) * DTH;
-  const int o0 = blockIdx.z * TO;
-  const T* xb = x + (int64_t)b * p.Hin * p.Win * p.Cin;
-
-  uint4 a[NCH][NT][MF];
-#pragma unroll
-  for (int cc = 0; cc < NCH; ++cc)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const int o = o0 + mf * 16 + lr;
-        a[cc][t][mf] = make_uint4(0, 0, 0, 0);
-        if (o < p.O)
-          a[cc][t][mf] = *reinterpret_cast<const uint4*>(w + ((int64_t)o * p.wtaps + p.widx[t]) * p.Cin + cc * 4 * CE + lc * CE);
-      }
-
-  const int gh_base = h0 * p.in_stride + p.ioff_h + p.dymin;
-  const int gh = h0 + wave;
-  for (int tw = blockIdx.x * WREG_TPB; tw < tiles_w && tw < (int)(blockIdx.x + 1) * WREG_TPB; ++tw) {
-    const int w0 = tw * DTW;
-    const int gw_base = w0 * p.in_stride + p.ioff_w + p.dxmin;
-    __syncthreads();
-    for (int id = tid; id < npix * 4 * NCH; id += 256) {
-      const int cc = id / (npix * 4);
-      const int rem = id - cc * (npix * 4);
-      const int pix = rem >> 2, ch = rem & 3;
-      const int iy = pix / p.cols, ix = pix - iy * p.cols;
-      int sh = gh_base + iy, sw = gw_base + ix;
-      bool zero = false;
-      if (p.hzero) zero = sh < 0 || sh >= p.Hin;
-      sh = sh < 0 ? 0 : (sh >= p.Hin ? p.Hin - 1 : sh);
-      sw = p.ring ? floormod(sw, p.Win) : (sw < 0 ? 0 : (sw >= p.Win ? p.Win - 1 : sw));
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (!zero) v = *reinterpret_cast<const uint4*>(xb + ((int64_t)sh * p.Win + sw) * p.Cin + cc * 4 * CE + ch * CE);
-      smem[cc * npix * 4 + pix * 4 + (ch ^ ((pix >> 2) & 3))] = v;
-    }
-    __syncthreads();
-    f32x4 acc[MF][2];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      acc[mf][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[mf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int cc = 0; cc < NCH; ++cc)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int prow = (wave * p.in_stride + p.dy[t] - p.dymin) * p.cols + p.dx[t] - p.dxmin;
-        uint4 bb[2];
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
-          const int pix = prow + (nf * 16 + lr) * p.in_stride;
-          bb[nf] = smem[cc * npix * 4 + pix * 4 + (lc ^ ((pix >> 2) & 3))];
-        }
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-          Mfma16<T>::run(acc[mf][0], a[cc][t][mf], bb[0]);
-          Mfma16<T>::run(acc[mf][1], a[cc][t][mf], bb[1]);
-        }
-      }
-    if (gh < p.Hg) {
-      const int yh = gh * p.out_stride + p.ooff_h;
-#pragma unroll
-      for (int nf = 0; nf < 2; ++nf) {
-        const int gw = w0 + nf * 16 + lr;
-        if (gw >= p.Wg) continue;
-        const int yw = gw * p.out_stride + p.ooff_w;
-        T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.O;
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-          const int o = o0 + mf * 16 + lc * 4;
-          if (o >= p.O) continue;
-          f32x4 v = acc[mf][nf];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (o + r >= p.O) continue;
-            float f = v[r];
-            if (p.accumulate) f += to_f32(row[o + r]);
-            if (p.bias) f += p.bias[o + r];
-            if (p.act == 3) f = (f > 0.f ? f : f * p.alpha) * p.scale;
-            v[r] = f;
-          }
-          if (o + 3 < p.O && (p.O & 3) == 0) {
-            if constexpr (sizeof(T) == 4) {
-              *reinterpret_cast<f32x4*>(row + o) = v;
-            } else {
-              union { uint2 u; bf16_t e[4]; } pk;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) pk.e[r] = (bf16_t)v[r];
-              *reinterpret_cast<uint2*>(row + o) = pk.u;
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (o + r < p.O) row[o + r] = from_f32<T>(v[r]);
-          }
-        }
-      }
-    }
-  }
-}
-
-template <typename T, int NCH, int NT>
-int launch_wreg(void* y, const void* x, const void* w, const DConv& p, hipStream_t st) {
-  const size_t lds = sizeof(uint4) * (size_t)p.rows * p.cols * 4 * NCH;
-  if (lds > 64 * 1024) return DGV2_EINVAL;
-  const int tiles_w = (p.Wg + DTW - 1) / DTW;
-  dim3 grid((tiles_w + WREG_TPB - 1) / WREG_TPB, ((p.Hg + DTH - 1) / DTH) * p.B, (p.O + 31) / 32);
-  conv_direct_wreg_kernel<T, NCH, NT><<<grid, 256, lds, st>>>((T*)y, (const T*)x, (const T*)w, p);
-  return 0;
-}
-
-template <typename T, int NCH>
-int dispatch_wreg(void* y, const void* x, const void* w, const DConv& p, hipStream_t st) {
-  switch (p.ntaps) {
-    case 1: return launch_wreg<T, NCH, 1>(y, x, w, p, st);
-    case 2: return launch_wreg<T, NCH, 2>(y, x, w, p, st);
-    case 3: return launch_wreg<T, NCH, 3>(y, x, w, p, st);
-    case 4: return launch_wreg<T, NCH, 4>(y, x, w, p, st);
-    case 9: return launch_wreg<T, NCH, 9>(y, x, w, p, st);
-    default: return -2;
   }
 }
 
 template <typename T, int TO>
-int launch_direct(void* y, const void* x, const void* w, const DConv& p, hipStream_t st) {
+int launch_direct(void* y, const void* x, const void* w, DConv p, hipStream_t st) {
+  p.rows = (DTH - 1) * p.in_stride + p.rows;   // p.rows / p.cols arrive as the tap extents
+  p.cols = (DTW - 1) * p.in_stride + p.cols;
   const size_t lds = sizeof(uint4) * ((size_t)p.rows * p.cols * 4 + (size_t)TO * p.ntaps * 4);
   if (lds > 160 * 1024) return DGV2_EINVAL;
   auto kern = conv_direct_kernel<T, TO>;
@@ -314,6 +358,42 @@ int launch_direct(void* y, const void* x, const void* w, const DConv& p, hipStre
   dim3 grid((p.Wg + DTW - 1) / DTW, ((p.Hg + DTH - 1) / DTH) * p.B, (p.O + TO - 1) / TO);
   kern<<<grid, 256, lds, st>>>((T*)y, (const T*)x, (const T*)w, p);
   return 0;
+}
+
+// returns -2 when the geometry does not fit this instantiation's register / LDS budget
+template <typename T, int TO, int RW, int NI>
+int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) {
+  constexpr int TH = 4 * RW;
+  constexpr int NW = (TO * 9 * 4 + 255) / 256;
+  p.rows = (TH - 1) * p.in_stride + p.rows;
+  p.cols = (DTW - 1) * p.in_stride + p.cols;
+  p.inv_cols = 1.0f / (float)p.cols;
+  const int n_in = p.rows * p.cols * 4, n_w = TO * p.ntaps * 4;
+  if (n_in > NI * 256 || n_w > NW * 256 || p.rows >= 32768 || p.cols >= 65536) return -2;
+  const size_t lds = sizeof(uint4) * ((size_t)n_in + n_w);
+  if (lds > 80 * 1024) return -2;   // two blocks per CU
+  auto kern = conv_pipe_kernel<T, TO, RW, NI>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int tiles_w = (p.Wg + DTW - 1) / DTW, tiles_h = (p.Hg + TH - 1) / TH, tiles_o = (p.O + TO - 1) / TO;
+  // walk several tiles per block while the grid still holds >= ~4 blocks per CU slot
+  const int64_t tiles = (int64_t)tiles_w * tiles_h * p.B * tiles_o;
+  int tpb = (int)(tiles / 2048);
+  tpb = tpb < 1 ? 1 : (tpb > tiles_w ? tiles_w : tpb);
+  tpb = tpb > 8 ? 8 : tpb;
+  p.tpb = tpb;
+  dim3 grid((tiles_w + tpb - 1) / tpb, tiles_h * p.B, tiles_o);
+  kern<<<grid, 256, lds, st>>>((T*)y, (const T*)x, (const T*)w, p);
+  return 0;
+}
+
+template <typename T, int TO>
+int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, hipStream_t st) {
+  if (p.in_stride == 1 && p.Hg >= 8) return launch_pipe<T, TO, 2, 6>(y, x, w, p, st);
+  if (p.in_stride == 1) return launch_pipe<T, TO, 1, 4>(y, x, w, p, st);
+  return launch_pipe<T, TO, 1, 10>(y, x, w, p, st);
 }
 
 }  // namespace
@@ -350,25 +430,28 @@ extern "C" int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int 
     }
   }
   p.dymin = dymin; p.dxmin = dxmin;
-  p.rows = (DTH - 1) * in_stride + (dymax - dymin) + 1;
-  p.cols = (DTW - 1) * in_stride + (dxmax - dxmin) + 1;
+  p.rows = dymax - dymin + 1;   // tap extents; the launchers add the tile extent
+  p.cols = dxmax - dxmin + 1;
   p.hzero = hzero; p.ring = ring; p.accumulate = accumulate;
-  { static const int abl = getenv("DGV2_ABLATE") ? atoi(getenv("DGV2_ABLATE")) : 0; p.ablate = abl; }
+  p.tpb = 1; p.inv_cols = 0.f;
   p.bias = bias; p.act = act; p.alpha = alpha; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  const int nchunks = Cin / kstep;
+  static const bool no_pipe = getenv("DGV2_NO_PIPE") != nullptr;   // A/B switch for benchmarking
+  // the ring wrap of the pipelined kernel assumes -Win <= gw < 4*Win
+  const bool wrap_ok = !ring || (ioff_w + dxmin >= -Win && in_stride * ((Wg + DTW - 1) / DTW * DTW) + ioff_w + dxmax < 4 * Win);
   DGV2_DISPATCH_DTYPE(dtype, {
-    // small-channel layers: weights in registers, several tiles per block
     rc = -2;
-    static const bool no_wreg = getenv("DGV2_NO_WREG") != nullptr;  // A/B switch for benchmarking
-    if (no_wreg) {
-    } else if (nchunks == 1) rc = dispatch_wreg<T, 1>(y, x, w, p, st);
-    else if (nchunks == 2 && sizeof(T) == 2) rc = dispatch_wreg<T, 2>(y, x, w, p, st);
-    if (rc == 0) DGV2_RETURN_LAST();
-    if (O <= 16) rc = launch_direct<T, 16>(y, x, w, p, st);
-    else if (O <= 32) rc = launch_direct<T, 32>(y, x, w, p, st);
-    else rc = launch_direct<T, 64>(y, x, w, p, st);  // TO = 64 keeps LDS <= 50 KB: 3 blocks/CU hide the staging latency
+    if (!no_pipe && wrap_ok) {
+      if (O <= 16) rc = dispatch_pipe<T, 16>(y, x, w, p, st);
+      else if (O <= 32) rc = dispatch_pipe<T, 32>(y, x, w, p, st);
+      else rc = dispatch_pipe<T, 64>(y, x, w, p, st);
+    }
+    if (rc == -2) {
+      if (O <= 16) rc = launch_direct<T, 16>(y, x, w, p, st);
+      else if (O <= 32) rc = launch_direct<T, 32>(y, x, w, p, st);
+      else rc = launch_direct<T, 64>(y, x, w, p, st);
+    }
   });
   if (rc) return rc;
   DGV2_RETURN_LAST();
