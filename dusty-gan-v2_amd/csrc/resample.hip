@@ -232,6 +232,112 @@ __global__ __launch_bounds__(256) void resample_tab_kernel(
   }
 }
 
+// Row-streaming separable variant (the production path: 16-byte-vectorisable tensors, <= 4 taps per
+// output column).  A thread owns one output column x one channel vector and walks a strip of SH output
+// rows.  Its W taps (<= 4 offsets + coefficients) live in registers for the whole walk; each input row
+// the strip needs is filtered along W exactly once (4 global loads) into a 4-slot fp32 ring in LDS that
+// only its own thread ever reads back, so there are no barriers; the H taps come from the (wave-uniform)
+// row table.  A 4x4 FIR costs ~4 global loads + 64 FMAs per output vector instead of 16 loads + 128 FMAs,
+// and all integer div/mod leaves the inner loop.  Ring slot = input row & 3 with a uniform tag check, so any
+// table is handled correctly; tables whose rows reuse a window of <= 4 consecutive input rows (every
+// up / down / blur FIR of this model and their adjoints) never re-filter a row.
+constexpr int RS_RB = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void resample_stream_kernel(
+    T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
+    const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
+    const int* __restrict__ cnt_w, int Ew, int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
+    int SH) {
+  constexpr int VN = vec16<T>::N;
+  constexpr int Q = VN / 4;
+  __shared__ float4 ring[RS_RB][Q][256];
+  const int tid = threadIdx.x;
+  const int cvecs = C / VN;
+  const int rowvecs = out_w * cvecs;
+  const int colblocks = (rowvecs + 255) / 256;
+  const int strips = (out_h + SH - 1) / SH;
+  int bid = blockIdx.x;
+  const int cb = bid % colblocks; bid /= colblocks;
+  const int strip = bid % strips;
+  const int b = bid / strips;
+  const int col = cb * 256 + tid;
+  const bool live = col < rowvecs;
+  const int wo = live ? col / cvecs : 0;
+  const int cv = live ? col - wo * cvecs : 0;
+
+  const int nw = live ? cnt_w[wo] : 0;
+  int xo[4];
+  float cw[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    xo[c] = -1;
+    cw[c] = 0.f;
+    if (c < nw) {
+      xo[c] = idx_w[wo * Ew + c] * ldx + cv * VN;
+      cw[c] = coef_w[wo * Ew + c];
+    }
+  }
+  const T* xb = x + (int64_t)b * in_h * in_w * ldx;
+  T* yp = y + (int64_t)b * out_h * out_w * ldy + (int64_t)wo * ldy + cv * VN;
+  const int ho0 = strip * SH;
+  const int ho1 = min(ho0 + SH, out_h);
+  int t0 = -1, t1 = -1, t2 = -1, t3 = -1;   // ring tags (block-uniform)
+  int rlast = -1;                           // last input row the strip reads: bound of the prefetch
+  for (int ho = ho0; ho < ho1; ++ho)
+    for (int a = 0; a < cnt_h[ho]; ++a) rlast = max(rlast, idx_h[ho * Eh + a]);
+  // input rows are consumed in (mostly) increasing order: after filtering row r the loads of row r + 1 are
+  // issued at once and stay in flight behind this row's FMAs / LDS traffic / output store
+  int pr = -1;
+  vec16<T> pv[4];
+  auto issue = [&](int r) {
+    const T* xr = xb + (int64_t)r * in_w * ldx;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      pv[c].raw = make_uint4(0, 0, 0, 0);
+      if (xo[c] >= 0) pv[c].load(xr + xo[c]);
+    }
+    pr = r;
+  };
+  for (int ho = ho0; ho < ho1; ++ho) {
+    const int n = cnt_h[ho];
+    float acc[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+    for (int a = 0; a < n; ++a) {
+      const int r = idx_h[ho * Eh + a];
+      const float fa = coef_h[ho * Eh + a];
+      const int s = r & (RS_RB - 1);
+      const int tag = s == 0 ? t0 : (s == 1 ? t1 : (s == 2 ? t2 : t3));
+      if (tag != r) {
+        if (pr != r) issue(r);
+        float h[VN];
+#pragma unroll
+        for (int j = 0; j < VN; ++j) h[j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < VN; ++j) h[j] += cw[c] * pv[c].get(j);
+        if (r + 1 <= rlast) issue(r + 1); else pr = -1;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) ring[s][q][tid] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+        t0 = s == 0 ? r : t0; t1 = s == 1 ? r : t1; t2 = s == 2 ? r : t2; t3 = s == 3 ? r : t3;
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float4 h4 = ring[s][q][tid];
+        acc[4 * q] += fa * h4.x; acc[4 * q + 1] += fa * h4.y; acc[4 * q + 2] += fa * h4.z; acc[4 * q + 3] += fa * h4.w;
+      }
+    }
+    if (live) {
+      vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
+      o.store(yp + (int64_t)ho * out_w * ldy);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const float* coef_h, const int* cnt_h,
@@ -247,7 +353,14 @@ extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const
     const bool vec = (C % VN == 0) && (ldx % VN == 0) && (ldy % VN == 0) && aligned16(x) && aligned16(y);
     const int64_t total = (int64_t)B * out_h * out_w * ((C + (vec ? VN : 1) - 1) / (vec ? VN : 1));
     const int grid = grid_for(total, 256, 256 * 64);
-    if (vec)
+    static const bool no_stream = getenv("DGV2_NO_RSTREAM") != nullptr;   // A/B switch for benchmarking
+    if (vec && Ew <= 4 && !no_stream) {
+      const int SH = out_h >= 32 ? 16 : (out_h >= 8 ? 8 : out_h);
+      const int64_t blocks = (int64_t)B * ((out_h + SH - 1) / SH) * (((int64_t)out_w * (C / VN) + 255) / 256);
+      if (blocks >= (1LL << 31)) return DGV2_EINVAL;
+      resample_stream_kernel<T><<<(int)blocks, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
+                                                             cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, SH);
+    } else if (vec)
       resample_tab_kernel<T, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
                                                         cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w);
     else

@@ -10,6 +10,7 @@ with its transpose, convolutions form the {fwd, dgrad, wgrad} triple, bias+lrelu
 its masked form -- so double backward never leaves the HIP kernels.
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -526,12 +527,15 @@ def _conv_dgrad_raw(gy, w, g, xshape):
     return gx
 
 
+_WGRAD_DIRECT_MAXC = int(os.environ.get("DGV2_WGRAD_DIRECT_MAXC", "64"))
+
+
 def _conv_wgrad_raw(gy, x, g):
     B, H, W, C = x.shape
     O = gy.shape[3]
     N.check(gy, x)
     gw = torch.empty((O, g.kh, g.kw, C), device=x.device, dtype=torch.float32)
-    small = C % 32 == 0 and C <= 64 and O % 8 == 0 and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0))
+    small = C % 32 == 0 and C <= _WGRAD_DIRECT_MAXC and O % 8 == 0 and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0))
     if small and g.stride in (1, 2) and (x.dtype == torch.bfloat16 or g.stride == 1):
         # small-channel / large-image layers: halo-tile engine (input staged once for all nine taps)
         N.call("dgv2_conv_wgrad_direct", N.ptr(gw), N.ptr(gy), N.ptr(x), B, H, W, C, O, g.kh, g.stride, g.pad,

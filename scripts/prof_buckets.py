@@ -1,0 +1,25 @@
+"""Aggregate a rocprofv3 kernel_stats.csv into per-engine buckets (ms per step).
+usage: python scripts/prof_buckets.py <kernel_stats.csv> <steps>"""
+import csv, sys, re, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = float(sys.argv[2])
+B = collections.OrderedDict([
+    ("conv_pipe", r"conv_pipe_kernel"), ("conv_direct_fallback", r"conv_direct_kernel"),
+    ("conv_wgrad_direct", r"wgrad_direct"), ("gemm_tn(im2col wgrad)", r"gemm_tn_kernel.*Im2col"),
+    ("gemm_tn", r"gemm_tn_kernel"), ("gemm_nn(conv)", r"gemm_nn_kernel.*Im2col"), ("gemm_nn", r"gemm_nn_kernel"),
+    ("resample", r"resample"), ("upfirdn/ada", r"upfirdn|ada_"), ("mod_prep", r"mod_"),
+    ("bias_act", r"bias_act|bias_grad"), ("sumsq", r"sum_squares"), ("tail/fourier/coords", r"gen_tail|fourier|coords|downsample_angle"),
+    ("zero", r"dgv2_zero"), ("blas", r"Cijk|rocblas|hipblas"), ("torch_other", r".*")])
+agg = collections.defaultdict(lambda: [0.0, 0])
+for r in rows:
+    name = r["Name"]; t = float(r["TotalDurationNs"]); c = int(r["Calls"])
+    for k, pat in B.items():
+        if re.search(pat, name):
+            agg[k][0] += t; agg[k][1] += c; break
+tot = sum(v[0] for v in agg.values())
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    print(f"{k:28s} {v[0]/1e6/steps:8.3f} ms/step  {v[1]/steps:8.1f} launches/step")
+print(f"{'TOTAL':28s} {tot/1e6/steps:8.3f} ms/step")
+others = [(float(r['TotalDurationNs']), r['Name'], int(r['Calls'])) for r in rows if not any(re.search(p, r['Name']) for p in list(B.values())[:-1])]
+for t, n, c in sorted(others, reverse=True)[:14]:
+    print(f"   other: {t/1e6/steps:7.3f} ms/step x{c/steps:6.1f}  {n[:110]}")
