@@ -528,6 +528,8 @@ def _conv_dgrad_raw(gy, w, g, xshape):
 
 
 _WGRAD_DIRECT_MAXC = int(os.environ.get("DGV2_WGRAD_DIRECT_MAXC", "64"))
+_WGRAD_STREAM = os.environ.get("DGV2_NO_WGRAD_STREAM") is None   # A/B switch for benchmarking
+_WGRAD_SCRATCH = {}
 
 
 def _conv_wgrad_raw(gy, x, g):
@@ -535,6 +537,17 @@ def _conv_wgrad_raw(gy, x, g):
     O = gy.shape[3]
     N.check(gy, x)
     gw = torch.empty((O, g.kh, g.kw, C), device=x.device, dtype=torch.float32)
+    if _WGRAD_STREAM and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2) \
+            and C % (16 // x.element_size()) == 0 and O % (16 // x.element_size()) == 0:
+        key = (B, H, W, C, O, g.kh, g.stride, g.pad, _dt(x))
+        if key not in _WGRAD_SCRATCH:
+            n = _ct.c_int64(0)
+            N.call("dgv2_conv_wgrad_stream_scratch", _ct.addressof(n), B, H, W, C, O, g.kh, g.stride, g.pad, _dt(x))
+            _WGRAD_SCRATCH[key] = n.value
+        scratch = torch.empty(_WGRAD_SCRATCH[key], device=x.device, dtype=torch.float32)
+        N.call("dgv2_conv_wgrad_stream", N.ptr(gw), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(x), B, H, W, C,
+               O, g.kh, g.stride, g.pad, g.ring, _dt(x), N.stream())
+        return gw
     small = C % 32 == 0 and C <= _WGRAD_DIRECT_MAXC and O % 8 == 0 and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0))
     if small and g.stride in (1, 2) and (x.dtype == torch.bfloat16 or g.stride == 1):
         # small-channel / large-image layers: halo-tile engine (input staged once for all nine taps)

@@ -201,6 +201,18 @@ int dgv2_conv_wgrad(float* gw, const void* gy, const void* x, int B, int H, int 
 int dgv2_conv_wgrad_direct(float* gw, const void* gy, const void* x, int B, int H, int W, int C, int O,
                            int k, int stride, int pad, int ring, int dtype, void* stream);
 
+/* Streaming weight gradient -- the hot-path engine for every discriminator conv (same reference lines as
+ * dgv2_conv_wgrad).  A block keeps one (o, c) tile of gw for all k*k taps in registers and streams its
+ * slice of the batch's pixel tiles; the per-slice partial sums go to `scratch` (plain stores) and are
+ * reduced into gw fp32 [O, k*k, C] (overwritten).  k in {1,3}, pad = (k-1)/2, stride in {1,2}, C and O
+ * multiples of the 16-byte vector.  dgv2_conv_wgrad_stream_scratch reports the fp32 element count the
+ * scratch buffer must hold for a geometry. */
+int dgv2_conv_wgrad_stream_scratch(int64_t* elems, int B, int H, int W, int C, int O, int k, int stride,
+                                   int pad, int dtype);
+int dgv2_conv_wgrad_stream(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
+                           int B, int H, int W, int C, int O, int k, int stride, int pad, int ring,
+                           int dtype, void* stream);
+
 /* Direct (LDS halo-tile) convolution with a generic tap list -- the hot-path engine for the
  * discriminator convs and their data gradients (same reference lines as dgv2_conv_*):
  *   y[b, gh*out_stride+ooff_h, gw*out_stride+ooff_w, o] (=|+=) act( sum_t sum_c
