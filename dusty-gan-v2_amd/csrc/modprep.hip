@@ -171,8 +171,11 @@ __device__ __forceinline__ void grad_m(const ModGeom& g, const float* __restrict
   }
 }
 
-// One block per (o, b): gm, then  gWraw[o,i] += gm t_b[i]  (summed over b),  gt[b,i] += gm w'[o,i]
-// (summed over o) with fp32 atomics, corr += sum_i gm t w' (max-norm correction of W).
+// A block owns an OG x BG group of (o, b) pairs: gm per pair, then
+//   gWraw[o,i] += sum_b gm t_b[i],   gt[b,i] += sum_o gm w'[o,i],   corr += sum gm t w'
+// with the sums over the group kept in registers, so the fp32 atomics that combine groups are OG (gt) and
+// BG (gWraw) times fewer than one per pair -- same-address float atomics are what bounds this kernel.
+template <int OG, int BG>
 __global__ __launch_bounds__(PB) void mod_prep_bwd_kernel(float* __restrict__ gWraw, float* __restrict__ gt,
                                                           float* __restrict__ corr, const float* __restrict__ G,
                                                           const float* __restrict__ W, const float* __restrict__ s,
@@ -182,20 +185,50 @@ __global__ __launch_bounds__(PB) void mod_prep_bwd_kernel(float* __restrict__ gW
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ fw, ModGeom g) {
   __shared__ float red[4];
-  const int o = blockIdx.x, b = blockIdx.y;
+  const int o0 = blockIdx.x * OG, b0 = blockIdx.y * BG;
   const float c = 1.f / (sqrtf(ema_var[0]) + 1e-8f);
-  float m[MAXJ], t[MAXJ], wp[MAXJ], gm[MAXJ];
-  mod_row(g, W, s, stats, b, o, m, t, wp);
-  grad_m(g, G, shift, fw, b, o, m, dsave[(int64_t)b * g.O + o], c, red, gm);
+  float gwacc[OG][MAXJ];
+#pragma unroll
+  for (int ol = 0; ol < OG; ++ol)
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) gwacc[ol][j] = 0.f;
   float part = 0.f;
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const int i = threadIdx.x + j * PB;
-    if (i < g.I) {
-      const float gw = gm[j] * t[j];
-      atomicAdd(&gWraw[(int64_t)o * g.I + i], gw);
-      atomicAdd(&gt[(int64_t)b * g.I + i], gm[j] * wp[j]);
-      part += gw * wp[j];
+  for (int bl = 0; bl < BG; ++bl) {
+    const int b = b0 + bl;
+    if (b >= g.B) break;
+    float gtacc[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) gtacc[j] = 0.f;
+#pragma unroll
+    for (int ol = 0; ol < OG; ++ol) {
+      const int o = o0 + ol;
+      if (o >= g.O) break;
+      float m[MAXJ], t[MAXJ], wp[MAXJ], gm[MAXJ];
+      mod_row(g, W, s, stats, b, o, m, t, wp);
+      grad_m(g, G, shift, fw, b, o, m, dsave[(int64_t)b * g.O + o], c, red, gm);
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const float gw = gm[j] * t[j];
+        gwacc[ol][j] += gw;
+        gtacc[j] += gm[j] * wp[j];
+        part += gw * wp[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int i = threadIdx.x + j * PB;
+      if (i < g.I) atomicAdd(&gt[(int64_t)b * g.I + i], gtacc[j]);
+    }
+  }
+#pragma unroll
+  for (int ol = 0; ol < OG; ++ol) {
+    const int o = o0 + ol;
+    if (o >= g.O) break;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int i = threadIdx.x + j * PB;
+      if (i < g.I) atomicAdd(&gWraw[(int64_t)o * g.I + i], gwacc[ol][j]);
     }
   }
   if (g.demod) {
@@ -292,8 +325,18 @@ extern "C" int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float*
   if (e == hipSuccess) e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)O * I, st);
   if (e == hipSuccess) e = hipMemsetAsync(gs, 0, sizeof(float) * (size_t)B * I, st);
   if (e != hipSuccess) return (int)e;
-  dim3 grid(O, B);
-  mod_prep_bwd_kernel<<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g);
+  // group size: as large as keeps >= ~1024 blocks in flight
+  const int64_t pairs = (int64_t)O * B;
+  if (pairs >= 16 * 1024) {
+    dim3 grid((O + 3) / 4, (B + 3) / 4);
+    mod_prep_bwd_kernel<4, 4><<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g);
+  } else if (pairs >= 4 * 1024) {
+    dim3 grid((O + 1) / 2, (B + 1) / 2);
+    mod_prep_bwd_kernel<2, 2><<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g);
+  } else {
+    dim3 grid(O, B);
+    mod_prep_bwd_kernel<1, 1><<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g);
+  }
   if (demod) mod_prep_bwd_s_fix_kernel<<<B, PB, 0, st>>>(gs, s, stats, I);
   mod_prep_bwd_w_fix_kernel<<<grid_for((int64_t)O * I, 256, 256), 256, 0, st>>>(gW, W, stats, corr, O * I, demod,
                                                                               g.scale);

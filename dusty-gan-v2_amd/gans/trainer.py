@@ -102,9 +102,9 @@ class Trainer:
         # counters on the device
         self.use_graphs = bool(cfg.training.get("hip_graph", False))
         self._graphs, self._graph_warm = {}, {}
-        self.optim_G = optim.Adam(self.G.parameters(), lr=lg.alpha * ratio_G, capturable=self.use_graphs,
+        self.optim_G = optim.Adam(self.G.parameters(), lr=lg.alpha * ratio_G, capturable=self.use_graphs, fused=self.device.type == "cuda",
                                   betas=(float(lg.beta1) ** ratio_G, float(lg.beta2) ** ratio_G))
-        self.optim_D = optim.Adam(self.D.parameters(), lr=ld.alpha * ratio_D, capturable=self.use_graphs,
+        self.optim_D = optim.Adam(self.D.parameters(), lr=ld.alpha * ratio_D, capturable=self.use_graphs, fused=self.device.type == "cuda",
                                   betas=(float(ld.beta1) ** ratio_D, float(ld.beta2) ** ratio_D))
         self.x_real = torch.empty(self.B, 1, *self.resolution, device=self.device)  # static input of the graphs
 
