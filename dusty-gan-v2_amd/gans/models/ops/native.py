@@ -530,6 +530,7 @@ def _conv_dgrad_raw(gy, w, g, xshape):
 _WGRAD_DIRECT_MAXC = int(os.environ.get("DGV2_WGRAD_DIRECT_MAXC", "64"))
 _WGRAD_STREAM = os.environ.get("DGV2_NO_WGRAD_STREAM") is None   # A/B switch for benchmarking
 _WGRAD_SCRATCH = {}
+_LIB_WGRAD = os.environ.get("DGV2_NO_LIB_WGRAD") is None         # A/B switch for benchmarking
 
 
 def _conv_wgrad_raw(gy, x, g):
@@ -847,11 +848,24 @@ class _ModLayer(Function):
         if xa is not None and ctx.needs_input_grad[1]:
             wt = wb[:, :, :Ka].transpose(1, 2).contiguous()
             gxa = _bmm_nn_raw(g3, wt, xa.dtype).reshape(xa.shape)
-        gwb = torch.empty((B, Otot, I), device=gy.device, dtype=torch.float32)
-        if xs is not None:
+        gwb = None
+        if xs is not None and _LIB_WGRAD and dt == torch.bfloat16 and P >= 2048:
+            # plain batched GEMMs (K = pixels of one sample, fp32 out): hipBLASLt's split-K kernels beat the
+            # generic dgv2 TN kernel on these long-K / short-M shapes; the batch-shared PE is a stride-0 operand
+            gT = g3.transpose(1, 2)
+            parts = []
+            if xa is not None:
+                parts.append(torch.bmm(gT, xa.reshape(B, P, Ka), out_dtype=torch.float32))
+            parts.append(torch.bmm(gT, xs.reshape(1, P, -1).expand(B, P, xs.shape[3]), out_dtype=torch.float32))
+            gwb = torch.cat(parts, dim=2) if len(parts) > 1 else parts[0]
+        if gwb is not None:
+            pass
+        elif xs is not None:
+            gwb = torch.empty((B, Otot, I), device=gy.device, dtype=torch.float32)
             N.call("dgv2_bmm_tn_cat", N.ptr(gwb), N.ptr(g3), N.ptr(xa), N.ptr(xs), B, P, Ka, xs.shape[3], Otot,
                    _dt(xs), N.stream())
         else:
+            gwb = torch.empty((B, Otot, I), device=gy.device, dtype=torch.float32)
             N.call("dgv2_bmm_tn", N.ptr(gwb), N.ptr(g3), N.ptr(xa.reshape(B, P, I)), B, P, I, Otot, Otot, I, _dt(xa),
                    N.stream())
         grads = []
