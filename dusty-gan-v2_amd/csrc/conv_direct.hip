@@ -42,6 +42,8 @@ struct DConv {
   int tpb;          // tiles per block along W (pipelined kernel)
   float inv_cols;   // 1 / cols
   const float* bias;
+  void* ybase;         // = y (lets the epilogue address resid at the same offset)
+  const void* resid;   // optional residual, same layout as y: added before bias / activation
   int act;
   float alpha, scale;
 };
@@ -49,11 +51,13 @@ struct DConv {
 // Epilogue shared by both kernels: one accumulator fragment (16 channels x 16 positions) -> y.
 template <typename T>
 __device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, int o, f32x4 v) {
+  const T* rrow = p.resid ? reinterpret_cast<const T*>(p.resid) + (row - reinterpret_cast<T*>(p.ybase)) : nullptr;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (o + r >= p.O) continue;
     float f = v[r];
     if (p.accumulate) f += to_f32(row[o + r]);
+    if (rrow) f += to_f32(rrow[o + r]);
     if (p.bias) f += p.bias[o + r];
     if (p.act == 3) f = (f > 0.f ? f : f * p.alpha) * p.scale;
     v[r] = f;
@@ -406,8 +410,8 @@ int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, hipStre
 extern "C" int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg, int Wg,
                               int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w, int out_stride,
                               int ooff_h, int ooff_w, int ntaps, int wtaps, const int* taps_host, int hzero, int ring,
-                              int accumulate, const float* bias, int act, float alpha, float scale, int dtype,
-                              void* stream) {
+                              int accumulate, const float* bias, const void* resid, int act, float alpha,
+                              float scale, int dtype, void* stream) {
   if (!y || !x || !w || !taps_host || ntaps < 1 || ntaps > 9 || wtaps < 1) return DGV2_EINVAL;
   if (B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Hg <= 0 || Wg <= 0 || O <= 0 || in_stride < 1 || out_stride < 1)
     return DGV2_EINVAL;
@@ -434,7 +438,7 @@ extern "C" int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int 
   p.cols = dxmax - dxmin + 1;
   p.hzero = hzero; p.ring = ring; p.accumulate = accumulate;
   p.tpb = 1; p.inv_cols = 0.f;
-  p.bias = bias; p.act = act; p.alpha = alpha; p.scale = scale;
+  p.bias = bias; p.resid = resid; p.ybase = y; p.act = act; p.alpha = alpha; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
   static const bool no_pipe = getenv("DGV2_NO_PIPE") != nullptr;   // A/B switch for benchmarking

@@ -330,9 +330,17 @@ class ResidualBlock(nn.Module):
 
     def forward_cl(self, x):
         h = self.conv1.forward_cl(x, act=self.bias_act1)
+        c = 1.0 / math.sqrt(2)
+        xs = native.resample(x, self.blur_down)
+        if native.conv_resid_ok(xs, self.skip_geom) and self.skip._params()[1] is None:
+            # (act(z) * sqrt2 + skip) / sqrt2 == act(z) * 1 + skip / sqrt2: the residual scale folds into the
+            # activation gain and the skip weights, the sum into the skip conv's epilogue
+            h = self.conv2.forward_cl(self.resample.forward_cl(h), act=self.bias_act2,
+                                      act_scale=self.bias_act2.scale * c)
+            return self.skip.forward_cl(xs, geom=self.skip_geom, resid=h, wscale=c)
         h = self.conv2.forward_cl(self.resample.forward_cl(h), act=self.bias_act2)
-        s = self.skip.forward_cl(native.resample(x, self.blur_down), geom=self.skip_geom)
-        return (h + s) * (1.0 / math.sqrt(2))
+        s = self.skip.forward_cl(xs, geom=self.skip_geom)
+        return (h + s) * c
 
     def forward(self, x):
         return ops.from_cl(self.forward_cl(ops.to_cl(x)))

@@ -141,7 +141,7 @@ class Conv2d(nn.Sequential):
             return last.effective_weight(), last.module.bias, last.gain_
         return last.weight, last.bias, 1.0
 
-    def forward_cl(self, x, pad_in_to=None, act=None, geom=None):
+    def forward_cl(self, x, pad_in_to=None, act=None, geom=None, act_scale=None, resid=None, wscale=None):
         """act: a FusedLeakyReLU module fused into the conv epilogue; geom overrides the stride
         (used when the caller has already decimated the input)."""
         w, b, gain = self._params()
@@ -149,8 +149,14 @@ class Conv2d(nn.Sequential):
         if pad_in_to is not None and pad_in_to > w.shape[3]:
             w = F.pad(w, (0, pad_in_to - w.shape[3]))
         geom = self.geom if geom is None else geom
+        if wscale is not None:
+            w = w * wscale
+        if resid is not None:   # conv(x, w) + resid in one launch (bias-free, activation-free skip conv)
+            assert b is None and act is None
+            return native.conv_ring_resid(x, w.contiguous(), resid, geom)
         if act is not None and b is None and act.bias is not None:
-            return native.conv_ring_act(x, w.contiguous(), act.bias, geom, act.negative_slope, act.scale)
+            return native.conv_ring_act(x, w.contiguous(), act.bias, geom, act.negative_slope,
+                                        act.scale if act_scale is None else act_scale)
         y = native.conv_ring(x, w.contiguous(), geom)
         if b is not None:
             y = y + (b * gain).to(y.dtype)

@@ -440,7 +440,7 @@ def _kstep(t):
 
 
 def _conv_taps(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, ooff, taps, hzero, accumulate=False,
-               bias=None, act=0, alpha=0.2, scale=1.0):
+               bias=None, act=0, alpha=0.2, scale=1.0, resid=None):
     """Direct halo-tile conv with a tap list (dgv2_conv_taps).  x [B,Hin,Win,Cin]; w3 [O,wtaps,Cin];
     y [B,Hy,Wy,O]; taps: list of (dy, dx, widx)."""
     B, Hin, Win, Cin = x.shape
@@ -449,7 +449,7 @@ def _conv_taps(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, ooff, taps, hzero,
     arr = (_ct.c_int * (3 * len(taps)))(*[v for t in taps for v in t])
     N.call("dgv2_conv_taps", N.ptr(y), N.ptr(x), N.ptr(w3), B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy, in_stride,
            ioff[0], ioff[1], out_stride, ooff[0], ooff[1], len(taps), wtaps, arr, int(hzero), 1, int(accumulate),
-           N.ptr(bias), act, alpha, scale, _dt(x), N.stream())
+           N.ptr(bias), N.ptr(resid), act, alpha, scale, _dt(x), N.stream())
 
 
 def _direct_ok(g, cin):
@@ -458,7 +458,7 @@ def _direct_ok(g, cin):
     return bool(g.ring) and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2) and cin
 
 
-def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0):
+def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None):
     B, H, W, C = x.shape
     O = w.shape[0]
     Ho, Wo = g.out_hw(H, W)
@@ -467,8 +467,10 @@ def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0):
     if _direct_ok(g, C % _kstep(x) == 0):
         taps = [(ky - g.pad, kx - g.pad, ky * g.kw + kx) for ky in range(g.kh) for kx in range(g.kw)]
         _conv_taps(y, x, w.reshape(O, g.kh * g.kw, C), Ho, Wo, g.stride, (0, 0), 1, (0, 0), taps, False,
-                   bias=bias, act=act, alpha=alpha, scale=scale)
+                   bias=bias, act=act, alpha=alpha, scale=scale, resid=resid)
         return y
+    if resid is not None:
+        raise RuntimeError("dgv2: fused residual needs the direct conv engine (ring padding, Cin % K-step == 0)")
     N.call("dgv2_conv_fwd", N.ptr(y), N.ptr(x), N.ptr(w), B, H, W, C, O, g.kh, g.kw, g.stride, g.pad, g.ring,
            N.ptr(bias), act, alpha, scale, _dt(x), N.stream())
     return y
@@ -637,6 +639,35 @@ class _ConvAct(Function):
         gx = _ConvDgrad.apply(gpre, w, g, tuple(x.shape)) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gpre, x, g) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None
+
+
+class _ConvResid(Function):
+    """conv(x, w) + resid with the residual added in the conv epilogue (reference: the skip sum of
+    ResidualBlock.forward, dusty_v2.py:343-345)."""
+
+    @staticmethod
+    def forward(ctx, x, w, resid, g):
+        x = x.contiguous()
+        resid = resid.contiguous()
+        wc = w.detach().to(x.dtype).contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.g = g
+        return _conv_fwd_raw(x, wc, g, resid=resid)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _ConvDgrad.apply(gy, w, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g) if ctx.needs_input_grad[1] else None
+        return gx, gw, (gy if ctx.needs_input_grad[2] else None), None
+
+
+def conv_ring_resid(x, w, resid, geom):
+    return _ConvResid.apply(x, w, resid, geom)
+
+
+def conv_resid_ok(x, geom):
+    return _direct_ok(geom, x.shape[3] % _kstep(x) == 0)
 
 
 def conv_ring_act(x, w, bias, geom, alpha=0.2, scale=math.sqrt(2.0)):

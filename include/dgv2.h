@@ -223,12 +223,14 @@ int dgv2_conv_wgrad_stream(float* gw, float* scratch, int64_t scratch_elems, con
  * forward conv: taps (ky-pad, kx-pad), in_stride = stride; stride-1 dgrad: taps (1-ky, 1-kx) on gy
  * with transposed weights; stride-2 dgrad: one launch per output parity class (out_stride = 2);
  * replicate-row border terms: one-row launches with accumulate = 1.
- * Cin must be a multiple of 32 (bf16) / 16 (fp32). */
+ * Cin must be a multiple of 32 (bf16) / 16 (fp32).  resid (optional, layout of y) is added to the
+ * accumulator before bias / activation: the residual sum of ResidualBlock (dusty_v2.py:343-345) costs
+ * no extra pass. */
 int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int Hin, int Win, int Cin,
                    int Hg, int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w,
                    int out_stride, int ooff_h, int ooff_w, int ntaps, int wtaps, const int* taps_host,
-                   int hzero, int ring, int accumulate, const float* bias, int act, float alpha,
-                   float scale, int dtype, void* stream);
+                   int hzero, int ring, int accumulate, const float* bias, const void* resid, int act,
+                   float alpha, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * generator output stage: cancel the azimuth shift (circular bilinear shift),
