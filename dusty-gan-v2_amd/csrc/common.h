@@ -36,6 +36,28 @@ template <typename T> struct vec16 {
   __device__ __forceinline__ void set(int i, float v) { e[i] = from_f32<T>(v); }
 };
 
+// Two accumulator fragments of the 16x16 MFMA D layout for the SAME 16 pixels and two consecutive
+// 16-channel blocks (lane holds channels 4*lc..4*lc+3 of each block at pixel lr, lc = lane >> 4) leave as ONE
+// 16-byte bf16 store per lane: lanes lc and lc^1 swap one packed quad, after which an even-lc lane owns
+// channels [4*lc, 4*lc+8) of block A and an odd-lc lane channels [4*(lc-1), 4*(lc-1)+8) of block B.  A store
+// instruction then writes whole 64-byte runs per pixel instead of four 8-byte pieces of two half-lines.
+// Returns the channel offset (relative to block A's first channel) of the 8 channels in `out`.
+__device__ __forceinline__ int pack_pair_bf16(const float (&va)[4], const float (&vb)[4], int lc, uint4& out) {
+  union { uint2 u; bf16_t e[4]; } pa, pb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    pa.e[r] = (bf16_t)va[r];
+    pb.e[r] = (bf16_t)vb[r];
+  }
+  const bool odd = lc & 1;
+  const uint2 send = odd ? pa.u : pb.u;
+  uint2 recv;
+  recv.x = __shfl_xor((int)send.x, 16, 64);
+  recv.y = __shfl_xor((int)send.y, 16, 64);
+  out = odd ? make_uint4(recv.x, recv.y, pb.u.x, pb.u.y) : make_uint4(pa.u.x, pa.u.y, recv.x, recv.y);
+  return odd ? 16 + 4 * (lc - 1) : 4 * lc;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Floor division / modulo for possibly negative numerators (b > 0).

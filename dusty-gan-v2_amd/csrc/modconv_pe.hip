@@ -1,0 +1,211 @@
+// Level-input modulated 1x1 conv of the generator on the batch-shared positional encoding -- the
+// kernel the top pyramid levels spend their time in:
+//   y[b,p,o] = act( sum_{k<Ka} xa[b,p,k] w[b,o,k] + sum_{k<Ks} xs[p,k] w[b,o,Ka+k] + bias[o] ) * scale
+// reference: torch.cat([h, pe]) + ModConv2d contraction + FusedLeakyReLU, gans/models/dusty_v2.py:153-162,
+// gans/models/ops/style.py:105-118 (same contract as dgv2_bmm_nn_cat, include/dgv2.h).
+//
+// At level 4 (32768 pixels, Ka = 64, Ks = 512, O = 32) the contraction is 77 GFLOP per 64-sample batch
+// against 0.4 GB of compulsory HBM traffic (xa in, y out) -- provided the 33 MB PE operand is NOT re-read
+// per sample.  The generic GEMM re-streams it through L2 for every sample (2.1 GB) and is bound by that.
+// Here the roles are turned round: a block owns a tile of pixels and walks the SAMPLES.
+//   * PE operand: each wave keeps the MFMA B-fragments of its 16*NFW pixels x all Ks channels in REGISTERS
+//     for the whole walk (loaded once, straight from global in fragment shape: one 16-byte K-chunk per lane).
+//   * xa operand: per sample, fragment-shaped global loads straight to registers, prefetched one sample ahead.
+//   * per-sample weights w[b] (O x (Ka+Ks), the only operand all waves share): two LDS buffers in the
+//     swizzled [kchunk][o][64 B] image of gemm_core.h, filled one sample ahead by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers -- the PE fragments own the register file -- with the
+//     swizzle applied on the source address), one raw barrier + counted vmcnt per sample.
+// LDS traffic is A-fragments only; HBM traffic is xa + y (+ PE once per block).
+#include <type_traits>
+
+#include "gemm_core.h"
+
+namespace {
+
+struct MPGeom {
+  int B, P, Ka, Ks, O, I;
+  int samples_per_block;
+  int ablate;   // benchmarking only (DGV2_MP_ABLATE): 1 skip stores, 2 skip MFMA loop, 4 skip weight staging, 8 skip xa loads
+  const float* bias;
+  int act;
+  float alpha, scale;
+};
+
+// MF = O / 16, NFW = 16-pixel fragments per wave, KA = Ka / 32, KS = Ks / 32 (compile-time: register arrays)
+template <int MF, int NFW, int KA, int KS>
+__global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ xa,
+                                                                const bf16_t* __restrict__ xs,
+                                                                const bf16_t* __restrict__ w, MPGeom g) {
+  constexpr int O = MF * 16, KC = KA + KS, I = KC * 32;
+  constexpr int NSLOT = O * KC * 4;                 // 16-byte slots of one sample's weights
+  constexpr int NW = (NSLOT + 511) / 512;
+  constexpr int WBUF = NW * 512;                    // slots per weight buffer (padded to whole DMA pieces)
+  constexpr int TP = 8 * 16 * NFW;                  // pixels per block
+  extern __shared__ __attribute__((aligned(16))) uint4 lds_w[];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lc = lane >> 4;
+  const int p0 = blockIdx.x * TP + wave * 16 * NFW;
+  const int b0 = blockIdx.y * g.samples_per_block;
+  const int b1 = min(b0 + g.samples_per_block, g.B);
+
+  // ---- PE fragments: registers for the whole block ----
+  uint4 pe[NFW][KS];
+#pragma unroll
+  for (int nf = 0; nf < NFW; ++nf) {
+    const int px = min(p0 + nf * 16 + lr, g.P - 1);   // clamped: pixels past the end are computed, never stored
+#pragma unroll
+    for (int kc = 0; kc < KS; ++kc)
+      pe[nf][kc] = *reinterpret_cast<const uint4*>(xs + (int64_t)px * g.Ks + kc * 32 + lc * 8);
+  }
+
+  float bias_r[MF][4];            // this lane's output channels: mf*16 + lc*4 + r
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias_r[mf][r] = g.bias ? g.bias[mf * 16 + lc * 4 + r] : 0.f;
+  constexpr int KAR = KA > 0 ? KA : 1;
+  uint4 xr[2][NFW][KAR];            // xa fragments of samples b, b+1
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef __attribute__((address_space(1))) const void gbl_void_t;
+  // LDS-DMA of sample b's weights into buffer `buf`: piece j of wave `wave` lands at slots [j*512 + wave*64, +64);
+  // LDS slot L = (kc*O + r)*4 + p holds logical chunk p ^ ((r>>2)&3) of row r (swizzle on the source side)
+  auto dma_w = [&](int b, int buf) {
+    const bf16_t* wb = w + (int64_t)b * O * I;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int L = min(tid + j * 512, NSLOT - 1);   // surplus lanes of the last piece land in the pad
+      const int chp = (L & 3) ^ ((L >> 4) & 3), r = (L >> 2) % O, kc = (L >> 2) / O;
+      const bf16_t* src = wb + r * I + kc * 32 + chp * 8;
+      uint4* dst = lds_w + buf * WBUF + j * 512 + wave * 64;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    }
+  };
+  auto issue_x = [&](auto slot, int b) {
+    if constexpr (KA > 0) {
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) {
+        const int px = min(p0 + nf * 16 + lr, g.P - 1);
+        const int bc = min(b, b1 - 1);               // branch-free: the tail re-reads the last sample
+#pragma unroll
+        for (int kc = 0; kc < KA; ++kc)
+          xr[slot.value][nf][kc] =
+              *reinterpret_cast<const uint4*>(xa + ((int64_t)bc * g.P + px) * g.Ka + kc * 32 + lc * 8);
+      }
+    }
+  };
+  const int aswz = lc ^ ((lr >> 2) & 3);
+
+  // one sample: weights of sample b are in rw, its xa fragments in ring slot `slot`
+  auto step = [&](auto slot, int b) {
+    constexpr int S = decltype(slot)::value;
+    const uint4* wbuf = lds_w + S * WBUF;
+    // weights of sample b: this wave's DMA pieces were issued a sample ago, followed by NFW*KA xa loads
+    // (+ that sample's stores); in-order retirement makes vmcnt(NFW*KA) sufficient for the DMA
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFW * KAR) : "memory");
+    __builtin_amdgcn_s_barrier();   // all pieces landed; every wave is done with the other buffer
+    asm volatile("" ::: "memory");
+    if (!(g.ablate & 4)) dma_w(min(b + 1, b1 - 1), S ^ 1);
+    if (!(g.ablate & 8)) issue_x(std::integral_constant<int, S ^ 1>{}, b + 1);
+
+    f32x4 acc[MF][NFW];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!(g.ablate & 2))
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      uint4 a[MF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) a[mf] = wbuf[(kc * O + mf * 16 + lr) * 4 + aswz];
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) {
+        const uint4 bf = kc < KA ? xr[S][nf][kc < KA ? kc : 0] : pe[nf][kc >= KA ? kc - KA : 0];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) Mfma16<bf16_t>::run(acc[mf][nf], a[mf], bf);
+      }
+    }
+
+    // epilogue: lane holds o = mf*16 + lc*4 + r at pixel nf*16 + lr; fragment pairs leave as 16-byte stores
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) {
+      const int px = p0 + nf * 16 + lr;
+      const bool live = px < g.P && !((g.ablate & 1) && acc[0][0][0] != 12345.678f);
+      bf16_t* row = y + ((int64_t)b * g.P + px) * O;
+#pragma unroll
+      for (int mf = 0; mf < MF; mf += 2) {
+        float va[4], vb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float fa = acc[mf][nf][r], fb = acc[mf + 1][nf][r];
+          fa += bias_r[mf][r];
+          fb += bias_r[mf + 1][r];
+          if (g.act == 3) {
+            fa = (fa > 0.f ? fa : fa * g.alpha) * g.scale;
+            fb = (fb > 0.f ? fb : fb * g.alpha) * g.scale;
+          }
+          va[r] = fa;
+          vb[r] = fb;
+        }
+        uint4 pk;
+        const int co = pack_pair_bf16(va, vb, lc, pk);   // all lanes take part in the exchange
+        if (live) *reinterpret_cast<uint4*>(row + mf * 16 + co) = pk;
+      }
+    }
+  };
+
+  if (b0 < b1) {
+    dma_w(b0, 0);
+    issue_x(std::integral_constant<int, 0>{}, b0);
+  }
+  for (int b = b0; b < b1; b += 2) {
+    step(std::integral_constant<int, 0>{}, b);
+    if (b + 1 < b1) step(std::integral_constant<int, 1>{}, b + 1);
+  }
+}
+
+template <int MF, int NFW, int KA, int KS>
+int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, hipStream_t st) {
+  constexpr int TP = 8 * 16 * NFW;
+  const int tiles = (g.P + TP - 1) / TP;
+  // one resident block per CU (the PE fragments fill the register file): one round of blocks, as few sample
+  // splits (= PE reloads) as that allows
+  static const int target = getenv("DGV2_MP_BLOCKS") ? atoi(getenv("DGV2_MP_BLOCKS")) : 256;
+  int nsplit = (target + tiles - 1) / tiles;
+  nsplit = nsplit < 1 ? 1 : (nsplit > g.B ? g.B : nsplit);
+  g.samples_per_block = (g.B + nsplit - 1) / nsplit;
+  nsplit = (g.B + g.samples_per_block - 1) / g.samples_per_block;
+  dim3 grid(tiles, nsplit);
+  constexpr size_t lds = sizeof(uint4) * 2 * (size_t)(((MF * 16) * (KA + KS) * 4 + 511) / 512 * 512);
+  auto kern = modconv_pe_fwd_kernel<MF, NFW, KA, KS>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  kern<<<grid, 512, lds, st>>>((bf16_t*)y, (const bf16_t*)xa, (const bf16_t*)xs,
+                                                             (const bf16_t*)w, g);
+  return 0;
+}
+
+}  // namespace
+
+// Same contract as dgv2_bmm_nn_cat (bf16 in / bf16 out) for the shapes of the two top generator levels:
+// (Ka, Ks, O) = (64, 512, 32) (level 4; the two weight buffers of other shapes do not fit LDS).  Returns DGV2_EINVAL for anything else: callers fall back to
+// dgv2_bmm_nn_cat.
+extern "C" int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
+                                   int Ks, int O, const float* bias, int act, float alpha, float scale, int dtype,
+                                   void* stream) {
+  if (!y || !xs || !w || (Ka > 0 && !xa) || B <= 0 || P <= 0) return DGV2_EINVAL;
+  if (dtype != DGV2_BF16 || (act != 0 && act != 3)) return DGV2_EINVAL;
+  if (!aligned16(y) || !aligned16(xa) || !aligned16(xs) || !aligned16(w)) return DGV2_EINVAL;
+  static const int abl = getenv("DGV2_MP_ABLATE") ? atoi(getenv("DGV2_MP_ABLATE")) : 0;
+  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, abl, bias, act, alpha, scale};
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (Ka == 64 && Ks == 512 && O == 32) rc = mp_launch<2, 2, 2, 16>(y, xa, xs, w, g, st);
+  else return DGV2_EINVAL;
+  if (rc) return rc;
+  DGV2_RETURN_LAST();
+}

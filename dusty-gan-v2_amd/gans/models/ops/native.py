@@ -532,6 +532,7 @@ def _conv_dgrad_raw(gy, w, g, xshape):
 _WGRAD_DIRECT_MAXC = int(os.environ.get("DGV2_WGRAD_DIRECT_MAXC", "64"))
 _WGRAD_STREAM = os.environ.get("DGV2_NO_WGRAD_STREAM") is None   # A/B switch for benchmarking
 _WGRAD_SCRATCH = {}
+_PE_FWD = os.environ.get("DGV2_NO_PE_FWD") is None               # A/B switch for benchmarking
 _LIB_WGRAD = os.environ.get("DGV2_NO_LIB_WGRAD") is None         # A/B switch for benchmarking
 
 
@@ -841,8 +842,13 @@ class _ModLayer(Function):
             Ka = 0 if xa is None else xa.shape[3]
             out = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
             N.check(xa, xs, wb, bias32)
-            N.call("dgv2_bmm_nn_cat", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3], Otot,
-                   N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs), N.stream())
+            if _PE_FWD and dt == torch.bfloat16 and (Ka, xs.shape[3], Otot) == (64, 512, 32):
+                # top pyramid levels: pixel-tile blocks walking the samples, PE fragments in registers
+                N.call("dgv2_modconv_pe_fwd", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3],
+                       Otot, N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), N.stream())
+            else:
+                N.call("dgv2_bmm_nn_cat", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3], Otot,
+                       N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs), N.stream())
         else:
             xa = xa.contiguous()
             out = _bmm_nn_raw(xa.reshape(B, P, I), wb, odt, bias32, act, cfg["alpha"], cfg["scale"]).reshape(

@@ -153,6 +153,14 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
 int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, int B, int P, int Ka, int Ks,
                     int O, int dtype, void* stream);
 
+/* The same contraction as dgv2_bmm_nn_cat, organised for the two top pyramid levels where it dominates
+ * the generator ((Ka, Ks, O) = (64, 512, 32), bf16): a block owns a tile of pixels and walks the
+ * samples, the shared PE fragments stay in registers, xa streams straight into registers and only the
+ * per-sample weights go through LDS (LDS-DMA, double-buffered) -- HBM sees xa and y once, the PE once per block.
+ * Returns DGV2_EINVAL for any other shape / dtype (use dgv2_bmm_nn_cat). */
+int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
+                        int O, const float* bias, int act, float alpha, float scale, int dtype, void* stream);
+
 /* Per-sample weights of the modulated conv, written directly as the GEMM operand, and the exact
  * backward of that preparation (max-normalisations, modulation, demodulation, input-magnitude
  * scaling, optional rotation of the positional-encoding columns by shift_b * fw).

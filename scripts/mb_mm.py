@@ -28,3 +28,12 @@ for (P,Ka,Ks,O) in [(32768,64,0,32),(32768,64,512,32),(8192,128,0,64),(8192,128,
     wa=w[:,:,:Ka].contiguous()
     line+=f"| own fwd(xa) {t(lambda: nat._bmm_nn_raw(xa, wa, bf, None, 0, 0.2, 1.0)):6.1f} "
     print(line)
+
+# dgv2_modconv_pe_fwd vs dgv2_bmm_nn_cat on the two top levels
+for (P,Ka,Ks,O) in [(32768,64,512,32)]:
+    xa=torch.randn(B,P,Ka,device="cuda",dtype=bf); xs=torch.randn(P,Ks,device="cuda",dtype=bf); w=torch.randn(B,O,Ka+Ks,device="cuda",dtype=bf)
+    bias=torch.randn(O,device="cuda"); y=torch.empty(B,P,O,device="cuda",dtype=bf)
+    t_new=t(lambda: N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks, O, N.ptr(bias), 3, 0.2, 1.414, N.BF16, N.stream()))
+    t_old=t(lambda: N.call("dgv2_bmm_nn_cat", N.ptr(y), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks, O, N.ptr(bias), 3, 0.2, 1.414, N.BF16, N.BF16, N.stream()))
+    fl=2.0*B*P*(Ka+Ks)*O
+    print(f"modconv P{P} Ka{Ka} Ks{Ks} O{O}: pe_fwd {t_new:7.1f}us ({fl/t_new/1e6:6.0f} TF/s)   bmm_nn_cat {t_old:7.1f}us ({fl/t_old/1e6:6.0f} TF/s)")

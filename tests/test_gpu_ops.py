@@ -196,6 +196,38 @@ def test_bmm_bf16_random_tolerance(nat):
     assert_rel(y.float().cpu(), want, 8e-3)
 
 
+@pytest.mark.parametrize("Ka,Ks,O,P,B", [(64, 512, 32, 700, 5), (64, 512, 32, 256, 2)])
+def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
+    """dgv2_modconv_pe_fwd (pixel-tile blocks walking the samples, shared PE in registers) against the
+    einsum of the reference's cat([h, pe]) + per-sample 1x1 conv + bias + lrelu (dusty_v2.py:153-162,
+    style.py:105-118): exact on integer operands, bf16 tolerance on random ones; ragged pixel tile."""
+    import dgv2_native as N
+    g = torch.Generator().manual_seed(11)
+    for exact in (True, False):
+        if exact:
+            xa = torch.randint(-2, 3, (B, P, Ka), generator=g).float()
+            xs = torch.randint(-2, 3, (P, Ks), generator=g).float()
+            w = torch.randint(-2, 3, (B, O, Ka + Ks), generator=g).float()
+            bias = torch.randint(-4, 5, (O,), generator=g).float()
+        else:
+            xa, xs = torch.randn(B, P, Ka, generator=g), torch.randn(P, Ks, generator=g)
+            w, bias = torch.randn(B, O, Ka + Ks, generator=g) / 8, torch.randn(O, generator=g)
+        xad, xsd, wd = (t.to(DEV).bfloat16().contiguous() for t in (xa, xs, w))
+        bd = bias.to(DEV)
+        for act in (0, 3):
+            y = torch.full((B, P, O), float("nan"), device=DEV, dtype=torch.bfloat16)
+            N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(xad), N.ptr(xsd), N.ptr(wd), B, P, Ka, Ks, O, N.ptr(bd), act,
+                   0.2, math.sqrt(2.0), N.BF16, N.stream())
+            xcat = torch.cat([xad.double().cpu(), xsd.double().cpu()[None].expand(B, P, Ks)], dim=2)
+            want = torch.einsum("bpi,boi->bpo", xcat, wd.double().cpu()) + bias.double()
+            if act == 3:
+                want = torch.where(want > 0, want, want * 0.2) * math.sqrt(2.0)
+            if exact and act == 0:
+                assert torch.equal(y.float().cpu(), want.float().bfloat16().float())
+            else:
+                assert_rel(y.float().cpu(), want, 8e-3)
+
+
 # ---------------------------------------------------------------------------------------
 CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     (2, 8, 16, 8, 16, 3, 1, 1, True),
