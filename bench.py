@@ -63,7 +63,7 @@ def make_cfg(args, rank, world):
     return cfg
 
 
-def cpu_baseline(batch, steps=2):
+def cpu_baseline(batch, steps=4):
     """The CPU oracle (oracle/step.py, a port of the reference's CPU path pinned by golden vectors)
     timed on this host: full-size dusty_v2, fp32, one iteration = G step + D step, ADA at p=0.6."""
     import numpy as np
@@ -72,7 +72,9 @@ def cpu_baseline(batch, steps=2):
     from oracle import step as o_step
     import recipe
 
-    cores = os.cpu_count() or 1
+    # the oracle's many small ATen ops scale to about a dozen threads; on the 256-core GPU host an unbounded
+    # pool makes every op slower than 8 threads do, so the pool is capped and `cores` reports the cap
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     cfg = full_cfg()
     G, D = build_models(cfg, "cpu")
@@ -105,31 +107,79 @@ def cpu_baseline(batch, steps=2):
                       f"of oracle/step.py after 1 warm-up; {dt:.2f} s/iteration"}
 
 
-def roofline_probe(args, reps=20):
-    """Roofline of the MFMA kernel north_star names: the modulated-conv contraction
-    gemm_nn_kernel (dgv2_bmm_nn) at the level-4 conv1 shape of the benchmarked batch
-    (B x 32768 pixels, I = 576, O = 32).  Timed live with HIP events on the launching stream.
-    Algorithmic FLOPs per launch = 2 * B * P * I * O (604 MMAC/img)."""
-    from gans.models.ops import native
-    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    B, P, I, O = args.batch_per_gpu, 64 * 512, 576, 32
-    x = torch.randn(B, P, I, device="cuda", dtype=dt)
-    w = torch.randn(B, O, I, device="cuda", dtype=dt)
+def _time_launches(fn, reps):
+    """Average duration of `reps` back-to-back launches, HIP events on the launching (= torch current) stream."""
     for _ in range(3):
-        native._bmm_nn_raw(x, w, dt)
+        fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps):
-        native._bmm_nn_raw(x, w, dt)
+        fn()
     e.record()
     torch.cuda.synchronize()
-    sec = s.elapsed_time(e) * 1e-3 / reps
-    flops = 2.0 * B * P * I * O
-    bytes_ = (B * P * I + B * O * I + B * P * O) * x.element_size()
-    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
-    return {"kernel": "gemm_nn_kernel (dgv2_bmm_nn, modconv level-4 conv1)", "bound": "mfma",
-            "achieved": flops / sec / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / peak,
-            "traffic": None, "avg_launch_us": sec * 1e6, "algorithmic_hbm_GBps": bytes_ / sec / 1e9}
+    return s.elapsed_time(e) * 1e-3 / reps
+
+
+def _pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed PMC passes (profiles/round1_pmc.json: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of scripts/pmc_probe.py, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no matching record is committed."""
+    path = os.path.join(ROOT, "profiles", "round1_pmc.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get(kernel_key)
+    return None if rec is None else rec.get("traffic_bytes_per_launch")
+
+
+def roofline_probe(args, reps=20):
+    """Roofline of the DOMINANT kernel of the step (largest share of GPU time in
+    profiles/round1_*_kernel_stats.csv): conv_pipe_kernel, the direct halo-tile conv engine behind
+    dgv2_conv_taps, at its most expensive call site -- the first ResidualBlock's conv1 in the D step
+    (real + fake = 2 x batch images, 64 x 512, 32 -> 32 channels, 3x3, ring padding, bias + lrelu fused).
+    HBM-bound: algorithmic bytes per image = H*W*(C + O)*2 B = 4.19 MB, per launch
+    2 x batch images + the 18 KB of weights."""
+    from gans.models.ops import native
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    B, H, W, C, O = 2 * args.batch_per_gpu, 64, 512, 32, 32
+    g = native.ConvGeom(3, 3, 1, 1, True)
+    x = torch.randn(B, H, W, C, device="cuda", dtype=dt)
+    w = torch.randn(O, 3, 3, C, device="cuda", dtype=dt)
+    bias = torch.randn(O, device="cuda")
+    sec = _time_launches(lambda: native._conv_fwd_raw(x, w, g, bias, 3, 0.2, 2.0 ** 0.5), reps)
+    nbytes = (B * H * W * (C + O) + O * 9 * C) * x.element_size()
+    flops = 2.0 * B * H * W * C * O * 9
+    ach = nbytes / sec / 1e9
+    return {"kernel": "conv_pipe_kernel (dgv2_conv_taps: D block-0 conv1 fwd, 2B x 64x512, 32->32, 3x3 ring, bias+lrelu)",
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+            "traffic": _pmc_traffic("conv_pipe_kernel"), "algorithmic_bytes_per_launch": nbytes,
+            "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12}
+
+
+def modconv_probe(args, reps=20):
+    """The MFMA kernel north_star names: the modulated 1x1 conv at its heaviest shape, generator level 4
+    conv1 (dgv2_modconv_pe_fwd: B x 32768 pixels, K = 64 + 512 shared-PE channels, O = 32, bias + lrelu).
+    Algorithmic FLOPs per launch = 2*B*P*K*O (604 MMAC/img); compulsory HBM bytes =
+    xa in + y out (the PE is batch-shared)."""
+    if args.dtype != "bf16":
+        return None
+    import dgv2_native as N
+    B, P, Ka, Ks, O = args.batch_per_gpu, 64 * 512, 64, 512, 32
+    bf = torch.bfloat16
+    xa = torch.randn(B, P, Ka, device="cuda", dtype=bf)
+    xs = torch.randn(P, Ks, device="cuda", dtype=bf)
+    w = torch.randn(B, O, Ka + Ks, device="cuda", dtype=bf)
+    bias = torch.randn(O, device="cuda")
+    y = torch.empty(B, P, O, device="cuda", dtype=bf)
+    sec = _time_launches(lambda: N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks,
+                                        O, N.ptr(bias), 3, 0.2, 2.0 ** 0.5, N.BF16, N.stream()), reps)
+    flops = 2.0 * B * P * (Ka + Ks) * O
+    nbytes = (B * P * (Ka + O) + P * Ks + B * O * (Ka + Ks)) * 2
+    ach = flops / sec / 1e12
+    return {"kernel": "modconv_pe_fwd_kernel (dgv2_modconv_pe_fwd: G level-4 conv1, B x 32768 px, K=64+512, O=32)",
+            "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": _pmc_traffic("modconv_pe_fwd_kernel"),
+            "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6,
+            "algorithmic_hbm_GBps": nbytes / sec / 1e9}
 
 
 def main():
@@ -175,6 +225,7 @@ def main():
     value = imgs / dt
 
     roof = roofline_probe(args) if rank == 0 else None
+    roof_mod = modconv_probe(args) if rank == 0 else None
 
     if rank == 0:
         out = {
@@ -188,6 +239,7 @@ def main():
                        "parallelism": f"dp{world}", "ada_p": args.ada_p, "hip_graph": not args.no_graph},
             "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3,
             "roofline": roof,
+            "roofline_modconv": roof_mod,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
