@@ -377,13 +377,32 @@ class Discriminator(nn.Module):
             ops.EqualLR(nn.Linear(ch(4), 1)),
         )
 
-    def forward(self, h, splits=1):
+    def _fused_stem(self, h, layers):
+        """BlurVH -> 1x1 conv -> bias + lrelu of a one-channel input as ONE streaming kernel (dgv2_stem_fwd/bwd)."""
+        blur, conv, act = layers[0], layers[1], layers[2]
+        w, b, _ = conv._params()
+        low = self.num_fp16_layers > 1 or self.num_fp16_layers == -1
+        return native.stem(h, w, act.bias, blur.blur_h.spec.ring, act.negative_slope, act.scale,
+                           LOW if low else torch.float32)
+
+    def forward(self, h, splits=1, double_backward=False):
         """h [B,C,H,W] (C = 1 on the dusty_v2 path) -> logits [B,1].  `splits` = number of independent
         sub-batches stacked along dim 0 (minibatch statistics are computed per sub-batch), so that
-        D(real) and D(fake) of the discriminator step can share one pass over the weights."""
-        x = ops.to_cl(h.float())
+        D(real) and D(fake) of the discriminator step can share one pass over the weights.
+        `double_backward`: the caller will differentiate the input gradient again (R1); the fused stem is
+        first-order only, so that pass runs the composable ops."""
         layers = list(self.layers)
         i = 0
+        fused = (not double_backward and h.is_cuda and h.shape[1] == 1 and len(layers) > 3
+                 and isinstance(layers[0], ops.BlurVH) and isinstance(layers[1], ops.Conv2d)
+                 and isinstance(layers[2], ops.FusedLeakyReLU) and layers[2].bias is not None
+                 and layers[1]._params()[1] is None and tuple(layers[1]._params()[0].shape[1:]) == (2, 1, 1)
+                 and layers[1]._params()[0].shape[0] in (8, 16, 32, 64))
+        if fused:
+            x = self._fused_stem(h, layers)
+            i = 3
+        else:
+            x = ops.to_cl(h.float())
         while i < len(layers):
             low = (self.num_fp16_layers > i) or (self.num_fp16_layers == -1)
             x = x.to(LOW if low else torch.float32)

@@ -676,6 +676,65 @@ def conv_ring_act(x, w, bias, geom, alpha=0.2, scale=math.sqrt(2.0)):
 
 
 # ---------------------------------------------------------------------------------------
+# discriminator stem: BlurVH + 1x1 conv + bias + lrelu in one pass
+# (reference: dusty_v2.py:364-367, common.py:141-155,187-210, fused_act.py:20-129)
+# ---------------------------------------------------------------------------------------
+class _Stem(Function):
+    """First-order only (the R1 double backward runs the composable ops instead)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, ring, alpha, scale, out_dtype):
+        H, W_ = ctx_hw = _stem_hw(x)
+        B = x.shape[0]
+        x3 = x.detach().float().reshape(B, -1).contiguous()
+        O = w.shape[0]
+        w32 = w.detach().float().reshape(O, 2).contiguous()
+        b32 = bias.detach().float().contiguous()
+        y = torch.empty((B, H, W_, O), device=x.device, dtype=out_dtype)
+        N.check(x3, w32, b32)
+        N.call("dgv2_stem_fwd", N.ptr(y), N.ptr(x3), N.ptr(w32), N.ptr(b32), B, H, W_, O, int(ring), alpha, scale,
+               _dt(y), N.stream())
+        ctx.save_for_backward(x3, w32, y)
+        ctx.cfg = (ctx_hw, ring, alpha, scale, tuple(x.shape), w.shape)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x3, w32, y = ctx.saved_tensors
+        (H, W_), ring, alpha, scale, xshape, wshape = ctx.cfg
+        B, O = x3.shape[0], w32.shape[0]
+        gy = gy.contiguous().to(y.dtype)
+        key = (B, H, W_, O)
+        if key not in _STEM_SCRATCH:
+            n = _ct.c_int64(0)
+            N.call("dgv2_stem_bwd_scratch", _ct.addressof(n), B, H, W_, O)
+            _STEM_SCRATCH[key] = n.value
+        scratch = torch.empty(_STEM_SCRATCH[key], device=gy.device, dtype=torch.float32)
+        gw = torch.empty((O, 2), device=gy.device, dtype=torch.float32)
+        gb = torch.empty(O, device=gy.device, dtype=torch.float32)
+        gx = torch.empty((B, H * W_), device=gy.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        N.call("dgv2_stem_bwd", N.ptr(gx), N.ptr(gw), N.ptr(gb), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(y),
+               N.ptr(x3), N.ptr(w32), B, H, W_, O, int(ring), alpha, scale, _dt(y), N.stream())
+        return (None if gx is None else gx.reshape(xshape)), gw.reshape(wshape), gb, None, None, None, None
+
+
+_STEM_SCRATCH = {}
+
+
+def _stem_hw(x):
+    """x [B,1,H,W] (NCHW) or [B,H,W,1] (channels-last): the same memory for one channel."""
+    if x.ndim != 4 or 1 not in (x.shape[1], x.shape[3]):
+        raise RuntimeError("dgv2 stem: expected a one-channel image batch")
+    return (x.shape[2], x.shape[3]) if x.shape[1] == 1 else (x.shape[1], x.shape[2])
+
+
+def stem(x, w, bias, ring=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=torch.float32):
+    """x one-channel images; w [O,2,1,1] or [O,2] effective conv weight; bias [O] -> [B,H,W,O] channels-last."""
+    return _Stem.apply(x, w, bias, bool(ring), float(alpha), float(scale), out_dtype)
+
+
+# ---------------------------------------------------------------------------------------
 # generator output stage (reference: dusty_v2.py:290-306, dusty_v1.py:20-25, gumbel.py:23-29)
 # ---------------------------------------------------------------------------------------
 class _GenTail(Function):

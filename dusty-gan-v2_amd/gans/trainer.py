@@ -195,7 +195,7 @@ class Trainer:
         set_requires_grad(self.D, True)
         self.d_sync.zero()
         x = x_real.detach().requires_grad_(True)
-        y_real = self.D(self.A(self.warmup(x)))
+        y_real = self.D(self.A(self.warmup(x)), double_backward=True)
         (grads,) = torch.autograd.grad(outputs=[y_real.sum()], inputs=[x], create_graph=True)
         r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
         loss = (self.gp_weight / 2) * r1 + 0.0 * y_real.squeeze()[0]

@@ -241,6 +241,21 @@ int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int Hin, int Wi
                    float alpha, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * discriminator stem in one pass: BlurVH -> 1x1 conv (2 -> O) -> bias + leaky ReLU, and its backward.
+ * replaces: Discriminator layers[0:3] (dusty_v2.py:364-367) = ops.BlurVH (common.py:141-155) +
+ *   ops.Conv2d 1x1 (common.py:187-210) + FusedLeakyReLU (fused_act.py:20-129) and their autograd.
+ * x fp32 [B,H,W] (one channel); w fp32 [O,2] (column 0 multiplies blur_v(x), column 1 blur_h(x)); O in
+ * {8,16,32,64}; y, gy [B,H,W,O] fp32 or bf16.  Backward outputs gw fp32 [O,2], gb fp32 [O], gx fp32 [B,H,W]
+ * (or NULL); scratch: fp32, element count from dgv2_stem_bwd_scratch.  First-order only: the R1 double
+ * backward uses the composable ops. */
+int dgv2_stem_fwd(void* y, const float* x, const float* w, const float* bias, int B, int H, int W, int O,
+                  int ring, float alpha, float scale, int ydtype, void* stream);
+int dgv2_stem_bwd_scratch(int64_t* elems, int B, int H, int W, int O);
+int dgv2_stem_bwd(float* gx, float* gw, float* gb, float* scratch, int64_t scratch_elems, const void* gy,
+                  const void* y, const float* x, const float* w, int B, int H, int W, int O, int ring,
+                  float alpha, float scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
  * generator output stage: cancel the azimuth shift (circular bilinear shift),
  * scale, tanh, Gumbel-sigmoid ray-drop mask, blend.
  * replaces: dusty_v2.py:290-306 (affine_grid + grid_sample + *0.25 + tanh),

@@ -228,6 +228,31 @@ def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
                 assert_rel(y.float().cpu(), want, 8e-3)
 
 
+@pytest.mark.parametrize("ring", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_matches_composed_reference(nat, ring, dtype):
+    """dgv2_stem_fwd/bwd (BlurVH + 1x1 conv + bias + lrelu in one pass) against the oracle's composition
+    of the same reference ops (dusty_v2.py:364-367): outputs and all three gradients."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, O = 3, 10, 24, 32
+    x = torch.randn(B, 1, H, W, generator=g)
+    w = torch.randn(O, 2, 1, 1, generator=g)
+    b = torch.randn(O, generator=g)
+    gy = torch.randn(B, O, H, W, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    z = torch.nn.functional.conv2d(o.blur_vh(xr, ring), wr) + br[None, :, None, None]
+    want = torch.nn.functional.leaky_relu(z, 0.2) * math.sqrt(2.0)
+    gxr, gwr, gbr = torch.autograd.grad(want, [xr, wr, br], gy)
+    xd, wd, bd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = nat.stem(xd, wd, bd, ring, 0.2, math.sqrt(2.0), dtype)
+    gx, gw, gb = torch.autograd.grad(y, [xd, wd, bd], cl(gy).to(dtype))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert_rel(nchw(y), want.detach(), tol, "y")
+    assert_rel(gx.cpu(), gxr, tol, "gx")
+    assert_rel(gw.cpu(), gwr, tol, "gw")
+    assert_rel(gb.cpu(), gbr, tol, "gb")
+
+
 # ---------------------------------------------------------------------------------------
 CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     (2, 8, 16, 8, 16, 3, 1, 1, True),
