@@ -40,6 +40,12 @@ struct DConv {
   int dymin, dxmin, rows, cols;
   int hzero, ring, accumulate;
   int tpb;          // tiles per block along W (pipelined kernel)
+  // output classes: taps [cls_t0[c], cls_t0[c+1]) accumulate into class c, written at offsets (cls_ooh, cls_oow)
+  // (one class = the plain conv; four = the parity classes of the stride-2 data gradient in ONE launch)
+  int ncls, cls_t0[5], cls_ooh[4], cls_oow[4];
+  // border extras: tap (x_dy, x_dx, weight slot x_slot) added to class x_cls for output row x_row only
+  // (the replicate-padding rows of the data gradient, formerly separate one-row accumulate launches)
+  int nx, x_dy[6], x_dx[6], x_slot[6], x_cls[6], x_row[6];
   float inv_cols;   // 1 / cols
   const float* bias;
   void* ybase;         // = y (lets the epilogue address resid at the same offset)
@@ -81,14 +87,14 @@ __device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, 
 // ---------------------------------------------------------------------------------------------
 // Pipelined kernel.  NI = input-tile staging slots (16 B each) per thread, NW = weight slots.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int TO, int RW, int NI>
+template <typename T, int TO, int RW, int NI, int NC>
 __global__ __launch_bounds__(256, 2) void conv_pipe_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                            const T* __restrict__ w, DConv p) {
   constexpr int CE = 16 / sizeof(T);
   constexpr int MF = TO / 16, NF = 2 * RW, TH = 4 * RW;
   constexpr int NW = (TO * 9 * 4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-  __shared__ int s_widx[9], s_tapoff[9];
+  __shared__ int s_widx[9], s_tapoff[9], s_t0[5], s_xoff[6], s_xslot[6], s_xcls[6], s_xrow[6];
   const int npix = p.rows * p.cols;
   uint4* lds_in = smem;
   uint4* lds_w = smem + npix * 4;
@@ -113,6 +119,15 @@ __global__ __launch_bounds__(256, 2) void conv_pipe_kernel(T* __restrict__ y, co
     for (int t = 0; t < 9; ++t) {
       s_widx[t] = p.widx[t];
       s_tapoff[t] = (p.dy[t] - p.dymin) * p.cols + p.dx[t] - p.dxmin;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) s_t0[c] = p.cls_t0[c];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      s_xoff[e] = (p.x_dy[e] - p.dymin) * p.cols + p.x_dx[e] - p.dxmin;
+      s_xslot[e] = p.x_slot[e];
+      s_xcls[e] = p.x_cls[e];
+      s_xrow[e] = p.x_row[e];
     }
   }
   __syncthreads();
@@ -171,11 +186,13 @@ __global__ __launch_bounds__(256, 2) void conv_pipe_kernel(T* __restrict__ y, co
   // slot id -> swizzled LDS index; (pix>>2)&3 and (r>>2)&3 are both (id>>4)&3 (TO is a multiple of 16)
   auto swz = [](int id) { return (id & ~3) | ((id & 3) ^ ((id >> 4) & 3)); };
 
-  f32x4 acc[MF][NF];
+  f32x4 acc[NC][MF][NF];
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) acc[c][mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   int bpix[NF];
 #pragma unroll
@@ -213,39 +230,70 @@ __global__ __launch_bounds__(256, 2) void conv_pipe_kernel(T* __restrict__ y, co
     }
     __syncthreads();                // stage s visible in LDS
 
-    for (int t = 0; t < p.ntaps; ++t) {
-      uint4 a[MF], bb[NF];
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) a[mf] = lds_w[(t * TO + mf * 16 + lr) * 4 + aswz];
-      const int tapoff = s_tapoff[t];
+    for (int c = 0; c < NC; ++c) {
+      for (int t = s_t0[c]; t < s_t0[c + 1]; ++t) {
+        uint4 a[MF], bb[NF];
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const int pix = bpix[nf] + tapoff;
-        bb[nf] = lds_in[pix * 4 + (lc ^ ((pix >> 2) & 3))];
+        for (int mf = 0; mf < MF; ++mf) a[mf] = lds_w[(t * TO + mf * 16 + lr) * 4 + aswz];
+        const int tapoff = s_tapoff[t];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const int pix = bpix[nf] + tapoff;
+          bb[nf] = lds_in[pix * 4 + (lc ^ ((pix >> 2) & 3))];
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) Mfma16<T>::run(acc[c][mf][nf], a[mf], bb[nf]);
       }
+    }
+    // border extras: only the wave rows that ARE the named output row take part (wave-uniform tests)
+    for (int e = 0; e < p.nx; ++e) {
+      const int xrow = s_xrow[e], xcls = s_xcls[e], xoff = s_xoff[e], xslot = s_xslot[e];
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf)
+      for (int rr = 0; rr < RW; ++rr) {
+        if (h0 + wave * RW + rr != xrow) continue;
+        uint4 a[MF], bb[2];
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) Mfma16<T>::run(acc[mf][nf], a[mf], bb[nf]);
+        for (int mf = 0; mf < MF; ++mf) a[mf] = lds_w[(xslot * TO + mf * 16 + lr) * 4 + aswz];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pix = bpix[rr * 2 + h] + xoff;
+          bb[h] = lds_in[pix * 4 + (lc ^ ((pix >> 2) & 3))];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (c != xcls) continue;
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            Mfma16<T>::run(acc[c][mf][rr * 2], a[mf], bb[0]);
+            Mfma16<T>::run(acc[c][mf][rr * 2 + 1], a[mf], bb[1]);
+          }
+        }
+      }
     }
 
     if (cc == nchunks - 1) {        // tile finished: epilogue, reset accumulators
       const int w0 = (tw0 + tile) * DTW;
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const int gh = h0 + wave * RW + (nf >> 1);
-        const int gw = w0 + (nf & 1) * 16 + lr;
-        if (gh < p.Hg && gw < p.Wg) {
-          const int yh = gh * p.out_stride + p.ooff_h, yw = gw * p.out_stride + p.ooff_w;
-          T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.O;
+      for (int c = 0; c < NC; ++c) {
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) {
-            const int o = o0 + mf * 16 + lc * 4;
-            if (o < p.O) store_frag<T>(p, row, o, acc[mf][nf]);
+        for (int nf = 0; nf < NF; ++nf) {
+          const int gh = h0 + wave * RW + (nf >> 1);
+          const int gw = w0 + (nf & 1) * 16 + lr;
+          if (gh < p.Hg && gw < p.Wg) {
+            const int yh = gh * p.out_stride + p.cls_ooh[c], yw = gw * p.out_stride + p.cls_oow[c];
+            T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.O;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+              const int o = o0 + mf * 16 + lc * 4;
+              if (o < p.O) store_frag<T>(p, row, o, acc[c][mf][nf]);
+            }
           }
-        }
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int mf = 0; mf < MF; ++mf) acc[c][mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
     tile = ntile_i; cc = ncc;
@@ -365,7 +413,7 @@ int launch_direct(void* y, const void* x, const void* w, DConv p, hipStream_t st
 }
 
 // returns -2 when the geometry does not fit this instantiation's register / LDS budget
-template <typename T, int TO, int RW, int NI>
+template <typename T, int TO, int RW, int NI, int NC>
 int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) {
   constexpr int TH = 4 * RW;
   constexpr int NW = (TO * 9 * 4 + 255) / 256;
@@ -376,7 +424,7 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   if (n_in > NI * 256 || n_w > NW * 256 || p.rows >= 32768 || p.cols >= 65536) return -2;
   const size_t lds = sizeof(uint4) * ((size_t)n_in + n_w);
   if (lds > 80 * 1024) return -2;   // two blocks per CU
-  auto kern = conv_pipe_kernel<T, TO, RW, NI>;
+  auto kern = conv_pipe_kernel<T, TO, RW, NI, NC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -395,24 +443,33 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
 
 template <typename T, int TO>
 int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, hipStream_t st) {
-  if (p.in_stride == 1 && p.Hg >= 8) return launch_pipe<T, TO, 2, 6>(y, x, w, p, st);
-  if (p.in_stride == 1) return launch_pipe<T, TO, 1, 4>(y, x, w, p, st);
-  return launch_pipe<T, TO, 1, 10>(y, x, w, p, st);
+  if (p.ncls == 4) return p.in_stride == 1 ? launch_pipe<T, TO, 1, 4, 4>(y, x, w, p, st) : -2;
+  if (p.ncls != 1) return -2;
+  if (p.in_stride == 1 && p.Hg >= 8) return launch_pipe<T, TO, 2, 6, 1>(y, x, w, p, st);
+  if (p.in_stride == 1) return launch_pipe<T, TO, 1, 4, 1>(y, x, w, p, st);
+  return launch_pipe<T, TO, 1, 10, 1>(y, x, w, p, st);
 }
 
 }  // namespace
 
-// y[b, gh*out_stride+ooff_h, gw*out_stride+ooff_w, o] (=|+=) act( sum_t sum_c
-//     x[b, H(gh*in_stride+ioff_h+dy_t), W(gw*in_stride+ioff_w+dx_t), c] * w[o, widx_t, c] + bias[o] )
-// for gh < Hg, gw < Wg.  taps_host: HOST pointer to ntaps triples (dy, dx, widx), ntaps <= 9.
+// y[b, gh*out_stride+ooff_h(c), gw*out_stride+ooff_w(c), o] (=|+=) act( sum_{t in class c} sum_ch
+//     x[b, H(gh*in_stride+ioff_h+dy_t), W(gw*in_stride+ioff_w+dx_t), ch] * w[o, widx_t, ch] + resid + bias[o] )
+// for gh < Hg, gw < Wg and every output class c.  taps_host: HOST pointer to ntaps quadruples
+// (dy, dx, widx, cls), sorted by class, ntaps <= 9; cls_host: ncls pairs (ooff_h, ooff_w), ncls in {1, 4};
+// extras_host: nextra <= 6 quintuples (dy, dx, widx, cls, row): an additional tap for output row gh == row only,
+// widx must be one of the main taps' (its weights are already staged).
 // H(): clamp (hzero = 0) or zero outside [0,Hin) (hzero = 1); W(): wrap (ring) or clamp.
-// Cin must be a multiple of 32 (bf16) / 16 (fp32).
-extern "C" int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg, int Wg,
-                              int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w, int out_stride,
-                              int ooff_h, int ooff_w, int ntaps, int wtaps, const int* taps_host, int hzero, int ring,
-                              int accumulate, const float* bias, const void* resid, int act, float alpha,
-                              float scale, int dtype, void* stream) {
-  if (!y || !x || !w || !taps_host || ntaps < 1 || ntaps > 9 || wtaps < 1) return DGV2_EINVAL;
+// Cin must be a multiple of 32 (bf16) / 16 (fp32).  Classes / extras need the pipelined kernel; geometries it
+// does not cover return DGV2_ENOTSUP (callers then issue one launch per class / border row).
+extern "C" int dgv2_conv_taps_ex(void* y, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg,
+                                 int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w,
+                                 int out_stride, int ncls, const int* cls_host, int ntaps, int wtaps,
+                                 const int* taps_host, int nextra, const int* extras_host, int hzero, int ring,
+                                 int accumulate, const float* bias, const void* resid, int act, float alpha,
+                                 float scale, int dtype, void* stream) {
+  if (!y || !x || !w || !taps_host || !cls_host || ntaps < 1 || ntaps > 9 || wtaps < 1) return DGV2_EINVAL;
+  if (ncls != 1 && ncls != 4) return DGV2_EINVAL;
+  if (nextra < 0 || nextra > 6 || (nextra > 0 && !extras_host)) return DGV2_EINVAL;
   if (B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Hg <= 0 || Wg <= 0 || O <= 0 || in_stride < 1 || out_stride < 1)
     return DGV2_EINVAL;
   if (act != 0 && act != 3) return DGV2_EINVAL;
@@ -421,16 +478,43 @@ extern "C" int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int 
   DConv p;
   p.B = B; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hg = Hg; p.Wg = Wg; p.O = O; p.Hy = Hy; p.Wy = Wy;
   p.in_stride = in_stride; p.ioff_h = ioff_h; p.ioff_w = ioff_w;
-  p.out_stride = out_stride; p.ooff_h = ooff_h; p.ooff_w = ooff_w;
+  p.out_stride = out_stride; p.ooff_h = cls_host[0]; p.ooff_w = cls_host[1];
   p.ntaps = ntaps; p.wtaps = wtaps;
+  p.ncls = ncls;
+  for (int c = 0; c < 4; ++c) {
+    p.cls_ooh[c] = c < ncls ? cls_host[2 * c] : 0;
+    p.cls_oow[c] = c < ncls ? cls_host[2 * c + 1] : 0;
+  }
   int dymin = 1 << 30, dymax = -(1 << 30), dxmin = 1 << 30, dxmax = -(1 << 30);
+  int prev_cls = 0;
+  for (int c = 0; c < 5; ++c) p.cls_t0[c] = ntaps;
+  p.cls_t0[0] = 0;
   for (int t = 0; t < 9; ++t) {
     p.dy[t] = p.dx[t] = p.widx[t] = 0;
     if (t < ntaps) {
-      p.dy[t] = taps_host[3 * t]; p.dx[t] = taps_host[3 * t + 1]; p.widx[t] = taps_host[3 * t + 2];
-      if (p.widx[t] < 0 || p.widx[t] >= wtaps) return DGV2_EINVAL;
+      p.dy[t] = taps_host[4 * t]; p.dx[t] = taps_host[4 * t + 1]; p.widx[t] = taps_host[4 * t + 2];
+      const int c = taps_host[4 * t + 3];
+      if (p.widx[t] < 0 || p.widx[t] >= wtaps || c < prev_cls || c >= ncls) return DGV2_EINVAL;
+      for (int k = prev_cls + 1; k <= c; ++k) p.cls_t0[k] = t;
+      prev_cls = c;
       dymin = p.dy[t] < dymin ? p.dy[t] : dymin; dymax = p.dy[t] > dymax ? p.dy[t] : dymax;
       dxmin = p.dx[t] < dxmin ? p.dx[t] : dxmin; dxmax = p.dx[t] > dxmax ? p.dx[t] : dxmax;
+    }
+  }
+  p.nx = nextra;
+  for (int e = 0; e < 6; ++e) {
+    p.x_dy[e] = p.x_dx[e] = p.x_slot[e] = p.x_cls[e] = 0;
+    p.x_row[e] = -1;
+    if (e < nextra) {
+      const int* q = extras_host + 5 * e;
+      p.x_dy[e] = q[0]; p.x_dx[e] = q[1]; p.x_cls[e] = q[3]; p.x_row[e] = q[4];
+      int slot = -1;
+      for (int t = 0; t < ntaps; ++t)
+        if (p.widx[t] == q[2]) slot = t;
+      if (slot < 0 || q[3] < 0 || q[3] >= ncls) return DGV2_EINVAL;
+      p.x_slot[e] = slot;
+      dymin = q[0] < dymin ? q[0] : dymin; dymax = q[0] > dymax ? q[0] : dymax;
+      dxmin = q[1] < dxmin ? q[1] : dxmin; dxmax = q[1] > dxmax ? q[1] : dxmax;
     }
   }
   p.dymin = dymin; p.dxmin = dxmin;
@@ -444,14 +528,16 @@ extern "C" int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int 
   static const bool no_pipe = getenv("DGV2_NO_PIPE") != nullptr;   // A/B switch for benchmarking
   // the ring wrap of the pipelined kernel assumes -Win <= gw < 4*Win
   const bool wrap_ok = !ring || (ioff_w + dxmin >= -Win && in_stride * ((Wg + DTW - 1) / DTW * DTW) + ioff_w + dxmax < 4 * Win);
+  const bool plain = ncls == 1 && nextra == 0;
   DGV2_DISPATCH_DTYPE(dtype, {
     rc = -2;
-    if (!no_pipe && wrap_ok) {
+    if ((!no_pipe || !plain) && wrap_ok) {
       if (O <= 16) rc = dispatch_pipe<T, 16>(y, x, w, p, st);
       else if (O <= 32) rc = dispatch_pipe<T, 32>(y, x, w, p, st);
       else rc = dispatch_pipe<T, 64>(y, x, w, p, st);
     }
     if (rc == -2) {
+      if (!plain) return DGV2_ENOTSUP;
       if (O <= 16) rc = launch_direct<T, 16>(y, x, w, p, st);
       else if (O <= 32) rc = launch_direct<T, 32>(y, x, w, p, st);
       else rc = launch_direct<T, 64>(y, x, w, p, st);
@@ -459,4 +545,22 @@ extern "C" int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int 
   });
   if (rc) return rc;
   DGV2_RETURN_LAST();
+}
+
+// The single-class, no-extras form (taps_host: ntaps triples (dy, dx, widx)).
+extern "C" int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg, int Wg,
+                              int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w, int out_stride,
+                              int ooff_h, int ooff_w, int ntaps, int wtaps, const int* taps_host, int hzero, int ring,
+                              int accumulate, const float* bias, const void* resid, int act, float alpha,
+                              float scale, int dtype, void* stream) {
+  if (!taps_host || ntaps < 1 || ntaps > 9) return DGV2_EINVAL;
+  int taps4[36];
+  for (int t = 0; t < ntaps; ++t) {
+    taps4[4 * t] = taps_host[3 * t]; taps4[4 * t + 1] = taps_host[3 * t + 1]; taps4[4 * t + 2] = taps_host[3 * t + 2];
+    taps4[4 * t + 3] = 0;
+  }
+  const int cls[2] = {ooff_h, ooff_w};
+  return dgv2_conv_taps_ex(y, x, w, B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy, in_stride, ioff_h, ioff_w, out_stride, 1, cls,
+                           ntaps, wtaps, taps4, 0, nullptr, hzero, ring, accumulate, bias, resid, act, alpha, scale,
+                           dtype, stream);
 }

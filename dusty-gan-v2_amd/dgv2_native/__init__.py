@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -45,6 +45,8 @@ SIGNATURES = {
     "dgv2_conv_fwd": [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_conv_taps": [_c_ptr] * 3 + [_c_int] * 17 + [_c_ptr] + [_c_int] * 3 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int,
                                                                                _c_ptr],
+    "dgv2_conv_taps_ex": [_c_ptr] * 3 + [_c_int] * 14 + [_c_ptr, _c_int, _c_int, _c_ptr, _c_int, _c_ptr] + [_c_int] * 3
+    + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_conv_wgrad_direct": [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr],
     "dgv2_conv_wgrad_stream_scratch": [_c_ptr] + [_c_int] * 9,
     "dgv2_conv_wgrad_stream": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 10 + [_c_ptr],
@@ -109,7 +111,20 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+ENOTSUP = -3
+
+
 def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed with code {rc}")
+
+
+def try_call(name, *args):
+    """Like call(), but returns False on DGV2_ENOTSUP (the documented 'use the fallback' code)."""
+    rc = getattr(lib, name)(*args)
+    if rc == ENOTSUP:
+        return False
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}")
+    return True

@@ -452,6 +452,23 @@ def _conv_taps(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, ooff, taps, hzero,
            N.ptr(bias), N.ptr(resid), act, alpha, scale, _dt(x), N.stream())
 
 
+_FUSED_DGRAD = os.environ.get("DGV2_NO_FUSED_DGRAD") is None   # A/B switch for benchmarking
+
+
+def _conv_taps_ex(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, classes, taps4, extras, hzero):
+    """dgv2_conv_taps_ex: output classes [(ooff_h, ooff_w)], taps [(dy, dx, widx, cls)] sorted by class, border
+    extras [(dy, dx, widx, cls, row)].  Returns False when the engine asks for the per-class fallback."""
+    B, Hin, Win, Cin = x.shape
+    O, wtaps, _ = w3.shape
+    _, Hy, Wy, _ = y.shape
+    carr = (_ct.c_int * (2 * len(classes)))(*[v for c in classes for v in c])
+    tarr = (_ct.c_int * (4 * len(taps4)))(*[v for t in taps4 for v in t])
+    earr = (_ct.c_int * max(5 * len(extras), 1))(*[v for e in extras for v in e])
+    return N.try_call("dgv2_conv_taps_ex", N.ptr(y), N.ptr(x), N.ptr(w3), B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy,
+                      in_stride, ioff[0], ioff[1], out_stride, len(classes), carr, len(taps4), wtaps, tarr,
+                      len(extras), earr, int(hzero), 1, 0, None, None, 0, 0.2, 1.0, _dt(x), N.stream())
+
+
 def _direct_ok(g, cin):
     """The direct engine handles the discriminator's geometries: ring padding, 3x3/pad 1 or 1x1/pad 0,
     stride 1 or 2, input channels a multiple of the K-step."""
@@ -494,6 +511,11 @@ def _conv_dgrad_direct(gy, wt3, g, xshape):
         return gx
     if g.stride == 1:
         taps = [(1 - ky, 1 - kx, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+        # one launch: the replicate rows ride along as border extras of output rows 0 and H-1
+        extras = [(0, 1 - kx, kx, 0, 0) for kx in range(3)] + [(0, 1 - kx, 6 + kx, 0, H - 1) for kx in range(3)]
+        if _FUSED_DGRAD and _conv_taps_ex(gx, gy, wt3, H, W, 1, (0, 0), 1, [(0, 0)], [t + (0,) for t in taps], extras,
+                                          True):
+            return gx
         _conv_taps(gx, gy, wt3, H, W, 1, (0, 0), 1, (0, 0), taps, True)
         # replicate-padding rows: padded row -1 (-> h = 0) is read by ky = 0 of output row 0,
         # padded row H (-> h = H-1) by ky = 2 of output row H-1
@@ -501,7 +523,17 @@ def _conv_dgrad_direct(gy, wt3, g, xshape):
         _conv_taps(gx, gy, wt3, 1, W, 1, (H - 1, 0), 1, (H - 1, 0), [(0, 1 - kx, 6 + kx) for kx in range(3)], True,
                    True)
         return gx
-    # stride 2: one launch per output parity class, only the taps that class can see
+    # stride 2: the four output parity classes (only the taps each class can see) and the top border in one launch
+    classes, taps4, extras = [], [], []
+    for ph in (0, 1):
+        for pw in (0, 1):
+            c = len(classes)
+            classes.append((ph, pw))
+            taps4 += [(dy, dx, ky * 3 + kx, c) for dy, ky in _axis_taps_s2(ph) for dx, kx in _axis_taps_s2(pw)]
+            if ph == 0:
+                extras += [(0, dx, kx, c, 0) for dx, kx in _axis_taps_s2(pw)]
+    if _FUSED_DGRAD and _conv_taps_ex(gx, gy, wt3, H // 2, W // 2, 1, (0, 0), 2, classes, taps4, extras, True):
+        return gx
     for ph in (0, 1):
         for pw in (0, 1):
             taps = [(dy, dx, ky * 3 + kx) for dy, ky in _axis_taps_s2(ph) for dx, kx in _axis_taps_s2(pw)]

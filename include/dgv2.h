@@ -29,6 +29,7 @@ extern "C" {
 #define DGV2_F32 0
 #define DGV2_BF16 1
 #define DGV2_EINVAL (-1)
+#define DGV2_ENOTSUP (-3) /* valid request that this build's kernels do not cover: use the documented fallback */
 
 /* Library/ABI version; bumped when a signature changes. */
 int dgv2_abi_version(void);
@@ -239,6 +240,22 @@ int dgv2_conv_taps(void* y, const void* x, const void* w, int B, int Hin, int Wi
                    int out_stride, int ooff_h, int ooff_w, int ntaps, int wtaps, const int* taps_host,
                    int hzero, int ring, int accumulate, const float* bias, const void* resid, int act,
                    float alpha, float scale, int dtype, void* stream);
+/* The general form: OUTPUT CLASSES and BORDER EXTRAS, so that a whole data gradient is one launch.
+ *   taps_host   ntaps quadruples (dy, dx, widx, cls) sorted by cls; class c is written at
+ *               (gh*out_stride + cls_host[2c], gw*out_stride + cls_host[2c+1]); ncls in {1, 4}
+ *               (4 = the parity classes of the stride-2 data gradient: the gy halo tile and all nine
+ *               weight taps are staged once instead of once per class);
+ *   extras_host nextra <= 6 quintuples (dy, dx, widx, cls, row): one more tap for output row gh == row
+ *               only -- the replicate-padding rows of the H border (dusty_v2.py Pad / common.py:10-24)
+ *               fold into the same launch instead of one-row accumulate launches.
+ * Returns DGV2_ENOTSUP when the geometry needs the synchronous fallback kernel, which has neither
+ * (callers then issue one dgv2_conv_taps launch per class / border row). */
+int dgv2_conv_taps_ex(void* y, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg,
+                      int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w,
+                      int out_stride, int ncls, const int* cls_host, int ntaps, int wtaps,
+                      const int* taps_host, int nextra, const int* extras_host, int hzero, int ring,
+                      int accumulate, const float* bias, const void* resid, int act, float alpha,
+                      float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * discriminator stem in one pass: BlurVH -> 1x1 conv (2 -> O) -> bias + leaky ReLU, and its backward.
