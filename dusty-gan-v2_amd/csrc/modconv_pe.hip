@@ -51,7 +51,8 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   const int b1 = min(b0 + g.samples_per_block, g.B);
 
   // ---- PE fragments: registers for the whole block ----
-  uint4 pe[NFW][KS];
+  constexpr int KSR = KS > 0 ? KS : 1;
+  uint4 pe[NFW][KSR];
 #pragma unroll
   for (int nf = 0; nf < NFW; ++nf) {
     const int px = min(p0 + nf * 16 + lr, g.P - 1);   // clamped: pixels past the end are computed, never stored
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
       for (int mf = 0; mf < MF; ++mf) a[mf] = wbuf[(kc * O + mf * 16 + lr) * 4 + aswz];
 #pragma unroll
       for (int nf = 0; nf < NFW; ++nf) {
-        const uint4 bf = kc < KA ? xr[S][nf][kc < KA ? kc : 0] : pe[nf][kc >= KA ? kc - KA : 0];
+        const uint4 bf = kc < KA ? xr[S][nf][kc < KA ? kc : 0] : pe[nf][(KS > 0 && kc >= KA) ? kc - KA : 0];
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) Mfma16<bf16_t>::run(acc[mf][nf], a[mf], bf);
       }
@@ -192,19 +193,26 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
 }  // namespace
 
 // Same contract as dgv2_bmm_nn_cat (bf16 in / bf16 out) for the shapes of the two top generator levels:
-// (Ka, Ks, O) = (64, 512, 32) (level 4; the two weight buffers of other shapes do not fit LDS).  Returns DGV2_EINVAL for anything else: callers fall back to
+// (Ka, Ks, O) = (64, 512, 32) (level-4 conv1) and, with Ks = 0 (xs unused), the PE-free shapes
+// (64,0,32), (32,0,64), (128,0,64), (64,0,128) = conv0 of levels 4/3 and the data gradients.  Returns DGV2_EINVAL for anything else: callers fall back to
 // dgv2_bmm_nn_cat.
 extern "C" int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
                                    int Ks, int O, const float* bias, int act, float alpha, float scale, int dtype,
                                    void* stream) {
-  if (!y || !xs || !w || (Ka > 0 && !xa) || B <= 0 || P <= 0) return DGV2_EINVAL;
+  if (!y || !w || (Ks > 0 && !xs) || (Ka > 0 && !xa) || B <= 0 || P <= 0) return DGV2_EINVAL;
   if (dtype != DGV2_BF16 || (act != 0 && act != 3)) return DGV2_EINVAL;
   if (!aligned16(y) || !aligned16(xa) || !aligned16(xs) || !aligned16(w)) return DGV2_EINVAL;
+  if (Ks == 0) xs = xa;   // never dereferenced (KS = 0), keeps the pointer arithmetic defined
   static const int abl = getenv("DGV2_MP_ABLATE") ? atoi(getenv("DGV2_MP_ABLATE")) : 0;
   MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, abl, bias, act, alpha, scale};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (Ka == 64 && Ks == 512 && O == 32) rc = mp_launch<2, 2, 2, 16>(y, xa, xs, w, g, st);
+  // the PE-free layers of the two top levels and their data gradients: same sample walk, weights by LDS-DMA
+  else if (Ks == 0 && Ka == 64 && O == 32) rc = mp_launch<2, 2, 2, 0>(y, xa, xs, w, g, st);
+  else if (Ks == 0 && Ka == 32 && O == 64) rc = mp_launch<4, 2, 1, 0>(y, xa, xs, w, g, st);
+  else if (Ks == 0 && Ka == 128 && O == 64) rc = mp_launch<4, 2, 4, 0>(y, xa, xs, w, g, st);
+  else if (Ks == 0 && Ka == 64 && O == 128) rc = mp_launch<8, 2, 2, 0>(y, xa, xs, w, g, st);
   else return DGV2_EINVAL;
   if (rc) return rc;
   DGV2_RETURN_LAST();

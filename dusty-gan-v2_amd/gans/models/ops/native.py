@@ -295,6 +295,12 @@ def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0):
     Bw, O, _ = w3.shape
     N.check(x3, w3, bias)
     y = torch.empty((B, P, O), device=x3.device, dtype=out_dtype)
+    if (_PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and P >= 4096
+            and (I, O) in ((64, 32), (32, 64), (128, 64), (64, 128))):
+        # streaming shapes of the two top levels: sample-walking kernel without a PE part
+        N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(bias), act, alpha,
+               scale, _dt(x3), N.stream())
+        return y
     N.call("dgv2_bmm_nn", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
            N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.stream())
     return y

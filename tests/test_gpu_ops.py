@@ -196,7 +196,8 @@ def test_bmm_bf16_random_tolerance(nat):
     assert_rel(y.float().cpu(), want, 8e-3)
 
 
-@pytest.mark.parametrize("Ka,Ks,O,P,B", [(64, 512, 32, 700, 5), (64, 512, 32, 256, 2)])
+@pytest.mark.parametrize("Ka,Ks,O,P,B", [(64, 512, 32, 700, 5), (64, 512, 32, 256, 2), (64, 0, 32, 700, 3), (32, 0, 64, 300, 2),
+                                          (128, 0, 64, 300, 2), (64, 0, 128, 260, 2)])
 def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
     """dgv2_modconv_pe_fwd (pixel-tile blocks walking the samples, shared PE in registers) against the
     einsum of the reference's cat([h, pe]) + per-sample 1x1 conv + bias + lrelu (dusty_v2.py:153-162,
@@ -216,7 +217,8 @@ def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
         bd = bias.to(DEV)
         for act in (0, 3):
             y = torch.full((B, P, O), float("nan"), device=DEV, dtype=torch.bfloat16)
-            N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(xad), N.ptr(xsd), N.ptr(wd), B, P, Ka, Ks, O, N.ptr(bd), act,
+            N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(xad), N.ptr(xsd) if Ks else None, N.ptr(wd), B, P, Ka, Ks, O,
+                   N.ptr(bd), act,
                    0.2, math.sqrt(2.0), N.BF16, N.stream())
             xcat = torch.cat([xad.double().cpu(), xsd.double().cpu()[None].expand(B, P, Ks)], dim=2)
             want = torch.einsum("bpi,boi->bpo", xcat, wd.double().cpu()) + bias.double()
