@@ -287,6 +287,27 @@ bool geom_ok(int B, int O, int I, int Otot, int row_off, int cin, int F) {
 
 }  // namespace
 
+// Input-magnitude EMA of ModConv2d (style.py:98-103) as one scalar kernel:
+//   ema <- lerp(ema, (sumsq + add) * inv_count, weight)   (skipped when sumsq == NULL and add == 0)
+//   snapshot <- ema        (the value this forward pass uses; the buffer itself keeps changing)
+static __global__ void ema_scalar_kernel(float* ema, float* snapshot, const float* sumsq, float add, float inv_count,
+                                  float weight, int update) {
+  float v = ema[0];
+  if (update) {
+    const float m = ((sumsq ? sumsq[0] : 0.f) + add) * inv_count;
+    v += weight * (m - v);
+    ema[0] = v;
+  }
+  snapshot[0] = v;
+}
+
+extern "C" int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, float add, float inv_count,
+                               float weight, int update, void* stream) {
+  if (!ema || !snapshot) return DGV2_EINVAL;
+  ema_scalar_kernel<<<1, 1, 0, (hipStream_t)stream>>>(ema, snapshot, sumsq, add, inv_count, weight, update);
+  DGV2_RETURN_LAST();
+}
+
 // Forward.  stats: fp32 [2 + 2B] scratch (filled here when demod); dsave: fp32 [B,O] (saved for backward).
 extern "C" int dgv2_mod_prep_fwd(void* wb, float* dsave, float* stats, const float* W, const float* s,
                                  const float* ema_var, const float* shift, const float* fw, int B, int O, int I,

@@ -135,19 +135,22 @@ class SynthesisBlock(nn.Module):
         hup = None if hin is None else self.resample.forward_cl(hin)
         cin = 0 if hup is None else hup.shape[3]
         conv = self.conv1
-        sumsq = None
+        sumsq, pe_sq = None, 0.0
         if conv.training:
             # sum of squares of cat(hup, PE): sin^2 + cos^2 = 1 per frequency pair
-            sumsq = torch.full((), float(self.pe.out_ch // 2) * B * H * W, device=angle.device)
+            pe_sq = float(self.pe.out_ch // 2) * B * H * W
             if hup is not None:
-                sumsq = sumsq + native.sum_squares(hup)
+                sumsq = native.sum_squares(hup)
         act = self.bias_act1
         if self.pe.out_ch == 512 and conv.in_ch <= 1024:
             # weight preparation (+ rotation), contraction, bias and lrelu as one autograd node
-            mods = [conv.prep_args(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch))]
+            mods = [conv.prep_args(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch), sumsq_add=pe_sq)]
             fw = self.pe.freqs2[:, 1].contiguous() if shift is not None else None
             return native.mod_layer(hup, pe0, mods, bias=act.bias, act=True, alpha=act.negative_slope,
                                     scale=act.scale, shift=shift, fw=fw, cin=cin)
+        if conv.training:
+            sumsq = pe_sq if sumsq is None else sumsq + pe_sq
+            sumsq = torch.as_tensor(sumsq, device=angle.device, dtype=torch.float32)
         wb = conv.sample_weights(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch))
         if shift is not None:
             nf = self.pe.out_ch // 2

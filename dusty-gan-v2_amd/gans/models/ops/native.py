@@ -236,6 +236,15 @@ def downsample_angle(angle, shift, taps, B, ring=True):
     return out
 
 
+def ema_update(ema, sumsq, add, count, weight, update=True):
+    """ModConv2d's input-magnitude EMA (style.py:98-103) in one scalar launch: updates the 0-dim buffer `ema`
+    in place with lerp(ema, (sumsq + add) / count, weight) and returns a fresh [1] snapshot of its value."""
+    snap = torch.empty(1, device=ema.device, dtype=torch.float32)
+    N.call("dgv2_ema_scalar", N.ptr(ema), N.ptr(snap), N.ptr(sumsq), float(add), 1.0 / float(count), float(weight),
+           int(update), N.stream())
+    return snap
+
+
 def sum_squares(x, C=None):
     """fp32 scalar: sum of squares of the first C channels of a channels-last tensor."""
     ld = x.shape[-1]
@@ -908,7 +917,9 @@ class _ModLayer(Function):
         nm = len(mods) // 3
         Ws = [mods[3 * k].detach().contiguous() for k in range(nm)]
         Ss = [mods[3 * k + 1].detach().float().contiguous() for k in range(nm)]
-        Es = [mods[3 * k + 2].detach().float().reshape(1).clone() for k in range(nm)]
+        # a [1] tensor is a fresh snapshot from ema_update; the 0-dim module buffer itself must be copied
+        Es = [(mods[3 * k + 2].detach() if mods[3 * k + 2].ndim == 1 else mods[3 * k + 2].detach().float().reshape(1).clone())
+              for k in range(nm)]
         ref = xa if xa is not None else xs
         dt = ref.dtype
         B = Ss[0].shape[0]

@@ -50,14 +50,20 @@ class ModConv2d(nn.Module):
             wb = wb / (torch.sqrt(self.ema_var) + 1e-8).detach().clone()
         return wb
 
-    def prep_args(self, w_latent, sumsq=None, count=None):
+    def prep_args(self, w_latent, sumsq=None, count=None, sumsq_add=0.0):
         """(weight [O,I], style [B,I], ema_var, demod) for native.mod_layer, which fuses the whole
-        weight preparation; the input-magnitude EMA is updated here first (style.py:98-103)."""
+        weight preparation; the input-magnitude EMA is updated here first (style.py:98-103): the mean square
+        is (sumsq + sumsq_add) / count, one scalar launch that also snapshots the value for this pass."""
         style = self.mod(w_latent.float())
-        if self.ema and self.training and sumsq is not None:
+        ev = self.ema_var
+        if ev.is_cuda and ev.dtype == torch.float32:
+            upd = self.ema and self.training and (sumsq is not None or sumsq_add != 0.0)
             with torch.no_grad():
-                self.ema_var.lerp_(sumsq / count, 1 - self.ema_decay)
-        return (self.weight[0, :, :, 0, 0], style, self.ema_var, self.demod)
+                ev = native.ema_update(self.ema_var, sumsq, sumsq_add, count if upd else 1, 1 - self.ema_decay, upd)
+        elif self.ema and self.training and sumsq is not None:
+            with torch.no_grad():
+                self.ema_var.lerp_((sumsq + sumsq_add) / count, 1 - self.ema_decay)
+        return (self.weight[0, :, :, 0, 0], style, ev, self.demod)
 
     def forward_cl(self, x, w_latent, out_dtype=None, act=None):
         """act: a FusedLeakyReLU module whose bias + leaky-ReLU is fused into the GEMM epilogue."""

@@ -170,6 +170,10 @@ int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, 
  * rows at [row_off, row_off+O)), dtype wb_dtype; stats fp32 [2+2B] and dsave fp32 [B,O] are produced
  * by fwd and consumed by bwd; shift fp32 [B] / fw fp32 [F] or NULL (F must be 256, PE columns
  * [cin, cin+2F)); I <= 1024.  bwd: G fp32 [B,Otot,I] -> gW fp32 [O,I], gs fp32 [B,I]; corr fp32 [1]. */
+/* Input-magnitude EMA of ModConv2d (style.py:98-103) as one scalar launch:
+ * if update: ema <- lerp(ema, (sumsq[0] + add) * inv_count, weight); snapshot[0] <- ema[0]. sumsq may be NULL. */
+int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, float add, float inv_count,
+                    float weight, int update, void* stream);
 int dgv2_mod_prep_fwd(void* wb, float* dsave, float* stats, const float* W, const float* s,
                       const float* ema_var, const float* shift, const float* fw, int B, int O, int I,
                       int Otot, int row_off, int demod, int cin, int F, int wb_dtype, void* stream);

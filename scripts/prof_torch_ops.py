@@ -1,0 +1,31 @@
+"""torch.profiler view of one eager training iteration: which ATen ops make up the small-launch glue."""
+import os, sys, argparse
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dusty-gan-v2_amd")]
+import torch
+import bench
+from torch.profiler import profile, ProfilerActivity
+args = argparse.Namespace(batch_per_gpu=64, dtype="bf16", ada_p=0.6, no_graph=True)
+from gans.trainer import Trainer
+from gans.utils import init_random_seed
+init_random_seed(0, 0)
+cfg = bench.make_cfg(args, 0, 1)
+tr = Trainer(cfg, sync_scalars=False)
+for it in (16, 1, 2):
+    tr.step(it)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    tr.step(3)
+    torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    t = getattr(e, "self_device_time_total", None)
+    if t is None:
+        t = e.self_cuda_time_total
+    if t > 0:
+        rows.append((t, e.count, e.key, str(e.input_shapes)[:90]))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f"total device us {tot:.0f}")
+for t, c, k, sh in rows[:90]:
+    print(f"{t:9.0f}us x{c:4d} {k[:44]:44s} {sh}")
