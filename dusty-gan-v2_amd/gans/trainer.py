@@ -162,18 +162,19 @@ class Trainer:
     # collectives stay ordinary stream work between them.
     def g_fb(self, scalars):
         set_requires_grad(self.G, True)
-        self.g_sync.zero()
+        self.g_sync.begin()
         z = self.sample_z(self.B)
         x_fake = self.G(z, **self.auxin)["image"]
         y_fake = self.D(self.A(self.warmup(x_fake)))
         loss_gan = self.adversarial_loss(None, y_fake, "G")
         (self.cfg.training.loss.gan * loss_gan).backward()
+        self.g_sync.collect()
         set_requires_grad(self.G, False)
         scalars["loss/G/adversarial"] = loss_gan.detach()
 
     def d_fb(self, x_real, scalars):
         set_requires_grad(self.D, True)
-        self.d_sync.zero()
+        self.d_sync.begin()
         z = self.sample_z(self.B)
         with torch.no_grad():
             x_fake = self.G(z, **self.auxin)["image"]
@@ -186,6 +187,7 @@ class Trainer:
         self.A.cumulate(y_real)
         loss_gan = self.adversarial_loss(y_real, y_fake, "D")
         (self.cfg.training.loss.gan * loss_gan).backward()
+        self.d_sync.collect()
         scalars["loss/D/output/real"] = y_real.mean().detach()
         scalars["loss/D/output/fake"] = y_fake.mean().detach()
         scalars["loss/D/adversarial"] = loss_gan.detach()
@@ -193,13 +195,14 @@ class Trainer:
     def r1_fb(self, x_real, scalars):
         """lazy R1 (reference: trainer.py:419-451): double backward through D and ADA."""
         set_requires_grad(self.D, True)
-        self.d_sync.zero()
+        self.d_sync.begin()
         x = x_real.detach().requires_grad_(True)
         y_real = self.D(self.A(self.warmup(x)), double_backward=True)
         (grads,) = torch.autograd.grad(outputs=[y_real.sum()], inputs=[x], create_graph=True)
         r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
         loss = (self.gp_weight / 2) * r1 + 0.0 * y_real.squeeze()[0]
         loss.backward()
+        self.d_sync.collect()
         scalars["loss/D/gradient_penalty"] = r1.detach()
 
     def ema_decay(self, iteration):

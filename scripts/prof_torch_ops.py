@@ -29,3 +29,14 @@ tot = sum(r[0] for r in rows)
 print(f"total device us {tot:.0f}")
 for t, c, k, sh in rows[:90]:
     print(f"{t:9.0f}us x{c:4d} {k[:44]:44s} {sh}")
+
+print("---- ATen ops by name ----")
+agg = {}
+for e in prof.key_averages():
+    t = getattr(e, "self_device_time_total", None)
+    if t is None:
+        t = e.self_cuda_time_total
+    if e.key.startswith("aten::") or "Memcpy" in e.key or "Memset" in e.key:
+        agg[e.key] = (t, e.count)
+for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"{t:9.0f}us x{c:5d} {k}")
