@@ -167,7 +167,8 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(T* __restrict__ gx, float* __restrict__ gb,
                                                            const T* __restrict__ gy, const T* __restrict__ ref,
-                                                           int64_t rows, int cvecs, float alpha, float scale) {
+                                                           int64_t rows, int cvecs, float alpha, float scale,
+                                                           float* __restrict__ partial) {
   constexpr int VN = vec16<T>::N;
   __shared__ float red[256 * VN];
   const int tid = threadIdx.x;
@@ -213,7 +214,28 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(T* __restrict__ gx, f
     const int v = c / VN, j = c - v * VN;
     float s = 0.f;
     for (int k = 0; k < lanes; ++k) s += red[(k * cvecs + v) * VN + j];
-    atomicAdd(&gb[c], s);
+    if (partial) partial[(int64_t)blockIdx.x * cvecs * VN + c] = s;   // many-block mode: summed by the reduce kernel
+    else atomicAdd(&gb[c], s);
+  }
+}
+
+// gb[c] = sum_blk partial[blk][c]: 16 channels x 16 block-lanes per workgroup
+__global__ __launch_bounds__(256) void bias_partial_reduce_kernel(float* __restrict__ gb, const float* __restrict__ partial,
+                                                                  int nblk, int C) {
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int k = bl; k < nblk; k += 16) s += partial[(int64_t)k * C + c];
+  }
+  red[bl][cl] = s;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][cl];
+    gb[c] = s;
   }
 }
 
@@ -222,19 +244,30 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(T* __restrict__ gx, f
 // gx [rows,C] and gb fp32 [C] from gy [rows,C] and the forward output ref [rows,C] (channels-last).
 // Returns DGV2_EINVAL when the shape does not fit the fused kernel (caller falls back to
 // dgv2_fused_bias_act + dgv2_bias_grad): C must be a multiple of the 16-byte vector with C/vec dividing 256.
+// scratch (optional, fp32 [scratch_elems >= 2048 * C]): with it the pass runs on up to 2048 blocks and the
+// per-block column sums are folded by a second kernel (no atomics, no zero fill of gb); without it <= 256 blocks
+// add their sums with fp32 atomics (same-address atomics would serialise a larger grid).
 extern "C" int dgv2_bias_act_bwd(void* gx, float* gb, const void* gy, const void* ref, int64_t rows, int C,
-                                 float alpha, float scale, int dtype, void* stream) {
+                                 float alpha, float scale, float* scratch, int64_t scratch_elems, int dtype,
+                                 void* stream) {
   if (!gx || !gb || !gy || !ref || rows <= 0 || C <= 0) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int vn = dtype == DGV2_BF16 ? 8 : 4;
   if (C % vn || 256 % (C / vn) || !aligned16(gx) || !aligned16(gy) || !aligned16(ref)) return DGV2_EINVAL;
-  hipError_t e = hipMemsetAsync(gb, 0, sizeof(float) * C, st);
-  if (e != hipSuccess) return (int)e;
   const int cvecs = C / vn, lanes = 256 / cvecs;
-  int64_t want = rows / ((int64_t)lanes * 32);  // >= 32 rows per row-lane before adding blocks
-  const int grid = (int)(want < 32 ? 32 : (want > 256 ? 256 : want));
+  const bool many = scratch && scratch_elems >= (int64_t)2048 * C && aligned16(scratch);
+  if (!many) {
+    hipError_t e = hipMemsetAsync(gb, 0, sizeof(float) * C, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  // 4 rows in flight per thread: >= 8 rows per row-lane before adding blocks (32 in the atomics mode)
+  int64_t want = rows / ((int64_t)lanes * (many ? 8 : 32));
+  const int cap = many ? 2048 : 256;
+  const int grid = (int)(want < 32 ? 32 : (want > cap ? cap : want));
   DGV2_DISPATCH_DTYPE(dtype, {
-    bias_act_bwd_kernel<T><<<grid, 256, 0, st>>>((T*)gx, gb, (const T*)gy, (const T*)ref, rows, cvecs, alpha, scale);
+    bias_act_bwd_kernel<T><<<grid, 256, 0, st>>>((T*)gx, gb, (const T*)gy, (const T*)ref, rows, cvecs, alpha, scale,
+                                                 many ? scratch : nullptr);
   });
+  if (many) bias_partial_reduce_kernel<<<(C + 15) / 16, 256, 0, st>>>(gb, scratch, grid, C);
   DGV2_RETURN_LAST();
 }

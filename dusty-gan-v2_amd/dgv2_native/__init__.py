@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -28,7 +28,7 @@ SIGNATURES = {
     "dgv2_abi_version": [],
     "dgv2_fused_bias_act": [_c_ptr] * 4 + [_c_i64] * 3 + [_c_int, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_bias_grad": [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr],
-    "dgv2_bias_act_bwd": [_c_ptr] * 4 + [_c_i64, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
+    "dgv2_bias_act_bwd": [_c_ptr] * 4 + [_c_i64, _c_int, _c_f32, _c_f32, _c_ptr, _c_i64, _c_int, _c_ptr],
     "dgv2_upfirdn2d": [_c_ptr] * 3 + [_c_int] * 15 + [_c_ptr],
     "dgv2_resample": [_c_ptr] * 4 + [_c_int] * 19 + [_c_ptr],
     "dgv2_resample_tab": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr],

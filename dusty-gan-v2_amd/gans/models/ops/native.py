@@ -46,8 +46,11 @@ class _BiasActBackward(Function):
             N.check(gy, out)
             gx = torch.empty_like(gy)
             gb = torch.empty(size_b, device=gy.device, dtype=torch.float32)
-            N.call("dgv2_bias_act_bwd", N.ptr(gx), N.ptr(gb), N.ptr(gy), N.ptr(out), gy.numel() // size_b, size_b,
-                   alpha, scale, _dt(gy), N.stream())
+            rows = gy.numel() // size_b
+            # big tensors: many-block mode, per-block column sums folded by a second kernel
+            scratch = torch.empty(2048 * size_b, device=gy.device, dtype=torch.float32) if rows >= 65536 else None
+            N.call("dgv2_bias_act_bwd", N.ptr(gx), N.ptr(gb), N.ptr(gy), N.ptr(out), rows, size_b, alpha, scale,
+                   N.ptr(scratch), 0 if scratch is None else scratch.numel(), _dt(gy), N.stream())
         else:
             gx = _bias_act_raw(gy, None, out, 1, alpha, scale, step_b, size_b)
             if has_bias:

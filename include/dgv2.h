@@ -58,8 +58,10 @@ int dgv2_bias_grad(float* gb, const void* x, int64_t size_x, int64_t step_b, int
  * replaces: FusedLeakyReLUFunctionBackward.forward (act kernel + grad_input.sum), fused_act.py:22-45.
  * Returns DGV2_EINVAL for shapes it does not cover (C % vec != 0 or (C/vec) not dividing 256);
  * callers then use dgv2_fused_bias_act(grad=1) + dgv2_bias_grad. */
+/* scratch (optional fp32 [>= 2048*C]): many-block mode with a partial-sum reduce instead of atomics. */
 int dgv2_bias_act_bwd(void* gx, float* gb, const void* gy, const void* ref, int64_t rows, int C,
-                      float alpha, float scale, int dtype, void* stream);
+                      float alpha, float scale, float* scratch, int64_t scratch_elems, int dtype,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------
  * upfirdn2d

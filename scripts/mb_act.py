@@ -14,7 +14,7 @@ for shape in [(64,64,512,32),(64,32,256,64),(64,16,128,128),(64,8,64,256),(64,4,
     C=shape[-1]
     def fused():
         gx=torch.empty_like(gy); gb=torch.empty(C,device="cuda")
-        N.call("dgv2_bias_act_bwd", N.ptr(gx), N.ptr(gb), N.ptr(gy), N.ptr(out), gy.numel()//C, C, 0.2, 1.4, 1, N.stream())
+        N.call("dgv2_bias_act_bwd", N.ptr(gx), N.ptr(gb), N.ptr(gy), N.ptr(out), gy.numel()//C, C, 0.2, 1.4, None, 0, 1, N.stream())
     def old():
         gx=nat._bias_act_raw(gy,None,out,1,0.2,1.4,1,C); gb=torch.empty(C,device="cuda")
         N.call("dgv2_bias_grad", N.ptr(gb), N.ptr(gx), gx.numel(), 1, C, 1, N.stream())

@@ -255,6 +255,27 @@ def test_stem_matches_composed_reference(nat, ring, dtype):
     assert_rel(gb.cpu(), gbr, tol, "gb")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_act_backward_many_block_mode(nat, dtype):
+    """The >= 65536-row path of dgv2_bias_act_bwd (2048 blocks, partial column sums + reduce kernel) against the
+    fused_leaky_relu backward of the reference (fused_act.py:36-60): gx = g * (y > 0 ? 1 : 0.2) * sqrt2, gb = sum gx."""
+    g = torch.Generator().manual_seed(3)
+    B, H, W, C = 2, 64, 520, 32   # 66560 rows, not a multiple of the block tiling
+    x = torch.randn(B, H, W, C, generator=g)
+    b = torch.randn(C, generator=g)
+    gy = torch.randn(B, H, W, C, generator=g)
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True)
+    y = nat.bias_act(xd, bd)
+    gx, gb = torch.autograd.grad(y, [xd, bd], gy.to(DEV).to(dtype))
+    yr = y.detach().float().cpu()
+    gyr = gy.to(dtype).float()
+    want_gx = torch.where(yr > 0, gyr, gyr * 0.2) * math.sqrt(2.0)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert_rel(gx.float().cpu(), want_gx, tol, "gx")
+    assert_rel(gb.float().cpu(), want_gx.to(dtype).float().sum(dim=(0, 1, 2)), 1e-4 if dtype == torch.float32 else 2e-2, "gb")
+
+
 # ---------------------------------------------------------------------------------------
 CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     (2, 8, 16, 8, 16, 3, 1, 1, True),
