@@ -87,8 +87,9 @@ __device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, 
 // ---------------------------------------------------------------------------------------------
 // Pipelined kernel.  NI = input-tile staging slots (16 B each) per thread, NW = weight slots.
 // ---------------------------------------------------------------------------------------------
+// TO <= 32: a third wave per SIMD (<= 168 VGPRs) keeps more staging loads in flight on the HBM-bound small-channel layers
 template <typename T, int TO, int RW, int NI, int NC>
-__global__ __launch_bounds__(256, 2) void conv_pipe_kernel(T* __restrict__ y, const T* __restrict__ x,
+__global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void conv_pipe_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                            const T* __restrict__ w, DConv p) {
   constexpr int CE = 16 / sizeof(T);
   constexpr int MF = TO / 16, NF = 2 * RW, TH = 4 * RW;
@@ -443,7 +444,10 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
 
 template <typename T, int TO>
 int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, hipStream_t st) {
-  if (p.ncls == 4) return p.in_stride == 1 ? launch_pipe<T, TO, 1, 4, 4>(y, x, w, p, st) : -2;
+  if (p.ncls == 4) {
+    if constexpr (TO <= 32) return p.in_stride == 1 ? launch_pipe<T, TO, 1, 4, 4>(y, x, w, p, st) : -2;
+    else return -2;
+  }
   if (p.ncls != 1) return -2;
   if (p.in_stride == 1 && p.Hg >= 8) return launch_pipe<T, TO, 2, 6, 1>(y, x, w, p, st);
   if (p.in_stride == 1) return launch_pipe<T, TO, 1, 4, 1>(y, x, w, p, st);
@@ -532,8 +536,9 @@ extern "C" int dgv2_conv_taps_ex(void* y, const void* x, const void* w, int B, i
   DGV2_DISPATCH_DTYPE(dtype, {
     rc = -2;
     if ((!no_pipe || !plain) && wrap_ok) {
+      // four output classes quadruple the accumulators: 32-channel tiles keep them in registers
       if (O <= 16) rc = dispatch_pipe<T, 16>(y, x, w, p, st);
-      else if (O <= 32) rc = dispatch_pipe<T, 32>(y, x, w, p, st);
+      else if (O <= 32 || ncls == 4) rc = dispatch_pipe<T, 32>(y, x, w, p, st);
       else rc = dispatch_pipe<T, 64>(y, x, w, p, st);
     }
     if (rc == -2) {
