@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
     T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
     const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
     const int* __restrict__ cnt_w, int Ew, int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
-    int SH) {
+    int SHA) {
+  const int SH = SHA & 0xffff, ablate = SHA >> 16;   // ablate: benchmarking only (DGV2_RS_ABLATE)
   constexpr int VN = vec16<T>::N;
   constexpr int Q = VN / 4;
   __shared__ float4 ring[RS_RB][Q][256];
@@ -283,9 +284,19 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
   const int ho0 = strip * SH;
   const int ho1 = min(ho0 + SH, out_h);
   int t0 = -1, t1 = -1, t2 = -1, t3 = -1;   // ring tags (block-uniform)
+  // The strip's slice of the H table (<= 64 entries, host-checked SH * Eh <= 64) lives in one VGPR per field,
+  // entry e in lane e; the walk below fetches entries with v_readlane (uniform index) -- no scalar-memory
+  // round trip per output row, which is what bounded this kernel before.
+  const int lane = threadIdx.x & 63;
+  const int nent = (ho1 - ho0) * Eh;
+  const int tb_idx = lane < nent ? idx_h[ho0 * Eh + lane] : 0;
+  const float tb_cf = lane < nent ? coef_h[ho0 * Eh + lane] : 0.f;
+  const int tb_cnt = lane < ho1 - ho0 ? cnt_h[ho0 + lane] : 0;
   int rlast = -1;                           // last input row the strip reads: bound of the prefetch
-  for (int ho = ho0; ho < ho1; ++ho)
-    for (int a = 0; a < cnt_h[ho]; ++a) rlast = max(rlast, idx_h[ho * Eh + a]);
+  for (int i = 0; i < ho1 - ho0; ++i) {
+    const int n = __builtin_amdgcn_readlane(tb_cnt, i);
+    for (int a = 0; a < n; ++a) rlast = max(rlast, __builtin_amdgcn_readlane(tb_idx, i * Eh + a));
+  }
   // input rows are consumed in (mostly) increasing order: after filtering row r the loads of row r + 1 are
   // issued at once and stay in flight behind this row's FMAs / LDS traffic / output store
   int pr = -1;
@@ -300,17 +311,18 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
     pr = r;
   };
   for (int ho = ho0; ho < ho1; ++ho) {
-    const int n = cnt_h[ho];
+    const int n = __builtin_amdgcn_readlane(tb_cnt, ho - ho0);
     float acc[VN];
 #pragma unroll
     for (int j = 0; j < VN; ++j) acc[j] = 0.f;
     for (int a = 0; a < n; ++a) {
-      const int r = idx_h[ho * Eh + a];
-      const float fa = coef_h[ho * Eh + a];
+      const int e = (ho - ho0) * Eh + a;
+      const int r = __builtin_amdgcn_readlane(tb_idx, e);
+      const float fa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tb_cf), e));
       const int s = r & (RS_RB - 1);
       const int tag = s == 0 ? t0 : (s == 1 ? t1 : (s == 2 ? t2 : t3));
       if (tag != r) {
-        if (pr != r) issue(r);
+        if (pr != r && !(ablate & 2)) issue(r);
         float h[VN];
 #pragma unroll
         for (int j = 0; j < VN; ++j) h[j] = 0.f;
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
         for (int c = 0; c < 4; ++c)
 #pragma unroll
           for (int j = 0; j < VN; ++j) h[j] += cw[c] * pv[c].get(j);
-        if (r + 1 <= rlast) issue(r + 1); else pr = -1;
+        if (r + 1 <= rlast && !(ablate & 2)) issue(r + 1); else pr = -1;
 #pragma unroll
         for (int q = 0; q < Q; ++q) ring[s][q][tid] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
         t0 = s == 0 ? r : t0; t1 = s == 1 ? r : t1; t2 = s == 2 ? r : t2; t3 = s == 3 ? r : t3;
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
         acc[4 * q] += fa * h4.x; acc[4 * q + 1] += fa * h4.y; acc[4 * q + 2] += fa * h4.z; acc[4 * q + 3] += fa * h4.w;
       }
     }
-    if (live) {
+    if (live && !((ablate & 1) && acc[0] != 12345.678f)) {
       vec16<T> o;
 #pragma unroll
       for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
@@ -354,12 +366,15 @@ extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const
     const int64_t total = (int64_t)B * out_h * out_w * ((C + (vec ? VN : 1) - 1) / (vec ? VN : 1));
     const int grid = grid_for(total, 256, 256 * 64);
     static const bool no_stream = getenv("DGV2_NO_RSTREAM") != nullptr;   // A/B switch for benchmarking
-    if (vec && Ew <= 4 && !no_stream) {
-      const int SH = out_h >= 32 ? 16 : (out_h >= 8 ? 8 : out_h);
+    static const int rs_ablate = getenv("DGV2_RS_ABLATE") ? atoi(getenv("DGV2_RS_ABLATE")) : 0;
+    if (vec && Ew <= 4 && Eh <= 64 && !no_stream) {
+      int SH = out_h >= 32 ? 16 : (out_h >= 8 ? 8 : out_h);
+      while (SH > 1 && SH * Eh > 64) SH >>= 1;   // the strip's H-table slice must fit one lane-indexed register
       const int64_t blocks = (int64_t)B * ((out_h + SH - 1) / SH) * (((int64_t)out_w * (C / VN) + 255) / 256);
       if (blocks >= (1LL << 31)) return DGV2_EINVAL;
       resample_stream_kernel<T><<<(int)blocks, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
-                                                             cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, SH);
+                                                             cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w,
+                                                             SH | (rs_ablate << 16));
     } else if (vec)
       resample_tab_kernel<T, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
                                                         cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w);

@@ -36,6 +36,19 @@ def _worker(rank, world, tmp, q):
     sync.all_reduce()
     averaged = float(sync.flat[0]), float(sync.flat[-1])
 
+    # the trainer's flow: fresh gradient tensors per body, packed into the flat buffer by collect()
+    sync.begin()
+    assert all(p.grad is None for p in G.parameters())
+    params = list(G.parameters())
+    for i, p in enumerate(params):
+        if i != 1:                       # parameter 1 receives no gradient in this body -> its slice must be zeroed
+            p.grad = torch.full_like(p, float(10 * (rank + 1)))
+    sync.collect()
+    for p in params:
+        assert p.grad.data_ptr() >= sync.flat.data_ptr()   # views re-attached
+    sync.all_reduce()
+    packed = float(params[0].grad.flatten()[0]), float(params[1].grad.abs().max()), float(sync.flat[-1])
+
     # mutable buffers: rank 0 wins
     with torch.no_grad():
         for b in parallel.mutable_buffers(G):
@@ -51,7 +64,8 @@ def _worker(rank, world, tmp, q):
     A.cumulate(torch.ones(4, 1))
     A.update_p()  # rt = 1 on both -> p += 8 / 1000
 
-    q.put((rank, w0.sum().item(), local_only, averaged, bufs, {k: float(v) for k, v in sc.items()}, rt, float(A.p)))
+    q.put((rank, w0.sum().item(), local_only, averaged, bufs, {k: float(v) for k, v in sc.items()}, rt, float(A.p),
+           packed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -75,6 +89,7 @@ def test_two_rank_data_parallel_plumbing():
     assert set(r0[4]) == {10.0} and set(r1[4]) == {10.0}    # rank-0 buffers everywhere
     assert r0[5] == r1[5] == {"a": 0.5, "b": 2.0}
     assert r0[6] == r1[6] == 0.0 and r0[7] == r1[7] == pytest.approx(8 / 1000)
+    assert r0[8] == r1[8] == (15.0, 0.0, 15.0)              # begin/collect: mean of (10, 20); untouched slice zeroed
 
 
 def test_infinite_sampler_ranks_interleave_the_single_stream():
