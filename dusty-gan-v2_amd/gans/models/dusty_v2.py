@@ -264,10 +264,40 @@ class SynthesisNetwork(nn.Module):
                 s = None
                 pyramid.insert(0, (a, None))
         h, skip, i = None, None, 0
-        for layer, (a, s) in zip(self.layers, pyramid):
-            h, skip = layer.forward_cl(h, skip, (ws[:, i], ws[:, i + 1], ws[:, min(i + 2, N - 1)]), a, s, B)
-            i += layer.num_conv
+        cached = self._batched_styles(ws) if (ws.is_cuda and angle.shape[0] == 1) else []
+        try:
+            for layer, (a, s) in zip(self.layers, pyramid):
+                h, skip = layer.forward_cl(h, skip, (ws[:, i], ws[:, i + 1], ws[:, min(i + 2, N - 1)]), a, s, B)
+                i += layer.num_conv
+        finally:
+            for m in cached:
+                m._style_cache = None
         return skip, shift
+
+    def _batched_styles(self, ws):
+        """All style affines (EqualLR Linear of every ModConv2d on the fused path) as one batched GEMM; each
+        module finds its [B, I] style in `_style_cache` (consumed by ModConv2d.prep_args)."""
+        N = ws.shape[1]
+        mods, kidx, i = [], [], 0
+        for layer in self.layers:
+            if not (layer.pe.out_ch == 512 and layer.conv1.in_ch <= 1024):
+                return []
+            mods.append(layer.conv1); kidx.append(i)
+            nxt = 1
+            if not layer.is_first:
+                mods.append(layer.conv2); kidx.append(i + 1)
+                nxt = 2
+            for head in layer.head.heads.values():
+                mods.append(head); kidx.append(min(i + nxt, N - 1))
+            i += layer.num_conv
+        lins = [m.mod for m in mods]
+        if len(mods) > 48 or any(l.module.bias is None or l.gain_ != 1.0 or l.scale != lins[0].scale for l in lins):
+            return []
+        styles = native.style_affines(ws, [l.module.weight for l in lins], [l.module.bias for l in lins], kidx,
+                                      lins[0].scale)
+        for m, s in zip(mods, styles):
+            m._style_cache = s
+        return mods
 
     def forward(self, ws, angle, shifts="auto"):
         skip, shift = self.synthesize(ws, angle, shifts)

@@ -239,6 +239,80 @@ def downsample_angle(angle, shift, taps, B, ring=True):
     return out
 
 
+# ---------------------------------------------------------------------------------------
+# all style affines of the generator as one batched GEMM (reference: ModConv2d.mod, style.py:30,75)
+# ---------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    return (_ct.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def _int_array(vals):
+    return (_ct.c_int * len(vals))(*[int(v) for v in vals])
+
+
+class _Pack2d(Function):
+    """[L, Rmax, Cmax] zero-padded stack of the 2-D fp32 tensors `ts` (one launch); backward = _Unpack2d."""
+
+    @staticmethod
+    def forward(ctx, Rmax, Cmax, *ts):
+        ts = [t.detach().float().contiguous() for t in ts]
+        rows, cols = [t.shape[0] for t in ts], [t.shape[1] for t in ts]
+        out = torch.empty((len(ts), Rmax, Cmax), device=ts[0].device, dtype=torch.float32)
+        N.call("dgv2_pack2d", N.ptr(out), _ptr_array(ts), _int_array(rows), _int_array(cols), len(ts), Rmax, Cmax,
+               N.stream())
+        ctx.cfg = (rows, cols)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, cols = ctx.cfg
+        return (None, None) + tuple(_Unpack2d.apply(g, tuple(rows), tuple(cols)))
+
+
+class _Unpack2d(Function):
+    """The blocks [:rows[l], :cols[l]] of a packed [L, Rmax, Cmax] tensor as L contiguous tensors (one launch)."""
+
+    @staticmethod
+    def forward(ctx, packed, rows, cols):
+        packed = packed.contiguous()
+        L, Rmax, Cmax = packed.shape
+        outs = [torch.empty((rows[l], cols[l]), device=packed.device, dtype=torch.float32) for l in range(L)]
+        N.call("dgv2_unpack2d", _ptr_array(outs), N.ptr(packed), _int_array(rows), _int_array(cols), L, Rmax, Cmax,
+               N.stream())
+        ctx.cfg = (Rmax, Cmax, rows, cols)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        Rmax, Cmax, rows, cols = ctx.cfg
+        dev = next(g.device for g in gs if g is not None)
+        gs = [None if g is None else g.contiguous().float() for g in gs]
+        out = torch.empty((len(gs), Rmax, Cmax), device=dev, dtype=torch.float32)
+        N.call("dgv2_pack2d", N.ptr(out), _ptr_array(gs), _int_array(rows), _int_array(cols), len(gs), Rmax, Cmax,
+               N.stream())
+        return out, None, None
+
+
+_KIDX_CACHE = {}
+
+
+def style_affines(ws, weights, biases, kidx, scale):
+    """styles[l] = (ws[:, kidx[l]] @ weights[l].T) * scale + biases[l] for all l at once.
+    ws [B,S,K] fp32; weights[l] [I_l,K]; biases[l] [I_l] -> list of contiguous [B, I_l]."""
+    B, S, K = ws.shape
+    L = len(weights)
+    Is = [w.shape[0] for w in weights]
+    Imax = max(Is)
+    Wp = _Pack2d.apply(Imax, K, *weights)
+    bp = _Pack2d.apply(1, Imax, *[b.reshape(1, -1) for b in biases])
+    key = (tuple(kidx), str(ws.device))
+    if key not in _KIDX_CACHE:
+        _KIDX_CACHE[key] = torch.tensor(list(kidx), device=ws.device, dtype=torch.long)
+    X = ws.float().transpose(0, 1).index_select(0, _KIDX_CACHE[key])           # [L,B,K]
+    Sout = torch.baddbmm(bp, X, Wp.transpose(1, 2), alpha=float(scale))         # [L,B,Imax]
+    return list(_Unpack2d.apply(Sout, tuple([B] * L), tuple(Is)))
+
+
 def ema_update(ema, sumsq, add, count, weight, update=True):
     """ModConv2d's input-magnitude EMA (style.py:98-103) in one scalar launch: updates the 0-dim buffer `ema`
     in place with lerp(ema, (sumsq + add) / count, weight) and returns a fresh [1] snapshot of its value."""

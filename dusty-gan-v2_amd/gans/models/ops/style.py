@@ -31,6 +31,7 @@ class ModConv2d(nn.Module):
         self.demod = demod
         self.ema, self.ema_decay = ema, ema_decay
         self.register_buffer("ema_var", torch.tensor(1.0))
+        self._style_cache = None   # set by SynthesisNetwork when all style affines are computed in one batched GEMM
 
     def sample_weights(self, w_latent, sumsq=None, count=None):
         """Per-sample weights [B,O,I] (fp32).  `sumsq`/`count`: sum of squares and element count of
@@ -54,7 +55,7 @@ class ModConv2d(nn.Module):
         """(weight [O,I], style [B,I], ema_var, demod) for native.mod_layer, which fuses the whole
         weight preparation; the input-magnitude EMA is updated here first (style.py:98-103): the mean square
         is (sumsq + sumsq_add) / count, one scalar launch that also snapshots the value for this pass."""
-        style = self.mod(w_latent.float())
+        style = self._style_cache if self._style_cache is not None else self.mod(w_latent.float())
         ev = self.ema_var
         if ev.is_cuda and ev.dtype == torch.float32:
             upd = self.ema and self.training and (sumsq is not None or sumsq_add != 0.0)

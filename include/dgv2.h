@@ -172,6 +172,14 @@ int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, 
  * rows at [row_off, row_off+O)), dtype wb_dtype; stats fp32 [2+2B] and dsave fp32 [B,O] are produced
  * by fwd and consumed by bwd; shift fp32 [B] / fw fp32 [F] or NULL (F must be 256, PE columns
  * [cin, cin+2F)); I <= 1024.  bwd: G fp32 [B,Otot,I] -> gW fp32 [O,I], gs fp32 [B,I]; corr fp32 [1]. */
+/* Pack / unpack a list of L <= 48 small fp32 matrices (HOST array of device pointers, by value in the launch)
+ * into / out of one zero-padded [L, Rmax, Cmax] tensor: the 19 style affines of the generator (EqualLR Linear
+ * of every ModConv2d, style.py:30,75) then run as one batched library GEMM forward and two backward. */
+int dgv2_pack2d(float* packed, const float* const* src, const int* rows, const int* cols, int L, int Rmax,
+                int Cmax, void* stream);
+int dgv2_unpack2d(float* const* dst, const float* packed, const int* rows, const int* cols, int L, int Rmax,
+                  int Cmax, void* stream);
+
 /* Input-magnitude EMA of ModConv2d (style.py:98-103) as one scalar launch:
  * if update: ema <- lerp(ema, (sumsq[0] + add) * inv_count, weight); snapshot[0] <- ema[0]. sumsq may be NULL. */
 int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, float add, float inv_count,

@@ -276,6 +276,29 @@ def test_bias_act_backward_many_block_mode(nat, dtype):
     assert_rel(gb.float().cpu(), want_gx.to(dtype).float().sum(dim=(0, 1, 2)), 1e-4 if dtype == torch.float32 else 2e-2, "gb")
 
 
+def test_style_affines_match_per_layer_linear(nat):
+    """native.style_affines (dgv2_pack2d / dgv2_unpack2d + one batched GEMM) against the per-layer EqualLR
+    Linear of ModConv2d (style.py:30,75): values and gradients w.r.t. ws, every weight and every bias."""
+    g = torch.Generator().manual_seed(21)
+    B, S, K = 5, 4, 64
+    Is, kidx, scale = [24, 40, 8, 40, 16], [0, 1, 1, 3, 2], 0.125
+    ws = torch.randn(B, S, K, generator=g)
+    Ws = [torch.randn(i, K, generator=g) for i in Is]
+    bs = [torch.randn(i, generator=g) for i in Is]
+    gys = [torch.randn(B, i, generator=g) for i in Is]
+    ref_in = [ws.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in Ws + bs]
+    want = [(ref_in[0][:, k] @ ref_in[1 + l].t()) * scale + ref_in[1 + len(Is) + l] for l, k in enumerate(kidx)]
+    gwant = torch.autograd.grad(want, ref_in, gys)
+    dev_in = [ws.to(DEV).requires_grad_(True)] + [t.to(DEV).requires_grad_(True) for t in Ws + bs]
+    got = nat.style_affines(dev_in[0], dev_in[1:1 + len(Is)], dev_in[1 + len(Is):], kidx, scale)
+    ggot = torch.autograd.grad(got, dev_in, [t.to(DEV) for t in gys])
+    for a, b in zip(got, want):
+        assert a.is_contiguous()
+        assert_rel(a.cpu(), b.detach(), 2e-6)
+    for a, b in zip(ggot, gwant):
+        assert_rel(a.cpu(), b, 5e-6)
+
+
 # ---------------------------------------------------------------------------------------
 CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     (2, 8, 16, 8, 16, 3, 1, 1, True),
