@@ -219,24 +219,16 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(T* __restrict__ gx, f
   }
 }
 
-// gb[c] = sum_blk partial[blk][c]: 16 channels x 16 block-lanes per workgroup
+// gb[c] = sum_blk partial[blk][c]: one wave per channel (4 channels per workgroup), 64 lanes split the blocks
 __global__ __launch_bounds__(256) void bias_partial_reduce_kernel(float* __restrict__ gb, const float* __restrict__ partial,
                                                                   int nblk, int C) {
-  __shared__ float red[16][16];
-  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
   float s = 0.f;
-  if (c < C) {
 #pragma unroll 4
-    for (int k = bl; k < nblk; k += 16) s += partial[(int64_t)k * C + c];
-  }
-  red[bl][cl] = s;
-  __syncthreads();
-  if (bl == 0 && c < C) {
-#pragma unroll
-    for (int k = 1; k < 16; ++k) s += red[k][cl];
-    gb[c] = s;
-  }
+  for (int k = threadIdx.x & 63; k < nblk; k += 64) s += partial[(int64_t)k * C + c];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) gb[c] = s;
 }
 
 }  // namespace
@@ -268,6 +260,6 @@ extern "C" int dgv2_bias_act_bwd(void* gx, float* gb, const void* gy, const void
     bias_act_bwd_kernel<T><<<grid, 256, 0, st>>>((T*)gx, gb, (const T*)gy, (const T*)ref, rows, cvecs, alpha, scale,
                                                  many ? scratch : nullptr);
   });
-  if (many) bias_partial_reduce_kernel<<<(C + 15) / 16, 256, 0, st>>>(gb, scratch, grid, C);
+  if (many) bias_partial_reduce_kernel<<<(C + 3) / 4, 256, 0, st>>>(gb, scratch, grid, C);
   DGV2_RETURN_LAST();
 }

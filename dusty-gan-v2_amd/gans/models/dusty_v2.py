@@ -362,18 +362,25 @@ class ResidualBlock(nn.Module):
         self.blur_down = native.ResampleSpec([1, 3, 3, 1], down=(2, 2), ring=True, pads=(2, 1))
         self.skip_geom = native.ConvGeom(1, 1, 1, 0, True)
 
-    def forward_cl(self, x):
-        h = self.conv1.forward_cl(x, act=self.bias_act1)
+    def bank_entries(self, vec):
+        """(conv, bank entry) of the three convs as forward_cl will call them (see Discriminator._weight_bank)."""
+        c = 1.0 / math.sqrt(2)
+        fused = self.skip.in_ch % vec == 0 and self.skip._params()[1] is None
+        return [(self.conv1, self.conv1.bank_entry()), (self.conv2, self.conv2.bank_entry()),
+                (self.skip, self.skip.bank_entry(wscale=c if fused else None))]
+
+    def forward_cl(self, x, bank=None):
+        h = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank)
         c = 1.0 / math.sqrt(2)
         xs = native.resample(x, self.blur_down)
         if native.conv_resid_ok(xs, self.skip_geom) and self.skip._params()[1] is None:
             # (act(z) * sqrt2 + skip) / sqrt2 == act(z) * 1 + skip / sqrt2: the residual scale folds into the
             # activation gain and the skip weights, the sum into the skip conv's epilogue
             h = self.conv2.forward_cl(self.resample.forward_cl(h), act=self.bias_act2,
-                                      act_scale=self.bias_act2.scale * c)
-            return self.skip.forward_cl(xs, geom=self.skip_geom, resid=h, wscale=c)
-        h = self.conv2.forward_cl(self.resample.forward_cl(h), act=self.bias_act2)
-        s = self.skip.forward_cl(xs, geom=self.skip_geom)
+                                      act_scale=self.bias_act2.scale * c, bank=bank)
+            return self.skip.forward_cl(xs, geom=self.skip_geom, resid=h, wscale=c, bank=bank)
+        h = self.conv2.forward_cl(self.resample.forward_cl(h), act=self.bias_act2, bank=bank)
+        s = self.skip.forward_cl(xs, geom=self.skip_geom, bank=bank)
         return (h + s) * c
 
     def forward(self, x):
@@ -411,6 +418,26 @@ class Discriminator(nn.Module):
             ops.EqualLR(nn.Linear(ch(4), 1)),
         )
 
+    def _weight_bank(self):
+        """Compute-dtype copies of every ResidualBlock / epilogue conv weight (forward and data-gradient layouts)
+        in ONE launch per pass instead of ~5 tiny scale / permute / cast launches per conv (first-order passes
+        only; uniform precision only).  {conv: (scale, cpad, wf, wt)}."""
+        if self.num_fp16_layers not in (-1, 0):
+            return None
+        dt = LOW if self.num_fp16_layers == -1 else torch.float32
+        vec = 32 if dt == LOW else 16
+        items = []
+        for layer in self.layers:
+            if isinstance(layer, ResidualBlock):
+                items += layer.bank_entries(vec)
+        mb, conv = self.epilogue[0], self.epilogue[1]
+        cin = conv.in_ch
+        items.append((conv, conv.bank_entry(pad_in_to=(cin + vec - 1) // vec * vec)))
+        if len(items) > 32:
+            return None
+        prepared = native.conv_weight_bank([e for _, e in items], dt)
+        return {m: (e[1], e[2], wf, wt) for (m, e), (wf, wt) in zip(items, prepared)}
+
     def _fused_stem(self, h, layers):
         """BlurVH -> 1x1 conv -> bias + lrelu of a one-channel input as ONE streaming kernel (dgv2_stem_fwd/bwd)."""
         blur, conv, act = layers[0], layers[1], layers[2]
@@ -427,6 +454,7 @@ class Discriminator(nn.Module):
         first-order only, so that pass runs the composable ops."""
         layers = list(self.layers)
         i = 0
+        bank = None if (double_backward or not h.is_cuda) else self._weight_bank()
         fused = (not double_backward and h.is_cuda and h.shape[1] == 1 and len(layers) > 3
                  and isinstance(layers[0], ops.BlurVH) and isinstance(layers[1], ops.Conv2d)
                  and isinstance(layers[2], ops.FusedLeakyReLU) and layers[2].bias is not None
@@ -445,6 +473,9 @@ class Discriminator(nn.Module):
             if isinstance(layer, ops.Conv2d) and isinstance(nxt, ops.FusedLeakyReLU):
                 x = layer.forward_cl(x, act=nxt)  # stem conv + its bias/lrelu in one kernel
                 i += 2
+            elif isinstance(layer, ResidualBlock):
+                x = layer.forward_cl(x, bank=bank)
+                i += 1
             else:
                 x = layer.forward_cl(x)
                 i += 1
@@ -458,7 +489,7 @@ class Discriminator(nn.Module):
         vec = 32 if edt == LOW else 16
         cpad = (cin + vec - 1) // vec * vec  # whole 64-byte K-steps for the direct conv engine
         x = mb.forward_cl(x, pad_to=cpad, splits=splits)
-        x = conv.forward_cl(x.to(edt), pad_in_to=cpad, act=act1)
+        x = conv.forward_cl(x.to(edt), pad_in_to=cpad, act=act1, bank=bank)
         x = ops.from_cl(x).flatten(1)  # NCHW flatten order of the reference's nn.Flatten
         if edt == LOW and lin1.module.bias is None and lin1.gain_ == 1.0:
             # "everything reduced": the 65536 -> 512 Linear (8.6 GFLOP at B = 128, 134 MB of fp32 weights) as a

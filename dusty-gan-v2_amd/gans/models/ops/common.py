@@ -141,9 +141,21 @@ class Conv2d(nn.Sequential):
             return last.effective_weight(), last.module.bias, last.gain_
         return last.weight, last.bias, 1.0
 
-    def forward_cl(self, x, pad_in_to=None, act=None, geom=None, act_scale=None, resid=None, wscale=None):
+    def bank_entry(self, wscale=None, pad_in_to=None):
+        """(master parameter, total runtime scale, padded input channels) for native.conv_weight_bank."""
+        last = self[len(self) - 1]
+        if isinstance(last, EqualLR):
+            p, s = last.module.weight, last.scale * last.gain_
+        else:
+            p, s = last.weight, 1.0
+        cpad = p.shape[1] if pad_in_to is None else max(int(pad_in_to), p.shape[1])
+        return (p, s * (1.0 if wscale is None else wscale), cpad)
+
+    def forward_cl(self, x, pad_in_to=None, act=None, geom=None, act_scale=None, resid=None, wscale=None, bank=None):
         """act: a FusedLeakyReLU module fused into the conv epilogue; geom overrides the stride
-        (used when the caller has already decimated the input)."""
+        (used when the caller has already decimated the input).  bank: {conv: (scale, cpad, wf, wt)} from
+        Discriminator's weight bank: the prepared compute-dtype weights ride along on `w` (which stays the
+        differentiable fp32 handle) when they were built with this call's scale and padding."""
         w, b, gain = self._params()
         w = w.permute(0, 2, 3, 1)  # [O,kh,kw,C]
         if pad_in_to is not None and pad_in_to > w.shape[3]:
@@ -151,13 +163,20 @@ class Conv2d(nn.Sequential):
         geom = self.geom if geom is None else geom
         if wscale is not None:
             w = w * wscale
+        ent = None if bank is None else bank.get(self)
+        if ent is not None:
+            _, s_used, cpad_used = self.bank_entry(wscale, pad_in_to)
+            if abs(ent[0] - s_used) <= 1e-12 * abs(s_used) and ent[1] == cpad_used == w.shape[3]:
+                w._dgv2_wf, w._dgv2_wt = ent[2], ent[3]
+            else:
+                ent = None
         if resid is not None:   # conv(x, w) + resid in one launch (bias-free, activation-free skip conv)
             assert b is None and act is None
-            return native.conv_ring_resid(x, w.contiguous(), resid, geom)
+            return native.conv_ring_resid(x, w if ent is not None else w.contiguous(), resid, geom)
         if act is not None and b is None and act.bias is not None:
-            return native.conv_ring_act(x, w.contiguous(), act.bias, geom, act.negative_slope,
+            return native.conv_ring_act(x, w if ent is not None else w.contiguous(), act.bias, geom, act.negative_slope,
                                         act.scale if act_scale is None else act_scale)
-        y = native.conv_ring(x, w.contiguous(), geom)
+        y = native.conv_ring(x, w if ent is not None else w.contiguous(), geom)
         if b is not None:
             y = y + (b * gain).to(y.dtype)
         return y if act is None else act.forward_cl(y)

@@ -636,10 +636,12 @@ def _conv_dgrad_direct(gy, wt3, g, xshape):
     return gx
 
 
-def _conv_dgrad_raw(gy, w, g, xshape):
+def _conv_dgrad_raw(gy, w, g, xshape, wt=None):
+    """w [O,kh,kw,C] in gy's dtype, or wt = the prepared transposed weights [C, kh*kw, O] (weight bank)."""
     B, H, W, C = xshape
-    O = w.shape[0]
-    wt = w.permute(3, 1, 2, 0).contiguous()
+    O = gy.shape[3]
+    if wt is None:
+        wt = w.permute(3, 1, 2, 0).contiguous()
     N.check(gy, wt)
     even = g.stride == 1 or (H % 2 == 0 and W % 2 == 0)
     if _direct_ok(g, O % _kstep(gy) == 0) and even and not (g.kh == 1 and g.stride == 2):
@@ -687,30 +689,42 @@ def _conv_wgrad_raw(gy, x, g):
     return gw
 
 
+def _bank(w, x):
+    """(forward-layout, transposed) compute-dtype weights prepared by conv_weight_bank for this call, or (None, None)."""
+    wf, wt = getattr(w, "_dgv2_wf", None), getattr(w, "_dgv2_wt", None)
+    if wf is not None and wf.dtype == x.dtype:
+        return wf, wt
+    return None, None
+
+
 class _ConvFwd(Function):
     @staticmethod
     def forward(ctx, x, w, g):
         x = x.contiguous()
-        wc = w.detach().to(x.dtype).contiguous()
+        wc, ctx.wt = _bank(w, x)
+        if wc is None:
+            wc = w.detach().to(x.dtype).contiguous()
         ctx.save_for_backward(x, w)
         ctx.g = g
-        return _conv_fwd_raw(x, wc, g)
+        return _conv_fwd_raw(x, wc.reshape(w.shape), g)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = _ConvDgrad.apply(gy, w, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        gx = _ConvDgrad.apply(gy, w, ctx.g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gy, x, ctx.g) if ctx.needs_input_grad[1] else None
         return gx, gw, None
 
 
 class _ConvDgrad(Function):
     @staticmethod
-    def forward(ctx, gy, w, g, xshape):
+    def forward(ctx, gy, w, g, xshape, wt=None):
         gy = gy.contiguous()
-        wc = w.detach().to(gy.dtype).contiguous()
         ctx.save_for_backward(gy, w)
         ctx.g = g
+        if wt is not None and wt.dtype == gy.dtype:
+            return _conv_dgrad_raw(gy, None, g, xshape, wt=wt)
+        wc = w.detach().to(gy.dtype).contiguous()
         return _conv_dgrad_raw(gy, wc, g, xshape)
 
     @staticmethod
@@ -718,7 +732,7 @@ class _ConvDgrad(Function):
         gy, w = ctx.saved_tensors
         g_gy = _ConvFwd.apply(ggx, w, ctx.g) if ctx.needs_input_grad[0] else None
         g_w = _ConvWgrad.apply(gy, ggx, ctx.g) if ctx.needs_input_grad[1] else None
-        return g_gy, g_w, None, None
+        return g_gy, g_w, None, None, None
 
 
 class _ConvWgrad(Function):
@@ -750,8 +764,10 @@ class _ConvAct(Function):
     @staticmethod
     def forward(ctx, x, w, bias, g, alpha, scale):
         x = x.contiguous()
-        wc = w.detach().to(x.dtype).contiguous()
-        out = _conv_fwd_raw(x, wc, g, bias.detach().float().contiguous(), 3, alpha, scale)
+        wc, ctx.wt = _bank(w, x)
+        if wc is None:
+            wc = w.detach().to(x.dtype).contiguous()
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
         ctx.save_for_backward(x, w, out)
         ctx.cfg = (g, alpha, scale, bias.numel())
         return out
@@ -761,9 +777,31 @@ class _ConvAct(Function):
         x, w, out = ctx.saved_tensors
         g, alpha, scale, size_b = ctx.cfg
         gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
-        gx = _ConvDgrad.apply(gpre, w, g, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        gx = _ConvDgrad.apply(gpre, w, g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gpre, x, g) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None
+
+
+def conv_weight_bank(entries, dtype):
+    """entries: list of (param fp32 [O,C,kh,kw], scale, Cpad).  One launch; returns [(wf [O,kh*kw,Cpad], wt
+    [Cpad,kh*kw,O])] in `dtype` (views of two flat buffers)."""
+    L = len(entries)
+    dev = entries[0][0].device
+    dims = [(p.shape[0], p.shape[1], int(cp), p.shape[2] * p.shape[3]) for p, _, cp in entries]
+    sizes = [o * kk * cp for o, _, cp, kk in dims]
+    flat_f = torch.empty(sum(sizes), device=dev, dtype=dtype)
+    flat_t = torch.empty(sum(sizes), device=dev, dtype=dtype)
+    wfs, wts, off = [], [], 0
+    for (o, c, cp, kk), n in zip(dims, sizes):
+        wfs.append(flat_f[off:off + n].view(o, kk, cp))
+        wts.append(flat_t[off:off + n].view(cp, kk, o))
+        off += n
+    srcs = [p.detach() for p, _, _ in entries]
+    N.check(*srcs)
+    N.call("dgv2_conv_weight_bank", _ptr_array(wfs), _ptr_array(wts), _ptr_array(srcs), _int_array([d[0] for d in dims]),
+           _int_array([d[1] for d in dims]), _int_array([d[2] for d in dims]), _int_array([d[3] for d in dims]),
+           (_ct.c_float * L)(*[float(s) for _, s, _ in entries]), L, N.dtype_code(flat_f), N.stream())
+    return list(zip(wfs, wts))
 
 
 class _ConvResid(Function):
@@ -774,15 +812,17 @@ class _ConvResid(Function):
     def forward(ctx, x, w, resid, g):
         x = x.contiguous()
         resid = resid.contiguous()
-        wc = w.detach().to(x.dtype).contiguous()
+        wc, ctx.wt = _bank(w, x)
+        if wc is None:
+            wc = w.detach().to(x.dtype).contiguous()
         ctx.save_for_backward(x, w)
         ctx.g = g
-        return _conv_fwd_raw(x, wc, g, resid=resid)
+        return _conv_fwd_raw(x, wc.reshape(w.shape), g, resid=resid)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = _ConvDgrad.apply(gy, w, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        gx = _ConvDgrad.apply(gy, w, ctx.g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gy, x, ctx.g) if ctx.needs_input_grad[1] else None
         return gx, gw, (gy if ctx.needs_input_grad[2] else None), None
 

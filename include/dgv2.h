@@ -224,6 +224,13 @@ int dgv2_conv_wgrad(float* gw, const void* gy, const void* x, int B, int H, int 
 int dgv2_conv_wgrad_direct(float* gw, const void* gy, const void* x, int B, int H, int W, int C, int O,
                            int k, int stride, int pad, int ring, int dtype, void* stream);
 
+/* Compute-dtype copies of all conv weights of the discriminator in ONE launch (L <= 32): from each fp32
+ * master [O,C,kh,kw] (EqualLR runtime scale folded in: common.py:158-184) the forward layout
+ * wf [O, kh*kw, Cpad] and the data-gradient layout wt [Cpad, kh*kw, O].  HOST arrays of device pointers. */
+int dgv2_conv_weight_bank(void* const* wf, void* const* wt, const float* const* src, const int* O,
+                          const int* C, const int* Cpad, const int* kk, const float* scale, int L,
+                          int dtype, void* stream);
+
 /* Streaming weight gradient -- the hot-path engine for every discriminator conv (same reference lines as
  * dgv2_conv_wgrad).  A block keeps one (o, c) tile of gw for all k*k taps in registers and streams its
  * slice of the batch's pixel tiles; the per-slice partial sums go to `scratch` (plain stores) and are
