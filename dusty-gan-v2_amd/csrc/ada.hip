@@ -49,6 +49,7 @@ __global__ void upfirdn2d_kernel(T* __restrict__ out, const T* __restrict__ in, 
 
 constexpr int ADA_TW = 64;  // output columns per block
 
+// Generic version: any H (dynamic LDS = H * ADA_TW floats).  Kept for H > 64 or H % 4 != 0.
 __global__ __launch_bounds__(256) void ada_apply_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                         const float* __restrict__ Ay, const float* __restrict__ kx,
                                                         const int* __restrict__ off, const int* __restrict__ sgn,
@@ -88,6 +89,77 @@ __global__ __launch_bounds__(256) void ada_apply_kernel(float* __restrict__ y, c
   }
 }
 
+// LDS-staged version for H <= 64, H % 4 == 0, K <= 64 (the model's 64-row images): the block stages the
+// 64 + K - 1 source columns its taps touch (ONE wrap computation per staged element instead of one integer
+// modulo per tap), the sample's H x H operator and the taps in LDS; phase 1 then walks consecutive LDS words,
+// phase 2 keeps H/4 output rows per thread in registers so each filtered value is read once per thread and the
+// operator rows come as wave-uniform 16-byte broadcasts.
+constexpr int ADA_HMAX = 64, ADA_KMAX = 64;
+constexpr int ADA_XT = ADA_TW + ADA_KMAX;   // staged source columns (row pitch of the LDS tile)
+
+__global__ __launch_bounds__(256) void ada_apply_lds_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                            const float* __restrict__ Ay, const float* __restrict__ kx,
+                                                            const int* __restrict__ off, const int* __restrict__ sgn,
+                                                            const float* __restrict__ a, const float* __restrict__ c,
+                                                            int H, int W, int K, int transpose) {
+  __shared__ float xt[ADA_HMAX][ADA_XT];
+  __shared__ float tmp[ADA_HMAX][ADA_TW];
+  __shared__ __attribute__((aligned(16))) float Al[ADA_HMAX][ADA_HMAX];   // Al[i][h] = operator row of OUTPUT row i
+  __shared__ float kl[ADA_KMAX];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int j0 = blockIdx.x * ADA_TW;
+  const float* xb = x + (int64_t)b * H * W;
+  const float* Ab = Ay + (int64_t)b * H * H;
+  const int of = off[b], sg = sgn[b];
+  // source column of (jl, t): forward sg*(j0+jl) + of + t, transpose sg*((j0+jl) - of - t)  =  c0 + qa*jl + qb*t,
+  // LDS column q = qa*jl + qb*t + qs >= 0
+  const int qa = sg, qb = transpose ? -sg : 1;
+  const int c0 = transpose ? sg * (j0 - of) : sg * j0 + of;
+  const int qs = (qa < 0 ? ADA_TW - 1 : 0) + (qb < 0 ? K - 1 : 0);
+  const int nq = ADA_TW + K - 1;
+  for (int it = tid; it < H * nq; it += 256) {
+    const int h = it / nq, q = it - h * nq;
+    xt[h][q] = xb[(int64_t)h * W + floormod(c0 + q - qs, W)];
+  }
+  for (int it = tid; it < H * H; it += 256) {
+    const int i = it / H, h = it - i * H;
+    Al[i][h] = transpose ? Ab[h * H + i] : Ab[it];
+  }
+  if (tid < K) kl[tid] = kx[(int64_t)b * K + tid];
+  __syncthreads();
+  for (int it = tid; it < H * ADA_TW; it += 256) {
+    const int jl = it % ADA_TW, h = it / ADA_TW;
+    const int q0 = qa * jl + qs;
+    float acc = 0.f;
+    for (int t = 0; t < K; ++t) acc += kl[t] * xt[h][q0 + qb * t];
+    tmp[h][jl] = acc;
+  }
+  __syncthreads();
+  const int jl = tid % ADA_TW, ig = tid / ADA_TW;   // 4 row groups x 64 columns
+  const int rpt = H / 4;                             // output rows per thread (<= 16)
+  const int j = j0 + jl;
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int h = 0; h < H; h += 4) {
+    const float t0 = tmp[h][jl], t1 = tmp[h + 1][jl], t2 = tmp[h + 2][jl], t3 = tmp[h + 3][jl];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < rpt) {
+        const float4 av = *reinterpret_cast<const float4*>(&Al[ig * rpt + r][h]);
+        acc[r] += av.x * t0 + av.y * t1 + av.z * t2 + av.w * t3;
+      }
+    }
+  }
+  if (j < W) {
+    const float ab = a[b];
+    const float cb = (transpose || !c) ? 0.f : c[b];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r < rpt) y[((int64_t)b * H + ig * rpt + r) * W + j] = ab * acc[r] + cb;
+  }
+}
+
 }  // namespace
 
 extern "C" int dgv2_upfirdn2d(void* out, const void* in, const float* kernel, int major, int in_h, int in_w, int minor,
@@ -115,6 +187,10 @@ extern "C" int dgv2_ada_apply(float* y, const float* x, const float* Ay, const f
   const size_t lds = sizeof(float) * (size_t)H * ADA_TW;
   if (lds > 64 * 1024) return DGV2_EINVAL;
   dim3 grid((W + ADA_TW - 1) / ADA_TW, B);
-  ada_apply_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(y, x, Ay, kx, off, sgn, a, c, H, W, K, transpose);
+  static const bool no_lds = getenv("DGV2_NO_ADA_LDS") != nullptr;   // A/B switch for benchmarking
+  if (!no_lds && H <= ADA_HMAX && H % 4 == 0 && K <= ADA_KMAX)
+    ada_apply_lds_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(y, x, Ay, kx, off, sgn, a, c, H, W, K, transpose);
+  else
+    ada_apply_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(y, x, Ay, kx, off, sgn, a, c, H, W, K, transpose);
   DGV2_RETURN_LAST();
 }
