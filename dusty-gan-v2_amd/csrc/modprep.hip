@@ -342,9 +342,14 @@ extern "C" int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float*
     return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   ModGeom g{B, O, I, Otot, row_off, demod, cin, (F > 0 && shift) ? F : 0, 1.f / sqrtf((float)I)};
-  hipError_t e = hipMemsetAsync(corr, 0, sizeof(float), st);
-  if (e == hipSuccess) e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)O * I, st);
-  if (e == hipSuccess) e = hipMemsetAsync(gs, 0, sizeof(float) * (size_t)B * I, st);
+  hipError_t e;
+  if (gs == gW + (size_t)O * I && corr == gs + (size_t)B * I) {   // one allocation [gW | gs | corr]: one clear
+    e = hipMemsetAsync(gW, 0, sizeof(float) * ((size_t)O * I + (size_t)B * I + 1), st);
+  } else {
+    e = hipMemsetAsync(corr, 0, sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)O * I, st);
+    if (e == hipSuccess) e = hipMemsetAsync(gs, 0, sizeof(float) * (size_t)B * I, st);
+  }
   if (e != hipSuccess) return (int)e;
   // group size: as large as keeps >= ~1024 blocks in flight
   const int64_t pairs = (int64_t)O * B;

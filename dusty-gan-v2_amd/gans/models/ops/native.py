@@ -1133,9 +1133,11 @@ class _ModLayer(Function):
         grads = []
         off = 0
         for k in range(nm):
-            gW = torch.empty((Os[k], I), device=gy.device, dtype=torch.float32)
-            gs = torch.empty((B, I), device=gy.device, dtype=torch.float32)
-            corr = torch.empty(1, device=gy.device, dtype=torch.float32)
+            # one allocation [gW | gs | corr]: dgv2_mod_prep_bwd then clears it with a single launch
+            buf = torch.empty(Os[k] * I + B * I + 1, device=gy.device, dtype=torch.float32)
+            gW = buf[:Os[k] * I].view(Os[k], I)
+            gs = buf[Os[k] * I:Os[k] * I + B * I].view(B, I)
+            corr = buf[Os[k] * I + B * I:]
             N.call("dgv2_mod_prep_bwd", N.ptr(gW), N.ptr(gs), N.ptr(corr), N.ptr(gwb), N.ptr(Ws[k]), N.ptr(Ss[k]),
                    N.ptr(small[2 * k]), N.ptr(small[2 * k + 1]), N.ptr(Es[k]), N.ptr(shift) if rot else None,
                    N.ptr(fw) if rot else None, B, Os[k], I, Otot, off, int(cfg["demod"][k]), cfg["cin"],
