@@ -194,7 +194,7 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
 
 // Same contract as dgv2_bmm_nn_cat (bf16 in / bf16 out) for the shapes of the two top generator levels:
 // (Ka, Ks, O) = (64, 512, 32) (level-4 conv1) and, with Ks = 0 (xs unused), the PE-free shapes
-// (64,0,32), (32,0,64), (128,0,64), (64,0,128) = conv0 of levels 4/3 and the data gradients.  Returns DGV2_EINVAL for anything else: callers fall back to
+// (64,0,32), (32,0,64), (128,0,64), (64,0,128), (32,0,32), (64,0,64) = conv0 / conv2 of levels 4/3 and the data gradients.  Returns DGV2_EINVAL for anything else: callers fall back to
 // dgv2_bmm_nn_cat.
 extern "C" int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
                                    int Ks, int O, const float* bias, int act, float alpha, float scale, int dtype,
@@ -213,6 +213,8 @@ extern "C" int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, cons
   else if (Ks == 0 && Ka == 32 && O == 64) rc = mp_launch<4, 2, 1, 0>(y, xa, xs, w, g, st);
   else if (Ks == 0 && Ka == 128 && O == 64) rc = mp_launch<4, 2, 4, 0>(y, xa, xs, w, g, st);
   else if (Ks == 0 && Ka == 64 && O == 128) rc = mp_launch<8, 2, 2, 0>(y, xa, xs, w, g, st);
+  else if (Ks == 0 && Ka == 32 && O == 32) rc = mp_launch<2, 2, 1, 0>(y, xa, xs, w, g, st);
+  else if (Ks == 0 && Ka == 64 && O == 64) rc = mp_launch<4, 2, 2, 0>(y, xa, xs, w, g, st);
   else return DGV2_EINVAL;
   if (rc) return rc;
   DGV2_RETURN_LAST();

@@ -288,23 +288,28 @@ bool geom_ok(int B, int O, int I, int Otot, int row_off, int cin, int F) {
 }  // namespace
 
 // Input-magnitude EMA of ModConv2d (style.py:98-103) as one scalar kernel:
-//   ema <- lerp(ema, (sumsq + add) * inv_count, weight)   (skipped when sumsq == NULL and add == 0)
+//   ema <- lerp(ema, (sum(sumsq[0..nsum)) + add) * inv_count, weight)   (when update)
 //   snapshot <- ema        (the value this forward pass uses; the buffer itself keeps changing)
-static __global__ void ema_scalar_kernel(float* ema, float* snapshot, const float* sumsq, float add, float inv_count,
-                                  float weight, int update) {
-  float v = ema[0];
-  if (update) {
-    const float m = ((sumsq ? sumsq[0] : 0.f) + add) * inv_count;
-    v += weight * (m - v);
-    ema[0] = v;
+static __global__ void ema_scalar_kernel(float* ema, float* snapshot, const float* sumsq, int nsum, float add,
+                                         float inv_count, float weight, int update) {
+  float s = 0.f;   // one wave: fold the nsum partial sums of dgv2_sum_squares
+  if (sumsq)
+    for (int k = threadIdx.x; k < nsum; k += 64) s += sumsq[k];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    float v = ema[0];
+    if (update) {
+      v += weight * ((s + add) * inv_count - v);
+      ema[0] = v;
+    }
+    snapshot[0] = v;
   }
-  snapshot[0] = v;
 }
 
-extern "C" int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, float add, float inv_count,
+extern "C" int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, int nsum, float add, float inv_count,
                                float weight, int update, void* stream) {
-  if (!ema || !snapshot) return DGV2_EINVAL;
-  ema_scalar_kernel<<<1, 1, 0, (hipStream_t)stream>>>(ema, snapshot, sumsq, add, inv_count, weight, update);
+  if (!ema || !snapshot || nsum < 0) return DGV2_EINVAL;
+  ema_scalar_kernel<<<1, 64, 0, (hipStream_t)stream>>>(ema, snapshot, sumsq, nsum, add, inv_count, weight, update);
   DGV2_RETURN_LAST();
 }
 

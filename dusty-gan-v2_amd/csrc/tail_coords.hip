@@ -140,6 +140,10 @@ __global__ void coords_kernel(float* __restrict__ out, const float* __restrict__
   }
 }
 
+// Per-block partial sums: acc[0 .. SUMSQ_SLOTS) is OVERWRITTEN (slots past the grid with 0) and its entries add
+// up to the result -- no zero fill before, no same-address atomics (512 of them cost ~25 us per call).
+constexpr int SUMSQ_SLOTS = 512;
+
 template <typename T>
 __global__ void sum_squares_kernel(float* __restrict__ acc, const T* __restrict__ x, int64_t N, int C, int ld) {
   __shared__ float red[4];
@@ -154,7 +158,9 @@ __global__ void sum_squares_kernel(float* __restrict__ acc, const T* __restrict_
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) acc[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (blockIdx.x == 0)
+    for (int k = gridDim.x + threadIdx.x; k < SUMSQ_SLOTS; k += blockDim.x) acc[k] = 0.f;
 }
 
 template <typename T>
@@ -178,7 +184,9 @@ __global__ void sum_squares_vec_kernel(float* __restrict__ acc, const T* __restr
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) acc[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (blockIdx.x == 0)
+    for (int k = gridDim.x + threadIdx.x; k < SUMSQ_SLOTS; k += blockDim.x) acc[k] = 0.f;
 }
 
 }  // namespace
@@ -221,9 +229,9 @@ extern "C" int dgv2_coords_convert(float* out, const float* in, const float* mas
   DGV2_RETURN_LAST();
 }
 
+// acc: fp32 [512], overwritten with per-block partial sums (sum them, or hand them to dgv2_ema_scalar).
 extern "C" int dgv2_sum_squares(float* acc, const void* x, int64_t N, int C, int ld, int dtype, void* stream) {
-  if (!acc || !x || N < 0 || C <= 0 || ld < C) return DGV2_EINVAL;
-  if (N == 0) return 0;
+  if (!acc || !x || N <= 0 || C <= 0 || ld < C) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   DGV2_DISPATCH_DTYPE(dtype, {
     constexpr int VN = vec16<T>::N;

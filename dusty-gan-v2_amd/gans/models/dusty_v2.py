@@ -149,7 +149,7 @@ class SynthesisBlock(nn.Module):
             return native.mod_layer(hup, pe0, mods, bias=act.bias, act=True, alpha=act.negative_slope,
                                     scale=act.scale, shift=shift, fw=fw, cin=cin)
         if conv.training:
-            sumsq = pe_sq if sumsq is None else sumsq + pe_sq
+            sumsq = pe_sq if sumsq is None else sumsq.sum() + pe_sq
             sumsq = torch.as_tensor(sumsq, device=angle.device, dtype=torch.float32)
         wb = conv.sample_weights(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch))
         if shift is not None:

@@ -317,16 +317,17 @@ def ema_update(ema, sumsq, add, count, weight, update=True):
     """ModConv2d's input-magnitude EMA (style.py:98-103) in one scalar launch: updates the 0-dim buffer `ema`
     in place with lerp(ema, (sumsq + add) / count, weight) and returns a fresh [1] snapshot of its value."""
     snap = torch.empty(1, device=ema.device, dtype=torch.float32)
-    N.call("dgv2_ema_scalar", N.ptr(ema), N.ptr(snap), N.ptr(sumsq), float(add), 1.0 / float(count), float(weight),
-           int(update), N.stream())
+    N.call("dgv2_ema_scalar", N.ptr(ema), N.ptr(snap), N.ptr(sumsq), 0 if sumsq is None else sumsq.numel(), float(add),
+           1.0 / float(count), float(weight), int(update), N.stream())
     return snap
 
 
 def sum_squares(x, C=None):
-    """fp32 scalar: sum of squares of the first C channels of a channels-last tensor."""
+    """Sum of squares of the first C channels of a channels-last tensor as fp32 [512] PARTIAL sums (one per
+    block, zero padded): `.sum()` gives the scalar, native.ema_update consumes the partials directly."""
     ld = x.shape[-1]
     C = ld if C is None else C
-    acc = torch.zeros((), device=x.device, dtype=torch.float32)
+    acc = torch.empty(512, device=x.device, dtype=torch.float32)
     N.check(x)
     N.call("dgv2_sum_squares", N.ptr(acc), N.ptr(x), x.numel() // ld, C, ld, _dt(x), N.stream())
     return acc
@@ -382,7 +383,7 @@ def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0):
     N.check(x3, w3, bias)
     y = torch.empty((B, P, O), device=x3.device, dtype=out_dtype)
     if (_PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and P >= 4096
-            and (I, O) in ((64, 32), (32, 64), (128, 64), (64, 128))):
+            and (I, O) in ((64, 32), (32, 64), (128, 64), (64, 128), (32, 32), (64, 64))):
         # streaming shapes of the two top levels: sample-walking kernel without a PE part
         N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(bias), act, alpha,
                scale, _dt(x3), N.stream())

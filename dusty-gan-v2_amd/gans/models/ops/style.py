@@ -47,7 +47,7 @@ class ModConv2d(nn.Module):
         if self.ema:
             if self.training and sumsq is not None:
                 with torch.no_grad():
-                    self.ema_var.lerp_(sumsq / count, 1 - self.ema_decay)
+                    self.ema_var.lerp_(sumsq.sum() / count, 1 - self.ema_decay)
             wb = wb / (torch.sqrt(self.ema_var) + 1e-8).detach().clone()
         return wb
 
@@ -63,7 +63,7 @@ class ModConv2d(nn.Module):
                 ev = native.ema_update(self.ema_var, sumsq, sumsq_add, count if upd else 1, 1 - self.ema_decay, upd)
         elif self.ema and self.training and sumsq is not None:
             with torch.no_grad():
-                self.ema_var.lerp_((sumsq + sumsq_add) / count, 1 - self.ema_decay)
+                self.ema_var.lerp_((sumsq.sum() + sumsq_add) / count, 1 - self.ema_decay)
         return (self.weight[0, :, :, 0, 0], style, ev, self.demod)
 
     def forward_cl(self, x, w_latent, out_dtype=None, act=None):

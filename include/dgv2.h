@@ -181,8 +181,9 @@ int dgv2_unpack2d(float* const* dst, const float* packed, const int* rows, const
                   int Cmax, void* stream);
 
 /* Input-magnitude EMA of ModConv2d (style.py:98-103) as one scalar launch:
- * if update: ema <- lerp(ema, (sumsq[0] + add) * inv_count, weight); snapshot[0] <- ema[0]. sumsq may be NULL. */
-int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, float add, float inv_count,
+ * if update: ema <- lerp(ema, (sum(sumsq[0..nsum)) + add) * inv_count, weight); snapshot[0] <- ema[0].
+ * sumsq (NULL allowed): the per-block partial sums dgv2_sum_squares leaves (nsum = 512). */
+int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, int nsum, float add, float inv_count,
                     float weight, int update, void* stream);
 int dgv2_mod_prep_fwd(void* wb, float* dsave, float* stats, const float* W, const float* s,
                       const float* ema_var, const float* shift, const float* fw, int B, int O, int I,

@@ -197,7 +197,7 @@ def test_bmm_bf16_random_tolerance(nat):
 
 
 @pytest.mark.parametrize("Ka,Ks,O,P,B", [(64, 512, 32, 700, 5), (64, 512, 32, 256, 2), (64, 0, 32, 700, 3), (32, 0, 64, 300, 2),
-                                          (128, 0, 64, 300, 2), (64, 0, 128, 260, 2)])
+                                          (128, 0, 64, 300, 2), (64, 0, 128, 260, 2), (32, 0, 32, 300, 2), (64, 0, 64, 300, 2)])
 def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
     """dgv2_modconv_pe_fwd (pixel-tile blocks walking the samples, shared PE in registers) against the
     einsum of the reference's cat([h, pe]) + per-sample 1x1 conv + bias + lrelu (dusty_v2.py:153-162,
@@ -479,6 +479,8 @@ def test_sum_squares(nat):
     x = torch.randn(3, 7, 9, 40, generator=g)
     for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
         got = nat.sum_squares(x.to(DEV).to(dtype))
+        assert got.shape == (512,)   # per-block partial sums, zero padded
+        got = got.sum()
         assert abs(float(got) - float(x.double().pow(2).sum())) <= tol * float(x.double().pow(2).sum())
-    got = nat.sum_squares(x.to(DEV), C=13)
+    got = nat.sum_squares(x.to(DEV), C=13).sum()
     assert abs(float(got) - float(x[..., :13].double().pow(2).sum())) <= 1e-5 * float(x.double().pow(2).sum())
