@@ -183,7 +183,7 @@ __global__ __launch_bounds__(PB) void mod_prep_bwd_kernel(float* __restrict__ gW
                                                           const float* __restrict__ dsave,
                                                           const float* __restrict__ ema_var,
                                                           const float* __restrict__ shift,
-                                                          const float* __restrict__ fw, ModGeom g) {
+                                                          const float* __restrict__ fw, ModGeom g, int corr_slots) {
   __shared__ float red[4];
   const int o0 = blockIdx.x * OG, b0 = blockIdx.y * BG;
   const float c = 1.f / (sqrtf(ema_var[0]) + 1e-8f);
@@ -233,7 +233,13 @@ __global__ __launch_bounds__(PB) void mod_prep_bwd_kernel(float* __restrict__ gW
   }
   if (g.demod) {
     part = block_sum(part, red);
-    if (threadIdx.x == 0) atomicAdd(corr, part);
+    // one slot per block when the caller provided them (plain store: the buffer was cleared, nobody else writes
+    // the slot); 1000+ same-address atomics would otherwise serialise into the longest part of this kernel
+    if (threadIdx.x == 0) {
+      const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+      if (corr_slots > 1) corr[blk] = part;
+      else atomicAdd(corr, part);
+    }
   }
 }
 
@@ -265,16 +271,26 @@ __global__ __launch_bounds__(PB) void mod_prep_bwd_s_fix_kernel(float* __restric
 
 // W' = W * k (k = 1/wmax or scale): gW = gWraw * k, and with demod the max-norm term
 //   gW_i -= [|W_i| == wmax] sign(W_i) corr / wmax,  corr = sum gWraw w'.
-__global__ void mod_prep_bwd_w_fix_kernel(float* __restrict__ gW, const float* __restrict__ W,
-                                          const float* __restrict__ stats, const float* __restrict__ corr, int OI,
-                                          int demod, float scale) {
+__global__ __launch_bounds__(256) void mod_prep_bwd_w_fix_kernel(float* __restrict__ gW, const float* __restrict__ W,
+                                                                 const float* __restrict__ stats,
+                                                                 const float* __restrict__ corr, int ncorr, int OI,
+                                                                 int demod, float scale) {
+  __shared__ float red[4];
   const float wmax = demod ? stats[0] : 1.f;
   const float k = demod ? 1.f / wmax : scale;
+  float csum = 0.f;
+  if (demod) {   // fold the per-block partial sums
+    for (int t = threadIdx.x; t < ncorr; t += 256) csum += corr[t];
+    csum = wave_sum(csum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = csum;
+    __syncthreads();
+    csum = red[0] + red[1] + red[2] + red[3];
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < OI; i += gridDim.x * blockDim.x) {
     float v = gW[i] * k;
     if (demod) {
       const float w = W[i];
-      if (fabsf(w) == wmax) v -= (w > 0.f ? 1.f : -1.f) * corr[0] / wmax;
+      if (fabsf(w) == wmax) v -= (w > 0.f ? 1.f : -1.f) * csum / wmax;
     }
     gW[i] = v;
   }
@@ -337,11 +353,14 @@ extern "C" int dgv2_mod_prep_fwd(void* wb, float* dsave, float* stats, const flo
   DGV2_RETURN_LAST();
 }
 
-// Backward.  G fp32 [B,Otot,I] = dL/dwb; outputs gW fp32 [O,I], gs fp32 [B,I]; corr: fp32 [1] scratch.
+// Backward.  G fp32 [B,Otot,I] = dL/dwb; outputs gW fp32 [O,I], gs fp32 [B,I]; corr: fp32 [corr_elems] scratch
+// (>= 1; with >= one slot per launched block -- O*B is always enough -- the max-norm correction is summed without
+// same-address atomics).
 extern "C" int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float* G, const float* W, const float* s,
                                  const float* stats, const float* dsave, const float* ema_var, const float* shift,
                                  const float* fw, int B, int O, int I, int Otot, int row_off, int demod, int cin,
-                                 int F, void* stream) {
+                                 int F, int corr_elems, void* stream) {
+  if (corr_elems < 1) return DGV2_EINVAL;
   if (!gW || !gs || !corr || !G || !W || !s || !stats || !dsave || !ema_var ||
       !geom_ok(B, O, I, Otot, row_off, cin, F))
     return DGV2_EINVAL;
@@ -349,27 +368,35 @@ extern "C" int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float*
   ModGeom g{B, O, I, Otot, row_off, demod, cin, (F > 0 && shift) ? F : 0, 1.f / sqrtf((float)I)};
   hipError_t e;
   if (gs == gW + (size_t)O * I && corr == gs + (size_t)B * I) {   // one allocation [gW | gs | corr]: one clear
-    e = hipMemsetAsync(gW, 0, sizeof(float) * ((size_t)O * I + (size_t)B * I + 1), st);
+    e = hipMemsetAsync(gW, 0, sizeof(float) * ((size_t)O * I + (size_t)B * I + corr_elems), st);
   } else {
-    e = hipMemsetAsync(corr, 0, sizeof(float), st);
+    e = hipMemsetAsync(corr, 0, sizeof(float) * corr_elems, st);
     if (e == hipSuccess) e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)O * I, st);
     if (e == hipSuccess) e = hipMemsetAsync(gs, 0, sizeof(float) * (size_t)B * I, st);
   }
   if (e != hipSuccess) return (int)e;
   // group size: as large as keeps >= ~1024 blocks in flight
   const int64_t pairs = (int64_t)O * B;
+  int nblk;
   if (pairs >= 16 * 1024) {
     dim3 grid((O + 3) / 4, (B + 3) / 4);
-    mod_prep_bwd_kernel<4, 4><<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g);
+    nblk = grid.x * grid.y;
+    mod_prep_bwd_kernel<4, 4><<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g,
+                                                   corr_elems >= nblk ? nblk : 1);
   } else if (pairs >= 4 * 1024) {
     dim3 grid((O + 1) / 2, (B + 1) / 2);
-    mod_prep_bwd_kernel<2, 2><<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g);
+    nblk = grid.x * grid.y;
+    mod_prep_bwd_kernel<2, 2><<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g,
+                                                   corr_elems >= nblk ? nblk : 1);
   } else {
     dim3 grid(O, B);
-    mod_prep_bwd_kernel<1, 1><<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g);
+    nblk = O * B;
+    mod_prep_bwd_kernel<1, 1><<<grid, PB, 0, st>>>(gW, gs, corr, G, W, s, stats, dsave, ema_var, shift, fw, g,
+                                                   corr_elems >= nblk ? nblk : 1);
   }
+  const int ncorr = corr_elems >= nblk ? nblk : 1;
   if (demod) mod_prep_bwd_s_fix_kernel<<<B, PB, 0, st>>>(gs, s, stats, I);
-  mod_prep_bwd_w_fix_kernel<<<grid_for((int64_t)O * I, 256, 256), 256, 0, st>>>(gW, W, stats, corr, O * I, demod,
-                                                                              g.scale);
+  mod_prep_bwd_w_fix_kernel<<<grid_for((int64_t)O * I, 256, 256), 256, 0, st>>>(gW, W, stats, corr, ncorr, O * I,
+                                                                              demod, g.scale);
   DGV2_RETURN_LAST();
 }

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -43,7 +43,7 @@ SIGNATURES = {
     "dgv2_unpack2d": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_ema_scalar": [_c_ptr] * 3 + [_c_int] + [_c_f32] * 3 + [_c_int, _c_ptr],
     "dgv2_mod_prep_fwd": [_c_ptr] * 8 + [_c_int] * 9 + [_c_ptr],
-    "dgv2_mod_prep_bwd": [_c_ptr] * 11 + [_c_int] * 8 + [_c_ptr],
+    "dgv2_mod_prep_bwd": [_c_ptr] * 11 + [_c_int] * 9 + [_c_ptr],
     "dgv2_sum_squares": [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_ptr],
     "dgv2_conv_fwd": [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_conv_taps": [_c_ptr] * 3 + [_c_int] * 17 + [_c_ptr] + [_c_int] * 3 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int,

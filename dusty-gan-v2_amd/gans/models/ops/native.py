@@ -1135,14 +1135,15 @@ class _ModLayer(Function):
         off = 0
         for k in range(nm):
             # one allocation [gW | gs | corr]: dgv2_mod_prep_bwd then clears it with a single launch
-            buf = torch.empty(Os[k] * I + B * I + 1, device=gy.device, dtype=torch.float32)
+            ncorr = min(Os[k] * B, 8192)   # one slot per launched block (the kernel groups pairs, so this is ample)
+            buf = torch.empty(Os[k] * I + B * I + ncorr, device=gy.device, dtype=torch.float32)
             gW = buf[:Os[k] * I].view(Os[k], I)
             gs = buf[Os[k] * I:Os[k] * I + B * I].view(B, I)
             corr = buf[Os[k] * I + B * I:]
             N.call("dgv2_mod_prep_bwd", N.ptr(gW), N.ptr(gs), N.ptr(corr), N.ptr(gwb), N.ptr(Ws[k]), N.ptr(Ss[k]),
                    N.ptr(small[2 * k]), N.ptr(small[2 * k + 1]), N.ptr(Es[k]), N.ptr(shift) if rot else None,
                    N.ptr(fw) if rot else None, B, Os[k], I, Otot, off, int(cfg["demod"][k]), cfg["cin"],
-                   cfg["F"] if rot else 0, N.stream())
+                   cfg["F"] if rot else 0, ncorr, N.stream())
             grads += [gW, gs, None]
             off += Os[k]
         return (None, gxa, None, gb, None, None, *grads)

@@ -191,7 +191,7 @@ int dgv2_mod_prep_fwd(void* wb, float* dsave, float* stats, const float* W, cons
 int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float* G, const float* W, const float* s,
                       const float* stats, const float* dsave, const float* ema_var, const float* shift,
                       const float* fw, int B, int O, int I, int Otot, int row_off, int demod, int cin,
-                      int F, void* stream);
+                      int F, int corr_elems, void* stream);
 
 /* Sum of squares of the first C channels of x [N, ld] into acc[0] (fp32, ACCUMULATES).
  * replaces: x.pow(2).mean() in ModConv2d.forward (style.py:100-101). */
