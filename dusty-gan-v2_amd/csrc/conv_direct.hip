@@ -55,8 +55,11 @@ struct DConv {
 };
 
 // Epilogue shared by both kernels: one accumulator fragment (16 channels x 16 positions) -> y.
+// bias4: this lane's four bias values (registers: a global bias read here would make the compiler drain every
+// prefetch in flight with vmcnt(0) before each tile's stores), or nullptr
 template <typename T>
-__device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, int o, f32x4 v) {
+__device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, int o, f32x4 v,
+                                           const float* bias4 = nullptr) {
   const T* rrow = p.resid ? reinterpret_cast<const T*>(p.resid) + (row - reinterpret_cast<T*>(p.ybase)) : nullptr;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -64,7 +67,8 @@ __device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, 
     float f = v[r];
     if (p.accumulate) f += to_f32(row[o + r]);
     if (rrow) f += to_f32(rrow[o + r]);
-    if (p.bias) f += p.bias[o + r];
+    if (bias4) f += bias4[r];
+    else if (p.bias) f += p.bias[o + r];
     if (p.act == 3) f = (f > 0.f ? f : f * p.alpha) * p.scale;
     v[r] = f;
   }
@@ -199,6 +203,14 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
     bpix[nf] = (wave * RW + (nf >> 1)) * p.in_stride * p.cols + ((nf & 1) * 16 + lr) * p.in_stride;
+  float biasr[MF][4];              // this lane's output channels o0 + mf*16 + lc*4 + r
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = o0 + mf * 16 + lc * 4 + r;
+      biasr[mf][r] = (p.bias && o < p.O) ? p.bias[o] : 0.f;
+    }
   const int aswz = lc ^ ((lr >> 2) & 3);
 
   // ---- pipeline over (tile, chunk) stages ----
@@ -277,19 +289,55 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 
     if (cc == nchunks - 1) {        // tile finished: epilogue, reset accumulators
       const int w0 = (tw0 + tile) * DTW;
+      // fast path (block-uniform): full channel tile, plain overwrite -- straight-line bias / lrelu / convert and,
+      // for bf16, fragment pairs leaving as 16-byte stores; everything else takes the general store_frag
+      const bool fast = !p.accumulate && !p.resid && o0 + TO <= p.O && (p.O & 7) == 0;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
           const int gh = h0 + wave * RW + (nf >> 1);
           const int gw = w0 + (nf & 1) * 16 + lr;
-          if (gh < p.Hg && gw < p.Wg) {
-            const int yh = gh * p.out_stride + p.cls_ooh[c], yw = gw * p.out_stride + p.cls_oow[c];
-            T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.O;
+          const bool live = gh < p.Hg && gw < p.Wg;
+          const int yh = gh * p.out_stride + p.cls_ooh[c], yw = gw * p.out_stride + p.cls_oow[c];
+          T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.O;
+          if (fast) {
+            float f[MF][4];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float t = acc[c][mf][nf][r] + biasr[mf][r];
+                if (p.act == 3) t = fmaxf(t, t * p.alpha) * p.scale;   // leaky ReLU, 0 <= alpha <= 1
+                f[mf][r] = t;
+              }
+            if constexpr (sizeof(T) == 2 && MF >= 2) {
+#pragma unroll
+              for (int mf = 0; mf < MF; mf += 2) {
+                uint4 pk;
+                const int co = pack_pair_bf16(f[mf], f[mf + 1], lc, pk);   // every lane takes part in the exchange
+                if (live) *reinterpret_cast<uint4*>(row + o0 + mf * 16 + co) = pk;
+              }
+            } else {
+#pragma unroll
+              for (int mf = 0; mf < MF; ++mf) {
+                if (!live) continue;
+                T* q = row + o0 + mf * 16 + lc * 4;
+                if constexpr (sizeof(T) == 4) {
+                  *reinterpret_cast<float4*>(q) = make_float4(f[mf][0], f[mf][1], f[mf][2], f[mf][3]);
+                } else {
+                  union { uint2 u; bf16_t e[4]; } pk;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) pk.e[r] = (bf16_t)f[mf][r];
+                  *reinterpret_cast<uint2*>(q) = pk.u;
+                }
+              }
+            }
+          } else if (live) {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
               const int o = o0 + mf * 16 + lc * 4;
-              if (o < p.O) store_frag<T>(p, row, o, acc[c][mf][nf]);
+              if (o < p.O) store_frag<T>(p, row, o, acc[c][mf][nf], biasr[mf]);
             }
           }
 #pragma unroll
