@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
   constexpr int NW = (TO * 9 * 4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   __shared__ int s_widx[9], s_tapoff[9], s_t0[5], s_xoff[6], s_xslot[6], s_xcls[6], s_xrow[6];
+  __shared__ __attribute__((aligned(16))) float s_bias[TO];
   const int npix = p.rows * p.cols;
   uint4* lds_in = smem;
   uint4* lds_w = smem + npix * 4;
@@ -203,14 +204,10 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
     bpix[nf] = (wave * RW + (nf >> 1)) * p.in_stride * p.cols + ((nf & 1) * 16 + lr) * p.in_stride;
-  float biasr[MF][4];              // this lane's output channels o0 + mf*16 + lc*4 + r
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = o0 + mf * 16 + lc * 4 + r;
-      biasr[mf][r] = (p.bias && o < p.O) ? p.bias[o] : 0.f;
-    }
+  // the tile's bias in LDS: read in the epilogue without a vector-memory wait (a global read there would drain
+  // every prefetch in flight) and without holding MF*4 registers through the MFMA loop
+  if (tid < TO) s_bias[tid] = (p.bias && o0 + tid < p.O) ? p.bias[o0 + tid] : 0.f;
+  __syncthreads();
   const int aswz = lc ^ ((lr >> 2) & 3);
 
   // ---- pipeline over (tile, chunk) stages ----
@@ -304,13 +301,16 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
           if (fast) {
             float f[MF][4];
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
+            for (int mf = 0; mf < MF; ++mf) {
+              const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[mf * 16 + lc * 4]);
+              const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                float t = acc[c][mf][nf][r] + biasr[mf][r];
+                float t = acc[c][mf][nf][r] + bq[r];
                 if (p.act == 3) t = fmaxf(t, t * p.alpha) * p.scale;   // leaky ReLU, 0 <= alpha <= 1
                 f[mf][r] = t;
               }
+            }
             if constexpr (sizeof(T) == 2 && MF >= 2) {
 #pragma unroll
               for (int mf = 0; mf < MF; mf += 2) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
               const int o = o0 + mf * 16 + lc * 4;
-              if (o < p.O) store_frag<T>(p, row, o, acc[c][mf][nf], biasr[mf]);
+              if (o < p.O) store_frag<T>(p, row, o, acc[c][mf][nf], &s_bias[mf * 16 + lc * 4]);
             }
           }
 #pragma unroll
