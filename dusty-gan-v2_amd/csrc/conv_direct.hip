@@ -153,16 +153,26 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
     const int iy = (int)(((float)pix + 0.5f) * p.inv_cols);
     ipos[j] = (iy << 16) | (pix - iy * p.cols);
   }
-  int goff[NI];   // element offset inside image b of the slot's 16 bytes at chunk 0, or -1 (zero fill)
-  auto tile_offsets = [&](int tw) {
+  // A block's tiles share their rows: the H part of every slot's address (clamp / zero fill) is computed once,
+  // per tile only the W coordinate is wrapped.
+  int grow[NI];   // clamped row offset (elements) + channel offset of the slot, or -1 (zero fill)
+  {
     const int gh_base = h0 * p.in_stride + p.ioff_h + p.dymin;
-    const int gw_base = tw * DTW * p.in_stride + p.ioff_w + p.dxmin;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int id = tid + j * 256;
-      int gh = gh_base + (ipos[j] >> 16), gw = gw_base + (ipos[j] & 0xffff);
+      int gh = gh_base + (ipos[j] >> 16);
       const bool zero = id >= n_in || (p.hzero && (gh < 0 || gh >= p.Hin));
       gh = gh < 0 ? 0 : (gh >= p.Hin ? p.Hin - 1 : gh);
+      grow[j] = zero ? -1 : gh * p.Win * p.Cin + (id & 3) * CE;
+    }
+  }
+  int goff[NI];   // element offset inside image b of the slot's 16 bytes at chunk 0, or -1 (zero fill)
+  auto tile_offsets = [&](int tw) {
+    const int gw_base = tw * DTW * p.in_stride + p.ioff_w + p.dxmin;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int gw = gw_base + (ipos[j] & 0xffff);
       if (p.ring) {   // -Win <= gw < 4*Win (host-checked)
         gw = gw < 0 ? gw + p.Win : gw;
         gw = gw >= 2 * p.Win ? gw - 2 * p.Win : gw;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
       } else {
         gw = gw < 0 ? 0 : (gw >= p.Win ? p.Win - 1 : gw);
       }
-      goff[j] = zero ? -1 : (gh * p.Win + gw) * p.Cin + (id & 3) * CE;
+      goff[j] = grow[j] < 0 ? -1 : grow[j] + gw * p.Cin;
     }
   };
 
