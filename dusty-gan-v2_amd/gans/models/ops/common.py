@@ -141,6 +141,10 @@ class Conv2d(nn.Sequential):
             return last.effective_weight(), last.module.bias, last.gain_
         return last.weight, last.bias, 1.0
 
+    def _params_bias(self):
+        last = self[len(self) - 1]
+        return (last.module.bias, last.gain_) if isinstance(last, EqualLR) else (last.bias, 1.0)
+
     def bank_entry(self, wscale=None, pad_in_to=None):
         """(master parameter, total runtime scale, padded input channels) for native.conv_weight_bank."""
         last = self[len(self) - 1]
@@ -156,20 +160,26 @@ class Conv2d(nn.Sequential):
         (used when the caller has already decimated the input).  bank: {conv: (scale, cpad, wf, wt)} from
         Discriminator's weight bank: the prepared compute-dtype weights ride along on `w` (which stays the
         differentiable fp32 handle) when they were built with this call's scale and padding."""
-        w, b, gain = self._params()
-        w = w.permute(0, 2, 3, 1)  # [O,kh,kw,C]
-        if pad_in_to is not None and pad_in_to > w.shape[3]:
-            w = F.pad(w, (0, pad_in_to - w.shape[3]))
         geom = self.geom if geom is None else geom
-        if wscale is not None:
-            w = w * wscale
         ent = None if bank is None else bank.get(self)
         if ent is not None:
-            _, s_used, cpad_used = self.bank_entry(wscale, pad_in_to)
-            if abs(ent[0] - s_used) <= 1e-12 * abs(s_used) and ent[1] == cpad_used == w.shape[3]:
+            p_raw, s_used, cpad_used = self.bank_entry(wscale, pad_in_to)
+            if abs(ent[0] - s_used) <= 1e-12 * abs(s_used) and ent[1] == cpad_used:
+                # the kernels read the bank's prepared copies; `w` only carries the autograd edge to the parameter
+                w = native.scaled_handle(p_raw, s_used)
+                if cpad_used > w.shape[3]:
+                    w = F.pad(w, (0, cpad_used - w.shape[3]))
                 w._dgv2_wf, w._dgv2_wt = ent[2], ent[3]
+                b, gain = self._params_bias()
             else:
                 ent = None
+        if ent is None:
+            w, b, gain = self._params()
+            w = w.permute(0, 2, 3, 1)  # [O,kh,kw,C]
+            if pad_in_to is not None and pad_in_to > w.shape[3]:
+                w = F.pad(w, (0, pad_in_to - w.shape[3]))
+            if wscale is not None:
+                w = w * wscale
         if resid is not None:   # conv(x, w) + resid in one launch (bias-free, activation-free skip conv)
             assert b is None and act is None
             return native.conv_ring_resid(x, w if ent is not None else w.contiguous(), resid, geom)

@@ -783,6 +783,25 @@ class _ConvAct(Function):
         return gx, gw, gb, None, None, None
 
 
+class _ScaledHandle(Function):
+    """Differentiable stand-in for `param * scale` laid out [O,kh,kw,C] whose VALUES are never read: with the
+    weight bank the conv kernels take the prepared compute-dtype copies, and this tensor only carries the autograd
+    edge back to the parameter (backward: grad * scale in parameter layout).  Saves the forward scaling launch."""
+
+    @staticmethod
+    def forward(ctx, param, scale):
+        ctx.scale = scale
+        return param.detach().permute(0, 2, 3, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.permute(0, 3, 1, 2) * ctx.scale, None
+
+
+def scaled_handle(param, scale):
+    return _ScaledHandle.apply(param, float(scale))
+
+
 def conv_weight_bank(entries, dtype):
     """entries: list of (param fp32 [O,C,kh,kw], scale, Cpad).  One launch; returns [(wf [O,kh*kw,Cpad], wt
     [Cpad,kh*kw,O])] in `dtype` (views of two flat buffers)."""

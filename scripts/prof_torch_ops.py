@@ -14,7 +14,7 @@ tr = Trainer(cfg, sync_scalars=False)
 for it in (16, 1, 2):
     tr.step(it)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     tr.step(3)
     torch.cuda.synchronize()
 rows = []
@@ -40,3 +40,15 @@ for e in prof.key_averages():
         agg[e.key] = (t, e.count)
 for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"{t:9.0f}us x{c:5d} {k}")
+
+print("---- small ATen ops by call site ----")
+import collections, re
+site = collections.Counter(); sitet = collections.Counter()
+for e in prof.events():
+    if e.name in ("aten::mul", "aten::fill_", "aten::copy_", "aten::add_", "aten::zero_", "aten::add", "aten::cat", "aten::sum", "aten::div"):
+        st = [f for f in (e.stack or []) if "dusty-gan-v2_amd" in f or "bench.py" in f]
+        key = (e.name, " <- ".join(re.sub(r".*dusty-gan-v2_amd/", "", f)[:60] for f in st[:3]))
+        site[key] += 1
+        sitet[key] += getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0)
+for k, c in site.most_common(45):
+    print(f"x{c:4d} {sitet[k]:8.0f}us {k[0]:12s} {k[1]}")
