@@ -170,16 +170,27 @@ __global__ void sum_squares_vec_kernel(float* __restrict__ acc, const T* __restr
   __shared__ float red[4];
   float s = 0.f;
   const int64_t total = N * cvecs;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / cvecs;
-    const int cv = (int)(t % cvecs);
-    vec16<T> v;
-    v.load(x + r * ld + cv * VN);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  constexpr int U = 4;   // independent 16-byte loads in flight per thread (512 blocks must cover HBM latency)
+  for (int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t0 < total; t0 += stride * U) {
+    vec16<T> v[U];
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      const float f = v.get(j);
-      s += f * f;
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = t0 + u * stride;
+      v[u].raw = make_uint4(0, 0, 0, 0);
+      if (t < total) {
+        const int64_t r = cvecs == ld / VN ? 0 : t / cvecs;   // dense rows: one flat index
+        const int64_t off = cvecs == ld / VN ? t * VN : r * ld + (t - r * cvecs) * VN;
+        v[u].load(x + off);
+      }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        const float f = v[u].get(j);
+        s += f * f;
+      }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
