@@ -236,9 +236,23 @@ class Trainer:
             # one private memory pool per graph: the bodies are replayed in a different order than they
             # were captured (lazy R1, shared optimizer graph), which a shared pool does not allow; HBM is
             # not the constraint here (288 GB)
-            with torch.cuda.graph(g):
+            # thread_local: API calls of other threads (the RCCL watchdog polls events) must not invalidate the capture
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    fn(*args, scalars)
+            except Exception as e:  # keep training: this body runs eagerly from now on
+                import warnings
+                torch.cuda.synchronize()
+                warnings.warn(f"hipGraph capture of '{name}' failed ({type(e).__name__}: {e}); running it eagerly")
+                self._graphs[name] = None
+                scalars = {}
                 fn(*args, scalars)
+                return scalars
             self._graphs[name] = (g, scalars)
+        if self._graphs[name] is None:
+            scalars = {}
+            fn(*args, scalars)
+            return scalars
         g, scalars = self._graphs[name]
         g.replay()
         if os.environ.get("DGV2_GRAPH_SYNC"):  # debugging aid: serialise host and device after each replay
