@@ -189,8 +189,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        # DGV2_DIST_SMOKE=1: functional test of the N > 1 path on a ONE-GPU box (every rank on cuda:0, gloo
+        # collectives); never a measurement
+        if os.environ.get("DGV2_DIST_SMOKE"):
+            os.environ["LOCAL_RANK"] = "0"
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     from gans.trainer import Trainer
     from gans.utils import init_random_seed
 
