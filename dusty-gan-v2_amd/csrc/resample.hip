@@ -243,7 +243,9 @@ __global__ __launch_bounds__(256) void resample_tab_kernel(
 // up / down / blur FIR of this model and their adjoints) never re-filter a row.
 constexpr int RS_RB = 4;
 
-template <typename T>
+// EW = taps per output column the table can hold (1..4): the horizontal pass is unrolled to exactly that many
+// loads / FMA groups (an up-2 FIR has 2, a blur 4)
+template <typename T, int EW>
 __global__ __launch_bounds__(256) void resample_stream_kernel(
     T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
     const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
@@ -268,10 +270,10 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
   const int cv = live ? col - wo * cvecs : 0;
 
   const int nw = live ? cnt_w[wo] : 0;
-  int xo[4];
-  float cw[4];
+  int xo[EW];
+  float cw[EW];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < EW; ++c) {
     xo[c] = -1;
     cw[c] = 0.f;
     if (c < nw) {
@@ -300,11 +302,11 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
   // input rows are consumed in (mostly) increasing order: after filtering row r the loads of row r + 1 are
   // issued at once and stay in flight behind this row's FMAs / LDS traffic / output store
   int pr = -1;
-  vec16<T> pv[4];
+  vec16<T> pv[EW];
   auto issue = [&](int r) {
     const T* xr = xb + (int64_t)r * in_w * ldx;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < EW; ++c) {
       pv[c].raw = make_uint4(0, 0, 0, 0);
       if (xo[c] >= 0) pv[c].load(xr + xo[c]);
     }
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
 #pragma unroll
         for (int j = 0; j < VN; ++j) h[j] = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < EW; ++c)
 #pragma unroll
           for (int j = 0; j < VN; ++j) h[j] += cw[c] * pv[c].get(j);
         if (r + 1 <= rlast && !(ablate & 2)) issue(r + 1); else pr = -1;
@@ -347,6 +349,18 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
       for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
       o.store(yp + (int64_t)ho * out_w * ldy);
     }
+  }
+}
+
+template <typename T>
+void rs_launch(int Ew, int blocks, hipStream_t st, T* y, const T* x, const int* idx_h, const float* coef_h,
+               const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int B, int C, int ldx,
+               int ldy, int in_h, int in_w, int out_h, int out_w, int sha) {
+  switch (Ew) {
+    case 1: resample_stream_kernel<T, 1><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha); break;
+    case 2: resample_stream_kernel<T, 2><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha); break;
+    case 3: resample_stream_kernel<T, 3><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha); break;
+    default: resample_stream_kernel<T, 4><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha); break;
   }
 }
 
@@ -372,9 +386,8 @@ extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const
       while (SH > 1 && SH * Eh > 64) SH >>= 1;   // the strip's H-table slice must fit one lane-indexed register
       const int64_t blocks = (int64_t)B * ((out_h + SH - 1) / SH) * (((int64_t)out_w * (C / VN) + 255) / 256);
       if (blocks >= (1LL << 31)) return DGV2_EINVAL;
-      resample_stream_kernel<T><<<(int)blocks, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
-                                                             cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w,
-                                                             SH | (rs_ablate << 16));
+rs_launch<T>(Ew, (int)blocks, st, (T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, B, C, ldx, ldy, in_h,
+                   in_w, out_h, out_w, SH | (rs_ablate << 16));
     } else if (vec)
       resample_tab_kernel<T, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
                                                         cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w);
