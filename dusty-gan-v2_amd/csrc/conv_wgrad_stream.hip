@@ -384,6 +384,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ g
   __shared__ float4 red[16][16];
   const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t i = ((int64_t)blockIdx.x * 16 + col) * 4;
+  part += (int64_t)blockIdx.y * nsplit * n;   // per-image mode: image blockIdx.y owns its own nsplit partials
+  gw += (int64_t)blockIdx.y * n;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n) {
 #pragma unroll 4
@@ -409,7 +411,8 @@ struct WSPlan {
   int nsplit, otiles, mfn, nfn;
 };
 
-bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, int pad, int ring, int dtype) {
+bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, int pad, int ring, int dtype,
+             bool per_image = false) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0) return false;
   if ((k != 1 && k != 3) || pad != (k - 1) / 2 || (stride != 1 && stride != 2)) return false;
   const int ce = dtype == DGV2_BF16 ? 8 : 4;
@@ -436,6 +439,16 @@ bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, in
   nsplit = nsplit < 1 ? 1 : (nsplit > g.ntiles ? g.ntiles : nsplit);
   g.tiles_per_split = (g.ntiles + nsplit - 1) / nsplit;
   p.nsplit = (g.ntiles + g.tiles_per_split - 1) / g.tiles_per_split;
+  if (per_image) {
+    // every split must lie inside one image: splits per image = the largest divisor of the image's tile count
+    // that keeps the launch near its block target
+    const int tpi = g.tiles_h * g.tiles_w;
+    int spi = nsplit / B;
+    spi = spi < 1 ? 1 : (spi > tpi ? tpi : spi);
+    while (tpi % spi) --spi;
+    g.tiles_per_split = tpi / spi;
+    p.nsplit = B * spi;
+  }
   return true;
 }
 
@@ -491,6 +504,36 @@ extern "C" int dgv2_conv_wgrad_stream_scratch(int64_t* elems, int B, int H, int 
   if (!ws_plan(p, B, H, W, C, O, k, stride, pad, 1, dtype)) return DGV2_EINVAL;
   *elems = (int64_t)p.nsplit * O * k * k * C;
   return 0;
+}
+
+// Per-sample 1x1 weight gradient (the modulated conv of the generator, ModConv2d autograd, style.py:105-118):
+//   gw[b, o, c] = sum_p gy[b, p, o] * x[b, p, c],  p over the H x W pixels of sample b.
+// Same streaming kernel; every split stays inside one image and the reduce runs per image.
+extern "C" int dgv2_bmm_tn_stream_scratch(int64_t* elems, int B, int H, int W, int C, int O, int dtype) {
+  if (!elems) return DGV2_EINVAL;
+  *elems = 0;
+  WSPlan p;
+  if (!ws_plan(p, B, H, W, C, O, 1, 1, 0, 0, dtype, true)) return DGV2_EINVAL;
+  *elems = (int64_t)p.nsplit * O * C;
+  return 0;
+}
+
+extern "C" int dgv2_bmm_tn_stream(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
+                                  int B, int H, int W, int C, int O, int dtype, void* stream) {
+  if (!gw || !scratch || !gy || !x || !aligned16(gy) || !aligned16(x) || !aligned16(scratch) || !aligned16(gw))
+    return DGV2_EINVAL;
+  if (dtype != DGV2_BF16 && dtype != DGV2_F32) return DGV2_EINVAL;
+  WSPlan p;
+  if (!ws_plan(p, B, H, W, C, O, 1, 1, 0, 0, dtype, true)) return DGV2_EINVAL;
+  const int64_t n = (int64_t)O * C;
+  if (scratch_elems < (int64_t)p.nsplit * n || (n & 3)) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = dtype == DGV2_BF16 ? ws_dispatch_geom<bf16_t>(scratch, gy, x, p, st)
+                                    : ws_dispatch_geom<float>(scratch, gy, x, p, st);
+  if (rc) return rc;
+  dim3 grid((unsigned)((n / 4 + 15) / 16), B);
+  wgrad_reduce_kernel<<<grid, 256, 0, st>>>(gw, scratch, n, p.nsplit / B);
+  DGV2_RETURN_LAST();
 }
 
 // gw fp32 [O, k*k, C] (overwritten).  k in {1,3}, pad = (k-1)/2, stride in {1,2}, C and O multiples of the

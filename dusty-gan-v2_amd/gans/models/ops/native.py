@@ -660,6 +660,8 @@ _WGRAD_DIRECT_MAXC = int(os.environ.get("DGV2_WGRAD_DIRECT_MAXC", "64"))
 _WGRAD_STREAM = os.environ.get("DGV2_NO_WGRAD_STREAM") is None   # A/B switch for benchmarking
 _WGRAD_SCRATCH = {}
 _PE_FWD = os.environ.get("DGV2_NO_PE_FWD") is None               # A/B switch for benchmarking
+_TN_STREAM = os.environ.get("DGV2_NO_TN_STREAM") is None           # A/B switch for benchmarking
+_TN_SCRATCH = {}
 _LIB_WGRAD = os.environ.get("DGV2_NO_LIB_WGRAD") is None         # A/B switch for benchmarking
 
 
@@ -1146,6 +1148,17 @@ class _ModLayer(Function):
             gwb = torch.empty((B, Otot, I), device=gy.device, dtype=torch.float32)
             N.call("dgv2_bmm_tn_cat", N.ptr(gwb), N.ptr(g3), N.ptr(xa), N.ptr(xs), B, P, Ka, xs.shape[3], Otot,
                    _dt(xs), N.stream())
+        elif _TN_STREAM and dt == torch.bfloat16 and P >= 2048 and I % 8 == 0 and Otot % 8 == 0:
+            # dense layers of the top levels: the streaming split-K engine of the conv weight gradient, per sample
+            key = (B, H, W_, I, Otot)
+            if key not in _TN_SCRATCH:
+                n = _ct.c_int64(0)
+                N.call("dgv2_bmm_tn_stream_scratch", _ct.addressof(n), B, H, W_, I, Otot, _dt(xa))
+                _TN_SCRATCH[key] = n.value
+            gwb = torch.empty((B, Otot, I), device=gy.device, dtype=torch.float32)
+            scratch = torch.empty(_TN_SCRATCH[key], device=gy.device, dtype=torch.float32)
+            N.call("dgv2_bmm_tn_stream", N.ptr(gwb), N.ptr(scratch), scratch.numel(), N.ptr(g3), N.ptr(xa), B, H, W_, I,
+                   Otot, _dt(xa), N.stream())
         else:
             gwb = torch.empty((B, Otot, I), device=gy.device, dtype=torch.float32)
             N.call("dgv2_bmm_tn", N.ptr(gwb), N.ptr(g3), N.ptr(xa.reshape(B, P, I)), B, P, I, Otot, Otot, I, _dt(xa),

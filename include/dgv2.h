@@ -225,6 +225,13 @@ int dgv2_conv_wgrad(float* gw, const void* gy, const void* x, int B, int H, int 
 int dgv2_conv_wgrad_direct(float* gw, const void* gy, const void* x, int B, int H, int W, int C, int O,
                            int k, int stride, int pad, int ring, int dtype, void* stream);
 
+/* Per-sample 1x1 weight gradient of the modulated conv (ModConv2d autograd, style.py:105-118) on the streaming
+ * engine above: gw fp32 [B,O,C] = sum over the H*W pixels of sample b of gy [B,H,W,O] x [B,H,W,C]; splits stay
+ * inside an image.  C, O multiples of the 16-byte vector and O*C a multiple of 4. */
+int dgv2_bmm_tn_stream_scratch(int64_t* elems, int B, int H, int W, int C, int O, int dtype);
+int dgv2_bmm_tn_stream(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
+                       int B, int H, int W, int C, int O, int dtype, void* stream);
+
 /* Compute-dtype copies of all conv weights of the discriminator in ONE launch (L <= 32): from each fp32
  * master [O,C,kh,kw] (EqualLR runtime scale folded in: common.py:158-184) the forward layout
  * wf [O, kh*kw, Cpad] and the data-gradient layout wt [Cpad, kh*kw, O].  HOST arrays of device pointers. */

@@ -299,6 +299,28 @@ def test_style_affines_match_per_layer_linear(nat):
         assert_rel(a.cpu(), b, 5e-6)
 
 
+@pytest.mark.parametrize("B,H,W,I,O", [(3, 32, 64, 64, 32), (2, 20, 96, 128, 64), (2, 8, 40, 32, 32)])
+def test_bmm_tn_stream_per_sample_weight_gradient(nat, B, H, W, I, O):
+    """dgv2_bmm_tn_stream (streaming split-K engine, every split inside one image) = the per-sample weight
+    gradient of the modulated 1x1 conv, gw[b,o,c] = sum_p gy[b,p,o] x[b,p,c] (ModConv2d autograd, style.py:105-118):
+    exact on integer-valued bf16 operands, ragged tiles included."""
+    import ctypes
+
+    import dgv2_native as N
+    g = torch.Generator().manual_seed(17)
+    x = torch.randint(-3, 4, (B, H, W, I), generator=g).float()
+    gy = torch.randint(-2, 3, (B, H, W, O), generator=g).float()
+    xd, gd = x.to(DEV).bfloat16(), gy.to(DEV).bfloat16()
+    n = ctypes.c_int64(0)
+    N.call("dgv2_bmm_tn_stream_scratch", ctypes.addressof(n), B, H, W, I, O, N.BF16)
+    scratch = torch.empty(n.value, device=DEV)
+    gw = torch.full((B, O, I), float("nan"), device=DEV)
+    N.call("dgv2_bmm_tn_stream", N.ptr(gw), N.ptr(scratch), scratch.numel(), N.ptr(gd), N.ptr(xd), B, H, W, I, O, N.BF16,
+           N.stream())
+    want = torch.einsum("bhwo,bhwc->boc", gy, x)
+    assert torch.equal(gw.cpu(), want)
+
+
 # ---------------------------------------------------------------------------------------
 CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     (2, 8, 16, 8, 16, 3, 1, 1, True),
