@@ -1046,6 +1046,20 @@ def coords_convert(x, mode, min_depth, max_depth, angle=None, mask=None, raydrop
 # act-grad, data gradient, weight gradient, preparation backward (dgv2_mod_prep_bwd).
 # reference: ModConv2d.forward + FusedLeakyReLU, gans/models/ops/style.py:68-126, dusty_v2.py:161-170
 # ---------------------------------------------------------------------------------------
+def _bmm_tn_stream(g3, xa, B, H, W_, I, O):
+    """gw fp32 [B,O,I] = per-sample sum over pixels of gy [B,H*W,O] x xa [B,H,W,I] (dgv2_bmm_tn_stream)."""
+    key = (B, H, W_, I, O)
+    if key not in _TN_SCRATCH:
+        n = _ct.c_int64(0)
+        N.call("dgv2_bmm_tn_stream_scratch", _ct.addressof(n), B, H, W_, I, O, _dt(xa))
+        _TN_SCRATCH[key] = n.value
+    gw = torch.empty((B, O, I), device=xa.device, dtype=torch.float32)
+    scratch = torch.empty(_TN_SCRATCH[key], device=xa.device, dtype=torch.float32)
+    N.call("dgv2_bmm_tn_stream", N.ptr(gw), N.ptr(scratch), scratch.numel(), N.ptr(g3), N.ptr(xa), B, H, W_, I, O,
+           _dt(xa), N.stream())
+    return gw
+
+
 class _ModLayer(Function):
     @staticmethod
     def forward(ctx, cfg, xa, xs, bias, shift, fw, *mods):
@@ -1138,7 +1152,9 @@ class _ModLayer(Function):
             # generic dgv2 TN kernel on these long-K / short-M shapes; the batch-shared PE is a stride-0 operand
             gT = g3.transpose(1, 2)
             parts = []
-            if xa is not None:
+            if xa is not None and _TN_STREAM and Ka % 8 == 0 and Otot % 8 == 0:
+                parts.append(_bmm_tn_stream(g3, xa, B, H, W_, Ka, Otot))   # own streaming engine, per sample
+            elif xa is not None:
                 parts.append(torch.bmm(gT, xa.reshape(B, P, Ka), out_dtype=torch.float32))
             parts.append(torch.bmm(gT, xs.reshape(1, P, -1).expand(B, P, xs.shape[3]), out_dtype=torch.float32))
             gwb = torch.cat(parts, dim=2) if len(parts) > 1 else parts[0]
@@ -1150,15 +1166,7 @@ class _ModLayer(Function):
                    _dt(xs), N.stream())
         elif _TN_STREAM and dt == torch.bfloat16 and P >= 2048 and I % 8 == 0 and Otot % 8 == 0:
             # dense layers of the top levels: the streaming split-K engine of the conv weight gradient, per sample
-            key = (B, H, W_, I, Otot)
-            if key not in _TN_SCRATCH:
-                n = _ct.c_int64(0)
-                N.call("dgv2_bmm_tn_stream_scratch", _ct.addressof(n), B, H, W_, I, Otot, _dt(xa))
-                _TN_SCRATCH[key] = n.value
-            gwb = torch.empty((B, Otot, I), device=gy.device, dtype=torch.float32)
-            scratch = torch.empty(_TN_SCRATCH[key], device=gy.device, dtype=torch.float32)
-            N.call("dgv2_bmm_tn_stream", N.ptr(gwb), N.ptr(scratch), scratch.numel(), N.ptr(g3), N.ptr(xa), B, H, W_, I,
-                   Otot, _dt(xa), N.stream())
+            gwb = _bmm_tn_stream(g3, xa, B, H, W_, I, Otot)
         else:
             gwb = torch.empty((B, Otot, I), device=gy.device, dtype=torch.float32)
             N.call("dgv2_bmm_tn", N.ptr(gwb), N.ptr(g3), N.ptr(xa.reshape(B, P, I)), B, P, I, Otot, Otot, I, _dt(xa),
