@@ -253,8 +253,10 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
     int SHA) {
   const int SH = SHA & 0xffff, ablate = SHA >> 16;   // ablate: benchmarking only (DGV2_RS_ABLATE)
   constexpr int VN = vec16<T>::N;
-  constexpr int Q = VN / 4;
-  __shared__ float4 ring[RS_RB][Q][256];
+  // the ring holds the W-filtered rows in the tensor's own dtype: for bf16 that halves its LDS footprint
+  // (16 KB per block -> 8 resident blocks per CU instead of 5; this kernel lives on occupancy) at the price of one
+  // extra bf16 rounding of the intermediate, far below the bf16 output rounding; fp32 tensors keep fp32
+  __shared__ uint4 ring[RS_RB][256];
   const int tid = threadIdx.x;
   const int cvecs = C / VN;
   const int rowvecs = out_w * cvecs;
@@ -333,14 +335,19 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
 #pragma unroll
           for (int j = 0; j < VN; ++j) h[j] += cw[c] * pv[c].get(j);
         if (r + 1 <= rlast && !(ablate & 2)) issue(r + 1); else pr = -1;
+        {
+          vec16<T> hv;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) ring[s][q][tid] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+          for (int j = 0; j < VN; ++j) hv.set(j, h[j]);
+          ring[s][tid] = hv.raw;
+        }
         t0 = s == 0 ? r : t0; t1 = s == 1 ? r : t1; t2 = s == 2 ? r : t2; t3 = s == 3 ? r : t3;
       }
+      {
+        vec16<T> hv;
+        hv.raw = ring[s][tid];
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const float4 h4 = ring[s][q][tid];
-        acc[4 * q] += fa * h4.x; acc[4 * q + 1] += fa * h4.y; acc[4 * q + 2] += fa * h4.z; acc[4 * q + 3] += fa * h4.w;
+        for (int j = 0; j < VN; ++j) acc[j] += fa * hv.get(j);
       }
     }
     if (live && !((ablate & 1) && acc[0] != 12345.678f)) {
