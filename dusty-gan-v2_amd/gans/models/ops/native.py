@@ -313,6 +313,45 @@ def style_affines(ws, weights, biases, kidx, scale):
     return list(_Unpack2d.apply(Sout, tuple([B] * L), tuple(Is)))
 
 
+def fused_adam_step(opt):
+    """One step of a torch.optim.Adam instance (single param group, no weight decay / amsgrad / maximize) on the
+    dgv2 kernels: the optimizer object, its hyper-parameters and its state_dict stay torch's, only the arithmetic
+    moves (1 + ceil(L/72) launches at HBM speed instead of torch's multi-tensor kernels).  The per-parameter
+    `step` entries alias ONE device counter."""
+    (group,) = opt.param_groups
+    if group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
+        raise RuntimeError("dgv2 fused Adam: unsupported optimizer options")
+    params = [p for p in group["params"] if p.grad is not None]
+    if not params:
+        return
+    dev = params[0].device
+    shared = getattr(opt, "_dgv2_step", None)
+    if shared is None:
+        shared = torch.zeros(1, device=dev, dtype=torch.float32)
+        opt._dgv2_step = shared
+        opt._dgv2_sc = torch.zeros(4, device=dev, dtype=torch.float32)
+    for p in params:
+        st = opt.state[p]
+        if len(st) == 0:
+            st["step"] = shared.view(())
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        elif st["step"].data_ptr() != shared.data_ptr():      # state came from load_state_dict: adopt its counter
+            shared.copy_(st["step"].reshape(1).to(dev, torch.float32))
+            st["step"] = shared.view(())
+    b1, b2 = group["betas"]
+    N.call("dgv2_adam_prep", N.ptr(opt._dgv2_sc), N.ptr(shared), float(b1), float(b2), N.stream())
+    for i in range(0, len(params), 72):
+        ch = params[i:i + 72]
+        ms = [opt.state[p]["exp_avg"] for p in ch]
+        vs = [opt.state[p]["exp_avg_sq"] for p in ch]
+        gs = [p.grad for p in ch]
+        N.check(*ch, *gs, *ms, *vs)
+        N.call("dgv2_adam_step", _ptr_array(ch), _ptr_array(gs), _ptr_array(ms), _ptr_array(vs),
+               _int_array([p.numel() for p in ch]), len(ch), N.ptr(opt._dgv2_sc), float(group["lr"]), float(b1),
+               float(b2), float(group["eps"]), N.stream())
+
+
 def ema_update(ema, sumsq, add, count, weight, update=True):
     """ModConv2d's input-magnitude EMA (style.py:98-103) in one scalar launch: updates the 0-dim buffer `ema`
     in place with lerp(ema, (sumsq + add) / count, weight) and returns a fresh [1] snapshot of its value."""

@@ -259,6 +259,13 @@ class Trainer:
             torch.cuda.synchronize()
         return scalars
 
+    def _opt_step(self, opt):
+        if self.device.type == "cuda" and os.environ.get("DGV2_TORCH_ADAM") is None:
+            from gans.models.ops import native
+            native.fused_adam_step(opt)
+        else:
+            opt.step()
+
     # ------------------------------------------------------------------ one iteration
     def step(self, iteration):
         self.G.train()
@@ -269,17 +276,17 @@ class Trainer:
         parallel.sync_buffers(self.G)
         scalars.update(self._run("g_fb", self.g_fb))
         self.g_sync.all_reduce()
-        self._run("g_opt", lambda sc: self.optim_G.step())
+        self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
 
         parallel.sync_buffers(self.G)
         scalars.update(self._run("d_fb", self.d_fb, self.x_real))
         self.d_sync.all_reduce()
-        self._run("d_opt", lambda sc: self.optim_D.step())
+        self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
 
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
             scalars.update(self._run("r1_fb", self.r1_fb, self.x_real))
             self.d_sync.all_reduce()
-            self._run("d_opt", lambda sc: self.optim_D.step())
+            self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
         set_requires_grad(self.D, False)
 
         decay = self.ema_decay(iteration)

@@ -172,6 +172,14 @@ int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, 
  * rows at [row_off, row_off+O)), dtype wb_dtype; stats fp32 [2+2B] and dsave fp32 [B,O] are produced
  * by fwd and consumed by bwd; shift fp32 [B] / fw fp32 [F] or NULL (F must be 256, PE columns
  * [cin, cin+2F)); I <= 1024.  bwd: G fp32 [B,Otot,I] -> gW fp32 [O,I], gs fp32 [B,I]; corr fp32 [1]. */
+/* Adam (torch.optim.Adam semantics, no weight decay / amsgrad; the optimizers of gans/trainer.py:142-171) over a
+ * list of L <= 72 fp32 parameter tensors in one launch -- the tensors of torch's own optimizer state, addresses
+ * by value (HOST arrays of device pointers).  dgv2_adam_prep advances the device step counter and leaves the
+ * bias corrections of that step in sc (fp32 [4]) for dgv2_adam_step. */
+int dgv2_adam_prep(float* sc, float* step, float b1, float b2, void* stream);
+int dgv2_adam_step(float* const* p, const float* const* g, float* const* m, float* const* v, const int* n,
+                   int L, const float* sc, float lr, float b1, float b2, float eps, void* stream);
+
 /* Pack / unpack a list of L <= 48 small fp32 matrices (HOST array of device pointers, by value in the launch)
  * into / out of one zero-padded [L, Rmax, Cmax] tensor: the 19 style affines of the generator (EqualLR Linear
  * of every ModConv2d, style.py:30,75) then run as one batched library GEMM forward and two backward. */

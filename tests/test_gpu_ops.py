@@ -321,6 +321,30 @@ def test_bmm_tn_stream_per_sample_weight_gradient(nat, B, H, W, I, O):
     assert torch.equal(gw.cpu(), want)
 
 
+def test_fused_adam_matches_torch_adam(nat):
+    """native.fused_adam_step (dgv2_adam_prep / dgv2_adam_step on the optimizer's own state tensors) against
+    torch.optim.Adam on the CPU (the optimizers of gans/trainer.py:142-171, beta1 = 0 included): three steps,
+    vectorised and ragged tensor sizes, state_dict layout unchanged."""
+    g = torch.Generator().manual_seed(2)
+    shapes = [(7, 5), (64, 33), (4096,), (3,)]
+    for b1 in (0.0, 0.9):
+        ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+        dev = [t.detach().clone().to(DEV).requires_grad_(True) for t in ref]
+        o_ref = torch.optim.Adam(ref, lr=2e-3, betas=(b1, 0.99))
+        o_dev = torch.optim.Adam(dev, lr=2e-3, betas=(b1, 0.99), capturable=True)
+        for _ in range(3):
+            grads = [torch.randn(s, generator=g) for s in shapes]
+            for t, d, gr in zip(ref, dev, grads):
+                t.grad, d.grad = gr.clone(), gr.to(DEV)
+            o_ref.step()
+            nat.fused_adam_step(o_dev)
+        for t, d in zip(ref, dev):
+            assert_rel(d.detach().cpu(), t.detach(), 1e-5)
+        sd = o_dev.state_dict()["state"]
+        assert float(sd[0]["step"]) == 3.0 and sd[1]["exp_avg"].shape == shapes[1]
+        assert_rel(sd[2]["exp_avg_sq"].cpu(), o_ref.state_dict()["state"][2]["exp_avg_sq"], 1e-5)
+
+
 # ---------------------------------------------------------------------------------------
 CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     (2, 8, 16, 8, 16, 3, 1, 1, True),
