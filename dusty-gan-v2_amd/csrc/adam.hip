@@ -59,7 +59,37 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, const float*
   }
 }
 
+struct LerpArgs {
+  float* dst[AD_MAX];
+  const float* src[AD_MAX];
+  int n[AD_MAX];
+};
+
+__global__ __launch_bounds__(256) void lerp_list_kernel(LerpArgs a, float w) {
+  const int l = blockIdx.y;
+  float* __restrict__ d = a.dst[l];
+  const float* __restrict__ s = a.src[l];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n[l]; i += gridDim.x * 256) d[i] += w * (s[i] - d[i]);
+}
+
 }  // namespace
+
+// dst[l] <- lerp(dst[l], src[l], weight) for L <= 72 fp32 tensors in one launch: the G_ema update
+// (ema_inplace, gans/trainer.py:30-41).  HOST arrays of device pointers.
+extern "C" int dgv2_lerp_list(float* const* dst, const float* const* src, const int* n, int L, float weight,
+                              void* stream) {
+  if (!dst || !src || !n || L < 1 || L > AD_MAX) return DGV2_EINVAL;
+  LerpArgs a;
+  int nmax = 0;
+  for (int l = 0; l < L; ++l) {
+    if (!dst[l] || !src[l] || n[l] < 0) return DGV2_EINVAL;
+    a.dst[l] = dst[l]; a.src[l] = src[l]; a.n[l] = n[l];
+    nmax = n[l] > nmax ? n[l] : nmax;
+  }
+  dim3 grid(grid_for(nmax, 256, 256), L);
+  lerp_list_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, weight);
+  DGV2_RETURN_LAST();
+}
 
 // step: fp32 [1] device counter (advanced by one); sc: fp32 [4] scratch receiving (step, 1 - b1^step, sqrt(1 - b2^step)).
 extern "C" int dgv2_adam_prep(float* sc, float* step, float b1, float b2, void* stream) {

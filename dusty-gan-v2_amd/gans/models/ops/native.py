@@ -313,6 +313,15 @@ def style_affines(ws, weights, biases, kidx, scale):
     return list(_Unpack2d.apply(Sout, tuple([B] * L), tuple(Is)))
 
 
+def lerp_list(dst, src, weight):
+    """dst[i] <- lerp(dst[i], src[i], weight) for lists of fp32 tensors, 72 per launch (the G_ema update)."""
+    for i in range(0, len(dst), 72):
+        d, s_ = dst[i:i + 72], src[i:i + 72]
+        N.check(*d, *s_)
+        N.call("dgv2_lerp_list", _ptr_array(d), _ptr_array(s_), _int_array([t.numel() for t in d]), len(d),
+               float(weight), N.stream())
+
+
 def fused_adam_step(opt):
     """One step of a torch.optim.Adam instance (single param group, no weight decay / amsgrad / maximize) on the
     dgv2 kernels: the optimizer object, its hyper-parameters and its state_dict stay torch's, only the arithmetic

@@ -35,8 +35,12 @@ def ema_inplace(ema_model, new_model, decay):
     """reference: trainer.py:30-41 -- parameters lerp, buffers copied; foreach-batched."""
     ep = [p for _, p in ema_model.named_parameters()]
     np_ = [p for _, p in new_model.named_parameters()]
-    torch._foreach_mul_(ep, decay)
-    torch._foreach_add_(ep, np_, alpha=1 - decay)
+    if ep and ep[0].is_cuda and all(p.dtype == torch.float32 and p.is_contiguous() for p in ep + np_):
+        from gans.models.ops import native
+        native.lerp_list(ep, np_, 1 - decay)   # p_ema <- decay * p_ema + (1 - decay) * p, 72 tensors per launch
+    else:
+        torch._foreach_mul_(ep, decay)
+        torch._foreach_add_(ep, np_, alpha=1 - decay)
     eb = [b for _, b in ema_model.named_buffers()]
     nb = [b for _, b in new_model.named_buffers()]
     torch._foreach_copy_(eb, nb)

@@ -176,6 +176,8 @@ int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, 
  * list of L <= 72 fp32 parameter tensors in one launch -- the tensors of torch's own optimizer state, addresses
  * by value (HOST arrays of device pointers).  dgv2_adam_prep advances the device step counter and leaves the
  * bias corrections of that step in sc (fp32 [4]) for dgv2_adam_step. */
+/* dst[l] <- lerp(dst[l], src[l], weight), L <= 72 fp32 tensors, one launch: ema_inplace (trainer.py:30-41). */
+int dgv2_lerp_list(float* const* dst, const float* const* src, const int* n, int L, float weight, void* stream);
 int dgv2_adam_prep(float* sc, float* step, float b1, float b2, void* stream);
 int dgv2_adam_step(float* const* p, const float* const* g, float* const* m, float* const* v, const int* n,
                    int L, const float* sc, float lr, float b1, float b2, float eps, void* stream);
