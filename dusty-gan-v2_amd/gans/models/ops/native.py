@@ -845,7 +845,11 @@ class _ScaledHandle(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g.permute(0, 3, 1, 2) * ctx.scale, None
+        # contiguous result in the parameter's layout (one strided-read launch): AccumulateGrad can then adopt the
+        # tensor instead of cloning a permuted one
+        gp = g.permute(0, 3, 1, 2)
+        out = torch.empty(gp.shape, device=g.device, dtype=g.dtype)
+        return torch.mul(gp, ctx.scale, out=out), None
 
 
 def scaled_handle(param, scale):

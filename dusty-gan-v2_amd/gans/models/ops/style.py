@@ -37,7 +37,7 @@ class ModConv2d(nn.Module):
         """Per-sample weights [B,O,I] (fp32).  `sumsq`/`count`: sum of squares and element count of
         the conv input, used for the input-magnitude EMA in training mode (style.py:98-103)."""
         style = self.mod(w_latent.float())
-        weight = self.weight[0, :, :, 0, 0] * float(self.scale)
+        weight = self.weight.reshape(self.weight.shape[1], self.weight.shape[2]) * float(self.scale)
         if self.demod:
             weight = weight / weight.abs().max()
             style = style / style.abs().amax(dim=1, keepdim=True)
@@ -64,7 +64,9 @@ class ModConv2d(nn.Module):
         elif self.ema and self.training and sumsq is not None:
             with torch.no_grad():
                 self.ema_var.lerp_((sumsq.sum() + sumsq_add) / count, 1 - self.ema_decay)
-        return (self.weight[0, :, :, 0, 0], style, ev, self.demod)
+        # reshape, not [0, :, :, 0, 0]: the backward of integer indexing allocates and zero-fills a full-size tensor
+        # per select (three fills + three copies per layer and pass); a view's backward is free
+        return (self.weight.reshape(self.weight.shape[1], self.weight.shape[2]), style, ev, self.demod)
 
     def forward_cl(self, x, w_latent, out_dtype=None, act=None):
         """act: a FusedLeakyReLU module whose bias + leaky-ReLU is fused into the GEMM epilogue."""
