@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
       const int w0 = (tw0 + tile) * DTW;
       // fast path (block-uniform): full channel tile, plain overwrite -- straight-line bias / lrelu / convert and,
       // for bf16, fragment pairs leaving as 16-byte stores; everything else takes the general store_frag
-      const bool fast = !p.accumulate && !p.resid && o0 + TO <= p.O && (p.O & 7) == 0;
+      const bool fast = !p.accumulate && o0 + TO <= p.O && (p.O & 7) == 0;
+      const T* rbase = reinterpret_cast<const T*>(p.resid);   // optional residual, same layout as y
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -326,13 +327,28 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
               for (int mf = 0; mf < MF; mf += 2) {
                 uint4 pk;
                 const int co = pack_pair_bf16(f[mf], f[mf + 1], lc, pk);   // every lane takes part in the exchange
-                if (live) *reinterpret_cast<uint4*>(row + o0 + mf * 16 + co) = pk;
+                if (live) {
+                  T* q = row + o0 + mf * 16 + co;
+                  if (rbase) {   // residual added on the packed 8-channel run (one 16-byte read)
+                    vec16<T> a, r;
+                    a.raw = pk;
+                    r.load(rbase + (q - y));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a.set(j, a.get(j) + r.get(j));
+                    pk = a.raw;
+                  }
+                  *reinterpret_cast<uint4*>(q) = pk;
+                }
               }
             } else {
 #pragma unroll
               for (int mf = 0; mf < MF; ++mf) {
                 if (!live) continue;
                 T* q = row + o0 + mf * 16 + lc * 4;
+                if (rbase) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) f[mf][r] += to_f32(rbase[(q - y) + r]);
+                }
                 if constexpr (sizeof(T) == 4) {
                   *reinterpret_cast<float4*>(q) = make_float4(f[mf][0], f[mf][1], f[mf][2], f[mf][3]);
                 } else {

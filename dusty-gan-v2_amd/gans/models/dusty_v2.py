@@ -370,7 +370,11 @@ class ResidualBlock(nn.Module):
                 (self.skip, self.skip.bank_entry(wscale=c if fused else None))]
 
     def forward_cl(self, x, bank=None):
-        h = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank)
+        if bank is not None and x.requires_grad:
+            # conv1 also hands x on to the skip branch: the two gradients of x then meet inside conv1's dgrad kernel
+            h, x = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank, fork=True)
+        else:
+            h = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank)
         c = 1.0 / math.sqrt(2)
         xs = native.resample(x, self.blur_down)
         if native.conv_resid_ok(xs, self.skip_geom) and self.skip._params()[1] is None:

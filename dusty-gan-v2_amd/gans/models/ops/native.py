@@ -596,7 +596,7 @@ def _conv_taps(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, ooff, taps, hzero,
 _FUSED_DGRAD = os.environ.get("DGV2_NO_FUSED_DGRAD") is None   # A/B switch for benchmarking
 
 
-def _conv_taps_ex(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, classes, taps4, extras, hzero):
+def _conv_taps_ex(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, classes, taps4, extras, hzero, resid=None):
     """dgv2_conv_taps_ex: output classes [(ooff_h, ooff_w)], taps [(dy, dx, widx, cls)] sorted by class, border
     extras [(dy, dx, widx, cls, row)].  Returns False when the engine asks for the per-class fallback."""
     B, Hin, Win, Cin = x.shape
@@ -607,7 +607,7 @@ def _conv_taps_ex(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, classes, taps4,
     earr = (_ct.c_int * max(5 * len(extras), 1))(*[v for e in extras for v in e])
     return N.try_call("dgv2_conv_taps_ex", N.ptr(y), N.ptr(x), N.ptr(w3), B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy,
                       in_stride, ioff[0], ioff[1], out_stride, len(classes), carr, len(taps4), wtaps, tarr,
-                      len(extras), earr, int(hzero), 1, 0, None, None, 0, 0.2, 1.0, _dt(x), N.stream())
+                      len(extras), earr, int(hzero), 1, 0, None, N.ptr(resid), 0, 0.2, 1.0, _dt(x), N.stream())
 
 
 def _direct_ok(g, cin):
@@ -640,10 +640,13 @@ def _axis_taps_s2(parity):
     return [(0, 1)] if parity == 0 else [(1, 0), (0, 2)]
 
 
-def _conv_dgrad_direct(gy, wt3, g, xshape):
-    """Data gradient on the direct engine: gy [B,Ho,Wo,O], wt3 [C,kh*kw,O] -> gx [B,H,W,C].
+def _conv_dgrad_direct(gy, wt3, g, xshape, resid=None):
+    """Data gradient on the direct engine: gy [B,Ho,Wo,O], wt3 [C,kh*kw,O] -> gx [B,H,W,C] (+ resid, the gradient
+    of a sibling branch of the same input, added in the epilogue of the one-launch stride-1 path).
     Circular W padding transposes to a wrap of the gy coordinate; the replicate rows of the H padding
     add one-row border terms (accumulate launches)."""
+    if resid is not None and not (_FUSED_DGRAD and g.kh == 3 and g.stride == 1):
+        return _conv_dgrad_direct(gy, wt3, g, xshape) + resid
     B, H, W, C = xshape
     gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
     k = g.kh
@@ -655,8 +658,10 @@ def _conv_dgrad_direct(gy, wt3, g, xshape):
         # one launch: the replicate rows ride along as border extras of output rows 0 and H-1
         extras = [(0, 1 - kx, kx, 0, 0) for kx in range(3)] + [(0, 1 - kx, 6 + kx, 0, H - 1) for kx in range(3)]
         if _FUSED_DGRAD and _conv_taps_ex(gx, gy, wt3, H, W, 1, (0, 0), 1, [(0, 0)], [t + (0,) for t in taps], extras,
-                                          True):
+                                          True, resid=resid):
             return gx
+        if resid is not None:
+            return _conv_dgrad_direct(gy, wt3, g, xshape) + resid
         _conv_taps(gx, gy, wt3, H, W, 1, (0, 0), 1, (0, 0), taps, True)
         # replicate-padding rows: padded row -1 (-> h = 0) is read by ky = 0 of output row 0,
         # padded row H (-> h = H-1) by ky = 2 of output row H-1
@@ -685,16 +690,18 @@ def _conv_dgrad_direct(gy, wt3, g, xshape):
     return gx
 
 
-def _conv_dgrad_raw(gy, w, g, xshape, wt=None):
+def _conv_dgrad_raw(gy, w, g, xshape, wt=None, resid=None):
     """w [O,kh,kw,C] in gy's dtype, or wt = the prepared transposed weights [C, kh*kw, O] (weight bank)."""
     B, H, W, C = xshape
     O = gy.shape[3]
     if wt is None:
         wt = w.permute(3, 1, 2, 0).contiguous()
-    N.check(gy, wt)
+    N.check(gy, wt, resid)
     even = g.stride == 1 or (H % 2 == 0 and W % 2 == 0)
     if _direct_ok(g, O % _kstep(gy) == 0) and even and not (g.kh == 1 and g.stride == 2):
-        return _conv_dgrad_direct(gy, wt.reshape(C, g.kh * g.kw, O), g, xshape)
+        return _conv_dgrad_direct(gy, wt.reshape(C, g.kh * g.kw, O), g, xshape, resid)
+    if resid is not None:
+        return _conv_dgrad_raw(gy, w, g, xshape, wt) + resid
     gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
     scratch = None
     if g.pad > 0:
@@ -762,28 +769,37 @@ class _ConvFwd(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = _ConvDgrad.apply(gy, w, ctx.g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gy, x, ctx.g) if ctx.needs_input_grad[1] else None
         return gx, gw, None
 
 
+def _dgrad(gy, w, g, xshape, wt=None, resid=None):
+    return _ConvDgrad.apply(gy, w, g, xshape, wt, resid)
+
+
 class _ConvDgrad(Function):
+    """dgrad(gy, w) [+ resid]: resid = the gradient arriving from a sibling branch of the same input, summed in
+    the kernel's epilogue instead of by a separate elementwise add over the activation."""
+
     @staticmethod
-    def forward(ctx, gy, w, g, xshape, wt=None):
+    def forward(ctx, gy, w, g, xshape, wt, resid):
         gy = gy.contiguous()
         ctx.save_for_backward(gy, w)
         ctx.g = g
+        if resid is not None:
+            resid = resid.contiguous().to(gy.dtype)
         if wt is not None and wt.dtype == gy.dtype:
-            return _conv_dgrad_raw(gy, None, g, xshape, wt=wt)
+            return _conv_dgrad_raw(gy, None, g, xshape, wt=wt, resid=resid)
         wc = w.detach().to(gy.dtype).contiguous()
-        return _conv_dgrad_raw(gy, wc, g, xshape)
+        return _conv_dgrad_raw(gy, wc, g, xshape, resid=resid)
 
     @staticmethod
     def backward(ctx, ggx):
         gy, w = ctx.saved_tensors
         g_gy = _ConvFwd.apply(ggx, w, ctx.g) if ctx.needs_input_grad[0] else None
         g_w = _ConvWgrad.apply(gy, ggx, ctx.g) if ctx.needs_input_grad[1] else None
-        return g_gy, g_w, None, None, None
+        return g_gy, g_w, None, None, None, (ggx if ctx.needs_input_grad[5] else None)
 
 
 class _ConvWgrad(Function):
@@ -799,7 +815,7 @@ class _ConvWgrad(Function):
     def backward(ctx, ggw):
         gy, x = ctx.saved_tensors
         g_gy = _ConvFwd.apply(x, ggw, ctx.g) if ctx.needs_input_grad[0] else None
-        g_x = _ConvDgrad.apply(gy, ggw, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[1] else None
+        g_x = _dgrad(gy, ggw, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[1] else None
         return g_gy, g_x, None
 
 
@@ -828,7 +844,7 @@ class _ConvAct(Function):
         x, w, out = ctx.saved_tensors
         g, alpha, scale, size_b = ctx.cfg
         gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
-        gx = _ConvDgrad.apply(gpre, w, g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gpre, x, g) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None
 
@@ -878,6 +894,36 @@ def conv_weight_bank(entries, dtype):
     return list(zip(wfs, wts))
 
 
+class _ConvActFork(Function):
+    """(lrelu(conv(x, w) + b) * scale, x): the second output hands the SAME input on to a sibling branch (the skip
+    path of ResidualBlock), so that in backward both gradients of x arrive here together and the sibling's is added
+    in the epilogue of this conv's data-gradient kernel -- no separate fork-point add over the activation."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, alpha, scale):
+        x = x.contiguous()
+        wc, ctx.wt = _bank(w, x)
+        if wc is None:
+            wc = w.detach().to(x.dtype).contiguous()
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
+        ctx.save_for_backward(x, w, out)
+        ctx.cfg = (g, alpha, scale, bias.numel())
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gx_sibling):
+        x, w, out = ctx.saved_tensors
+        g, alpha, scale, size_b = ctx.cfg
+        gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gpre, x, g) if ctx.needs_input_grad[1] else None
+        return gx, gw, gb, None, None, None
+
+
+def conv_ring_act_fork(x, w, bias, geom, alpha=0.2, scale=math.sqrt(2.0)):
+    return _ConvActFork.apply(x, w, bias, geom, float(alpha), float(scale))
+
+
 class _ConvResid(Function):
     """conv(x, w) + resid with the residual added in the conv epilogue (reference: the skip sum of
     ResidualBlock.forward, dusty_v2.py:343-345)."""
@@ -896,7 +942,7 @@ class _ConvResid(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = _ConvDgrad.apply(gy, w, ctx.g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gy, x, ctx.g) if ctx.needs_input_grad[1] else None
         return gx, gw, (gy if ctx.needs_input_grad[2] else None), None
 
