@@ -414,6 +414,27 @@ def test_conv_bf16_exact_on_integers(nat, cfg):
     assert torch.equal(gwd.permute(0, 3, 1, 2).cpu(), gw)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_weight_bank_both_layouts(nat, dtype):
+    """wf = scale * w as [O, kh*kw, Cpad] and wt = the same as [Cpad, kh*kw, O], zero padded channels -- exact
+    (one rounding of the fp32 product); ragged O / C exercise the tile edges (reference: EqualLR runtime scaling
+    + ops.Conv2d weight use, gans/models/ops/common.py:158-210)."""
+    g = torch.Generator().manual_seed(21)
+    shapes = [(64, 64, 3, 64), (128, 64, 3, 64), (128, 64, 1, 64), (72, 40, 3, 48), (8, 33, 1, 64), (130, 65, 3, 96)]
+    entries, refs = [], []
+    for i, (O, C, k, cp) in enumerate(shapes):
+        w = torch.randn(O, C, k, k, generator=g)
+        sc = 0.25 + 0.125 * i
+        entries.append((w.to(DEV), sc, cp))
+        full = torch.zeros(O, k * k, cp)
+        full[:, :, :C] = (w * sc).reshape(O, C, k * k).permute(0, 2, 1)
+        refs.append(full.to(dtype))
+    out = nat.conv_weight_bank(entries, dtype)
+    for (wf, wt), ref in zip(out, refs):
+        assert torch.equal(wf.cpu(), ref)
+        assert torch.equal(wt.cpu(), ref.permute(2, 1, 0))
+
+
 # ---------------------------------------------------------------------------------------
 def test_gen_tail_forward_backward(nat):
     g = torch.Generator().manual_seed(4)
