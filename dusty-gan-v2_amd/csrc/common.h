@@ -77,6 +77,30 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// block-level sum (blockDim.x a multiple of 64, <= 1024; `red` = 16 floats of LDS); the result is valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+// sum of squares of the 8 bf16 values packed in a 16-byte quad
+__device__ __forceinline__ float sumsq_bf16x8(uint4 q) {
+  const unsigned w[4] = {q.x, q.y, q.z, q.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+    s = fmaf(lo, lo, s);
+    s = fmaf(hi, hi, s);
+  }
+  return s;
+}
+
 #define DGV2_RETURN_LAST()                 \
   do {                                     \
     hipError_t e__ = hipGetLastError();    \

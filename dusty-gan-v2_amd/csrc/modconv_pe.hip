@@ -29,6 +29,7 @@ struct MPGeom {
   const float* bias;
   int act;
   float alpha, scale;
+  float* sumsq;   // optional: one partial sum of squares of the stored outputs per block
 };
 
 // MF = O / 16, NFW = 16-pixel fragments per wave, KA = Ka / 32, KS = Ks / 32 (compile-time: register arrays)
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   };
   const int aswz = lc ^ ((lr >> 2) & 3);
 
+  float ss = 0.f;
   // one sample: weights of sample b are in rw, its xa fragments in ring slot `slot`
   auto step = [&](auto slot, int b) {
     constexpr int S = decltype(slot)::value;
@@ -152,7 +154,10 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
         }
         uint4 pk;
         const int co = pack_pair_bf16(va, vb, lc, pk);   // all lanes take part in the exchange
-        if (live) *reinterpret_cast<uint4*>(row + mf * 16 + co) = pk;
+        if (live) {
+          *reinterpret_cast<uint4*>(row + mf * 16 + co) = pk;
+          if (g.sumsq) ss += sumsq_bf16x8(pk);
+        }
       }
     }
   };
@@ -165,10 +170,16 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     step(std::integral_constant<int, 0>{}, b);
     if (b + 1 < b1) step(std::integral_constant<int, 1>{}, b + 1);
   }
+  if (g.sumsq) {
+    __shared__ float red[16];
+    const float s = block_sum(ss, red);
+    if (tid == 0) g.sumsq[blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
 }
 
 template <int MF, int NFW, int KA, int KS>
-int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, hipStream_t st) {
+int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, hipStream_t st, int sumsq_cap,
+              int* sumsq_used) {
   constexpr int TP = 8 * 16 * NFW;
   const int tiles = (g.P + TP - 1) / TP;
   // one resident block per CU (the PE fragments fill the register file): one round of blocks, as few sample
@@ -179,6 +190,8 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
   g.samples_per_block = (g.B + nsplit - 1) / nsplit;
   nsplit = (g.B + g.samples_per_block - 1) / g.samples_per_block;
   dim3 grid(tiles, nsplit);
+  if (g.sumsq && sumsq_used && tiles * nsplit <= sumsq_cap) *sumsq_used = tiles * nsplit;
+  else g.sumsq = nullptr;
   constexpr size_t lds = sizeof(uint4) * 2 * (size_t)(((MF * 16) * (KA + KS) * 4 + 511) / 512 * 512);
   auto kern = modconv_pe_fwd_kernel<MF, NFW, KA, KS>;
   if (lds > 64 * 1024) {
@@ -199,22 +212,29 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
 extern "C" int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
                                    int Ks, int O, const float* bias, int act, float alpha, float scale, int dtype,
                                    void* stream) {
+  return dgv2_modconv_pe_fwd_sq(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, dtype, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
+                                      int Ks, int O, const float* bias, int act, float alpha, float scale, int dtype,
+                                      float* sumsq, int sumsq_cap, int* sumsq_used, void* stream) {
+  if (sumsq_used) *sumsq_used = 0;
   if (!y || !w || (Ks > 0 && !xs) || (Ka > 0 && !xa) || B <= 0 || P <= 0) return DGV2_EINVAL;
   if (dtype != DGV2_BF16 || (act != 0 && act != 3)) return DGV2_EINVAL;
   if (!aligned16(y) || !aligned16(xa) || !aligned16(xs) || !aligned16(w)) return DGV2_EINVAL;
   if (Ks == 0) xs = xa;   // never dereferenced (KS = 0), keeps the pointer arithmetic defined
   static const int abl = getenv("DGV2_MP_ABLATE") ? atoi(getenv("DGV2_MP_ABLATE")) : 0;
-  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, abl, bias, act, alpha, scale};
+  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, abl, bias, act, alpha, scale, sumsq};
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (Ka == 64 && Ks == 512 && O == 32) rc = mp_launch<2, 2, 2, 16>(y, xa, xs, w, g, st);
+  if (Ka == 64 && Ks == 512 && O == 32) rc = mp_launch<2, 2, 2, 16>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   // the PE-free layers of the two top levels and their data gradients: same sample walk, weights by LDS-DMA
-  else if (Ks == 0 && Ka == 64 && O == 32) rc = mp_launch<2, 2, 2, 0>(y, xa, xs, w, g, st);
-  else if (Ks == 0 && Ka == 32 && O == 64) rc = mp_launch<4, 2, 1, 0>(y, xa, xs, w, g, st);
-  else if (Ks == 0 && Ka == 128 && O == 64) rc = mp_launch<4, 2, 4, 0>(y, xa, xs, w, g, st);
-  else if (Ks == 0 && Ka == 64 && O == 128) rc = mp_launch<8, 2, 2, 0>(y, xa, xs, w, g, st);
-  else if (Ks == 0 && Ka == 32 && O == 32) rc = mp_launch<2, 2, 1, 0>(y, xa, xs, w, g, st);
-  else if (Ks == 0 && Ka == 64 && O == 64) rc = mp_launch<4, 2, 2, 0>(y, xa, xs, w, g, st);
+  else if (Ks == 0 && Ka == 64 && O == 32) rc = mp_launch<2, 2, 2, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ks == 0 && Ka == 32 && O == 64) rc = mp_launch<4, 2, 1, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ks == 0 && Ka == 128 && O == 64) rc = mp_launch<4, 2, 4, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ks == 0 && Ka == 64 && O == 128) rc = mp_launch<8, 2, 2, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ks == 0 && Ka == 32 && O == 32) rc = mp_launch<2, 2, 1, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ks == 0 && Ka == 64 && O == 64) rc = mp_launch<4, 2, 2, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   else return DGV2_EINVAL;
   if (rc) return rc;
   DGV2_RETURN_LAST();

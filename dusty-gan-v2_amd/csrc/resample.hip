@@ -250,8 +250,10 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
     T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
     const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
     const int* __restrict__ cnt_w, int Ew, int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
-    int SHA) {
+    int SHA, float* __restrict__ sumsq) {
   const int SH = SHA & 0xffff, ablate = SHA >> 16;   // ablate: benchmarking only (DGV2_RS_ABLATE)
+  __shared__ float red[16];
+  float ss = 0.f;   // sum of squares of what this thread stores (sumsq != nullptr: one partial per block)
   constexpr int VN = vec16<T>::N;
   // the ring holds the W-filtered rows in the tensor's own dtype: for bf16 that halves its LDS footprint
   // (16 KB per block -> 8 resident blocks per CU instead of 5; this kernel lives on occupancy) at the price of one
@@ -355,19 +357,27 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
 #pragma unroll
       for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
       o.store(yp + (int64_t)ho * out_w * ldy);
+      if (sumsq) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) ss = fmaf(o.get(j), o.get(j), ss);
+      }
     }
+  }
+  if (sumsq) {
+    const float s = block_sum(ss, red);
+    if (tid == 0) sumsq[blockIdx.x] = s;
   }
 }
 
 template <typename T>
 void rs_launch(int Ew, int blocks, hipStream_t st, T* y, const T* x, const int* idx_h, const float* coef_h,
                const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int B, int C, int ldx,
-               int ldy, int in_h, int in_w, int out_h, int out_w, int sha) {
+               int ldy, int in_h, int in_w, int out_h, int out_w, int sha, float* sumsq) {
   switch (Ew) {
-    case 1: resample_stream_kernel<T, 1><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha); break;
-    case 2: resample_stream_kernel<T, 2><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha); break;
-    case 3: resample_stream_kernel<T, 3><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha); break;
-    default: resample_stream_kernel<T, 4><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha); break;
+    case 1: resample_stream_kernel<T, 1><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha, sumsq); break;
+    case 2: resample_stream_kernel<T, 2><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha, sumsq); break;
+    case 3: resample_stream_kernel<T, 3><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha, sumsq); break;
+    default: resample_stream_kernel<T, 4><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha, sumsq); break;
   }
 }
 
@@ -377,6 +387,15 @@ extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const
                                  int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew, int B,
                                  int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w, int dtype,
                                  void* stream) {
+  return dgv2_resample_tab_sq(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h,
+                              out_w, dtype, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, const float* coef_h, const int* cnt_h,
+                                    int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew, int B,
+                                    int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w, int dtype,
+                                    float* sumsq, int sumsq_cap, int* sumsq_used, void* stream) {
+  if (sumsq_used) *sumsq_used = 0;
   if (!y || !x || !idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w) return DGV2_EINVAL;
   if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || Eh <= 0 || Ew <= 0) return DGV2_EINVAL;
   if (ldx < C || ldy < C) return DGV2_EINVAL;
@@ -393,8 +412,10 @@ extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const
       while (SH > 1 && SH * Eh > 64) SH >>= 1;   // the strip's H-table slice must fit one lane-indexed register
       const int64_t blocks = (int64_t)B * ((out_h + SH - 1) / SH) * (((int64_t)out_w * (C / VN) + 255) / 256);
       if (blocks >= (1LL << 31)) return DGV2_EINVAL;
-rs_launch<T>(Ew, (int)blocks, st, (T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, B, C, ldx, ldy, in_h,
-                   in_w, out_h, out_w, SH | (rs_ablate << 16));
+      float* sq = (sumsq && sumsq_used && blocks <= sumsq_cap) ? sumsq : nullptr;   // one partial per block
+      if (sq) *sumsq_used = (int)blocks;
+      rs_launch<T>(Ew, (int)blocks, st, (T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, B, C, ldx, ldy, in_h,
+                   in_w, out_h, out_w, SH | (rs_ablate << 16), sq);
     } else if (vec)
       resample_tab_kernel<T, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
                                                         cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w);

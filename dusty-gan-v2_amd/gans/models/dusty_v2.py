@@ -61,9 +61,11 @@ class Head(nn.Module):
             self.heads[o["name"]] = ops.ModConv2d(out_ch=o["ch"], in_ch=in_ch, mod_ch=mod_ch, ksize=1, stride=1,
                                                   padding=0, demod=False, ema=True)
 
-    def forward_cl(self, x, style):
-        """x [B,H,W,C] -> fp32 [B,H,W,sum(ch)] (heads concatenated in dict order)."""
-        sumsq = native.sum_squares(x) if self.training else None
+    def forward_cl(self, x, style, sumsq=None):
+        """x [B,H,W,C] -> fp32 [B,H,W,sum(ch)] (heads concatenated in dict order); sumsq = partial sums of
+        squares of x when its producer already took them."""
+        if sumsq is None and self.training:
+            sumsq = native.sum_squares(x)
         mods = [head.prep_args(style, sumsq, x.numel()) for head in self.heads.values()]
         bias = torch.cat([head.bias.reshape(-1) for head in self.heads.values()])
         return native.mod_layer(x, None, mods, bias=bias, act=False, out_dtype=torch.float32)
@@ -121,7 +123,7 @@ class SynthesisBlock(nn.Module):
         B = angle.shape[0] if batch is None else batch
         return native.downsample_angle(angle.float().contiguous(), shift, self.downsample.kernel, B, self.ring)
 
-    def _conv1_shared_pe(self, hin, w_latent, angle, shift, B, dt):
+    def _conv1_shared_pe(self, hin, w_latent, angle, shift, B, dt, want_sq=False):
         """conv1 + bias + lrelu when the whole batch shares one angle grid (the training / sampling
         case).  The reference encodes angle + shift_b per sample and concatenates 512 PE channels to
         every sample's activation (dusty_v2.py:267-274,153-159): 90 % of conv1's input bytes.  The
@@ -132,22 +134,27 @@ class SynthesisBlock(nn.Module):
         H, W = angle.shape[2:]
         pe0 = torch.empty((1, H, W, self.pe.out_ch), device=angle.device, dtype=dt)
         self.pe.encode_into(pe0, 0, angle)
-        hup = None if hin is None else self.resample.forward_cl(hin)
-        cin = 0 if hup is None else hup.shape[3]
         conv = self.conv1
         sumsq, pe_sq = None, 0.0
+        hup = None
+        if hin is not None and conv.training and isinstance(self.resample, ops.Resample):
+            hup, sumsq = native.resample_sq(hin, self.resample.spec)   # the statistic leaves the same kernel
+        elif hin is not None:
+            hup = self.resample.forward_cl(hin)
+        cin = 0 if hup is None else hup.shape[3]
         if conv.training:
             # sum of squares of cat(hup, PE): sin^2 + cos^2 = 1 per frequency pair
             pe_sq = float(self.pe.out_ch // 2) * B * H * W
-            if hup is not None:
+            if hup is not None and sumsq is None:
                 sumsq = native.sum_squares(hup)
         act = self.bias_act1
+        want = want_sq and not self.is_first and self.conv2.training
         if self.pe.out_ch == 512 and conv.in_ch <= 1024:
             # weight preparation (+ rotation), contraction, bias and lrelu as one autograd node
             mods = [conv.prep_args(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch), sumsq_add=pe_sq)]
             fw = self.pe.freqs2[:, 1].contiguous() if shift is not None else None
             return native.mod_layer(hup, pe0, mods, bias=act.bias, act=True, alpha=act.negative_slope,
-                                    scale=act.scale, shift=shift, fw=fw, cin=cin)
+                                    scale=act.scale, shift=shift, fw=fw, cin=cin, want_sq=want)
         if conv.training:
             sumsq = pe_sq if sumsq is None else sumsq.sum() + pe_sq
             sumsq = torch.as_tensor(sumsq, device=angle.device, dtype=torch.float32)
@@ -169,18 +176,24 @@ class SynthesisBlock(nn.Module):
         hin = None if h is None else h.to(dt)
         vec = 8 if dt == LOW else 4
         if angle.shape[0] == 1 and (hin is None or hin.shape[3] % vec == 0):
-            h = self._conv1_shared_pe(hin, ws[0], angle, shift, B, dt)
+            h = self._conv1_shared_pe(hin, ws[0], angle, shift, B, dt, want_sq=True)
         else:
             x1 = native.up_cat_pe(hin, spec, angle, shift, self.pe.freqs2.contiguous(), self.pe.phase, dt, B)
             h = self.conv1.forward_cl(x1, ws[0], act=self.bias_act1)
         nxt = 1
+        sq_h = None
+        if isinstance(h, tuple):   # (activation, partial sums of squares) from the producing kernel
+            h, sq_h = h
         if not self.is_first:
             a2 = self.bias_act2
-            sumsq = native.sum_squares(h) if self.conv2.training else None
+            sumsq = (sq_h if sq_h is not None else native.sum_squares(h)) if self.conv2.training else None
             h = native.mod_layer(h, None, [self.conv2.prep_args(ws[1], sumsq, h.numel())], bias=a2.bias, act=True,
-                                 alpha=a2.negative_slope, scale=a2.scale)
+                                 alpha=a2.negative_slope, scale=a2.scale, want_sq=self.head.training)
+            sq_h = None
+            if isinstance(h, tuple):
+                h, sq_h = h
             nxt = 2
-        o = self.head.forward_cl(h, ws[nxt])
+        o = self.head.forward_cl(h, ws[nxt], sumsq=sq_h)
         if skip is not None:
             o = o + self.resample.forward_cl(skip)
         return h, o

@@ -181,8 +181,18 @@ class ResampleSpec:
         return self._tab[key]
 
 
-def _resample_raw(x, spec, adjoint, in_hw, out=None, ldy=None, ldx=None, C=None):
-    """x [B,h,w,ldx]; forward maps in_hw -> spec.out_size(in_hw); adjoint the other way."""
+_SQ_CAP = 8192   # capacity of a producer's sum-of-squares partial buffer (one slot per block)
+_FUSED_SQ = os.environ.get("DGV2_NO_FUSED_SUMSQ") is None
+
+
+def _sq_args(dev):
+    """(buffer, capacity, host int the library fills with the number of partials it wrote)."""
+    return torch.empty(_SQ_CAP, device=dev, dtype=torch.float32), _ct.c_int(0)
+
+
+def _resample_raw(x, spec, adjoint, in_hw, out=None, ldy=None, ldx=None, C=None, sq=None):
+    """x [B,h,w,ldx]; forward maps in_hw -> spec.out_size(in_hw); adjoint the other way.
+    sq = _sq_args(): also leave the sum-of-squares partials of the output (sq[1].value of them, 0 = unsupported)."""
     B = x.shape[0]
     H, W = in_hw
     Ho, Wo = spec.out_size(H, W)
@@ -194,9 +204,44 @@ def _resample_raw(x, spec, adjoint, in_hw, out=None, ldy=None, ldx=None, C=None)
         out = torch.empty((B, oh, ow, C), device=x.device, dtype=x.dtype)
         ldy = C
     (ih_idx, ih_coef, ih_cnt, Eh), (iw_idx, iw_coef, iw_cnt, Ew) = spec.tables(H, W, adjoint, x.device)
+    if sq is not None:
+        N.call("dgv2_resample_tab_sq", N.ptr(out), N.ptr(x), N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt), Eh,
+               N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew, B, C, ldx, ldy, ih, iw, oh, ow, _dt(x), N.ptr(sq[0]),
+               _SQ_CAP, _ct.addressof(sq[1]), N.stream())
+        return out
     N.call("dgv2_resample_tab", N.ptr(out), N.ptr(x), N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt), Eh,
            N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew, B, C, ldx, ldy, ih, iw, oh, ow, _dt(x), N.stream())
     return out
+
+
+class _ResampleSq(Function):
+    """resample + the sum-of-squares partials of its output (input statistic of the modulated conv that follows,
+    style.py:98-103) from the same kernel; the partials carry no gradient (the reference computes the statistic
+    under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, in_hw):
+        x = x.contiguous()
+        N.check(x)
+        ctx.cfg = (spec, in_hw)
+        sq = _sq_args(x.device)
+        y = _resample_raw(x, spec, False, in_hw, sq=sq)
+        part = sq[0][:sq[1].value] if sq[1].value > 0 else sum_squares(y)
+        ctx.mark_non_differentiable(part)
+        return y, part
+
+    @staticmethod
+    def backward(ctx, g, _):
+        spec, in_hw = ctx.cfg
+        return _Resample.apply(g, spec, True, in_hw), None, None
+
+
+def resample_sq(x, spec):
+    """(resample(x, spec), fp32 partial sums of squares of the result)."""
+    if not _FUSED_SQ:
+        y = resample(x, spec)
+        return y, sum_squares(y)
+    return _ResampleSq.apply(x, spec, (x.shape[1], x.shape[2]))
 
 
 class _Resample(Function):
@@ -423,9 +468,9 @@ def up_cat_pe(h, spec, angle, shift, freqs2, phase, dtype, B):
 # batched channel GEMM = contraction of the modulated 1x1 conv
 # (reference: grouped F.conv2d in ModConv2d.forward, gans/models/ops/style.py:105-118)
 # ---------------------------------------------------------------------------------------
-def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0):
+def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=None):
     """x3 [B,P,I]; w3 [Bw,O,I] (Bw = B or 1) same dtype -> [B,P,O]; optional fused
-    bias (fp32 [O]) + leaky-ReLU epilogue."""
+    bias (fp32 [O]) + leaky-ReLU epilogue.  sq = _sq_args(): sum-of-squares partials where the kernel has them."""
     B, P, I = x3.shape
     Bw, O, _ = w3.shape
     N.check(x3, w3, bias)
@@ -433,6 +478,10 @@ def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0):
     if (_PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and P >= 4096
             and (I, O) in ((64, 32), (32, 64), (128, 64), (64, 128), (32, 32), (64, 64))):
         # streaming shapes of the two top levels: sample-walking kernel without a PE part
+        if sq is not None:
+            N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(bias), act,
+                   alpha, scale, _dt(x3), N.ptr(sq[0]), _SQ_CAP, _ct.addressof(sq[1]), N.stream())
+            return y
         N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(bias), act, alpha,
                scale, _dt(x3), N.stream())
         return y
@@ -1195,6 +1244,7 @@ class _ModLayer(Function):
         act = 3 if cfg["act"] else 0
         bias32 = None if bias is None else bias.detach().float().contiguous()
         odt = cfg["out_dtype"]
+        sq = _sq_args(dev) if (cfg["want_sq"] and _FUSED_SQ) else None
         if xs is not None:
             xs = xs.contiguous()
             xa = None if xa is None else xa.contiguous()
@@ -1203,21 +1253,26 @@ class _ModLayer(Function):
             N.check(xa, xs, wb, bias32)
             if _PE_FWD and dt == torch.bfloat16 and (Ka, xs.shape[3], Otot) == (64, 512, 32):
                 # top pyramid levels: pixel-tile blocks walking the samples, PE fragments in registers
-                N.call("dgv2_modconv_pe_fwd", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3],
-                       Otot, N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), N.stream())
+                N.call("dgv2_modconv_pe_fwd_sq", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3],
+                       Otot, N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), N.ptr(sq[0]) if sq else None,
+                       _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
             else:
                 N.call("dgv2_bmm_nn_cat", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3], Otot,
                        N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs), N.stream())
         else:
             xa = xa.contiguous()
-            out = _bmm_nn_raw(xa.reshape(B, P, I), wb, odt, bias32, act, cfg["alpha"], cfg["scale"]).reshape(
+            out = _bmm_nn_raw(xa.reshape(B, P, I), wb, odt, bias32, act, cfg["alpha"], cfg["scale"], sq=sq).reshape(
                 B, H, W_, Otot)
         ctx.cfg = dict(cfg, Os=Os, I=I, B=B, rot=rot, has_bias=bias is not None)
         ctx.save_for_backward(xa, xs, wb, out if cfg["act"] else None, shift, fw, *Ws, *Ss, *Es, *saved_small)
+        if cfg["want_sq"]:
+            part = sq[0][:sq[1].value] if (sq is not None and sq[1].value > 0) else sum_squares(out)
+            ctx.mark_non_differentiable(part)
+            return out, part
         return out
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _=None):
         cfg = ctx.cfg
         Os, I, B, rot = cfg["Os"], cfg["I"], cfg["B"], cfg["rot"]
         nm = len(Os)
@@ -1288,12 +1343,14 @@ class _ModLayer(Function):
 
 
 def mod_layer(xa, xs, mods, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=None, shift=None,
-              fw=None, cin=0):
-    """mods: list of (W [O,I] fp32, style [B,I] fp32, ema_var scalar tensor, demod flag)."""
+              fw=None, cin=0, want_sq=False):
+    """mods: list of (W [O,I] fp32, style [B,I] fp32, ema_var scalar tensor, demod flag).
+    want_sq: return (out, partial sums of squares of out) -- the statistic the NEXT modulated layer needs of its
+    input, taken in this layer's epilogue where the kernel supports it instead of by another pass."""
     ref = xa if xa is not None else xs
     cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0,
                out_dtype=ref.dtype if out_dtype is None else out_dtype, demod=[bool(m[3]) for m in mods], cin=int(cin),
-               F=0 if fw is None else int(fw.numel()))
+               F=0 if fw is None else int(fw.numel()), want_sq=bool(want_sq))
     flat = []
     for W, s, ev, _ in mods:
         flat += [W, s, ev]

@@ -104,6 +104,16 @@ int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const float* coe
                       int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
                       int dtype, void* stream);
 
+/* dgv2_resample_tab that can also leave the sum of squares of what it wrote (the next modulated conv's input
+ * statistic, ModConv2d.forward style.py:98-103: x.square().mean() for the EMA) as per-block partials, saving a
+ * separate pass over the activation: sumsq fp32 [sumsq_cap] device buffer (NULL = plain dgv2_resample_tab);
+ * *sumsq_used (host) = number of partials written, 0 when this launch configuration cannot provide them
+ * (the caller then runs dgv2_sum_squares).  Partials feed dgv2_ema_scalar(sumsq, nsum = *sumsq_used). */
+int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, const float* coef_h, const int* cnt_h,
+                         int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew,
+                         int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
+                         int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Fourier features (positional encoding of the laser angles)
  * replaces: FourierFeature.forward, gans/models/ops/fourier.py:77-82
@@ -163,6 +173,10 @@ int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, i
  * Returns DGV2_EINVAL for any other shape / dtype (use dgv2_bmm_nn_cat). */
 int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
                         int O, const float* bias, int act, float alpha, float scale, int dtype, void* stream);
+/* ... with the per-block sum-of-squares partials of the stored outputs (contract as in dgv2_resample_tab_sq). */
+int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
+                           int O, const float* bias, int act, float alpha, float scale, int dtype, float* sumsq,
+                           int sumsq_cap, int* sumsq_used, void* stream);
 
 /* Per-sample weights of the modulated conv, written directly as the GEMM operand, and the exact
  * backward of that preparation (max-normalisations, modulation, demodulation, input-magnitude

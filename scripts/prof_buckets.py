@@ -7,8 +7,9 @@ B = collections.OrderedDict([
     ("conv_pipe", r"conv_pipe_kernel"), ("conv_direct_fallback", r"conv_direct_kernel"),
     ("conv_wgrad_stream", r"wgrad_stream|wgrad_reduce"), ("conv_wgrad_direct", r"wgrad_direct"), ("gemm_tn(im2col wgrad)", r"gemm_tn_kernel.*Im2col"),
     ("gemm_tn", r"gemm_tn_kernel"), ("gemm_nn(conv)", r"gemm_nn_kernel.*Im2col"), ("gemm_nn", r"gemm_nn_kernel"),
-    ("resample", r"resample"), ("upfirdn/ada", r"upfirdn|ada_"), ("mod_prep", r"mod_"),
+    ("resample", r"resample"), ("upfirdn/ada", r"upfirdn|ada_"), ("mod_prep", r"mod_prep"),
     ("bias_act", r"bias_act|bias_grad"), ("sumsq", r"sum_squares"), ("tail/fourier/coords", r"gen_tail|fourier|coords|downsample_angle"),
+    ("modconv_pe", r"modconv_pe"), ("stem", r"stem_"), ("adam/lerp", r"adam_|lerp_list"), ("ema/pack/bank", r"ema_scalar|pack2d|weight_bank"),
     ("zero", r"dgv2_zero"), ("blas", r"Cijk|rocblas|hipblas"), ("torch_other", r".*")])
 agg = collections.defaultdict(lambda: [0.0, 0])
 for r in rows:

@@ -230,6 +230,50 @@ def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
                 assert_rel(y.float().cpu(), want, 8e-3)
 
 
+def test_producers_leave_sum_of_squares_partials(nat, g_ops):
+    """The input statistic of a modulated conv (x.square().mean(), style.py:98-103) taken in the epilogue of the
+    kernel that PRODUCES x: dgv2_resample_tab_sq / dgv2_modconv_pe_fwd_sq partials must sum to the sum of squares
+    of exactly what the kernel stored (the rounded bf16 values), and the outputs must equal the plain entries'."""
+    import ctypes
+    import dgv2_native as N
+    g = torch.Generator().manual_seed(5)
+    # resample (FIR up-2, ring): odd batch, several strips
+    x = torch.randn(3, 16, 64, 32, generator=g).to(DEV).bfloat16()
+    spec = nat.ResampleSpec([1, 3, 3, 1], (2, 2), (1, 1), True, "hw", True)
+    y0 = nat.resample(x, spec)
+    y1, part = nat.resample_sq(x, spec)
+    assert torch.equal(y0, y1) and part.numel() > 1 and not part.requires_grad
+    want = y1.double().square().sum().item()
+    assert abs(part.double().sum().item() - want) <= 1e-5 * want
+    xg = x.clone().requires_grad_(True)
+    yg, _ = nat.resample_sq(xg, spec)
+    (gx,) = torch.autograd.grad(yg, xg, torch.ones_like(yg))
+    xg2 = x.clone().requires_grad_(True)
+    (gx2,) = torch.autograd.grad(nat.resample(xg2, spec), xg2, torch.ones_like(yg))
+    assert torch.equal(gx, gx2)
+    # modulated conv, PE and PE-free shapes, ragged pixel tile
+    for Ka, Ks, O, P, B in [(64, 512, 32, 700, 5), (32, 0, 32, 300, 2), (64, 0, 64, 4500, 3)]:
+        xa = torch.randn(B, P, Ka, generator=g).to(DEV).bfloat16()
+        xs = torch.randn(P, max(Ks, 8), generator=g).to(DEV).bfloat16()
+        w = (torch.randn(B, O, Ka + Ks, generator=g) / 8).to(DEV).bfloat16()
+        bias = torch.randn(O, generator=g).to(DEV)
+        y0 = torch.empty((B, P, O), device=DEV, dtype=torch.bfloat16)
+        y1 = torch.empty_like(y0)
+        buf = torch.full((8192,), float("nan"), device=DEV)
+        used = ctypes.c_int(-1)
+        args = (N.ptr(xa), N.ptr(xs) if Ks else None, N.ptr(w), B, P, Ka, Ks, O, N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16)
+        N.call("dgv2_modconv_pe_fwd", N.ptr(y0), *args, N.stream())
+        N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y1), *args, N.ptr(buf), 8192, ctypes.addressof(used), N.stream())
+        assert torch.equal(y0, y1) and used.value > 0
+        want = y1.double().square().sum().item()
+        assert abs(buf[:used.value].double().sum().item() - want) <= 1e-5 * want
+        # capacity too small: no partials, the output is still written
+        used2 = ctypes.c_int(-1)
+        y2 = torch.empty_like(y0)
+        N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y2), *args, N.ptr(buf), 1, ctypes.addressof(used2), N.stream())
+        assert used2.value == 0 and torch.equal(y2, y0)
+
+
 @pytest.mark.parametrize("ring", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_stem_matches_composed_reference(nat, ring, dtype):
