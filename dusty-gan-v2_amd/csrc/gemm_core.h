@@ -256,6 +256,11 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(ALoad al, BLoad bl, Epi ep
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
       epi(batch, m0 + mf * 16 + lc * 4, n0 + wave * 32 + nf * 16 + lr, acc[mf][nf]);
+  if (epi.sumsq) {   // one partial sum of squares of the stored outputs per block (see dgv2_bmm_nn_sq)
+    __shared__ float red[16];
+    const float s = block_sum(epi.ss, red);
+    if (tid == 0) epi.sumsq[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+  }
 }
 
 // Store epilogue: Y[batch][n][m..m+3] (channels-last), optional fp32 output for bf16 inputs, and
@@ -269,7 +274,9 @@ template <typename TY> struct StoreEpilogue {
   const float* bias;  // fp32 [M] or nullptr
   int act;            // 0 = none, 3 = leaky ReLU
   float alpha, scale;
-  __device__ __forceinline__ void operator()(int batch, int m, int n, f32x4 acc) const {
+  float* sumsq;       // optional: per-block partial sums of squares of the stored (rounded) outputs
+  float ss;           // this thread's running sum (kernel-private state, initialise to 0)
+  __device__ __forceinline__ void operator()(int batch, int m, int n, f32x4 acc) {
     if (n >= N || m >= M) return;
     if (bias || act) {
 #pragma unroll
@@ -281,6 +288,14 @@ template <typename TY> struct StoreEpilogue {
       }
     }
     TY* p = y + batch * batch_stride + (int64_t)n * ld + m;
+    if (sumsq) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (m + r < M) {
+          const float v = to_f32(from_f32<TY>(acc[r]));
+          ss = fmaf(v, v, ss);
+        }
+    }
     if (vec && m + 3 < M) {
       if constexpr (sizeof(TY) == 4) {
         *reinterpret_cast<f32x4*>(p) = acc;

@@ -37,6 +37,10 @@ SIGNATURES = {
     "dgv2_bmm_nn": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr],
     "dgv2_bmm_tn": [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr],
     "dgv2_bmm_nn_cat": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr],
+    "dgv2_bmm_nn_cat_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr, _c_int, _c_ptr,
+                           _c_ptr],
+    "dgv2_bmm_nn_sq": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr, _c_int,
+                       _c_ptr, _c_ptr],
     "dgv2_modconv_pe_fwd": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_modconv_pe_fwd_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                                _c_ptr],

@@ -148,7 +148,7 @@ class SynthesisBlock(nn.Module):
             if hup is not None and sumsq is None:
                 sumsq = native.sum_squares(hup)
         act = self.bias_act1
-        want = want_sq and not self.is_first and self.conv2.training
+        want = want_sq and (self.head.training if self.is_first else self.conv2.training)
         if self.pe.out_ch == 512 and conv.in_ch <= 1024:
             # weight preparation (+ rotation), contraction, bias and lrelu as one autograd node
             mods = [conv.prep_args(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch), sumsq_add=pe_sq)]

@@ -485,6 +485,11 @@ def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=No
         N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(bias), act, alpha,
                scale, _dt(x3), N.stream())
         return y
+    if sq is not None:
+        N.call("dgv2_bmm_nn_sq", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
+               N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.ptr(sq[0]), _SQ_CAP, _ct.addressof(sq[1]),
+               N.stream())
+        return y
     N.call("dgv2_bmm_nn", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
            N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.stream())
     return y
@@ -1257,8 +1262,9 @@ class _ModLayer(Function):
                        Otot, N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), N.ptr(sq[0]) if sq else None,
                        _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
             else:
-                N.call("dgv2_bmm_nn_cat", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3], Otot,
-                       N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs), N.stream())
+                N.call("dgv2_bmm_nn_cat_sq", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3], Otot,
+                       N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs), N.ptr(sq[0]) if sq else None,
+                       _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
         else:
             xa = xa.contiguous()
             out = _bmm_nn_raw(xa.reshape(B, P, I), wb, odt, bias32, act, cfg["alpha"], cfg["scale"], sq=sq).reshape(

@@ -163,6 +163,14 @@ int dgv2_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I, i
 int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
                     int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
                     void* stream);
+/* dgv2_bmm_nn / dgv2_bmm_nn_cat that also leave per-block partial sums of squares of the stored outputs
+ * (contract as in dgv2_resample_tab_sq). */
+int dgv2_bmm_nn_sq(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
+                   int64_t wstride, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
+                   float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
+int dgv2_bmm_nn_cat_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
+                       int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
+                       float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, int B, int P, int Ka, int Ks,
                     int O, int dtype, void* stream);
 

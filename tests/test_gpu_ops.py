@@ -272,6 +272,28 @@ def test_producers_leave_sum_of_squares_partials(nat, g_ops):
         y2 = torch.empty_like(y0)
         N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y2), *args, N.ptr(buf), 1, ctypes.addressof(used2), N.stream())
         assert used2.value == 0 and torch.equal(y2, y0)
+    # generic batched GEMM kernels (the lower pyramid levels), ragged tiles
+    for Ka, Ks, O, P, B in [(16, 0, 24, 300, 3), (128, 512, 64, 200, 2)]:
+        xa = torch.randn(B, P, Ka, generator=g).to(DEV).bfloat16()
+        xs = torch.randn(P, max(Ks, 8), generator=g).to(DEV).bfloat16()
+        w = (torch.randn(B, O, Ka + Ks, generator=g) / 8).to(DEV).bfloat16()
+        bias = torch.randn(O, generator=g).to(DEV)
+        y0 = torch.empty((B, P, O), device=DEV, dtype=torch.bfloat16)
+        y1 = torch.empty_like(y0)
+        buf = torch.full((8192,), float("nan"), device=DEV)
+        used = ctypes.c_int(-1)
+        tail = (N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, N.BF16)
+        if Ks:
+            N.call("dgv2_bmm_nn_cat", N.ptr(y0), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks, O, *tail, N.stream())
+            N.call("dgv2_bmm_nn_cat_sq", N.ptr(y1), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks, O, *tail, N.ptr(buf), 8192,
+                   ctypes.addressof(used), N.stream())
+        else:
+            N.call("dgv2_bmm_nn", N.ptr(y0), N.ptr(xa), N.ptr(w), B, P, Ka, O, Ka, O, O * Ka, *tail, N.stream())
+            N.call("dgv2_bmm_nn_sq", N.ptr(y1), N.ptr(xa), N.ptr(w), B, P, Ka, O, Ka, O, O * Ka, *tail, N.ptr(buf), 8192,
+                   ctypes.addressof(used), N.stream())
+        assert torch.equal(y0, y1) and used.value > 0
+        want = y1.double().square().sum().item()
+        assert abs(buf[:used.value].double().sum().item() - want) <= 1e-5 * want
 
 
 @pytest.mark.parametrize("ring", [True, False])
