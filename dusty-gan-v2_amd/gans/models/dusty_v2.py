@@ -378,7 +378,7 @@ class ResidualBlock(nn.Module):
     def bank_entries(self, vec):
         """(conv, bank entry) of the three convs as forward_cl will call them (see Discriminator._weight_bank)."""
         c = 1.0 / math.sqrt(2)
-        fused = self.skip.in_ch % vec == 0 and self.skip._params()[1] is None
+        fused = self.skip.in_ch % vec == 0 and self.skip._params_bias()[0] is None
         return [(self.conv1, self.conv1.bank_entry()), (self.conv2, self.conv2.bank_entry()),
                 (self.skip, self.skip.bank_entry(wscale=c if fused else None))]
 
@@ -390,7 +390,7 @@ class ResidualBlock(nn.Module):
             h = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank)
         c = 1.0 / math.sqrt(2)
         xs = native.resample(x, self.blur_down)
-        if native.conv_resid_ok(xs, self.skip_geom) and self.skip._params()[1] is None:
+        if native.conv_resid_ok(xs, self.skip_geom) and self.skip._params_bias()[0] is None:
             # (act(z) * sqrt2 + skip) / sqrt2 == act(z) * 1 + skip / sqrt2: the residual scale folds into the
             # activation gain and the skip weights, the sum into the skip conv's epilogue
             h = self.conv2.forward_cl(self.resample.forward_cl(h), act=self.bias_act2,
@@ -475,8 +475,8 @@ class Discriminator(nn.Module):
         fused = (not double_backward and h.is_cuda and h.shape[1] == 1 and len(layers) > 3
                  and isinstance(layers[0], ops.BlurVH) and isinstance(layers[1], ops.Conv2d)
                  and isinstance(layers[2], ops.FusedLeakyReLU) and layers[2].bias is not None
-                 and layers[1]._params()[1] is None and tuple(layers[1]._params()[0].shape[1:]) == (2, 1, 1)
-                 and layers[1]._params()[0].shape[0] in (8, 16, 32, 64))
+                 and layers[1]._params_bias()[0] is None and tuple(layers[1].raw_weight().shape[1:]) == (2, 1, 1)
+                 and layers[1].raw_weight().shape[0] in (8, 16, 32, 64))
         if fused:
             x = self._fused_stem(h, layers)
             i = 3

@@ -141,6 +141,11 @@ class Conv2d(nn.Sequential):
             return last.effective_weight(), last.module.bias, last.gain_
         return last.weight, last.bias, 1.0
 
+    def raw_weight(self):
+        """The master parameter [O,C,kh,kw] (unscaled): for shape checks without a scaling launch."""
+        last = self[len(self) - 1]
+        return last.module.weight if isinstance(last, EqualLR) else last.weight
+
     def _params_bias(self):
         last = self[len(self) - 1]
         return (last.module.bias, last.gain_) if isinstance(last, EqualLR) else (last.bias, 1.0)
@@ -167,9 +172,7 @@ class Conv2d(nn.Sequential):
             p_raw, s_used, cpad_used = self.bank_entry(wscale, pad_in_to)
             if abs(ent[0] - s_used) <= 1e-12 * abs(s_used) and ent[1] == cpad_used:
                 # the kernels read the bank's prepared copies; `w` only carries the autograd edge to the parameter
-                w = native.scaled_handle(p_raw, s_used)
-                if cpad_used > w.shape[3]:
-                    w = F.pad(w, (0, cpad_used - w.shape[3]))
+                w = native.scaled_handle(p_raw, s_used, cpad_used)
                 w._dgv2_wf, w._dgv2_wt = ent[2], ent[3]
                 b, gain = self._params_bias()
             else:

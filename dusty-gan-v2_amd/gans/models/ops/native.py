@@ -512,7 +512,7 @@ class _ModGemm(Function):
     def forward(ctx, x, w, out_dtype):
         shp = x.shape
         x3 = x.contiguous().reshape(shp[0], -1, shp[-1])
-        wc = w.detach().to(x.dtype).contiguous()
+        wc = _values(w, x.dtype)
         y = _bmm_nn_raw(x3, wc, out_dtype)
         ctx.save_for_backward(x3, wc)
         ctx.cfg = (shp, w.shape[0] == 1)
@@ -547,7 +547,7 @@ class _ModGemmAct(Function):
     def forward(ctx, x, w, bias, alpha, scale):
         shp = x.shape
         x3 = x.contiguous().reshape(shp[0], -1, shp[-1])
-        wc = w.detach().to(x.dtype).contiguous()
+        wc = _values(w, x.dtype)
         out = _bmm_nn_raw(x3, wc, x.dtype, bias.detach().float().contiguous(), 3, alpha, scale)
         ctx.save_for_backward(x3, wc, out)
         ctx.cfg = (shp, w.shape[0] == 1, alpha, scale, bias.numel())
@@ -815,7 +815,7 @@ class _ConvFwd(Function):
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
         if wc is None:
-            wc = w.detach().to(x.dtype).contiguous()
+            wc = _values(w, x.dtype)
         ctx.save_for_backward(x, w)
         ctx.g = g
         return _conv_fwd_raw(x, wc.reshape(w.shape), g)
@@ -845,7 +845,7 @@ class _ConvDgrad(Function):
             resid = resid.contiguous().to(gy.dtype)
         if wt is not None and wt.dtype == gy.dtype:
             return _conv_dgrad_raw(gy, None, g, xshape, wt=wt, resid=resid)
-        wc = w.detach().to(gy.dtype).contiguous()
+        wc = _values(w, gy.dtype)
         return _conv_dgrad_raw(gy, wc, g, xshape, resid=resid)
 
     @staticmethod
@@ -887,7 +887,7 @@ class _ConvAct(Function):
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
         if wc is None:
-            wc = w.detach().to(x.dtype).contiguous()
+            wc = _values(w, x.dtype)
         out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
         ctx.save_for_backward(x, w, out)
         ctx.cfg = (g, alpha, scale, bias.numel())
@@ -909,21 +909,34 @@ class _ScaledHandle(Function):
     edge back to the parameter (backward: grad * scale in parameter layout).  Saves the forward scaling launch."""
 
     @staticmethod
-    def forward(ctx, param, scale):
-        ctx.scale = scale
-        return param.detach().permute(0, 2, 3, 1)
+    def forward(ctx, param, scale, cpad):
+        ctx.scale, ctx.C = scale, param.shape[1]
+        O, C, kh, kw = param.shape
+        # uninitialised on purpose (no launch): see the class docstring; cpad >= C input channels (zero-padded K)
+        return torch.empty((O, kh, kw, max(C, cpad)), device=param.device, dtype=param.dtype)
 
     @staticmethod
     def backward(ctx, g):
         # contiguous result in the parameter's layout (one strided-read launch): AccumulateGrad can then adopt the
         # tensor instead of cloning a permuted one
-        gp = g.permute(0, 3, 1, 2)
+        gp = g[..., :ctx.C].permute(0, 3, 1, 2)
         out = torch.empty(gp.shape, device=g.device, dtype=g.dtype)
-        return torch.mul(gp, ctx.scale, out=out), None
+        return torch.mul(gp, ctx.scale, out=out), None, None
 
 
-def scaled_handle(param, scale):
-    return _ScaledHandle.apply(param, float(scale))
+def scaled_handle(param, scale, cpad=0):
+    h = _ScaledHandle.apply(param, float(scale), int(cpad))
+    h._dgv2_handle = True
+    return h
+
+
+def _values(w, dtype):
+    """Compute-dtype VALUES of a conv weight; a weight-bank handle has none (its prepared copies did not match
+    this call: wrong dtype, or a second-order pass that must run with the bank off)."""
+    if getattr(w, "_dgv2_handle", False):
+        raise RuntimeError("conv weight handle without values: run this pass without the weight bank "
+                           "(Discriminator.forward(double_backward=True))")
+    return w.detach().to(dtype).contiguous()
 
 
 def conv_weight_bank(entries, dtype):
@@ -958,7 +971,7 @@ class _ConvActFork(Function):
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
         if wc is None:
-            wc = w.detach().to(x.dtype).contiguous()
+            wc = _values(w, x.dtype)
         out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
         ctx.save_for_backward(x, w, out)
         ctx.cfg = (g, alpha, scale, bias.numel())
@@ -988,7 +1001,7 @@ class _ConvResid(Function):
         resid = resid.contiguous()
         wc, ctx.wt = _bank(w, x)
         if wc is None:
-            wc = w.detach().to(x.dtype).contiguous()
+            wc = _values(w, x.dtype)
         ctx.save_for_backward(x, w)
         ctx.g = g
         return _conv_fwd_raw(x, wc.reshape(w.shape), g, resid=resid)
