@@ -168,7 +168,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(T* __restrict__ gx, float* __restrict__ gb,
                                                            const T* __restrict__ gy, const T* __restrict__ ref,
                                                            int64_t rows, int cvecs, float alpha, float scale,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial,
+                                                           const float* __restrict__ row_scale) {
   constexpr int VN = vec16<T>::N;
   __shared__ float red[256 * VN];
   const int tid = threadIdx.x;
@@ -178,6 +179,11 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(T* __restrict__ gx, f
 #pragma unroll
   for (int j = 0; j < VN; ++j) acc[j] = 0.f;
   const int64_t C = (int64_t)cvecs * VN;
+  // optional per-channel factor on the STORED gradient only (gb sums the unscaled one): the modulated convs keep
+  // their input-magnitude factor c[o] out of the weights, y = act(c[o] * acc + b[o]), so d/dacc carries c[o]
+  float rs[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) rs[j] = row_scale ? row_scale[cv * VN + j] : 1.f;
   constexpr int U = 4;  // rows in flight per thread (few blocks, so the loop itself must cover the latency)
   const int64_t stride = (int64_t)gridDim.x * lanes;
   for (int64_t r0 = (int64_t)blockIdx.x * lanes + rl; r0 < rows; r0 += stride * U) {
@@ -200,6 +206,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(T* __restrict__ gx, f
           const float v = (f[u].get(j) > 0.f ? g[u].get(j) : g[u].get(j) * alpha) * scale;
           o.set(j, v);
           acc[j] += o.get(j);  // sum what is actually stored (the reference sums the rounded gx)
+          if (row_scale) o.set(j, v * rs[j]);
         }
         o.store(gx + r * C + cv * VN);
       }
@@ -242,6 +249,12 @@ __global__ __launch_bounds__(256) void bias_partial_reduce_kernel(float* __restr
 extern "C" int dgv2_bias_act_bwd(void* gx, float* gb, const void* gy, const void* ref, int64_t rows, int C,
                                  float alpha, float scale, float* scratch, int64_t scratch_elems, int dtype,
                                  void* stream) {
+  return dgv2_bias_act_bwd_rs(gx, gb, gy, ref, rows, C, alpha, scale, nullptr, scratch, scratch_elems, dtype, stream);
+}
+
+extern "C" int dgv2_bias_act_bwd_rs(void* gx, float* gb, const void* gy, const void* ref, int64_t rows, int C,
+                                    float alpha, float scale, const float* row_scale, float* scratch,
+                                    int64_t scratch_elems, int dtype, void* stream) {
   if (!gx || !gb || !gy || !ref || rows <= 0 || C <= 0) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int vn = dtype == DGV2_BF16 ? 8 : 4;
@@ -258,8 +271,35 @@ extern "C" int dgv2_bias_act_bwd(void* gx, float* gb, const void* gy, const void
   const int grid = (int)(want < 32 ? 32 : (want > cap ? cap : want));
   DGV2_DISPATCH_DTYPE(dtype, {
     bias_act_bwd_kernel<T><<<grid, 256, 0, st>>>((T*)gx, gb, (const T*)gy, (const T*)ref, rows, cvecs, alpha, scale,
-                                                 many ? scratch : nullptr);
+                                                 many ? scratch : nullptr, row_scale);
   });
   if (many) bias_partial_reduce_kernel<<<(C + 3) / 4, 256, 0, st>>>(gb, scratch, grid, C);
+  DGV2_RETURN_LAST();
+}
+
+// y[i] = (TY)(x[i] * row_scale[i % C]): the activation-free modulated layers (the output heads) hand their output
+// gradient on to the GEMMs with the per-channel input-magnitude factor applied and in the compute dtype.
+namespace {
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void scale_cast_kernel(TY* __restrict__ y, const TX* __restrict__ x,
+                                                         const float* __restrict__ row_scale, int64_t n, int C) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = from_f32<TY>(to_f32(x[i]) * row_scale[i % C]);
+}
+}  // namespace
+
+extern "C" int dgv2_scale_cast(void* y, const void* x, const float* row_scale, int64_t n, int C, int xdtype, int ydtype,
+                               void* stream) {
+  if (!y || !x || !row_scale || n <= 0 || C <= 0) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for(n, 256, 4096);
+  if (xdtype == DGV2_F32 && ydtype == DGV2_F32)
+    scale_cast_kernel<float, float><<<grid, 256, 0, st>>>((float*)y, (const float*)x, row_scale, n, C);
+  else if (xdtype == DGV2_F32 && ydtype == DGV2_BF16)
+    scale_cast_kernel<float, bf16_t><<<grid, 256, 0, st>>>((bf16_t*)y, (const float*)x, row_scale, n, C);
+  else if (xdtype == DGV2_BF16 && ydtype == DGV2_BF16)
+    scale_cast_kernel<bf16_t, bf16_t><<<grid, 256, 0, st>>>((bf16_t*)y, (const bf16_t*)x, row_scale, n, C);
+  else
+    return DGV2_EINVAL;
   DGV2_RETURN_LAST();
 }

@@ -7,14 +7,14 @@ namespace {
 template <typename T, typename TY, int TO>
 int launch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
                   int64_t wstride, const float* bias, int act, float alpha, float scale, hipStream_t st, float* sumsq,
-                  int sumsq_cap, int* sumsq_used) {
+                  int sumsq_cap, int* sumsq_used, const float* row_scale) {
   constexpr int CE = 16 / sizeof(T);
   DenseRowLoader<T> al{(const T*)w, wstride, I, O, I, (I % CE == 0) && (wstride % CE == 0) && aligned16(w)};
   DenseRowLoader<T> bl{(const T*)x, (int64_t)P * ldx, ldx, P, I, (ldx % CE == 0) && aligned16(x)};
   constexpr int YE = 16 / sizeof(TY);
   StoreEpilogue<TY> epi{(TY*)y, (int64_t)P * ldy, ldy, O, P,
                         (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & (4 * sizeof(TY) - 1)) == 0),
-                        bias, act, alpha, scale, nullptr, 0.f};
+                        bias, act, alpha, scale, nullptr, 0.f, row_scale};
   (void)YE;
   dim3 grid((P + 127) / 128, (O + TO - 1) / TO, B);
   const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
@@ -29,11 +29,11 @@ int launch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, in
 template <typename T, typename TY>
 int dispatch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
                     int64_t wstride, const float* bias, int act, float alpha, float scale, hipStream_t st, float* sumsq,
-                    int sumsq_cap, int* sumsq_used) {
-  if (O <= 16) return launch_bmm_nn<T, TY, 16>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
-  if (O <= 32) return launch_bmm_nn<T, TY, 32>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
-  if (O <= 64) return launch_bmm_nn<T, TY, 64>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
-  return launch_bmm_nn<T, TY, 128>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
+                    int sumsq_cap, int* sumsq_used, const float* row_scale) {
+  if (O <= 16) return launch_bmm_nn<T, TY, 16>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+  if (O <= 32) return launch_bmm_nn<T, TY, 32>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+  if (O <= 64) return launch_bmm_nn<T, TY, 64>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+  return launch_bmm_nn<T, TY, 128>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
 }
 
 template <typename T, int TO, int TJ>
@@ -52,11 +52,11 @@ int launch_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I,
 template <typename T, typename TY, int TO>
 int launch_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks, int O,
                       const float* bias, int act, float alpha, float scale, hipStream_t st, float* sumsq, int sumsq_cap,
-                      int* sumsq_used) {
+                      int* sumsq_used, const float* row_scale) {
   const int K = Ka + Ks;
   DenseRowLoader<T> al{(const T*)w, (int64_t)O * K, K, O, K, true};
   ConcatRowLoader<T> bl{(const T*)xa, (int64_t)P * Ka, Ka, Ka, (const T*)xs, Ks, Ks, P};
-  StoreEpilogue<TY> epi{(TY*)y, (int64_t)P * O, O, O, P, (O % 4 == 0), bias, act, alpha, scale, nullptr, 0.f};
+  StoreEpilogue<TY> epi{(TY*)y, (int64_t)P * O, O, O, P, (O % 4 == 0), bias, act, alpha, scale, nullptr, 0.f, row_scale};
   dim3 grid(B, (O + TO - 1) / TO, (P + 127) / 128);
   const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
   if (sumsq && sumsq_used && nblk <= sumsq_cap) {
@@ -70,11 +70,11 @@ int launch_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, in
 template <typename T, typename TY>
 int dispatch_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks, int O,
                         const float* bias, int act, float alpha, float scale, hipStream_t st, float* sumsq, int sumsq_cap,
-                        int* sumsq_used) {
-  if (O <= 16) return launch_bmm_nn_cat<T, TY, 16>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
-  if (O <= 32) return launch_bmm_nn_cat<T, TY, 32>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
-  if (O <= 64) return launch_bmm_nn_cat<T, TY, 64>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
-  return launch_bmm_nn_cat<T, TY, 128>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
+                        int* sumsq_used, const float* row_scale) {
+  if (O <= 16) return launch_bmm_nn_cat<T, TY, 16>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+  if (O <= 32) return launch_bmm_nn_cat<T, TY, 32>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+  if (O <= 64) return launch_bmm_nn_cat<T, TY, 64>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+  return launch_bmm_nn_cat<T, TY, 128>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
 }
 
 template <typename T, int TO, int TJ>
@@ -96,23 +96,23 @@ int launch_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs,
 extern "C" int dgv2_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
                            int64_t wstride, const float* bias, int act, float alpha, float scale, int dtype,
                            int ydtype, void* stream) {
-  return dgv2_bmm_nn_sq(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, dtype, ydtype, nullptr, 0, nullptr,
-                        stream);
+  return dgv2_bmm_nn_sq(y, x, w, B, P, I, O, ldx, ldy, wstride, nullptr, bias, act, alpha, scale, dtype, ydtype, nullptr, 0,
+                        nullptr, stream);
 }
 
 extern "C" int dgv2_bmm_nn_sq(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
-                              int64_t wstride, const float* bias, int act, float alpha, float scale, int dtype,
+                              int64_t wstride, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype,
                               int ydtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream) {
   if (sumsq_used) *sumsq_used = 0;
   if (!y || !x || !w || B <= 0 || P <= 0 || I <= 0 || O <= 0 || ldx < I || ldy < O) return DGV2_EINVAL;
   if (act != 0 && act != 3) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DGV2_F32 && ydtype == DGV2_F32)
-    dispatch_bmm_nn<float, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
+    dispatch_bmm_nn<float, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
   else if (dtype == DGV2_BF16 && ydtype == DGV2_BF16)
-    dispatch_bmm_nn<bf16_t, bf16_t>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
+    dispatch_bmm_nn<bf16_t, bf16_t>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
   else if (dtype == DGV2_BF16 && ydtype == DGV2_F32)
-    dispatch_bmm_nn<bf16_t, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
+    dispatch_bmm_nn<bf16_t, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
   else
     return DGV2_EINVAL;
   DGV2_RETURN_LAST();
@@ -146,11 +146,12 @@ extern "C" int dgv2_bmm_tn(float* gw, const void* gy, const void* x, int B, int 
 extern "C" int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
                                int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
                                void* stream) {
-  return dgv2_bmm_nn_cat_sq(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, dtype, ydtype, nullptr, 0, nullptr, stream);
+  return dgv2_bmm_nn_cat_sq(y, xa, xs, w, B, P, Ka, Ks, O, nullptr, bias, act, alpha, scale, dtype, ydtype, nullptr, 0, nullptr,
+                            stream);
 }
 
 extern "C" int dgv2_bmm_nn_cat_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
-                                  int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
+                                  int O, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
                                   float* sumsq, int sumsq_cap, int* sumsq_used, void* stream) {
   if (sumsq_used) *sumsq_used = 0;
   if (!y || !xs || !w || (Ka > 0 && !xa) || B <= 0 || P <= 0 || Ka < 0 || Ks <= 0 || O <= 0) return DGV2_EINVAL;
@@ -160,9 +161,9 @@ extern "C" int dgv2_bmm_nn_cat_sq(void* y, const void* xa, const void* xs, const
     return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DGV2_F32 && ydtype == DGV2_F32)
-    dispatch_bmm_nn_cat<float, float>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
+    dispatch_bmm_nn_cat<float, float>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
   else if (dtype == DGV2_BF16 && ydtype == DGV2_BF16)
-    dispatch_bmm_nn_cat<bf16_t, bf16_t>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used);
+    dispatch_bmm_nn_cat<bf16_t, bf16_t>(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
   else
     return DGV2_EINVAL;
   DGV2_RETURN_LAST();

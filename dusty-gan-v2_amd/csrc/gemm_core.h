@@ -276,8 +276,14 @@ template <typename TY> struct StoreEpilogue {
   float alpha, scale;
   float* sumsq;       // optional: per-block partial sums of squares of the stored (rounded) outputs
   float ss;           // this thread's running sum (kernel-private state, initialise to 0)
+  const float* row_scale;  // optional fp32 [M]: y = act(acc * row_scale[m] + bias[m])
   __device__ __forceinline__ void operator()(int batch, int m, int n, f32x4 acc) {
     if (n >= N || m >= M) return;
+    if (row_scale) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (m + r < M) acc[r] *= row_scale[m + r];
+    }
     if (bias || act) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -30,6 +30,7 @@ struct MPGeom {
   int act;
   float alpha, scale;
   float* sumsq;   // optional: one partial sum of squares of the stored outputs per block
+  const float* row_scale;   // optional fp32 [O]: y = act(acc * row_scale[o] + bias[o])
 };
 
 // MF = O / 16, NFW = 16-pixel fragments per wave, KA = Ka / 32, KS = Ks / 32 (compile-time: register arrays)
@@ -67,6 +68,11 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias_r[mf][r] = g.bias ? g.bias[mf * 16 + lc * 4 + r] : 0.f;
+  float cs_r[MF][4];              // per-channel output scale (1 when absent)
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs_r[mf][r] = g.row_scale ? g.row_scale[mf * 16 + lc * 4 + r] : 1.f;
   constexpr int KAR = KA > 0 ? KA : 1;
   uint4 xr[2][NFW][KAR];            // xa fragments of samples b, b+1
   typedef __attribute__((address_space(3))) void lds_void_t;
@@ -143,8 +149,8 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float fa = acc[mf][nf][r], fb = acc[mf + 1][nf][r];
-          fa += bias_r[mf][r];
-          fb += bias_r[mf + 1][r];
+          fa = fmaf(fa, cs_r[mf][r], bias_r[mf][r]);
+          fb = fmaf(fb, cs_r[mf + 1][r], bias_r[mf + 1][r]);
           if (g.act == 3) {
             fa = (fa > 0.f ? fa : fa * g.alpha) * g.scale;
             fb = (fb > 0.f ? fb : fb * g.alpha) * g.scale;
@@ -212,19 +218,21 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
 extern "C" int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
                                    int Ks, int O, const float* bias, int act, float alpha, float scale, int dtype,
                                    void* stream) {
-  return dgv2_modconv_pe_fwd_sq(y, xa, xs, w, B, P, Ka, Ks, O, bias, act, alpha, scale, dtype, nullptr, 0, nullptr, stream);
+  return dgv2_modconv_pe_fwd_sq(y, xa, xs, w, B, P, Ka, Ks, O, nullptr, bias, act, alpha, scale, dtype, nullptr, 0, nullptr,
+                                stream);
 }
 
 extern "C" int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
-                                      int Ks, int O, const float* bias, int act, float alpha, float scale, int dtype,
-                                      float* sumsq, int sumsq_cap, int* sumsq_used, void* stream) {
+                                      int Ks, int O, const float* row_scale, const float* bias, int act, float alpha,
+                                      float scale, int dtype, float* sumsq, int sumsq_cap, int* sumsq_used,
+                                      void* stream) {
   if (sumsq_used) *sumsq_used = 0;
   if (!y || !w || (Ks > 0 && !xs) || (Ka > 0 && !xa) || B <= 0 || P <= 0) return DGV2_EINVAL;
   if (dtype != DGV2_BF16 || (act != 0 && act != 3)) return DGV2_EINVAL;
   if (!aligned16(y) || !aligned16(xa) || !aligned16(xs) || !aligned16(w)) return DGV2_EINVAL;
   if (Ks == 0) xs = xa;   // never dereferenced (KS = 0), keeps the pointer arithmetic defined
   static const int abl = getenv("DGV2_MP_ABLATE") ? atoi(getenv("DGV2_MP_ABLATE")) : 0;
-  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, abl, bias, act, alpha, scale, sumsq};
+  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, abl, bias, act, alpha, scale, sumsq, row_scale};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (Ka == 64 && Ks == 512 && O == 32) rc = mp_launch<2, 2, 2, 16>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);

@@ -92,15 +92,14 @@ __device__ __forceinline__ bool is_sin_col(const ModGeom& g, int j) {
   return g.F > 0 && i >= g.cin && i < g.cin + g.F;
 }
 
+// one (o, b) row of the prepared weights; ema_var == nullptr: c = 1 (the caller applies the input-magnitude factor
+// in the GEMM epilogue instead, see dgv2_mod_prep_all_fwd)
 template <typename TO>
-__global__ __launch_bounds__(PB) void mod_prep_fwd_kernel(TO* __restrict__ wb, float* __restrict__ dsave,
-                                                          const float* __restrict__ W, const float* __restrict__ s,
-                                                          const float* __restrict__ stats,
-                                                          const float* __restrict__ ema_var,
-                                                          const float* __restrict__ shift,
-                                                          const float* __restrict__ fw, ModGeom g) {
-  __shared__ float red[4];
-  const int o = blockIdx.x, b = blockIdx.y;
+__device__ __forceinline__ void prep_fwd_row(TO* __restrict__ wb, float* __restrict__ dsave,
+                                             const float* __restrict__ W, const float* __restrict__ s,
+                                             const float* __restrict__ stats, const float* __restrict__ ema_var,
+                                             const float* __restrict__ shift, const float* __restrict__ fw,
+                                             const ModGeom& g, int o, int b, float* red) {
   float m[MAXJ], t[MAXJ], wp[MAXJ];
   mod_row(g, W, s, stats, b, o, m, t, wp);
   float d = 1.f;
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(PB) void mod_prep_fwd_kernel(TO* __restrict__ wb, f
     ss = block_sum(ss, red);
     d = rsqrtf(ss + 1e-8f);
   }
-  const float c = 1.f / (sqrtf(ema_var[0]) + 1e-8f);
+  const float c = ema_var ? 1.f / (sqrtf(ema_var[0]) + 1e-8f) : 1.f;
   if (threadIdx.x == 0) dsave[(int64_t)b * g.O + o] = d;
   const float k = d * c;
   if (g.F > 0 && shift) {
@@ -132,6 +131,17 @@ __global__ __launch_bounds__(PB) void mod_prep_fwd_kernel(TO* __restrict__ wb, f
     const int i = threadIdx.x + j * PB;
     if (i < g.I) out[i] = from_f32<TO>(m[j] * k);
   }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(PB) void mod_prep_fwd_kernel(TO* __restrict__ wb, float* __restrict__ dsave,
+                                                          const float* __restrict__ W, const float* __restrict__ s,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ ema_var,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ fw, ModGeom g) {
+  __shared__ float red[4];
+  prep_fwd_row<TO>(wb, dsave, W, s, stats, ema_var, shift, fw, g, blockIdx.x, blockIdx.y, red);
 }
 
 // gradient of the loss w.r.t. the pre-rotation modulated weight m (per owned column), given G = dL/dwb
@@ -176,17 +186,14 @@ __device__ __forceinline__ void grad_m(const ModGeom& g, const float* __restrict
 // with the sums over the group kept in registers, so the fp32 atomics that combine groups are OG (gt) and
 // BG (gWraw) times fewer than one per pair -- same-address float atomics are what bounds this kernel.
 template <int OG, int BG>
-__global__ __launch_bounds__(PB) void mod_prep_bwd_kernel(float* __restrict__ gWraw, float* __restrict__ gt,
-                                                          float* __restrict__ corr, const float* __restrict__ G,
-                                                          const float* __restrict__ W, const float* __restrict__ s,
-                                                          const float* __restrict__ stats,
-                                                          const float* __restrict__ dsave,
-                                                          const float* __restrict__ ema_var,
-                                                          const float* __restrict__ shift,
-                                                          const float* __restrict__ fw, ModGeom g, int corr_slots) {
-  __shared__ float red[4];
-  const int o0 = blockIdx.x * OG, b0 = blockIdx.y * BG;
-  const float c = 1.f / (sqrtf(ema_var[0]) + 1e-8f);
+__device__ __forceinline__ void prep_bwd_group(float* __restrict__ gWraw, float* __restrict__ gt,
+                                               float* __restrict__ corr, const float* __restrict__ G,
+                                               const float* __restrict__ W, const float* __restrict__ s,
+                                               const float* __restrict__ stats, const float* __restrict__ dsave,
+                                               const float* __restrict__ ema_var, const float* __restrict__ shift,
+                                               const float* __restrict__ fw, const ModGeom& g, int corr_slots,
+                                               int o0, int b0, int blk, float* red) {
+  const float c = ema_var ? 1.f / (sqrtf(ema_var[0]) + 1e-8f) : 1.f;   // nullptr: G is already dL/d(m d)
   float gwacc[OG][MAXJ];
 #pragma unroll
   for (int ol = 0; ol < OG; ++ol)
@@ -236,18 +243,29 @@ __global__ __launch_bounds__(PB) void mod_prep_bwd_kernel(float* __restrict__ gW
     // one slot per block when the caller provided them (plain store: the buffer was cleared, nobody else writes
     // the slot); 1000+ same-address atomics would otherwise serialise into the longest part of this kernel
     if (threadIdx.x == 0) {
-      const int blk = blockIdx.y * gridDim.x + blockIdx.x;
       if (corr_slots > 1) corr[blk] = part;
       else atomicAdd(corr, part);
     }
   }
 }
 
-// s' = s / smax:  gs_i = gt_i / smax - [|s_i| == smax] sign(s_i) (sum_j gt_j s_j) / smax^2   (in place on gt)
-__global__ __launch_bounds__(PB) void mod_prep_bwd_s_fix_kernel(float* __restrict__ gs, const float* __restrict__ s,
-                                                                const float* __restrict__ stats, int I) {
+template <int OG, int BG>
+__global__ __launch_bounds__(PB) void mod_prep_bwd_kernel(float* __restrict__ gWraw, float* __restrict__ gt,
+                                                          float* __restrict__ corr, const float* __restrict__ G,
+                                                          const float* __restrict__ W, const float* __restrict__ s,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ dsave,
+                                                          const float* __restrict__ ema_var,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ fw, ModGeom g, int corr_slots) {
   __shared__ float red[4];
-  const int b = blockIdx.x;
+  prep_bwd_group<OG, BG>(gWraw, gt, corr, G, W, s, stats, dsave, ema_var, shift, fw, g, corr_slots, blockIdx.x * OG,
+                         blockIdx.y * BG, blockIdx.y * gridDim.x + blockIdx.x, red);
+}
+
+// s' = s / smax:  gs_i = gt_i / smax - [|s_i| == smax] sign(s_i) (sum_j gt_j s_j) / smax^2   (in place on gt)
+__device__ __forceinline__ void s_fix_row(float* __restrict__ gs, const float* __restrict__ s,
+                                          const float* __restrict__ stats, int I, int b, float* red) {
   const float smax = stats[2 + 2 * b];
   float acc[MAXJ], sv[MAXJ], dot = 0.f;
 #pragma unroll
@@ -269,13 +287,17 @@ __global__ __launch_bounds__(PB) void mod_prep_bwd_s_fix_kernel(float* __restric
   }
 }
 
+__global__ __launch_bounds__(PB) void mod_prep_bwd_s_fix_kernel(float* __restrict__ gs, const float* __restrict__ s,
+                                                                const float* __restrict__ stats, int I) {
+  __shared__ float red[4];
+  s_fix_row(gs, s, stats, I, blockIdx.x, red);
+}
+
 // W' = W * k (k = 1/wmax or scale): gW = gWraw * k, and with demod the max-norm term
 //   gW_i -= [|W_i| == wmax] sign(W_i) corr / wmax,  corr = sum gWraw w'.
-__global__ __launch_bounds__(256) void mod_prep_bwd_w_fix_kernel(float* __restrict__ gW, const float* __restrict__ W,
-                                                                 const float* __restrict__ stats,
-                                                                 const float* __restrict__ corr, int ncorr, int OI,
-                                                                 int demod, float scale) {
-  __shared__ float red[4];
+__device__ __forceinline__ void w_fix_part(float* __restrict__ gW, const float* __restrict__ W,
+                                           const float* __restrict__ stats, const float* __restrict__ corr,
+                                           int ncorr, int OI, int demod, float scale, int blk, int nblk, float* red) {
   const float wmax = demod ? stats[0] : 1.f;
   const float k = demod ? 1.f / wmax : scale;
   float csum = 0.f;
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(256) void mod_prep_bwd_w_fix_kernel(float* __restri
     __syncthreads();
     csum = red[0] + red[1] + red[2] + red[3];
   }
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < OI; i += gridDim.x * blockDim.x) {
+  for (int i = blk * 256 + threadIdx.x; i < OI; i += nblk * 256) {
     float v = gW[i] * k;
     if (demod) {
       const float w = W[i];
@@ -294,6 +316,120 @@ __global__ __launch_bounds__(256) void mod_prep_bwd_w_fix_kernel(float* __restri
     }
     gW[i] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void mod_prep_bwd_w_fix_kernel(float* __restrict__ gW, const float* __restrict__ W,
+                                                                 const float* __restrict__ stats,
+                                                                 const float* __restrict__ corr, int ncorr, int OI,
+                                                                 int demod, float scale) {
+  __shared__ float red[4];
+  w_fix_part(gW, W, stats, corr, ncorr, OI, demod, scale, blockIdx.x, gridDim.x, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched forms: ALL modulated layers of one generator pass in one launch each (19 on dusty_v2).  The per-layer
+// operands travel by value in the kernel arguments; a block finds its layer in a prefix table of block counts.
+// The input-magnitude factor c = 1/(sqrt(ema_var)+1e-8) is NOT folded into these weights (it depends on the
+// activation statistics of the running pass, which would serialise the preparation layer by layer): the GEMM
+// epilogues apply it per output channel (row_scale), and the backward takes G = dL/d(m d) directly.
+// ------------------------------------------------------------------------------------------------
+constexpr int MPA_MAX = 32;
+
+struct PrepAll {
+  const float* W[MPA_MAX];
+  const float* s[MPA_MAX];
+  const float* fw[MPA_MAX];
+  void* wb[MPA_MAX];           // fwd: prepared weights;  bwd: G = dL/dwb (fp32)
+  float* dsave[MPA_MAX];
+  float* gW[MPA_MAX];          // bwd: [gW | gs | corr] of the layer, contiguous
+  int O[MPA_MAX], I[MPA_MAX], Otot[MPA_MAX], row_off[MPA_MAX], cin[MPA_MAX], flags[MPA_MAX];  // 1 demod, 2 rotate, 4 bf16
+  int blk_end[MPA_MAX];        // prefix ends of this launch's blocks per layer
+  int aux[MPA_MAX];            // stats: W blocks;  bwd groups: corr slots;  w_fix: blocks of the layer
+  int ncorr[MPA_MAX];
+  float* stats;                // [L, 2 + 2B]
+  const float* shift;
+  int B, L;
+};
+
+__device__ __forceinline__ int find_layer(const PrepAll& a, int bid, int& local) {
+  int l = 0;
+  while (l < a.L - 1 && bid >= a.blk_end[l]) ++l;
+  local = bid - (l ? a.blk_end[l - 1] : 0);
+  return l;
+}
+
+__device__ __forceinline__ ModGeom layer_geom(const PrepAll& a, int l) {
+  return ModGeom{a.B, a.O[l], a.I[l], a.Otot[l], a.row_off[l], a.flags[l] & 1, a.cin[l],
+                 ((a.flags[l] & 2) && a.shift) ? PB : 0, rsqrtf((float)a.I[l])};
+}
+
+__global__ __launch_bounds__(PB) void mod_stats_all_kernel(PrepAll a) {
+  __shared__ float red[4];
+  int local;
+  const int l = find_layer(a, blockIdx.x, local);
+  float* stats = a.stats + (size_t)l * (2 + 2 * a.B);
+  const int I = a.I[l], OI = a.O[l] * I, wblocks = a.aux[l];
+  const float* W = a.W[l];
+  const float* s = a.s[l];
+  float m = 0.f;
+  int slot;
+  if (local < wblocks) {
+    for (int i = local * PB + threadIdx.x; i < OI; i += wblocks * PB) m = fmaxf(m, fabsf(W[i]));
+    slot = 0;
+  } else {
+    const int b = local - wblocks;
+    for (int i = threadIdx.x; i < I; i += PB) m = fmaxf(m, fabsf(s[(int64_t)b * I + i]));
+    slot = 2 + 2 * b;
+  }
+  m = block_max(m, red);
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(stats + slot), __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(PB) void mod_prep_all_fwd_kernel(PrepAll a) {
+  __shared__ float red[4];
+  int local;
+  const int l = find_layer(a, blockIdx.x, local);
+  const ModGeom g = layer_geom(a, l);
+  const int o = local % g.O, b = local / g.O;
+  const float* stats = a.stats + (size_t)l * (2 + 2 * a.B);
+  if (a.flags[l] & 4)
+    prep_fwd_row<bf16_t>((bf16_t*)a.wb[l], a.dsave[l], a.W[l], a.s[l], stats, nullptr, a.shift, a.fw[l], g, o, b, red);
+  else
+    prep_fwd_row<float>((float*)a.wb[l], a.dsave[l], a.W[l], a.s[l], stats, nullptr, a.shift, a.fw[l], g, o, b, red);
+}
+
+template <int OG, int BG>
+__global__ __launch_bounds__(PB) void mod_prep_all_bwd_kernel(PrepAll a) {
+  __shared__ float red[4];
+  int local;
+  const int l = find_layer(a, blockIdx.x, local);
+  const ModGeom g = layer_geom(a, l);
+  const int gx = (g.O + OG - 1) / OG;
+  float* gW = a.gW[l];
+  float* gs = gW + (size_t)g.O * g.I;
+  float* corr = gs + (size_t)g.B * g.I;
+  prep_bwd_group<OG, BG>(gW, gs, corr, (const float*)a.wb[l], a.W[l], a.s[l], a.stats + (size_t)l * (2 + 2 * a.B),
+                         a.dsave[l], nullptr, a.shift, a.fw[l], g, a.aux[l], (local % gx) * OG, (local / gx) * BG, local,
+                         red);
+}
+
+__global__ __launch_bounds__(PB) void mod_prep_all_s_fix_kernel(PrepAll a) {
+  __shared__ float red[4];
+  int local;
+  const int l = find_layer(a, blockIdx.x, local);
+  float* gs = a.gW[l] + (size_t)a.O[l] * a.I[l];
+  s_fix_row(gs, a.s[l], a.stats + (size_t)l * (2 + 2 * a.B), a.I[l], local, red);
+}
+
+__global__ __launch_bounds__(256) void mod_prep_all_w_fix_kernel(PrepAll a) {
+  __shared__ float red[4];
+  int local;
+  const int l = find_layer(a, blockIdx.x, local);
+  const int O = a.O[l], I = a.I[l];
+  float* gW = a.gW[l];
+  const float* corr = gW + (size_t)O * I + (size_t)a.B * I;
+  w_fix_part(gW, a.W[l], a.stats + (size_t)l * (2 + 2 * a.B), corr, a.ncorr[l], O * I, a.flags[l] & 1,
+             rsqrtf((float)I), local, a.aux[l], red);
 }
 
 bool geom_ok(int B, int O, int I, int Otot, int row_off, int cin, int F) {
@@ -307,25 +443,26 @@ bool geom_ok(int B, int O, int I, int Otot, int row_off, int cin, int F) {
 //   ema <- lerp(ema, (sum(sumsq[0..nsum)) + add) * inv_count, weight)   (when update)
 //   snapshot <- ema        (the value this forward pass uses; the buffer itself keeps changing)
 static __global__ void ema_scalar_kernel(float* ema, float* snapshot, const float* sumsq, int nsum, float add,
-                                         float inv_count, float weight, int update) {
+                                         float inv_count, float weight, int update, float* cvec, int ncvec) {
   float s = 0.f;   // one wave: fold the nsum partial sums of dgv2_sum_squares
   if (sumsq)
     for (int k = threadIdx.x; k < nsum; k += 64) s += sumsq[k];
   s = wave_sum(s);
+  float v = ema[0];   // every lane computes the same value; lane 0 stores it
+  if (update) v += weight * ((s + add) * inv_count - v);
   if (threadIdx.x == 0) {
-    float v = ema[0];
-    if (update) {
-      v += weight * ((s + add) * inv_count - v);
-      ema[0] = v;
-    }
-    snapshot[0] = v;
+    if (update) ema[0] = v;
+    if (snapshot) snapshot[0] = v;
   }
+  const float c = 1.f / (sqrtf(v) + 1e-8f);   // the factor the modulated conv applies to its output rows
+  for (int i = threadIdx.x; i < ncvec; i += 64) cvec[i] = c;
 }
 
 extern "C" int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, int nsum, float add, float inv_count,
-                               float weight, int update, void* stream) {
-  if (!ema || !snapshot || nsum < 0) return DGV2_EINVAL;
-  ema_scalar_kernel<<<1, 64, 0, (hipStream_t)stream>>>(ema, snapshot, sumsq, nsum, add, inv_count, weight, update);
+                               float weight, int update, float* cvec, int ncvec, void* stream) {
+  if (!ema || (!snapshot && !cvec) || nsum < 0 || ncvec < 0 || (ncvec > 0 && !cvec)) return DGV2_EINVAL;
+  ema_scalar_kernel<<<1, 64, 0, (hipStream_t)stream>>>(ema, snapshot, sumsq, nsum, add, inv_count, weight, update, cvec,
+                                                       ncvec);
   DGV2_RETURN_LAST();
 }
 
@@ -398,5 +535,117 @@ extern "C" int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float*
   if (demod) mod_prep_bwd_s_fix_kernel<<<B, PB, 0, st>>>(gs, s, stats, I);
   mod_prep_bwd_w_fix_kernel<<<grid_for((int64_t)O * I, 256, 256), 256, 0, st>>>(gW, W, stats, corr, ncorr, O * I,
                                                                               demod, g.scale);
+  DGV2_RETURN_LAST();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched preparation of L <= 32 modulated layers (see the kernels above).  All pointer / int arguments are HOST
+// arrays of length L; wb[l] is the layer's GEMM operand buffer [B, Otot[l], I[l]] (layers that share a GEMM pass
+// the same buffer with different row_off), in bf16 when flags[l] & 4 else fp32; dsave[l] fp32 [B, O[l]];
+// stats fp32 [L, 2 + 2B] (filled here, needed by the backward); fw[l] fp32 [256] azimuth frequencies of layers
+// with flags[l] & 2 (rotation of the PE columns [cin, cin + 512) by shift[b], shift NULL = no rotation).
+// The prepared weights do NOT contain 1/(sqrt(ema_var)+1e-8): pass that factor as row_scale to the GEMM.
+// ------------------------------------------------------------------------------------------------
+static int fill_common(PrepAll& a, const float* const* W, const float* const* s, const float* const* fw, const int* O,
+                       const int* I, const int* Otot, const int* row_off, const int* cin, const int* flags, int B, int L) {
+  if (!W || !s || !fw || !O || !I || !Otot || !row_off || !cin || !flags || B < 1 || L < 1 || L > MPA_MAX) return DGV2_EINVAL;
+  for (int l = 0; l < L; ++l) {
+    const int F = (flags[l] & 2) ? PB : 0;
+    if (!W[l] || !s[l] || (F && !fw[l]) || !geom_ok(B, O[l], I[l], Otot[l], row_off[l], cin[l], F)) return DGV2_EINVAL;
+    if ((int64_t)O[l] * B >= (1 << 24)) return DGV2_EINVAL;
+    a.W[l] = W[l]; a.s[l] = s[l]; a.fw[l] = fw[l];
+    a.O[l] = O[l]; a.I[l] = I[l]; a.Otot[l] = Otot[l]; a.row_off[l] = row_off[l]; a.cin[l] = cin[l]; a.flags[l] = flags[l];
+    a.aux[l] = 0; a.ncorr[l] = 0; a.gW[l] = nullptr; a.dsave[l] = nullptr; a.wb[l] = nullptr;
+  }
+  a.B = B; a.L = L;
+  return 0;
+}
+
+extern "C" int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float* stats, const float* const* W,
+                                     const float* const* s, const float* const* fw, const int* O, const int* I,
+                                     const int* Otot, const int* row_off, const int* cin, const int* flags,
+                                     const float* shift, int B, int L, void* stream) {
+  PrepAll a;
+  if (!wb || !dsave || !stats) return DGV2_EINVAL;
+  int rc = fill_common(a, W, s, fw, O, I, Otot, row_off, cin, flags, B, L);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  a.stats = stats; a.shift = shift;
+  int nstat = 0;
+  for (int l = 0; l < L; ++l) {
+    if (!wb[l] || !dsave[l]) return DGV2_EINVAL;
+    a.wb[l] = wb[l]; a.dsave[l] = dsave[l];
+    if (flags[l] & 1) {
+      a.aux[l] = (O[l] * I[l] + PB * 8 - 1) / (PB * 8);
+      nstat += a.aux[l] + B;
+    }
+    a.blk_end[l] = nstat;
+  }
+  if (nstat > 0) {
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * (size_t)L * (2 + 2 * B), st);
+    if (e != hipSuccess) return (int)e;
+    mod_stats_all_kernel<<<nstat, PB, 0, st>>>(a);
+  }
+  int nblk = 0;
+  for (int l = 0; l < L; ++l) {
+    nblk += O[l] * B;
+    a.blk_end[l] = nblk;
+  }
+  mod_prep_all_fwd_kernel<<<nblk, PB, 0, st>>>(a);
+  DGV2_RETURN_LAST();
+}
+
+// Backward of the above.  G[l] fp32 [B, Otot[l], I[l]] = dL/d(prepared weights) (layers sharing a buffer pass the
+// same pointer); out[l] = one fp32 allocation [gW (O*I) | gs (B*I) | corr (ncorr[l] >= 1 scratch)], all inside
+// `flat` [flat_elems], which is cleared here with ONE launch.  stats / dsave: as left by the forward.
+extern "C" int dgv2_mod_prep_all_bwd(float* flat, int64_t flat_elems, float* const* out, const int* ncorr,
+                                     const float* const* G, const float* const* W, const float* const* s,
+                                     const float* stats, float* const* dsave, const float* const* fw, const int* O,
+                                     const int* I, const int* Otot, const int* row_off, const int* cin,
+                                     const int* flags, const float* shift, int B, int L, void* stream) {
+  PrepAll a;
+  if (!flat || flat_elems < 1 || !out || !ncorr || !G || !stats || !dsave) return DGV2_EINVAL;
+  int rc = fill_common(a, W, s, fw, O, I, Otot, row_off, cin, flags, B, L);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  a.stats = const_cast<float*>(stats); a.shift = shift;
+  int cls[MPA_MAX], nb[MPA_MAX];
+  for (int l = 0; l < L; ++l) {
+    if (!out[l] || !G[l] || !dsave[l] || ncorr[l] < 1) return DGV2_EINVAL;
+    if (out[l] < flat || out[l] + (size_t)O[l] * I[l] + (size_t)B * I[l] + ncorr[l] > flat + flat_elems) return DGV2_EINVAL;
+    a.gW[l] = out[l]; a.wb[l] = const_cast<float*>(G[l]); a.dsave[l] = dsave[l];
+    // group size: as large as keeps >= ~1024 blocks in flight (same rule as dgv2_mod_prep_bwd)
+    const int64_t pairs = (int64_t)O[l] * B;
+    cls[l] = pairs >= 16 * 1024 ? 4 : (pairs >= 4 * 1024 ? 2 : 1);
+    nb[l] = ((O[l] + cls[l] - 1) / cls[l]) * ((B + cls[l] - 1) / cls[l]);
+    a.ncorr[l] = ncorr[l] >= nb[l] ? nb[l] : 1;
+  }
+  hipError_t e = hipMemsetAsync(flat, 0, sizeof(float) * (size_t)flat_elems, st);
+  if (e != hipSuccess) return (int)e;
+  for (int c = 4; c >= 1; c >>= 1) {
+    int n = 0;
+    for (int l = 0; l < L; ++l) {
+      if (cls[l] == c) n += nb[l];
+      a.blk_end[l] = n;
+      a.aux[l] = a.ncorr[l];
+    }
+    if (n == 0) continue;
+    if (c == 4) mod_prep_all_bwd_kernel<4, 4><<<n, PB, 0, st>>>(a);
+    else if (c == 2) mod_prep_all_bwd_kernel<2, 2><<<n, PB, 0, st>>>(a);
+    else mod_prep_all_bwd_kernel<1, 1><<<n, PB, 0, st>>>(a);
+  }
+  int n = 0;
+  for (int l = 0; l < L; ++l) {
+    if (flags[l] & 1) n += B;
+    a.blk_end[l] = n;
+  }
+  if (n > 0) mod_prep_all_s_fix_kernel<<<n, PB, 0, st>>>(a);
+  n = 0;
+  for (int l = 0; l < L; ++l) {
+    a.aux[l] = grid_for((int64_t)O[l] * I[l], 256, 64);
+    n += a.aux[l];
+    a.blk_end[l] = n;
+  }
+  mod_prep_all_w_fix_kernel<<<n, 256, 0, st>>>(a);
   DGV2_RETURN_LAST();
 }

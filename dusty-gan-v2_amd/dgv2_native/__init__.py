@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -29,6 +29,8 @@ SIGNATURES = {
     "dgv2_fused_bias_act": [_c_ptr] * 4 + [_c_i64] * 3 + [_c_int, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_bias_grad": [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr],
     "dgv2_bias_act_bwd": [_c_ptr] * 4 + [_c_i64, _c_int, _c_f32, _c_f32, _c_ptr, _c_i64, _c_int, _c_ptr],
+    "dgv2_bias_act_bwd_rs": [_c_ptr] * 4 + [_c_i64, _c_int, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr],
+    "dgv2_scale_cast": [_c_ptr] * 3 + [_c_i64, _c_int, _c_int, _c_int, _c_ptr],
     "dgv2_upfirdn2d": [_c_ptr] * 3 + [_c_int] * 15 + [_c_ptr],
     "dgv2_resample": [_c_ptr] * 4 + [_c_int] * 19 + [_c_ptr],
     "dgv2_resample_tab": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr],
@@ -37,12 +39,12 @@ SIGNATURES = {
     "dgv2_bmm_nn": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr],
     "dgv2_bmm_tn": [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr],
     "dgv2_bmm_nn_cat": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr],
-    "dgv2_bmm_nn_cat_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr, _c_int, _c_ptr,
+    "dgv2_bmm_nn_cat_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr, _c_int, _c_ptr,
                            _c_ptr],
-    "dgv2_bmm_nn_sq": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr, _c_int,
+    "dgv2_bmm_nn_sq": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr, _c_int,
                        _c_ptr, _c_ptr],
     "dgv2_modconv_pe_fwd": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
-    "dgv2_modconv_pe_fwd_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
+    "dgv2_modconv_pe_fwd_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                                _c_ptr],
     "dgv2_resample_tab_sq": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr, _c_int, _c_ptr, _c_ptr],
     "dgv2_bmm_tn_cat": [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr],
@@ -51,7 +53,9 @@ SIGNATURES = {
     "dgv2_adam_step": [_c_ptr] * 5 + [_c_int, _c_ptr] + [_c_f32] * 4 + [_c_ptr],
     "dgv2_pack2d": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_unpack2d": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
-    "dgv2_ema_scalar": [_c_ptr] * 3 + [_c_int] + [_c_f32] * 3 + [_c_int, _c_ptr],
+    "dgv2_ema_scalar": [_c_ptr] * 3 + [_c_int] + [_c_f32] * 3 + [_c_int, _c_ptr, _c_int, _c_ptr],
+    "dgv2_mod_prep_all_fwd": [_c_ptr] * 12 + [_c_ptr, _c_int, _c_int, _c_ptr],
+    "dgv2_mod_prep_all_bwd": [_c_ptr, _c_i64] + [_c_ptr] * 14 + [_c_ptr, _c_int, _c_int, _c_ptr],
     "dgv2_mod_prep_fwd": [_c_ptr] * 8 + [_c_int] * 9 + [_c_ptr],
     "dgv2_mod_prep_bwd": [_c_ptr] * 11 + [_c_int] * 9 + [_c_ptr],
     "dgv2_sum_squares": [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_ptr],

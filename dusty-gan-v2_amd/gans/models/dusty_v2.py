@@ -18,6 +18,7 @@ precision, 0 = fp32, n = last n generator blocks / first n discriminator layers)
 precision here is bfloat16 storage with fp32 MFMA accumulation (the reference autocasts to fp16).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -47,6 +48,9 @@ class MappingNetwork(nn.Sequential):
         super().__init__(*layers)
 
 
+_BATCHED_PREP = os.environ.get("DGV2_NO_BATCHED_PREP") is None
+
+
 class Head(nn.Module):
     """reference: dusty_v2.py:32-57.  All heads share the input, so they run as ONE GEMM whose
     per-sample weight rows are the stacked head weights; output stays fp32 (dusty_v2.py:174-178)."""
@@ -66,8 +70,16 @@ class Head(nn.Module):
         squares of x when its producer already took them."""
         if sumsq is None and self.training:
             sumsq = native.sum_squares(x)
-        mods = [head.prep_args(style, sumsq, x.numel()) for head in self.heads.values()]
-        bias = torch.cat([head.bias.reshape(-1) for head in self.heads.values()])
+        heads = list(self.heads.values())
+        bias = torch.cat([head.bias.reshape(-1) for head in heads])
+        if heads[0]._prep is not None:   # weights of the whole pass prepared up front (SynthesisNetwork._batched_weights)
+            handle, wb, cvec = heads[0]._prep
+            off = 0
+            for head in heads:
+                head.update_ema(sumsq, x.numel(), 0.0, cvec[off:off + head.out_ch])
+                off += head.out_ch
+            return native.mod_gemm_layer(x, None, handle, wb, cvec, bias=bias, act=False, out_dtype=torch.float32)
+        mods = [head.prep_args(style, sumsq, x.numel()) for head in heads]
         return native.mod_layer(x, None, mods, bias=bias, act=False, out_dtype=torch.float32)
 
     def forward(self, x, style):
@@ -149,6 +161,11 @@ class SynthesisBlock(nn.Module):
                 sumsq = native.sum_squares(hup)
         act = self.bias_act1
         want = want_sq and (self.head.training if self.is_first else self.conv2.training)
+        if conv._prep is not None:
+            handle, wb, cvec = conv._prep
+            conv.update_ema(sumsq, B * H * W * (cin + self.pe.out_ch), pe_sq, cvec)
+            return native.mod_gemm_layer(hup, pe0, handle, wb, cvec, bias=act.bias, act=True, alpha=act.negative_slope,
+                                         scale=act.scale, want_sq=want)
         if self.pe.out_ch == 512 and conv.in_ch <= 1024:
             # weight preparation (+ rotation), contraction, bias and lrelu as one autograd node
             mods = [conv.prep_args(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch), sumsq_add=pe_sq)]
@@ -187,8 +204,14 @@ class SynthesisBlock(nn.Module):
         if not self.is_first:
             a2 = self.bias_act2
             sumsq = (sq_h if sq_h is not None else native.sum_squares(h)) if self.conv2.training else None
-            h = native.mod_layer(h, None, [self.conv2.prep_args(ws[1], sumsq, h.numel())], bias=a2.bias, act=True,
-                                 alpha=a2.negative_slope, scale=a2.scale, want_sq=self.head.training)
+            if self.conv2._prep is not None:
+                handle, wb, cvec = self.conv2._prep
+                self.conv2.update_ema(sumsq, h.numel(), 0.0, cvec)
+                h = native.mod_gemm_layer(h, None, handle, wb, cvec, bias=a2.bias, act=True, alpha=a2.negative_slope,
+                                          scale=a2.scale, want_sq=self.head.training)
+            else:
+                h = native.mod_layer(h, None, [self.conv2.prep_args(ws[1], sumsq, h.numel())], bias=a2.bias,
+                                     act=True, alpha=a2.negative_slope, scale=a2.scale, want_sq=self.head.training)
             sq_h = None
             if isinstance(h, tuple):
                 h, sq_h = h
@@ -278,6 +301,8 @@ class SynthesisNetwork(nn.Module):
                 pyramid.insert(0, (a, None))
         h, skip, i = None, None, 0
         cached = self._batched_styles(ws) if (ws.is_cuda and angle.shape[0] == 1) else []
+        if cached and _BATCHED_PREP:
+            self._batched_weights(cached, shift)
         try:
             for layer, (a, s) in zip(self.layers, pyramid):
                 h, skip = layer.forward_cl(h, skip, (ws[:, i], ws[:, i + 1], ws[:, min(i + 2, N - 1)]), a, s, B)
@@ -285,7 +310,47 @@ class SynthesisNetwork(nn.Module):
         finally:
             for m in cached:
                 m._style_cache = None
+                m._prep = None
         return skip, shift
+
+    def _batched_weights(self, mods, shift):
+        """Per-sample weights of ALL modulated layers of this pass in one launch (native.mod_prep_all): every module
+        finds (handle, weights, its rows of the group's output factor) in `_prep`.  mods: the modules
+        _batched_styles filled, in network order (conv1, [conv2], heads... per block)."""
+        if len(mods) > 32 or any((not m.ema) or m.ema_var.dtype != torch.float32 or not m.ema_var.is_cuda
+                                 or m.in_ch > 1024 for m in mods):
+            return
+        layers, groups = [], []
+        for blk in self.layers:
+            dt = blk.compute_dtype
+            fw = blk.pe.freqs2[:, 1].contiguous() if shift is not None else None
+            convs = [(blk.conv1, blk.conv1.in_ch - blk.pe.out_ch, fw)]
+            if not blk.is_first:
+                convs.append((blk.conv2, 0, None))
+            for conv, cin, f in convs:
+                groups.append(dict(Otot=conv.out_ch, I=conv.in_ch, dtype=dt))
+                layers.append(dict(W=conv.weight.reshape(conv.out_ch, conv.in_ch), s=conv._style_cache, O=conv.out_ch,
+                                   I=conv.in_ch, demod=bool(conv.demod), cin=cin, fw=f, group=len(groups) - 1,
+                                   row_off=0, mod=conv))
+            heads = list(blk.head.heads.values())
+            groups.append(dict(Otot=sum(h.out_ch for h in heads), I=heads[0].in_ch, dtype=dt))
+            off = 0
+            for h in heads:
+                layers.append(dict(W=h.weight.reshape(h.out_ch, h.in_ch), s=h._style_cache, O=h.out_ch, I=h.in_ch,
+                                   demod=bool(h.demod), cin=0, fw=None, group=len(groups) - 1, row_off=off, mod=h))
+                off += h.out_ch
+        modules = [m.pop("mod") for m in layers]
+        prepared = native.mod_prep_all(layers, groups, shift)
+        cflat = torch.empty(sum(g["Otot"] for g in groups), device=shift.device if shift is not None
+                            else layers[0]["W"].device, dtype=torch.float32)
+        coff = [0]
+        for g in groups:
+            coff.append(coff[-1] + g["Otot"])
+        for m, mod in zip(layers, modules):
+            k = m["group"]
+            handle, wb = prepared[k]
+            # single-layer groups see their own rows; the heads of a block share the group's vector
+            mod._prep = (handle, wb, cflat[coff[k]:coff[k + 1]])
 
     def _batched_styles(self, ws):
         """All style affines (EqualLR Linear of every ModConv2d on the fused path) as one batched GEMM; each

@@ -406,13 +406,14 @@ def fused_adam_step(opt):
                float(b2), float(group["eps"]), N.stream())
 
 
-def ema_update(ema, sumsq, add, count, weight, update=True):
+def ema_update(ema, sumsq, add, count, weight, update=True, cvec=None):
     """ModConv2d's input-magnitude EMA (style.py:98-103) in one scalar launch: updates the 0-dim buffer `ema`
-    in place with lerp(ema, (sumsq + add) / count, weight) and returns a fresh [1] snapshot of its value."""
-    snap = torch.empty(1, device=ema.device, dtype=torch.float32)
+    in place with lerp(ema, (sumsq + add) / count, weight) and returns a fresh [1] snapshot of its value.
+    cvec (fp32 [n], optional): filled with the layer's output factor 1/(sqrt(ema)+1e-8) instead (returns cvec)."""
+    snap = None if cvec is not None else torch.empty(1, device=ema.device, dtype=torch.float32)
     N.call("dgv2_ema_scalar", N.ptr(ema), N.ptr(snap), N.ptr(sumsq), 0 if sumsq is None else sumsq.numel(), float(add),
-           1.0 / float(count), float(weight), int(update), N.stream())
-    return snap
+           1.0 / float(count), float(weight), int(update), N.ptr(cvec), 0 if cvec is None else cvec.numel(), N.stream())
+    return snap if cvec is None else cvec
 
 
 def sum_squares(x, C=None):
@@ -468,7 +469,7 @@ def up_cat_pe(h, spec, angle, shift, freqs2, phase, dtype, B):
 # batched channel GEMM = contraction of the modulated 1x1 conv
 # (reference: grouped F.conv2d in ModConv2d.forward, gans/models/ops/style.py:105-118)
 # ---------------------------------------------------------------------------------------
-def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=None):
+def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=None, row_scale=None):
     """x3 [B,P,I]; w3 [Bw,O,I] (Bw = B or 1) same dtype -> [B,P,O]; optional fused
     bias (fp32 [O]) + leaky-ReLU epilogue.  sq = _sq_args(): sum-of-squares partials where the kernel has them."""
     B, P, I = x3.shape
@@ -478,17 +479,18 @@ def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=No
     if (_PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and P >= 4096
             and (I, O) in ((64, 32), (32, 64), (128, 64), (64, 128), (32, 32), (64, 64))):
         # streaming shapes of the two top levels: sample-walking kernel without a PE part
-        if sq is not None:
-            N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(bias), act,
-                   alpha, scale, _dt(x3), N.ptr(sq[0]), _SQ_CAP, _ct.addressof(sq[1]), N.stream())
+        if sq is not None or row_scale is not None:
+            N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(row_scale),
+                   N.ptr(bias), act, alpha, scale, _dt(x3), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0,
+                   _ct.addressof(sq[1]) if sq else None, N.stream())
             return y
         N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(bias), act, alpha,
                scale, _dt(x3), N.stream())
         return y
-    if sq is not None:
+    if sq is not None or row_scale is not None:
         N.call("dgv2_bmm_nn_sq", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
-               N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.ptr(sq[0]), _SQ_CAP, _ct.addressof(sq[1]),
-               N.stream())
+               N.ptr(row_scale), N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.ptr(sq[0]) if sq else None,
+               _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
         return y
     N.call("dgv2_bmm_nn", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
            N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.stream())
@@ -1272,12 +1274,13 @@ class _ModLayer(Function):
             if _PE_FWD and dt == torch.bfloat16 and (Ka, xs.shape[3], Otot) == (64, 512, 32):
                 # top pyramid levels: pixel-tile blocks walking the samples, PE fragments in registers
                 N.call("dgv2_modconv_pe_fwd_sq", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3],
-                       Otot, N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), N.ptr(sq[0]) if sq else None,
+                       Otot, None, N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), N.ptr(sq[0]) if sq else None,
                        _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
             else:
                 N.call("dgv2_bmm_nn_cat_sq", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3], Otot,
-                       N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs), N.ptr(sq[0]) if sq else None,
-                       _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
+                       None, N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs),
+                       N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None,
+                       N.stream())
         else:
             xa = xa.contiguous()
             out = _bmm_nn_raw(xa.reshape(B, P, I), wb, odt, bias32, act, cfg["alpha"], cfg["scale"], sq=sq).reshape(
@@ -1374,3 +1377,217 @@ def mod_layer(xa, xs, mods, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0)
     for W, s, ev, _ in mods:
         flat += [W, s, ev]
     return _ModLayer.apply(cfg, xa, xs, bias, shift, fw, *flat)
+
+
+# ---------------------------------------------------------------------------------------
+# Batched form of the above for a whole generator pass: ALL layers' weights prepared by one launch each way
+# (dgv2_mod_prep_all_fwd / _bwd), the per-layer work reduced to the contraction.  The input-magnitude factor
+# c = 1/(sqrt(ema_var)+1e-8) depends on the running pass' activations, so it stays out of the prepared weights and
+# enters as the GEMM's per-output-channel row_scale: y = act(c[o] * (x . wb[o]) + bias[o]).
+# ---------------------------------------------------------------------------------------
+class _ModPrepAll(Function):
+    @staticmethod
+    def forward(ctx, meta, shift, *flat):
+        """meta: dict(layers=[dict(O, I, demod, cin, fw (fp32 [256] or None), group, row_off)],
+        groups=[dict(Otot, I, dtype)]); flat = (W_0, s_0, W_1, s_1, ...): W fp32 [O,I], s fp32 [B,I].
+        Returns one fp32 HANDLE [B,Otot,I] per group (zero storage; carries the autograd edge: its gradient is
+        dL/d(prepared weights)) followed by the prepared weights themselves (compute dtype, non-differentiable)."""
+        L = len(meta["layers"])
+        Ws = [flat[2 * l].detach().contiguous() for l in range(L)]
+        Ss = [flat[2 * l + 1].detach().float().contiguous() for l in range(L)]
+        B = Ss[0].shape[0]
+        dev = Ws[0].device
+        wbs = [torch.empty((B, g["Otot"], g["I"]), device=dev, dtype=g["dtype"]) for g in meta["groups"]]
+        lay = meta["layers"]
+        dflat = torch.empty(sum(B * m["O"] for m in lay), device=dev, dtype=torch.float32)
+        dsaves, off = [], 0
+        for m in lay:
+            dsaves.append(dflat[off:off + B * m["O"]])
+            off += B * m["O"]
+        stats = torch.empty(L * (2 + 2 * B), device=dev, dtype=torch.float32)
+        fws = [m["fw"] for m in lay]
+        rot = shift is not None
+        flags = [(1 if m["demod"] else 0) | (2 if (rot and m["fw"] is not None) else 0)
+                 | (4 if meta["groups"][m["group"]]["dtype"] == torch.bfloat16 else 0) for m in lay]
+        ints = dict(O=_int_array([m["O"] for m in lay]), I=_int_array([m["I"] for m in lay]),
+                    Otot=_int_array([meta["groups"][m["group"]]["Otot"] for m in lay]),
+                    row_off=_int_array([m["row_off"] for m in lay]), cin=_int_array([m["cin"] for m in lay]),
+                    flags=_int_array(flags))
+        N.check(*Ws, *Ss, shift, *[f for f in fws if f is not None])
+        N.call("dgv2_mod_prep_all_fwd", _ptr_array([wbs[m["group"]] for m in lay]), _ptr_array(dsaves), N.ptr(stats),
+               _ptr_array(Ws), _ptr_array(Ss), _ptr_array(fws), ints["O"], ints["I"], ints["Otot"], ints["row_off"],
+               ints["cin"], ints["flags"], N.ptr(shift) if rot else None, B, L, N.stream())
+        ctx.meta, ctx.ints, ctx.B, ctx.rot = meta, ints, B, rot
+        ctx.save_for_backward(shift, stats, dflat, *Ws, *Ss)
+        handles = [torch.empty(1, device=dev, dtype=torch.float32).expand(B, g["Otot"], g["I"]) for g in meta["groups"]]
+        ctx.mark_non_differentiable(*wbs)
+        return (*handles, *wbs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        meta, ints, B = ctx.meta, ctx.ints, ctx.B
+        lay, groups = meta["layers"], meta["groups"]
+        L, ng = len(lay), len(groups)
+        sv = ctx.saved_tensors
+        shift, stats, dflat = sv[:3]
+        Ws, Ss = sv[3:3 + L], sv[3 + L:3 + 2 * L]
+        dev = stats.device
+        Gs = []
+        for k, g in enumerate(groups):   # a group the loss does not reach contributes zeros
+            gk = grads[k]
+            Gs.append(torch.zeros((B, g["Otot"], g["I"]), device=dev) if gk is None else gk.float().contiguous())
+        sizes, ncorr = [], []
+        for m in lay:
+            nc = min(m["O"] * B, 8192)
+            ncorr.append(nc)
+            sizes.append(m["O"] * m["I"] + B * m["I"] + nc)
+        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        outs, off = [], 0
+        for n in sizes:
+            outs.append(flat[off:off + n])
+            off += n
+        dsaves, off = [], 0
+        for m in lay:
+            dsaves.append(dflat[off:off + B * m["O"]])
+            off += B * m["O"]
+        N.call("dgv2_mod_prep_all_bwd", N.ptr(flat), flat.numel(), _ptr_array(outs), _int_array(ncorr),
+               _ptr_array([Gs[m["group"]] for m in lay]), _ptr_array(list(Ws)), _ptr_array(list(Ss)), N.ptr(stats),
+               _ptr_array(dsaves), _ptr_array([m["fw"] for m in lay]), ints["O"], ints["I"], ints["Otot"],
+               ints["row_off"], ints["cin"], ints["flags"], N.ptr(shift) if ctx.rot else None, B, L, N.stream())
+        res = []
+        for m, o in zip(lay, outs):
+            OI, BI = m["O"] * m["I"], B * m["I"]
+            res += [o[:OI].view(m["O"], m["I"]), o[OI:OI + BI].view(B, m["I"])]
+        return (None, None, *res)
+
+
+def mod_prep_all(layers, groups, shift):
+    """layers: list of dict(W, s, O, I, demod, cin, fw, group, row_off); groups: list of dict(Otot, I, dtype).
+    -> [(handle, prepared weights)] per group (see _ModPrepAll)."""
+    meta = dict(layers=[{k: v for k, v in m.items() if k not in ("W", "s")} for m in layers], groups=groups)
+    flat = []
+    for m in layers:
+        flat += [m["W"], m["s"]]
+    out = _ModPrepAll.apply(meta, shift, *flat)
+    ng = len(groups)
+    return list(zip(out[:ng], out[ng:]))
+
+
+class _ModGemmPrepared(Function):
+    """y = act(c[o] * ([xa | xs] . wb[b,o,:]) + bias[o]) with weights prepared by mod_prep_all; `handle` carries
+    the gradient dL/dwb back to the batched preparation, c (fp32 [Otot], no gradient) is the layers' output factor."""
+
+    @staticmethod
+    def forward(ctx, cfg, xa, xs, bias, handle, wb, cvec):
+        ref = xa if xa is not None else xs
+        dt = ref.dtype
+        B, Otot, I = wb.shape
+        H, W_ = ref.shape[1:3]
+        P = H * W_
+        dev = ref.device
+        act = 3 if cfg["act"] else 0
+        bias32 = None if bias is None else bias.detach().float().contiguous()
+        odt = cfg["out_dtype"]
+        sq = _sq_args(dev) if (cfg["want_sq"] and _FUSED_SQ) else None
+        N.check(xa, xs, wb, bias32, cvec)
+        if xs is not None:
+            xs = xs.contiguous()
+            xa = None if xa is None else xa.contiguous()
+            Ka = 0 if xa is None else xa.shape[3]
+            out = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
+            tail = (N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
+            if _PE_FWD and dt == torch.bfloat16 and (Ka, xs.shape[3], Otot) == (64, 512, 32):
+                N.call("dgv2_modconv_pe_fwd_sq", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3],
+                       Otot, N.ptr(cvec), N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), *tail)
+            else:
+                N.call("dgv2_bmm_nn_cat_sq", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3], Otot,
+                       N.ptr(cvec), N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs), *tail)
+        else:
+            xa = xa.contiguous()
+            out = _bmm_nn_raw(xa.reshape(B, P, I), wb, odt, bias32, act, cfg["alpha"], cfg["scale"], sq=sq,
+                              row_scale=cvec).reshape(B, H, W_, Otot)
+        ctx.cfg = dict(cfg, has_bias=bias is not None)
+        ctx.save_for_backward(xa, xs, wb, out if cfg["act"] else None, cvec)
+        if cfg["want_sq"]:
+            part = sq[0][:sq[1].value] if (sq is not None and sq[1].value > 0) else sum_squares(out)
+            ctx.mark_non_differentiable(part)
+            return out, part
+        return out
+
+    @staticmethod
+    def backward(ctx, gy, _=None):
+        cfg = ctx.cfg
+        xa, xs, wb, out, cvec = ctx.saved_tensors
+        B, Otot, I = wb.shape
+        dt = wb.dtype
+        gy = gy.contiguous()
+        H, W_ = gy.shape[1:3]
+        P = H * W_
+        dev = gy.device
+        # gradient w.r.t. the accumulator (c[o] applied; the bias gradient sums the unscaled one)
+        gb = None
+        vn = 8 if gy.dtype == torch.bfloat16 else 4
+        rows = gy.numel() // Otot
+        gpre = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
+        if cfg["act"] and gy.dtype == dt and Otot % vn == 0 and 256 % (Otot // vn) == 0:
+            gb = torch.empty(Otot, device=dev, dtype=torch.float32)
+            scratch = torch.empty(2048 * Otot, device=dev, dtype=torch.float32) if rows >= 65536 else None
+            N.call("dgv2_bias_act_bwd_rs", N.ptr(gpre), N.ptr(gb), N.ptr(gy), N.ptr(out), rows, Otot, cfg["alpha"],
+                   cfg["scale"], N.ptr(cvec), N.ptr(scratch), 0 if scratch is None else scratch.numel(), _dt(gy),
+                   N.stream())
+            if not cfg["has_bias"]:
+                gb = None
+        else:
+            g0 = gy
+            if cfg["act"]:
+                g0 = _bias_act_raw(gy, None, out, 1, cfg["alpha"], cfg["scale"], 1, Otot)
+            if cfg["has_bias"]:
+                gb = torch.empty(Otot, device=dev, dtype=torch.float32)
+                N.call("dgv2_bias_grad", N.ptr(gb), N.ptr(g0), g0.numel(), 1, Otot, _dt(g0), N.stream())
+            N.call("dgv2_scale_cast", N.ptr(gpre), N.ptr(g0), N.ptr(cvec), g0.numel(), Otot, _dt(g0), _dt(gpre),
+                   N.stream())
+        g3 = gpre.reshape(B, P, Otot)
+        Ka = 0 if xa is None else xa.shape[3]
+        gxa = None
+        if xa is not None and ctx.needs_input_grad[1]:
+            wt = wb[:, :, :Ka].transpose(1, 2).contiguous()
+            gxa = _bmm_nn_raw(g3, wt, xa.dtype).reshape(xa.shape)
+        gwb = None
+        if ctx.needs_input_grad[4]:
+            gwb = _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt)
+        return None, gxa, None, gb, gwb, None, None
+
+
+def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
+    """gwb fp32 [B,Otot,I] = per-sample g3^T [xa | xs] (the engine choice of _ModLayer.backward)."""
+    P = H * W_
+    Ka = 0 if xa is None else xa.shape[3]
+    if xs is not None and _LIB_WGRAD and dt == torch.bfloat16 and P >= 2048:
+        gT = g3.transpose(1, 2)
+        parts = []
+        if xa is not None and _TN_STREAM and Ka % 8 == 0 and Otot % 8 == 0:
+            parts.append(_bmm_tn_stream(g3, xa, B, H, W_, Ka, Otot))
+        elif xa is not None:
+            parts.append(torch.bmm(gT, xa.reshape(B, P, Ka), out_dtype=torch.float32))
+        parts.append(torch.bmm(gT, xs.reshape(1, P, -1).expand(B, P, xs.shape[3]), out_dtype=torch.float32))
+        return torch.cat(parts, dim=2) if len(parts) > 1 else parts[0]
+    if xs is not None:
+        gwb = torch.empty((B, Otot, I), device=g3.device, dtype=torch.float32)
+        N.call("dgv2_bmm_tn_cat", N.ptr(gwb), N.ptr(g3), N.ptr(xa), N.ptr(xs), B, P, Ka, xs.shape[3], Otot, _dt(xs),
+               N.stream())
+        return gwb
+    if _TN_STREAM and dt == torch.bfloat16 and P >= 2048 and I % 8 == 0 and Otot % 8 == 0:
+        return _bmm_tn_stream(g3, xa, B, H, W_, I, Otot)
+    gwb = torch.empty((B, Otot, I), device=g3.device, dtype=torch.float32)
+    N.call("dgv2_bmm_tn", N.ptr(gwb), N.ptr(g3), N.ptr(xa.reshape(B, P, I)), B, P, I, Otot, Otot, I, _dt(xa), N.stream())
+    return gwb
+
+
+def mod_gemm_layer(xa, xs, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=None,
+                   want_sq=False):
+    """The contraction of a modulated layer whose weights came from mod_prep_all (handle, wb) and whose
+    input-magnitude factor is cvec fp32 [Otot] (native.ema_update(..., cvec=...))."""
+    ref = xa if xa is not None else xs
+    cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0,
+               out_dtype=ref.dtype if out_dtype is None else out_dtype, want_sq=bool(want_sq))
+    return _ModGemmPrepared.apply(cfg, xa, xs, bias, handle, wb, cvec)

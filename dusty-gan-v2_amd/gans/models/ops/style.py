@@ -32,6 +32,7 @@ class ModConv2d(nn.Module):
         self.ema, self.ema_decay = ema, ema_decay
         self.register_buffer("ema_var", torch.tensor(1.0))
         self._style_cache = None   # set by SynthesisNetwork when all style affines are computed in one batched GEMM
+        self._prep = None          # (handle, prepared weights, c slice) when all layers are prepared in one launch
 
     def sample_weights(self, w_latent, sumsq=None, count=None):
         """Per-sample weights [B,O,I] (fp32).  `sumsq`/`count`: sum of squares and element count of
@@ -67,6 +68,13 @@ class ModConv2d(nn.Module):
         # reshape, not [0, :, :, 0, 0]: the backward of integer indexing allocates and zero-fills a full-size tensor
         # per select (three fills + three copies per layer and pass); a view's backward is free
         return (self.weight.reshape(self.weight.shape[1], self.weight.shape[2]), style, ev, self.demod)
+
+    def update_ema(self, sumsq, count, sumsq_add, cvec):
+        """Input-magnitude EMA update (style.py:98-103) for the batched-preparation path: one scalar launch that
+        also writes this layer's output factor 1/(sqrt(ema_var)+1e-8) into `cvec` (its rows of the GEMM's scale)."""
+        upd = self.ema and self.training and (sumsq is not None or sumsq_add != 0.0)
+        with torch.no_grad():
+            native.ema_update(self.ema_var, sumsq, sumsq_add, count if upd else 1, 1 - self.ema_decay, upd, cvec=cvec)
 
     def forward_cl(self, x, w_latent, out_dtype=None, act=None):
         """act: a FusedLeakyReLU module whose bias + leaky-ReLU is fused into the GEMM epilogue."""

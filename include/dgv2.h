@@ -62,6 +62,14 @@ int dgv2_bias_grad(float* gb, const void* x, int64_t size_x, int64_t step_b, int
 int dgv2_bias_act_bwd(void* gx, float* gb, const void* gy, const void* ref, int64_t rows, int C,
                       float alpha, float scale, float* scratch, int64_t scratch_elems, int dtype,
                       void* stream);
+/* ... with an optional per-channel factor row_scale fp32 [C] on the STORED gradient only (gb sums the unscaled
+ * one): backward of y = act(acc * row_scale[c] + b[c]) with respect to acc. */
+int dgv2_bias_act_bwd_rs(void* gx, float* gb, const void* gy, const void* ref, int64_t rows, int C,
+                         float alpha, float scale, const float* row_scale, float* scratch,
+                         int64_t scratch_elems, int dtype, void* stream);
+/* y[i] = (ydtype)(x[i] * row_scale[i % C]): the same for activation-free layers (the output heads). */
+int dgv2_scale_cast(void* y, const void* x, const float* row_scale, int64_t n, int C, int xdtype, int ydtype,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------
  * upfirdn2d
@@ -164,12 +172,14 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
                     int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
                     void* stream);
 /* dgv2_bmm_nn / dgv2_bmm_nn_cat that also leave per-block partial sums of squares of the stored outputs
- * (contract as in dgv2_resample_tab_sq). */
+ * (contract as in dgv2_resample_tab_sq), with an optional per-output-channel factor ahead of the bias:
+ * y = act(acc * row_scale[o] + bias[o]) (row_scale fp32 [O] or NULL) -- the input-magnitude factor of
+ * ModConv2d (style.py:98-103) when the weights were prepared by dgv2_mod_prep_all_fwd. */
 int dgv2_bmm_nn_sq(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
-                   int64_t wstride, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
+                   int64_t wstride, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
                    float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 int dgv2_bmm_nn_cat_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
-                       int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
+                       int O, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
                        float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, int B, int P, int Ka, int Ks,
                     int O, int dtype, void* stream);
@@ -183,7 +193,7 @@ int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, 
                         int O, const float* bias, int act, float alpha, float scale, int dtype, void* stream);
 /* ... with the per-block sum-of-squares partials of the stored outputs (contract as in dgv2_resample_tab_sq). */
 int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
-                           int O, const float* bias, int act, float alpha, float scale, int dtype, float* sumsq,
+                           int O, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype, float* sumsq,
                            int sumsq_cap, int* sumsq_used, void* stream);
 
 /* Per-sample weights of the modulated conv, written directly as the GEMM operand, and the exact
@@ -214,9 +224,11 @@ int dgv2_unpack2d(float* const* dst, const float* packed, const int* rows, const
 
 /* Input-magnitude EMA of ModConv2d (style.py:98-103) as one scalar launch:
  * if update: ema <- lerp(ema, (sum(sumsq[0..nsum)) + add) * inv_count, weight); snapshot[0] <- ema[0].
- * sumsq (NULL allowed): the per-block partial sums dgv2_sum_squares leaves (nsum = 512). */
+ * sumsq (NULL allowed): the per-block partial sums dgv2_sum_squares leaves (nsum = 512).
+ * cvec (NULL allowed): cvec[0..ncvec) <- 1/(sqrt(ema)+1e-8), the factor the layer applies to its output rows
+ * (row_scale of the GEMM entries below); snapshot may then be NULL. */
 int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, int nsum, float add, float inv_count,
-                    float weight, int update, void* stream);
+                    float weight, int update, float* cvec, int ncvec, void* stream);
 int dgv2_mod_prep_fwd(void* wb, float* dsave, float* stats, const float* W, const float* s,
                       const float* ema_var, const float* shift, const float* fw, int B, int O, int I,
                       int Otot, int row_off, int demod, int cin, int F, int wb_dtype, void* stream);
@@ -224,6 +236,25 @@ int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float* G, const f
                       const float* stats, const float* dsave, const float* ema_var, const float* shift,
                       const float* fw, int B, int O, int I, int Otot, int row_off, int demod, int cin,
                       int F, int corr_elems, void* stream);
+
+/* All L <= 32 modulated layers of one generator pass prepared in one launch each way (the per-layer entries
+ * above cost four launches per layer and pass).  Host arrays of length L: W[l] fp32 [O,I], s[l] fp32 [B,I],
+ * fw[l] fp32 [256] (layers with flags & 2), wb[l] -> [B, Otot[l], I[l]] GEMM operand (bf16 if flags & 4 else
+ * fp32; layers sharing a GEMM pass the same buffer and different row_off), dsave[l] fp32 [B,O]; stats fp32
+ * [L, 2+2B].  flags: 1 demodulate, 2 rotate the PE columns [cin, cin+512) by shift[b] (shift NULL: none),
+ * 4 bf16 operand.  These weights do NOT contain 1/(sqrt(ema_var)+1e-8): that factor is the GEMM's row_scale
+ * (dgv2_*_sq), its gradient side dgv2_bias_act_bwd_rs / dgv2_scale_cast; so G below is dL/d(these weights).
+ * bwd: out[l] = [gW (O*I) | gs (B*I) | corr scratch (ncorr[l] >= 1)] fp32, all inside flat[flat_elems] which
+ * is cleared here once.  replaces: ModConv2d.forward weight path, gans/models/ops/style.py:72-103. */
+int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float* stats, const float* const* W,
+                          const float* const* s, const float* const* fw, const int* O, const int* I,
+                          const int* Otot, const int* row_off, const int* cin, const int* flags,
+                          const float* shift, int B, int L, void* stream);
+int dgv2_mod_prep_all_bwd(float* flat, int64_t flat_elems, float* const* out, const int* ncorr,
+                          const float* const* G, const float* const* W, const float* const* s,
+                          const float* stats, float* const* dsave, const float* const* fw, const int* O,
+                          const int* I, const int* Otot, const int* row_off, const int* cin,
+                          const int* flags, const float* shift, int B, int L, void* stream);
 
 /* Sum of squares of the first C channels of x [N, ld] into acc[0] (fp32, ACCUMULATES).
  * replaces: x.pow(2).mean() in ModConv2d.forward (style.py:100-101). */

@@ -261,8 +261,10 @@ def test_producers_leave_sum_of_squares_partials(nat, g_ops):
         y1 = torch.empty_like(y0)
         buf = torch.full((8192,), float("nan"), device=DEV)
         used = ctypes.c_int(-1)
-        args = (N.ptr(xa), N.ptr(xs) if Ks else None, N.ptr(w), B, P, Ka, Ks, O, N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16)
-        N.call("dgv2_modconv_pe_fwd", N.ptr(y0), *args, N.stream())
+        head = (N.ptr(xa), N.ptr(xs) if Ks else None, N.ptr(w), B, P, Ka, Ks, O)
+        tail = (N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16)
+        args = (*head, None, *tail)   # row_scale = NULL
+        N.call("dgv2_modconv_pe_fwd", N.ptr(y0), *head, *tail, N.stream())
         N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y1), *args, N.ptr(buf), 8192, ctypes.addressof(used), N.stream())
         assert torch.equal(y0, y1) and used.value > 0
         want = y1.double().square().sum().item()
@@ -285,11 +287,11 @@ def test_producers_leave_sum_of_squares_partials(nat, g_ops):
         tail = (N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, N.BF16)
         if Ks:
             N.call("dgv2_bmm_nn_cat", N.ptr(y0), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks, O, *tail, N.stream())
-            N.call("dgv2_bmm_nn_cat_sq", N.ptr(y1), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks, O, *tail, N.ptr(buf), 8192,
-                   ctypes.addressof(used), N.stream())
+            N.call("dgv2_bmm_nn_cat_sq", N.ptr(y1), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks, O, None, *tail, N.ptr(buf),
+                   8192, ctypes.addressof(used), N.stream())
         else:
             N.call("dgv2_bmm_nn", N.ptr(y0), N.ptr(xa), N.ptr(w), B, P, Ka, O, Ka, O, O * Ka, *tail, N.stream())
-            N.call("dgv2_bmm_nn_sq", N.ptr(y1), N.ptr(xa), N.ptr(w), B, P, Ka, O, Ka, O, O * Ka, *tail, N.ptr(buf), 8192,
+            N.call("dgv2_bmm_nn_sq", N.ptr(y1), N.ptr(xa), N.ptr(w), B, P, Ka, O, Ka, O, O * Ka, None, *tail, N.ptr(buf), 8192,
                    ctypes.addressof(used), N.stream())
         assert torch.equal(y0, y1) and used.value > 0
         want = y1.double().square().sum().item()
