@@ -27,6 +27,7 @@ struct ModGeom {
   int B, O, I, Otot, row_off;
   int demod, cin, F;          // F = 0: no rotation
   float scale;                // 1/sqrt(I) (used when !demod)
+  const float* rot;           // optional table [B, 256] of (sin, cos)(shift[b] * fw[f]) (batched kernels), else nullptr
 };
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -67,68 +68,97 @@ __global__ __launch_bounds__(PB) void mod_stats_kernel(float* __restrict__ stats
   if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(stats + slot), __float_as_uint(m));
 }
 
+// NT threads own one row of <= 1024 columns (column i = lane + j*NT): NT = 256 = the whole block in the per-layer
+// kernels, NT = 64 = one wave in the batched kernels (four rows per block, reductions by shuffles, no barriers)
+template <int NT>
+__device__ __forceinline__ float row_sum(float v, float* red) {
+  if constexpr (NT == 64) return wave_sum(v);
+  else return block_sum(v, red);
+}
+
+// (sin, cos) of the azimuth rotation of frequency f for sample b: read from the layer's table when the launch
+// prepared one (batched kernels: g.rot), evaluated otherwise -- and then only for the PE columns (`need`).
+__device__ __forceinline__ void rot_factors(const ModGeom& g, const float* __restrict__ shift,
+                                            const float* __restrict__ fw, int b, int f, bool need, float& sd,
+                                            float& cd) {
+  sd = 0.f;
+  cd = 1.f;
+  f = min(max(f, 0), 255);
+  if (g.rot) {
+    const float2 sc = reinterpret_cast<const float2*>(g.rot)[b * 256 + f];
+    sd = sc.x;
+    cd = sc.y;
+  } else if (need) {
+    sincosf(shift[b] * fw[f], &sd, &cd);
+  }
+}
+
 // pre-rotation modulated weight m[j] (j-th owned column i = tid + j*PB) and t
+template <int NT>
 __device__ __forceinline__ void mod_row(const ModGeom& g, const float* __restrict__ W, const float* __restrict__ s,
-                                        const float* __restrict__ stats, int b, int o, float (&m)[MAXJ],
-                                        float (&t)[MAXJ], float (&wp)[MAXJ]) {
+                                        const float* __restrict__ stats, int b, int o, float (&m)[(1024 / NT)],
+                                        float (&t)[(1024 / NT)], float (&wp)[(1024 / NT)]) {
   const float inv_wmax = g.demod ? 1.f / stats[0] : g.scale;
   const float inv_smax = g.demod ? 1.f / stats[2 + 2 * b] : 1.f;
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const int i = threadIdx.x + j * PB;
-    m[j] = t[j] = wp[j] = 0.f;
-    if (i < g.I) {
-      wp[j] = W[(int64_t)o * g.I + i] * inv_wmax;
-      t[j] = s[(int64_t)b * g.I + i] * inv_smax + 1.f;
-      m[j] = wp[j] * t[j];
-    }
+  for (int j = 0; j < (1024 / NT); ++j) {
+    // straight-line code (clamped address + select): conditional blocks around register-array updates made the
+    // compiler shuffle the whole arrays at every merge point (2000+ moves, 240 VGPRs in the wave-per-row kernels)
+    const int i = (threadIdx.x & (NT - 1)) + j * NT;
+    const int ic = min(i, g.I - 1);
+    const bool in = i < g.I;
+    wp[j] = in ? W[(int64_t)o * g.I + ic] * inv_wmax : 0.f;
+    t[j] = in ? s[(int64_t)b * g.I + ic] * inv_smax + 1.f : 0.f;
+    m[j] = wp[j] * t[j];
   }
 }
 
 // rotation pair bookkeeping: column i = tid + j*PB is a "sin" column when cin <= i < cin+F, its "cos"
 // partner is i + F = column j+1 of the same thread (F == PB).
+template <int NT>
 __device__ __forceinline__ bool is_sin_col(const ModGeom& g, int j) {
-  const int i = threadIdx.x + j * PB;
+  const int i = (threadIdx.x & (NT - 1)) + j * NT;
   return g.F > 0 && i >= g.cin && i < g.cin + g.F;
 }
 
 // one (o, b) row of the prepared weights; ema_var == nullptr: c = 1 (the caller applies the input-magnitude factor
 // in the GEMM epilogue instead, see dgv2_mod_prep_all_fwd)
-template <typename TO>
+template <int NT, typename TO>
 __device__ __forceinline__ void prep_fwd_row(TO* __restrict__ wb, float* __restrict__ dsave,
                                              const float* __restrict__ W, const float* __restrict__ s,
                                              const float* __restrict__ stats, const float* __restrict__ ema_var,
                                              const float* __restrict__ shift, const float* __restrict__ fw,
                                              const ModGeom& g, int o, int b, float* red) {
-  float m[MAXJ], t[MAXJ], wp[MAXJ];
-  mod_row(g, W, s, stats, b, o, m, t, wp);
+  float m[(1024 / NT)], t[(1024 / NT)], wp[(1024 / NT)];
+  mod_row<NT>(g, W, s, stats, b, o, m, t, wp);
   float d = 1.f;
   if (g.demod) {
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) ss += m[j] * m[j];
-    ss = block_sum(ss, red);
+    for (int j = 0; j < (1024 / NT); ++j) ss += m[j] * m[j];
+    ss = row_sum<NT>(ss, red);
     d = rsqrtf(ss + 1e-8f);
   }
   const float c = ema_var ? 1.f / (sqrtf(ema_var[0]) + 1e-8f) : 1.f;
-  if (threadIdx.x == 0) dsave[(int64_t)b * g.O + o] = d;
+  if ((threadIdx.x & (NT - 1)) == 0) dsave[(int64_t)b * g.O + o] = d;
   const float k = d * c;
   if (g.F > 0 && shift) {
 #pragma unroll
-    for (int j = 0; j + 1 < MAXJ; ++j)
-      if (is_sin_col(g, j)) {
-        const int f = threadIdx.x + j * PB - g.cin;
-        float sd, cd;
-        sincosf(shift[b] * fw[f], &sd, &cd);
-        const float ws = m[j], wc = m[j + 1];
-        m[j] = ws * cd - wc * sd;
-        m[j + 1] = ws * sd + wc * cd;
-      }
+    for (int j = 0; j + 256 / NT < (1024 / NT); ++j)
+    {
+      const bool sc = is_sin_col<NT>(g, j);
+      const int f = (threadIdx.x & (NT - 1)) + j * NT - g.cin;
+      float sd, cd;
+      rot_factors(g, shift, fw, b, f, sc, sd, cd);
+      const float ws = m[j], wc = m[j + 256 / NT];
+      m[j] = sc ? ws * cd - wc * sd : ws;
+      m[j + 256 / NT] = sc ? ws * sd + wc * cd : wc;
+    }
   }
   TO* out = wb + ((int64_t)b * g.Otot + g.row_off + o) * g.I;
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const int i = threadIdx.x + j * PB;
+  for (int j = 0; j < (1024 / NT); ++j) {
+    const int i = (threadIdx.x & (NT - 1)) + j * NT;
     if (i < g.I) out[i] = from_f32<TO>(m[j] * k);
   }
 }
@@ -141,43 +171,46 @@ __global__ __launch_bounds__(PB) void mod_prep_fwd_kernel(TO* __restrict__ wb, f
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ fw, ModGeom g) {
   __shared__ float red[4];
-  prep_fwd_row<TO>(wb, dsave, W, s, stats, ema_var, shift, fw, g, blockIdx.x, blockIdx.y, red);
+  prep_fwd_row<PB, TO>(wb, dsave, W, s, stats, ema_var, shift, fw, g, blockIdx.x, blockIdx.y, red);
 }
 
 // gradient of the loss w.r.t. the pre-rotation modulated weight m (per owned column), given G = dL/dwb
+template <int NT>
 __device__ __forceinline__ void grad_m(const ModGeom& g, const float* __restrict__ G, const float* __restrict__ shift,
-                                       const float* __restrict__ fw, int b, int o, const float (&m)[MAXJ], float d,
-                                       float c, float* red, float (&gm)[MAXJ]) {
+                                       const float* __restrict__ fw, int b, int o, const float (&m)[(1024 / NT)], float d,
+                                       float c, float* red, float (&gm)[(1024 / NT)]) {
   const float* Gr = G + ((int64_t)b * g.Otot + g.row_off + o) * g.I;
-  float gp[MAXJ];
+  float gp[(1024 / NT)];
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const int i = threadIdx.x + j * PB;
-    gp[j] = i < g.I ? Gr[i] : 0.f;
+  for (int j = 0; j < (1024 / NT); ++j) {
+    const int i = (threadIdx.x & (NT - 1)) + j * NT;
+    const float v = Gr[min(i, g.I - 1)];
+    gp[j] = i < g.I ? v : 0.f;
   }
   if (g.F > 0 && shift) {  // transpose of the rotation
 #pragma unroll
-    for (int j = 0; j + 1 < MAXJ; ++j)
-      if (is_sin_col(g, j)) {
-        const int f = threadIdx.x + j * PB - g.cin;
-        float sd, cd;
-        sincosf(shift[b] * fw[f], &sd, &cd);
-        const float gs = gp[j], gc = gp[j + 1];
-        gp[j] = gs * cd + gc * sd;
-        gp[j + 1] = -gs * sd + gc * cd;
-      }
+    for (int j = 0; j + 256 / NT < (1024 / NT); ++j)
+    {
+      const bool sc = is_sin_col<NT>(g, j);
+      const int f = (threadIdx.x & (NT - 1)) + j * NT - g.cin;
+      float sd, cd;
+      rot_factors(g, shift, fw, b, f, sc, sd, cd);
+      const float gs = gp[j], gc = gp[j + 256 / NT];
+      gp[j] = sc ? gs * cd + gc * sd : gs;
+      gp[j + 256 / NT] = sc ? -gs * sd + gc * cd : gc;
+    }
   }
   if (g.demod) {
     float r = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) r += gp[j] * m[j];
-    r = block_sum(r, red);
+    for (int j = 0; j < (1024 / NT); ++j) r += gp[j] * m[j];
+    r = row_sum<NT>(r, red);
     const float k = c * d, d2r = d * d * r;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) gm[j] = k * (gp[j] - m[j] * d2r);
+    for (int j = 0; j < (1024 / NT); ++j) gm[j] = k * (gp[j] - m[j] * d2r);
   } else {
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) gm[j] = c * gp[j];
+    for (int j = 0; j < (1024 / NT); ++j) gm[j] = c * gp[j];
   }
 }
 
@@ -185,7 +218,7 @@ __device__ __forceinline__ void grad_m(const ModGeom& g, const float* __restrict
 //   gWraw[o,i] += sum_b gm t_b[i],   gt[b,i] += sum_o gm w'[o,i],   corr += sum gm t w'
 // with the sums over the group kept in registers, so the fp32 atomics that combine groups are OG (gt) and
 // BG (gWraw) times fewer than one per pair -- same-address float atomics are what bounds this kernel.
-template <int OG, int BG>
+template <int NT, int OG, int BG>
 __device__ __forceinline__ void prep_bwd_group(float* __restrict__ gWraw, float* __restrict__ gt,
                                                float* __restrict__ corr, const float* __restrict__ G,
                                                const float* __restrict__ W, const float* __restrict__ s,
@@ -194,28 +227,28 @@ __device__ __forceinline__ void prep_bwd_group(float* __restrict__ gWraw, float*
                                                const float* __restrict__ fw, const ModGeom& g, int corr_slots,
                                                int o0, int b0, int blk, float* red) {
   const float c = ema_var ? 1.f / (sqrtf(ema_var[0]) + 1e-8f) : 1.f;   // nullptr: G is already dL/d(m d)
-  float gwacc[OG][MAXJ];
+  float gwacc[OG][(1024 / NT)];
 #pragma unroll
   for (int ol = 0; ol < OG; ++ol)
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) gwacc[ol][j] = 0.f;
+    for (int j = 0; j < (1024 / NT); ++j) gwacc[ol][j] = 0.f;
   float part = 0.f;
 #pragma unroll
   for (int bl = 0; bl < BG; ++bl) {
     const int b = b0 + bl;
     if (b >= g.B) break;
-    float gtacc[MAXJ];
+    float gtacc[(1024 / NT)];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) gtacc[j] = 0.f;
+    for (int j = 0; j < (1024 / NT); ++j) gtacc[j] = 0.f;
 #pragma unroll
     for (int ol = 0; ol < OG; ++ol) {
       const int o = o0 + ol;
       if (o >= g.O) break;
-      float m[MAXJ], t[MAXJ], wp[MAXJ], gm[MAXJ];
-      mod_row(g, W, s, stats, b, o, m, t, wp);
-      grad_m(g, G, shift, fw, b, o, m, dsave[(int64_t)b * g.O + o], c, red, gm);
+      float m[(1024 / NT)], t[(1024 / NT)], wp[(1024 / NT)], gm[(1024 / NT)];
+      mod_row<NT>(g, W, s, stats, b, o, m, t, wp);
+      grad_m<NT>(g, G, shift, fw, b, o, m, dsave[(int64_t)b * g.O + o], c, red, gm);
 #pragma unroll
-      for (int j = 0; j < MAXJ; ++j) {
+      for (int j = 0; j < (1024 / NT); ++j) {
         const float gw = gm[j] * t[j];
         gwacc[ol][j] += gw;
         gtacc[j] += gm[j] * wp[j];
@@ -223,8 +256,8 @@ __device__ __forceinline__ void prep_bwd_group(float* __restrict__ gWraw, float*
       }
     }
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int i = threadIdx.x + j * PB;
+    for (int j = 0; j < (1024 / NT); ++j) {
+      const int i = (threadIdx.x & (NT - 1)) + j * NT;
       if (i < g.I) atomicAdd(&gt[(int64_t)b * g.I + i], gtacc[j]);
     }
   }
@@ -233,16 +266,16 @@ __device__ __forceinline__ void prep_bwd_group(float* __restrict__ gWraw, float*
     const int o = o0 + ol;
     if (o >= g.O) break;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int i = threadIdx.x + j * PB;
+    for (int j = 0; j < (1024 / NT); ++j) {
+      const int i = (threadIdx.x & (NT - 1)) + j * NT;
       if (i < g.I) atomicAdd(&gWraw[(int64_t)o * g.I + i], gwacc[ol][j]);
     }
   }
   if (g.demod) {
-    part = block_sum(part, red);
+    part = row_sum<NT>(part, red);
     // one slot per block when the caller provided them (plain store: the buffer was cleared, nobody else writes
     // the slot); 1000+ same-address atomics would otherwise serialise into the longest part of this kernel
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & (NT - 1)) == 0) {
       if (corr_slots > 1) corr[blk] = part;
       else atomicAdd(corr, part);
     }
@@ -259,26 +292,29 @@ __global__ __launch_bounds__(PB) void mod_prep_bwd_kernel(float* __restrict__ gW
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ fw, ModGeom g, int corr_slots) {
   __shared__ float red[4];
-  prep_bwd_group<OG, BG>(gWraw, gt, corr, G, W, s, stats, dsave, ema_var, shift, fw, g, corr_slots, blockIdx.x * OG,
+  prep_bwd_group<PB, OG, BG>(gWraw, gt, corr, G, W, s, stats, dsave, ema_var, shift, fw, g, corr_slots, blockIdx.x * OG,
                          blockIdx.y * BG, blockIdx.y * gridDim.x + blockIdx.x, red);
 }
 
 // s' = s / smax:  gs_i = gt_i / smax - [|s_i| == smax] sign(s_i) (sum_j gt_j s_j) / smax^2   (in place on gt)
+template <int NT>
 __device__ __forceinline__ void s_fix_row(float* __restrict__ gs, const float* __restrict__ s,
                                           const float* __restrict__ stats, int I, int b, float* red) {
   const float smax = stats[2 + 2 * b];
-  float acc[MAXJ], sv[MAXJ], dot = 0.f;
+  float acc[(1024 / NT)], sv[(1024 / NT)], dot = 0.f;
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const int i = threadIdx.x + j * PB;
-    acc[j] = i < I ? gs[(int64_t)b * I + i] : 0.f;
-    sv[j] = i < I ? s[(int64_t)b * I + i] : 0.f;
+  for (int j = 0; j < (1024 / NT); ++j) {
+    const int i = (threadIdx.x & (NT - 1)) + j * NT;
+    const int ic = min(i, I - 1);
+    const float av = gs[(int64_t)b * I + ic], bv = s[(int64_t)b * I + ic];
+    acc[j] = i < I ? av : 0.f;
+    sv[j] = i < I ? bv : 0.f;
     dot += acc[j] * sv[j];
   }
-  dot = block_sum(dot, red);
+  dot = row_sum<NT>(dot, red);
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const int i = threadIdx.x + j * PB;
+  for (int j = 0; j < (1024 / NT); ++j) {
+    const int i = (threadIdx.x & (NT - 1)) + j * NT;
     if (i < I) {
       float v = acc[j] / smax;
       if (fabsf(sv[j]) == smax) v -= (sv[j] > 0.f ? 1.f : -1.f) * dot / (smax * smax);
@@ -290,7 +326,7 @@ __device__ __forceinline__ void s_fix_row(float* __restrict__ gs, const float* _
 __global__ __launch_bounds__(PB) void mod_prep_bwd_s_fix_kernel(float* __restrict__ gs, const float* __restrict__ s,
                                                                 const float* __restrict__ stats, int I) {
   __shared__ float red[4];
-  s_fix_row(gs, s, stats, I, blockIdx.x, red);
+  s_fix_row<PB>(gs, s, stats, I, blockIdx.x, red);
 }
 
 // W' = W * k (k = 1/wmax or scale): gW = gWraw * k, and with demod the max-norm term
@@ -347,9 +383,17 @@ struct PrepAll {
   int aux[MPA_MAX];            // stats: W blocks;  bwd groups: corr slots;  w_fix: blocks of the layer
   int ncorr[MPA_MAX];
   float* stats;                // [L, 2 + 2B]
+  float* rot;                  // [L, B, 256, 2] (sin, cos) of shift[b] * fw[l][f] for the rotating layers
   const float* shift;
   int B, L;
 };
+
+// The by-value argument block, read where it lies (the kernarg segment) instead of through the private copy clang
+// makes of a dynamically indexed by-value struct (which cost these kernels ~200 VGPRs): uniform indices then
+// become scalar loads.
+__device__ __forceinline__ const PrepAll& kernarg_view(const PrepAll&) {
+  return *(const PrepAll*)__builtin_amdgcn_kernarg_segment_ptr();
+}
 
 __device__ __forceinline__ int find_layer(const PrepAll& a, int bid, int& local) {
   int l = 0;
@@ -359,11 +403,13 @@ __device__ __forceinline__ int find_layer(const PrepAll& a, int bid, int& local)
 }
 
 __device__ __forceinline__ ModGeom layer_geom(const PrepAll& a, int l) {
-  return ModGeom{a.B, a.O[l], a.I[l], a.Otot[l], a.row_off[l], a.flags[l] & 1, a.cin[l],
-                 ((a.flags[l] & 2) && a.shift) ? PB : 0, rsqrtf((float)a.I[l])};
+  const bool rotate = (a.flags[l] & 2) && a.shift;
+  return ModGeom{a.B, a.O[l], a.I[l], a.Otot[l], a.row_off[l], a.flags[l] & 1, a.cin[l], rotate ? PB : 0,
+                 rsqrtf((float)a.I[l]), rotate ? a.rot + (size_t)l * a.B * PB * 2 : nullptr};
 }
 
-__global__ __launch_bounds__(PB) void mod_stats_all_kernel(PrepAll a) {
+__global__ __launch_bounds__(PB) void mod_stats_all_kernel(PrepAll a_by_value) {
+  const PrepAll& a = kernarg_view(a_by_value);
   __shared__ float red[4];
   int local;
   const int l = find_layer(a, blockIdx.x, local);
@@ -371,6 +417,14 @@ __global__ __launch_bounds__(PB) void mod_stats_all_kernel(PrepAll a) {
   const int I = a.I[l], OI = a.O[l] * I, wblocks = a.aux[l];
   const float* W = a.W[l];
   const float* s = a.s[l];
+  const int nstat = (a.flags[l] & 1) ? wblocks + a.B : 0;
+  if (local >= nstat) {   // rotation table of this layer: one block per sample, one thread per frequency
+    const int b = local - nstat;
+    float sd, cd;
+    sincosf(a.shift[b] * a.fw[l][threadIdx.x], &sd, &cd);
+    reinterpret_cast<float2*>(a.rot)[((size_t)l * a.B + b) * PB + threadIdx.x] = make_float2(sd, cd);
+    return;
+  }
   float m = 0.f;
   int slot;
   if (local < wblocks) {
@@ -385,43 +439,53 @@ __global__ __launch_bounds__(PB) void mod_stats_all_kernel(PrepAll a) {
   if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(stats + slot), __float_as_uint(m));
 }
 
-__global__ __launch_bounds__(PB) void mod_prep_all_fwd_kernel(PrepAll a) {
+__global__ __launch_bounds__(PB) void mod_prep_all_fwd_kernel(PrepAll a_by_value) {
+  const PrepAll& a = kernarg_view(a_by_value);
   __shared__ float red[4];
   int local;
   const int l = find_layer(a, blockIdx.x, local);
   const ModGeom g = layer_geom(a, l);
-  const int o = local % g.O, b = local / g.O;
+  const int row = local * 4 + (threadIdx.x >> 6);   // one wave per (o, b) row
+  if (row >= g.O * g.B) return;
+  const int o = row % g.O, b = row / g.O;
   const float* stats = a.stats + (size_t)l * (2 + 2 * a.B);
   if (a.flags[l] & 4)
-    prep_fwd_row<bf16_t>((bf16_t*)a.wb[l], a.dsave[l], a.W[l], a.s[l], stats, nullptr, a.shift, a.fw[l], g, o, b, red);
+    prep_fwd_row<64, bf16_t>((bf16_t*)a.wb[l], a.dsave[l], a.W[l], a.s[l], stats, nullptr, a.shift, a.fw[l], g, o, b, red);
   else
-    prep_fwd_row<float>((float*)a.wb[l], a.dsave[l], a.W[l], a.s[l], stats, nullptr, a.shift, a.fw[l], g, o, b, red);
+    prep_fwd_row<64, float>((float*)a.wb[l], a.dsave[l], a.W[l], a.s[l], stats, nullptr, a.shift, a.fw[l], g, o, b, red);
 }
 
 template <int OG, int BG>
-__global__ __launch_bounds__(PB) void mod_prep_all_bwd_kernel(PrepAll a) {
+__global__ __launch_bounds__(PB) void mod_prep_all_bwd_kernel(PrepAll a_by_value) {
+  const PrepAll& a = kernarg_view(a_by_value);
   __shared__ float red[4];
   int local;
   const int l = find_layer(a, blockIdx.x, local);
   const ModGeom g = layer_geom(a, l);
+  // one BLOCK per OG x BG group (a wave per group would hold 16 columns x 4 rows of partial sums per lane and
+  // drops to one wave per SIMD); the rotation factors are evaluated (3 per thread), not read from the table
   const int gx = (g.O + OG - 1) / OG;
   float* gW = a.gW[l];
   float* gs = gW + (size_t)g.O * g.I;
   float* corr = gs + (size_t)g.B * g.I;
-  prep_bwd_group<OG, BG>(gW, gs, corr, (const float*)a.wb[l], a.W[l], a.s[l], a.stats + (size_t)l * (2 + 2 * a.B),
-                         a.dsave[l], nullptr, a.shift, a.fw[l], g, a.aux[l], (local % gx) * OG, (local / gx) * BG, local,
-                         red);
+  prep_bwd_group<PB, OG, BG>(gW, gs, corr, (const float*)a.wb[l], a.W[l], a.s[l], a.stats + (size_t)l * (2 + 2 * a.B),
+                             a.dsave[l], nullptr, a.shift, a.fw[l], g, a.aux[l], (local % gx) * OG, (local / gx) * BG,
+                             local, red);
 }
 
-__global__ __launch_bounds__(PB) void mod_prep_all_s_fix_kernel(PrepAll a) {
+__global__ __launch_bounds__(PB) void mod_prep_all_s_fix_kernel(PrepAll a_by_value) {
+  const PrepAll& a = kernarg_view(a_by_value);
   __shared__ float red[4];
   int local;
   const int l = find_layer(a, blockIdx.x, local);
   float* gs = a.gW[l] + (size_t)a.O[l] * a.I[l];
-  s_fix_row(gs, a.s[l], a.stats + (size_t)l * (2 + 2 * a.B), a.I[l], local, red);
+  const int b = local * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  s_fix_row<64>(gs, a.s[l], a.stats + (size_t)l * (2 + 2 * a.B), a.I[l], b, red);
 }
 
-__global__ __launch_bounds__(256) void mod_prep_all_w_fix_kernel(PrepAll a) {
+__global__ __launch_bounds__(256) void mod_prep_all_w_fix_kernel(PrepAll a_by_value) {
+  const PrepAll& a = kernarg_view(a_by_value);
   __shared__ float red[4];
   int local;
   const int l = find_layer(a, blockIdx.x, local);
@@ -444,9 +508,19 @@ bool geom_ok(int B, int O, int I, int Otot, int row_off, int cin, int F) {
 //   snapshot <- ema        (the value this forward pass uses; the buffer itself keeps changing)
 static __global__ void ema_scalar_kernel(float* ema, float* snapshot, const float* sumsq, int nsum, float add,
                                          float inv_count, float weight, int update, float* cvec, int ncvec) {
-  float s = 0.f;   // one wave: fold the nsum partial sums of dgv2_sum_squares
-  if (sumsq)
-    for (int k = threadIdx.x; k < nsum; k += 64) s += sumsq[k];
+  float s = 0.f;   // one wave: fold the nsum partial sums (up to 8192 from the producing kernels), 4 loads in flight
+  if (sumsq) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = threadIdx.x;
+    for (; k + 192 < nsum; k += 256) {
+      s0 += sumsq[k];
+      s1 += sumsq[k + 64];
+      s2 += sumsq[k + 128];
+      s3 += sumsq[k + 192];
+    }
+    for (; k < nsum; k += 64) s0 += sumsq[k];
+    s = (s0 + s1) + (s2 + s3);
+  }
   s = wave_sum(s);
   float v = ema[0];   // every lane computes the same value; lane 0 stores it
   if (update) v += weight * ((s + add) * inv_count - v);
@@ -561,16 +635,16 @@ static int fill_common(PrepAll& a, const float* const* W, const float* const* s,
   return 0;
 }
 
-extern "C" int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float* stats, const float* const* W,
+extern "C" int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float* stats, float* rot, const float* const* W,
                                      const float* const* s, const float* const* fw, const int* O, const int* I,
                                      const int* Otot, const int* row_off, const int* cin, const int* flags,
                                      const float* shift, int B, int L, void* stream) {
   PrepAll a;
-  if (!wb || !dsave || !stats) return DGV2_EINVAL;
+  if (!wb || !dsave || !stats || !rot) return DGV2_EINVAL;
   int rc = fill_common(a, W, s, fw, O, I, Otot, row_off, cin, flags, B, L);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  a.stats = stats; a.shift = shift;
+  a.stats = stats; a.shift = shift; a.rot = rot;
   int nstat = 0;
   for (int l = 0; l < L; ++l) {
     if (!wb[l] || !dsave[l]) return DGV2_EINVAL;
@@ -579,6 +653,7 @@ extern "C" int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float
       a.aux[l] = (O[l] * I[l] + PB * 8 - 1) / (PB * 8);
       nstat += a.aux[l] + B;
     }
+    if ((flags[l] & 2) && shift) nstat += B;   // rotation-table blocks
     a.blk_end[l] = nstat;
   }
   if (nstat > 0) {
@@ -588,7 +663,7 @@ extern "C" int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float
   }
   int nblk = 0;
   for (int l = 0; l < L; ++l) {
-    nblk += O[l] * B;
+    nblk += (O[l] * B + 3) / 4;   // one wave per row
     a.blk_end[l] = nblk;
   }
   mod_prep_all_fwd_kernel<<<nblk, PB, 0, st>>>(a);
@@ -600,15 +675,16 @@ extern "C" int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float
 // `flat` [flat_elems], which is cleared here with ONE launch.  stats / dsave: as left by the forward.
 extern "C" int dgv2_mod_prep_all_bwd(float* flat, int64_t flat_elems, float* const* out, const int* ncorr,
                                      const float* const* G, const float* const* W, const float* const* s,
-                                     const float* stats, float* const* dsave, const float* const* fw, const int* O,
-                                     const int* I, const int* Otot, const int* row_off, const int* cin,
-                                     const int* flags, const float* shift, int B, int L, void* stream) {
+                                     const float* stats, const float* rot, float* const* dsave,
+                                     const float* const* fw, const int* O, const int* I, const int* Otot,
+                                     const int* row_off, const int* cin, const int* flags, const float* shift, int B,
+                                     int L, void* stream) {
   PrepAll a;
-  if (!flat || flat_elems < 1 || !out || !ncorr || !G || !stats || !dsave) return DGV2_EINVAL;
+  if (!flat || flat_elems < 1 || !out || !ncorr || !G || !stats || !dsave || !rot) return DGV2_EINVAL;
   int rc = fill_common(a, W, s, fw, O, I, Otot, row_off, cin, flags, B, L);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  a.stats = const_cast<float*>(stats); a.shift = shift;
+  a.stats = const_cast<float*>(stats); a.shift = shift; a.rot = const_cast<float*>(rot);
   int cls[MPA_MAX], nb[MPA_MAX];
   for (int l = 0; l < L; ++l) {
     if (!out[l] || !G[l] || !dsave[l] || ncorr[l] < 1) return DGV2_EINVAL;
@@ -636,7 +712,7 @@ extern "C" int dgv2_mod_prep_all_bwd(float* flat, int64_t flat_elems, float* con
   }
   int n = 0;
   for (int l = 0; l < L; ++l) {
-    if (flags[l] & 1) n += B;
+    if (flags[l] & 1) n += (B + 3) / 4;
     a.blk_end[l] = n;
   }
   if (n > 0) mod_prep_all_s_fix_kernel<<<n, PB, 0, st>>>(a);

@@ -54,8 +54,8 @@ SIGNATURES = {
     "dgv2_pack2d": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_unpack2d": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_ema_scalar": [_c_ptr] * 3 + [_c_int] + [_c_f32] * 3 + [_c_int, _c_ptr, _c_int, _c_ptr],
-    "dgv2_mod_prep_all_fwd": [_c_ptr] * 12 + [_c_ptr, _c_int, _c_int, _c_ptr],
-    "dgv2_mod_prep_all_bwd": [_c_ptr, _c_i64] + [_c_ptr] * 14 + [_c_ptr, _c_int, _c_int, _c_ptr],
+    "dgv2_mod_prep_all_fwd": [_c_ptr] * 13 + [_c_ptr, _c_int, _c_int, _c_ptr],
+    "dgv2_mod_prep_all_bwd": [_c_ptr, _c_i64] + [_c_ptr] * 15 + [_c_ptr, _c_int, _c_int, _c_ptr],
     "dgv2_mod_prep_fwd": [_c_ptr] * 8 + [_c_int] * 9 + [_c_ptr],
     "dgv2_mod_prep_bwd": [_c_ptr] * 11 + [_c_int] * 9 + [_c_ptr],
     "dgv2_sum_squares": [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_ptr],

@@ -1405,6 +1405,7 @@ class _ModPrepAll(Function):
             dsaves.append(dflat[off:off + B * m["O"]])
             off += B * m["O"]
         stats = torch.empty(L * (2 + 2 * B), device=dev, dtype=torch.float32)
+        rot_tab = torch.empty(L * B * 512, device=dev, dtype=torch.float32)
         fws = [m["fw"] for m in lay]
         rot = shift is not None
         flags = [(1 if m["demod"] else 0) | (2 if (rot and m["fw"] is not None) else 0)
@@ -1415,10 +1416,10 @@ class _ModPrepAll(Function):
                     flags=_int_array(flags))
         N.check(*Ws, *Ss, shift, *[f for f in fws if f is not None])
         N.call("dgv2_mod_prep_all_fwd", _ptr_array([wbs[m["group"]] for m in lay]), _ptr_array(dsaves), N.ptr(stats),
-               _ptr_array(Ws), _ptr_array(Ss), _ptr_array(fws), ints["O"], ints["I"], ints["Otot"], ints["row_off"],
+               N.ptr(rot_tab), _ptr_array(Ws), _ptr_array(Ss), _ptr_array(fws), ints["O"], ints["I"], ints["Otot"], ints["row_off"],
                ints["cin"], ints["flags"], N.ptr(shift) if rot else None, B, L, N.stream())
         ctx.meta, ctx.ints, ctx.B, ctx.rot = meta, ints, B, rot
-        ctx.save_for_backward(shift, stats, dflat, *Ws, *Ss)
+        ctx.save_for_backward(shift, stats, dflat, rot_tab, *Ws, *Ss)
         handles = [torch.empty(1, device=dev, dtype=torch.float32).expand(B, g["Otot"], g["I"]) for g in meta["groups"]]
         ctx.mark_non_differentiable(*wbs)
         return (*handles, *wbs)
@@ -1429,8 +1430,8 @@ class _ModPrepAll(Function):
         lay, groups = meta["layers"], meta["groups"]
         L, ng = len(lay), len(groups)
         sv = ctx.saved_tensors
-        shift, stats, dflat = sv[:3]
-        Ws, Ss = sv[3:3 + L], sv[3 + L:3 + 2 * L]
+        shift, stats, dflat, rot_tab = sv[:4]
+        Ws, Ss = sv[4:4 + L], sv[4 + L:4 + 2 * L]
         dev = stats.device
         Gs = []
         for k, g in enumerate(groups):   # a group the loss does not reach contributes zeros
@@ -1452,7 +1453,7 @@ class _ModPrepAll(Function):
             off += B * m["O"]
         N.call("dgv2_mod_prep_all_bwd", N.ptr(flat), flat.numel(), _ptr_array(outs), _int_array(ncorr),
                _ptr_array([Gs[m["group"]] for m in lay]), _ptr_array(list(Ws)), _ptr_array(list(Ss)), N.ptr(stats),
-               _ptr_array(dsaves), _ptr_array([m["fw"] for m in lay]), ints["O"], ints["I"], ints["Otot"],
+               N.ptr(rot_tab), _ptr_array(dsaves), _ptr_array([m["fw"] for m in lay]), ints["O"], ints["I"], ints["Otot"],
                ints["row_off"], ints["cin"], ints["flags"], N.ptr(shift) if ctx.rot else None, B, L, N.stream())
         res = []
         for m, o in zip(lay, outs):

@@ -241,20 +241,22 @@ int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float* G, const f
  * above cost four launches per layer and pass).  Host arrays of length L: W[l] fp32 [O,I], s[l] fp32 [B,I],
  * fw[l] fp32 [256] (layers with flags & 2), wb[l] -> [B, Otot[l], I[l]] GEMM operand (bf16 if flags & 4 else
  * fp32; layers sharing a GEMM pass the same buffer and different row_off), dsave[l] fp32 [B,O]; stats fp32
- * [L, 2+2B].  flags: 1 demodulate, 2 rotate the PE columns [cin, cin+512) by shift[b] (shift NULL: none),
+ * [L, 2+2B]; rot fp32 [L, B, 512] scratch (the rotating layers' sin/cos table, filled by fwd, read by bwd).
+ * flags: 1 demodulate, 2 rotate the PE columns [cin, cin+512) by shift[b] (shift NULL: none),
  * 4 bf16 operand.  These weights do NOT contain 1/(sqrt(ema_var)+1e-8): that factor is the GEMM's row_scale
  * (dgv2_*_sq), its gradient side dgv2_bias_act_bwd_rs / dgv2_scale_cast; so G below is dL/d(these weights).
  * bwd: out[l] = [gW (O*I) | gs (B*I) | corr scratch (ncorr[l] >= 1)] fp32, all inside flat[flat_elems] which
  * is cleared here once.  replaces: ModConv2d.forward weight path, gans/models/ops/style.py:72-103. */
-int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float* stats, const float* const* W,
+int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float* stats, float* rot, const float* const* W,
                           const float* const* s, const float* const* fw, const int* O, const int* I,
                           const int* Otot, const int* row_off, const int* cin, const int* flags,
                           const float* shift, int B, int L, void* stream);
 int dgv2_mod_prep_all_bwd(float* flat, int64_t flat_elems, float* const* out, const int* ncorr,
                           const float* const* G, const float* const* W, const float* const* s,
-                          const float* stats, float* const* dsave, const float* const* fw, const int* O,
-                          const int* I, const int* Otot, const int* row_off, const int* cin,
-                          const int* flags, const float* shift, int B, int L, void* stream);
+                          const float* stats, const float* rot, float* const* dsave,
+                          const float* const* fw, const int* O, const int* I, const int* Otot,
+                          const int* row_off, const int* cin, const int* flags, const float* shift, int B,
+                          int L, void* stream);
 
 /* Sum of squares of the first C channels of x [N, ld] into acc[0] (fp32, ACCUMULATES).
  * replaces: x.pow(2).mean() in ModConv2d.forward (style.py:100-101). */

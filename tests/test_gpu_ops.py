@@ -230,6 +230,69 @@ def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
                 assert_rel(y.float().cpu(), want, 8e-3)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_batched_weight_preparation_matches_per_layer_path(nat, dtype, tol):
+    """dgv2_mod_prep_all_fwd/_bwd + GEMM row scale (all layers of a pass prepared in one launch, the input-magnitude
+    factor applied in the epilogue) against the per-layer path (dgv2_mod_prep_fwd/_bwd, itself pinned to the oracle's
+    ModConv2d restatement, style.py:72-118): outputs and every gradient.  Layers: a PE conv with azimuth rotation,
+    a plain demodulated conv, and two heads sharing one GEMM (no demodulation, no activation, fp32 output)."""
+    g = torch.Generator().manual_seed(31)
+    B, H, W = 3, 4, 40
+    P = H * W
+    cin, F = 64, 256
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+    shift = (torch.rand(B, generator=g) * 6.28).to(DEV)
+    fw = torch.arange(1, F + 1, dtype=torch.float32).to(DEV) * 0.25
+    spec = [dict(O=32, I=cin + 2 * F, demod=True, cin=cin, fw=fw, ev=0.7),
+            dict(O=24, I=32, demod=True, cin=0, fw=None, ev=1.9),
+            dict(O=1, I=24, demod=False, cin=0, fw=None, ev=0.4),
+            dict(O=2, I=24, demod=False, cin=0, fw=None, ev=2.5)]
+    Ws = [rnd(m["O"], m["I"]).requires_grad_(True) for m in spec]
+    Ss = [rnd(B, m["I"], scale=0.5).requires_grad_(True) for m in spec]
+    xa0 = rnd(B, H, W, cin).to(dtype).requires_grad_(True)
+    pe = rnd(1, H, W, 2 * F).to(dtype)
+    x1 = rnd(B, H, W, 32).to(dtype).requires_grad_(True)
+    x2 = rnd(B, H, W, 24).to(dtype).requires_grad_(True)
+    b0, b1, b2 = rnd(32).requires_grad_(True), rnd(24).requires_grad_(True), rnd(3).requires_grad_(True)
+    evs = [torch.tensor([m["ev"]], device=DEV) for m in spec]
+    leaves = [*Ws, *Ss, xa0, x1, x2, b0, b1, b2]
+
+    def loss(y0, y1, y2):
+        return (y0.float() * 0.5).square().sum() + y1.float().sum() * 0.3 + (y2.float() * y2.float()).sum()
+
+    # per-layer path
+    y0 = nat.mod_layer(xa0, pe, [(Ws[0], Ss[0], evs[0], True)], bias=b0, act=True, shift=shift, fw=fw, cin=cin)
+    y1 = nat.mod_layer(x1, None, [(Ws[1], Ss[1], evs[1], True)], bias=b1, act=True)
+    y2 = nat.mod_layer(x2, None, [(Ws[2], Ss[2], evs[2], False), (Ws[3], Ss[3], evs[3], False)], bias=b2, act=False,
+                       out_dtype=torch.float32)
+    ref_out = [t.detach().float() for t in (y0, y1, y2)]
+    ref_grads = torch.autograd.grad(loss(y0, y1, y2), leaves)
+    # batched path
+    layers = [dict(W=Ws[0], s=Ss[0], O=32, I=cin + 2 * F, demod=True, cin=cin, fw=fw, group=0, row_off=0),
+              dict(W=Ws[1], s=Ss[1], O=24, I=32, demod=True, cin=0, fw=None, group=1, row_off=0),
+              dict(W=Ws[2], s=Ss[2], O=1, I=24, demod=False, cin=0, fw=None, group=2, row_off=0),
+              dict(W=Ws[3], s=Ss[3], O=2, I=24, demod=False, cin=0, fw=None, group=2, row_off=1)]
+    groups = [dict(Otot=32, I=cin + 2 * F, dtype=dtype), dict(Otot=24, I=32, dtype=dtype), dict(Otot=3, I=24, dtype=dtype)]
+    prepared = nat.mod_prep_all(layers, groups, shift)
+
+    def cvec(vals):
+        return torch.cat([(1.0 / (torch.sqrt(e) + 1e-8)).expand(n) for e, n in vals]).contiguous()
+
+    z0 = nat.mod_gemm_layer(xa0, pe, *prepared[0], cvec([(evs[0], 32)]), bias=b0, act=True)
+    z1 = nat.mod_gemm_layer(x1, None, *prepared[1], cvec([(evs[1], 24)]), bias=b1, act=True)
+    z2 = nat.mod_gemm_layer(x2, None, *prepared[2], cvec([(evs[2], 1), (evs[3], 2)]), bias=b2, act=False,
+                            out_dtype=torch.float32)
+    got_grads = torch.autograd.grad(loss(z0, z1, z2), leaves)
+    for r, z, name in zip(ref_out, (z0, z1, z2), ("conv+PE", "conv", "heads")):
+        assert_rel(z.detach().float().cpu(), r.cpu(), tol, name)
+    names = [f"gW{k}" for k in range(4)] + [f"gs{k}" for k in range(4)] + ["gxa0", "gx1", "gx2", "gb0", "gb1", "gb2"]
+    for gr, gg, name in zip(ref_grads, got_grads, names):
+        assert_rel(gg.float().cpu(), gr.float().cpu(), tol * 5, name)
+
+
 def test_producers_leave_sum_of_squares_partials(nat, g_ops):
     """The input statistic of a modulated conv (x.square().mean(), style.py:98-103) taken in the epilogue of the
     kernel that PRODUCES x: dgv2_resample_tab_sq / dgv2_modconv_pe_fwd_sq partials must sum to the sum of squares
