@@ -396,8 +396,12 @@ __device__ __forceinline__ const PrepAll& kernarg_view(const PrepAll&) {
 }
 
 __device__ __forceinline__ int find_layer(const PrepAll& a, int bid, int& local) {
+  // number of prefix ends <= bid, all 32 entries compared at once (entries past L are INT_MAX): a dependent
+  // while-loop over the table cost one scalar-load latency per layer, microseconds per block
   int l = 0;
-  while (l < a.L - 1 && bid >= a.blk_end[l]) ++l;
+#pragma unroll
+  for (int k = 0; k < MPA_MAX; ++k) l += bid >= a.blk_end[k] ? 1 : 0;
+  l = min(l, a.L - 1);
   local = bid - (l ? a.blk_end[l - 1] : 0);
   return l;
 }
@@ -631,6 +635,7 @@ static int fill_common(PrepAll& a, const float* const* W, const float* const* s,
     a.O[l] = O[l]; a.I[l] = I[l]; a.Otot[l] = Otot[l]; a.row_off[l] = row_off[l]; a.cin[l] = cin[l]; a.flags[l] = flags[l];
     a.aux[l] = 0; a.ncorr[l] = 0; a.gW[l] = nullptr; a.dsave[l] = nullptr; a.wb[l] = nullptr;
   }
+  for (int l = 0; l < MPA_MAX; ++l) a.blk_end[l] = 0x7fffffff;   // launches overwrite [0, L)
   a.B = B; a.L = L;
   return 0;
 }
