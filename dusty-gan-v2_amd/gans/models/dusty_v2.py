@@ -169,7 +169,7 @@ class SynthesisBlock(nn.Module):
         if self.pe.out_ch == 512 and conv.in_ch <= 1024:
             # weight preparation (+ rotation), contraction, bias and lrelu as one autograd node
             mods = [conv.prep_args(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch), sumsq_add=pe_sq)]
-            fw = self.pe.freqs2[:, 1].contiguous() if shift is not None else None
+            fw = self.pe.freqs_w() if shift is not None else None
             return native.mod_layer(hup, pe0, mods, bias=act.bias, act=True, alpha=act.negative_slope,
                                     scale=act.scale, shift=shift, fw=fw, cin=cin, want_sq=want)
         if conv.training:
@@ -323,7 +323,7 @@ class SynthesisNetwork(nn.Module):
         layers, groups = [], []
         for blk in self.layers:
             dt = blk.compute_dtype
-            fw = blk.pe.freqs2[:, 1].contiguous() if shift is not None else None
+            fw = blk.pe.freqs_w() if shift is not None else None
             convs = [(blk.conv1, blk.conv1.in_ch - blk.pe.out_ch, fw)]
             if not blk.is_first:
                 convs.append((blk.conv2, 0, None))

@@ -48,6 +48,15 @@ class FourierFeature(nn.Module):
     def freqs2(self):
         return self.freqs.reshape(-1, 2)
 
+    def freqs_w(self):
+        """Contiguous copy of the azimuth frequencies [F] (the rotation of the PE columns needs them every pass):
+        cached, and rebuilt when the buffer changes (load_state_dict, .to())."""
+        f = self.freqs
+        key = (f.data_ptr(), f._version, f.device)
+        if getattr(self, "_fw_key", None) != key:
+            self._fw_key, self._fw = key, f.reshape(-1, 2)[:, 1].contiguous()
+        return self._fw
+
     def encode_into(self, out, c0, angle, shift=None):
         native.fourier_feature_into(out, c0, angle, shift, self.freqs2.contiguous(), self.phase)
 

@@ -221,6 +221,7 @@ class _ResampleSq(Function):
 
     @staticmethod
     def forward(ctx, x, spec, in_hw):
+        ctx.set_materialize_grads(False)   # no zero tensor for the statistic's (absent) gradient
         x = x.contiguous()
         N.check(x)
         ctx.cfg = (spec, in_hw)
@@ -233,7 +234,7 @@ class _ResampleSq(Function):
     @staticmethod
     def backward(ctx, g, _):
         spec, in_hw = ctx.cfg
-        return _Resample.apply(g, spec, True, in_hw), None, None
+        return (None if g is None else _Resample.apply(g, spec, True, in_hw)), None, None
 
 
 def resample_sq(x, spec):
@@ -899,6 +900,8 @@ class _ConvAct(Function):
     def backward(ctx, gy):
         x, w, out = ctx.saved_tensors
         g, alpha, scale, size_b = ctx.cfg
+        if gy is None:   # only the sibling branch carries a gradient
+            return gx_sibling, None, None, None, None, None
         gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gpre, x, g) if ctx.needs_input_grad[1] else None
@@ -970,6 +973,7 @@ class _ConvActFork(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, g, alpha, scale):
+        ctx.set_materialize_grads(False)
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
         if wc is None:
@@ -1097,6 +1101,7 @@ class _GenTail(Function):
         B, H, W, _ = skip.shape
         N.check(skip, shift, u)
         outs = [torch.empty((B, 1, H, W), device=skip.device, dtype=torch.float32) for _ in range(4)]
+        ctx.set_materialize_grads(False)   # unused outputs reach backward as None (the kernel takes NULL)
         image, image_orig, logit, mask = outs
         N.call("dgv2_gen_tail_fwd", N.ptr(image), N.ptr(image_orig), N.ptr(logit), N.ptr(mask), N.ptr(skip),
                N.ptr(shift), N.ptr(u), B, H, W, out_scale, raydrop_const, temperature, N.stream())
@@ -1234,6 +1239,7 @@ class _ModLayer(Function):
         xa [B,H,W,Ka] per-sample input (or None), xs [1,H,W,Ks] batch-shared PE (or None);
         bias fp32 [Otot] (or None); mods = (W_0, s_0, ev_0, W_1, s_1, ev_1, ...): weight [O_k,I] fp32,
         style [B,I] fp32, ema_var scalar (value to use)."""
+        ctx.set_materialize_grads(False)
         nm = len(mods) // 3
         Ws = [mods[3 * k].detach().contiguous() for k in range(nm)]
         Ss = [mods[3 * k + 1].detach().float().contiguous() for k in range(nm)]
@@ -1297,6 +1303,8 @@ class _ModLayer(Function):
     def backward(ctx, gy, _=None):
         cfg = ctx.cfg
         Os, I, B, rot = cfg["Os"], cfg["I"], cfg["B"], cfg["rot"]
+        if gy is None:
+            return (None,) * (6 + 3 * len(Os))
         nm = len(Os)
         sv = ctx.saved_tensors
         xa, xs, wb, out, shift, fw = sv[:6]
@@ -1392,6 +1400,7 @@ class _ModPrepAll(Function):
         groups=[dict(Otot, I, dtype)]); flat = (W_0, s_0, W_1, s_1, ...): W fp32 [O,I], s fp32 [B,I].
         Returns one fp32 HANDLE [B,Otot,I] per group (zero storage; carries the autograd edge: its gradient is
         dL/d(prepared weights)) followed by the prepared weights themselves (compute dtype, non-differentiable)."""
+        ctx.set_materialize_grads(False)   # the prepared weights are outputs too: no zero fills for their "gradients"
         L = len(meta["layers"])
         Ws = [flat[2 * l].detach().contiguous() for l in range(L)]
         Ss = [flat[2 * l + 1].detach().float().contiguous() for l in range(L)]
@@ -1480,6 +1489,7 @@ class _ModGemmPrepared(Function):
 
     @staticmethod
     def forward(ctx, cfg, xa, xs, bias, handle, wb, cvec):
+        ctx.set_materialize_grads(False)
         ref = xa if xa is not None else xs
         dt = ref.dtype
         B, Otot, I = wb.shape
@@ -1518,6 +1528,8 @@ class _ModGemmPrepared(Function):
     @staticmethod
     def backward(ctx, gy, _=None):
         cfg = ctx.cfg
+        if gy is None:
+            return (None,) * 7
         xa, xs, wb, out, cvec = ctx.saved_tensors
         B, Otot, I = wb.shape
         dt = wb.dtype

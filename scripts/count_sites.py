@@ -1,0 +1,35 @@
+"""Where do the small ATen launches of one eager training iteration come from?  (op, innermost package frame) census."""
+import os, sys, argparse, collections, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dusty-gan-v2_amd")]
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+import bench
+args = argparse.Namespace(batch_per_gpu=64, dtype="bf16", ada_p=0.6, no_graph=True)
+from gans.trainer import Trainer
+from gans.utils import init_random_seed
+init_random_seed(0, 0)
+tr = Trainer(bench.make_cfg(args, 0, 1), sync_scalars=False)
+for it in (16, 1, 2):
+    tr.step(it)
+SKIP = ("view", "reshape", "detach", "empty", "as_strided", "slice", "select", "transpose", "permute", "t.default", "expand",
+        "unsqueeze", "squeeze", "alias", "is_", "stride", "size", "unbind", "split", "_unsafe_view", "lift_fresh", "numel", "dim")
+counts = collections.Counter()
+class Census(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, a=(), k=None):
+        name = str(func)
+        if not any(s in name for s in SKIP):
+            site = "autograd-engine"
+            for fr in reversed(traceback.extract_stack(limit=40)):
+                if "dusty-gan-v2_amd" in fr.filename and "count_sites" not in fr.filename:
+                    site = f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}"
+                    break
+            shp = tuple(tuple(t.shape) for t in a[:2] if isinstance(t, torch.Tensor))
+            counts[(name, site, shp if site == "autograd-engine" else ())] += 1
+        return func(*a, **(k or {}))
+with Census():
+    tr.step(3)
+torch.cuda.synchronize()
+for (n, site, shp), c in sorted(counts.items(), key=lambda kv: -kv[1])[:110]:
+    print(f"x{c:4d} {n:30s} {site} {shp if shp else ''}")
+print("total", sum(counts.values()))
