@@ -561,7 +561,6 @@ class Discriminator(nn.Module):
             else:
                 x = layer.forward_cl(x)
                 i += 1
-        x = x.float()
         mb, conv, act1, _, lin1, act2, lin2 = self.epilogue
         # The reference runs the epilogue in fp32.  With num_fp16_layers == -1 ("everything reduced")
         # the 3x3 epilogue conv (303 MMAC/img) runs in bf16 with fp32 accumulation here; mbstd and the
@@ -570,8 +569,13 @@ class Discriminator(nn.Module):
         cin = x.shape[3] + mb.features
         vec = 32 if edt == LOW else 16
         cpad = (cin + vec - 1) // vec * vec  # whole 64-byte K-steps for the direct conv engine
-        x = mb.forward_cl(x, pad_to=cpad, splits=splits)
-        x = conv.forward_cl(x.to(edt), pad_in_to=cpad, act=act1, bank=bank)
+        if (not double_backward and x.dtype == edt and cpad > x.shape[3]
+                and native.mbstd_cat_ok(x, mb.group, splits, mb.features, cpad)):
+            # statistic in fp32 on the stored values (= x.float() of the reference), concat + padding in the same pass
+            x = native.mbstd_cat(x, mb.group, splits, cpad)
+        else:
+            x = mb.forward_cl(x.float(), pad_to=cpad, splits=splits).to(edt)
+        x = conv.forward_cl(x, pad_in_to=cpad, act=act1, bank=bank)
         x = ops.from_cl(x).flatten(1)  # NCHW flatten order of the reference's nn.Flatten
         if edt == LOW and lin1.module.bias is None and lin1.gain_ == 1.0:
             # "everything reduced": the 65536 -> 512 Linear (8.6 GFLOP at B = 128, 134 MB of fp32 weights) as a

@@ -908,6 +908,58 @@ class _ConvAct(Function):
         return gx, gw, gb, None, None, None
 
 
+class _MbstdCat(Function):
+    """[x | minibatch-stddev statistic | zero padding] (dgv2_mbstd_cat_fwd/_bwd): MinibatchStdDev + concat of the
+    discriminator epilogue (common.py:226-250) in two launches forward and one backward; first order only."""
+
+    @staticmethod
+    def forward(ctx, x, group, splits, cpad):
+        x = x.contiguous()
+        N.check(x)
+        B, H, W, C = x.shape
+        out = torch.empty((B, H, W, cpad), device=x.device, dtype=x.dtype)
+        scratch = torch.empty(64 * max(1, B // group), device=x.device, dtype=torch.float32)
+        N.call("dgv2_mbstd_cat_fwd", N.ptr(out), N.ptr(scratch), N.ptr(x), B, H * W, C, cpad, splits, group, _dt(x),
+               N.stream())
+        ctx.save_for_backward(x)
+        ctx.cfg = (group, splits, cpad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        group, splits, cpad = ctx.cfg
+        B, H, W, C = x.shape
+        if torch.is_grad_enabled():
+            # create_graph=True (e.g. an R1 penalty taken through this path): the same gradient from differentiable ops
+            m = B // (splits * group)
+            xf, gf = x.float(), g.float()
+            y = xf.reshape(splits, group, m, H, W, C)
+            d = y - y.mean(1, keepdim=True)
+            sd = torch.sqrt((d * d).mean(1, keepdim=True) + 1e-8)
+            gst = gf[..., C].reshape(splits, group, m, H * W).sum(dim=(1, 3))
+            term = gst[:, None, :, None, None, None] / float(H * W * C) * d / (group * sd)
+            return (gf[..., :C] + term.reshape(B, H, W, C)).to(x.dtype), None, None, None
+        g = g.contiguous().to(x.dtype)
+        gx = torch.empty_like(x)
+        N.call("dgv2_mbstd_cat_bwd", N.ptr(gx), N.ptr(g), N.ptr(x), B, H * W, C, cpad, splits, group, _dt(x), N.stream())
+        return gx, None, None, None
+
+
+def mbstd_cat_ok(x, group, splits, features, cpad):
+    vn = 8 if x.dtype == torch.bfloat16 else 4
+    B, C = x.shape[0], x.shape[3]
+    g = min(B // splits, group)
+    return (x.is_cuda and features == 1 and x.dtype in (torch.bfloat16, torch.float32) and C % vn == 0 and cpad % vn == 0
+            and cpad > C and 1 <= g <= 8 and B % (splits * g) == 0)
+
+
+def mbstd_cat(x, group, splits, cpad):
+    """x [B,H,W,C] -> [B,H,W,cpad]: x, then the per-sample minibatch-stddev statistic in channel C, then zeros."""
+    g = min(x.shape[0] // splits, group)
+    return _MbstdCat.apply(x, g, splits, cpad)
+
+
 class _ScaledHandle(Function):
     """Differentiable stand-in for `param * scale` laid out [O,kh,kw,C] whose VALUES are never read: with the
     weight bank the conv kernels take the prepared compute-dtype copies, and this tensor only carries the autograd

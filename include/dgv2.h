@@ -263,6 +263,20 @@ int dgv2_mod_prep_all_bwd(float* flat, int64_t flat_elems, float* const* out, co
 int dgv2_sum_squares(float* acc, const void* x, int64_t N, int C, int ld, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * minibatch standard deviation + concat (discriminator epilogue)
+ * replaces: MinibatchStdDev.forward + torch.cat, gans/models/ops/common.py:226-250 (mbdis_feat = 1), used at
+ *   gans/models/dusty_v2.py:376-385.  x [B, P, C] channels-last (P = H*W), out [B, P, Cp] same dtype with
+ *   out[..., :C] = x, out[..., C] = the group statistic of the sample, out[..., C+1:] = 0 (channel padding for the
+ *   conv engine, Cp > C, both multiples of the 16-byte vector).  B = splits * group * m: `splits` independent
+ *   sub-batches (real | fake in one pass), group members strided by m as in the reference.  scratch: fp32
+ *   [>= 64 * B / group].  bwd: gx [B, P, C] from the gradient of `out` and x.
+ * ------------------------------------------------------------------------- */
+int dgv2_mbstd_cat_fwd(void* out, float* scratch, const void* x, int B, int P, int C, int Cp, int splits,
+                       int group, int dtype, void* stream);
+int dgv2_mbstd_cat_bwd(void* gx, const void* gout, const void* x, int B, int P, int C, int Cp, int splits,
+                       int group, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
  * dense convolution with ring padding (discriminator)
  * replaces: ops.Conv2d = Pad(circular W / replicate H) + nn.Conv2d, via cuDNN/ATen
  *   gans/models/ops/common.py:10-24,187-210, used at gans/models/dusty_v2.py:325-385

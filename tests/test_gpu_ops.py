@@ -293,6 +293,35 @@ def test_batched_weight_preparation_matches_per_layer_path(nat, dtype, tol):
         assert_rel(gg.float().cpu(), gr.float().cpu(), tol * 5, name)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("B,splits,group", [(8, 1, 4), (16, 2, 4), (6, 2, 4), (4, 1, 4)])
+def test_mbstd_cat_matches_composed_reference(nat, dtype, tol, B, splits, group):
+    """dgv2_mbstd_cat_fwd/_bwd against MinibatchStdDev (group members strided through the batch, biased variance,
+    eps 1e-8, mean over H, W, C) + concat + zero channel padding composed from torch ops (common.py:226-250);
+    `splits` sub-batches are independent, a sub-batch smaller than the group shrinks the group."""
+    g = torch.Generator().manual_seed(17)
+    H, W, C, cpad = 4, 8, 16, 32
+    x = torch.randn(B, H, W, C, generator=g).to(dtype)
+    gout = torch.randn(B, H, W, cpad, generator=g).to(dtype)
+    xr = x.double().requires_grad_(True)
+    Bs = B // splits
+    gg = min(Bs, group)
+    m = Bs // gg
+    y = xr.reshape(splits, gg, m, H, W, C)
+    sd = torch.sqrt(y.var(1, unbiased=False) + 1e-8)
+    st = sd.mean(dim=(2, 3, 4))                                   # [S, m]
+    stb = st[:, None].expand(splits, gg, m).reshape(B)
+    ref = torch.cat([xr, stb[:, None, None, None].expand(B, H, W, 1), xr.new_zeros(B, H, W, cpad - C - 1)], dim=3)
+    (gref,) = torch.autograd.grad(ref, xr, gout.double())
+    xd = x.to(DEV).requires_grad_(True)
+    assert nat.mbstd_cat_ok(xd, group, splits, 1, cpad)
+    out = nat.mbstd_cat(xd, group, splits, cpad)
+    (gx,) = torch.autograd.grad(out, xd, gout.to(DEV))
+    assert torch.equal(out[..., :C].cpu(), x) and torch.count_nonzero(out[..., C + 1:]) == 0
+    assert_rel(out[..., C].float().cpu(), ref[..., C].detach(), tol, "statistic")
+    assert_rel(gx.float().cpu(), gref, tol, "gx")
+
+
 def test_producers_leave_sum_of_squares_partials(nat, g_ops):
     """The input statistic of a modulated conv (x.square().mean(), style.py:98-103) taken in the epilogue of the
     kernel that PRODUCES x: dgv2_resample_tab_sq / dgv2_modconv_pe_fwd_sq partials must sum to the sum of squares
