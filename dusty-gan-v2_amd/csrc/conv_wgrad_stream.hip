@@ -379,8 +379,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_bf16_kernel(float* _
 
 // gw[i] = sum_k part[k][i].  256 threads = 16 float4 columns x 16 split lanes: every lane sums its share
 // of the splits with independent loads, LDS folds the 16 lanes.  n is a multiple of 4.
+// scale: factor on the result; kkC > 0: write the PARAMETER's layout [O, C, kh*kw] instead of [O, kh*kw, C]
+// (kkC = kh*kw*C, C = Cc), so that the gradient needs no permute / scale pass before the optimizer sees it.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ gw, const float* __restrict__ part,
-                                                           int64_t n, int nsplit) {
+                                                           int64_t n, int nsplit, float scale = 1.f, int kkC = 0,
+                                                           int Cc = 0) {
   __shared__ float4 red[16][16];
   const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t i = ((int64_t)blockIdx.x * 16 + col) * 4;
@@ -402,7 +405,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ g
       const float4 v = red[k][col];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    *reinterpret_cast<float4*>(gw + i) = s;
+    s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+    if (kkC == 0) {
+      *reinterpret_cast<float4*>(gw + i) = s;
+    } else {
+      const float v4[4] = {s.x, s.y, s.z, s.w};
+      const int kk = kkC / Cc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t lin = i + e;
+        const int64_t o = lin / kkC;
+        const int r = (int)(lin - o * kkC);
+        const int t = r / Cc, c = r - t * Cc;
+        gw[(o * Cc + c) * kk + t] = v4[e];
+      }
+    }
   }
 }
 
@@ -541,6 +558,13 @@ extern "C" int dgv2_bmm_tn_stream(float* gw, float* scratch, int64_t scratch_ele
 extern "C" int dgv2_conv_wgrad_stream(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
                                       int B, int H, int W, int C, int O, int k, int stride, int pad, int ring,
                                       int dtype, void* stream) {
+  return dgv2_conv_wgrad_stream_pl(gw, scratch, scratch_elems, gy, x, B, H, W, C, O, k, stride, pad, ring, 1.f, 0, dtype,
+                                   stream);
+}
+
+extern "C" int dgv2_conv_wgrad_stream_pl(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
+                                         int B, int H, int W, int C, int O, int k, int stride, int pad, int ring,
+                                         float scale, int param_layout, int dtype, void* stream) {
   if (!gw || !scratch || !gy || !x || !aligned16(gy) || !aligned16(x) || !aligned16(scratch) || !aligned16(gw))
     return DGV2_EINVAL;
   if (dtype != DGV2_BF16 && dtype != DGV2_F32) return DGV2_EINVAL;
@@ -554,6 +578,7 @@ extern "C" int dgv2_conv_wgrad_stream(float* gw, float* scratch, int64_t scratch
   if (ring && (p.g.tiles_w * 32 - 1) * stride + k - 1 - pad < 2 * W && pad <= W) p.g.ring = 2;
   rc = dtype == DGV2_BF16 ? ws_dispatch_geom<bf16_t>(scratch, gy, x, p, st) : ws_dispatch_geom<float>(scratch, gy, x, p, st);
   if (rc) return rc;
-  wgrad_reduce_kernel<<<(int)((n / 4 + 15) / 16), 256, 0, st>>>(gw, scratch, n, p.nsplit);
+  wgrad_reduce_kernel<<<(int)((n / 4 + 15) / 16), 256, 0, st>>>(gw, scratch, n, p.nsplit, scale,
+                                                                 param_layout ? k * k * C : 0, C);
   DGV2_RETURN_LAST();
 }

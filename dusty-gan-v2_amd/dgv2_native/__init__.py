@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "dgv2_conv_weight_bank": [_c_ptr] * 8 + [_c_int, _c_int, _c_ptr],
     "dgv2_conv_wgrad_stream_scratch": [_c_ptr] + [_c_int] * 9,
     "dgv2_conv_wgrad_stream": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 10 + [_c_ptr],
+    "dgv2_conv_wgrad_stream_pl": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 9 + [_c_f32, _c_int, _c_int, _c_ptr],
     "dgv2_conv_dgrad": [_c_ptr] * 4 + [_c_int] * 11 + [_c_ptr],
     "dgv2_conv_wgrad": [_c_ptr] * 3 + [_c_int] * 11 + [_c_ptr],
     "dgv2_stem_fwd": [_c_ptr] * 4 + [_c_int] * 5 + [_c_f32, _c_f32, _c_int, _c_ptr],

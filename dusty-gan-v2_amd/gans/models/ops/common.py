@@ -172,7 +172,13 @@ class Conv2d(nn.Sequential):
             p_raw, s_used, cpad_used = self.bank_entry(wscale, pad_in_to)
             if abs(ent[0] - s_used) <= 1e-12 * abs(s_used) and ent[1] == cpad_used:
                 # the kernels read the bank's prepared copies; `w` only carries the autograd edge to the parameter
-                w = native.scaled_handle(p_raw, s_used, cpad_used)
+                if cpad_used == p_raw.shape[1]:
+                    # a free view of the parameter: the weight-gradient kernel writes scale * gw in the parameter's
+                    # own layout, so the permute-backward of this view is the finished gradient (no launch)
+                    w = p_raw.permute(0, 2, 3, 1)
+                    w._dgv2_handle, w._dgv2_gscale = True, float(s_used)
+                else:
+                    w = native.scaled_handle(p_raw, s_used, cpad_used)
                 w._dgv2_wf, w._dgv2_wt = ent[2], ent[3]
                 b, gain = self._params_bias()
             else:

@@ -777,11 +777,21 @@ _TN_SCRATCH = {}
 _LIB_WGRAD = os.environ.get("DGV2_NO_LIB_WGRAD") is None         # A/B switch for benchmarking
 
 
-def _conv_wgrad_raw(gy, x, g):
+def _conv_wgrad_raw(gy, x, g, gscale=None):
+    """gw fp32 [O,kh,kw,C].  gscale: return scale * gw as a PERMUTED VIEW of a contiguous [O,C,kh,kw] buffer (the
+    parameter's layout): the permute-backward of a weight handle then hands the optimizer a contiguous gradient."""
     B, H, W, C = x.shape
     O = gy.shape[3]
     N.check(gy, x)
-    gw = torch.empty((O, g.kh, g.kw, C), device=x.device, dtype=torch.float32)
+    stream_ok = (_WGRAD_STREAM and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2)
+                 and C % (16 // x.element_size()) == 0 and O % (16 // x.element_size()) == 0)
+    if gscale is not None:
+        if not stream_ok:
+            gp = _conv_wgrad_raw(gy, x, g).permute(0, 3, 1, 2)
+            return torch.mul(gp, gscale, out=torch.empty(gp.shape, device=x.device)).permute(0, 2, 3, 1)
+        gw = torch.empty((O, C, g.kh, g.kw), device=x.device, dtype=torch.float32)
+    else:
+        gw = torch.empty((O, g.kh, g.kw, C), device=x.device, dtype=torch.float32)
     if _WGRAD_STREAM and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2) \
             and C % (16 // x.element_size()) == 0 and O % (16 // x.element_size()) == 0:
         key = (B, H, W, C, O, g.kh, g.stride, g.pad, _dt(x))
@@ -790,9 +800,10 @@ def _conv_wgrad_raw(gy, x, g):
             N.call("dgv2_conv_wgrad_stream_scratch", _ct.addressof(n), B, H, W, C, O, g.kh, g.stride, g.pad, _dt(x))
             _WGRAD_SCRATCH[key] = n.value
         scratch = torch.empty(_WGRAD_SCRATCH[key], device=x.device, dtype=torch.float32)
-        N.call("dgv2_conv_wgrad_stream", N.ptr(gw), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(x), B, H, W, C,
-               O, g.kh, g.stride, g.pad, g.ring, _dt(x), N.stream())
-        return gw
+        N.call("dgv2_conv_wgrad_stream_pl", N.ptr(gw), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(x), B, H, W,
+               C, O, g.kh, g.stride, g.pad, g.ring, 1.0 if gscale is None else float(gscale), int(gscale is not None),
+               _dt(x), N.stream())
+        return gw if gscale is None else gw.permute(0, 2, 3, 1)
     small = C % 32 == 0 and C <= _WGRAD_DIRECT_MAXC and O % 8 == 0 and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0))
     if small and g.stride in (1, 2) and (x.dtype == torch.bfloat16 or g.stride == 1):
         # small-channel / large-image layers: halo-tile engine (input staged once for all nine taps)
@@ -817,6 +828,7 @@ class _ConvFwd(Function):
     def forward(ctx, x, w, g):
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
         ctx.save_for_backward(x, w)
@@ -826,13 +838,13 @@ class _ConvFwd(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g) if ctx.needs_input_grad[1] else None
+        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if ctx.needs_input_grad[1] else None
         return gx, gw, None
 
 
-def _dgrad(gy, w, g, xshape, wt=None, resid=None):
-    return _ConvDgrad.apply(gy, w, g, xshape, wt, resid)
+def _dgrad(gy, w, g, xshape, wt=None, resid=None, gscale=None):
+    return _ConvDgrad.apply(gy, w, g, xshape, wt, resid, gscale)
 
 
 class _ConvDgrad(Function):
@@ -840,10 +852,12 @@ class _ConvDgrad(Function):
     the kernel's epilogue instead of by a separate elementwise add over the activation."""
 
     @staticmethod
-    def forward(ctx, gy, w, g, xshape, wt, resid):
+    def forward(ctx, gy, w, g, xshape, wt, resid, gscale=None):
+        """gscale: `w` is a plain view of the parameter whose VALUE the kernels take from the weight bank as
+        gscale * parameter; gradients that flow to `w` carry that factor explicitly."""
         gy = gy.contiguous()
         ctx.save_for_backward(gy, w)
-        ctx.g = g
+        ctx.g, ctx.gscale = g, gscale
         if resid is not None:
             resid = resid.contiguous().to(gy.dtype)
         if wt is not None and wt.dtype == gy.dtype:
@@ -855,25 +869,27 @@ class _ConvDgrad(Function):
     def backward(ctx, ggx):
         gy, w = ctx.saved_tensors
         g_gy = _ConvFwd.apply(ggx, w, ctx.g) if ctx.needs_input_grad[0] else None
-        g_w = _ConvWgrad.apply(gy, ggx, ctx.g) if ctx.needs_input_grad[1] else None
-        return g_gy, g_w, None, None, None, (ggx if ctx.needs_input_grad[5] else None)
+        g_w = _ConvWgrad.apply(gy, ggx, ctx.g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w, None, None, None, (ggx if ctx.needs_input_grad[5] else None), None
 
 
 class _ConvWgrad(Function):
     @staticmethod
-    def forward(ctx, gy, x, g):
+    def forward(ctx, gy, x, g, gscale=None):
         gy = gy.contiguous()
         x = x.contiguous()
         ctx.save_for_backward(gy, x)
-        ctx.g = g
-        return _conv_wgrad_raw(gy.to(x.dtype), x, g)
+        ctx.g, ctx.gscale = g, gscale
+        return _conv_wgrad_raw(gy.to(x.dtype), x, g, gscale)
 
     @staticmethod
     def backward(ctx, ggw):
+        if ctx.gscale is not None:   # out = gscale * wgrad(gy, x)
+            ggw = ggw * ctx.gscale
         gy, x = ctx.saved_tensors
         g_gy = _ConvFwd.apply(x, ggw, ctx.g) if ctx.needs_input_grad[0] else None
         g_x = _dgrad(gy, ggw, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[1] else None
-        return g_gy, g_x, None
+        return g_gy, g_x, None, None
 
 
 def conv_ring(x, w, geom):
@@ -889,6 +905,7 @@ class _ConvAct(Function):
     def forward(ctx, x, w, bias, g, alpha, scale):
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
         out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
@@ -900,11 +917,9 @@ class _ConvAct(Function):
     def backward(ctx, gy):
         x, w, out = ctx.saved_tensors
         g, alpha, scale, size_b = ctx.cfg
-        if gy is None:   # only the sibling branch carries a gradient
-            return gx_sibling, None, None, None, None, None
         gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
-        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gpre, x, g) if ctx.needs_input_grad[1] else None
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None
 
 
@@ -1028,6 +1043,7 @@ class _ConvActFork(Function):
         ctx.set_materialize_grads(False)
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
         out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
@@ -1039,9 +1055,11 @@ class _ConvActFork(Function):
     def backward(ctx, gy, gx_sibling):
         x, w, out = ctx.saved_tensors
         g, alpha, scale, size_b = ctx.cfg
+        if gy is None:   # only the sibling branch carries a gradient
+            return gx_sibling, None, None, None, None, None
         gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
-        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gpre, x, g) if ctx.needs_input_grad[1] else None
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None
 
 
@@ -1058,6 +1076,7 @@ class _ConvResid(Function):
         x = x.contiguous()
         resid = resid.contiguous()
         wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
         ctx.save_for_backward(x, w)
@@ -1067,8 +1086,8 @@ class _ConvResid(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g) if ctx.needs_input_grad[1] else None
+        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if ctx.needs_input_grad[1] else None
         return gx, gw, (gy if ctx.needs_input_grad[2] else None), None
 
 

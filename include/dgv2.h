@@ -329,6 +329,12 @@ int dgv2_conv_wgrad_stream_scratch(int64_t* elems, int B, int H, int W, int C, i
 int dgv2_conv_wgrad_stream(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
                            int B, int H, int W, int C, int O, int k, int stride, int pad, int ring,
                            int dtype, void* stream);
+/* ... writing scale * gw, and with param_layout != 0 in the parameter's own layout [O, C, k, k] (nn.Conv2d weight,
+ * common.py:187-210) instead of [O, k*k, C]: the EqualLR factor and the layout change of the weight gradient cost
+ * no separate pass. */
+int dgv2_conv_wgrad_stream_pl(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
+                              int B, int H, int W, int C, int O, int k, int stride, int pad, int ring,
+                              float scale, int param_layout, int dtype, void* stream);
 
 /* Direct (LDS halo-tile) convolution with a generic tap list -- the hot-path engine for the
  * discriminator convs and their data gradients (same reference lines as dgv2_conv_*):
