@@ -73,12 +73,12 @@ class Head(nn.Module):
         heads = list(self.heads.values())
         bias = torch.cat([head.bias.reshape(-1) for head in heads])
         if heads[0]._prep is not None:   # weights of the whole pass prepared up front (SynthesisNetwork._batched_weights)
-            handle, wb, cvec = heads[0]._prep
+            handle, wb, cvec, wt = heads[0]._prep
             off = 0
             for head in heads:
                 head.update_ema(sumsq, x.numel(), 0.0, cvec[off:off + head.out_ch])
                 off += head.out_ch
-            return native.mod_gemm_layer(x, None, handle, wb, cvec, bias=bias, act=False, out_dtype=torch.float32)
+            return native.mod_gemm_layer(x, None, handle, wb, cvec, bias=bias, act=False, out_dtype=torch.float32, wt=wt)
         mods = [head.prep_args(style, sumsq, x.numel()) for head in heads]
         return native.mod_layer(x, None, mods, bias=bias, act=False, out_dtype=torch.float32)
 
@@ -162,10 +162,10 @@ class SynthesisBlock(nn.Module):
         act = self.bias_act1
         want = want_sq and (self.head.training if self.is_first else self.conv2.training)
         if conv._prep is not None:
-            handle, wb, cvec = conv._prep
+            handle, wb, cvec, wt = conv._prep
             conv.update_ema(sumsq, B * H * W * (cin + self.pe.out_ch), pe_sq, cvec)
             return native.mod_gemm_layer(hup, pe0, handle, wb, cvec, bias=act.bias, act=True, alpha=act.negative_slope,
-                                         scale=act.scale, want_sq=want)
+                                         scale=act.scale, want_sq=want, wt=wt)
         if self.pe.out_ch == 512 and conv.in_ch <= 1024:
             # weight preparation (+ rotation), contraction, bias and lrelu as one autograd node
             mods = [conv.prep_args(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch), sumsq_add=pe_sq)]
@@ -205,10 +205,10 @@ class SynthesisBlock(nn.Module):
             a2 = self.bias_act2
             sumsq = (sq_h if sq_h is not None else native.sum_squares(h)) if self.conv2.training else None
             if self.conv2._prep is not None:
-                handle, wb, cvec = self.conv2._prep
+                handle, wb, cvec, wt = self.conv2._prep
                 self.conv2.update_ema(sumsq, h.numel(), 0.0, cvec)
                 h = native.mod_gemm_layer(h, None, handle, wb, cvec, bias=a2.bias, act=True, alpha=a2.negative_slope,
-                                          scale=a2.scale, want_sq=self.head.training)
+                                          scale=a2.scale, want_sq=self.head.training, wt=wt)
             else:
                 h = native.mod_layer(h, None, [self.conv2.prep_args(ws[1], sumsq, h.numel())], bias=a2.bias,
                                      act=True, alpha=a2.negative_slope, scale=a2.scale, want_sq=self.head.training)
@@ -328,12 +328,12 @@ class SynthesisNetwork(nn.Module):
             if not blk.is_first:
                 convs.append((blk.conv2, 0, None))
             for conv, cin, f in convs:
-                groups.append(dict(Otot=conv.out_ch, I=conv.in_ch, dtype=dt))
+                groups.append(dict(Otot=conv.out_ch, I=conv.in_ch, dtype=dt, Ka=cin if conv is blk.conv1 else conv.in_ch))
                 layers.append(dict(W=conv.weight.reshape(conv.out_ch, conv.in_ch), s=conv._style_cache, O=conv.out_ch,
                                    I=conv.in_ch, demod=bool(conv.demod), cin=cin, fw=f, group=len(groups) - 1,
                                    row_off=0, mod=conv))
             heads = list(blk.head.heads.values())
-            groups.append(dict(Otot=sum(h.out_ch for h in heads), I=heads[0].in_ch, dtype=dt))
+            groups.append(dict(Otot=sum(h.out_ch for h in heads), I=heads[0].in_ch, dtype=dt, Ka=heads[0].in_ch))
             off = 0
             for h in heads:
                 layers.append(dict(W=h.weight.reshape(h.out_ch, h.in_ch), s=h._style_cache, O=h.out_ch, I=h.in_ch,
@@ -348,9 +348,9 @@ class SynthesisNetwork(nn.Module):
             coff.append(coff[-1] + g["Otot"])
         for m, mod in zip(layers, modules):
             k = m["group"]
-            handle, wb = prepared[k]
+            handle, wb, wt = prepared[k]
             # single-layer groups see their own rows; the heads of a block share the group's vector
-            mod._prep = (handle, wb, cflat[coff[k]:coff[k + 1]])
+            mod._prep = (handle, wb, cflat[coff[k]:coff[k + 1]], wt)
 
     def _batched_styles(self, ws):
         """All style affines (EqualLR Linear of every ModConv2d on the fused path) as one batched GEMM; each

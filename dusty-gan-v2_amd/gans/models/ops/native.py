@@ -1501,8 +1501,18 @@ class _ModPrepAll(Function):
         ctx.meta, ctx.ints, ctx.B, ctx.rot = meta, ints, B, rot
         ctx.save_for_backward(shift, stats, dflat, rot_tab, *Ws, *Ss)
         handles = [torch.empty(1, device=dev, dtype=torch.float32).expand(B, g["Otot"], g["I"]) for g in meta["groups"]]
-        ctx.mark_non_differentiable(*wbs)
-        return (*handles, *wbs)
+        # operands of the data gradients, [B, Ka, Otot] = the first Ka input columns transposed: one launch for all
+        wts = [torch.empty((B, g.get("Ka", 0), g["Otot"]) if (meta["want_wt"] and g.get("Ka", 0) > 0) else (0,),
+                           device=dev, dtype=g["dtype"]) for g in meta["groups"]]
+        idx = [k for k, t in enumerate(wts) if t.numel() > 0]
+        for es in (2, 4):
+            sel = [k for k in idx if wts[k].element_size() == es]
+            if sel:
+                N.call("dgv2_transpose_list", _ptr_array([wts[k] for k in sel]), _ptr_array([wbs[k] for k in sel]),
+                       _int_array([meta["groups"][k]["Otot"] for k in sel]), _int_array([meta["groups"][k]["Ka"] for k in sel]),
+                       _int_array([meta["groups"][k]["I"] for k in sel]), len(sel), B, es, N.stream())
+        ctx.mark_non_differentiable(*wbs, *wts)
+        return (*handles, *wbs, *wts)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -1545,13 +1555,16 @@ class _ModPrepAll(Function):
 def mod_prep_all(layers, groups, shift):
     """layers: list of dict(W, s, O, I, demod, cin, fw, group, row_off); groups: list of dict(Otot, I, dtype).
     -> [(handle, prepared weights)] per group (see _ModPrepAll)."""
-    meta = dict(layers=[{k: v for k, v in m.items() if k not in ("W", "s")} for m in layers], groups=groups)
+    want_wt = torch.is_grad_enabled() and any(m["W"].requires_grad or m["s"].requires_grad for m in layers)
+    meta = dict(layers=[{k: v for k, v in m.items() if k not in ("W", "s")} for m in layers], groups=groups,
+                want_wt=want_wt)
     flat = []
     for m in layers:
         flat += [m["W"], m["s"]]
     out = _ModPrepAll.apply(meta, shift, *flat)
     ng = len(groups)
-    return list(zip(out[:ng], out[ng:]))
+    wts = [t if t.numel() > 0 else None for t in out[2 * ng:]]
+    return list(zip(out[:ng], out[ng:2 * ng], wts))
 
 
 class _ModGemmPrepared(Function):
@@ -1559,7 +1572,7 @@ class _ModGemmPrepared(Function):
     the gradient dL/dwb back to the batched preparation, c (fp32 [Otot], no gradient) is the layers' output factor."""
 
     @staticmethod
-    def forward(ctx, cfg, xa, xs, bias, handle, wb, cvec):
+    def forward(ctx, cfg, xa, xs, bias, handle, wb, cvec, wt=None):
         ctx.set_materialize_grads(False)
         ref = xa if xa is not None else xs
         dt = ref.dtype
@@ -1589,7 +1602,7 @@ class _ModGemmPrepared(Function):
             out = _bmm_nn_raw(xa.reshape(B, P, I), wb, odt, bias32, act, cfg["alpha"], cfg["scale"], sq=sq,
                               row_scale=cvec).reshape(B, H, W_, Otot)
         ctx.cfg = dict(cfg, has_bias=bias is not None)
-        ctx.save_for_backward(xa, xs, wb, out if cfg["act"] else None, cvec)
+        ctx.save_for_backward(xa, xs, wb, out if cfg["act"] else None, cvec, wt)
         if cfg["want_sq"]:
             part = sq[0][:sq[1].value] if (sq is not None and sq[1].value > 0) else sum_squares(out)
             ctx.mark_non_differentiable(part)
@@ -1600,8 +1613,8 @@ class _ModGemmPrepared(Function):
     def backward(ctx, gy, _=None):
         cfg = ctx.cfg
         if gy is None:
-            return (None,) * 7
-        xa, xs, wb, out, cvec = ctx.saved_tensors
+            return (None,) * 8
+        xa, xs, wb, out, cvec, wt = ctx.saved_tensors
         B, Otot, I = wb.shape
         dt = wb.dtype
         gy = gy.contiguous()
@@ -1634,12 +1647,13 @@ class _ModGemmPrepared(Function):
         Ka = 0 if xa is None else xa.shape[3]
         gxa = None
         if xa is not None and ctx.needs_input_grad[1]:
-            wt = wb[:, :, :Ka].transpose(1, 2).contiguous()
+            if wt is None:
+                wt = wb[:, :, :Ka].transpose(1, 2).contiguous()
             gxa = _bmm_nn_raw(g3, wt, xa.dtype).reshape(xa.shape)
         gwb = None
         if ctx.needs_input_grad[4]:
             gwb = _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt)
-        return None, gxa, None, gb, gwb, None, None
+        return None, gxa, None, gb, gwb, None, None, None
 
 
 def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
@@ -1668,10 +1682,10 @@ def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
 
 
 def mod_gemm_layer(xa, xs, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=None,
-                   want_sq=False):
+                   want_sq=False, wt=None):
     """The contraction of a modulated layer whose weights came from mod_prep_all (handle, wb) and whose
     input-magnitude factor is cvec fp32 [Otot] (native.ema_update(..., cvec=...))."""
     ref = xa if xa is not None else xs
     cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0,
                out_dtype=ref.dtype if out_dtype is None else out_dtype, want_sq=bool(want_sq))
-    return _ModGemmPrepared.apply(cfg, xa, xs, bias, handle, wb, cvec)
+    return _ModGemmPrepared.apply(cfg, xa, xs, bias, handle, wb, cvec, wt)

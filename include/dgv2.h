@@ -258,6 +258,13 @@ int dgv2_mod_prep_all_bwd(float* flat, int64_t flat_elems, float* const* out, co
                           const int* row_off, const int* cin, const int* flags, const float* shift, int B,
                           int L, void* stream);
 
+/* Batched transposes in one launch: dst[l][b, c, r] = src[l][b, r, c] (r < rows[l], c < cols[l], source leading
+ * dimension ld[l]); HOST arrays of L <= 32 device pointers, elem_size 2 or 4 bytes.  Produces the operands of all
+ * modulated layers' data gradients (contraction over the output channels of the per-sample weights [B, O, I])
+ * up front instead of one strided copy per layer in backward (ModConv2d autograd, style.py:105-118). */
+int dgv2_transpose_list(void* const* dst, const void* const* src, const int* rows, const int* cols,
+                        const int* ld, int L, int B, int elem_size, void* stream);
+
 /* Sum of squares of the first C channels of x [N, ld] into acc[0] (fp32, ACCUMULATES).
  * replaces: x.pow(2).mean() in ModConv2d.forward (style.py:100-101). */
 int dgv2_sum_squares(float* acc, const void* x, int64_t N, int C, int ld, int dtype, void* stream);

@@ -275,15 +275,18 @@ def test_batched_weight_preparation_matches_per_layer_path(nat, dtype, tol):
               dict(W=Ws[1], s=Ss[1], O=24, I=32, demod=True, cin=0, fw=None, group=1, row_off=0),
               dict(W=Ws[2], s=Ss[2], O=1, I=24, demod=False, cin=0, fw=None, group=2, row_off=0),
               dict(W=Ws[3], s=Ss[3], O=2, I=24, demod=False, cin=0, fw=None, group=2, row_off=1)]
-    groups = [dict(Otot=32, I=cin + 2 * F, dtype=dtype), dict(Otot=24, I=32, dtype=dtype), dict(Otot=3, I=24, dtype=dtype)]
+    groups = [dict(Otot=32, I=cin + 2 * F, dtype=dtype, Ka=cin), dict(Otot=24, I=32, dtype=dtype, Ka=32),
+              dict(Otot=3, I=24, dtype=dtype)]   # the last group leaves the transposed operand to the backward
     prepared = nat.mod_prep_all(layers, groups, shift)
 
     def cvec(vals):
         return torch.cat([(1.0 / (torch.sqrt(e) + 1e-8)).expand(n) for e, n in vals]).contiguous()
 
-    z0 = nat.mod_gemm_layer(xa0, pe, *prepared[0], cvec([(evs[0], 32)]), bias=b0, act=True)
-    z1 = nat.mod_gemm_layer(x1, None, *prepared[1], cvec([(evs[1], 24)]), bias=b1, act=True)
-    z2 = nat.mod_gemm_layer(x2, None, *prepared[2], cvec([(evs[2], 1), (evs[3], 2)]), bias=b2, act=False,
+    assert prepared[0][2].shape == (B, cin, 32) and prepared[2][2] is None
+    assert torch.equal(prepared[1][2], prepared[1][1].transpose(1, 2))
+    z0 = nat.mod_gemm_layer(xa0, pe, *prepared[0][:2], cvec([(evs[0], 32)]), bias=b0, act=True, wt=prepared[0][2])
+    z1 = nat.mod_gemm_layer(x1, None, *prepared[1][:2], cvec([(evs[1], 24)]), bias=b1, act=True, wt=prepared[1][2])
+    z2 = nat.mod_gemm_layer(x2, None, *prepared[2][:2], cvec([(evs[2], 1), (evs[3], 2)]), bias=b2, act=False,
                             out_dtype=torch.float32)
     got_grads = torch.autograd.grad(loss(z0, z1, z2), leaves)
     for r, z, name in zip(ref_out, (z0, z1, z2), ("conv+PE", "conv", "heads")):
