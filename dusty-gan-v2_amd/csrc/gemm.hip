@@ -7,14 +7,14 @@ namespace {
 template <typename T, typename TY, int TO>
 int launch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
                   int64_t wstride, const float* bias, int act, float alpha, float scale, hipStream_t st, float* sumsq,
-                  int sumsq_cap, int* sumsq_used, const float* row_scale) {
+                  int sumsq_cap, int* sumsq_used, const float* row_scale, const void* resid) {
   constexpr int CE = 16 / sizeof(T);
   DenseRowLoader<T> al{(const T*)w, wstride, I, O, I, (I % CE == 0) && (wstride % CE == 0) && aligned16(w)};
   DenseRowLoader<T> bl{(const T*)x, (int64_t)P * ldx, ldx, P, I, (ldx % CE == 0) && aligned16(x)};
   constexpr int YE = 16 / sizeof(TY);
   StoreEpilogue<TY> epi{(TY*)y, (int64_t)P * ldy, ldy, O, P,
                         (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & (4 * sizeof(TY) - 1)) == 0),
-                        bias, act, alpha, scale, nullptr, 0.f, row_scale};
+                        bias, act, alpha, scale, nullptr, 0.f, row_scale, (const TY*)resid};
   (void)YE;
   dim3 grid((P + 127) / 128, (O + TO - 1) / TO, B);
   const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
@@ -29,11 +29,11 @@ int launch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, in
 template <typename T, typename TY>
 int dispatch_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
                     int64_t wstride, const float* bias, int act, float alpha, float scale, hipStream_t st, float* sumsq,
-                    int sumsq_cap, int* sumsq_used, const float* row_scale) {
-  if (O <= 16) return launch_bmm_nn<T, TY, 16>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
-  if (O <= 32) return launch_bmm_nn<T, TY, 32>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
-  if (O <= 64) return launch_bmm_nn<T, TY, 64>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
-  return launch_bmm_nn<T, TY, 128>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+                    int sumsq_cap, int* sumsq_used, const float* row_scale, const void* resid) {
+  if (O <= 16) return launch_bmm_nn<T, TY, 16>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale, resid);
+  if (O <= 32) return launch_bmm_nn<T, TY, 32>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale, resid);
+  if (O <= 64) return launch_bmm_nn<T, TY, 64>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale, resid);
+  return launch_bmm_nn<T, TY, 128>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale, resid);
 }
 
 template <typename T, int TO, int TJ>
@@ -96,23 +96,24 @@ int launch_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs,
 extern "C" int dgv2_bmm_nn(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
                            int64_t wstride, const float* bias, int act, float alpha, float scale, int dtype,
                            int ydtype, void* stream) {
-  return dgv2_bmm_nn_sq(y, x, w, B, P, I, O, ldx, ldy, wstride, nullptr, bias, act, alpha, scale, dtype, ydtype, nullptr, 0,
-                        nullptr, stream);
+  return dgv2_bmm_nn_sq(y, x, w, B, P, I, O, ldx, ldy, wstride, nullptr, bias, act, alpha, scale, nullptr, dtype, ydtype,
+                        nullptr, 0, nullptr, stream);
 }
 
 extern "C" int dgv2_bmm_nn_sq(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
-                              int64_t wstride, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype,
-                              int ydtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream) {
+                              int64_t wstride, const float* row_scale, const float* bias, int act, float alpha,
+                              float scale, const void* resid, int dtype, int ydtype, float* sumsq, int sumsq_cap,
+                              int* sumsq_used, void* stream) {
   if (sumsq_used) *sumsq_used = 0;
   if (!y || !x || !w || B <= 0 || P <= 0 || I <= 0 || O <= 0 || ldx < I || ldy < O) return DGV2_EINVAL;
   if (act != 0 && act != 3) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DGV2_F32 && ydtype == DGV2_F32)
-    dispatch_bmm_nn<float, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+    dispatch_bmm_nn<float, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale, resid);
   else if (dtype == DGV2_BF16 && ydtype == DGV2_BF16)
-    dispatch_bmm_nn<bf16_t, bf16_t>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+    dispatch_bmm_nn<bf16_t, bf16_t>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale, resid);
   else if (dtype == DGV2_BF16 && ydtype == DGV2_F32)
-    dispatch_bmm_nn<bf16_t, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale);
+    dispatch_bmm_nn<bf16_t, float>(y, x, w, B, P, I, O, ldx, ldy, wstride, bias, act, alpha, scale, st, sumsq, sumsq_cap, sumsq_used, row_scale, resid);
   else
     return DGV2_EINVAL;
   DGV2_RETURN_LAST();

@@ -277,6 +277,7 @@ template <typename TY> struct StoreEpilogue {
   float* sumsq;       // optional: per-block partial sums of squares of the stored (rounded) outputs
   float ss;           // this thread's running sum (kernel-private state, initialise to 0)
   const float* row_scale;  // optional fp32 [M]: y = act(acc * row_scale[m] + bias[m])
+  const TY* resid;         // optional, same layout as y: added to the result (after the activation)
   __device__ __forceinline__ void operator()(int batch, int m, int n, f32x4 acc) {
     if (n >= N || m >= M) return;
     if (row_scale) {
@@ -294,6 +295,25 @@ template <typename TY> struct StoreEpilogue {
       }
     }
     TY* p = y + batch * batch_stride + (int64_t)n * ld + m;
+    if (resid) {
+      const TY* rp = resid + batch * batch_stride + (int64_t)n * ld + m;
+      if (vec && m + 3 < M) {   // one 8- or 16-byte load (resid shares y's layout and alignment)
+        if constexpr (sizeof(TY) == 4) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += rv[r];
+        } else {
+          union { uint2 u; bf16_t e[4]; } rv;
+          rv.u = *reinterpret_cast<const uint2*>(rp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += (float)rv.e[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (m + r < M) acc[r] += to_f32(rp[r]);
+      }
+    }
     if (sumsq) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)

@@ -65,7 +65,7 @@ class Head(nn.Module):
             self.heads[o["name"]] = ops.ModConv2d(out_ch=o["ch"], in_ch=in_ch, mod_ch=mod_ch, ksize=1, stride=1,
                                                   padding=0, demod=False, ema=True)
 
-    def forward_cl(self, x, style, sumsq=None):
+    def forward_cl(self, x, style, sumsq=None, fork=False):
         """x [B,H,W,C] -> fp32 [B,H,W,sum(ch)] (heads concatenated in dict order); sumsq = partial sums of
         squares of x when its producer already took them."""
         if sumsq is None and self.training:
@@ -78,7 +78,10 @@ class Head(nn.Module):
             for head in heads:
                 head.update_ema(sumsq, x.numel(), 0.0, cvec[off:off + head.out_ch])
                 off += head.out_ch
-            return native.mod_gemm_layer(x, None, handle, wb, cvec, bias=bias, act=False, out_dtype=torch.float32, wt=wt)
+            # fork: also return x for the NEXT consumer (the following block), so that both gradients of x meet in
+            # this layer's data-gradient GEMM
+            return native.mod_gemm_layer(x, None, handle, wb, cvec, bias=bias, act=False, out_dtype=torch.float32, wt=wt,
+                                         fork=fork)
         mods = [head.prep_args(style, sumsq, x.numel()) for head in heads]
         return native.mod_layer(x, None, mods, bias=bias, act=False, out_dtype=torch.float32)
 
@@ -216,7 +219,9 @@ class SynthesisBlock(nn.Module):
             if isinstance(h, tuple):
                 h, sq_h = h
             nxt = 2
-        o = self.head.forward_cl(h, ws[nxt], sumsq=sq_h)
+        o = self.head.forward_cl(h, ws[nxt], sumsq=sq_h, fork=True)
+        if isinstance(o, tuple):
+            o, h = o
         if skip is not None:
             o = o + self.resample.forward_cl(skip)
         return h, o

@@ -470,14 +470,14 @@ def up_cat_pe(h, spec, angle, shift, freqs2, phase, dtype, B):
 # batched channel GEMM = contraction of the modulated 1x1 conv
 # (reference: grouped F.conv2d in ModConv2d.forward, gans/models/ops/style.py:105-118)
 # ---------------------------------------------------------------------------------------
-def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=None, row_scale=None):
+def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=None, row_scale=None, resid=None):
     """x3 [B,P,I]; w3 [Bw,O,I] (Bw = B or 1) same dtype -> [B,P,O]; optional fused
     bias (fp32 [O]) + leaky-ReLU epilogue.  sq = _sq_args(): sum-of-squares partials where the kernel has them."""
     B, P, I = x3.shape
     Bw, O, _ = w3.shape
     N.check(x3, w3, bias)
     y = torch.empty((B, P, O), device=x3.device, dtype=out_dtype)
-    if (_PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and P >= 4096
+    if (resid is None and _PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and P >= 4096
             and (I, O) in ((64, 32), (32, 64), (128, 64), (64, 128), (32, 32), (64, 64))):
         # streaming shapes of the two top levels: sample-walking kernel (DESIGN.md section 5.3) without a PE part
         if sq is not None or row_scale is not None:
@@ -488,10 +488,13 @@ def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=No
         N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(bias), act, alpha,
                scale, _dt(x3), N.stream())
         return y
-    if sq is not None or row_scale is not None:
+    if sq is not None or row_scale is not None or resid is not None:
+        if resid is not None:
+            resid = resid.contiguous().to(out_dtype)
+            N.check(resid)
         N.call("dgv2_bmm_nn_sq", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
-               N.ptr(row_scale), N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.ptr(sq[0]) if sq else None,
-               _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
+               N.ptr(row_scale), N.ptr(bias), act, alpha, scale, N.ptr(resid), _dt(x3), N.dtype_code(y),
+               N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
         return y
     N.call("dgv2_bmm_nn", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
            N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.stream())
@@ -1603,17 +1606,21 @@ class _ModGemmPrepared(Function):
                               row_scale=cvec).reshape(B, H, W_, Otot)
         ctx.cfg = dict(cfg, has_bias=bias is not None)
         ctx.save_for_backward(xa, xs, wb, out if cfg["act"] else None, cvec, wt)
+        outs = [out]
         if cfg["want_sq"]:
             part = sq[0][:sq[1].value] if (sq is not None and sq[1].value > 0) else sum_squares(out)
             ctx.mark_non_differentiable(part)
-            return out, part
-        return out
+            outs.append(part)
+        if cfg["fork"]:   # hand the input on to a sibling consumer: its gradient then arrives HERE and is added in
+            outs.append(xa.view_as(xa))   # the epilogue of this layer's data-gradient GEMM (no fork-point add)
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     @staticmethod
-    def backward(ctx, gy, _=None):
+    def backward(ctx, gy, *rest):
         cfg = ctx.cfg
+        g_sib = rest[-1] if cfg["fork"] else None
         if gy is None:
-            return (None,) * 8
+            return (None, g_sib) + (None,) * 6
         xa, xs, wb, out, cvec, wt = ctx.saved_tensors
         B, Otot, I = wb.shape
         dt = wb.dtype
@@ -1649,7 +1656,9 @@ class _ModGemmPrepared(Function):
         if xa is not None and ctx.needs_input_grad[1]:
             if wt is None:
                 wt = wb[:, :, :Ka].transpose(1, 2).contiguous()
-            gxa = _bmm_nn_raw(g3, wt, xa.dtype).reshape(xa.shape)
+            gxa = _bmm_nn_raw(g3, wt, xa.dtype, resid=None if g_sib is None else g_sib.reshape(B, P, Ka)).reshape(xa.shape)
+        elif g_sib is not None:
+            gxa = g_sib
         gwb = None
         if ctx.needs_input_grad[4]:
             gwb = _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt)
@@ -1682,10 +1691,11 @@ def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
 
 
 def mod_gemm_layer(xa, xs, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=None,
-                   want_sq=False, wt=None):
+                   want_sq=False, wt=None, fork=False):
     """The contraction of a modulated layer whose weights came from mod_prep_all (handle, wb) and whose
     input-magnitude factor is cvec fp32 [Otot] (native.ema_update(..., cvec=...))."""
     ref = xa if xa is not None else xs
     cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0,
-               out_dtype=ref.dtype if out_dtype is None else out_dtype, want_sq=bool(want_sq))
+               out_dtype=ref.dtype if out_dtype is None else out_dtype, want_sq=bool(want_sq),
+               fork=bool(fork and xa is not None and xa.requires_grad))
     return _ModGemmPrepared.apply(cfg, xa, xs, bias, handle, wb, cvec, wt)

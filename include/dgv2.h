@@ -176,7 +176,8 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
  * y = act(acc * row_scale[o] + bias[o]) (row_scale fp32 [O] or NULL) -- the input-magnitude factor of
  * ModConv2d (style.py:98-103) when the weights were prepared by dgv2_mod_prep_all_fwd. */
 int dgv2_bmm_nn_sq(void* y, const void* x, const void* w, int B, int P, int I, int O, int ldx, int ldy,
-                   int64_t wstride, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
+                   int64_t wstride, const float* row_scale, const float* bias, int act, float alpha, float scale,
+                   const void* resid /* optional [B,P,ldy] in ydtype, added to the result */, int dtype, int ydtype,
                    float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 int dgv2_bmm_nn_cat_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
                        int O, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,

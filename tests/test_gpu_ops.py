@@ -386,8 +386,13 @@ def test_producers_leave_sum_of_squares_partials(nat, g_ops):
                    8192, ctypes.addressof(used), N.stream())
         else:
             N.call("dgv2_bmm_nn", N.ptr(y0), N.ptr(xa), N.ptr(w), B, P, Ka, O, Ka, O, O * Ka, *tail, N.stream())
-            N.call("dgv2_bmm_nn_sq", N.ptr(y1), N.ptr(xa), N.ptr(w), B, P, Ka, O, Ka, O, O * Ka, None, *tail, N.ptr(buf), 8192,
-                   ctypes.addressof(used), N.stream())
+            N.call("dgv2_bmm_nn_sq", N.ptr(y1), N.ptr(xa), N.ptr(w), B, P, Ka, O, Ka, O, O * Ka, None, *tail[:4], None, *tail[4:],
+                   N.ptr(buf), 8192, ctypes.addressof(used), N.stream())
+            # residual operand: added after the activation, the statistic covers what was stored
+            y3 = torch.empty_like(y0)
+            N.call("dgv2_bmm_nn_sq", N.ptr(y3), N.ptr(xa), N.ptr(w), B, P, Ka, O, Ka, O, O * Ka, None, *tail[:4], N.ptr(y0),
+                   *tail[4:], None, 0, None, N.stream())
+            assert_rel(y3.float().cpu(), 2 * y0.float().cpu(), 8e-3, "resid")
         assert torch.equal(y0, y1) and used.value > 0
         want = y1.double().square().sum().item()
         assert abs(buf[:used.value].double().sum().item() - want) <= 1e-5 * want
