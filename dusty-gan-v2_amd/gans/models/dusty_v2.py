@@ -585,7 +585,8 @@ class Discriminator(nn.Module):
         if edt == LOW and lin1.module.bias is None and lin1.gain_ == 1.0:
             # "everything reduced": the 65536 -> 512 Linear (8.6 GFLOP at B = 128, 134 MB of fp32 weights) as a
             # bf16 hipBLASLt GEMM with fp32 accumulation, like the autocast path of the reference's AMP mode
-            x = F.linear(x, lin1.module.weight.to(LOW)).float() * lin1.scale
+            x = native.linear_low(x, lin1.module.weight, lin1.scale) if x.is_cuda else \
+                F.linear(x, lin1.module.weight.to(LOW)).float() * lin1.scale
         else:
             x = lin1(x.float())
         x = act2.forward_cl(x)

@@ -926,6 +926,38 @@ class _ConvAct(Function):
         return gx, gw, gb, None, None, None
 
 
+class _LinearLow(Function):
+    """y = (x @ W^T) * scale with bf16 operands and fp32 accumulation / output (the 65536 -> 512 Linear of the
+    discriminator epilogue in "everything reduced" mode, dusty_v2.py:381-383 under the reference's AMP autocast).
+    Plain library GEMMs; the point of the Function is what it does NOT launch: the weight is cast once per pass and
+    reused by the backward, and the weight gradient leaves the GEMM in fp32 (no bf16 -> fp32 pass over 33.5 M values)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale):
+        x16 = x.to(torch.bfloat16)
+        w16 = weight.detach().to(torch.bfloat16)
+        y = torch.mm(x16, w16.t(), out_dtype=torch.float32)
+        y.mul_(scale)
+        ctx.save_for_backward(x, weight, w16)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, w16 = ctx.saved_tensors
+        if torch.is_grad_enabled():   # create_graph=True: the same gradients from differentiable ops
+            g16 = (gy * ctx.scale).to(torch.bfloat16)
+            return g16 @ weight.to(torch.bfloat16), (g16.t() @ x.to(torch.bfloat16)).float(), None
+        g16 = torch.mul(gy, ctx.scale).to(torch.bfloat16)
+        gx = torch.mm(g16, w16) if ctx.needs_input_grad[0] else None
+        gw = torch.mm(g16.t(), x.to(torch.bfloat16), out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+def linear_low(x, weight, scale):
+    return _LinearLow.apply(x, weight, float(scale))
+
+
 class _MbstdCat(Function):
     """[x | minibatch-stddev statistic | zero padding] (dgv2_mbstd_cat_fwd/_bwd): MinibatchStdDev + concat of the
     discriminator epilogue (common.py:226-250) in two launches forward and one backward; first order only."""
