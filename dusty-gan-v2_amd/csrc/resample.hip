@@ -245,12 +245,17 @@ constexpr int RS_RB = 4;
 
 // EW = taps per output column the table can hold (1..4): the horizontal pass is unrolled to exactly that many
 // loads / FMA groups (an up-2 FIR has 2, a blur 4)
-template <typename T, int EW>
+// ACT: the output is a gradient that continues through a fused bias + leaky-ReLU (the discriminator's conv1 ->
+// FusedLeakyReLU -> blur/down chain run backwards): store acc * (ref > 0 ? 1 : alpha) * ascale (ref = the forward
+// OUTPUT of that activation, laid out like y) and leave per-block column sums of the stored values in bias_partial
+// [gridDim.x, C] for the bias gradient -- FusedLeakyReLUFunctionBackward (fused_act.py:22-45) without its own pass.
+template <typename T, int EW, bool ACT = false>
 __global__ __launch_bounds__(256) void resample_stream_kernel(
     T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
     const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
     const int* __restrict__ cnt_w, int Ew, int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
-    int SHA, float* __restrict__ sumsq) {
+    int SHA, float* __restrict__ sumsq, const T* __restrict__ ref = nullptr, float alpha = 1.f, float ascale = 1.f,
+    float* __restrict__ bias_partial = nullptr) {
   const int SH = SHA & 0xffff, ablate = SHA >> 16;   // ablate: benchmarking only (DGV2_RS_ABLATE)
   __shared__ float red[16];
   float ss = 0.f;   // sum of squares of what this thread stores (sumsq != nullptr: one partial per block)
@@ -287,6 +292,10 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
   }
   const T* xb = x + (int64_t)b * in_h * in_w * ldx;
   T* yp = y + (int64_t)b * out_h * out_w * ldy + (int64_t)wo * ldy + cv * VN;
+  const T* rp = ACT ? ref + (int64_t)b * out_h * out_w * ldy + (int64_t)wo * ldy + cv * VN : nullptr;
+  float bsum[VN];   // ACT: this thread's column sums of what it stores
+#pragma unroll
+  for (int j = 0; j < VN; ++j) bsum[j] = 0.f;
   const int ho0 = strip * SH;
   const int ho1 = min(ho0 + SH, out_h);
   int t0 = -1, t1 = -1, t2 = -1, t3 = -1;   // ring tags (block-uniform)
@@ -354,8 +363,18 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
     }
     if (live && !((ablate & 1) && acc[0] != 12345.678f)) {
       vec16<T> o;
+      if constexpr (ACT) {
+        vec16<T> f;
+        f.load(rp + (int64_t)ho * out_w * ldy);
 #pragma unroll
-      for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
+        for (int j = 0; j < VN; ++j) {
+          o.set(j, (f.get(j) > 0.f ? acc[j] : acc[j] * alpha) * ascale);
+          bsum[j] += o.get(j);   // the reference sums the rounded gradient
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
+      }
       o.store(yp + (int64_t)ho * out_w * ldy);
       if (sumsq) {
 #pragma unroll
@@ -366,6 +385,23 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
   if (sumsq) {
     const float s = block_sum(ss, red);
     if (tid == 0) sumsq[blockIdx.x] = s;
+  }
+  if constexpr (ACT) {
+    // threads with the same channel vector are cvecs apart (cvecs divides 256, host-checked): fold them through LDS,
+    // one thread per channel writes this block's slot
+    float* fold = reinterpret_cast<float*>(&ring[0][0]);   // the ring is dead by now: 256 * VN floats fit
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VN; ++j) fold[tid * VN + j] = live ? bsum[j] : 0.f;
+    __syncthreads();
+    const int off = (cb * 256) % cvecs;   // channel vector of thread 0 in this column block
+    for (int c = tid; c < C; c += 256) {
+      const int v = c / VN, j = c - v * VN;
+      // threads t with (off + t) % cvecs == v
+      float s2 = 0.f;
+      for (int t = (v - off + cvecs) % cvecs; t < 256; t += cvecs) s2 += fold[t * VN + j];
+      bias_partial[(int64_t)blockIdx.x * C + c] = s2;
+    }
   }
 }
 
@@ -381,7 +417,65 @@ void rs_launch(int Ew, int blocks, hipStream_t st, T* y, const T* x, const int* 
   }
 }
 
+template <typename T>
+void rs_launch_act(int Ew, int blocks, hipStream_t st, T* y, const T* x, const int* idx_h, const float* coef_h,
+                   const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int B, int C,
+                   int ldx, int ldy, int in_h, int in_w, int out_h, int out_w, int sha, const T* ref, float alpha,
+                   float ascale, float* partial) {
+  switch (Ew) {
+    case 1: resample_stream_kernel<T, 1, true><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha, nullptr, ref, alpha, ascale, partial); break;
+    case 2: resample_stream_kernel<T, 2, true><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha, nullptr, ref, alpha, ascale, partial); break;
+    case 3: resample_stream_kernel<T, 3, true><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha, nullptr, ref, alpha, ascale, partial); break;
+    default: resample_stream_kernel<T, 4, true><<<blocks, 256, 0, st>>>(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w, sha, nullptr, ref, alpha, ascale, partial); break;
+  }
+}
+
+// gb[c] = sum_blk partial[blk][c] (one wave per channel)
+__global__ __launch_bounds__(256) void rs_bias_reduce_kernel(float* __restrict__ gb, const float* __restrict__ partial,
+                                                             int nblk, int C) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float s = 0.f;
+#pragma unroll 4
+  for (int k = threadIdx.x & 63; k < nblk; k += 64) s += partial[(int64_t)k * C + c];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) gb[c] = s;
+}
+
 }  // namespace
+
+// Resampling (normally the ADJOINT tables of a blur/down) followed by the backward of a fused bias + leaky-ReLU:
+//   y = R(x) * (ref > 0 ? 1 : alpha) * scale,   gb[c] = sum of y over everything but the channel   (fp32 [C])
+// ref: forward output of the activation, [B, out_h, out_w, C] contiguous like y (ldy == C).  scratch: fp32
+// [>= blocks * C] with blocks = *blocks_needed reported when scratch is NULL (query call: nothing is launched).
+// Returns DGV2_ENOTSUP when the streaming kernel does not cover the geometry (callers run dgv2_resample_tab and
+// dgv2_bias_act_bwd).  replaces: Resample adjoint (common.py:105-135) + FusedLeakyReLUFunctionBackward
+// (fused_act.py:22-45) of the discriminator's conv1 -> activation -> blur/down chain (dusty_v2.py:325-345).
+extern "C" int dgv2_resample_tab_actbwd(void* y, float* gb, float* scratch, int64_t scratch_elems, int64_t* blocks_needed,
+                                        const void* x, const void* ref, const int* idx_h, const float* coef_h,
+                                        const int* cnt_h, int Eh, const int* idx_w, const float* coef_w,
+                                        const int* cnt_w, int Ew, int B, int C, int in_h, int in_w, int out_h,
+                                        int out_w, float alpha, float scale, int dtype, void* stream) {
+  if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || Eh <= 0 || Ew <= 0) return DGV2_EINVAL;
+  const int vn = dtype == DGV2_BF16 ? 8 : (dtype == DGV2_F32 ? 4 : 0);
+  if (!vn) return DGV2_EINVAL;
+  if (C % vn || 256 % (C / vn) || Ew > 4 || Eh > 64) return DGV2_ENOTSUP;
+  int SH = out_h >= 32 ? 16 : (out_h >= 8 ? 8 : out_h);
+  while (SH > 1 && SH * Eh > 64) SH >>= 1;
+  const int64_t blocks = (int64_t)B * ((out_h + SH - 1) / SH) * (((int64_t)out_w * (C / vn) + 255) / 256);
+  if (blocks >= (1LL << 31)) return DGV2_ENOTSUP;
+  if (blocks_needed) *blocks_needed = blocks;
+  if (!scratch) return blocks_needed ? 0 : DGV2_EINVAL;
+  if (!y || !gb || !x || !ref || !idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w) return DGV2_EINVAL;
+  if (scratch_elems < blocks * C || !aligned16(x) || !aligned16(y) || !aligned16(ref)) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  DGV2_DISPATCH_DTYPE(dtype, {
+    rs_launch_act<T>(Ew, (int)blocks, st, (T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, B, C, C, C,
+                     in_h, in_w, out_h, out_w, SH, (const T*)ref, alpha, scale, scratch);
+  });
+  rs_bias_reduce_kernel<<<(C + 3) / 4, 256, 0, st>>>(gb, scratch, (int)blocks, C);
+  DGV2_RETURN_LAST();
+}
 
 extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const float* coef_h, const int* cnt_h,
                                  int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew, int B,

@@ -453,9 +453,14 @@ class ResidualBlock(nn.Module):
                 (self.skip, self.skip.bank_entry(wscale=c if fused else None))]
 
     def forward_cl(self, x, bank=None):
-        if bank is not None and x.requires_grad:
-            # conv1 also hands x on to the skip branch: the two gradients of x then meet inside conv1's dgrad kernel
-            h, x = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank, fork=True)
+        hd = None   # conv1's activation after the blur/down
+        if bank is not None and bank.get(self.conv1) is not None and isinstance(self.resample, ops.Resample):
+            # conv1 -> act -> blur/down as one autograd node (one fused pass in backward); it also hands x on to the skip
+            # branch: the two gradients of x then meet inside conv1's dgrad kernel
+            if x.requires_grad:
+                hd, x = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank, fork=True, down=self.resample.spec)
+            else:
+                hd = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank, down=self.resample.spec)
         else:
             h = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank)
         c = 1.0 / math.sqrt(2)
@@ -463,10 +468,10 @@ class ResidualBlock(nn.Module):
         if native.conv_resid_ok(xs, self.skip_geom) and self.skip._params_bias()[0] is None:
             # (act(z) * sqrt2 + skip) / sqrt2 == act(z) * 1 + skip / sqrt2: the residual scale folds into the
             # activation gain and the skip weights, the sum into the skip conv's epilogue
-            h = self.conv2.forward_cl(self.resample.forward_cl(h), act=self.bias_act2,
+            h = self.conv2.forward_cl(self.resample.forward_cl(h) if hd is None else hd, act=self.bias_act2,
                                       act_scale=self.bias_act2.scale * c, bank=bank)
             return self.skip.forward_cl(xs, geom=self.skip_geom, resid=h, wscale=c, bank=bank)
-        h = self.conv2.forward_cl(self.resample.forward_cl(h), act=self.bias_act2, bank=bank)
+        h = self.conv2.forward_cl(self.resample.forward_cl(h) if hd is None else hd, act=self.bias_act2, bank=bank)
         s = self.skip.forward_cl(xs, geom=self.skip_geom, bank=bank)
         return (h + s) * c
 

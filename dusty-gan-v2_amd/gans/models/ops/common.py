@@ -161,7 +161,7 @@ class Conv2d(nn.Sequential):
         return (p, s * (1.0 if wscale is None else wscale), cpad)
 
     def forward_cl(self, x, pad_in_to=None, act=None, geom=None, act_scale=None, resid=None, wscale=None, bank=None,
-                   fork=False):
+                   fork=False, down=None):
         """act: a FusedLeakyReLU module fused into the conv epilogue; geom overrides the stride
         (used when the caller has already decimated the input).  bank: {conv: (scale, cpad, wf, wt)} from
         Discriminator's weight bank: the prepared compute-dtype weights ride along on `w` (which stays the
@@ -193,6 +193,10 @@ class Conv2d(nn.Sequential):
         if resid is not None:   # conv(x, w) + resid in one launch (bias-free, activation-free skip conv)
             assert b is None and act is None
             return native.conv_ring_resid(x, w if ent is not None else w.contiguous(), resid, geom)
+        if down is not None:   # conv + act + blur/down as one node (native._ConvActDown); -> y or (y, x) with fork
+            assert act is not None and b is None and act.bias is not None and resid is None and ent is not None
+            return native.conv_ring_act_down(x, w, act.bias, geom, down, act.negative_slope,
+                                             act.scale if act_scale is None else act_scale, fork=fork)
         if fork:   # -> (activation, x handed on to the sibling branch); see native._ConvActFork
             assert act is not None and b is None and act.bias is not None and resid is None
             return native.conv_ring_act_fork(x, w if ent is not None else w.contiguous(), act.bias, geom,

@@ -1102,6 +1102,80 @@ def conv_ring_act_fork(x, w, bias, geom, alpha=0.2, scale=math.sqrt(2.0)):
     return _ConvActFork.apply(x, w, bias, geom, float(alpha), float(scale))
 
 
+_ACTBWD_BLOCKS = {}
+_FUSED_ACTBWD = os.environ.get("DGV2_NO_FUSED_ACTBWD") is None   # A/B switch for benchmarking
+
+
+def _resample_actbwd(g, out, spec, in_hw, alpha, scale):
+    """(gpre, gb): adjoint of `spec` applied to g [B,Ho,Wo,C], then the backward of the bias + leaky-ReLU whose forward
+    output is `out` [B,H,W,C] -- one kernel (dgv2_resample_tab_actbwd); None where it does not apply."""
+    if not _FUSED_ACTBWD or g.dtype != out.dtype:
+        return None
+    B, H, W, C = out.shape
+    Ho, Wo = spec.out_size(H, W)
+    (ih_idx, ih_coef, ih_cnt, Eh), (iw_idx, iw_coef, iw_cnt, Ew) = spec.tables(H, W, True, g.device)
+    tabs = (N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt), Eh, N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew)
+    key = (B, H, W, C, Eh, Ew, _dt(g))
+    if key not in _ACTBWD_BLOCKS:
+        nb = _ct.c_int64(0)
+        ok = N.try_call("dgv2_resample_tab_actbwd", None, None, None, 0, _ct.addressof(nb), None, None, *tabs, B, C, Ho, Wo,
+                        H, W, alpha, scale, _dt(g), N.stream())
+        _ACTBWD_BLOCKS[key] = nb.value if ok else 0
+    nblk = _ACTBWD_BLOCKS[key]
+    if nblk == 0:
+        return None
+    g = g.contiguous()
+    N.check(g, out)
+    gpre = torch.empty_like(out)
+    gb = torch.empty(C, device=g.device, dtype=torch.float32)
+    scratch = torch.empty(nblk * C, device=g.device, dtype=torch.float32)
+    N.call("dgv2_resample_tab_actbwd", N.ptr(gpre), N.ptr(gb), N.ptr(scratch), scratch.numel(), None, N.ptr(g), N.ptr(out),
+           *tabs, B, C, Ho, Wo, H, W, alpha, scale, _dt(g), N.stream())
+    return gpre, gb
+
+
+class _ConvActDown(Function):
+    """resample(lrelu(conv(x, w) + b) * scale) [, x]: conv1 -> FusedLeakyReLU -> blur/down of ResidualBlock
+    (dusty_v2.py:325-345) as one autograd node, so that the backward can run the adjoint resampling and the
+    activation backward (+ bias gradient) in ONE pass over the full-resolution gradient instead of two, and (fork)
+    add the skip branch's gradient of x in the data-gradient epilogue.  First-order passes with the weight bank."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, alpha, scale, spec, fork):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
+        if wc is None:
+            wc = _values(w, x.dtype)
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
+        in_hw = (out.shape[1], out.shape[2])
+        y = _resample_raw(out, spec, False, in_hw)
+        ctx.save_for_backward(x, w, out)
+        ctx.cfg = (g, alpha, scale, bias.numel(), spec, in_hw)
+        return (y, x.view_as(x)) if fork else y
+
+    @staticmethod
+    def backward(ctx, gy, gx_sibling=None):
+        x, w, out = ctx.saved_tensors
+        g, alpha, scale, size_b, spec, in_hw = ctx.cfg
+        if gy is None:
+            return gx_sibling, None, None, None, None, None, None, None
+        fused = None if torch.is_grad_enabled() else _resample_actbwd(gy.to(out.dtype), out, spec, in_hw, alpha, scale)
+        if fused is not None:
+            gpre, gb = fused
+        else:   # composed (also the differentiable form for create_graph=True)
+            gh = _Resample.apply(gy, spec, True, in_hw)
+            gpre, gb = _BiasActBackward.apply(gh, out, True, alpha, scale, 1, size_b)
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale) if ctx.needs_input_grad[0] else gx_sibling
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        return gx, gw, gb, None, None, None, None, None
+
+
+def conv_ring_act_down(x, w, bias, geom, spec, alpha=0.2, scale=math.sqrt(2.0), fork=False):
+    return _ConvActDown.apply(x, w, bias, geom, float(alpha), float(scale), spec, bool(fork))
+
+
 class _ConvResid(Function):
     """conv(x, w) + resid with the residual added in the conv epilogue (reference: the skip sum of
     ResidualBlock.forward, dusty_v2.py:343-345)."""

@@ -122,6 +122,19 @@ int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, const float* 
                          int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
                          int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 
+/* Resampling (normally the ADJOINT tables of a blur/down) followed by the backward of a fused bias + leaky-ReLU in the
+ * same pass:  y = R(x) * (ref > 0 ? 1 : alpha) * scale,  gb[c] = sum of the stored y over everything but the channel.
+ * ref = forward OUTPUT of the activation, [B, out_h, out_w, C] contiguous like y; gb fp32 [C].
+ * scratch fp32 [>= *blocks_needed * C]; a call with scratch == NULL only reports *blocks_needed.  DGV2_ENOTSUP when
+ * the streaming kernel does not cover the geometry (then: dgv2_resample_tab + dgv2_bias_act_bwd).
+ * replaces: Resample adjoint (common.py:105-135) + FusedLeakyReLUFunctionBackward (fused_act.py:22-45) of the
+ * discriminator's conv1 -> activation -> blur/down chain (dusty_v2.py:325-345) run backwards. */
+int dgv2_resample_tab_actbwd(void* y, float* gb, float* scratch, int64_t scratch_elems, int64_t* blocks_needed,
+                             const void* x, const void* ref, const int* idx_h, const float* coef_h,
+                             const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w,
+                             int Ew, int B, int C, int in_h, int in_w, int out_h, int out_w, float alpha,
+                             float scale, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Fourier features (positional encoding of the laser angles)
  * replaces: FourierFeature.forward, gans/models/ops/fourier.py:77-82

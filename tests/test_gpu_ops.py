@@ -325,6 +325,29 @@ def test_mbstd_cat_matches_composed_reference(nat, dtype, tol, B, splits, group)
     assert_rel(gx.float().cpu(), gref, tol, "gx")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adjoint_resample_fused_with_activation_backward(nat, dtype):
+    """dgv2_resample_tab_actbwd (adjoint blur/down + bias/leaky-ReLU backward + bias gradient in one pass) against the
+    two kernels it replaces (dgv2_resample_tab adjoint, then dgv2_bias_act_bwd): same stored gradient bit for bit,
+    bias gradient to summation-order tolerance.  Odd batch, several strips and column blocks."""
+    g = torch.Generator().manual_seed(23)
+    B, H, W, C = 3, 16, 64, 32
+    spec = nat.ResampleSpec([1, 3, 3, 1], (1, 1), (2, 2), True, "hw", True)
+    out = torch.randn(B, H, W, C, generator=g).to(DEV).to(dtype)          # forward output of the activation
+    gy = torch.randn(B, H // 2, W // 2, C, generator=g).to(DEV).to(dtype)  # gradient of the blurred / decimated tensor
+    alpha, scale = 0.2, math.sqrt(2.0)
+    gh = nat._resample_raw(gy, spec, True, (H, W))
+    want_g, want_b = nat._BiasActBackward.apply(gh, out, True, alpha, scale, 1, C)
+    got = nat._resample_actbwd(gy, out, spec, (H, W), alpha, scale)
+    assert got is not None
+    if dtype == torch.float32:
+        assert torch.equal(got[0], want_g)
+        assert_rel(got[1].cpu(), want_b.cpu(), 1e-5, "bias gradient")
+    else:   # the fused pass rounds once (fp32 accumulator -> bf16), the two-kernel chain twice
+        assert_rel(got[0].float().cpu(), want_g.float().cpu(), 8e-3, "gradient")
+        assert_rel(got[1].cpu(), want_b.cpu(), 8e-3, "bias gradient")
+
+
 def test_producers_leave_sum_of_squares_partials(nat, g_ops):
     """The input statistic of a modulated conv (x.square().mean(), style.py:98-103) taken in the epilogue of the
     kernel that PRODUCES x: dgv2_resample_tab_sq / dgv2_modconv_pe_fwd_sq partials must sum to the sum of squares
