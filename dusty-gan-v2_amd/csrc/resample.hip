@@ -502,7 +502,9 @@ extern "C" int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, co
     static const bool no_stream = getenv("DGV2_NO_RSTREAM") != nullptr;   // A/B switch for benchmarking
     static const int rs_ablate = getenv("DGV2_RS_ABLATE") ? atoi(getenv("DGV2_RS_ABLATE")) : 0;
     if (vec && Ew <= 4 && Eh <= 64 && !no_stream) {
+      static const int sh_env = getenv("DGV2_RS_SH") ? atoi(getenv("DGV2_RS_SH")) : 0;   // experiments
       int SH = out_h >= 32 ? 16 : (out_h >= 8 ? 8 : out_h);
+      if (sh_env > 0 && sh_env < SH) SH = sh_env;
       while (SH > 1 && SH * Eh > 64) SH >>= 1;   // the strip's H-table slice must fit one lane-indexed register
       const int64_t blocks = (int64_t)B * ((out_h + SH - 1) / SH) * (((int64_t)out_w * (C / VN) + 255) / 256);
       if (blocks >= (1LL << 31)) return DGV2_EINVAL;
