@@ -192,3 +192,92 @@ extern "C" int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const 
   });
   DGV2_RETURN_LAST();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the output heads: gw[b,o,i] = sum_p gy[b,p,o] x[b,p,i] with O <= 4 output channels (image,
+// ray-drop logit).  As a GEMM it fills 2 of 16 MFMA rows and ran at a quarter of the streaming rate; it is a
+// weighted column sum of x, so: a thread owns one 16-byte channel vector and a lane of pixels, partial sums meet
+// in LDS and leave as one fp32 atomic per (o, i) and block (gw cleared first; B * nsplit blocks).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T, int O>
+__global__ __launch_bounds__(256) void bmm_tn_small_kernel(float* __restrict__ gw, const T* __restrict__ gy,
+                                                           const T* __restrict__ x, int P, int I, int ppb) {
+  constexpr int VN = vec16<T>::N;
+  __shared__ float red[256 * VN];
+  const int b = blockIdx.y;
+  const int cvecs = I / VN, lanes = 256 / cvecs;
+  const int cv = threadIdx.x % cvecs, pl = threadIdx.x / cvecs;
+  const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, P);
+  float acc[O][VN];
+#pragma unroll
+  for (int o = 0; o < O; ++o)
+#pragma unroll
+    for (int j = 0; j < VN; ++j) acc[o][j] = 0.f;
+  const T* xb = x + (int64_t)b * P * I;
+  const T* gb = gy + (int64_t)b * P * O;
+  constexpr int U = 4;   // pixels in flight per thread
+  for (int p = p0 + pl; p < p1; p += lanes * U) {
+    vec16<T> v[U];
+    float g[U][O];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = p + u * lanes;
+      const int qc = min(q, p1 - 1);
+      v[u].load(xb + (int64_t)qc * I + cv * VN);
+#pragma unroll
+      for (int o = 0; o < O; ++o) g[u][o] = q < p1 ? to_f32(gb[(int64_t)qc * O + o]) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int j = 0; j < VN; ++j) acc[o][j] = fmaf(g[u][o], v[u].get(j), acc[o][j]);
+  }
+#pragma unroll
+  for (int o = 0; o < O; ++o) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VN; ++j) red[threadIdx.x * VN + j] = acc[o][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < I; c += 256) {
+      const int v = c / VN, j = c - v * VN;
+      float s = 0.f;
+      for (int k = 0; k < lanes; ++k) s += red[(k * cvecs + v) * VN + j];
+      atomicAdd(&gw[((int64_t)b * O + o) * I + c], s);
+    }
+  }
+}
+
+}  // namespace
+
+// gw fp32 [B, O, I] (overwritten); gy [B, P, O], x [B, P, I] in `dtype`; 1 <= O <= 4, I a multiple of the 16-byte
+// vector with I / vector dividing 256.  DGV2_ENOTSUP otherwise (use dgv2_bmm_tn).
+extern "C" int dgv2_bmm_tn_small(float* gw, const void* gy, const void* x, int B, int P, int I, int O, int dtype,
+                                 void* stream) {
+  if (!gw || !gy || !x || B <= 0 || P <= 0 || I <= 0 || O <= 0) return DGV2_EINVAL;
+  const int vn = dtype == DGV2_BF16 ? 8 : (dtype == DGV2_F32 ? 4 : 0);
+  if (!vn) return DGV2_EINVAL;
+  if (O > 4 || I % vn || 256 % (I / vn) || !aligned16(x)) return DGV2_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)B * O * I, st);
+  if (e != hipSuccess) return (int)e;
+  const int lanes = 256 / (I / vn);
+  int nsplit = (1024 + B - 1) / B;                       // ~1024 blocks
+  const int minpix = lanes * 16;                         // >= 16 pixels per thread
+  if ((int64_t)nsplit * minpix > P) nsplit = (P + minpix - 1) / minpix;
+  nsplit = nsplit < 1 ? 1 : nsplit;
+  const int ppb = (P + nsplit - 1) / nsplit;
+  dim3 grid((P + ppb - 1) / ppb, B);
+  DGV2_DISPATCH_DTYPE(dtype, {
+    switch (O) {
+      case 1: bmm_tn_small_kernel<T, 1><<<grid, 256, 0, st>>>(gw, (const T*)gy, (const T*)x, P, I, ppb); break;
+      case 2: bmm_tn_small_kernel<T, 2><<<grid, 256, 0, st>>>(gw, (const T*)gy, (const T*)x, P, I, ppb); break;
+      case 3: bmm_tn_small_kernel<T, 3><<<grid, 256, 0, st>>>(gw, (const T*)gy, (const T*)x, P, I, ppb); break;
+      default: bmm_tn_small_kernel<T, 4><<<grid, 256, 0, st>>>(gw, (const T*)gy, (const T*)x, P, I, ppb); break;
+    }
+  });
+  DGV2_RETURN_LAST();
+}

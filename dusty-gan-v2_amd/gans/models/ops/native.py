@@ -1792,6 +1792,9 @@ def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
     if _TN_STREAM and dt == torch.bfloat16 and P >= 2048 and I % 8 == 0 and Otot % 8 == 0:
         return _bmm_tn_stream(g3, xa, B, H, W_, I, Otot)
     gwb = torch.empty((B, Otot, I), device=g3.device, dtype=torch.float32)
+    if Otot <= 4 and g3.dtype == xa.dtype and N.try_call("dgv2_bmm_tn_small", N.ptr(gwb), N.ptr(g3), N.ptr(xa), B, P, I,
+                                                         Otot, _dt(xa), N.stream()):
+        return gwb   # the output heads: streaming weighted column sum
     N.call("dgv2_bmm_tn", N.ptr(gwb), N.ptr(g3), N.ptr(xa.reshape(B, P, I)), B, P, I, Otot, Otot, I, _dt(xa), N.stream())
     return gwb
 

@@ -197,6 +197,10 @@ int dgv2_bmm_nn_cat_sq(void* y, const void* xa, const void* xs, const void* w, i
                        float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, int B, int P, int Ka, int Ks,
                     int O, int dtype, void* stream);
+/* The same per-sample weight gradient for O <= 4 output channels (the generator's output heads, dusty_v2.py:32-57):
+ * a streaming weighted column sum instead of a 2-of-16-rows GEMM.  DGV2_ENOTSUP outside its shapes. */
+int dgv2_bmm_tn_small(float* gw, const void* gy, const void* x, int B, int P, int I, int O, int dtype,
+                      void* stream);
 
 /* The same contraction as dgv2_bmm_nn_cat, organised for the two top pyramid levels where it dominates
  * the generator ((Ka, Ks, O) = (64, 512, 32), bf16): a block owns a tile of pixels and walks the

@@ -348,6 +348,21 @@ def test_adjoint_resample_fused_with_activation_backward(nat, dtype):
         assert_rel(got[1].cpu(), want_b.cpu(), 8e-3, "bias gradient")
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-3)])
+@pytest.mark.parametrize("B,P,I,O", [(3, 1000, 32, 2), (2, 70, 64, 1), (2, 4100, 512, 3), (1, 33, 16, 4)])
+def test_bmm_tn_small_head_weight_gradient(nat, dtype, tol, B, P, I, O):
+    """dgv2_bmm_tn_small (weight gradient of the <= 4-channel output heads) against an fp64 einsum; ragged pixel
+    splits, one to four output channels."""
+    import dgv2_native as N
+    g = torch.Generator().manual_seed(9)
+    gy = torch.randn(B, P, O, generator=g).to(DEV).to(dtype)
+    x = torch.randn(B, P, I, generator=g).to(DEV).to(dtype)
+    gw = torch.full((B, O, I), float("nan"), device=DEV)
+    N.call("dgv2_bmm_tn_small", N.ptr(gw), N.ptr(gy), N.ptr(x), B, P, I, O, N.dtype_code(x), N.stream())
+    want = torch.einsum("bpo,bpi->boi", gy.double().cpu(), x.double().cpu())
+    assert_rel(gw.cpu(), want, tol)
+
+
 def test_producers_leave_sum_of_squares_partials(nat, g_ops):
     """The input statistic of a modulated conv (x.square().mean(), style.py:98-103) taken in the epilogue of the
     kernel that PRODUCES x: dgv2_resample_tab_sq / dgv2_modconv_pe_fwd_sq partials must sum to the sum of squares
