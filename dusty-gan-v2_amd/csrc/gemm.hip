@@ -281,3 +281,73 @@ extern "C" int dgv2_bmm_tn_small(float* gw, const void* gy, const void* x, int B
   });
   DGV2_RETURN_LAST();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Data gradient of the output heads: y[b,p,k] = sum_{o<O} x[b,p,o] w[b,k,o] (+ resid[b,p,k]) with a contraction of
+// only O <= 4 terms -- an outer-product stream, not a GEMM (K = 2 padded to 32 wasted 15/16 of the MFMA work and
+// ran at 2.6 TB/s of output).  A thread owns one 16-byte vector of k for a lane of pixels; the sample's w rows for
+// those k live in registers.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T, int O>
+__global__ __launch_bounds__(256) void bmm_nn_small_kernel(T* __restrict__ y, const T* __restrict__ x,
+                                                           const T* __restrict__ w, const T* __restrict__ resid, int P,
+                                                           int K, int ppb) {
+  constexpr int VN = vec16<T>::N;
+  const int b = blockIdx.y;
+  const int kvecs = K / VN, lanes = 256 / kvecs;
+  const int kv = threadIdx.x % kvecs, pl = threadIdx.x / kvecs;
+  float wr[VN][O];
+#pragma unroll
+  for (int j = 0; j < VN; ++j)
+#pragma unroll
+    for (int o = 0; o < O; ++o) wr[j][o] = to_f32(w[((int64_t)b * K + kv * VN + j) * O + o]);
+  const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, P);
+  const T* xb = x + (int64_t)b * P * O;
+  for (int p = p0 + pl; p < p1; p += lanes) {
+    float g[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) g[o] = to_f32(xb[(int64_t)p * O + o]);
+    const int64_t off = ((int64_t)b * P + p) * K + kv * VN;
+    vec16<T> r, out;
+    if (resid) r.load(resid + off);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      float s = resid ? r.get(j) : 0.f;
+#pragma unroll
+      for (int o = 0; o < O; ++o) s = fmaf(g[o], wr[j][o], s);
+      out.set(j, s);
+    }
+    out.store(y + off);
+  }
+}
+
+}  // namespace
+
+// y [B, P, K] = x [B, P, O] . w [B, K, O]^T (+ resid [B, P, K]), all in `dtype`; 1 <= O <= 4, K a multiple of the
+// 16-byte vector with K / vector dividing 256.  DGV2_ENOTSUP otherwise (use dgv2_bmm_nn).
+extern "C" int dgv2_bmm_nn_small(void* y, const void* x, const void* w, const void* resid, int B, int P, int O, int K,
+                                 int dtype, void* stream) {
+  if (!y || !x || !w || B <= 0 || P <= 0 || O <= 0 || K <= 0) return DGV2_EINVAL;
+  const int vn = dtype == DGV2_BF16 ? 8 : (dtype == DGV2_F32 ? 4 : 0);
+  if (!vn) return DGV2_EINVAL;
+  if (O > 4 || K % vn || 256 % (K / vn) || !aligned16(y) || (resid && !aligned16(resid))) return DGV2_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  const int lanes = 256 / (K / vn);
+  int nsplit = (2048 + B - 1) / B;
+  const int minpix = lanes * 8;
+  if ((int64_t)nsplit * minpix > P) nsplit = (P + minpix - 1) / minpix;
+  nsplit = nsplit < 1 ? 1 : nsplit;
+  const int ppb = (P + nsplit - 1) / nsplit;
+  dim3 grid((P + ppb - 1) / ppb, B);
+  DGV2_DISPATCH_DTYPE(dtype, {
+    switch (O) {
+      case 1: bmm_nn_small_kernel<T, 1><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
+      case 2: bmm_nn_small_kernel<T, 2><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
+      case 3: bmm_nn_small_kernel<T, 3><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
+      default: bmm_nn_small_kernel<T, 4><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
+    }
+  });
+  DGV2_RETURN_LAST();
+}

@@ -477,6 +477,11 @@ def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=No
     Bw, O, _ = w3.shape
     N.check(x3, w3, bias)
     y = torch.empty((B, P, O), device=x3.device, dtype=out_dtype)
+    if I <= 4 and Bw == B and bias is None and act == 0 and sq is None and row_scale is None and out_dtype == x3.dtype:
+        # contraction over the <= 4 channels of the output heads (their data gradient): outer-product stream
+        r = None if resid is None else resid.contiguous().to(out_dtype)
+        if N.try_call("dgv2_bmm_nn_small", N.ptr(y), N.ptr(x3), N.ptr(w3), N.ptr(r), B, P, I, O, _dt(x3), N.stream()):
+            return y
     if (resid is None and _PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and P >= 4096
             and (I, O) in ((64, 32), (32, 64), (128, 64), (64, 128), (32, 32), (64, 64))):
         # streaming shapes of the two top levels: sample-walking kernel without a PE part

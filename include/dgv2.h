@@ -201,6 +201,9 @@ int dgv2_bmm_tn_cat(float* gw, const void* gy, const void* xa, const void* xs, i
  * a streaming weighted column sum instead of a 2-of-16-rows GEMM.  DGV2_ENOTSUP outside its shapes. */
 int dgv2_bmm_tn_small(float* gw, const void* gy, const void* x, int B, int P, int I, int O, int dtype,
                       void* stream);
+/* ... and their data gradient y[b,p,k] = sum_{o<O} x[b,p,o] w[b,k,o] (+ resid), a contraction of O <= 4 terms. */
+int dgv2_bmm_nn_small(void* y, const void* x, const void* w, const void* resid, int B, int P, int O, int K,
+                      int dtype, void* stream);
 
 /* The same contraction as dgv2_bmm_nn_cat, organised for the two top pyramid levels where it dominates
  * the generator ((Ka, Ks, O) = (64, 512, 32), bf16): a block owns a tile of pixels and walks the

@@ -363,6 +363,24 @@ def test_bmm_tn_small_head_weight_gradient(nat, dtype, tol, B, P, I, O):
     assert_rel(gw.cpu(), want, tol)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("B,P,O,K,with_resid", [(3, 1000, 2, 32, True), (2, 70, 1, 64, False), (2, 300, 4, 512, True)])
+def test_bmm_nn_small_head_data_gradient(nat, dtype, tol, B, P, O, K, with_resid):
+    """dgv2_bmm_nn_small (data gradient of the <= 4-channel heads, + the sibling branch's gradient as resid) against
+    an fp64 einsum."""
+    import dgv2_native as N
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(B, P, O, generator=g).to(DEV).to(dtype)
+    w = torch.randn(B, K, O, generator=g).to(DEV).to(dtype)
+    r = torch.randn(B, P, K, generator=g).to(DEV).to(dtype) if with_resid else None
+    y = torch.empty((B, P, K), device=DEV, dtype=dtype)
+    N.call("dgv2_bmm_nn_small", N.ptr(y), N.ptr(x), N.ptr(w), N.ptr(r), B, P, O, K, N.dtype_code(x), N.stream())
+    want = torch.einsum("bpo,bko->bpk", x.double().cpu(), w.double().cpu())
+    if with_resid:
+        want = want + r.double().cpu()
+    assert_rel(y.float().cpu(), want, tol)
+
+
 def test_producers_leave_sum_of_squares_partials(nat, g_ops):
     """The input statistic of a modulated conv (x.square().mean(), style.py:98-103) taken in the epilogue of the
     kernel that PRODUCES x: dgv2_resample_tab_sq / dgv2_modconv_pe_fwd_sq partials must sum to the sum of squares
