@@ -49,6 +49,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   const int wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lc = lane >> 4;
   const int p0 = blockIdx.x * TP + wave * 16 * NFW;
+  const int o_base = blockIdx.z * O;   // output channels come in slabs of O = MF*16 (g.O = all of them)
   const int b0 = blockIdx.y * g.samples_per_block;
   const int b1 = min(b0 + g.samples_per_block, g.B);
 
@@ -67,12 +68,12 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias_r[mf][r] = g.bias ? g.bias[mf * 16 + lc * 4 + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bias_r[mf][r] = g.bias ? g.bias[o_base + mf * 16 + lc * 4 + r] : 0.f;
   float cs_r[MF][4];              // per-channel output scale (1 when absent)
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cs_r[mf][r] = g.row_scale ? g.row_scale[mf * 16 + lc * 4 + r] : 1.f;
+    for (int r = 0; r < 4; ++r) cs_r[mf][r] = g.row_scale ? g.row_scale[o_base + mf * 16 + lc * 4 + r] : 1.f;
   constexpr int KAR = KA > 0 ? KA : 1;
   uint4 xr[2][NFW][KAR];            // xa fragments of samples b, b+1
   typedef __attribute__((address_space(3))) void lds_void_t;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   // LDS-DMA of sample b's weights into buffer `buf`: piece j of wave `wave` lands at slots [j*512 + wave*64, +64);
   // LDS slot L = (kc*O + r)*4 + p holds logical chunk p ^ ((r>>2)&3) of row r (swizzle on the source side)
   auto dma_w = [&](int b, int buf) {
-    const bf16_t* wb = w + (int64_t)b * O * I;
+    const bf16_t* wb = w + ((int64_t)b * g.O + o_base) * I;   // this block's slab of O output channels
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int L = min(tid + j * 512, NSLOT - 1);   // surplus lanes of the last piece land in the pad
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     for (int nf = 0; nf < NFW; ++nf) {
       const int px = p0 + nf * 16 + lr;
       const bool live = px < g.P && !((g.ablate & 1) && acc[0][0][0] != 12345.678f);
-      bf16_t* row = y + ((int64_t)b * g.P + px) * O;
+      bf16_t* row = y + ((int64_t)b * g.P + px) * g.O + o_base;
 #pragma unroll
       for (int mf = 0; mf < MF; mf += 2) {
         float va[4], vb[4];
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   if (g.sumsq) {
     __shared__ float red[16];
     const float s = block_sum(ss, red);
-    if (tid == 0) g.sumsq[blockIdx.y * gridDim.x + blockIdx.x] = s;
+    if (tid == 0) g.sumsq[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
   }
 }
 
@@ -195,8 +196,16 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
   nsplit = nsplit < 1 ? 1 : (nsplit > g.B ? g.B : nsplit);
   g.samples_per_block = (g.B + nsplit - 1) / nsplit;
   nsplit = (g.B + g.samples_per_block - 1) / g.samples_per_block;
-  dim3 grid(tiles, nsplit);
-  if (g.sumsq && sumsq_used && tiles * nsplit <= sumsq_cap) *sumsq_used = tiles * nsplit;
+  const int slabs = g.O / (MF * 16);   // host-checked: a whole number
+  // with several slabs fewer sample splits are needed to fill the chip
+  if (slabs > 1) {
+    nsplit = (target + tiles * slabs - 1) / (tiles * slabs);
+    nsplit = nsplit < 1 ? 1 : (nsplit > g.B ? g.B : nsplit);
+    g.samples_per_block = (g.B + nsplit - 1) / nsplit;
+    nsplit = (g.B + g.samples_per_block - 1) / g.samples_per_block;
+  }
+  dim3 grid(tiles, nsplit, slabs);
+  if (g.sumsq && sumsq_used && tiles * nsplit * slabs <= sumsq_cap) *sumsq_used = tiles * nsplit * slabs;
   else g.sumsq = nullptr;
   constexpr size_t lds = sizeof(uint4) * 2 * (size_t)(((MF * 16) * (KA + KS) * 4 + 511) / 512 * 512);
   auto kern = modconv_pe_fwd_kernel<MF, NFW, KA, KS>;
@@ -236,6 +245,8 @@ extern "C" int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, c
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (Ka == 64 && Ks == 512 && O == 32) rc = mp_launch<2, 2, 2, 16>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  // level-3 conv1: two slabs of 32 output channels (a 64-channel slab's weights, 2 x 82 KB, do not fit the LDS)
+  else if (Ka == 128 && Ks == 512 && O == 64) rc = mp_launch<2, 1, 4, 16>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   // the PE-free layers of the two top levels and their data gradients: same sample walk, weights by LDS-DMA
   else if (Ks == 0 && Ka == 64 && O == 32) rc = mp_launch<2, 2, 2, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   else if (Ks == 0 && Ka == 32 && O == 64) rc = mp_launch<4, 2, 1, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);

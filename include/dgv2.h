@@ -206,7 +206,7 @@ int dgv2_bmm_nn_small(void* y, const void* x, const void* w, const void* resid, 
                       int dtype, void* stream);
 
 /* The same contraction as dgv2_bmm_nn_cat, organised for the two top pyramid levels where it dominates
- * the generator ((Ka, Ks, O) = (64, 512, 32), bf16): a block owns a tile of pixels and walks the
+ * the generator ((Ka, Ks, O) = (64, 512, 32) and, as two 32-channel slabs, (128, 512, 64); bf16): a block owns a tile of pixels and walks the
  * samples, the shared PE fragments stay in registers, xa streams straight into registers and only the
  * per-sample weights go through LDS (LDS-DMA, double-buffered) -- HBM sees xa and y once, the PE once per block.
  * Returns DGV2_EINVAL for any other shape / dtype (use dgv2_bmm_nn_cat). */
