@@ -48,8 +48,10 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lc = lane >> 4;
-  const int p0 = blockIdx.x * TP + wave * 16 * NFW;
-  const int o_base = blockIdx.z * O;   // output channels come in slabs of O = MF*16 (g.O = all of them)
+  // slabs of one pixel tile are neighbouring blocks: they run together and share the tile's xa through L2
+  const int slabs = g.O / O;
+  const int p0 = (blockIdx.x / slabs) * TP + wave * 16 * NFW;
+  const int o_base = (blockIdx.x % slabs) * O;   // output channels come in slabs of O = MF*16 (g.O = all of them)
   const int b0 = blockIdx.y * g.samples_per_block;
   const int b1 = min(b0 + g.samples_per_block, g.B);
 
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   if (g.sumsq) {
     __shared__ float red[16];
     const float s = block_sum(ss, red);
-    if (tid == 0) g.sumsq[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    if (tid == 0) g.sumsq[blockIdx.y * gridDim.x + blockIdx.x] = s;
   }
 }
 
@@ -204,7 +206,7 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
     g.samples_per_block = (g.B + nsplit - 1) / nsplit;
     nsplit = (g.B + g.samples_per_block - 1) / g.samples_per_block;
   }
-  dim3 grid(tiles, nsplit, slabs);
+  dim3 grid(tiles * slabs, nsplit);
   if (g.sumsq && sumsq_used && tiles * nsplit * slabs <= sumsq_cap) *sumsq_used = tiles * nsplit * slabs;
   else g.sumsq = nullptr;
   constexpr size_t lds = sizeof(uint4) * 2 * (size_t)(((MF * 16) * (KA + KS) * 4 + 511) / 512 * 512);
@@ -247,6 +249,7 @@ extern "C" int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, c
   if (Ka == 64 && Ks == 512 && O == 32) rc = mp_launch<2, 2, 2, 16>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   // level-3 conv1: two slabs of 32 output channels (a 64-channel slab's weights, 2 x 82 KB, do not fit the LDS)
   else if (Ka == 128 && Ks == 512 && O == 64) rc = mp_launch<2, 1, 4, 16>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ka == 256 && Ks == 512 && O == 128) rc = mp_launch<2, 1, 8, 16>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   // the PE-free layers of the two top levels and their data gradients: same sample walk, weights by LDS-DMA
   else if (Ks == 0 && Ka == 64 && O == 32) rc = mp_launch<2, 2, 2, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   else if (Ks == 0 && Ka == 32 && O == 64) rc = mp_launch<4, 2, 1, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);

@@ -1462,7 +1462,7 @@ class _ModLayer(Function):
             Ka = 0 if xa is None else xa.shape[3]
             out = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
             N.check(xa, xs, wb, bias32)
-            if _PE_FWD and dt == torch.bfloat16 and (Ka, xs.shape[3], Otot) in ((64, 512, 32), (128, 512, 64)):
+            if _PE_FWD and dt == torch.bfloat16 and (Ka, xs.shape[3], Otot) in ((64, 512, 32), (128, 512, 64), (256, 512, 128)):
                 # top pyramid levels: pixel-tile blocks walking the samples, PE fragments in registers
                 N.call("dgv2_modconv_pe_fwd_sq", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3],
                        Otot, None, N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), N.ptr(sq[0]) if sq else None,
@@ -1705,7 +1705,7 @@ class _ModGemmPrepared(Function):
             Ka = 0 if xa is None else xa.shape[3]
             out = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
             tail = (N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
-            if _PE_FWD and dt == torch.bfloat16 and (Ka, xs.shape[3], Otot) in ((64, 512, 32), (128, 512, 64)):
+            if _PE_FWD and dt == torch.bfloat16 and (Ka, xs.shape[3], Otot) in ((64, 512, 32), (128, 512, 64), (256, 512, 128)):
                 N.call("dgv2_modconv_pe_fwd_sq", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3],
                        Otot, N.ptr(cvec), N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), *tail)
             else:

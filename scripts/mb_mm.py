@@ -30,7 +30,7 @@ for (P,Ka,Ks,O) in [(32768,64,0,32),(32768,64,512,32),(8192,128,0,64),(8192,128,
     print(line)
 
 # dgv2_modconv_pe_fwd vs dgv2_bmm_nn_cat on the two top levels
-for (P,Ka,Ks,O) in [(32768,64,512,32),(8192,128,512,64)]:
+for (P,Ka,Ks,O) in [(32768,64,512,32),(8192,128,512,64),(2048,256,512,128)]:
     xa=torch.randn(B,P,Ka,device="cuda",dtype=bf); xs=torch.randn(P,Ks,device="cuda",dtype=bf); w=torch.randn(B,O,Ka+Ks,device="cuda",dtype=bf)
     bias=torch.randn(O,device="cuda"); y=torch.empty(B,P,O,device="cuda",dtype=bf)
     t_new=t(lambda: N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks, O, N.ptr(bias), 3, 0.2, 1.414, N.BF16, N.stream()))

@@ -196,7 +196,7 @@ def test_bmm_bf16_random_tolerance(nat):
     assert_rel(y.float().cpu(), want, 8e-3)
 
 
-@pytest.mark.parametrize("Ka,Ks,O,P,B", [(64, 512, 32, 700, 5), (64, 512, 32, 256, 2), (128, 512, 64, 300, 3), (64, 0, 32, 700, 3), (32, 0, 64, 300, 2),
+@pytest.mark.parametrize("Ka,Ks,O,P,B", [(64, 512, 32, 700, 5), (64, 512, 32, 256, 2), (128, 512, 64, 300, 3), (256, 512, 128, 200, 2), (64, 0, 32, 700, 3), (32, 0, 64, 300, 2),
                                           (128, 0, 64, 300, 2), (64, 0, 128, 260, 2), (32, 0, 32, 300, 2), (64, 0, 64, 300, 2)])
 def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
     """dgv2_modconv_pe_fwd (pixel-tile blocks walking the samples, shared PE in registers) against the
