@@ -939,9 +939,20 @@ class _LinearLow(Function):
 
     @staticmethod
     def forward(ctx, x, weight, scale):
-        x16 = x.to(torch.bfloat16)
+        x16 = x.to(torch.bfloat16).contiguous()
         w16 = weight.detach().to(torch.bfloat16)
-        y = torch.mm(x16, w16.t(), out_dtype=torch.float32)
+        Bn, K = x16.shape
+        O = w16.shape[0]
+        S = 32
+        if K % (S * 8) == 0 and K >= 8192:
+            # a skinny GEMM (M = batch) over K = 65536: the library's single-pass kernel reads the 67 MB of weights at
+            # < 1 TB/s; as S strided-batched partial GEMMs + one sum it streams them (135 -> 28 us at B = 128)
+            kc = K // S
+            part = torch.bmm(x16.view(Bn, S, kc).transpose(0, 1), w16.view(O, S, kc).permute(1, 2, 0),
+                             out_dtype=torch.float32)
+            y = part.sum(0)
+        else:
+            y = torch.mm(x16, w16.t(), out_dtype=torch.float32)
         y.mul_(scale)
         ctx.save_for_backward(x, weight, w16)
         ctx.scale = scale
@@ -955,7 +966,18 @@ class _LinearLow(Function):
             return g16 @ weight.to(torch.bfloat16), (g16.t() @ x.to(torch.bfloat16)).float(), None
         g16 = torch.mul(gy, ctx.scale).to(torch.bfloat16)
         gx = torch.mm(g16, w16) if ctx.needs_input_grad[0] else None
-        gw = torch.mm(g16.t(), x.to(torch.bfloat16), out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            x16 = x.to(torch.bfloat16).contiguous()
+            Bn, K = x16.shape
+            O = w16.shape[0]
+            if K % 8 == 0 and O % 8 == 0:
+                # gw = g^T x with the batch as the contraction: the TN engine (transposing LDS reads), fp32 out
+                gw = torch.empty((O, K), device=x.device, dtype=torch.float32)
+                N.check(g16, x16)
+                N.call("dgv2_bmm_tn", N.ptr(gw), N.ptr(g16), N.ptr(x16), 1, Bn, K, O, O, K, N.BF16, N.stream())
+            else:
+                gw = torch.mm(g16.t(), x16, out_dtype=torch.float32)
         return gx, gw, None
 
 
