@@ -21,6 +21,7 @@ struct WSGeom {
   int B, H, W, C, O, Ho, Wo, k, stride, pad, ring;
   int tiles_h, tiles_w, ntiles, tiles_per_split, ctiles;
   int ablate;   // benchmarking only (DGV2_WS_ABLATE): 1 skip the partial stores, 2 skip the MFMA loop
+  int x_shared; // x is ONE image [H, W, C] shared by all samples (the batch-shared positional encoding)
 };
 
 template <typename T, int S, int MFN, int NFN, bool K3>
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_kernel(float* __rest
   auto issue = [&]() {           // global loads of that tile into registers, then advance
     const int h0 = th_n * WR, w0 = tw_n * 32;
     const T* gyb = gy + (int64_t)b_n * g.Ho * g.Wo * g.O + o0;
-    const T* xb = x + (int64_t)b_n * g.H * g.W * g.C + c0;
+    const T* xb = x + (g.x_shared ? 0 : (int64_t)b_n * g.H * g.W * g.C) + c0;
     if (++tw_n == g.tiles_w) {
       tw_n = 0;
       if (++th_n == g.tiles_h) { th_n = 0; ++b_n; }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_bf16_kernel(float* _
   auto issue = [&]() {           // global loads of that tile into registers, then advance
     const int h0 = th_n * WR, w0 = tw_n * 32;
     const bf16_t* gyb = gy + (int64_t)b_n * g.Ho * g.Wo * g.O + o0;
-    const bf16_t* xb = x + (int64_t)b_n * g.H * g.W * g.C + c0;
+    const bf16_t* xb = x + (g.x_shared ? 0 : (int64_t)b_n * g.H * g.W * g.C) + c0;
     if (++tw_n == g.tiles_w) {
       tw_n = 0;
       if (++th_n == g.tiles_h) { th_n = 0; ++b_n; }
@@ -450,6 +451,7 @@ bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, in
   const int pairs = g.ctiles * p.otiles;
   static const int abl = getenv("DGV2_WS_ABLATE") ? atoi(getenv("DGV2_WS_ABLATE")) : 0;
   g.ablate = abl;
+  g.x_shared = 0;
   static const int blocks_big = getenv("DGV2_WS_BLOCKS_BIG") ? atoi(getenv("DGV2_WS_BLOCKS_BIG")) : 256;
   static const int blocks_small = getenv("DGV2_WS_BLOCKS_SMALL") ? atoi(getenv("DGV2_WS_BLOCKS_SMALL")) : 512;
   int nsplit = ((p.mfn == 4 && p.nfn == 4) ? blocks_big : blocks_small) / pairs;
@@ -537,11 +539,19 @@ extern "C" int dgv2_bmm_tn_stream_scratch(int64_t* elems, int B, int H, int W, i
 
 extern "C" int dgv2_bmm_tn_stream(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
                                   int B, int H, int W, int C, int O, int dtype, void* stream) {
+  return dgv2_bmm_tn_stream_x(gw, scratch, scratch_elems, gy, x, 0, B, H, W, C, O, dtype, stream);
+}
+
+// x_shared != 0: x is one image [H, W, C] contracted against every sample's gy (the batch-shared positional encoding:
+// gw[b, o, c] = sum_p gy[b, p, o] * pe[p, c]).
+extern "C" int dgv2_bmm_tn_stream_x(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
+                                    int x_shared, int B, int H, int W, int C, int O, int dtype, void* stream) {
   if (!gw || !scratch || !gy || !x || !aligned16(gy) || !aligned16(x) || !aligned16(scratch) || !aligned16(gw))
     return DGV2_EINVAL;
   if (dtype != DGV2_BF16 && dtype != DGV2_F32) return DGV2_EINVAL;
   WSPlan p;
   if (!ws_plan(p, B, H, W, C, O, 1, 1, 0, 0, dtype, true)) return DGV2_EINVAL;
+  p.g.x_shared = x_shared != 0;
   const int64_t n = (int64_t)O * C;
   if (scratch_elems < (int64_t)p.nsplit * n || (n & 3)) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;

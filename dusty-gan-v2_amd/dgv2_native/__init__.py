@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -74,6 +74,7 @@ SIGNATURES = {
     "dgv2_conv_wgrad_direct": [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr],
     "dgv2_bmm_tn_stream_scratch": [_c_ptr] + [_c_int] * 6,
     "dgv2_bmm_tn_stream": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 6 + [_c_ptr],
+    "dgv2_bmm_tn_stream_x": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 7 + [_c_ptr],
     "dgv2_conv_weight_bank": [_c_ptr] * 8 + [_c_int, _c_int, _c_ptr],
     "dgv2_conv_wgrad_stream_scratch": [_c_ptr] + [_c_int] * 9,
     "dgv2_conv_wgrad_stream": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 10 + [_c_ptr],

@@ -1425,8 +1425,9 @@ def coords_convert(x, mode, min_depth, max_depth, angle=None, mask=None, raydrop
 # act-grad, data gradient, weight gradient, preparation backward (dgv2_mod_prep_bwd).
 # reference: ModConv2d.forward + FusedLeakyReLU, gans/models/ops/style.py:68-126, dusty_v2.py:161-170
 # ---------------------------------------------------------------------------------------
-def _bmm_tn_stream(g3, xa, B, H, W_, I, O):
-    """gw fp32 [B,O,I] = per-sample sum over pixels of gy [B,H*W,O] x xa [B,H,W,I] (dgv2_bmm_tn_stream)."""
+def _bmm_tn_stream(g3, xa, B, H, W_, I, O, shared=False):
+    """gw fp32 [B,O,I] = per-sample sum over pixels of gy [B,H*W,O] x xa [B,H,W,I] (dgv2_bmm_tn_stream); shared: xa is
+    one image [1,H,W,I] contracted against every sample (the positional encoding)."""
     key = (B, H, W_, I, O)
     if key not in _TN_SCRATCH:
         n = _ct.c_int64(0)
@@ -1434,8 +1435,8 @@ def _bmm_tn_stream(g3, xa, B, H, W_, I, O):
         _TN_SCRATCH[key] = n.value
     gw = torch.empty((B, O, I), device=xa.device, dtype=torch.float32)
     scratch = torch.empty(_TN_SCRATCH[key], device=xa.device, dtype=torch.float32)
-    N.call("dgv2_bmm_tn_stream", N.ptr(gw), N.ptr(scratch), scratch.numel(), N.ptr(g3), N.ptr(xa), B, H, W_, I, O,
-           _dt(xa), N.stream())
+    N.call("dgv2_bmm_tn_stream_x", N.ptr(gw), N.ptr(scratch), scratch.numel(), N.ptr(g3), N.ptr(xa), int(shared), B, H,
+           W_, I, O, _dt(xa), N.stream())
     return gw
 
 
@@ -1798,6 +1799,12 @@ class _ModGemmPrepared(Function):
         return None, gxa, None, gb, gwb, None, None, None
 
 
+# the positional-encoding part on the own streaming engine (shared-x mode): measured SLOWER than the library's batched
+# GEMM on every level (3996 vs 4031 img/s), so it is opt-in for experiments only
+_PE_TN_STREAM = os.environ.get("DGV2_PE_TN_STREAM") is not None
+_PE_TN_MINP = int(os.environ.get("DGV2_PE_TN_MINP", "16384"))
+
+
 def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
     """gwb fp32 [B,Otot,I] = per-sample g3^T [xa | xs] (the engine choice of _ModLayer.backward)."""
     P = H * W_
@@ -1809,7 +1816,10 @@ def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
             parts.append(_bmm_tn_stream(g3, xa, B, H, W_, Ka, Otot))
         elif xa is not None:
             parts.append(torch.bmm(gT, xa.reshape(B, P, Ka), out_dtype=torch.float32))
-        parts.append(torch.bmm(gT, xs.reshape(1, P, -1).expand(B, P, xs.shape[3]), out_dtype=torch.float32))
+        if _PE_TN_STREAM and Otot % 8 == 0 and P >= _PE_TN_MINP:
+            parts.append(_bmm_tn_stream(g3, xs.contiguous(), B, H, W_, xs.shape[3], Otot, shared=True))
+        else:
+            parts.append(torch.bmm(gT, xs.reshape(1, P, -1).expand(B, P, xs.shape[3]), out_dtype=torch.float32))
         return torch.cat(parts, dim=2) if len(parts) > 1 else parts[0]
     if xs is not None:
         gwb = torch.empty((B, Otot, I), device=g3.device, dtype=torch.float32)

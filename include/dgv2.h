@@ -338,6 +338,10 @@ int dgv2_conv_wgrad_direct(float* gw, const void* gy, const void* x, int B, int 
 int dgv2_bmm_tn_stream_scratch(int64_t* elems, int B, int H, int W, int C, int O, int dtype);
 int dgv2_bmm_tn_stream(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
                        int B, int H, int W, int C, int O, int dtype, void* stream);
+/* ... with x_shared != 0: x is ONE image [H, W, C] contracted against every sample's gy -- the weight gradient of the
+ * batch-shared positional-encoding columns, gw[b,o,c] = sum_p gy[b,p,o] * pe[p,c]. */
+int dgv2_bmm_tn_stream_x(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
+                         int x_shared, int B, int H, int W, int C, int O, int dtype, void* stream);
 
 /* Compute-dtype copies of all conv weights of the discriminator in ONE launch (L <= 32): from each fp32
  * master [O,C,kh,kw] (EqualLR runtime scale folded in: common.py:158-184) the forward layout

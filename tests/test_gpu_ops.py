@@ -545,6 +545,18 @@ def test_bmm_tn_stream_per_sample_weight_gradient(nat, B, H, W, I, O):
     assert torch.equal(gw.cpu(), want)
 
 
+def test_bmm_tn_stream_shared_operand(nat):
+    """dgv2_bmm_tn_stream_x with x_shared: one image contracted against every sample's gradient
+    (gw[b,o,c] = sum_p gy[b,p,o] pe[p,c], the positional-encoding columns of the modulated convs)."""
+    g = torch.Generator().manual_seed(12)
+    B, H, W, I, O = 3, 16, 64, 64, 32
+    gy = torch.randn(B, H * W, O, generator=g).to(DEV).bfloat16()
+    pe = torch.randn(1, H, W, I, generator=g).to(DEV).bfloat16()
+    gw = nat._bmm_tn_stream(gy, pe, B, H, W, I, O, shared=True)
+    want = torch.einsum("bpo,pi->boi", gy.double().cpu(), pe.double().cpu().reshape(H * W, I))
+    assert_rel(gw.cpu(), want, 2e-3)
+
+
 def test_fused_adam_matches_torch_adam(nat):
     """native.fused_adam_step (dgv2_adam_prep / dgv2_adam_step on the optimizer's own state tensors) against
     torch.optim.Adam on the CPU (the optimizers of gans/trainer.py:142-171, beta1 = 0 included): three steps,
