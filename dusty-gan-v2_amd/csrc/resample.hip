@@ -180,6 +180,42 @@ extern "C" int dgv2_resample(void* y, const void* x, const float* taps_h, const 
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// Few-channel images (the generator's 2-channel output pyramid, C <= 4, packed pixels): a thread owns a whole output
+// pixel, so the table rows are fetched once per pixel instead of once per channel and the pixel is one 8/16-byte access.
+template <typename T, int CC>
+__global__ __launch_bounds__(256) void resample_tab_smallc_kernel(
+    T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
+    const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
+    const int* __restrict__ cnt_w, int Ew, int B, int in_h, int in_w, int out_h, int out_w) {
+  struct alignas(sizeof(T) * CC) Px { T e[CC]; };
+  const int64_t total = (int64_t)B * out_h * out_w;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int wo = (int)(t % out_w);
+    const int64_t r = t / out_w;
+    const int ho = (int)(r % out_h);
+    const int b = (int)(r / out_h);
+    const int nh = cnt_h[ho], nw = cnt_w[wo];
+    const Px* xb = reinterpret_cast<const Px*>(x) + (int64_t)b * in_h * in_w;
+    float acc[CC];
+#pragma unroll
+    for (int j = 0; j < CC; ++j) acc[j] = 0.f;
+    for (int a = 0; a < nh; ++a) {
+      const float fa = coef_h[ho * Eh + a];
+      const Px* xr = xb + (int64_t)idx_h[ho * Eh + a] * in_w;
+      for (int c = 0; c < nw; ++c) {
+        const float cf = fa * coef_w[wo * Ew + c];
+        const Px v = xr[idx_w[wo * Ew + c]];
+#pragma unroll
+        for (int j = 0; j < CC; ++j) acc[j] += cf * to_f32(v.e[j]);
+      }
+    }
+    Px o;
+#pragma unroll
+    for (int j = 0; j < CC; ++j) o.e[j] = from_f32<T>(acc[j]);
+    reinterpret_cast<Px*>(y)[t] = o;
+  }
+}
+
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void resample_tab_kernel(
     T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
@@ -512,6 +548,12 @@ extern "C" int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, co
       if (sq) *sumsq_used = (int)blocks;
       rs_launch<T>(Ew, (int)blocks, st, (T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, B, C, ldx, ldy, in_h,
                    in_w, out_h, out_w, SH | (rs_ablate << 16), sq);
+    } else if (!vec && (C == 1 || C == 2 || C == 4) && ldx == C && ldy == C &&
+               (reinterpret_cast<uintptr_t>(x) % (sizeof(T) * C)) == 0 && (reinterpret_cast<uintptr_t>(y) % (sizeof(T) * C)) == 0) {
+      const int g2 = grid_for((int64_t)B * out_h * out_w, 256, 256 * 64);
+      if (C == 1) resample_tab_smallc_kernel<T, 1><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w);
+      else if (C == 2) resample_tab_smallc_kernel<T, 2><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w);
+      else resample_tab_smallc_kernel<T, 4><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w);
     } else if (vec)
       resample_tab_kernel<T, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w,
                                                         cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h, out_w);
