@@ -88,15 +88,28 @@ class FlatGradSync:
         finally:
             self._sync = old
 
-    def all_reduce(self):
-        """Average the flat gradient over ranks (no-op for one process or inside no_sync)."""
-        if self._sync and is_dist():
-            if _avg_supported(self.flat.device):
-                # RCCL averages inside the reduction: no extra pass over the 154 MB buffer
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-                self.flat.mul_(1.0 / dist.get_world_size())
+    def all_reduce(self, async_op=False):
+        """Average the flat gradient over ranks (no-op for one process or inside no_sync).  async_op: start the
+        reduction on the communication stream and return a handle for wait(); work issued in between overlaps it."""
+        if not (self._sync and is_dist()):
+            return None
+        avg = _avg_supported(self.flat.device)
+        # RCCL averages inside the reduction: no extra pass over the 154 MB buffer
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            return (work, avg)
+        if not avg:
+            self.flat.mul_(1.0 / dist.get_world_size())
+        return None
+
+    def wait(self, handle):
+        """Complete an all_reduce(async_op=True): the current stream waits for the reduction."""
+        if handle is None:
+            return
+        work, avg = handle
+        work.wait()
+        if not avg:
+            self.flat.mul_(1.0 / dist.get_world_size())
 
 
 _AVG_OK = None

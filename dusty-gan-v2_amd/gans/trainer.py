@@ -284,7 +284,12 @@ class Trainer:
 
         parallel.sync_buffers(self.G)
         scalars.update(self._run("d_fb", self.d_fb, self.x_real))
-        self.d_sync.all_reduce()
+        # the 154 MB gradient reduction of D runs on the communication stream while the EMA generator is updated
+        # (G is final for this iteration: nothing below touches it)
+        pending = self.d_sync.all_reduce(async_op=True)
+        decay = self.ema_decay(iteration)
+        ema_inplace(self.G_ema, self.G, decay)
+        self.d_sync.wait(pending)
         self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
 
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
@@ -293,8 +298,6 @@ class Trainer:
             self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
         set_requires_grad(self.D, False)
 
-        decay = self.ema_decay(iteration)
-        ema_inplace(self.G_ema, self.G, decay)
         if iteration % self.lazy_ada == 0:
             scalars["stats/ada_rt"] = self.A.update_p().reshape(())
             scalars["stats/ada_p"] = self.A.p.detach().clone()

@@ -46,7 +46,9 @@ def _worker(rank, world, tmp, q):
     sync.collect()
     for p in params:
         assert p.grad.data_ptr() >= sync.flat.data_ptr()   # views re-attached
-    sync.all_reduce()
+    pending = sync.all_reduce(async_op=True)   # the trainer's overlapped form: start, do other work, wait
+    assert pending is not None
+    sync.wait(pending)
     packed = float(params[0].grad.flatten()[0]), float(params[1].grad.abs().max()), float(sync.flat[-1])
 
     # mutable buffers: rank 0 wins
