@@ -107,11 +107,11 @@ class EqualLR(nn.Module):
             # (x * scale) @ W^T + b as ONE hipBLASLt call (alpha = scale), output gain only if != 1
             w, b = self.module.weight, self.module.bias
             if b is not None and x.ndim == 2:
-                y = torch.addmm(b, x, w.t(), alpha=self.scale)
-            else:
-                y = F.linear(x, w) * self.scale
-                if b is not None:
-                    y = y + b
+                # gain * (b + scale * x W^T) in the one call (beta = gain): no separate scaling launch
+                return torch.addmm(b, x, w.t(), alpha=self.scale * self.gain_, beta=self.gain_)
+            y = F.linear(x, w) * self.scale
+            if b is not None:
+                y = y + b
             return y if self.gain_ == 1.0 else y * self.gain_
         raise RuntimeError("EqualLR(conv) is executed by ops.Conv2d on this build")
 
