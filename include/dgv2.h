@@ -478,6 +478,14 @@ int dgv2_coords_convert(float* out, const float* in, const float* mask, const fl
                         int B, int H, int W, float min_depth, float max_depth, float raydrop_const,
                         int mode, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * surface normals of a coordinated point map (logging / visualisation path)
+ * replaces: estimate_surface_normal, gans/geometry.py:38-127
+ * points / out fp32 [B,3,H,W]; neighbours at distance d (replicate rows, circular columns);
+ * mode 0 "closest" (pair (k,k+2) with the smallest summed distance, first minimum), 1 "mean".
+ * ------------------------------------------------------------------------- */
+int dgv2_surface_normal(float* out, const float* points, int B, int H, int W, int d, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,11 @@ def g_coords():
 
 
 @pytest.fixture(scope="session")
+def g_geometry():
+    return load_golden("geometry.npz")
+
+
+@pytest.fixture(scope="session")
 def g_small():
     return load_golden("model_small.npz")
 

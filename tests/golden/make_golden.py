@@ -186,6 +186,24 @@ def golden_coords():
 
 
 # ----------------------------------------------------------------------------
+def golden_geometry():
+    """estimate_surface_normal (gans/geometry.py:38-127) on a point map of the small angle grid (smooth surface
+    + noise so that the closest-pair choice is exercised) and on plain random points."""
+    from gans.geometry import estimate_surface_normal
+    out = {}
+    coords_npz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "coords.npz"))
+    pm = torch.from_numpy(coords_npz["cv_depth__point_map"]).float()          # (2,3,8,32)
+    g = torch.Generator().manual_seed(5)
+    rnd = torch.randn(2, 3, 12, 40, generator=g) * 10.0
+    for name, pts in (("pm", pm), ("rnd", rnd)):
+        out[f"{name}_points"] = pts
+        for d in (1, 2):
+            for mode in ("closest", "mean"):
+                out[f"{name}_d{d}_{mode}"] = estimate_surface_normal(pts.clone(), d=d, mode=mode)
+    save("geometry.npz", out)
+
+
+# ----------------------------------------------------------------------------
 def capture_g_noise(B, shape_hw, seed):
     """Replay SynthesisNetwork.forward's shift draw (dusty_v2.py:268-273) and the
     Gumbel uniform draw (RelaxedBernoulli.rsample) for a given seed."""
@@ -391,11 +409,13 @@ def golden_full():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "coords", "small", "full"]
+    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full"]
     if "ops" in which:
         golden_ops()
     if "coords" in which:
         golden_coords()
+    if "geometry" in which:
+        golden_geometry()
     if "small" in which:
         golden_small()
     if "full" in which:

@@ -777,6 +777,26 @@ def test_coords_convert(nat, g_coords):
     assert_rel(cb.fetch_reals(depth.to(DEV), mask.to(DEV)).cpu(), torch.from_numpy(want), 2e-6, "fetch_reals")
 
 
+def test_surface_normal_kernel(nat, g_geometry):
+    """dgv2_surface_normal through gans.geometry.estimate_surface_normal against the reference-generated vectors
+    and, at the full 64x512 size, against the oracle (the closest-pair choice is discrete: no pixel may differ)."""
+    from gans.geometry import estimate_surface_normal
+    from oracle import geometry as o_geo
+    for name in ("pm", "rnd"):
+        pts = g_geometry[f"{name}_points"]
+        for d in (1, 2):
+            for mode in ("closest", "mean"):
+                got = estimate_surface_normal(pts.to(DEV), d=d, mode=mode).cpu()
+                assert float((got - g_geometry[f"{name}_d{d}_{mode}"]).abs().max()) <= 1e-5, (name, d, mode)
+    g = torch.Generator().manual_seed(2)
+    big = torch.randn(2, 3, 64, 512, generator=g) * 20.0
+    got = estimate_surface_normal(big.to(DEV), d=2, mode="closest").cpu().numpy()
+    want = o_geo.estimate_surface_normal(big.numpy(), 2, "closest")
+    assert float(np.abs(got - want).max()) <= 1e-5
+    with pytest.raises(RuntimeError):
+        estimate_surface_normal(big)   # CPU tensor: no fallback
+
+
 def test_sum_squares(nat):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(3, 7, 9, 40, generator=g)

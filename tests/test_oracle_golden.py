@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import sub_dict
-from oracle import augment, coords, model, ops, step
+from oracle import augment, coords, geometry, model, ops, step
 
 TOL = dict(rtol=1e-5, atol=1e-5)
 
@@ -107,6 +107,21 @@ def test_coords_convert_all_pairs(g_coords):
         np.testing.assert_allclose(got, want.numpy(), rtol=1e-6, atol=1e-6, err_msg=key)
         n += 1
     assert n >= 20
+
+
+def test_surface_normals_match_reference(g_geometry):
+    """oracle.geometry.estimate_surface_normal against vectors generated by the reference (gans/geometry.py:38-127):
+    both modes, d = 1 and 2, a smooth point map and random points (border rows exercise the replicate padding)."""
+    n = 0
+    for name in ("pm", "rnd"):
+        pts = g_geometry[f"{name}_points"].numpy()
+        for d in (1, 2):
+            for mode in ("closest", "mean"):
+                got = geometry.estimate_surface_normal(pts, d, mode)
+                np.testing.assert_allclose(got, g_geometry[f"{name}_d{d}_{mode}"].numpy(), rtol=0, atol=1e-5,
+                                           err_msg=f"{name} d={d} {mode}")
+                n += 1
+    assert n == 8
 
 
 # ----------------------------------------------------------------------------
