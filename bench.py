@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--res", default="64x512", help="HxW of the range image (BASELINE configs[4] runs 128x1024; "
+                    "the metric and the roofline probes are quoted on the default 64x512)")
     return ap.parse_args()
 
 
@@ -60,6 +62,10 @@ def make_cfg(args, rank, world):
     cfg.training.warmup.fade_kimg = 0  # post-fade regime: no warm-up dropout / blur
     cfg.training.resume = None
     cfg.training.hip_graph = not args.no_graph
+    res = [int(v) for v in getattr(args, "res", "64x512").lower().split("x")]
+    if res != [64, 512]:
+        cfg.model.generator.synthesis_kwargs.resolution = res
+        cfg.model.discriminator.layer_kwargs.resolution = res
     return cfg
 
 
@@ -237,15 +243,15 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "range-images/sec (G+D step) on dusty_v2 64x512",
+            "metric": f"range-images/sec (G+D step) on dusty_v2 {args.res}",
             "value": value, "unit": "range-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[2]: configs/gans/dusty_v2.yaml full G+D train step "
-                                   "(G step + D step + lazy R1/16 + ADA + EMA + Adam), 64x512 synthetic",
+                                   f"(G step + D step + lazy R1/16 + ADA + EMA + Adam), {args.res} synthetic",
                        "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
                        "parallelism": f"dp{world}", "ada_p": args.ada_p, "hip_graph": not args.no_graph},
-            "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3,
+            "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3 if args.res == "64x512" else None,
             "roofline": roof,
             "roofline_modconv": roof_mod,
         }
