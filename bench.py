@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--workload", choices=["train", "gfwd"], default="train",
+                    help="train: the G+D iteration (BASELINE metric, configs[2]); gfwd: generator-only forward "
+                         "(configs[1], quoted at --batch-per-gpu 32), eval mode, no graph")
     ap.add_argument("--res", default="64x512", help="HxW of the range image (BASELINE configs[4] runs 128x1024; "
                     "the metric and the roofline probes are quoted on the default 64x512)")
     return ap.parse_args()
@@ -216,6 +219,35 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.workload == "gfwd":   # BASELINE configs[1]: generator-only forward
+        G = trainer.G_ema.eval()
+        z = trainer.sample_z(args.batch_per_gpu)
+        with torch.no_grad():
+            for _ in range(max(args.warmup, 1)):
+                G(z, **trainer.auxin)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                G(z, **trainer.auxin)
+            barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        if rank == 0:
+            print(json.dumps({
+                "metric": f"range-images/sec (generator forward) on dusty_v2 {args.res}",
+                "value": args.steps * args.batch_per_gpu * world / dt, "unit": "range-images/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"configs[1]: dusty_v2 generator-only forward (eval, EMA weights), {args.res}",
+                           "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
+                           "parallelism": f"dp{world}"}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # warm-up: first call uses iteration 16 so that the lazy-R1 and ADA-update paths are also warm
     # (with hipGraphs every body needs 2 eager runs + 1 capture before it replays)
