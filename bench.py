@@ -282,7 +282,10 @@ def main():
             "config": {"workload": "configs[2]: configs/gans/dusty_v2.yaml full G+D train step "
                                    f"(G step + D step + lazy R1/16 + ADA + EMA + Adam), {args.res} synthetic",
                        "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
-                       "parallelism": f"dp{world}", "ada_p": args.ada_p, "hip_graph": not args.no_graph},
+                       "parallelism": f"dp{world}", "ada_p": args.ada_p, "hip_graph": not args.no_graph,
+                       # the encoding of the constant sensor grid is a table computed once;
+                       # DGV2_NO_CONST_CACHE=1 recomputes it every forward (-1 %)
+                       "pe_table_precomputed": os.environ.get("DGV2_NO_CONST_CACHE") is None},
             "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3 if args.res == "64x512" else None,
             "roofline": roof,
             "roofline_modconv": roof_mod,

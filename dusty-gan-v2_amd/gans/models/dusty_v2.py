@@ -28,6 +28,7 @@ from torch.nn.modules.utils import _pair
 
 from . import base, dusty_v1, ops
 from .ops import native
+from .ops.fourier import _CONST_CACHE
 
 LOW = torch.bfloat16
 
@@ -147,8 +148,7 @@ class SynthesisBlock(nn.Module):
         d = f_w * shift_b.  We encode the UNSHIFTED grid once for the batch and rotate the PE columns
         of the per-sample weights instead: the PE operand is never materialised per sample."""
         H, W = angle.shape[2:]
-        pe0 = torch.empty((1, H, W, self.pe.out_ch), device=angle.device, dtype=dt)
-        self.pe.encode_into(pe0, 0, angle)
+        pe0 = self.pe.encoded(angle, dt)   # cached: the grid and the frequencies are constants of the training run
         conv = self.conv1
         sumsq, pe_sq = None, 0.0
         hup = None
@@ -291,11 +291,7 @@ class SynthesisNetwork(nn.Module):
         if angle.shape[0] == 1:
             # shared grid: the pyramid is built once from the UNSHIFTED angles and every level applies
             # the shift as a weight rotation (sin/cos -> FIR -> atan2 commutes with a constant shift)
-            pyramid = [(angle, shift)]
-            a = angle
-            for layer in self.layers[:0:-1]:
-                a = layer.downsample_angle(a, None, None)
-                pyramid.insert(0, (a, shift))
+            pyramid = [(a, shift) for a in self._angle_pyramid(angle)]
         else:
             # per-sample grids: the shift enters at the finest level and is baked into the pyramid
             pyramid = [(angle, shift)]
@@ -356,6 +352,20 @@ class SynthesisNetwork(nn.Module):
             handle, wb, wt = prepared[k]
             # single-layer groups see their own rows; the heads of a block share the group's vector
             mod._prep = (handle, wb, cflat[coff[k]:coff[k + 1]], wt)
+
+    def _angle_pyramid(self, angle):
+        """[coarsest ... finest] unshifted angle grids of a batch-shared grid; cached like FourierFeature.encoded (the
+        sensor's grid is a constant; not while a hipGraph is being captured)."""
+        key = (angle.data_ptr(), angle._version, tuple(angle.shape))
+        if getattr(self, "_pyr_key", None) == key:
+            return self._pyr
+        pyr, a = [angle], angle
+        for layer in self.layers[:0:-1]:
+            a = layer.downsample_angle(a, None, None)
+            pyr.insert(0, a)
+        if _CONST_CACHE and not (angle.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._pyr_key, self._pyr = key, pyr
+        return pyr
 
     def _batched_styles(self, ws):
         """All style affines (EqualLR Linear of every ModConv2d on the fused path) as one batched GEMM; each

@@ -11,6 +11,12 @@ from .common import from_cl
 __all__ = ["FourierFeature"]
 
 
+import os as _os
+
+# DGV2_NO_CONST_CACHE=1 recomputes the encoding of the (constant) angle grid on every call, as the reference does
+_CONST_CACHE = _os.environ.get("DGV2_NO_CONST_CACHE") is None
+
+
 class FourierFeature(nn.Module):
     def __init__(self, resolution, basis_scale="random", num_freqs=512, L_offset=(3, -1), mapping=False,
                  mapping_ch=64):
@@ -56,6 +62,22 @@ class FourierFeature(nn.Module):
         if getattr(self, "_fw_key", None) != key:
             self._fw_key, self._fw = key, f.reshape(-1, 2)[:, 1].contiguous()
         return self._fw
+
+    def encoded(self, angle, dtype):
+        """[1,H,W,2F] channels-last encoding of a batch-shared angle grid.  Frequencies and phases are buffers and the
+        sensor's angle grid is a constant, so the result is cached across calls (keyed on the storage and version of
+        everything it depends on): the training step then spends no launch on it.  Nothing is cached while a hipGraph
+        is being captured (a tensor born inside a capture belongs to that graph's memory pool)."""
+        key = (angle.data_ptr(), angle._version, tuple(angle.shape), dtype, self.freqs.data_ptr(), self.freqs._version,
+               self.phase.data_ptr(), self.phase._version)
+        if getattr(self, "_enc_key", None) == key:
+            return self._enc
+        H, W = angle.shape[2:]
+        pe0 = torch.empty((1, H, W, self.out_ch), device=angle.device, dtype=dtype)
+        self.encode_into(pe0, 0, angle)
+        if _CONST_CACHE and not (angle.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._enc_key, self._enc = key, pe0
+        return pe0
 
     def encode_into(self, out, c0, angle, shift=None):
         native.fourier_feature_into(out, c0, angle, shift, self.freqs2.contiguous(), self.phase)
