@@ -290,11 +290,17 @@ extern "C" int dgv2_bmm_tn_small(float* gw, const void* gy, const void* x, int B
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-template <typename T, int O>
+// ACT: y is the gradient of the OUTPUT of an upstream bias + leaky-ReLU layer whose forward output is `ref` (same layout
+// as y): apply that layer's activation backward here -- store v * row_scale[k] with v = (sum + resid) * (ref > 0 ? 1 :
+// alpha) * ascale, and leave per-block column sums of the rounded v in `partial` [blocks, K] for its bias gradient.
+template <typename T, int O, bool ACT>
 __global__ __launch_bounds__(256) void bmm_nn_small_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                            const T* __restrict__ w, const T* __restrict__ resid, int P,
-                                                           int K, int ppb) {
+                                                           int K, int ppb, const T* __restrict__ ref = nullptr,
+                                                           const float* __restrict__ row_scale = nullptr, float alpha = 1.f,
+                                                           float ascale = 1.f, float* __restrict__ partial = nullptr) {
   constexpr int VN = vec16<T>::N;
+  __shared__ float red[ACT ? 256 * VN : 1];
   const int b = blockIdx.y;
   const int kvecs = K / VN, lanes = 256 / kvecs;
   const int kv = threadIdx.x % kvecs, pl = threadIdx.x / kvecs;
@@ -305,22 +311,59 @@ __global__ __launch_bounds__(256) void bmm_nn_small_kernel(T* __restrict__ y, co
     for (int o = 0; o < O; ++o) wr[j][o] = to_f32(w[((int64_t)b * K + kv * VN + j) * O + o]);
   const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, P);
   const T* xb = x + (int64_t)b * P * O;
+  float rs[VN], bsum[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) {
+    rs[j] = (ACT && row_scale) ? row_scale[kv * VN + j] : 1.f;
+    bsum[j] = 0.f;
+  }
   for (int p = p0 + pl; p < p1; p += lanes) {
     float g[O];
 #pragma unroll
     for (int o = 0; o < O; ++o) g[o] = to_f32(xb[(int64_t)p * O + o]);
     const int64_t off = ((int64_t)b * P + p) * K + kv * VN;
-    vec16<T> r, out;
+    vec16<T> r, f, out;
     if (resid) r.load(resid + off);
+    if constexpr (ACT) f.load(ref + off);
 #pragma unroll
     for (int j = 0; j < VN; ++j) {
       float s = resid ? r.get(j) : 0.f;
 #pragma unroll
       for (int o = 0; o < O; ++o) s = fmaf(g[o], wr[j][o], s);
-      out.set(j, s);
+      if constexpr (ACT) {
+        const float v = (f.get(j) > 0.f ? s : s * alpha) * ascale;
+        out.set(j, v);
+        bsum[j] += out.get(j);          // the bias gradient sums the rounded, unscaled gradient
+        out.set(j, v * rs[j]);
+      } else {
+        out.set(j, s);
+      }
     }
     out.store(y + off);
   }
+  if constexpr (ACT) {
+#pragma unroll
+    for (int j = 0; j < VN; ++j) red[threadIdx.x * VN + j] = bsum[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += 256) {
+      const int v = c / VN, j = c - v * VN;
+      float s2 = 0.f;
+      for (int t = 0; t < lanes; ++t) s2 += red[(t * kvecs + v) * VN + j];
+      partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * K + c] = s2;
+    }
+  }
+}
+
+// gb[c] = sum_blk partial[blk][c] (one wave per channel)
+__global__ __launch_bounds__(256) void small_bias_reduce_kernel(float* __restrict__ gb, const float* __restrict__ partial,
+                                                                int nblk, int C) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float s = 0.f;
+#pragma unroll 4
+  for (int k = threadIdx.x & 63; k < nblk; k += 64) s += partial[(int64_t)k * C + c];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) gb[c] = s;
 }
 
 }  // namespace
@@ -329,7 +372,19 @@ __global__ __launch_bounds__(256) void bmm_nn_small_kernel(T* __restrict__ y, co
 // 16-byte vector with K / vector dividing 256.  DGV2_ENOTSUP otherwise (use dgv2_bmm_nn).
 extern "C" int dgv2_bmm_nn_small(void* y, const void* x, const void* w, const void* resid, int B, int P, int O, int K,
                                  int dtype, void* stream) {
-  if (!y || !x || !w || B <= 0 || P <= 0 || O <= 0 || K <= 0) return DGV2_EINVAL;
+  return dgv2_bmm_nn_small_act(y, x, w, resid, B, P, O, K, nullptr, nullptr, 1.f, 1.f, nullptr, nullptr, 0, nullptr, dtype,
+                               stream);
+}
+
+// ... followed (ref != NULL) by the activation backward of the upstream layer that produced this operator's input:
+//   y = (x.w^T + resid) * (ref > 0 ? 1 : alpha) * ascale * row_scale[k],  gb[k] = column sums of the unscaled result.
+// scratch: fp32 [>= *blocks_needed * K]; scratch == NULL only reports *blocks_needed.
+extern "C" int dgv2_bmm_nn_small_act(void* y, const void* x, const void* w, const void* resid, int B, int P, int O, int K,
+                                     const void* ref, const float* row_scale, float alpha, float ascale, float* gb,
+                                     float* scratch, int64_t scratch_elems, int64_t* blocks_needed, int dtype,
+                                     void* stream) {
+  if (B <= 0 || P <= 0 || O <= 0 || K <= 0) return DGV2_EINVAL;
+  if (!blocks_needed && (!y || !x || !w)) return DGV2_EINVAL;
   const int vn = dtype == DGV2_BF16 ? 8 : (dtype == DGV2_F32 ? 4 : 0);
   if (!vn) return DGV2_EINVAL;
   if (O > 4 || K % vn || 256 % (K / vn) || !aligned16(y) || (resid && !aligned16(resid))) return DGV2_ENOTSUP;
@@ -341,12 +396,28 @@ extern "C" int dgv2_bmm_nn_small(void* y, const void* x, const void* w, const vo
   nsplit = nsplit < 1 ? 1 : nsplit;
   const int ppb = (P + nsplit - 1) / nsplit;
   dim3 grid((P + ppb - 1) / ppb, B);
+  const int64_t nblk = (int64_t)grid.x * grid.y;
+  if (blocks_needed) *blocks_needed = nblk;
+  if (blocks_needed && !y) return 0;   // query only
+  if (ref) {
+    if (!gb || !scratch || scratch_elems < nblk * K || !aligned16(ref)) return DGV2_EINVAL;
+    DGV2_DISPATCH_DTYPE(dtype, {
+      switch (O) {
+        case 1: bmm_nn_small_kernel<T, 1, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb, (const T*)ref, row_scale, alpha, ascale, scratch); break;
+        case 2: bmm_nn_small_kernel<T, 2, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb, (const T*)ref, row_scale, alpha, ascale, scratch); break;
+        case 3: bmm_nn_small_kernel<T, 3, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb, (const T*)ref, row_scale, alpha, ascale, scratch); break;
+        default: bmm_nn_small_kernel<T, 4, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb, (const T*)ref, row_scale, alpha, ascale, scratch); break;
+      }
+    });
+    small_bias_reduce_kernel<<<(K + 3) / 4, 256, 0, st>>>(gb, scratch, (int)nblk, K);
+    DGV2_RETURN_LAST();
+  }
   DGV2_DISPATCH_DTYPE(dtype, {
     switch (O) {
-      case 1: bmm_nn_small_kernel<T, 1><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
-      case 2: bmm_nn_small_kernel<T, 2><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
-      case 3: bmm_nn_small_kernel<T, 3><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
-      default: bmm_nn_small_kernel<T, 4><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
+      case 1: bmm_nn_small_kernel<T, 1, false><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
+      case 2: bmm_nn_small_kernel<T, 2, false><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
+      case 3: bmm_nn_small_kernel<T, 3, false><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
+      default: bmm_nn_small_kernel<T, 4, false><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb); break;
     }
   });
   DGV2_RETURN_LAST();

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     "dgv2_unpack2d": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_ema_scalar": [_c_ptr] * 3 + [_c_int] + [_c_f32] * 3 + [_c_int, _c_ptr, _c_int, _c_ptr],
     "dgv2_bmm_nn_small": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr],
+    "dgv2_bmm_nn_small_act": [_c_ptr] * 4 + [_c_int] * 4 + [_c_ptr, _c_ptr, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int,
+                              _c_ptr],
     "dgv2_bmm_tn_small": [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr],
     "dgv2_transpose_list": [_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr],
     "dgv2_mod_prep_all_fwd": [_c_ptr] * 13 + [_c_ptr, _c_int, _c_int, _c_ptr],

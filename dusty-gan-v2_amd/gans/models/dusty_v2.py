@@ -66,7 +66,7 @@ class Head(nn.Module):
             self.heads[o["name"]] = ops.ModConv2d(out_ch=o["ch"], in_ch=in_ch, mod_ch=mod_ch, ksize=1, stride=1,
                                                   padding=0, demod=False, ema=True)
 
-    def forward_cl(self, x, style, sumsq=None, fork=False):
+    def forward_cl(self, x, style, sumsq=None, fork=False, upstream=None):
         """x [B,H,W,C] -> fp32 [B,H,W,sum(ch)] (heads concatenated in dict order); sumsq = partial sums of
         squares of x when its producer already took them."""
         if sumsq is None and self.training:
@@ -82,7 +82,7 @@ class Head(nn.Module):
             # fork: also return x for the NEXT consumer (the following block), so that both gradients of x meet in
             # this layer's data-gradient GEMM
             return native.mod_gemm_layer(x, None, handle, wb, cvec, bias=bias, act=False, out_dtype=torch.float32, wt=wt,
-                                         fork=fork)
+                                         fork=fork, upstream=upstream)
         mods = [head.prep_args(style, sumsq, x.numel()) for head in heads]
         return native.mod_layer(x, None, mods, bias=bias, act=False, out_dtype=torch.float32)
 
@@ -139,7 +139,7 @@ class SynthesisBlock(nn.Module):
         B = angle.shape[0] if batch is None else batch
         return native.downsample_angle(angle.float().contiguous(), shift, self.downsample.kernel, B, self.ring)
 
-    def _conv1_shared_pe(self, hin, w_latent, angle, shift, B, dt, want_sq=False):
+    def _conv1_shared_pe(self, hin, w_latent, angle, shift, B, dt, want_sq=False, link=None):
         """conv1 + bias + lrelu when the whole batch shares one angle grid (the training / sampling
         case).  The reference encodes angle + shift_b per sample and concatenates 512 PE channels to
         every sample's activation (dusty_v2.py:267-274,153-159): 90 % of conv1's input bytes.  The
@@ -168,7 +168,7 @@ class SynthesisBlock(nn.Module):
             handle, wb, cvec, wt = conv._prep
             conv.update_ema(sumsq, B * H * W * (cin + self.pe.out_ch), pe_sq, cvec)
             return native.mod_gemm_layer(hup, pe0, handle, wb, cvec, bias=act.bias, act=True, alpha=act.negative_slope,
-                                         scale=act.scale, want_sq=want, wt=wt)
+                                         scale=act.scale, want_sq=want, wt=wt, defer=link)
         if self.pe.out_ch == 512 and conv.in_ch <= 1024:
             # weight preparation (+ rotation), contraction, bias and lrelu as one autograd node
             mods = [conv.prep_args(w_latent, sumsq, B * H * W * (cin + self.pe.out_ch), sumsq_add=pe_sq)]
@@ -192,11 +192,17 @@ class SynthesisBlock(nn.Module):
         angle fp32 [B or 1, 2, H, W] for this level; shift [B]: azimuth shift still to be applied at
         this level (None if absent or already folded into `angle`)."""
         dt = self.compute_dtype
+        link, up = {}, None
         spec = None if self.is_first else self.resample.spec
         hin = None if h is None else h.to(dt)
         vec = 8 if dt == LOW else 4
         if angle.shape[0] == 1 and (hin is None or hin.shape[3] % vec == 0):
-            h = self._conv1_shared_pe(hin, ws[0], angle, shift, B, dt, want_sq=True)
+            # the layer that feeds the head shares a link with it: the head's data-gradient kernel then also runs that
+            # layer's activation backward (native._head_dgrad_actbwd)
+            h = self._conv1_shared_pe(hin, ws[0], angle, shift, B, dt, want_sq=True, link=link if self.is_first else None)
+            if self.is_first and self.conv1._prep is not None:
+                a1 = self.bias_act1
+                up = dict(link=link, alpha=float(a1.negative_slope), scale=float(a1.scale), cvec=self.conv1._prep[2])
         else:
             x1 = native.up_cat_pe(hin, spec, angle, shift, self.pe.freqs2.contiguous(), self.pe.phase, dt, B)
             h = self.conv1.forward_cl(x1, ws[0], act=self.bias_act1)
@@ -211,7 +217,8 @@ class SynthesisBlock(nn.Module):
                 handle, wb, cvec, wt = self.conv2._prep
                 self.conv2.update_ema(sumsq, h.numel(), 0.0, cvec)
                 h = native.mod_gemm_layer(h, None, handle, wb, cvec, bias=a2.bias, act=True, alpha=a2.negative_slope,
-                                          scale=a2.scale, want_sq=self.head.training, wt=wt)
+                                          scale=a2.scale, want_sq=self.head.training, wt=wt, defer=link)
+                up = dict(link=link, alpha=float(a2.negative_slope), scale=float(a2.scale), cvec=cvec)
             else:
                 h = native.mod_layer(h, None, [self.conv2.prep_args(ws[1], sumsq, h.numel())], bias=a2.bias,
                                      act=True, alpha=a2.negative_slope, scale=a2.scale, want_sq=self.head.training)
@@ -219,7 +226,7 @@ class SynthesisBlock(nn.Module):
             if isinstance(h, tuple):
                 h, sq_h = h
             nxt = 2
-        o = self.head.forward_cl(h, ws[nxt], sumsq=sq_h, fork=True)
+        o = self.head.forward_cl(h, ws[nxt], sumsq=sq_h, fork=True, upstream=up)
         if isinstance(o, tuple):
             o, h = o
         if skip is not None:

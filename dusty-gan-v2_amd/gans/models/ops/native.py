@@ -1766,8 +1766,18 @@ class _ModGemmPrepared(Function):
         gb = None
         vn = 8 if gy.dtype == torch.bfloat16 else 4
         rows = gy.numel() // Otot
-        gpre = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
-        if cfg["act"] and gy.dtype == dt and Otot % vn == 0 and 256 % (Otot // vn) == 0:
+        link = cfg.get("defer")
+        deferred = link is not None and bool(link.get("done"))
+        if deferred:
+            # the layer that consumed this output (a head, fork form) already ran THIS layer's activation backward in
+            # the epilogue of its data-gradient kernel: gy is the accumulator gradient, the bias gradient waits in `link`
+            gpre, gb = gy.to(dt), (link.get("gb") if cfg["has_bias"] else None)
+            link.clear()
+        else:
+            gpre = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
+        if deferred:
+            pass
+        elif cfg["act"] and gy.dtype == dt and Otot % vn == 0 and 256 % (Otot // vn) == 0:
             gb = torch.empty(Otot, device=dev, dtype=torch.float32)
             scratch = torch.empty(2048 * Otot, device=dev, dtype=torch.float32) if rows >= 65536 else None
             N.call("dgv2_bias_act_bwd_rs", N.ptr(gpre), N.ptr(gb), N.ptr(gy), N.ptr(out), rows, Otot, cfg["alpha"],
@@ -1787,10 +1797,18 @@ class _ModGemmPrepared(Function):
         g3 = gpre.reshape(B, P, Otot)
         Ka = 0 if xa is None else xa.shape[3]
         gxa = None
+        up = cfg.get("upstream")
         if xa is not None and ctx.needs_input_grad[1]:
             if wt is None:
                 wt = wb[:, :, :Ka].transpose(1, 2).contiguous()
-            gxa = _bmm_nn_raw(g3, wt, xa.dtype, resid=None if g_sib is None else g_sib.reshape(B, P, Ka)).reshape(xa.shape)
+            resid = None if g_sib is None else g_sib.reshape(B, P, Ka)
+            fused = None
+            if up is not None and cfg["fork"] and not torch.is_grad_enabled():
+                fused = _head_dgrad_actbwd(g3, wt, resid, xa, up)
+            if fused is not None:
+                gxa = fused.reshape(xa.shape)
+            else:
+                gxa = _bmm_nn_raw(g3, wt, xa.dtype, resid=resid).reshape(xa.shape)
         elif g_sib is not None:
             gxa = g_sib
         gwb = None
@@ -1836,12 +1854,49 @@ def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
     return gwb
 
 
+_HEAD_ACT_BLOCKS = {}
+_HEAD_ACTBWD = os.environ.get("DGV2_NO_HEAD_ACTBWD") is None   # A/B switch for benchmarking
+
+
+def _head_dgrad_actbwd(g3, wt, resid, xa, up):
+    """Data gradient of a head layer fused with the activation backward of the trunk layer that produced the head's
+    input xa (dgv2_bmm_nn_small_act).  up = dict(link, alpha, scale, cvec, has_bias): the upstream layer's activation
+    parameters and the shared `link` through which it learns that its backward is done.  None where it does not apply."""
+    B, P, Otot = g3.shape
+    Ka = wt.shape[1]
+    if not _HEAD_ACTBWD or Otot > 4 or g3.dtype != xa.dtype or wt.dtype != xa.dtype:
+        return None
+    key = (B, P, Otot, Ka, _dt(xa))
+    if key not in _HEAD_ACT_BLOCKS:
+        nb = _ct.c_int64(0)
+        ok = N.try_call("dgv2_bmm_nn_small_act", None, None, None, None, B, P, Otot, Ka, None, None, 1.0, 1.0, None, None, 0,
+                        _ct.addressof(nb), _dt(xa), N.stream())
+        _HEAD_ACT_BLOCKS[key] = nb.value if ok else 0
+    nblk = _HEAD_ACT_BLOCKS[key]
+    if nblk == 0:
+        return None
+    r = None if resid is None else resid.contiguous().to(xa.dtype)
+    xr = xa.contiguous()
+    y = torch.empty((B, P, Ka), device=xa.device, dtype=xa.dtype)
+    gb = torch.empty(Ka, device=xa.device, dtype=torch.float32)
+    scratch = torch.empty(nblk * Ka, device=xa.device, dtype=torch.float32)
+    N.check(g3, wt, r, xr, up["cvec"])
+    N.call("dgv2_bmm_nn_small_act", N.ptr(y), N.ptr(g3), N.ptr(wt), N.ptr(r), B, P, Otot, Ka, N.ptr(xr), N.ptr(up["cvec"]),
+           up["alpha"], up["scale"], N.ptr(gb), N.ptr(scratch), scratch.numel(), None, _dt(xa), N.stream())
+    up["link"]["done"] = True
+    up["link"]["gb"] = gb
+    return y
+
+
 def mod_gemm_layer(xa, xs, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=None,
-                   want_sq=False, wt=None, fork=False):
-    """The contraction of a modulated layer whose weights came from mod_prep_all (handle, wb) and whose
+                   want_sq=False, wt=None, fork=False, defer=None, upstream=None):
+    """defer: a dict shared with the ONE consumer of this layer's output (a head in fork form); when that consumer
+    ran this layer's activation backward inside its own data-gradient kernel it marks the dict and this layer's
+    backward skips its own pass.  upstream: the consumer's side of the same link (see _head_dgrad_actbwd).
+    The contraction of a modulated layer whose weights came from mod_prep_all (handle, wb) and whose
     input-magnitude factor is cvec fp32 [Otot] (native.ema_update(..., cvec=...))."""
     ref = xa if xa is not None else xs
     cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0,
                out_dtype=ref.dtype if out_dtype is None else out_dtype, want_sq=bool(want_sq),
-               fork=bool(fork and xa is not None and xa.requires_grad))
+               fork=bool(fork and xa is not None and xa.requires_grad), defer=defer, upstream=upstream)
     return _ModGemmPrepared.apply(cfg, xa, xs, bias, handle, wb, cvec, wt)

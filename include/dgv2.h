@@ -204,6 +204,14 @@ int dgv2_bmm_tn_small(float* gw, const void* gy, const void* x, int B, int P, in
 /* ... and their data gradient y[b,p,k] = sum_{o<O} x[b,p,o] w[b,k,o] (+ resid), a contraction of O <= 4 terms. */
 int dgv2_bmm_nn_small(void* y, const void* x, const void* w, const void* resid, int B, int P, int O, int K,
                       int dtype, void* stream);
+/* ... followed (ref != NULL) by the activation backward of the upstream bias + leaky-ReLU layer whose OUTPUT `ref`
+ * [B,P,K] is this operator's forward input (the heads read the trunk's last activation):
+ *   y = (x.w^T + resid) * (ref > 0 ? 1 : alpha) * ascale * row_scale[k];  gb[k] = column sums of the value before
+ *   row_scale (fp32 [K]) -- FusedLeakyReLUFunctionBackward (fused_act.py:22-45) without its own pass.
+ * scratch fp32 [>= *blocks_needed * K]; y == NULL with blocks_needed != NULL only reports the block count. */
+int dgv2_bmm_nn_small_act(void* y, const void* x, const void* w, const void* resid, int B, int P, int O, int K,
+                          const void* ref, const float* row_scale, float alpha, float ascale, float* gb,
+                          float* scratch, int64_t scratch_elems, int64_t* blocks_needed, int dtype, void* stream);
 
 /* The same contraction as dgv2_bmm_nn_cat, organised for the two top pyramid levels where it dominates
  * the generator ((Ka, Ks, O) = (64, 512, 32) and, as two 32-channel slabs, (128, 512, 64); bf16): a block owns a tile of pixels and walks the

@@ -381,6 +381,35 @@ def test_bmm_nn_small_head_data_gradient(nat, dtype, tol, B, P, O, K, with_resid
     assert_rel(y.float().cpu(), want, tol)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("B,P,O,K,with_resid", [(3, 1000, 2, 32, True), (2, 333, 2, 64, False)])
+def test_head_data_gradient_with_upstream_activation_backward(nat, dtype, tol, B, P, O, K, with_resid):
+    """dgv2_bmm_nn_small_act = head data gradient (+ sibling gradient) followed by the activation backward of the trunk
+    layer that produced the head's input, against the two-step chain it replaces (dgv2_bmm_nn_small, then
+    dgv2_bias_act_bwd_rs): gradient and bias gradient (FusedLeakyReLUFunctionBackward, fused_act.py:22-45)."""
+    import ctypes
+    import dgv2_native as N
+    g = torch.Generator().manual_seed(14)
+    gy = torch.randn(B, P, O, generator=g).to(DEV).to(dtype)
+    w = torch.randn(B, K, O, generator=g).to(DEV).to(dtype)
+    ref = torch.randn(B, P, K, generator=g).to(DEV).to(dtype)          # forward output of the upstream activation
+    r = torch.randn(B, P, K, generator=g).to(DEV).to(dtype) if with_resid else None
+    cvec = (torch.rand(K, generator=g) + 0.5).to(DEV)
+    alpha, scale = 0.2, math.sqrt(2.0)
+    # fused
+    up = dict(link={}, alpha=alpha, scale=scale, cvec=cvec)
+    got = nat._head_dgrad_actbwd(gy, w, r, ref, up)
+    assert got is not None and up["link"]["done"]
+    gb = up["link"]["gb"]
+    # composed, in fp64
+    gx = torch.einsum("bpo,bko->bpk", gy.double().cpu(), w.double().cpu())
+    if with_resid:
+        gx = gx + r.double().cpu()
+    v = torch.where(ref.double().cpu() > 0, gx, gx * alpha) * scale
+    assert_rel(got.float().cpu(), v * cvec.double().cpu(), tol, "gradient")
+    assert_rel(gb.cpu(), v.sum(dim=(0, 1)), max(tol, 1e-4), "bias gradient")
+
+
 def test_producers_leave_sum_of_squares_partials(nat, g_ops):
     """The input statistic of a modulated conv (x.square().mean(), style.py:98-103) taken in the epilogue of the
     kernel that PRODUCES x: dgv2_resample_tab_sq / dgv2_modconv_pe_fwd_sq partials must sum to the sum of squares
