@@ -356,14 +356,15 @@ __global__ __launch_bounds__(256) void bmm_nn_small_kernel(T* __restrict__ y, co
 
 // gb[c] = sum_blk partial[blk][c] (one wave per channel)
 __global__ __launch_bounds__(256) void small_bias_reduce_kernel(float* __restrict__ gb, const float* __restrict__ partial,
-                                                                int nblk, int C) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+                                                             int nblk, int C) {
+  // one BLOCK per channel: thousands of per-block partials (one row per producer block) fold in ~nblk/256 steps
+  __shared__ float red[16];
+  const int c = blockIdx.x;
   float s = 0.f;
 #pragma unroll 4
-  for (int k = threadIdx.x & 63; k < nblk; k += 64) s += partial[(int64_t)k * C + c];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) gb[c] = s;
+  for (int k = threadIdx.x; k < nblk; k += 256) s += partial[(int64_t)k * C + c];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) gb[c] = s;
 }
 
 }  // namespace
@@ -409,7 +410,7 @@ extern "C" int dgv2_bmm_nn_small_act(void* y, const void* x, const void* w, cons
         default: bmm_nn_small_kernel<T, 4, true><<<grid, 256, 0, st>>>((T*)y, (const T*)x, (const T*)w, (const T*)resid, P, K, ppb, (const T*)ref, row_scale, alpha, ascale, scratch); break;
       }
     });
-    small_bias_reduce_kernel<<<(K + 3) / 4, 256, 0, st>>>(gb, scratch, (int)nblk, K);
+    small_bias_reduce_kernel<<<K, 256, 0, st>>>(gb, scratch, (int)nblk, K);
     DGV2_RETURN_LAST();
   }
   DGV2_DISPATCH_DTYPE(dtype, {

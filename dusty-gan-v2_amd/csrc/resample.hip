@@ -469,13 +469,14 @@ void rs_launch_act(int Ew, int blocks, hipStream_t st, T* y, const T* x, const i
 // gb[c] = sum_blk partial[blk][c] (one wave per channel)
 __global__ __launch_bounds__(256) void rs_bias_reduce_kernel(float* __restrict__ gb, const float* __restrict__ partial,
                                                              int nblk, int C) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  // one BLOCK per channel: thousands of per-block partials (one row per producer block) fold in ~nblk/256 steps
+  __shared__ float red[16];
+  const int c = blockIdx.x;
   float s = 0.f;
 #pragma unroll 4
-  for (int k = threadIdx.x & 63; k < nblk; k += 64) s += partial[(int64_t)k * C + c];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) gb[c] = s;
+  for (int k = threadIdx.x; k < nblk; k += 256) s += partial[(int64_t)k * C + c];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) gb[c] = s;
 }
 
 }  // namespace
@@ -509,7 +510,7 @@ extern "C" int dgv2_resample_tab_actbwd(void* y, float* gb, float* scratch, int6
     rs_launch_act<T>(Ew, (int)blocks, st, (T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, B, C, C, C,
                      in_h, in_w, out_h, out_w, SH, (const T*)ref, alpha, scale, scratch);
   });
-  rs_bias_reduce_kernel<<<(C + 3) / 4, 256, 0, st>>>(gb, scratch, (int)blocks, C);
+  rs_bias_reduce_kernel<<<C, 256, 0, st>>>(gb, scratch, (int)blocks, C);
   DGV2_RETURN_LAST();
 }
 
