@@ -226,16 +226,16 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(T* __restrict__ gx, f
   }
 }
 
-// gb[c] = sum_blk partial[blk][c]: one wave per channel (4 channels per workgroup), 64 lanes split the blocks
+// gb[c] = sum_blk partial[blk][c]: one block per channel, 256 threads split the producer blocks
 __global__ __launch_bounds__(256) void bias_partial_reduce_kernel(float* __restrict__ gb, const float* __restrict__ partial,
                                                                   int nblk, int C) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  __shared__ float red[16];
+  const int c = blockIdx.x;
   float s = 0.f;
 #pragma unroll 4
-  for (int k = threadIdx.x & 63; k < nblk; k += 64) s += partial[(int64_t)k * C + c];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) gb[c] = s;
+  for (int k = threadIdx.x; k < nblk; k += 256) s += partial[(int64_t)k * C + c];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) gb[c] = s;
 }
 
 }  // namespace
@@ -273,7 +273,7 @@ extern "C" int dgv2_bias_act_bwd_rs(void* gx, float* gb, const void* gy, const v
     bias_act_bwd_kernel<T><<<grid, 256, 0, st>>>((T*)gx, gb, (const T*)gy, (const T*)ref, rows, cvecs, alpha, scale,
                                                  many ? scratch : nullptr, row_scale);
   });
-  if (many) bias_partial_reduce_kernel<<<(C + 3) / 4, 256, 0, st>>>(gb, scratch, grid, C);
+  if (many) bias_partial_reduce_kernel<<<C, 256, 0, st>>>(gb, scratch, grid, C);
   DGV2_RETURN_LAST();
 }
 
