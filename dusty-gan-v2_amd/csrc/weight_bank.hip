@@ -42,12 +42,16 @@ __global__ __launch_bounds__(256) void weight_bank_kernel(BankArgs a) {
 // Tiled variant (kk <= 9): a block owns a 64 (o) x 32 (c) x kk tile, reads it with contiguous runs of the master
 // layout into LDS and writes both layouts with contiguous runs (the transposed layout's scattered 2-byte stores
 // were the whole cost of the straightforward kernel above: 71 us per launch on the dusty_v2 discriminator).
-constexpr int WB_TO = 64, WB_TC = 32, WB_KK = 9;
+constexpr int WB_TO = 16, WB_TC = 32, WB_KK = 9;   // small tiles: ~1000 blocks; the kernel is latency-, not bandwidth-shaped
 
-template <typename T>
+// KK: compile-time taps per filter (1 or 9; 0 = read it from the arguments): the index arithmetic below divides by it
+// six times per element, and with a run-time divisor those divisions WERE the kernel (71 us; 2.5 M elements)
+template <typename T, int KK>
 __global__ __launch_bounds__(256) void weight_bank_tiled_kernel(BankArgs a) {
   const int l = blockIdx.y;
-  const int O = a.O[l], C = a.C[l], Cp = a.Cpad[l], kk = a.kk[l];
+  const int O = a.O[l], C = a.C[l], Cp = a.Cpad[l];
+  const int kk = KK > 0 ? KK : a.kk[l];
+  if (KK > 0 && a.kk[l] != KK) return;   // this launch handles the layers with KK taps
   const int tc = (Cp + WB_TC - 1) / WB_TC, to = (O + WB_TO - 1) / WB_TO;
   if ((int)blockIdx.x >= tc * to) return;
   const int o0 = (blockIdx.x / tc) * WB_TO, c0 = (blockIdx.x % tc) * WB_TC;
@@ -57,12 +61,28 @@ __global__ __launch_bounds__(256) void weight_bank_tiled_kernel(BankArgs a) {
   T* wt = reinterpret_cast<T*>(a.wt[l]);
   __shared__ float tile[WB_TO][WB_TC * WB_KK + 1];
   const int run = WB_TC * kk;
-  for (int e = threadIdx.x; e < WB_TO * run; e += 256) {
-    const int o = e / run, r = e - o * run;
-    const int c = c0 + r / kk;
-    float v = 0.f;
-    if (o0 + o < O && c < C) v = src[((size_t)(o0 + o) * C + c0) * kk + r] * s;
-    tile[o][r] = v;
+  // eight loads in flight per thread: with a rolled loop every iteration waited for its own load (72 serial HBM/L2
+  // latencies per block were the whole 60 us of this kernel)
+  for (int e0 = threadIdx.x; e0 < WB_TO * run; e0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256;
+      const int ec = min(e, WB_TO * run - 1);
+      const int o = ec / run, r = ec - o * run;
+      const int c = c0 + r / kk;
+      const bool ok = e < WB_TO * run && o0 + o < O && c < C;
+      const size_t idx = ok ? ((size_t)(o0 + o) * C + c0) * kk + r : 0;
+      v[u] = ok ? src[idx] * s : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256;
+      if (e < WB_TO * run) {
+        const int o = e / run, r = e - o * run;
+        tile[o][r] = v[u];
+      }
+    }
   }
   __syncthreads();
   for (int f = threadIdx.x; f < WB_TO * run; f += 256) {   // forward layout: runs of 32 channels
@@ -101,7 +121,20 @@ extern "C" int dgv2_conv_weight_bank(void* const* wf, void* const* wt, const flo
   static const bool no_tiled = getenv("DGV2_NO_WB_TILED") != nullptr;
   if (kmax <= WB_KK && !no_tiled) {
     dim3 tgrid(tmax, L);
-    DGV2_DISPATCH_DTYPE(dtype, { weight_bank_tiled_kernel<T><<<tgrid, 256, 0, st>>>(a); });
+    bool has1 = false, has9 = false, other = false;
+    for (int l = 0; l < L; ++l) {
+      if (kk[l] == 1) has1 = true;
+      else if (kk[l] == 9) has9 = true;
+      else other = true;
+    }
+    DGV2_DISPATCH_DTYPE(dtype, {
+      if (other) {
+        weight_bank_tiled_kernel<T, 0><<<tgrid, 256, 0, st>>>(a);
+      } else {
+        if (has9) weight_bank_tiled_kernel<T, 9><<<tgrid, 256, 0, st>>>(a);
+        if (has1) weight_bank_tiled_kernel<T, 1><<<tgrid, 256, 0, st>>>(a);
+      }
+    });
     DGV2_RETURN_LAST();
   }
   dim3 grid(grid_for(nmax, 256, 256), L);
