@@ -1,0 +1,19 @@
+"""400 training iterations under hipGraph replay: losses, parameter finiteness and the input-magnitude EMAs every 50."""
+import os, sys, argparse
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dusty-gan-v2_amd")]
+import torch
+import bench
+args = argparse.Namespace(batch_per_gpu=64, dtype="bf16", ada_p=0.6, no_graph=False, res="64x512")
+from gans.trainer import Trainer
+from gans.utils import init_random_seed
+init_random_seed(0, 0)
+tr = Trainer(bench.make_cfg(args, 0, 1), sync_scalars=False)
+hist = []
+for it in range(1, 401):
+    out = tr.step(it)
+    if it % 50 == 0:
+        vals = {k: float(v) for k, v in out.items() if hasattr(v, "item") or isinstance(v, float)}
+        finite = all(torch.isfinite(p).all().item() for p in list(tr.G.parameters()) + list(tr.D.parameters()))
+        ev = [float(b) for n, b in tr.G.named_buffers() if n.endswith("ema_var")][:4]
+        print(it, {k: round(v, 4) for k, v in vals.items() if "loss" in k or "ada" in k}, "finite", finite, "ema_var", [round(e, 3) for e in ev])
