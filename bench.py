@@ -246,6 +246,7 @@ def main():
                            "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
                            "parallelism": f"dp{world}"}}))
         if world > 1:
+            dist.barrier()   # leave together: rank 0 may still be printing
             dist.destroy_process_group()
         return
 
@@ -294,6 +295,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()   # the other ranks wait for rank 0's roofline probes, then everybody tears down together
         dist.destroy_process_group()
 
 
