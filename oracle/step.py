@@ -122,3 +122,120 @@ def ema_update(sd_ema, sd_new, decay, buffer_suffixes=G_BUFFER_SUFFIXES):
     for k, v in sd_ema.items():
         out[k] = sd_new[k].clone() if is_buffer(k, buffer_suffixes) else v * decay + sd_new[k] * (1 - decay)
     return out
+
+
+def warmup_blur(x, sigma):
+    """trainer.py:236-240 + ops/common.py:27-42 (filter2d): normalised kernel exp2(-(t/sigma)^2), t in
+    [-floor(3 sigma), floor(3 sigma)], ring extension along W, replicate along H, separable."""
+    n = int(math.floor(sigma * 3))
+    if n <= 0:
+        return x
+    t = torch.arange(-n, n + 1, dtype=x.dtype)
+    k = torch.exp2(-(t / sigma) ** 2)
+    k = k / k.sum()
+    W, H = x.shape[3], x.shape[2]
+    cols = (torch.arange(W)[:, None] + torch.arange(-n, n + 1)[None, :]) % W            # circular
+    x = (x[:, :, :, cols] * k).sum(-1)
+    rows = (torch.arange(H)[:, None] + torch.arange(-n, n + 1)[None, :]).clamp(0, H - 1)  # replicate
+    return (x[:, :, rows, :] * k[None, None, None, :, None]).sum(3)
+
+
+def warmup_params(iteration, batch_size, fade_kimg, blur_init_sigma, dropout_init_ratio):
+    """trainer.py:219-232."""
+    fade_imgs = fade_kimg * 1e3
+    if fade_imgs <= 0:
+        return 0.0, 0.0
+    fade = max(1 - int(iteration * batch_size) / fade_imgs, 0)
+    return fade * blur_init_sigma, fade * dropout_init_ratio
+
+
+def _warm(x, sigma, keep):
+    return warmup(warmup_blur(x, sigma), keep)
+
+
+def new_train_state(sdG, sdD, p_init):
+    """State carried across iterations: G, D, G_ema state dicts (reference layout), Adam moments, ADA controller."""
+    def opt(sd, suffixes):
+        return {k: {"step": 0, "m": torch.zeros_like(v), "v": torch.zeros_like(v)} for k, v in sd.items()
+                if not is_buffer(k, suffixes)}
+    G = {k: v.detach().clone() for k, v in sdG.items()}
+    D = {k: v.detach().clone() for k, v in sdD.items()}
+    return {"G": G, "D": D, "G_ema": {k: v.clone() for k, v in G.items()}, "optG": opt(G, G_BUFFER_SUFFIXES),
+            "optD": opt(D, D_BUFFER_SUFFIXES), "p": float(p_init), "sign_cum": 0.0, "n_pred_cum": 0.0}
+
+
+def _adam_all(sd, grads, opt, hp):
+    lr, b1, b2 = hp
+    for k, g in grads.items():
+        g = torch.zeros_like(sd[k]) if g is None else g
+        sd[k] = adam_update(sd[k], g, opt[k], lr, b1, b2).detach()
+
+
+def train_iteration(state, iteration, draws, x_real, angle, hp):
+    """One whole Trainer.step (trainer.py:247-482) for one rank and one micro-batch.  `draws` maps the call-site
+    names of tests/golden/make_golden.py::TRAINER_SITES to the recorded random numbers; `hp` holds batch_size,
+    lr/betas of both optimizers BEFORE the lazy correction, lazy_gp, lazy_ada, gp (loss.gp), loss_gan, ema_kimg,
+    ema_rampup, warm-up settings and the ADA controller constants.  Returns the logged scalars."""
+    from . import augment as aug
+    B = x_real.shape[0]
+    sigma, ratio = warmup_params(iteration, hp["batch_size"], hp.get("fade_kimg", 0), hp.get("blur_init_sigma", 0),
+                                 hp.get("dropout_init_ratio", 0))
+    keep = (lambda s: draws[s].float() if ratio > 0 else None)
+    ada = (lambda s: {"G": draws[s + ".G"], "C": draws[s + ".C"]})
+    hpG = adam_hparams(hp["lrG"], hp["beta1G"], hp["beta2G"], None)
+    hpD = adam_hparams(hp["lrD"], hp["beta1D"], hp["beta2D"], hp["lazy_gp"] if hp["gp"] > 0 else None)
+    scalars = {}
+
+    # ---- G step (trainer.py:262-301)
+    G = with_grad(state["G"], G_BUFFER_SUFFIXES)
+    D = {k: v.detach() for k, v in state["D"].items()}
+    out, bufs = model.generator(G, draws["g.z"], angle, training=True, shifts=draws["g.shifts"], gumbel_u=draws["g.u"])
+    y_fake = model.discriminator(D, _augment(_warm(out["image"], sigma, keep("g.keep")), ada("g.ada")))
+    loss = model.loss_g_nsgan(y_fake)
+    keys = [k for k, v in G.items() if v.requires_grad]
+    grads = torch.autograd.grad(hp.get("loss_gan", 1.0) * loss, [G[k] for k in keys], allow_unused=True)
+    state["G"].update(bufs)
+    _adam_all(state["G"], dict(zip(keys, grads)), state["optG"], hpG)
+    scalars["loss/G/adversarial"] = float(loss.detach())
+
+    # ---- D step (trainer.py:373-412)
+    Gd = {k: v.detach() for k, v in state["G"].items()}
+    D = with_grad(state["D"], D_BUFFER_SUFFIXES)
+    with torch.no_grad():
+        out, bufs = model.generator(Gd, draws["d.z"], angle, training=True, shifts=draws["d.shifts"], gumbel_u=draws["d.u"])
+        xr = _augment(_warm(x_real, sigma, keep("d.keep_real")), ada("d.ada_real"))
+        xf = _augment(_warm(out["image"], sigma, keep("d.keep_fake")), ada("d.ada_fake"))
+    state["G"].update(bufs)
+    y_real, y_fake = model.discriminator(D, xr), model.discriminator(D, xf)
+    state["sign_cum"] += float(y_real.detach().sign().sum())
+    state["n_pred_cum"] += float(len(y_real))
+    loss = model.loss_d_nsgan(y_real, y_fake)
+    keys = [k for k, v in D.items() if v.requires_grad]
+    grads = torch.autograd.grad(hp.get("loss_gan", 1.0) * loss, [D[k] for k in keys])
+    _adam_all(state["D"], dict(zip(keys, grads)), state["optD"], hpD)
+    scalars.update({"loss/D/output/real": float(y_real.mean().detach()), "loss/D/output/fake": float(y_fake.mean().detach()),
+                    "loss/D/adversarial": float(loss.detach())})
+
+    # ---- lazy R1 (trainer.py:419-451); gp_weight = loss.gp * lazy.gp (trainer.py:131)
+    if hp["gp"] > 0 and iteration % hp["lazy_gp"] == 0:
+        D = with_grad(state["D"], D_BUFFER_SUFFIXES)
+        x = x_real.detach().clone().requires_grad_(True)
+        y = model.discriminator(D, _augment(_warm(x, sigma, keep("r1.keep")), ada("r1.ada")))
+        (g,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+        r1 = model.r1_penalty(g)
+        loss = (hp["gp"] * hp["lazy_gp"] / 2) * r1 + 0.0 * y.squeeze()[0]
+        keys = [k for k, v in D.items() if v.requires_grad]
+        grads = torch.autograd.grad(loss, [D[k] for k in keys], allow_unused=True)
+        _adam_all(state["D"], dict(zip(keys, grads)), state["optD"], hpD)
+        scalars["loss/D/gradient_penalty"] = float(r1.detach())
+
+    # ---- EMA generator (trainer.py:455-459) and ADA controller (:461-464)
+    decay = ema_decay(iteration, hp["batch_size"], hp["ema_kimg"], hp["ema_rampup"])
+    state["G_ema"] = ema_update(state["G_ema"], state["G"], decay)
+    if iteration % hp["lazy_ada"] == 0:
+        state["p"], rt = aug.ada_update_p(state["p"], state["sign_cum"], state["n_pred_cum"], hp["p_target"],
+                                          hp["ada_kimg"])
+        state["sign_cum"] = state["n_pred_cum"] = 0.0
+        scalars["stats/ada_rt"], scalars["stats/ada_p"] = rt, state["p"]
+    scalars.update({"stats/ema_decay": decay, "stats/warmup_blur_sigma": sigma, "stats/warmup_dropout_ratio": ratio})
+    return scalars

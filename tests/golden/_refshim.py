@@ -48,12 +48,16 @@ def install():
     cpp_ext.load = lambda *a, **k: types.SimpleNamespace()
     for name in [
         "kornia", "kornia.geometry", "kornia.geometry.conversions", "cv2", "imageio",
-        "seaborn", "numba", "torchvision", "torchvision.utils", "omegaconf",
+        "seaborn", "numba", "torchvision", "torchvision.utils", "torchvision.transforms",
+        "torchvision.transforms.functional", "omegaconf",
     ]:
         if name not in sys.modules:
             m = _Stub(name)
             m.__path__ = []
             sys.modules[name] = m
+            if "." in name:  # `import a.b.c as x` resolves c as an attribute of a.b
+                parent, _, leaf = name.rpartition(".")
+                object.__setattr__(sys.modules[parent], leaf, m)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
 

@@ -12,6 +12,7 @@ own draw sequence (same calls, same order), which reproduces them exactly.
 import copy
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -408,8 +409,214 @@ def golden_full():
     save("model_full.npz", out)
 
 
+# ----------------------------------------------------------------------------
+TRAINER_SITES = {
+    "z": ["g.z", "d.z"],
+    "G": ["g", "d"],
+    "A": ["g.ada", "d.ada_real", "d.ada_fake", "r1.ada"],
+    "W": ["g.keep", "d.keep_real", "d.keep_fake", "r1.keep"],
+}
+
+
+def golden_trainer():
+    """Whole iterations of the reference's OWN `Trainer.__init__` + `Trainer.step` (gans/trainer.py:45-202,247-482) on
+    CPU: optimizer hyper-parameters (:142-171), G step, D step, lazy R1, EMA (:455-459), ADA update (:461-464) and the
+    logged scalars, for the reduced configuration.  The class is instantiated unmodified; only names in the trainer
+    module's namespace that need a GPU / NCCL / KITTI are replaced: `torch.device` (-> cpu), `DDP` (pass-through holder
+    of `.module`), `KITTIRaw` (items from recipe.raw_batches), `InfiniteSampler` (sequential).  Every random draw of
+    an iteration is recorded at its call site (the draw is replayed from a saved RNG state right before the
+    reference consumes it) so that the oracle and the HIP Trainer can be fed the same numbers.
+    Two runs of 4 iterations at batch 8 with lazy.gp = lazy.ada = 2:  "t." (post-fade regime, warm-up off) and
+    "w." (warm-up active: Gaussian blur + Bernoulli dropout of trainer.py:219-245)."""
+    import contextlib
+    import tempfile
+    from collections import defaultdict
+
+    import torch.distributed as dist
+
+    import gans.trainer as rtr
+
+    class PassThroughDDP(torch.nn.Module):
+        def __init__(self, module, **kw):
+            super().__init__()
+            self.module = module
+
+        def forward(self, *a, **k):
+            return self.module(*a, **k)
+
+        def no_sync(self):
+            return contextlib.nullcontext()
+
+    H, W, B, NIT = 16, 64, 8, 4
+
+    class RecipeReals(torch.utils.data.Dataset):
+        def __init__(self, root, split, shape, min_depth, max_depth, **kw):
+            self.depth, self.mask = recipe.raw_batches(31 if split == "train" else 32, B * NIT, *shape, min_depth, max_depth)
+
+        def __len__(self):
+            return len(self.depth)
+
+        def __getitem__(self, i):
+            return {"depth": self.depth[i], "mask": self.mask[i]}
+
+    class Sequential(torch.utils.data.Sampler):
+        def __init__(self, dataset, rank=0, num_replicas=1, seed=0, **kw):
+            self.n = len(dataset)
+
+        def __iter__(self):
+            i = 0
+            while True:
+                yield i % self.n
+                i += 1
+
+    class TorchOnCPU:
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def device(*a, **k):
+            return torch.device("cpu")
+
+    rtr.torch = TorchOnCPU()
+    rtr.DDP = PassThroughDDP
+    rtr.KITTIRaw = RecipeReals
+    rtr.InfiniteSampler = Sequential
+    rtr.Console = lambda **kw: types.SimpleNamespace(log=lambda *a, **k: None)
+
+    work = tempfile.mkdtemp(prefix="dgv2_golden_trainer_")
+    os.makedirs(os.path.join(work, "data", "coords"))
+    small = np.load(os.path.join(HERE, "coords.npz"))["small_angle_file"]
+    np.save(os.path.join(work, "data", "coords", "small.npy"), small)
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"file://{work}/pg", rank=0, world_size=1)
+    cwd = os.getcwd()
+    os.chdir(work)
+    out = {}
+    try:
+        for tag, warm in (("t.", None), ("w.", dict(fade_kimg=0.1, blur_init_sigma=0.7, dropout_init_ratio=0.5))):
+            cfg = _refshim.load_cfg()
+            gk = cfg.model.generator
+            gk.mapping_kwargs.update(in_ch=32, out_ch=32)
+            gk.synthesis_kwargs.update(in_ch=32, ch_base=4, ch_max=16, resolution=[H, W], layers=[2, 2])
+            cfg.model.discriminator.layer_kwargs.update(ch_base=4, ch_max=16, resolution=[H, W])
+            cfg.dataset.name = "small"
+            t = cfg.training
+            t.update(rank=0, num_gpus=1, batch_size=B, batch_size_per_gpu=B, num_workers=0, resume=None)
+            t.lazy.update(gp=2, ada=2)
+            t.augment.update(p_init=0.5, kimg=1)
+            t.warmup.update(warm or dict(fade_kimg=0))
+            np.random.seed(0)
+            torch.manual_seed(0)
+            tr = rtr.Trainer(cfg)
+            recipe.fill_state_dict(tr.G.module.state_dict(), 7)
+            recipe.fill_state_dict(tr.D.module.state_dict(), 8)
+            tr.G_ema.load_state_dict(tr.G.module.state_dict())
+            for k, v in tr.G.module.state_dict().items():
+                if k.endswith(("pe.freqs", "pe.phase")):
+                    out[f"{tag}pe.{k}"] = v.clone()
+            out[f"{tag}angle"] = tr.coord.angle.clone()
+            for name, opt in (("optG", tr.optim_G), ("optD", tr.optim_D)):
+                pg = opt.param_groups[0]
+                out[f"{tag}{name}.hparams"] = np.array([pg["lr"], pg["betas"][0], pg["betas"][1], pg["eps"]], dtype=np.float64)
+            out[f"{tag}gp_weight"] = np.float64(cfg.training.loss.gp)   # already multiplied by lazy.gp (trainer.py:131)
+
+            rec, counts = {}, defaultdict(int)
+            clamp_probs = torch.distributions.utils.clamp_probs
+
+            def site(kind):
+                s = TRAINER_SITES[kind][counts[kind]]
+                counts[kind] += 1
+                return s
+
+            orig_z = tr.sample_z
+
+            def sample_z(batch_size):
+                z = orig_z(batch_size)
+                rec[site("z")] = z.clone()
+                return z
+
+            def g_pre(mod, args, kwargs):
+                if not mod.training:
+                    return
+                st = torch.get_rng_state()
+                n = args[0].shape[0]
+                shifts = torch.zeros((n, 2))
+                shifts[:, 1].uniform_(0, 1)
+                shifts = shifts.mul(2 * np.pi)
+                u = clamp_probs(torch.rand(n, 1, H, W))
+                torch.set_rng_state(st)
+                s = site("G")
+                rec[s + ".shifts"], rec[s + ".u"] = shifts[:, 1].clone(), u
+
+            def a_pre(mod, args):
+                st = torch.get_rng_state()
+                n = args[0].shape[0]
+                Gm = mod.sample_affine(n, H, W)
+                Cm = mod.sample_color(n)
+                torch.set_rng_state(st)
+                s = site("A")
+                rec[s + ".G"], rec[s + ".C"] = Gm, Cm
+
+            orig_warmup = tr.warmup
+
+            def warmup(x):
+                s = site("W")
+                if tr.dropout_ratio > 0:
+                    st = torch.get_rng_state()
+                    rec[s] = torch.bernoulli(1 - torch.full_like(x, tr.dropout_ratio))
+                    torch.set_rng_state(st)
+                return orig_warmup(x)
+
+            tr.sample_z, tr.warmup = sample_z, warmup
+            tr.G.module.register_forward_pre_hook(g_pre, with_kwargs=True)
+            tr.A.register_forward_pre_hook(a_pre)
+
+            mods = (("G", tr.G.module), ("D", tr.D.module), ("Gema", tr.G_ema))
+            opts = (("optG", tr.optim_G, tr.G.module), ("optD", tr.optim_D, tr.D.module))
+            pkeys = {name: [k for k, _ in m.named_parameters()] for name, m in mods}
+            bkeys = {name: [k for k in m.state_dict() if k.endswith("ema_var") or k == "w_avg"] for name, m in mods}
+            for name in pkeys:
+                out[f"{tag}keys.param.{name}"] = np.array(pkeys[name])
+                out[f"{tag}keys.buf.{name}"] = np.array(bkeys[name])
+
+            torch.manual_seed(77)
+            for it in range(1, (NIT if warm is None else 2) + 1):
+                rec.clear()
+                counts.clear()
+                scalars = tr.step(it)
+                pre = f"{tag}it{it}."
+                for k, v in rec.items():
+                    out[pre + "draw." + k] = v.to(torch.uint8) if ".keep" in k else v.clone()
+                for k, v in scalars.items():
+                    out[pre + "scalar." + k] = np.float64(v)
+                # per-tensor L2 norms of every parameter and the values of the mutable buffers, in keys.* order
+                for name, m in mods:
+                    sd = m.state_dict()
+                    out[f"{pre}norm.{name}"] = torch.stack([sd[k].double().norm() for k in pkeys[name]])
+                    if bkeys[name]:
+                        out[f"{pre}buf.{name}"] = torch.cat([sd[k].double().reshape(-1) for k in bkeys[name]])
+                for k in ("p", "sign_cum", "n_pred_cum"):
+                    out[f"{pre}A.{k}"] = getattr(tr.A, k).clone()
+                for name, opt, mod in opts:
+                    st = [opt.state[p] for p in mod.parameters()]
+                    out[f"{pre}{name}.v_norm"] = torch.stack([s_["exp_avg_sq"].double().norm() for s_ in st])
+                    out[f"{pre}{name}.step"] = np.array([float(s_["step"]) for s_ in st])
+            if warm is None:
+                for name, m in mods:
+                    for k, v in m.state_dict().items():
+                        if not k.endswith(recipe.SKIP_SUFFIXES):
+                            out[f"{tag}final.{name}.{k}"] = v.clone()
+                for name, opt, mod in opts:
+                    out[f"{tag}final.{name}.v_slice"] = torch.stack(
+                        [torch.nn.functional.pad(opt.state[p]["exp_avg_sq"].flatten()[:16], (0, max(0, 16 - p.numel())))
+                         for p in mod.parameters()])
+    finally:
+        os.chdir(cwd)
+    save("trainer_small.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full"]
+    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer"]
     if "ops" in which:
         golden_ops()
     if "coords" in which:
@@ -420,3 +627,5 @@ if __name__ == "__main__":
         golden_small()
     if "full" in which:
         golden_full()
+    if "trainer" in which:
+        golden_trainer()

@@ -32,3 +32,13 @@ def fill_state_dict(sd, seed=1234):
         with torch.no_grad():
             t.copy_(v.to(t.dtype))
     return sd
+
+
+def raw_batches(seed, n, H, W, min_depth=1.45, max_depth=80.0):
+    """Deterministic stand-in for the KITTI loader's items (gans/datasets/kitti.py returns {"depth", "mask"} per
+    scan): depth ~ U(0, 1.1 max_depth) so that some pixels fall outside [min_depth, max_depth] and exercise
+    CoordBridge's validity mask; mask ~ Bernoulli(0.85).  Returns (depth, mask) [n,1,H,W]."""
+    g = torch.Generator().manual_seed(seed)
+    depth = torch.rand(n, 1, H, W, generator=g) * (1.1 * max_depth)
+    mask = (torch.rand(n, 1, H, W, generator=g) < 0.85).float()
+    return depth, mask

@@ -199,3 +199,73 @@ def test_ada_fixed_max_padding_is_equivalent(g_small):
     want = augment.ada_forward(x, d["ds_adaG_real"], d["ds_adaC_real"])
     got = augment.ada_forward(x, d["ds_adaG_real"], d["ds_adaC_real"], pads=(W - 1, W - 1, H - 1, H - 1))
     close(got, want, atol=5e-5)
+
+
+# ---------------------------------------------------------------------------- whole iterations
+@pytest.fixture(scope="session")
+def g_trainer():
+    import os
+    from conftest import GOLDEN
+    d = np.load(os.path.join(GOLDEN, "trainer_small.npz"))
+    return {k: ([str(x) for x in d[k]] if ".keys." in k else torch.from_numpy(d[k])) for k in d.files}
+
+
+def _norm_err(sd, keys, want):
+    got = torch.stack([sd[k].double().norm() for k in keys])
+    return float(((got - want).abs() / (want.abs() + 1e-12)).max())
+
+
+@pytest.mark.parametrize("tag", ["t.", "w."])
+def test_whole_iterations_match_reference_trainer(g_trainer, tag):
+    """oracle.step.train_iteration (G step, D step, lazy R1, Adam with the lazy-regularisation correction, EMA
+    generator, ADA controller, warm-up blur/dropout) against the fixture produced by the reference's own
+    Trainer.__init__ + Trainer.step: scalars, per-parameter norms, mutable buffers and p after EVERY iteration, every
+    tensor of G, D, G_ema after the last one."""
+    from helpers import trainer_fixture_draws, trainer_fixture_hp, trainer_fixture_reals, trainer_fixture_state
+    d = g_trainer
+    cfg, sdG, sdD = trainer_fixture_state(d, tag)
+    hp = trainer_fixture_hp(d, tag)
+    # optimizer hyper-parameters of trainer.py:142-171
+    for name, lazy in (("optG", None), ("optD", hp["lazy_gp"])):
+        lr, b1, b2 = step.adam_hparams(0.002, 0.0, 0.99, lazy)
+        np.testing.assert_allclose(d[f"{tag}{name}.hparams"].numpy()[:3], [lr, b1, b2], rtol=1e-12)
+    assert float(d[f"{tag}gp_weight"]) == hp["gp"] * hp["lazy_gp"]
+    state = step.new_train_state(sdG, sdD, hp["p_init"])
+    angle = d[f"{tag}angle"]
+    for it in range(1, hp["iterations"] + 1):
+        depth, mask = trainer_fixture_reals(tag, it)
+        x_real = torch.from_numpy(coords.fetch_reals(depth.numpy(), mask.numpy(), 1.45, 80.0, -1.0))
+        draws = trainer_fixture_draws(d, tag, it)
+        B = x_real.shape[0]
+        sc = step.train_iteration(state, it, draws, x_real, angle.repeat_interleave(B, 0), hp)
+        pre = f"{tag}it{it}."
+        want = {k[len(pre) + 7:]: float(v) for k, v in d.items() if k.startswith(pre + "scalar.")}
+        assert set(sc) == set(want), (it, set(sc) ^ set(want))
+        for k, v in want.items():
+            assert abs(sc[k] - v) <= 2e-4 * abs(v) + 1e-6, (it, k, sc[k], v)
+        for name, sd in (("G", state["G"]), ("D", state["D"]), ("Gema", state["G_ema"])):
+            assert _norm_err(sd, d[f"{tag}keys.param.{name}"], d[f"{pre}norm.{name}"]) < 1e-4, (it, name)
+            bk = d[f"{tag}keys.buf.{name}"]
+            if bk:
+                got = torch.cat([sd[k].double().reshape(-1) for k in bk])
+                close(got, d[f"{pre}buf.{name}"], rtol=1e-4, atol=1e-6)
+        assert abs(state["p"] - float(d[f"{pre}A.p"])) < 1e-6
+        assert abs(state["sign_cum"] - float(d[f"{pre}A.sign_cum"])) < 1e-6
+        for name, opt in (("optG", state["optG"]), ("optD", state["optD"])):
+            keys = d[f"{tag}keys.param.{name[3:]}"]
+            got = torch.stack([opt[k]["v"].double().norm() for k in keys])
+            wantv = d[f"{pre}{name}.v_norm"]
+            assert float(((got - wantv).abs() / (wantv + 1e-20)).max()) < 2e-3, (it, name)
+            assert [opt[k]["step"] for k in keys] == [int(s) for s in d[f"{pre}{name}.step"]]
+    if tag == "t.":
+        # Adam with beta1 = 0 moves every element by ~lr * sign(g): an element whose gradient is rounding noise may
+        # differ by 2 lr per step; everything else must agree to 1e-3 of the tensor's scale
+        for name, sd in (("G", state["G"]), ("D", state["D"]), ("Gema", state["G_ema"])):
+            bad = tot = 0
+            for k, v in sub_dict(d, f"{tag}final.{name}.").items():
+                err = (sd[k] - v).abs()
+                tol = 1e-3 * float(v.abs().max()) + 1e-7
+                bad += int((err > tol).sum())
+                tot += v.numel()
+                assert float(err.max()) <= 2 * 0.002 * hp["iterations"] * 1.5 + tol, (name, k)
+            assert bad <= 1e-4 * tot, (name, bad, tot)
