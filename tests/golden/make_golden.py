@@ -406,6 +406,41 @@ def golden_full():
         out[f"ds_gradnorm.{k}"] = gv.norm()
         out[f"ds_gradslice.{k}"] = gv.flatten()[:32].clone()
     out["x_real"] = x_real
+    out["G1buf.w_avg"] = G.state_dict()["w_avg"].clone()
+
+    # ---- lazy R1 at full size (trainer.py:419-451): double backward through D and ADA
+    Gm, Cm = capture_ada(A, B, H, W, 204)
+    xin = x_real.detach().clone().requires_grad_(True)
+    torch.manual_seed(204)
+    y = D(A(xin))
+    (gx,) = torch.autograd.grad(y.sum(), xin, create_graph=True)
+    r1 = (gx ** 2).sum(dim=[1, 2, 3]).mean()
+    loss = (16.0 / 2) * r1 + 0.0 * y.squeeze()[0]
+    rgrads = torch.autograd.grad(loss, list(dparams.values()), allow_unused=True)
+    out.update(r1_adaG=Gm, r1_adaC=Cm, r1_gradx_row=gx[:, :, 31].detach().clone(), r1_gradx_norm=gx.detach().norm(),
+               r1_penalty=r1.detach())
+    for k, gv in zip(dparams.keys(), rgrads):
+        if gv is not None:
+            out[f"r1_gradnorm.{k}"] = gv.norm()
+            out[f"r1_gradslice.{k}"] = gv.flatten()[:32].clone()
+
+    # ---- eval forwards with the buffers the G step left (BASELINE configs[0]: B = 1, truncation_psi = 0.7, the
+    # quick_demo.py call; configs[1]-shaped: B = 32).  z by recipe: torch.Generator().manual_seed(10).
+    G.eval().requires_grad_(False)
+    z32 = torch.randn(32, 512, generator=torch.Generator().manual_seed(10))
+    torch.manual_seed(205)
+    with torch.no_grad():
+        o1 = G(z32[:1], angle=cb.angle, truncation_psi=0.7)
+    torch.manual_seed(205)
+    out["ev1_u"] = torch.distributions.utils.clamp_probs(torch.rand(1, 1, H, W))
+    out.update(ev1_image=o1["image"], ev1_image_orig=o1["image_orig"], ev1_raydrop_logit=o1["raydrop_logit"])
+    with torch.no_grad():
+        o32 = G(z32, angle=cb.angle.repeat_interleave(32, dim=0), truncation_psi=0.7)
+    for name in ("image_orig", "raydrop_logit"):
+        v = o32[name]
+        out[f"ev32_{name}_row"] = v[:, 0, 31].clone()                      # [32, 512]
+        out[f"ev32_{name}_mean"] = v.double().mean(dim=[1, 2, 3])
+        out[f"ev32_{name}_norm"] = v.double().flatten(1).norm(dim=1)
     save("model_full.npz", out)
 
 

@@ -269,3 +269,82 @@ def test_whole_iterations_match_reference_trainer(g_trainer, tag):
                 tot += v.numel()
                 assert float(err.max()) <= 2 * 0.002 * hp["iterations"] * 1.5 + tol, (name, k)
             assert bad <= 1e-4 * tot, (name, bad, tot)
+
+
+# ---------------------------------------------------------------------------- full size (64x512, full widths)
+def _full_state():
+    """Reference-layout state dicts of the full-size fixture: weights by recipe (seeds of golden_full)."""
+    import recipe
+    from helpers import build_models, full_cfg
+    G, D = build_models(full_cfg(), "cpu")
+    sdG = recipe.fill_state_dict({k: v.clone() for k, v in G.state_dict().items()}, 1234)
+    sdD = recipe.fill_state_dict({k: v.clone() for k, v in D.state_dict().items()}, 4321)
+    return sdG, sdD
+
+
+def _slice_check(grads, d, prefix, n, rtol_norm=1e-3, floor=0.0):
+    for k, sl in sub_dict(d, f"{prefix}gradslice.").items():
+        want_norm = float(d[f"{prefix}gradnorm.{k}"])
+        assert abs(float(grads[k].norm()) - want_norm) <= rtol_norm * want_norm + floor, k
+        assert float((grads[k].flatten()[:n] - sl).abs().max()) <= 1e-3 * float(sl.abs().max()) + 1e-3 * want_norm / max(
+            1.0, grads[k].numel() ** 0.5) + floor, k
+
+
+def test_full_size_steps_match_reference(g_full, g_coords):
+    """The oracle at the benchmark's size (64x512, channel widths 512..32, B = 2) against tests/golden/model_full.npz:
+    G step (outputs, every parameter gradient's norm and leading slice, ema_var / w_avg after the step), D step,
+    lazy R1 (double backward) and the eval forwards of BASELINE configs[0] / [1]."""
+    d = g_full
+    sdG, sdD = _full_state()
+    for k, v in sub_dict(d, "G.").items():
+        sdG[k] = v
+    B = d["z"].shape[0]
+    angle = g_coords["angle_64x512"]
+    ang = angle.repeat_interleave(B, 0)
+    ada = {"G": d["gs_adaG"], "C": d["gs_adaC"]}
+    loss, grads, bufs, ex = step.g_step(sdG, sdD, d["z"], ang, d["gs_shifts"], d["gs_u"], ada=ada)
+    close(loss, d["gs_loss"], rtol=1e-4)
+    close(ex["y_fake"], d["gs_y_fake"], rtol=1e-3, atol=1e-3 * float(d["gs_y_fake"].abs().max()))
+    close(ex["x_aug"][:, :, 31], d["gs_x_aug_row"], atol=1e-4)
+    _slice_check(grads, d, "gs_", 32)
+    for k, v in sub_dict(d, "G1buf.").items():
+        close(bufs[k], v, rtol=1e-5, atol=1e-6)
+    # D step of the fixture: real batch + the G step's augmented fakes
+    D = step.with_grad(sdD, step.D_BUFFER_SUFFIXES)
+    xr = augment.ada_forward(d["x_real"], d["ds_adaG_real"], d["ds_adaC_real"])
+    y_real, y_fake = model.discriminator(D, xr), model.discriminator(D, ex["x_aug"])
+    lossd = model.loss_d_nsgan(y_real, y_fake)
+    close(y_real, d["ds_y_real"], rtol=1e-3, atol=1e-3 * float(d["ds_y_real"].abs().max()))
+    close(lossd, d["ds_loss"], rtol=1e-4)
+    keys = [k for k, v in D.items() if v.requires_grad]
+    _slice_check(dict(zip(keys, torch.autograd.grad(lossd, [D[k] for k in keys]))), d, "ds_", 32)
+    # lazy R1
+    r1, rgrads, rex = step.r1_step(sdD, d["x_real"], 16.0, ada={"G": d["r1_adaG"], "C": d["r1_adaC"]})
+    close(r1, d["r1_penalty"], rtol=1e-3)
+    close(rex["grad_x"][:, :, 31], d["r1_gradx_row"], rtol=1e-3, atol=1e-3 * float(d["r1_gradx_row"].abs().max()))
+    top = max(float(v) for k, v in d.items() if k.startswith("r1_gradnorm."))
+    _slice_check({k: v for k, v in rgrads.items() if v is not None}, d, "r1_", 32, rtol_norm=2e-3, floor=1e-5 * top)
+
+
+def test_full_size_eval_forwards_match_reference(g_full, g_coords):
+    """BASELINE configs[0] (quick_demo.py call: eval, B = 1, truncation_psi = 0.7) and the configs[1]-shaped B = 32
+    eval forward, with the buffers the fixture's G step left."""
+    d = g_full
+    sdG, _ = _full_state()
+    sdG.update(sub_dict(d, "G."))
+    sdG.update(sub_dict(d, "G1buf."))
+    angle = g_coords["angle_64x512"]
+    z32 = torch.randn(32, 512, generator=torch.Generator().manual_seed(10))
+    with torch.no_grad():
+        o, _ = model.generator(sdG, z32[:1], angle, training=False, gumbel_u=d["ev1_u"], truncation_psi=0.7)
+        close(o["image_orig"], d["ev1_image_orig"], atol=1e-4)
+        close(o["raydrop_logit"], d["ev1_raydrop_logit"], rtol=1e-4, atol=1e-3 * float(d["ev1_raydrop_logit"].abs().max()))
+        # the ray-drop mask may flip where the Gumbel-perturbed logit is ~0; everything else agrees
+        assert float(((o["image"] - d["ev1_image"]).abs() > 1e-4).float().mean()) < 1e-3
+        o, _ = model.generator(sdG, z32, angle.repeat_interleave(32, 0), training=False, truncation_psi=0.7,
+                               gumbel_u=torch.full((32, 1, 64, 512), 0.5))
+    for name in ("image_orig", "raydrop_logit"):
+        v = o[name]
+        scale = float(d[f"ev32_{name}_row"].abs().max())
+        close(v[:, 0, 31], d[f"ev32_{name}_row"], rtol=1e-4, atol=1e-3 * scale)
+        close(v.double().flatten(1).norm(dim=1), d[f"ev32_{name}_norm"], rtol=1e-4, atol=0)
