@@ -363,15 +363,15 @@ class SynthesisNetwork(nn.Module):
     def _angle_pyramid(self, angle):
         """[coarsest ... finest] unshifted angle grids of a batch-shared grid; cached like FourierFeature.encoded (the
         sensor's grid is a constant; not while a hipGraph is being captured)."""
-        key = (angle.data_ptr(), angle._version, tuple(angle.shape))
-        if getattr(self, "_pyr_key", None) == key:
+        key = (angle._version, tuple(angle.shape))
+        if getattr(self, "_pyr_src", None) is angle and self._pyr_key == key:   # same tensor object, unmodified
             return self._pyr
         pyr, a = [angle], angle
         for layer in self.layers[:0:-1]:
             a = layer.downsample_angle(a, None, None)
             pyr.insert(0, a)
         if _CONST_CACHE and not (angle.is_cuda and torch.cuda.is_current_stream_capturing()):
-            self._pyr_key, self._pyr = key, pyr
+            self._pyr_src, self._pyr_key, self._pyr = angle, key, pyr
         return pyr
 
     def _batched_styles(self, ws):
@@ -511,6 +511,11 @@ class Discriminator(nn.Module):
 
         kw = dict(bias=False, ring=ring, equal_lr=True)
         self.num_fp16_layers = num_fp16_layers
+        # The reference leaves its autocast region before the epilogue (dusty_v2.py:394-395): minibatch-stddev, the
+        # 3x3 513->512 conv and both Linear layers run in fp32 whatever num_fp16_layers says.  "fp32" keeps that;
+        # "bf16" (opt-in: attribute, or DGV2_D_EPILOGUE=bf16) runs the conv and the 65536->512 Linear with bf16
+        # operands and fp32 accumulation when num_fp16_layers == -1.
+        self.epilogue_dtype = os.environ.get("DGV2_D_EPILOGUE", "fp32")
         c_in = in_ch * 2 if pre_blur else in_ch
         layers = [ops.BlurVH(ring=ring)] if pre_blur else []
         layers += [ops.Conv2d(c_in, ch(0), 1, 1, 0, **kw)]
@@ -541,11 +546,24 @@ class Discriminator(nn.Module):
                 items += layer.bank_entries(vec)
         mb, conv = self.epilogue[0], self.epilogue[1]
         cin = conv.in_ch
-        items.append((conv, conv.bank_entry(pad_in_to=(cin + vec - 1) // vec * vec)))
+        edt = self._epilogue_dtype()
+        evec = 32 if edt == LOW else 16
+        epi = (conv, conv.bank_entry(pad_in_to=(cin + evec - 1) // evec * evec))
+        if edt == dt:
+            items.append(epi)
         if len(items) > 32:
             return None
         prepared = native.conv_weight_bank([e for _, e in items], dt)
-        return {m: (e[1], e[2], wf, wt) for (m, e), (wf, wt) in zip(items, prepared)}
+        bank = {m: (e[1], e[2], wf, wt) for (m, e), (wf, wt) in zip(items, prepared)}
+        if edt != dt:   # fp32 epilogue behind a reduced-precision trunk: its weight is prepared by a launch of its own
+            (wf, wt), = native.conv_weight_bank([epi[1]], edt)
+            bank[conv] = (epi[1][1], epi[1][2], wf, wt)
+        return bank
+
+    def _epilogue_dtype(self):
+        if self.epilogue_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"epilogue_dtype must be 'fp32' or 'bf16', got {self.epilogue_dtype!r}")
+        return LOW if (self.epilogue_dtype == "bf16" and self.num_fp16_layers == -1) else torch.float32
 
     def _fused_stem(self, h, layers):
         """BlurVH -> 1x1 conv -> bias + lrelu of a one-channel input as ONE streaming kernel (dgv2_stem_fwd/bwd)."""
@@ -555,8 +573,9 @@ class Discriminator(nn.Module):
         return native.stem(h, w, act.bias, blur.blur_h.spec.ring, act.negative_slope, act.scale,
                            LOW if low else torch.float32)
 
-    def forward(self, h, splits=1, double_backward=False):
-        """h [B,C,H,W] (C = 1 on the dusty_v2 path) -> logits [B,1].  `splits` = number of independent
+    def forward(self, h, splits=1, double_backward=False, features_only=False):
+        """h [B,C,H,W] (C = 1 on the dusty_v2 path) -> logits [B,1]  (features_only: the trunk's output [B,H/16,W/16,C]
+        channels-last, before the fp32 epilogue -- used by the precision tests).  `splits` = number of independent
         sub-batches stacked along dim 0 (minibatch statistics are computed per sub-batch), so that
         D(real) and D(fake) of the discriminator step can share one pass over the weights.
         `double_backward`: the caller will differentiate the input gradient again (R1); the fused stem is
@@ -588,11 +607,12 @@ class Discriminator(nn.Module):
             else:
                 x = layer.forward_cl(x)
                 i += 1
+        if features_only:
+            return x
         mb, conv, act1, _, lin1, act2, lin2 = self.epilogue
-        # The reference runs the epilogue in fp32.  With num_fp16_layers == -1 ("everything reduced")
-        # the 3x3 epilogue conv (303 MMAC/img) runs in bf16 with fp32 accumulation here; mbstd and the
-        # two Linear layers stay fp32.  See DESIGN.md section 4.
-        edt = LOW if self.num_fp16_layers == -1 else torch.float32
+        # fp32 island of the reference (dusty_v2.py:394-395) unless epilogue_dtype == "bf16" was asked for
+        edt = self._epilogue_dtype()
+        x = x.to(edt)
         cin = x.shape[3] + mb.features
         vec = 32 if edt == LOW else 16
         cpad = (cin + vec - 1) // vec * vec  # whole 64-byte K-steps for the direct conv engine
@@ -605,8 +625,8 @@ class Discriminator(nn.Module):
         x = conv.forward_cl(x, pad_in_to=cpad, act=act1, bank=bank)
         x = ops.from_cl(x).flatten(1)  # NCHW flatten order of the reference's nn.Flatten
         if edt == LOW and lin1.module.bias is None and lin1.gain_ == 1.0:
-            # "everything reduced": the 65536 -> 512 Linear (8.6 GFLOP at B = 128, 134 MB of fp32 weights) as a
-            # bf16 hipBLASLt GEMM with fp32 accumulation, like the autocast path of the reference's AMP mode
+            # epilogue_dtype == "bf16": the 65536 -> 512 Linear (8.6 GFLOP at B = 128, 134 MB of fp32 weights) with
+            # bf16 operands and fp32 accumulation
             x = native.linear_low(x, lin1.module.weight, lin1.scale) if x.is_cuda else \
                 F.linear(x, lin1.module.weight.to(LOW)).float() * lin1.scale
         else:

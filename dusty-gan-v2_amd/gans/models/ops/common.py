@@ -266,11 +266,14 @@ class MinibatchStdDev(nn.Module):
         return f"group={self.group}, features={self.features}"
 
 
-def filter2d(x, kernel, gain=1):
+def filter2d(x, kernel, gain=1, normalize=True):
     """Separable blur with ring / replicate extension (reference: common.py:27-42); only used by
-    the warm-up blur of the trainer, which is off in configs/gans/dusty_v2.yaml (sigma 0)."""
+    the warm-up blur of the trainer, which is off in configs/gans/dusty_v2.yaml (sigma 0).
+    normalize=False: the taps already sum to one (device-side schedule of the trainer)."""
     assert kernel.ndim == 1
-    kernel = kernel / kernel.sum() * (gain ** 0.5)
+    if normalize:
+        kernel = kernel / kernel.sum()
+    kernel = kernel * (gain ** 0.5)
     k = len(kernel)
     p0, p1 = k // 2, (k - 1) // 2
     x = F.pad(x, (p0, p1, 0, 0), mode="circular")

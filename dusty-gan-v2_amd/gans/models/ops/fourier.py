@@ -58,25 +58,26 @@ class FourierFeature(nn.Module):
         """Contiguous copy of the azimuth frequencies [F] (the rotation of the PE columns needs them every pass):
         cached, and rebuilt when the buffer changes (load_state_dict, .to())."""
         f = self.freqs
-        key = (f.data_ptr(), f._version, f.device)
-        if getattr(self, "_fw_key", None) != key:
-            self._fw_key, self._fw = key, f.reshape(-1, 2)[:, 1].contiguous()
+        if getattr(self, "_fw_src", None) is not f or self._fw_key != f._version:
+            self._fw_src, self._fw_key, self._fw = f, f._version, f.reshape(-1, 2)[:, 1].contiguous()
         return self._fw
 
     def encoded(self, angle, dtype):
         """[1,H,W,2F] channels-last encoding of a batch-shared angle grid.  Frequencies and phases are buffers and the
-        sensor's angle grid is a constant, so the result is cached across calls (keyed on the storage and version of
-        everything it depends on): the training step then spends no launch on it.  Nothing is cached while a hipGraph
-        is being captured (a tensor born inside a capture belongs to that graph's memory pool)."""
-        key = (angle.data_ptr(), angle._version, tuple(angle.shape), dtype, self.freqs.data_ptr(), self.freqs._version,
-               self.phase.data_ptr(), self.phase._version)
-        if getattr(self, "_enc_key", None) == key:
+        sensor's angle grid is a constant, so the result is cached across calls: the training step then spends no launch
+        on it.  The entry is valid for the very tensor OBJECTS it was computed from (held by the entry, so their storage
+        cannot be recycled for another grid) at the versions they had; a fresh or modified angle tensor always misses.
+        Nothing is cached while a hipGraph is being captured (a tensor born inside a capture belongs to that graph's
+        memory pool)."""
+        key = (angle._version, tuple(angle.shape), dtype, self.freqs._version, self.phase._version)
+        src = getattr(self, "_enc_src", None)
+        if src is not None and src[0] is angle and src[1] is self.freqs and src[2] is self.phase and self._enc_key == key:
             return self._enc
         H, W = angle.shape[2:]
         pe0 = torch.empty((1, H, W, self.out_ch), device=angle.device, dtype=dtype)
         self.encode_into(pe0, 0, angle)
         if _CONST_CACHE and not (angle.is_cuda and torch.cuda.is_current_stream_capturing()):
-            self._enc_key, self._enc = key, pe0
+            self._enc_src, self._enc_key, self._enc = (angle, self.freqs, self.phase), key, pe0
         return pe0
 
     def encode_into(self, out, c0, angle, shift=None):

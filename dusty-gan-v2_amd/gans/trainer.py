@@ -58,6 +58,15 @@ class Trainer:
         self.resolution = cfg.model.generator.synthesis_kwargs.resolution
         self.B = int(cfg.training.get("batch_size_per_gpu", cfg.training.batch_size // self.num_gpus))
         self.batch_size = int(cfg.training.batch_size)
+        if self.batch_size != self.B * self.num_gpus:
+            # train_gan.py:183-185 derives batch_size_per_gpu = batch_size // num_gpus and the loader hands out exactly
+            # one chunk of that size per step, so the reference's accumulation loop (trainer.py:255-257) always runs
+            # once; EMA, warm-up and the resume arithmetic all assume the global batch is what one step processed
+            raise ValueError(f"training.batch_size ({self.batch_size}) must equal batch_size_per_gpu ({self.B}) x "
+                             f"num_gpus ({self.num_gpus}): gradient accumulation over several chunks is not built")
+        if cfg.training.gan_objective in ("ragan", "rahinge", "ralsgan"):
+            raise NotImplementedError(f"gan_objective={cfg.training.gan_objective}: the relativistic objectives need "
+                                      "D(A(real)) in the generator step (trainer.py:283-287), which is not built")
 
         # models (rank 0's initial weights are broadcast, as DDP's constructor does)
         self.G = build_generator(cfg.model.generator).to(self.device)
@@ -81,10 +90,9 @@ class Trainer:
         self.auxin = {"angle": self.coord.angle}  # [1,2,H,W]; kernels broadcast it over the batch
 
         # data
-        root = cfg.dataset.get("root", "")
-        if cfg.dataset.name != "synthetic" and os.path.isdir(root):
-            raise NotImplementedError("the KITTI loader is outside this round's scope (SURVEY.md section 8f); "
-                                      "use dataset.name=synthetic or remove dataset.root")
+        if cfg.dataset.name != "synthetic":
+            raise NotImplementedError(f"dataset.name={cfg.dataset.name}: the KITTI loader is outside this tier's scope "
+                                      "(SURVEY.md section 8f); set dataset.name=synthetic for in-HBM synthetic scans")
         self.iter_train_loader = iter(SyntheticRangeImages(
             self.resolution, cfg.dataset.min_depth, cfg.dataset.max_depth, self.B, self.device,
             seed=cfg.random_seed + self.rank))
@@ -131,6 +139,13 @@ class Trainer:
         self.blur_sigma = 0
         self.dropout_ratio = 0
         self.iters_to_imgs = lambda i: int(i * self.batch_size)
+        # device-side warm-up schedule: the step bodies read the blur taps and the dropout ratio from these two static
+        # buffers (refreshed by set_warmup_params), so the fade-in regime replays as hipGraphs too
+        self._wu_n = int(np.floor(float(cfg.training.warmup.blur_init_sigma) * 3)) if self.warmup_fade_kimg > 0 else 0
+        self._wu_taps = torch.zeros(2 * self._wu_n + 1, device=self.device)
+        self._wu_ratio = torch.zeros((), device=self.device)
+        self._wu_host = None
+        self._injected = None   # static buffers of injected random draws (parity tests), see set_draws
 
     # ------------------------------------------------------------------ helpers
     def sample_z(self, batch_size):
@@ -143,22 +158,73 @@ class Trainer:
         return {"image": x, "raydrop_mask": mask}
 
     def set_warmup_params(self, iteration):
+        """reference: trainer.py:219-232; also refreshes the device copies the step bodies read."""
         num_imgs = self.iters_to_imgs(iteration)
         w = self.cfg.training.warmup
         fade = max(1 - num_imgs / self.warmup_fade_kimg, 0) if self.warmup_fade_kimg > 0 else 0
         self.blur_sigma = fade * w.blur_init_sigma
         self.dropout_ratio = fade * w.dropout_init_ratio
+        if (self.blur_sigma, self.dropout_ratio) != self._wu_host:
+            self._wu_host = (self.blur_sigma, self.dropout_ratio)
+            n, nmax = int(np.floor(self.blur_sigma * 3)), self._wu_n
+            taps = np.zeros(2 * nmax + 1, dtype=np.float32)
+            if n > 0:   # trainer.py:238-239 + the normalisation of filter2d (common.py:29), zero beyond floor(3 sigma)
+                k = np.exp2(-np.square(np.arange(-n, n + 1, dtype=np.float32) / np.float32(self.blur_sigma)))
+                taps[nmax - n:nmax + n + 1] = k / k.sum()
+            else:
+                taps[nmax] = 1.0
+            self._wu_taps.copy_(torch.from_numpy(taps))
+            self._wu_ratio.fill_(float(self.dropout_ratio))
 
-    def warmup(self, x):
-        """reference: trainer.py:234-245."""
-        blur_size = np.floor(self.blur_sigma * 3)
-        if blur_size > 0:
-            k = torch.arange(-blur_size, blur_size + 1, device=x.device)
-            x = filter2d(x, k.div(self.blur_sigma).square().neg().exp2())
-        if self.dropout_ratio > 0:
-            keep = (torch.rand_like(x) < (1 - self.dropout_ratio)).to(x.dtype)
-            x = keep * x + (1 - keep) * float(self.cfg.dataset.raydrop_const)
-        return x
+    def _warm(self):
+        return self.blur_sigma > 0 or self.dropout_ratio > 0
+
+    def warmup(self, x, keep=None):
+        """reference: trainer.py:234-245.  Static shapes: the blur always has 2 floor(3 sigma_init) + 1 taps (zeros
+        beyond the current floor(3 sigma): the ring / replicate extension they touch is weighted by zero) and the
+        Bernoulli keep mask compares against the device-side ratio.  `keep` injects the mask (parity tests)."""
+        if not self._warm():
+            return x
+        if self._wu_n > 0:
+            x = filter2d(x, self._wu_taps, normalize=False)
+        if keep is None:
+            keep = (torch.rand_like(x) < (1 - self._wu_ratio)).to(x.dtype)
+        return keep * x + (1 - keep) * float(self.cfg.dataset.raydrop_const)
+
+    # ------------------------------------------------------------------ injected randomness (parity tests)
+    def set_draws(self, draws):
+        """Inject the random numbers of the NEXT iteration, keyed by call site as in tests/golden/make_golden.py
+        (TRAINER_SITES): g.z, g.shifts, g.u, g.keep, g.ada.{G,C}, d.z, d.shifts, d.u, d.keep_real, d.keep_fake,
+        d.ada_real.{G,C}, d.ada_fake.{G,C}, r1.keep, r1.ada.{G,C}.  The values are copied into static device buffers
+        that the step bodies read, so injected runs replay as hipGraphs as well.  None restores on-device sampling."""
+        if draws is None:
+            self._injected = None
+            return
+        if self._injected is None:
+            self._injected = {}
+        for k, v in draws.items():
+            v = v.to(self.device, torch.float32)
+            if k not in self._injected:
+                self._injected[k] = v.clone()
+            else:
+                self._injected[k].copy_(v)
+
+    def _draw(self, key):
+        return None if self._injected is None else self._injected.get(key)
+
+    def _z(self, site):
+        z = self._draw(site + ".z")
+        return self.sample_z(self.B) if z is None else z
+
+    def _g_noise(self, site):
+        if self._injected is None:
+            return None
+        return {"shifts": self._injected[site + ".shifts"], "gumbel_u": self._injected[site + ".u"]}
+
+    def _ada(self, site):
+        if self._injected is None:
+            return None
+        return {"G": self._injected[site + ".G"], "C": self._injected[site + ".C"]}
 
     # ------------------------------------------------------------------ sub-steps
     # Each sub-step is split into a forward/backward body (`*_fb`), the gradient all-reduce (eager,
@@ -167,9 +233,9 @@ class Trainer:
     def g_fb(self, scalars):
         set_requires_grad(self.G, True)
         self.g_sync.begin()
-        z = self.sample_z(self.B)
-        x_fake = self.G(z, **self.auxin)["image"]
-        y_fake = self.D(self.A(self.warmup(x_fake)))
+        z = self._z("g")
+        x_fake = self.G(z, noise=self._g_noise("g"), **self.auxin)["image"]
+        y_fake = self.D(self.A(self.warmup(x_fake, self._draw("g.keep")), draws=self._ada("g.ada")))
         loss_gan = self.adversarial_loss(None, y_fake, "G")
         (self.cfg.training.loss.gan * loss_gan).backward()
         self.g_sync.collect()
@@ -179,11 +245,11 @@ class Trainer:
     def d_fb(self, x_real, scalars):
         set_requires_grad(self.D, True)
         self.d_sync.begin()
-        z = self.sample_z(self.B)
+        z = self._z("d")
         with torch.no_grad():
-            x_fake = self.G(z, **self.auxin)["image"]
-            x_real_aug = self.A(self.warmup(x_real))
-            x_fake_aug = self.A(self.warmup(x_fake))
+            x_fake = self.G(z, noise=self._g_noise("d"), **self.auxin)["image"]
+            x_real_aug = self.A(self.warmup(x_real, self._draw("d.keep_real")), draws=self._ada("d.ada_real"))
+            x_fake_aug = self.A(self.warmup(x_fake, self._draw("d.keep_fake")), draws=self._ada("d.ada_fake"))
         # D(real) and D(fake) in ONE pass over the discriminator (minibatch-stddev per half), instead of
         # the reference's two calls (trainer.py:391-392): same result, half the launches / weight reads
         y = self.D(torch.cat([x_real_aug, x_fake_aug], dim=0), splits=2)
@@ -201,7 +267,7 @@ class Trainer:
         set_requires_grad(self.D, True)
         self.d_sync.begin()
         x = x_real.detach().requires_grad_(True)
-        y_real = self.D(self.A(self.warmup(x)), double_backward=True)
+        y_real = self.D(self.A(self.warmup(x, self._draw("r1.keep")), draws=self._ada("r1.ada")), double_backward=True)
         (grads,) = torch.autograd.grad(outputs=[y_real.sum()], inputs=[x], create_graph=True)
         r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
         loss = (self.gp_weight / 2) * r1 + 0.0 * y_real.squeeze()[0]
@@ -217,8 +283,7 @@ class Trainer:
 
     # ------------------------------------------------------------------ hipGraph plumbing
     def _graphs_usable(self):
-        # host-scheduled warm-up (blur / dropout ratios change every iteration) runs eagerly
-        return self.use_graphs and self.blur_sigma == 0 and self.dropout_ratio == 0
+        return self.use_graphs
 
     def _run(self, name, fn, *args):
         """Run `fn(*args, scalars)` eagerly, or capture it once as a hipGraph and replay it.
@@ -228,6 +293,8 @@ class Trainer:
             scalars = {}
             fn(*args, scalars)
             return scalars
+        if self._warm() and not name.endswith("_opt"):
+            name = name + "/warmup"   # the fade-in regime has its own captures (extra blur / dropout work)
         if name not in self._graphs:
             if self._graph_warm.get(name, 0) < 2:  # allocator / autotune warm-up before capture
                 self._graph_warm[name] = self._graph_warm.get(name, 0) + 1
@@ -321,10 +388,19 @@ class Trainer:
 
     def save_checkpoint(self, save_path, step):
         """Same keys as the reference (trainer.py:551-567)."""
+        def optim_state(opt):
+            # the fused Adam kernel keeps ONE device step counter that every per-parameter `step` entry views; a
+            # checkpoint carries independent copies so that stock torch.optim.Adam can resume from it
+            sd = opt.state_dict()
+            for st in sd["state"].values():
+                if torch.is_tensor(st.get("step")):
+                    st["step"] = st["step"].detach().clone().reshape(())
+            return sd
+
         ckpt = {
             "cfg": self.cfg, "step": step, "angle": self.coord.angle.detach().cpu(),
             "G": self.G.state_dict(), "D": self.D.state_dict(), "G_ema": self.G_ema.state_dict(),
-            "A": self.A.state_dict(), "optim_G": self.optim_G.state_dict(), "optim_D": self.optim_D.state_dict(),
+            "A": self.A.state_dict(), "optim_G": optim_state(self.optim_G), "optim_D": optim_state(self.optim_D),
         }
         save_path.parent.mkdir(parents=True, exist_ok=True)
         torch.save(ckpt, save_path)

@@ -281,7 +281,7 @@ def run_steps(G, D, A, angle, x_real, B, tag, out, seeds, gp_weight=16.0):
                 f"{tag}ds_adaG_fake": Gf, f"{tag}ds_adaC_fake": Cf, f"{tag}ds_x_fake": x_fake,
                 f"{tag}ds_xr_aug": xr, f"{tag}ds_y_real": y_real, f"{tag}ds_y_fake": y_fake, f"{tag}ds_loss": loss_D})
     for k, gv in zip(dparams.keys(), dgrads):
-        out[f"{tag}ds_gradnorm.{k}"] = gv.norm()
+        out[f"{tag}ds_gradnorm.{k}"] = gv.double().norm()
         out[f"{tag}ds_gradslice.{k}"] = gv.flatten()[:64].clone()
 
     # ---- lazy R1 ------------------------------------------------------------
@@ -297,7 +297,7 @@ def run_steps(G, D, A, angle, x_real, B, tag, out, seeds, gp_weight=16.0):
     out.update({f"{tag}r1_adaG": Gm, f"{tag}r1_adaC": Cm, f"{tag}r1_gradx": gx, f"{tag}r1_penalty": r1})
     for k, gv in zip(dparams.keys(), rgrads):
         if gv is not None:
-            out[f"{tag}r1_gradnorm.{k}"] = gv.norm()
+            out[f"{tag}r1_gradnorm.{k}"] = gv.double().norm()
             out[f"{tag}r1_gradslice.{k}"] = gv.flatten()[:64].clone()
     return out
 
@@ -385,7 +385,7 @@ def golden_full():
                gs_x_aug_row=x_aug[:, :, 31].clone(), gs_y_fake=y_fake, gs_loss=loss_G)
     for k, gv in zip(params.keys(), grads):
         if gv is not None:
-            out[f"gs_gradnorm.{k}"] = gv.norm()
+            out[f"gs_gradnorm.{k}"] = gv.double().norm()
             out[f"gs_gradslice.{k}"] = gv.flatten()[:32].clone()
     for k, v in G.state_dict().items():
         if k.endswith("ema_var"):
@@ -403,7 +403,7 @@ def golden_full():
     dgrads = torch.autograd.grad(loss_D, list(dparams.values()))
     out.update(ds_adaG_real=Gr, ds_adaC_real=Cr, ds_y_real=y_real, ds_loss=loss_D)
     for k, gv in zip(dparams.keys(), dgrads):
-        out[f"ds_gradnorm.{k}"] = gv.norm()
+        out[f"ds_gradnorm.{k}"] = gv.double().norm()
         out[f"ds_gradslice.{k}"] = gv.flatten()[:32].clone()
     out["x_real"] = x_real
     out["G1buf.w_avg"] = G.state_dict()["w_avg"].clone()
@@ -417,11 +417,11 @@ def golden_full():
     r1 = (gx ** 2).sum(dim=[1, 2, 3]).mean()
     loss = (16.0 / 2) * r1 + 0.0 * y.squeeze()[0]
     rgrads = torch.autograd.grad(loss, list(dparams.values()), allow_unused=True)
-    out.update(r1_adaG=Gm, r1_adaC=Cm, r1_gradx_row=gx[:, :, 31].detach().clone(), r1_gradx_norm=gx.detach().norm(),
+    out.update(r1_adaG=Gm, r1_adaC=Cm, r1_gradx_row=gx[:, :, 31].detach().clone(), r1_gradx_norm=gx.detach().double().norm(),
                r1_penalty=r1.detach())
     for k, gv in zip(dparams.keys(), rgrads):
         if gv is not None:
-            out[f"r1_gradnorm.{k}"] = gv.norm()
+            out[f"r1_gradnorm.{k}"] = gv.double().norm()
             out[f"r1_gradslice.{k}"] = gv.flatten()[:32].clone()
 
     # ---- eval forwards with the buffers the G step left (BASELINE configs[0]: B = 1, truncation_psi = 0.7, the

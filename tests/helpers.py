@@ -74,3 +74,45 @@ def trainer_fixture_reals(tag, it, B=8, H=16, W=64, n_it=4):
     import recipe
     depth, mask = recipe.raw_batches(31, B * n_it, H, W, 1.45, 80.0)
     return depth[(it - 1) * B:it * B], mask[(it - 1) * B:it * B]
+
+
+# ---------------------------------------------------------------------------- fp64 evaluation of the oracle
+def oracle_f64_full(d, angle):
+    """The oracle's G step, D step and lazy R1 on the full-size fixture's inputs evaluated in float64 (the same
+    restatement that tests/test_oracle_golden.py pins to the reference, run at higher precision): the yardstick that
+    separates rounding noise from error.  Several of the reference's own fp32 numbers are cancellation-dominated sums
+    over 65 k pixels (e.g. the bias gradient of the image heads deviates from its fp64 value by 5e-3), so "within 1e-3
+    of the reference's fp32 run" is only meaningful up to that deviation.  Returns dict(loss_g, y_fake, x_aug, grads_g,
+    bufs, y_real, loss_d, grads_d, r1, grad_x, grads_r1), fp64 CPU tensors.  ~15 s on 8 cores."""
+    import recipe
+    from conftest import sub_dict
+    from oracle import augment, model, step
+    # weights by recipe: drawn in fp32 (the recipe's random stream depends on the dtype), THEN everything goes to fp64
+    G, D = build_models(full_cfg(), "cpu")
+    sdG = recipe.fill_state_dict({k: v.clone() for k, v in G.state_dict().items()}, 1234)
+    sdD = recipe.fill_state_dict({k: v.clone() for k, v in D.state_dict().items()}, 4321)
+    sdG.update(sub_dict(d, "G."))
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        f64 = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+        sdG, sdD = {k: f64(v) for k, v in sdG.items()}, {k: f64(v) for k, v in sdD.items()}
+        B = d["z"].shape[0]
+        ang = f64(angle.cpu()).repeat_interleave(B, 0)
+        out = {}
+        loss, grads, bufs, ex = step.g_step(sdG, sdD, f64(d["z"]), ang, f64(d["gs_shifts"]), f64(d["gs_u"]),
+                                            ada={"G": f64(d["gs_adaG"]), "C": f64(d["gs_adaC"])})
+        out.update(loss_g=loss, y_fake=ex["y_fake"], x_aug=ex["x_aug"], image=ex["image"], bufs=bufs,
+                   grads_g={k: v for k, v in grads.items() if v is not None})
+        Dg = step.with_grad(sdD, step.D_BUFFER_SUFFIXES)
+        xr = augment.ada_forward(f64(d["x_real"]), f64(d["ds_adaG_real"]), f64(d["ds_adaC_real"]))
+        y_real, y_fake = model.discriminator(Dg, xr), model.discriminator(Dg, ex["x_aug"])
+        loss_d = model.loss_d_nsgan(y_real, y_fake)
+        keys = [k for k, v in Dg.items() if v.requires_grad]
+        out.update(y_real=y_real.detach(), loss_d=loss_d.detach(),
+                   grads_d=dict(zip(keys, torch.autograd.grad(loss_d, [Dg[k] for k in keys]))))
+        r1, rg, rex = step.r1_step(sdD, f64(d["x_real"]), 16.0, ada={"G": f64(d["r1_adaG"]), "C": f64(d["r1_adaC"])})
+        out.update(r1=r1, grad_x=rex["grad_x"], grads_r1={k: v for k, v in rg.items() if v is not None})
+        return out
+    finally:
+        torch.set_default_dtype(old)

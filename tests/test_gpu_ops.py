@@ -836,3 +836,41 @@ def test_sum_squares(nat):
         assert abs(float(got) - float(x.double().pow(2).sum())) <= tol * float(x.double().pow(2).sum())
     got = nat.sum_squares(x.to(DEV), C=13).sum()
     assert abs(float(got) - float(x[..., :13].double().pow(2).sum())) <= 1e-5 * float(x.double().pow(2).sum())
+
+
+
+@pytest.mark.parametrize("tag,demod,bias", [("trunk", True, False), ("head", False, True)])
+def test_mod_prep_per_layer_matches_reference_vectors(nat, g_ops, tag, demod, bias):
+    """dgv2_mod_prep_fwd/_bwd + the batched GEMMs (native.mod_layer, the per-layer path) against the vectors the
+    reference's ModConv2d produced (tests/golden/ops.npz mc_trunk / mc_head: style.py:68-126): eval and training output,
+    input-magnitude EMA after the call, gradients w.r.t. input, latent, weight, style affine and bias."""
+    from gans.models.ops.style import ModConv2d
+    sd = sub_dict(g_ops, f"mc_{tag}_sd.")
+    O, I = sd["weight"].shape[1:3]
+    m = ModConv2d(in_ch=I, out_ch=O, mod_ch=16, ksize=1, stride=1, padding=0, demod=demod, bias=bias, ema=True)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x = g_ops[f"mc_{tag}_x"]
+    xcl = cl(x).requires_grad_(True)
+    s = g_ops[f"mc_{tag}_s"].to(DEV).requires_grad_(True)
+    b = m.bias.reshape(-1) if bias else None
+
+    def run():
+        sumsq = nat.sum_squares(xcl.detach()) if m.training else None
+        y = nat.mod_layer(xcl, None, [m.prep_args(s, sumsq, xcl.numel())], bias=b, act=False, out_dtype=torch.float32)
+        return y
+
+    m.eval()
+    assert_rel(nchw(run().detach()), g_ops[f"mc_{tag}_y_eval"], 1e-4, "eval")
+    assert float(m.ema_var) == float(sd["ema_var"])
+    m.train()
+    y = run()
+    assert_rel(nchw(y.detach()), g_ops[f"mc_{tag}_y_train"], 1e-4, "train")
+    assert abs(float(m.ema_var) - float(g_ops[f"mc_{tag}_ema_after"])) < 1e-6
+    params = dict(m.named_parameters())
+    gy = cl(g_ops[f"mc_{tag}_gy"])
+    grads = torch.autograd.grad(y, [xcl, s] + list(params.values()), gy)
+    assert_rel(nchw(grads[0]), g_ops[f"mc_{tag}_gx"], 1e-4, "gx")
+    assert_rel(grads[1].cpu(), g_ops[f"mc_{tag}_gs"], 1e-4, "gs")
+    for k, gv in zip(params, grads[2:]):
+        assert_rel(gv.cpu(), g_ops[f"mc_{tag}_g.{k}"], 1e-4, k)

@@ -284,8 +284,8 @@ def _full_state():
 
 def _slice_check(grads, d, prefix, n, rtol_norm=1e-3, floor=0.0):
     for k, sl in sub_dict(d, f"{prefix}gradslice.").items():
-        want_norm = float(d[f"{prefix}gradnorm.{k}"])
-        assert abs(float(grads[k].norm()) - want_norm) <= rtol_norm * want_norm + floor, k
+        want_norm = float(d[f"{prefix}gradnorm.{k}"])   # fp64 accumulation on both sides (33 M element tensors)
+        assert abs(float(grads[k].double().norm()) - want_norm) <= rtol_norm * want_norm + floor, k
         assert float((grads[k].flatten()[:n] - sl).abs().max()) <= 1e-3 * float(sl.abs().max()) + 1e-3 * want_norm / max(
             1.0, grads[k].numel() ** 0.5) + floor, k
 
@@ -348,3 +348,28 @@ def test_full_size_eval_forwards_match_reference(g_full, g_coords):
         scale = float(d[f"ev32_{name}_row"].abs().max())
         close(v[:, 0, 31], d[f"ev32_{name}_row"], rtol=1e-4, atol=1e-3 * scale)
         close(v.double().flatten(1).norm(dim=1), d[f"ev32_{name}_norm"], rtol=1e-4, atol=0)
+
+
+def test_fp64_oracle_agrees_with_reference_and_shows_its_rounding_floor(g_full, g_coords):
+    """The float64 evaluation of the oracle (the yardstick of the -m gpu full-size tests) against the reference's fp32
+    fixture: almost every gradient tensor agrees to ~1e-5; the few that are sums cancelling over the 64x512 image (bias
+    gradient of the image heads: the same number at all five levels) show the reference's OWN fp32 rounding, several
+    1e-3 -- which is why "1e-3 of the reference's fp32 run" cannot be asked of those scalars, only of their fp64 value."""
+    from helpers import oracle_f64_full
+    d = g_full
+    t = oracle_f64_full(d, g_coords["angle_64x512"])
+    close(t["loss_g"], d["gs_loss"].double(), rtol=1e-5, atol=0)
+    close(t["loss_d"], d["ds_loss"].double(), rtol=1e-5, atol=0)
+    close(t["r1"], d["r1_penalty"].double(), rtol=1e-4, atol=0)
+    dev = {}
+    for prefix, grads in (("gs_", t["grads_g"]), ("ds_", t["grads_d"])):
+        for k, g in grads.items():
+            sl = d[f"{prefix}gradslice.{k}"].double()
+            scale = float(g.abs().max())
+            dev[prefix + k] = max(float((g.flatten()[:32] - sl).abs().max()) / scale,
+                                  abs(float(g.norm()) - float(d[f"{prefix}gradnorm.{k}"])) / float(g.norm()))
+    vals = sorted(dev.values())
+    print("reference fp32 vs fp64 oracle: median %.2e, 90%% %.2e, max %.2e" % (vals[len(vals) // 2], vals[int(len(vals) * 0.9)], vals[-1]))
+    assert vals[len(vals) // 2] < 1e-3 and vals[int(len(vals) * 0.9)] < 3e-3
+    worst = max(dev, key=dev.get)
+    assert worst.endswith("head.heads.image.bias") and 1e-3 < dev[worst] < 2e-2, (worst, dev[worst])
