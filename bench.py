@@ -47,6 +47,12 @@ def parse():
                          "(configs[1], quoted at --batch-per-gpu 32), eval mode, no graph")
     ap.add_argument("--res", default="64x512", help="HxW of the range image (BASELINE configs[4] runs 128x1024; "
                     "the metric and the roofline probes are quoted on the default 64x512)")
+    ap.add_argument("--d-epilogue", choices=["fp32", "bf16"], default="fp32",
+                    help="precision of the discriminator's epilogue (mbstd, 3x3 513->512 conv, Linear 65536->512): fp32 "
+                         "is what the reference runs (dusty_v2.py:394-395) and what `value` is quoted on; bf16 is an "
+                         "opt-in whose throughput is reported next to it as `extra.value_d_epilogue_bf16`")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurement points (ADA p = 0, bf16 "
+                    "epilogue, separately timed R1 / plain iterations)")
     return ap.parse_args()
 
 
@@ -129,11 +135,15 @@ def _time_launches(fn, reps):
     return s.elapsed_time(e) * 1e-3 / reps
 
 
+PMC_FILE = os.path.join("profiles", "round2_pmc.json")
+
+
 def _pmc_traffic(kernel_key):
-    """HBM bytes per launch from the committed PMC passes (profiles/round1_pmc.json: separate
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of scripts/pmc_probe.py, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when no matching record is committed."""
-    path = os.path.join(ROOT, "profiles", "round1_pmc.json")
+    """HBM bytes per launch of the probe's launch from the COMMITTED PMC passes (separate `rocprofv3 --pmc FETCH_SIZE`
+    / `--pmc WRITE_SIZE` runs of scripts/pmc_probe.py, which issues exactly the launches the probes below time;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  A counter pass cannot run inside this process,
+    so the figure is read from the file and labelled with its source; None when no matching record is committed."""
+    path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None
     rec = json.load(open(path)).get(kernel_key)
@@ -160,8 +170,8 @@ def roofline_probe(args, reps=20):
     ach = nbytes / sec / 1e9
     return {"kernel": "conv_pipe_kernel (dgv2_conv_taps: D block-0 conv1 fwd, 2B x 64x512, 32->32, 3x3 ring, bias+lrelu)",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-            "traffic": _pmc_traffic("conv_pipe_kernel"), "algorithmic_bytes_per_launch": nbytes,
-            "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12}
+            "traffic": _pmc_traffic("conv_pipe_kernel"), "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
+            "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12}
 
 
 def modconv_probe(args, reps=20):
@@ -187,8 +197,45 @@ def modconv_probe(args, reps=20):
     return {"kernel": "modconv_pe_fwd_kernel (dgv2_modconv_pe_fwd: G level-4 conv1, B x 32768 px, K=64+512, O=32)",
             "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": _pmc_traffic("modconv_pe_fwd_kernel"),
+            "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6,
             "algorithmic_hbm_GBps": nbytes / sec / 1e9}
+
+
+def build_trainer(args, rank, world, d_epilogue=None):
+    from gans.trainer import Trainer
+    cfg = make_cfg(args, rank, world)
+    trainer = Trainer(cfg, sync_scalars=False)
+    trainer.D.epilogue_dtype = d_epilogue or args.d_epilogue
+    return cfg, trainer
+
+
+def timed_steps(trainer, first_it, n, barrier):
+    """Wall time of `n` consecutive iterations first_it, first_it+1, ... bracketed by barrier + synchronize."""
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(n):
+        trainer.step(first_it + k)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def warm(trainer, cfg, n):
+    # the first calls use iteration 16 so that the lazy-R1 and ADA-update paths are warm as well
+    # (with hipGraphs every body needs 2 eager runs + 1 capture before it replays)
+    for _ in range(max(n, 1) + (3 if cfg.training.hip_graph else 0)):
+        trainer.step(16)
+
+
+def gfwd_probe_roofline(args, sec_per_batch):
+    """configs[1]: the forward is dominated by dgv2_modconv_pe_fwd at level 4 (same kernel as roofline_modconv);
+    whole-forward figure: algorithmic FLOPs of the generator forward (2.894 GFLOP + PE projection per
+    image) over the measured batch time."""
+    flops = args.batch_per_gpu * 2.894e9
+    ach = flops / sec_per_batch / 1e12
+    return {"kernel": "whole generator forward (modulated convs: 2.894 GFLOP/img algorithmic)", "bound": "mfma",
+            "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+            "traffic": None}
 
 
 def main():
@@ -208,34 +255,46 @@ def main():
         else:
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    from gans.trainer import Trainer
     from gans.utils import init_random_seed
 
     init_random_seed(0, rank)
-    cfg = make_cfg(args, rank, world)
-    trainer = Trainer(cfg, sync_scalars=False)
+    cfg, trainer = build_trainer(args, rank, world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.workload == "gfwd":   # BASELINE configs[1]: generator-only forward
+    def max_over_ranks(dt):
+        """(max over ranks, list of every rank's own time)"""
+        if world == 1:
+            return dt, [dt]
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        every = [float(v) for v in every]
+        return max(every), every
+
+    if args.workload == "gfwd":   # BASELINE configs[1]: generator-only forward, replayed as ONE hipGraph
         G = trainer.G_ema.eval()
         z = trainer.sample_z(args.batch_per_gpu)
+        graph = None
         with torch.no_grad():
-            for _ in range(max(args.warmup, 1)):
+            for _ in range(max(args.warmup, 2)):
                 G(z, **trainer.auxin)
+            if not args.no_graph:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = G(z, **trainer.auxin)
+                graph.replay()
+            run = graph.replay if graph is not None else (lambda: G(z, **trainer.auxin))
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                G(z, **trainer.auxin)
+                run()
             barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t)
+        dt, every = max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
             print(json.dumps({
                 "metric": f"range-images/sec (generator forward) on dusty_v2 {args.res}",
@@ -244,35 +303,55 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"configs[1]: dusty_v2 generator-only forward (eval, EMA weights), {args.res}",
                            "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
-                           "parallelism": f"dp{world}"}}))
+                           "parallelism": f"dp{world}", "hip_graph": graph is not None},
+                "roofline": gfwd_probe_roofline(args, dt / args.steps) if args.res == "64x512" else None,
+                "roofline_modconv": modconv_probe(args)}))
         if world > 1:
             dist.barrier()   # leave together: rank 0 may still be printing
             dist.destroy_process_group()
         return
 
-    # warm-up: first call uses iteration 16 so that the lazy-R1 and ADA-update paths are also warm
-    # (with hipGraphs every body needs 2 eager runs + 1 capture before it replays)
-    it = 16
-    for _ in range(max(args.warmup, 1) + (3 if cfg.training.hip_graph else 0)):
-        trainer.step(16 if cfg.training.hip_graph else it)
-        it += 1
-    it = 1
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step(it)
-        it += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    warm(trainer, cfg, args.warmup)
+    # Lazy R1 runs on every 16th iteration.  The K timed iterations start where they contain ceil(K / 16) of them (K = 20:
+    # two, i.e. 1/10 instead of 1/16), so the timed region never under-counts the regulariser whatever --steps is;
+    # `extra` reports the separately timed plain / R1 iterations and the exactly 1/16-weighted step next to it.
+    lazy = int(cfg.training.lazy.gp)
+    n_r1 = -(-args.steps // lazy)
+    first_it = lazy * n_r1 - args.steps + 1 if args.steps % lazy else 1
+    first_it = max(first_it, 1)
+    dt, every = max_over_ranks(timed_steps(trainer, first_it, args.steps, barrier))
+    r1_in_region = sum(1 for k in range(args.steps) if (first_it + k) % lazy == 0)
     imgs = args.steps * args.batch_per_gpu * world
     value = imgs / dt
 
+    extra = {"r1_iterations_in_timed_region": r1_in_region, "first_timed_iteration": first_it,
+             "per_rank_images_per_s": [args.steps * args.batch_per_gpu / t for t in every],
+             "world_size_seen": dist.get_world_size() if world > 1 else 1,
+             "backend": dist.get_backend() if world > 1 else None}
+    if not args.no_extra:
+        # plain and R1 iterations timed on their own (every rank takes part: the steps contain collectives)
+        t_plain = max_over_ranks(timed_steps(trainer, 1, 6, barrier))[0] / 6
+        t_r1 = sum(max_over_ranks(timed_steps(trainer, lazy, 1, barrier))[0] for _ in range(3)) / 3
+        w16 = ((lazy - 1) * t_plain + t_r1) / lazy
+        extra.update(ms_plain_iteration=1e3 * t_plain, ms_r1_iteration=1e3 * t_r1, ms_per_step_r1_every_16th=1e3 * w16,
+                     value_r1_every_16th=args.batch_per_gpu * world / w16)
+        # ADA at p = 0 (start of training; the headline point is the controller's target p = 0.6)
+        p_keep = trainer.A.p.clone()
+        trainer.A.p.zero_()
+        extra["value_ada_p0"] = 8 * args.batch_per_gpu * world / max_over_ranks(timed_steps(trainer, 1, 8, barrier))[0]
+        trainer.A.p.copy_(p_keep)
+
     roof = roofline_probe(args) if rank == 0 else None
     roof_mod = modconv_probe(args) if rank == 0 else None
+    if not args.no_extra and world == 1 and args.dtype == "bf16":
+        # the same step with the discriminator epilogue in bf16 (opt-in; NOT what `value` is quoted on)
+        other = "bf16" if args.d_epilogue == "fp32" else "fp32"
+        del trainer
+        torch.cuda.empty_cache()
+        cfg2, tr2 = build_trainer(args, rank, world, d_epilogue=other)
+        warm(tr2, cfg2, 1)
+        extra[f"value_d_epilogue_{other}"] = args.steps * args.batch_per_gpu / timed_steps(tr2, first_it, args.steps, barrier)
+        del tr2
 
     if rank == 0:
         out = {
@@ -281,13 +360,17 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[2]: configs/gans/dusty_v2.yaml full G+D train step "
-                                   f"(G step + D step + lazy R1/16 + ADA + EMA + Adam), {args.res} synthetic",
+                                   f"(G step + D step + lazy R1 + ADA + EMA + Adam), {args.res} synthetic",
                        "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
                        "parallelism": f"dp{world}", "ada_p": args.ada_p, "hip_graph": not args.no_graph,
+                       # conv trunks of G and D: bf16 storage, fp32 accumulation.  Heads / skip sums / ADA fp32.
+                       # Discriminator epilogue (mbstd, 3x3 513->512 conv, Linear 65536->512 -> 1): see d_epilogue_dtype
+                       "d_epilogue_dtype": args.d_epilogue,
                        # the encoding of the constant sensor grid is a table computed once;
                        # DGV2_NO_CONST_CACHE=1 recomputes it every forward (-1 %)
                        "pe_table_precomputed": os.environ.get("DGV2_NO_CONST_CACHE") is None},
             "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3 if args.res == "64x512" else None,
+            "extra": extra,
             "roofline": roof,
             "roofline_modconv": roof_mod,
         }

@@ -516,6 +516,15 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   return 0;
 }
 
+}  // namespace
+
+// conv_strip.hip: streaming kernel for 3x3 stride-1 ring convs with 32 -> 32 channels (bf16); -2 = not covered
+int dgv2_conv_strip_try(void* y, const void* x, const void* w, int B, int H, int W, int Cin, int O, int ntaps, int wtaps,
+                        const int* taps4, int nextra, const int* extras5, int hzero, const float* bias,
+                        const void* resid, int act, float alpha, float scale, hipStream_t st);
+
+namespace {
+
 template <typename T, int TO>
 int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, hipStream_t st) {
   if (p.ncls == 4) {
@@ -603,6 +612,18 @@ extern "C" int dgv2_conv_taps_ex(void* y, const void* x, const void* w, int B, i
   p.bias = bias; p.resid = resid; p.ybase = y; p.act = act; p.alpha = alpha; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
+  if (dtype == DGV2_BF16 && ncls == 1 && in_stride == 1 && out_stride == 1 && ring && !accumulate && Hin == Hg &&
+      Win == Wg && Hy == Hg && Wy == Wg && ioff_h == 0 && ioff_w == 0 && cls_host[0] == 0 && cls_host[1] == 0 &&
+      aligned16(y) && (!resid || aligned16(resid))) {
+    // full-resolution 32 -> 32 channel layers: the strip-streaming kernel (conv_strip.hip)
+    rc = dgv2_conv_strip_try(y, x, w, B, Hin, Win, Cin, O, ntaps, wtaps, taps_host, nextra, extras_host, hzero, bias,
+                             resid, act, alpha, scale, st);
+    if (rc != -2) {
+      if (rc) return rc;
+      DGV2_RETURN_LAST();
+    }
+    rc = 0;
+  }
   static const bool no_pipe = getenv("DGV2_NO_PIPE") != nullptr;   // A/B switch for benchmarking
   // the ring wrap of the pipelined kernel assumes -Win <= gw < 4*Win
   const bool wrap_ok = !ring || (ioff_w + dxmin >= -Win && in_stride * ((Wg + DTW - 1) / DTW * DTW) + ioff_w + dxmax < 4 * Win);

@@ -624,6 +624,9 @@ CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     (1, 6, 36, 64, 32, 1, 1, 0, True),
     (2, 4, 32, 64, 16, 3, 2, 1, True),
     (1, 10, 70, 32, 130, 3, 1, 1, True),
+    # strip-streaming kernel (conv_strip.hip: 32 -> 32 channels, H % 8 == 0, W % 32 == 0): several strips / images
+    (3, 16, 96, 32, 32, 3, 1, 1, True),
+    (2, 40, 64, 32, 32, 3, 1, 1, True),
 ]
 
 
@@ -874,3 +877,48 @@ def test_mod_prep_per_layer_matches_reference_vectors(nat, g_ops, tag, demod, bi
     assert_rel(grads[1].cpu(), g_ops[f"mc_{tag}_gs"], 1e-4, "gs")
     for k, gv in zip(params, grads[2:]):
         assert_rel(gv.cpu(), g_ops[f"mc_{tag}_g.{k}"], 1e-4, k)
+
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 512), (3, 16, 64), (1, 24, 32)])
+def test_conv_strip_kernel_forward_and_data_gradient(nat, B, H, W):
+    """conv_strip.hip through dgv2_conv_taps / dgv2_conv_taps_ex (bf16, 32 -> 32 channels, 3x3, ring): forward with the
+    fused bias + leaky ReLU epilogue, and the stride-1 data gradient with the replicate-row border terms and the fused
+    residual, against float64 F.conv2d on the ring-padded input (ops.Conv2d, common.py:187-210) and its autograd.
+    Integer-valued operands make the bf16 MFMA results exact; random operands use the bf16 tolerance.  The generic
+    engine (DGV2_NO_STRIP) must give the same numbers: checked on the integer case."""
+    g = torch.Generator().manual_seed(B * H + W)
+    geom = nat.ConvGeom(3, 3, 1, 1, True)
+    for exact in (True, False):
+        if exact:
+            x = torch.randint(-2, 3, (B, 32, H, W), generator=g).double()
+            w = torch.randint(-2, 3, (32, 32, 3, 3), generator=g).double()
+            bias = torch.randint(-3, 4, (32,), generator=g).double()
+            gy = torch.randint(-2, 3, (B, 32, H, W), generator=g).double()
+            res = torch.randint(-3, 4, (B, 32, H, W), generator=g).double()
+        else:
+            x, w = torch.randn(B, 32, H, W, generator=g).double(), torch.randn(32, 32, 3, 3, generator=g).double() / 8
+            bias, gy = torch.randn(32, generator=g).double(), torch.randn(B, 32, H, W, generator=g).double()
+            res = torch.randn(B, 32, H, W, generator=g).double()
+        xq, wq = x.bfloat16().double().requires_grad_(True), w.bfloat16().double()
+        gyq, resq = gy.bfloat16().double(), res.bfloat16().double()
+        y = _conv_oracle(xq, wq, 1, 1, True)
+        want_y = y + bias[None, :, None, None]
+        want_act = torch.where(want_y > 0, want_y, want_y * 0.2) * math.sqrt(2.0)
+        (want_gx,) = torch.autograd.grad(y, xq, gyq)
+        xd = cl(x.float()).bfloat16()
+        wd = w.float().permute(0, 2, 3, 1).contiguous().to(DEV).bfloat16()
+        got_y = nat._conv_fwd_raw(xd, wd, geom, bias.float().to(DEV), 3, 0.2, math.sqrt(2.0))
+        got_lin = nat._conv_fwd_raw(xd, wd, geom)
+        got_gx = nat._conv_dgrad_raw(cl(gy.float()).bfloat16(), wd, geom, tuple(xd.shape))
+        got_gxr = nat._conv_dgrad_raw(cl(gy.float()).bfloat16(), wd, geom, tuple(xd.shape), resid=cl(res.float()).bfloat16())
+        if exact:
+            assert torch.equal(nchw(got_lin).double(), y.detach())
+            assert torch.equal(nchw(got_gx).double(), want_gx)
+            assert torch.equal(nchw(got_gxr).double(), want_gx + resq)
+            assert_rel(nchw(got_y), want_act.detach(), 4e-3, "bias + lrelu")   # one bf16 rounding of the activation
+        else:
+            assert_rel(nchw(got_lin), y.detach(), 8e-3, "y")
+            assert_rel(nchw(got_y), want_act.detach(), 8e-3, "act")
+            assert_rel(nchw(got_gx), want_gx, 8e-3, "gx")
+            assert_rel(nchw(got_gxr), want_gx + resq, 1.2e-2, "gx + resid")
