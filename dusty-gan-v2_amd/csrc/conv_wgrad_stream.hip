@@ -20,7 +20,12 @@ namespace {
 struct WSGeom {
   int B, H, W, C, O, Ho, Wo, k, stride, pad, ring;
   int tiles_h, tiles_w, ntiles, tiles_per_split, ctiles;
-  int ablate;   // benchmarking only (DGV2_WS_ABLATE): 1 skip the partial stores, 2 skip the MFMA loop
+#ifdef DGV2_ABLATE   // benchmarking builds only (make ABLATE=1): wrong results by design, never in the shipped library
+  int ablate;        // DGV2_WS_ABLATE: 1 skip the partial stores, 2 skip the MFMA loop
+#define WS_ABL (g.ablate)
+#else
+#define WS_ABL 0
+#endif
   int x_shared; // x is ONE image [H, W, C] shared by all samples (the batch-shared positional encoding)
 };
 
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_bf16_kernel(float* _
       if (tid + j * 256 < n_x) lds_x[xw_[j]] = rx[j];
     if (t + 1 < t_end) issue();
     __syncthreads();
-    if (g.ablate & 2) continue;
+    if (WS_ABL & 2) continue;
 #pragma unroll
     for (int r = 0; r < WR; ++r) {
       uint4 a[MW];
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_bf16_kernel(float* _
   const int lr = lane & 15, lc = lane >> 4;
   float* pb = part + (int64_t)split * g.O * NT * g.C;
   const int c = c0 + nf * 16 + lr;
-  if (c < g.C && !((g.ablate & 1) && acc[0][0][0] != 12345.678f)) {
+  if (c < g.C && !((WS_ABL & 1) && acc[0][0][0] != 12345.678f)) {
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
@@ -449,8 +454,10 @@ bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, in
   g.ctiles = (C + 16 * p.nfn - 1) / (16 * p.nfn);
   p.otiles = (O + 16 * p.mfn - 1) / (16 * p.mfn);
   const int pairs = g.ctiles * p.otiles;
+#ifdef DGV2_ABLATE
   static const int abl = getenv("DGV2_WS_ABLATE") ? atoi(getenv("DGV2_WS_ABLATE")) : 0;
   g.ablate = abl;
+#endif
   g.x_shared = 0;
   static const int blocks_big = getenv("DGV2_WS_BLOCKS_BIG") ? atoi(getenv("DGV2_WS_BLOCKS_BIG")) : 256;
   static const int blocks_small = getenv("DGV2_WS_BLOCKS_SMALL") ? atoi(getenv("DGV2_WS_BLOCKS_SMALL")) : 512;

@@ -22,10 +22,18 @@
 
 namespace {
 
+#ifdef DGV2_ABLATE
+#define MP_ABL (g.ablate)
+#else
+#define MP_ABL 0
+#endif
+
 struct MPGeom {
   int B, P, Ka, Ks, O, I;
   int samples_per_block;
-  int ablate;   // benchmarking only (DGV2_MP_ABLATE): 1 skip stores, 2 skip MFMA loop, 4 skip weight staging, 8 skip xa loads
+#ifdef DGV2_ABLATE   // benchmarking builds only (make ABLATE=1): wrong results by design, never in the shipped library
+  int ablate;        // DGV2_MP_ABLATE: 1 skip stores, 2 skip MFMA loop, 4 skip weight staging, 8 skip xa loads
+#endif
   const float* bias;
   int act;
   float alpha, scale;
@@ -118,15 +126,15 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFW * KAR) : "memory");
     __builtin_amdgcn_s_barrier();   // all pieces landed; every wave is done with the other buffer
     asm volatile("" ::: "memory");
-    if (!(g.ablate & 4)) dma_w(min(b + 1, b1 - 1), S ^ 1);
-    if (!(g.ablate & 8)) issue_x(std::integral_constant<int, S ^ 1>{}, b + 1);
+    if (!(MP_ABL & 4)) dma_w(min(b + 1, b1 - 1), S ^ 1);
+    if (!(MP_ABL & 8)) issue_x(std::integral_constant<int, S ^ 1>{}, b + 1);
 
     f32x4 acc[MF][NFW];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
       for (int nf = 0; nf < NFW; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!(g.ablate & 2))
+    if (!(MP_ABL & 2))
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       uint4 a[MF];
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
 #pragma unroll
     for (int nf = 0; nf < NFW; ++nf) {
       const int px = p0 + nf * 16 + lr;
-      const bool live = px < g.P && !((g.ablate & 1) && acc[0][0][0] != 12345.678f);
+      const bool live = px < g.P && !((MP_ABL & 1) && acc[0][0][0] != 12345.678f);
       bf16_t* row = y + ((int64_t)b * g.P + px) * g.O + o_base;
 #pragma unroll
       for (int mf = 0; mf < MF; mf += 2) {
@@ -242,8 +250,12 @@ extern "C" int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, c
   if (dtype != DGV2_BF16 || (act != 0 && act != 3)) return DGV2_EINVAL;
   if (!aligned16(y) || !aligned16(xa) || !aligned16(xs) || !aligned16(w)) return DGV2_EINVAL;
   if (Ks == 0) xs = xa;   // never dereferenced (KS = 0), keeps the pointer arithmetic defined
+#ifdef DGV2_ABLATE
   static const int abl = getenv("DGV2_MP_ABLATE") ? atoi(getenv("DGV2_MP_ABLATE")) : 0;
   MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, abl, bias, act, alpha, scale, sumsq, row_scale};
+#else
+  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, bias, act, alpha, scale, sumsq, row_scale};
+#endif
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (Ka == 64 && Ks == 512 && O == 32) rc = mp_launch<2, 2, 2, 16>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);

@@ -292,7 +292,12 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
     const int* __restrict__ cnt_w, int Ew, int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
     int SHA, float* __restrict__ sumsq, const T* __restrict__ ref = nullptr, float alpha = 1.f, float ascale = 1.f,
     float* __restrict__ bias_partial = nullptr) {
-  const int SH = SHA & 0xffff, ablate = SHA >> 16;   // ablate: benchmarking only (DGV2_RS_ABLATE)
+#ifdef DGV2_ABLATE   // benchmarking builds only (make ABLATE=1): wrong results by design, never in the shipped library
+  const int SH = SHA & 0xffff, ablate = SHA >> 16;   // DGV2_RS_ABLATE
+#else
+  const int SH = SHA & 0xffff;
+  constexpr int ablate = 0;
+#endif
   __shared__ float red[16];
   float ss = 0.f;   // sum of squares of what this thread stores (sumsq != nullptr: one partial per block)
   constexpr int VN = vec16<T>::N;
@@ -537,7 +542,11 @@ extern "C" int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, co
     const int64_t total = (int64_t)B * out_h * out_w * ((C + (vec ? VN : 1) - 1) / (vec ? VN : 1));
     const int grid = grid_for(total, 256, 256 * 64);
     static const bool no_stream = getenv("DGV2_NO_RSTREAM") != nullptr;   // A/B switch for benchmarking
+#ifdef DGV2_ABLATE
     static const int rs_ablate = getenv("DGV2_RS_ABLATE") ? atoi(getenv("DGV2_RS_ABLATE")) : 0;
+#else
+    constexpr int rs_ablate = 0;
+#endif
     if (vec && Ew <= 4 && Eh <= 64 && !no_stream) {
       static const int sh_env = getenv("DGV2_RS_SH") ? atoi(getenv("DGV2_RS_SH")) : 0;   // experiments
       int SH = out_h >= 32 ? 16 : (out_h >= 8 ? 8 : out_h);

@@ -111,6 +111,14 @@ class AdaptiveAugment(torch.nn.Module):
         self.register_buffer("Hz_fbank", torch.as_tensor(fb, dtype=torch.float32))
         self._chain = {}
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # the reference re-assigns `self.p = (self.p + adjust).clamp_(...)` with a [1]-shaped `adjust`
+        # (adaptive_augment.py:372-380), so its checkpoints carry p as [1] once update_p has run; ours stays 0-dim
+        k = prefix + "p"
+        if k in state_dict and state_dict[k].numel() == 1 and state_dict[k].shape != self.p.shape:
+            state_dict[k] = state_dict[k].reshape(self.p.shape)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     # ------------------------------------------------------------------ p controller
     @torch.no_grad()
     def cumulate(self, y_real):

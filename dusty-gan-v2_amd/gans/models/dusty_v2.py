@@ -139,6 +139,14 @@ class SynthesisBlock(nn.Module):
         B = angle.shape[0] if batch is None else batch
         return native.downsample_angle(angle.float().contiguous(), shift, self.downsample.kernel, B, self.ring)
 
+    def downsample_angle_diff(self, angle):
+        """The same map built from differentiable ops (sin / cos, the FIR kernel's autograd, atan2): the path of an
+        angle tensor that requires grad (inversion optimises `angle + phase`, demo_inversion.py:164)."""
+        C = angle.shape[1]
+        per = torch.cat([angle.sin(), angle.cos()], dim=1)
+        per = ops.from_cl(self.downsample.forward_cl(ops.to_cl(per)))
+        return torch.atan2(per[:, :C], per[:, C:])
+
     def _conv1_shared_pe(self, hin, w_latent, angle, shift, B, dt, want_sq=False, link=None):
         """conv1 + bias + lrelu when the whole batch shares one angle grid (the training / sampling
         case).  The reference encodes angle + shift_b per sample and concatenates 512 PE channels to
@@ -196,13 +204,20 @@ class SynthesisBlock(nn.Module):
         spec = None if self.is_first else self.resample.spec
         hin = None if h is None else h.to(dt)
         vec = 8 if dt == LOW else 4
-        if angle.shape[0] == 1 and (hin is None or hin.shape[3] % vec == 0):
+        if angle.shape[0] == 1 and not angle.requires_grad and (hin is None or hin.shape[3] % vec == 0):
             # the layer that feeds the head shares a link with it: the head's data-gradient kernel then also runs that
             # layer's activation backward (native._head_dgrad_actbwd)
             h = self._conv1_shared_pe(hin, ws[0], angle, shift, B, dt, want_sq=True, link=link if self.is_first else None)
             if self.is_first and self.conv1._prep is not None:
                 a1 = self.bias_act1
                 up = dict(link=link, alpha=float(a1.negative_slope), scale=float(a1.scale), cvec=self.conv1._prep[2])
+        elif angle.requires_grad and torch.is_grad_enabled():
+            # differentiable encoding (gradients w.r.t. the angles: inversion / demo consumers; not the training path)
+            a = angle if shift is None else angle + torch.stack([torch.zeros_like(shift), shift], dim=1)[:, :, None, None]
+            c = torch.einsum("bahw,fa->bhwf", a.float(), self.pe.freqs2.float()) + self.pe.phase.float()
+            pe = torch.cat([c.sin(), c.cos()], dim=3).to(dt)
+            x1 = pe if hin is None else torch.cat([self.resample.forward_cl(hin), pe], dim=3)
+            h = self.conv1.forward_cl(x1, ws[0], act=self.bias_act1)
         else:
             x1 = native.up_cat_pe(hin, spec, angle, shift, self.pe.freqs2.contiguous(), self.pe.phase, dt, B)
             h = self.conv1.forward_cl(x1, ws[0], act=self.bias_act1)
@@ -294,8 +309,19 @@ class SynthesisNetwork(nn.Module):
         angle = angle.float().contiguous()
         if angle.shape[0] not in (1, B):
             raise RuntimeError(f"angle batch {angle.shape[0]} does not match style batch {B}")
+        diff = angle.requires_grad and torch.is_grad_enabled()
+        if diff and angle.shape[0] == 1:
+            angle = angle.expand(B, -1, -1, -1)   # the shared-grid fast path encodes without autograd
         # multi-scale angles, full resolution last
-        if angle.shape[0] == 1:
+        if diff:
+            # gradients w.r.t. the angles wanted (demo_inversion.py:164 optimises `angle + phase`): per-sample grids,
+            # pyramid and encoding from differentiable ops
+            a = angle if shift is None else angle + torch.stack([torch.zeros_like(shift), shift], dim=1)[:, :, None, None]
+            pyramid = [(a, None)]
+            for layer in self.layers[:0:-1]:
+                a = layer.downsample_angle_diff(a)
+                pyramid.insert(0, (a, None))
+        elif angle.shape[0] == 1:
             # shared grid: the pyramid is built once from the UNSHIFTED angles and every level applies
             # the shift as a weight rotation (sin/cos -> FIR -> atan2 commutes with a constant shift)
             pyramid = [(a, shift) for a in self._angle_pyramid(angle)]

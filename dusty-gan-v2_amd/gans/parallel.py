@@ -30,8 +30,13 @@ def world_size():
 class FlatGradSync:
     """Owns the gradients of `module`: p.grad are views of self.flat (fp32)."""
 
-    def __init__(self, module):
+    def __init__(self, module, payload_dtype=None):
+        """payload_dtype: torch.bfloat16 sends the gradients as bf16 (half the xGMI bytes; one cast pass each way, the
+        sum itself is then rounded to bf16 -- NOT what the reference's fp32 DDP buckets do, hence opt-in:
+        training.grad_payload: bf16).  None / torch.float32: the flat fp32 buffer itself is reduced in place."""
         self.module = module
+        self.payload_dtype = None if payload_dtype in (None, torch.float32) else payload_dtype
+        self._payload = None
         self.params = [p for p in module.parameters()]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -94,13 +99,24 @@ class FlatGradSync:
         if not (self._sync and is_dist()):
             return None
         avg = _avg_supported(self.flat.device)
+        buf = self.flat
+        if self.payload_dtype is not None:
+            if self._payload is None:
+                self._payload = torch.empty_like(self.flat, dtype=self.payload_dtype)
+            self._payload.copy_(self.flat)
+            buf = self._payload
         # RCCL averages inside the reduction: no extra pass over the 154 MB buffer
-        work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
+        work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
         if async_op:
             return (work, avg)
+        self._finish(avg)
+        return None
+
+    def _finish(self, avg):
+        if self.payload_dtype is not None:
+            self.flat.copy_(self._payload)
         if not avg:
             self.flat.mul_(1.0 / dist.get_world_size())
-        return None
 
     def wait(self, handle):
         """Complete an all_reduce(async_op=True): the current stream waits for the reduction."""
@@ -108,8 +124,7 @@ class FlatGradSync:
             return
         work, avg = handle
         work.wait()
-        if not avg:
-            self.flat.mul_(1.0 / dist.get_world_size())
+        self._finish(avg)
 
 
 _AVG_OK = None
@@ -136,18 +151,30 @@ def mutable_buffers(module):
     return [b for n, b in module.named_buffers() if n.endswith("ema_var") or n == "w_avg"]
 
 
+_SYNC_PACK = {}
+
+
 @torch.no_grad()
 def sync_buffers(module, src=0):
+    """Rank `src`'s mutable buffers to every rank (DDP broadcast_buffers=True, trainer.py:77): ONE multi-tensor pack
+    into a persistent flat buffer, one broadcast, one multi-tensor unpack (the buffer list and its views are built
+    once per module)."""
     if not is_dist():
         return
+    ent = _SYNC_PACK.get(id(module))
     bufs = mutable_buffers(module)
-    flat = torch.cat([b.reshape(-1) for b in bufs])
+    if ent is None or [b.data_ptr() for b in bufs] != ent[2]:
+        flat = torch.empty(sum(b.numel() for b in bufs), device=bufs[0].device, dtype=bufs[0].dtype)
+        views, off = [], 0
+        for b in bufs:
+            views.append(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+        ent = (flat, views, [b.data_ptr() for b in bufs])
+        _SYNC_PACK[id(module)] = ent
+    flat, views, _ = ent
+    torch._foreach_copy_(views, bufs)
     dist.broadcast(flat, src=src)
-    views, off = [], 0
-    for b in bufs:
-        views.append(flat[off:off + b.numel()].view_as(b))
-        off += b.numel()
-    torch._foreach_copy_(bufs, views)   # one multi-tensor launch instead of one copy per buffer
+    torch._foreach_copy_(bufs, views)
 
 
 @torch.no_grad()

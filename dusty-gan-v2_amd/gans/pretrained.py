@@ -1,0 +1,124 @@
+"""Checkpoint loading for the consumers of the reference's checkpoint layout (reference: gans/pretrained.py:9-33,
+quick_demo.py:24-34, test_gan.py:47-49,92, trainer.py:551-567):
+
+    ckpt = autoload_ckpt(path)                       # {"cfg", "step", "angle", "G", "D", "G_ema", "A", "optim_*"}
+    G = build_generator(ckpt["cfg"].model.generator); G.load_state_dict(ckpt["G_ema"])
+
+The published files pickle `cfg` as an OmegaConf DictConfig.  omegaconf is not a dependency here, so the file is read
+with a RESTRICTED unpickler: tensors / storages and plain containers load normally, every class under `omegaconf.` is
+replaced by an inert stand-in that only receives its pickled attribute dict, and the node tree (DictConfig._content ->
+{key: node}, ListConfig._content -> [node], value nodes ._val) is converted to `gans.config.Config`.  Anything else
+(arbitrary globals) is refused, so a checkpoint cannot run code on load.  Checkpoints written by this build (cfg is a
+`gans.config.Config`) load through the same function.  There is no network here: release names resolve to
+$DGV2_CKPT_DIR/<file> if that file exists."""
+import os
+import pickle
+
+import torch
+
+from gans.config import Config
+
+_TAG = "weights-wacv23"
+_ROOT = f"https://github.com/kazuto1011/dusty-gan-v2/releases/download/{_TAG}/"
+PRETRAINED_CKPTS = {
+    "dusty_v1": _ROOT + "dustyv1_kitti_64x512_25M.pth",
+    "dusty_v2": _ROOT + "dustyv2_kitti_64x512_25M.pth",
+    "vanilla": _ROOT + "vanilla_kitti_64x512_25M.pth",
+}
+
+
+def is_available_model(name: str) -> bool:
+    return name in PRETRAINED_CKPTS
+
+
+class _OmegaStandIn:
+    """Receives the pickled __dict__ of any omegaconf object (pickle's default: update __dict__ with the state)."""
+    _dgv2_cls = ""
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple):     # (dict, slots) form
+            for part in state:
+                if isinstance(part, dict):
+                    self.__dict__.update(part)
+        elif isinstance(state, dict):
+            self.__dict__.update(state)
+
+
+def _stand_in(module, name):
+    return type(name, (_OmegaStandIn,), {"_dgv2_cls": f"{module}.{name}", "__module__": __name__})
+
+
+_SAFE_PREFIXES = ("torch", "collections", "numpy", "_codecs", "typing", "enum", "pathlib", "copyreg")
+_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
+                  "complex", "slice", "range", "object", "NoneType", "getattr"}
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        module = {"__builtin__": "builtins", "copy_reg": "copyreg"}.get(module, module)   # protocol-2 pickles
+        root = module.split(".")[0]
+        if root == "omegaconf":
+            return _stand_in(module, name)
+        if module == "gans.config" and name == "Config":
+            return Config
+        if module == "builtins" and name in _SAFE_BUILTINS:
+            return super().find_class(module, name)
+        if root in _SAFE_PREFIXES and not (root == "torch" and name in ("load", "hub")):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}: refused by the restricted loader")
+
+
+class _RestrictedPickle:
+    """The `pickle_module` torch.load asks for."""
+    __name__ = "dgv2_restricted_pickle"
+    Unpickler = _RestrictedUnpickler
+    load = staticmethod(lambda f, **kw: _RestrictedUnpickler(f, **kw).load())
+    loads = staticmethod(pickle.loads)
+    dump = staticmethod(pickle.dump)
+    dumps = staticmethod(pickle.dumps)
+    HIGHEST_PROTOCOL = pickle.HIGHEST_PROTOCOL
+    UnpicklingError = pickle.UnpicklingError
+    PicklingError = pickle.PicklingError
+
+
+def _plain(node):
+    """OmegaConf node tree (stand-ins) -> Config / list / python values."""
+    if isinstance(node, _OmegaStandIn):
+        d = node.__dict__
+        if "_content" in d:
+            c = d["_content"]
+            if isinstance(c, dict):
+                return Config({(k if isinstance(k, str) else _plain(k)): _plain(v) for k, v in c.items()})
+            if isinstance(c, (list, tuple)):
+                return [_plain(v) for v in c]
+            return _plain(c)                 # None / "???" containers
+        if "_val" in d:
+            return _plain(d["_val"])
+        if "_value_" in d:                    # enum members pickled by value
+            return d["_value_"]
+        return None
+    if isinstance(node, dict):
+        return Config({k: _plain(v) for k, v in node.items()})
+    if isinstance(node, (list, tuple)):
+        return [_plain(v) for v in node]
+    return node
+
+
+def load_checkpoint(path, map_location="cpu"):
+    ckpt = torch.load(path, map_location=map_location, pickle_module=_RestrictedPickle, weights_only=False)
+    if isinstance(ckpt, dict) and "cfg" in ckpt:
+        ckpt["cfg"] = _plain(ckpt["cfg"])
+    return ckpt
+
+
+def autoload_ckpt(ckpt_name: str):
+    """reference: gans/pretrained.py:26-33 (the download is replaced by a local lookup: no network)."""
+    if is_available_model(ckpt_name):
+        local = os.path.join(os.environ.get("DGV2_CKPT_DIR", "."), os.path.basename(PRETRAINED_CKPTS[ckpt_name]))
+        if not os.path.exists(local):
+            raise FileNotFoundError(f"{ckpt_name}: put {os.path.basename(local)} (from {PRETRAINED_CKPTS[ckpt_name]}) "
+                                    f"into $DGV2_CKPT_DIR (looked for {local}); this build has no network access")
+        return load_checkpoint(local)
+    if os.path.exists(ckpt_name):
+        return load_checkpoint(ckpt_name)
+    raise ValueError(f"invalid model name: {ckpt_name}")

@@ -84,8 +84,9 @@ class Trainer:
         ).eval().to(self.device)
         for m in (self.G, self.G_ema, self.D, self.A, self.coord):
             m.requires_grad_(False)
-        self.g_sync = parallel.FlatGradSync(self.G)
-        self.d_sync = parallel.FlatGradSync(self.D)
+        payload = {"fp32": None, "bf16": torch.bfloat16}[str(cfg.training.get("grad_payload", "fp32"))]
+        self.g_sync = parallel.FlatGradSync(self.G, payload)
+        self.d_sync = parallel.FlatGradSync(self.D, payload)
         self.ddp_models = (self.g_sync, self.d_sync)
         self.auxin = {"angle": self.coord.angle}  # [1,2,H,W]; kernels broadcast it over the batch
 

@@ -39,6 +39,14 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
+def to_plain(obj):
+    if isinstance(obj, dict):
+        return {k: to_plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [to_plain(v) for v in obj]
+    return obj
+
+
 def save(name, d):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **{k: (npy(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()})
@@ -444,6 +452,59 @@ def golden_full():
     save("model_full.npz", out)
 
 
+
+def fake_omegaconf_tree(obj):
+    """omegaconf is not in the image, so the published checkpoints' pickled `cfg` (an OmegaConf DictConfig) is imitated:
+    classes with omegaconf's module paths and names whose instances carry omegaconf's own attribute layout
+    (DictConfig / ListConfig: `_metadata`, `_parent`, `_flags_cache`, `_content` = {key: node} / [node]; value nodes:
+    `_metadata`, `_parent`, `_val`).  Only used to WRITE the checkpoint fixture; the loader under test
+    (gans/pretrained.py) never imports these."""
+    mods = {}
+    for name in ("omegaconf", "omegaconf.base", "omegaconf.dictconfig", "omegaconf.listconfig", "omegaconf.nodes"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+        mods[name] = m
+
+    def cls(module, name, base=object):
+        c = type(name, (base,), {"__module__": module})
+        setattr(mods[module], name, c)
+        return c
+
+    Metadata = cls("omegaconf.base", "Metadata")
+    ContainerMetadata = cls("omegaconf.base", "ContainerMetadata", Metadata)
+    DictConfig = cls("omegaconf.dictconfig", "DictConfig")
+    ListConfig = cls("omegaconf.listconfig", "ListConfig")
+    nodes = {bool: cls("omegaconf.nodes", "BooleanNode"), int: cls("omegaconf.nodes", "IntegerNode"),
+             float: cls("omegaconf.nodes", "FloatNode"), str: cls("omegaconf.nodes", "StringNode"),
+             type(None): cls("omegaconf.nodes", "AnyNode")}
+
+    def meta(container, key):
+        m = (ContainerMetadata if container else Metadata)()
+        m.__dict__.update(ref_type=object, object_type=dict if container else None, optional=True, key=key, flags={},
+                          flags_root=False, resolver_cache={})
+        return m
+
+    def wrap(v, parent, key):
+        if isinstance(v, dict):
+            n = DictConfig()
+            n.__dict__.update(_metadata=meta(True, key), _parent=parent, _flags_cache=None, _content={})
+            for k, x in v.items():
+                n._content[k] = wrap(x, n, k)
+            return n
+        if isinstance(v, (list, tuple)):
+            n = ListConfig()
+            n.__dict__.update(_metadata=meta(True, key), _parent=parent, _flags_cache=None, _content=[])
+            for i, x in enumerate(v):
+                n._content.append(wrap(x, n, i))
+            return n
+        n = nodes.get(type(v), nodes[type(None)])()
+        n.__dict__.update(_metadata=meta(False, key), _parent=parent, _val=v)
+        return n
+
+    return wrap(obj, None, None)
+
+
 # ----------------------------------------------------------------------------
 TRAINER_SITES = {
     "z": ["g.z", "d.z"],
@@ -645,6 +706,27 @@ def golden_trainer():
                     out[f"{tag}final.{name}.v_slice"] = torch.stack(
                         [torch.nn.functional.pad(opt.state[p]["exp_avg_sq"].flatten()[:16], (0, max(0, 16 - p.numel())))
                          for p in mod.parameters()])
+                # ---- checkpoint in the published layout (trainer.py:551-567 run by the reference itself), `cfg` pickled
+                # as an (imitated) OmegaConf tree, plus what its consumers compute from it (quick_demo.py:24-34)
+                import pathlib
+                plain = to_plain(cfg)
+                tr.cfg = fake_omegaconf_tree(plain)
+                tr.cfg.__dict__["training"] = types.SimpleNamespace(loss=types.SimpleNamespace(pl=0.0))   # read by save_checkpoint
+                ck_path = pathlib.Path(HERE) / "checkpoint_small.pth"
+                tr.save_checkpoint(ck_path, NIT * B)
+                ck = torch.load(ck_path, map_location="cpu", weights_only=False)
+                for k in ("optim_G", "optim_D"):      # keep the fixture small: hyper-parameters only
+                    ck[k] = {"state": {}, "param_groups": ck[k]["param_groups"]}
+                ck["cfg"].__dict__.pop("training")
+                torch.save(ck, ck_path)
+                Gd = build_generator(cfg.model.generator)
+                Gd.load_state_dict(ck["G_ema"])
+                Gd.eval()
+                zc = torch.randn(2, 32, generator=torch.Generator().manual_seed(4))
+                torch.manual_seed(56)
+                with torch.no_grad():
+                    oc = Gd(zc, angle=ck["angle"].repeat_interleave(2, dim=0), truncation_psi=0.7)
+                out.update({"ckpt.z": zc, "ckpt.image_orig": oc["image_orig"], "ckpt.raydrop_logit": oc["raydrop_logit"]})
     finally:
         os.chdir(cwd)
     save("trainer_small.npz", out)

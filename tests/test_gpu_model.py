@@ -189,3 +189,69 @@ def test_fresh_angle_tensors_never_hit_a_stale_constant_cache(models, g_small):
         assert rel(outs[-1], per_sample) < 1e-4, k
         del angle
     assert rel(outs[1], outs[0]) > 1e-3 and rel(outs[2], outs[1]) > 1e-3   # different grids, different images
+
+
+def test_inversion_gradients_wrt_w_and_angle_phase(models, g_small):
+    """demo_inversion.py:125-131,164 optimises the latent w+ AND a per-sample phase added to the angle grid:
+    G(w, angle=coord.angle + phase, input_w=True).  Gradients of a functional of the outputs w.r.t. both against the
+    oracle's autograd (CPU), and the checkpoint consumers' eval forward (quick_demo.py:24-34) against the outputs the
+    reference computed from tests/golden/checkpoint_small.pth."""
+    from oracle import model as o_model
+    cfg, G, D, A = models
+    d = g_small
+    load(G, D, d, "Gev.")
+    G.eval().requires_grad_(False)
+    B = 2
+    g = torch.Generator().manual_seed(12)
+    w = (torch.randn(B, G.synthesis_network.num_styles, 32, generator=g) * 0.5)
+    phase = torch.randn(B, 2, 1, 1, generator=g) * 0.05
+    r1, r2 = torch.randn(B, 1, 16, 64, generator=g), torch.randn(B, 1, 16, 64, generator=g)
+    # oracle
+    sdG = dict(sub_dict(d, "G0."))
+    sdG.update(sub_dict(d, "Gev."))
+    wo, po = w.clone().requires_grad_(True), phase.clone().requires_grad_(True)
+    oo, _ = o_model.generator(sdG, wo, d["angle"] + po, training=False, gumbel_u=torch.full((B, 1, 16, 64), 0.5),
+                              input_w=True)
+    lo = (oo["image_orig"] * r1).sum() + (oo["raydrop_logit"] * r2).sum()
+    gw_o, gp_o = torch.autograd.grad(lo, [wo, po])
+    # HIP
+    wd, pd = w.to(DEV).requires_grad_(True), phase.to(DEV).requires_grad_(True)
+    o = G(wd, angle=d["angle"].to(DEV) + pd, input_w=True)
+    assert rel(o["image_orig"], oo["image_orig"]) < 1e-3 and rel(o["raydrop_logit"], oo["raydrop_logit"]) < 1e-3
+    l = (o["image_orig"] * r1.to(DEV)).sum() + (o["raydrop_logit"] * r2.to(DEV)).sum()
+    gw, gp = torch.autograd.grad(l, [wd, pd])
+    assert rel(gw, gw_o) < 1e-3, rel(gw, gw_o)
+    assert rel(gp, gp_o) < 1e-3, rel(gp, gp_o)
+    # a [1,2,H,W] grid that requires grad must not fall onto the cached (non-differentiable) shared-grid path
+    a1 = d["angle"].to(DEV).clone().requires_grad_(True)
+    o1 = G(wd.detach(), angle=a1, input_w=True)
+    (ga,) = torch.autograd.grad((o1["image_orig"] * r1.to(DEV)).sum(), a1)
+    ao = d["angle"].clone().requires_grad_(True)
+    oo1, _ = o_model.generator(sdG, w, ao.expand(B, -1, -1, -1), training=False,
+                               gumbel_u=torch.full((B, 1, 16, 64), 0.5), input_w=True)
+    (ga_o,) = torch.autograd.grad((oo1["image_orig"] * r1).sum(), ao)
+    assert rel(ga, ga_o) < 1e-3
+
+
+def test_checkpoint_consumer_eval_forward_matches_reference():
+    """quick_demo.py:24-34 on the new generator: build from the checkpoint's pickled cfg, load G_ema, eval forward with
+    truncation 0.7 -- against the outputs the reference computed from the same file."""
+    import os
+
+    import numpy as np
+
+    from conftest import GOLDEN
+    from gans.models.builder import build_generator
+    from gans.pretrained import autoload_ckpt
+    ck = autoload_ckpt(os.path.join(GOLDEN, "checkpoint_small.pth"))
+    cfg = ck["cfg"].model.generator
+    cfg.synthesis_kwargs.num_fp16_layers = 0
+    G = build_generator(cfg)
+    G.load_state_dict(ck["G_ema"])
+    G.eval().to(DEV)
+    ref = np.load(os.path.join(GOLDEN, "trainer_small.npz"))
+    z = torch.from_numpy(ref["ckpt.z"]).to(DEV)
+    with torch.no_grad():
+        o = G(z=z, angle=ck["angle"].repeat_interleave(2, dim=0).to(DEV), truncation_psi=0.7)
+    assert rel(o["image_orig"], torch.from_numpy(ref["ckpt.image_orig"])) < 1e-3
+    assert rel(o["raydrop_logit"], torch.from_numpy(ref["ckpt.raydrop_logit"])) < 1e-3
