@@ -62,7 +62,9 @@ def main():
     cfg.training.lazy.update(gp=2, ada=2)
     cfg.training.augment.update(p_init=0.5, kimg=1)
     cfg.training.warmup.fade_kimg = 0
+    import numpy as np
     torch.manual_seed(rank)    # different initial weights per rank on purpose: rank 0's must win (DDP ctor semantics)
+    np.random.seed(rank)       # (the PE frequencies are drawn with numpy's generator)
     tr = Trainer(cfg, sync_scalars=False)
     if rank == 0:
         G0, D0 = build_models(cfg, "cpu")
