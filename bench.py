@@ -151,11 +151,11 @@ def _pmc_traffic(kernel_key):
 
 
 def roofline_probe(args, reps=20):
-    """Roofline of the DOMINANT kernel of the step (largest share of GPU time in
-    profiles/round1_*_kernel_stats.csv): conv_pipe_kernel, the direct halo-tile conv engine behind
-    dgv2_conv_taps, at its most expensive call site -- the first ResidualBlock's conv1 in the D step
-    (real + fake = 2 x batch images, 64 x 512, 32 -> 32 channels, 3x3, ring padding, bias + lrelu fused).
-    HBM-bound: algorithmic bytes per image = H*W*(C + O)*2 B = 4.19 MB (DESIGN.md section 5), per launch
+    """Roofline of the conv engine (largest share of GPU time in profiles/round*_kernel_stats.csv) at its most
+    expensive call site -- the first ResidualBlock's conv1 in the D step (real + fake = 2 x batch images, 64 x 512,
+    32 -> 32 channels, 3x3, ring padding, bias + lrelu fused): dgv2_conv_taps, which runs conv3x3_strip_kernel
+    (csrc/conv_strip.hip) for this geometry (conv_pipe_kernel with DGV2_NO_STRIP=1).
+    HBM-bound: algorithmic bytes per image = H*W*(C + O)*2 B = 4.19 MB (DESIGN.md section 4), per launch
     2 x batch images + the 18 KB of weights."""
     from gans.models.ops import native
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -168,38 +168,57 @@ def roofline_probe(args, reps=20):
     nbytes = (B * H * W * (C + O) + O * 9 * C) * x.element_size()
     flops = 2.0 * B * H * W * C * O * 9
     ach = nbytes / sec / 1e9
-    return {"kernel": "conv_pipe_kernel (dgv2_conv_taps: D block-0 conv1 fwd, 2B x 64x512, 32->32, 3x3 ring, bias+lrelu)",
+    strip = dt == torch.bfloat16 and os.environ.get("DGV2_NO_STRIP") is None
+    kname = "conv3x3_strip_kernel" if strip else "conv_pipe_kernel"
+    return {"kernel": kname + " (dgv2_conv_taps: D block-0 conv1 fwd, 2B x 64x512, 32->32, 3x3 ring, bias+lrelu)",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-            "traffic": _pmc_traffic("conv_pipe_kernel"), "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
+            "traffic": _pmc_traffic(kname), "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12}
 
 
 def modconv_probe(args, reps=20):
-    """The MFMA kernel north_star names: the modulated 1x1 conv at its heaviest shape, generator level 4
-    conv1 (dgv2_modconv_pe_fwd: B x 32768 pixels, K = 64 + 512 shared-PE channels, O = 32, bias + lrelu).
-    Algorithmic FLOPs per launch = 2*B*P*K*O (604 MMAC/img); compulsory HBM bytes =
-    xa in + y out (the PE is batch-shared)."""
+    """The MFMA kernel north_star names: the modulated 1x1 conv at its heaviest site, generator level-4 conv1
+    (B x 32768 pixels, K = 64 + 512 shared-PE channels, O = 32, bias + lrelu) as the training step runs it:
+      dgv2_bmm_nn          t = W_a . h at 32x256 (the xa columns, commuted past the up-sampling: a quarter of the pixels)
+      dgv2_modconv_up_fwd  y = act(c * (up2(t) + W_s . PE) + bias)   <- the kernel reported (csrc/modconv_up.hip)
+    `achieved` = the kernel's own algorithmic FLOPs 2*B*P*Ks*O over its launch time; `layer_tflops` = the whole layer's
+    2*B*P*(Ka+Ks)*O (604 MMAC/img) over both launches + the statistic-only pass of training mode.
+    Compulsory HBM bytes of the kernel = y out + t in (the PE is batch-shared, the weights per-sample 37 KB)."""
     if args.dtype != "bf16":
         return None
     import dgv2_native as N
-    B, P, Ka, Ks, O = args.batch_per_gpu, 64 * 512, 64, 512, 32
+    from gans.models.ops import native
+    from gans.models.ops.common import Resample
+    B, hl, wl, Ka, Ks, O = args.batch_per_gpu, 32, 256, 64, 512, 32
+    H, W = 2 * hl, 2 * wl
+    P = H * W
     bf = torch.bfloat16
-    xa = torch.randn(B, P, Ka, device="cuda", dtype=bf)
-    xs = torch.randn(P, Ks, device="cuda", dtype=bf)
-    w = torch.randn(B, O, Ka + Ks, device="cuda", dtype=bf)
+    spec = Resample(up=2, window=[1, 3, 3, 1], ring=True).spec
+    h = torch.randn(B, hl, wl, Ka, device="cuda", dtype=bf)
+    xs = torch.randn(1, H, W, Ks, device="cuda", dtype=bf)
+    w = torch.randn(B, O, Ka + Ks, device="cuda", dtype=bf) / 16
     bias = torch.randn(O, device="cuda")
-    y = torch.empty(B, P, O, device="cuda", dtype=bf)
-    sec = _time_launches(lambda: N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(xa), N.ptr(xs), N.ptr(w), B, P, Ka, Ks,
-                                        O, N.ptr(bias), 3, 0.2, 2.0 ** 0.5, N.BF16, N.stream()), reps)
-    flops = 2.0 * B * P * (Ka + Ks) * O
-    nbytes = (B * P * (Ka + O) + P * Ks + B * O * (Ka + Ks)) * 2
+    cvec = torch.ones(O, device="cuda")
+    y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
+    t = native._bmm_nn_raw(h.reshape(B, hl * wl, Ka), w[:, :, :Ka].contiguous(), bf)
+    ih, ch, iw, cw = native._up_tables(spec, hl, wl, h.device)
+    sec = _time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(xs), N.ptr(w), B, H, W, hl, wl, Ks,
+                                        O, Ka + Ks, Ka, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(cvec),
+                                        N.ptr(bias), 3, 0.2, 2.0 ** 0.5, N.BF16, None, 0, None, N.stream()), reps)
+    sec_lo = _time_launches(lambda: native._bmm_nn_raw(h.reshape(B, hl * wl, Ka), w[:, :, :Ka].contiguous(), bf), reps)
+    sec_sq = _time_launches(lambda: native.resample_sq_only(h, spec), reps)
+    flops = 2.0 * B * P * Ks * O
+    nbytes = (B * P * O + B * hl * wl * O + P * Ks + B * O * Ks) * 2
     ach = flops / sec / 1e12
-    return {"kernel": "modconv_pe_fwd_kernel (dgv2_modconv_pe_fwd: G level-4 conv1, B x 32768 px, K=64+512, O=32)",
+    return {"kernel": "modconv_up_kernel (dgv2_modconv_up_fwd: G level-4 conv1, B x 32768 px, PE K=512, O=32, "
+                      "up2 of the low-res xa part in the epilogue)",
             "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": _pmc_traffic("modconv_pe_fwd_kernel"),
+            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": _pmc_traffic("modconv_up_kernel"),
             "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6,
-            "algorithmic_hbm_GBps": nbytes / sec / 1e9}
+            "algorithmic_hbm_GBps": nbytes / sec / 1e9,
+            "layer_tflops": 2.0 * B * P * (Ka + Ks) * O / (sec + sec_lo + sec_sq) / 1e12,
+            "layer_us": {"modconv_up": sec * 1e6, "lowres_gemm": sec_lo * 1e6, "statistic_pass": sec_sq * 1e6}}
 
 
 def build_trainer(args, rank, world, d_epilogue=None):

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
 #pragma unroll
         for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
       }
-      o.store(yp + (int64_t)ho * out_w * ldy);
+      if (y) o.store(yp + (int64_t)ho * out_w * ldy);   // y == nullptr: statistic only (sum of squares of the result)
       if (sumsq) {
 #pragma unroll
         for (int j = 0; j < VN; ++j) ss = fmaf(o.get(j), o.get(j), ss);
@@ -532,13 +532,17 @@ extern "C" int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, co
                                     int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w, int dtype,
                                     float* sumsq, int sumsq_cap, int* sumsq_used, void* stream) {
   if (sumsq_used) *sumsq_used = 0;
-  if (!y || !x || !idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w) return DGV2_EINVAL;
+  // y == NULL: only the sum-of-squares partials of the (never stored) result are produced -- the input statistic of a
+  // modulated conv whose up-sampling was commuted past the contraction (modconv_up.hip); needs the streaming kernel
+  const bool stat_only = !y;
+  if ((stat_only && !(sumsq && sumsq_used)) || !x || !idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w) return DGV2_EINVAL;
   if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || Eh <= 0 || Ew <= 0) return DGV2_EINVAL;
   if (ldx < C || ldy < C) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   DGV2_DISPATCH_DTYPE(dtype, {
     constexpr int VN = vec16<T>::N;
     const bool vec = (C % VN == 0) && (ldx % VN == 0) && (ldy % VN == 0) && aligned16(x) && aligned16(y);
+    if (stat_only && !(vec && Ew <= 4 && Eh <= 64)) return DGV2_ENOTSUP;
     const int64_t total = (int64_t)B * out_h * out_w * ((C + (vec ? VN : 1) - 1) / (vec ? VN : 1));
     const int grid = grid_for(total, 256, 256 * 64);
     static const bool no_stream = getenv("DGV2_NO_RSTREAM") != nullptr;   // A/B switch for benchmarking
@@ -547,7 +551,7 @@ extern "C" int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, co
 #else
     constexpr int rs_ablate = 0;
 #endif
-    if (vec && Ew <= 4 && Eh <= 64 && !no_stream) {
+    if (vec && Ew <= 4 && Eh <= 64 && (!no_stream || stat_only)) {
       static const int sh_env = getenv("DGV2_RS_SH") ? atoi(getenv("DGV2_RS_SH")) : 0;   // experiments
       int SH = out_h >= 32 ? 16 : (out_h >= 8 ? 8 : out_h);
       if (sh_env > 0 && sh_env < SH) SH = sh_env;
@@ -555,6 +559,7 @@ extern "C" int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, co
       const int64_t blocks = (int64_t)B * ((out_h + SH - 1) / SH) * (((int64_t)out_w * (C / VN) + 255) / 256);
       if (blocks >= (1LL << 31)) return DGV2_EINVAL;
       float* sq = (sumsq && sumsq_used && blocks <= sumsq_cap) ? sumsq : nullptr;   // one partial per block
+      if (stat_only && !sq) return DGV2_ENOTSUP;
       if (sq) *sumsq_used = (int)blocks;
       rs_launch<T>(Ew, (int)blocks, st, (T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, B, C, ldx, ldy, in_h,
                    in_w, out_h, out_w, SH | (rs_ablate << 16), sq);

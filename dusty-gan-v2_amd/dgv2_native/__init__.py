@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -49,6 +49,8 @@ SIGNATURES = {
     "dgv2_modconv_pe_fwd": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_modconv_pe_fwd_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                                _c_ptr],
+    "dgv2_modconv_up_fwd": [_c_ptr] * 4 + [_c_int] * 9 + [_c_ptr] * 6 + [_c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
+                            _c_ptr],
     "dgv2_resample_tab_actbwd": [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr] + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3
                                 + [_c_int] * 7 + [_c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_resample_tab_sq": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr, _c_int, _c_ptr, _c_ptr],

@@ -160,6 +160,20 @@ class SynthesisBlock(nn.Module):
         conv = self.conv1
         sumsq, pe_sq = None, 0.0
         hup = None
+        if (conv._prep is not None and hin is not None and isinstance(self.resample, ops.Resample) and link is None
+                and native.mod_up_ok(hin, pe0, conv._prep[1], self.resample.spec)):
+            # the up-sampling commutes with the 1x1 contraction: the xa columns run at this block's INPUT resolution
+            # and up2(h) is never materialised (csrc/modconv_up.hip); its statistic comes from a read-only pass
+            handle, wb, cvec, wt = conv._prep
+            cin = hin.shape[3]
+            if conv.training:
+                pe_sq = float(self.pe.out_ch // 2) * B * H * W
+                sumsq = native.resample_sq_only(hin, self.resample.spec)
+            conv.update_ema(sumsq, B * H * W * (cin + self.pe.out_ch), pe_sq, cvec)
+            act = self.bias_act1
+            want = want_sq and (self.head.training if self.is_first else self.conv2.training)
+            return native.mod_up_layer(hin, pe0, self.resample.spec, handle, wb, cvec, bias=act.bias, act=True,
+                                       alpha=act.negative_slope, scale=act.scale, want_sq=want, wt=wt)
         if hin is not None and conv.training and isinstance(self.resample, ops.Resample):
             hup, sumsq = native.resample_sq(hin, self.resample.spec)   # the statistic leaves the same kernel
         elif hin is not None:

@@ -184,6 +184,19 @@ int dgv2_bmm_tn(float* gw, const void* gy, const void* x, int B, int P, int I, i
 int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
                     int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
                     void* stream);
+/* The same level-input conv with the block's up-sampling COMMUTED past the contraction (a 1x1 conv acts per pixel, the
+ * FIR per channel): W_a . up2(h) == up2(W_a . h), so the xa columns run at a quarter of the pixels (t = W_a . h, a
+ * dgv2_bmm_nn at the previous level's resolution) and this entry evaluates
+ *   y[b,p,:O] = act( row_scale * ( up2(t)[b,p,:] + sum_{k<Ks} xs[p,k] w[b,:,koff+k] ) + bias )      (bf16)
+ * t [B,Hin,Win,O]; up2 given as two-tap tables idx/coef [Hout][2], [Wout][2] (low-resolution index, weight: the sparse
+ * rows of Resample(up=2), gans/models/ops/common.py:105-135, with its ring / replicate extension); xs [Hout*Wout,Ks];
+ * w [B,O,I] (PE columns start at koff).  O = 32, Ks = 512 (generator level 4); DGV2_ENOTSUP otherwise.
+ * replaces: Resample(up=2) + torch.cat([h, pe]) + ModConv2d contraction + FusedLeakyReLU,
+ *   gans/models/dusty_v2.py:153-162, gans/models/ops/style.py:105-118. */
+int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const void* w, int B, int Hout, int Wout, int Hin,
+                        int Win, int Ks, int O, int I, int koff, const int* idx_h, const float* coef_h,
+                        const int* idx_w, const float* coef_w, const float* row_scale, const float* bias, int act,
+                        float alpha, float scale, int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 /* dgv2_bmm_nn / dgv2_bmm_nn_cat that also leave per-block partial sums of squares of the stored outputs
  * (contract as in dgv2_resample_tab_sq), with an optional per-output-channel factor ahead of the bias:
  * y = act(acc * row_scale[o] + bias[o]) (row_scale fp32 [O] or NULL) -- the input-magnitude factor of

@@ -1,0 +1,40 @@
+"""Generator level-4 conv1 (B x 64x512, Ka = 64 from 32x256, Ks = 512, O = 32, bf16): the path that materialises up2(h)
+(resample_sq + dgv2_modconv_pe_fwd) against the commuted one (low-res dgv2_bmm_nn + dgv2_modconv_up_fwd + statistic-only
+pass); us per launch."""
+import math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dusty-gan-v2_amd")]
+import torch
+import bench
+import dgv2_native as N
+from gans.models.ops import native
+from gans.models.ops.common import Resample
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+bf = torch.bfloat16
+hl, wl, Ka, Ks, O = 32, 256, 64, 512, 32
+H, W = 64, 512
+spec = Resample(up=2, window=[1, 3, 3, 1], ring=True).spec
+h = torch.randn(B, hl, wl, Ka, device="cuda", dtype=bf)
+pe = torch.randn(1, H, W, Ks, device="cuda", dtype=bf)
+wb = torch.randn(B, O, Ka + Ks, device="cuda", dtype=bf) / 16
+bias = torch.randn(O, device="cuda"); cvec = torch.ones(O, device="cuda")
+hup = native._resample_raw(h, spec, False, (hl, wl))
+y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
+t_rs = bench._time_launches(lambda: native._resample_raw(h, spec, False, (hl, wl), sq=native._sq_args(h.device)), 20)
+t_pe = bench._time_launches(lambda: N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(hup), N.ptr(pe), N.ptr(wb), B, H * W, Ka, Ks, O, N.ptr(cvec), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
+y0 = y.clone()
+wa = wb[:, :, :Ka].contiguous()
+t = native._bmm_nn_raw(h.reshape(B, hl * wl, Ka), wa, bf)
+ih, ch, iw, cw = native._up_tables(spec, hl, wl, h.device)
+t_sq = bench._time_launches(lambda: native.resample_sq_only(h, spec), 20)
+t_lo = bench._time_launches(lambda: native._bmm_nn_raw(h.reshape(B, hl * wl, Ka), wb[:, :, :Ka].contiguous(), bf), 20)
+t_up = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pe), N.ptr(wb), B, H, W, hl, wl, Ks, O, Ka + Ks, Ka, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(cvec), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
+y1 = y.clone()
+wimg = wb[:, :, Ka:].reshape(B, O, Ks // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+t_img = bench._time_launches(lambda: wb[:, :, Ka:].reshape(B, O, Ks // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous(), 20)
+t_up2 = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pe), N.ptr(wimg), B, H, W, hl, wl, Ks, O, 0, 0, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(cvec), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
+print(f"modconv_up on the weight image: {t_up2*1e6:6.1f} us (+ repack {t_img*1e6:5.1f} us), same result: {bool(torch.equal(y, y1))}")
+fl = 2.0 * B * H * W * (Ka + Ks) * O
+print(f"cat path : resample_sq {t_rs*1e6:6.1f} + modconv_pe {t_pe*1e6:6.1f} = {(t_rs+t_pe)*1e6:6.1f} us  (kernel {fl/t_pe/1e12:5.0f} TF/s, layer {fl/(t_rs+t_pe)/1e12:5.0f} TF/s)")
+print(f"commuted : stat-only {t_sq*1e6:6.1f} + low-res gemm {t_lo*1e6:6.1f} + modconv_up {t_up*1e6:6.1f} = {(t_sq+t_lo+t_up)*1e6:6.1f} us  (kernel {2.0*B*H*W*Ks*O/t_up/1e12:5.0f} TF/s own FLOPs, layer {fl/(t_sq+t_lo+t_up)/1e12:5.0f} TF/s)")
+print("max |diff| vs cat path:", float((y.float() - y0.float()).abs().max()), "of", float(y0.float().abs().max()))

@@ -6,7 +6,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "conv_pipe" in k or "modconv_pe" in k or "conv3x3" in k:
+            if "conv_pipe" in k or "modconv_pe" in k or "conv3x3" in k or "modconv_up" in k:
                 agg[(k.split("(")[0][:70], r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for (k, g), cs in sorted(agg.items()):
     m = {c: sum(v) / len(v) for c, v in cs.items()}

@@ -922,3 +922,62 @@ def test_conv_strip_kernel_forward_and_data_gradient(nat, B, H, W):
             assert_rel(nchw(got_y), want_act.detach(), 8e-3, "act")
             assert_rel(nchw(got_gx), want_gx, 8e-3, "gx")
             assert_rel(nchw(got_gxr), want_gx + resq, 1.2e-2, "gx + resid")
+
+
+def test_modconv_up_commuted_upsampling_matches_cat_path(nat):
+    """dgv2_modconv_up_fwd (conv1 of a generator level with the up-sampling commuted past the 1x1 contraction,
+    csrc/modconv_up.hip) + its backward against (a) the float64 statement of the reference, act(c * ([up2(h) | PE] . W) +
+    bias) (dusty_v2.py:153-162, style.py:105-118, Resample common.py:105-135), and (b) the existing path that
+    materialises up2(h) (resample + dgv2_modconv_pe_fwd), outputs and every gradient; plus the statistic-only pass."""
+    from gans.models.ops.common import Resample
+    g = torch.Generator().manual_seed(77)
+    B, hl, wl, Ka, F, O = 3, 8, 32, 64, 256, 32
+    H, W = 2 * hl, 2 * wl
+    up = Resample(up=2, window=[1, 3, 3, 1], ring=True)
+    spec = up.spec
+    dt = torch.bfloat16
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+    h = rnd(B, hl, wl, Ka).to(dt)
+    pe = rnd(1, H, W, 2 * F).to(dt)
+    Wp = rnd(O, Ka + 2 * F).requires_grad_(True)
+    Sp = rnd(B, Ka + 2 * F, scale=0.5).requires_grad_(True)
+    bias = rnd(O).requires_grad_(True)
+    ev = torch.tensor([0.8], device=DEV)
+    cvec = (1.0 / (torch.sqrt(ev) + 1e-8)).expand(O).contiguous()
+    layers = [dict(W=Wp, s=Sp, O=O, I=Ka + 2 * F, demod=True, cin=Ka, fw=None, group=0, row_off=0)]
+    groups = [dict(Otot=O, I=Ka + 2 * F, dtype=dt, Ka=Ka)]
+    gy = rnd(B, H, W, O).to(dt)
+    res = {}
+    for mode in ("cat", "up"):
+        for act in (True, False):
+            hh = h.clone().requires_grad_(True)
+            handle, wb, wt = nat.mod_prep_all(layers, groups, None)[0]
+            if mode == "cat":
+                hup, sq_ref = nat.resample_sq(hh, spec)
+                y = nat.mod_gemm_layer(hup, pe, handle, wb, cvec, bias=bias, act=act, wt=wt)
+            else:
+                assert nat.mod_up_ok(hh, pe, wb, spec)
+                y, sq_y = nat.mod_up_layer(hh, pe, spec, handle, wb, cvec, bias=bias, act=act, wt=wt, want_sq=True)
+                assert_rel(sq_y.sum().cpu(), y.detach().float().square().sum().cpu(), 2e-3, "sum of squares of y")
+                sq_only = nat.resample_sq_only(hh.detach(), spec)
+                assert_rel(sq_only.sum().cpu(), sq_ref.sum().cpu(), 1e-5, "statistic of up2(h) without materialising it")
+            if act:
+                res[mode] = [y.detach().float().cpu(), None, wb.detach()]
+            else:
+                # gradients are compared on the LINEAR layer: with the leaky ReLU, pixels whose pre-activation two bf16
+                # paths round to different sides of zero make any two implementations differ by several percent
+                res[mode][1] = [t.float().cpu() for t in torch.autograd.grad(y, [hh, Wp, Sp, bias], gy)]
+    # float64 statement with the same prepared (bf16) weights
+    wb = res["up"][2].double().cpu()
+    hup = o.resample(h.double().cpu().permute(0, 3, 1, 2), (1, 3, 3, 1), up=2, ring=True).permute(0, 2, 3, 1)
+    x = torch.cat([hup, pe.double().cpu().expand(B, H, W, 2 * F)], dim=3)
+    pre = torch.einsum("bhwi,boi->bhwo", x, wb) * cvec.double().cpu() + bias.detach().double().cpu()
+    want = torch.where(pre > 0, pre, pre * 0.2) * math.sqrt(2.0)
+    assert_rel(res["up"][0], want, 1.2e-2, "y vs float64")     # bf16 storage of up2(h) resp. t, bf16 output
+    assert_rel(res["cat"][0], want, 1.2e-2, "cat path vs float64")
+    assert_rel(res["up"][0], res["cat"][0], 1.5e-2, "y")
+    for a, b, name in zip(res["up"][1], res["cat"][1], ("gh", "gW", "gs", "gb")):
+        assert_rel(a, b, 1.5e-2, name)
