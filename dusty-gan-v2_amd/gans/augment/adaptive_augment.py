@@ -121,8 +121,10 @@ class AdaptiveAugment(torch.nn.Module):
 
     # ------------------------------------------------------------------ p controller
     @torch.no_grad()
-    def cumulate(self, y_real):
-        self.sign_cum += y_real.detach().sign().sum()
+    def cumulate(self, y_real, sign_sum=None):
+        """reference: adaptive_augment.py:368-370.  sign_sum: the statistic when the caller already has it (the fused
+        objective kernel leaves it)."""
+        self.sign_cum += y_real.detach().sign().sum() if sign_sum is None else sign_sum
         self.n_pred_cum += len(y_real)
 
     @torch.no_grad()

@@ -16,6 +16,16 @@ class GANLoss(nn.Module):
         self.metric = metric
         self.smoothing = smoothing
 
+    def fused_nsgan(self, y, n_real):
+        """nsgan on stacked logits y [n,1] (first n_real rows real, the rest fake) in ONE launch, with the statistics
+        the trainer logs: returns (loss, stats) with stats = [loss, mean y_real, mean y_fake, sum sign(y_real)].
+        n_real = len(y) gives loss_G's formula applied to fakes (softplus(-y).mean(), loss.py:66-69)."""
+        from .ops import native
+        return native.nsgan_loss(y, n_real)
+
+    def can_fuse(self, y):
+        return self.metric == "nsgan" and y.is_cuda and y.dtype == torch.float32
+
     def forward(self, pred_real, pred_fake, mode):
         if mode == "G":
             return self.loss_G(pred_real, pred_fake)

@@ -1818,6 +1818,37 @@ class _ModGemmPrepared(Function):
 
 
 # ---------------------------------------------------------------------------------------
+# non-saturating GAN objective + logged statistics in one launch (dgv2_nsgan_loss)
+# ---------------------------------------------------------------------------------------
+class _NsganLoss(Function):
+    """loss = mean softplus(-y[:n_real]) + mean softplus(y[n_real:]); also returns (no gradient) the 4 statistics
+    [loss, mean y_real, mean y_fake, sum sign(y_real)].  First order only (the R1 penalty does not go through it)."""
+
+    @staticmethod
+    def forward(ctx, y, n_real):
+        yf = y.detach().float().contiguous().reshape(-1)
+        n = yf.numel()
+        stats = torch.empty(4, device=y.device, dtype=torch.float32)
+        gy = torch.empty(n, device=y.device, dtype=torch.float32)
+        N.check(yf)
+        N.call("dgv2_nsgan_loss", N.ptr(stats), N.ptr(gy), N.ptr(yf), int(n_real), n - int(n_real), N.stream())
+        ctx.save_for_backward(gy)
+        ctx.shape, ctx.dtype = y.shape, y.dtype
+        ctx.mark_non_differentiable(stats)
+        return stats[0].clone(), stats
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (gy,) = ctx.saved_tensors
+        return (gy * g).reshape(ctx.shape).to(ctx.dtype), None
+
+
+def nsgan_loss(y, n_real):
+    """(loss, stats[4]) for logits y [n,1] with the first n_real rows judged as real (see _NsganLoss)."""
+    return _NsganLoss.apply(y, n_real)
+
+
+# ---------------------------------------------------------------------------------------
 # conv1 of a generator level with the block's up-sampling COMMUTED past the contraction (csrc/modconv_up.hip):
 #   y = act(c * (W_a . up2(h) + W_s . PE) + bias)  ==  act(c * (up2(W_a . h) + W_s . PE) + bias)
 # forward: t = W_a . h at the previous level's resolution (dgv2_bmm_nn), then dgv2_modconv_up_fwd;

@@ -237,7 +237,10 @@ class Trainer:
         z = self._z("g")
         x_fake = self.G(z, noise=self._g_noise("g"), **self.auxin)["image"]
         y_fake = self.D(self.A(self.warmup(x_fake, self._draw("g.keep")), draws=self._ada("g.ada")))
-        loss_gan = self.adversarial_loss(None, y_fake, "G")
+        if self.adversarial_loss.can_fuse(y_fake):
+            loss_gan, _ = self.adversarial_loss.fused_nsgan(y_fake, len(y_fake))   # softplus(-y_fake).mean(), one launch
+        else:
+            loss_gan = self.adversarial_loss(None, y_fake, "G")
         (self.cfg.training.loss.gan * loss_gan).backward()
         self.g_sync.collect()
         set_requires_grad(self.G, False)
@@ -255,12 +258,19 @@ class Trainer:
         # the reference's two calls (trainer.py:391-392): same result, half the launches / weight reads
         y = self.D(torch.cat([x_real_aug, x_fake_aug], dim=0), splits=2)
         y_real, y_fake = y[:self.B], y[self.B:]
-        self.A.cumulate(y_real)
-        loss_gan = self.adversarial_loss(y_real, y_fake, "D")
+        if self.adversarial_loss.can_fuse(y):
+            # objective, its gradient, both output means and ADA's sign statistic from one launch
+            loss_gan, stats = self.adversarial_loss.fused_nsgan(y, self.B)
+            self.A.cumulate(y_real, sign_sum=stats[3])
+            out_real, out_fake = stats[1], stats[2]
+        else:
+            self.A.cumulate(y_real)
+            loss_gan = self.adversarial_loss(y_real, y_fake, "D")
+            out_real, out_fake = y_real.mean().detach(), y_fake.mean().detach()
         (self.cfg.training.loss.gan * loss_gan).backward()
         self.d_sync.collect()
-        scalars["loss/D/output/real"] = y_real.mean().detach()
-        scalars["loss/D/output/fake"] = y_fake.mean().detach()
+        scalars["loss/D/output/real"] = out_real
+        scalars["loss/D/output/fake"] = out_fake
         scalars["loss/D/adversarial"] = loss_gan.detach()
 
     def r1_fb(self, x_real, scalars):

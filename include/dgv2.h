@@ -507,6 +507,16 @@ int dgv2_coords_convert(float* out, const float* in, const float* mask, const fl
  * ------------------------------------------------------------------------- */
 int dgv2_surface_normal(float* out, const float* points, int B, int H, int W, int d, int mode, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * non-saturating GAN objective + the logged discriminator statistics in one launch
+ * replaces: GANLoss("nsgan") gans/models/loss.py:37-41,66-69 (softplus + mean), the y.mean() scalars of
+ *   gans/trainer.py:400-406 and AdaptiveAugment.cumulate's sign sum (adaptive_augment.py:368-370)
+ * y fp32 [n_real + n_fake] logits, reals first (either count may be 0: loss_G = mean softplus(-y_fake) is the
+ * "real" formula applied to the fakes); stats fp32 [4] = loss, mean y_real, mean y_fake, sum sign(y_real);
+ * gy fp32 [n_real + n_fake] = d loss / d y.
+ * ------------------------------------------------------------------------- */
+int dgv2_nsgan_loss(float* stats, float* gy, const float* y, int n_real, int n_fake, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -981,3 +981,26 @@ def test_modconv_up_commuted_upsampling_matches_cat_path(nat):
     assert_rel(res["up"][0], res["cat"][0], 1.5e-2, "y")
     for a, b, name in zip(res["up"][1], res["cat"][1], ("gh", "gW", "gs", "gb")):
         assert_rel(a, b, 1.5e-2, name)
+
+
+def test_fused_nsgan_loss_matches_ganloss(nat):
+    """dgv2_nsgan_loss against GANLoss("nsgan") (gans/models/loss.py:37-41,66-69) and the statistics the trainer logs
+    (trainer.py:400-406, adaptive_augment.py:368-370): loss, gradient w.r.t. the logits, means, sign sum."""
+    from gans.models.loss import GANLoss
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(3)
+    crit = GANLoss("nsgan")
+    for n_real, n_fake in ((64, 64), (5, 3), (8, 0)):
+        y = (torch.randn(n_real + n_fake, 1, generator=g) * 3).to(DEV).requires_grad_(True)
+        y.data[0] = 30.0   # softplus threshold branch
+        loss, stats = crit.fused_nsgan(y, n_real)
+        (gy,) = torch.autograd.grad(loss * 0.7, y)
+        yr = y.detach().cpu().double().requires_grad_(True)
+        want = F.softplus(-yr[:n_real]).mean() + (F.softplus(yr[n_real:]).mean() if n_fake else 0.0)
+        (gw,) = torch.autograd.grad(want * 0.7, yr)
+        assert abs(float(loss) - float(want)) < 1e-5 * abs(float(want)) + 1e-7
+        assert_rel(gy.cpu(), gw, 1e-5, "d loss / d y")
+        assert abs(float(stats[1]) - float(yr[:n_real].mean())) < 1e-5
+        if n_fake:
+            assert abs(float(stats[2]) - float(yr[n_real:].mean())) < 1e-5
+        assert float(stats[3]) == float(yr[:n_real].sign().sum())
