@@ -669,6 +669,8 @@ class Discriminator(nn.Module):
             # bf16 operands and fp32 accumulation
             x = native.linear_low(x, lin1.module.weight, lin1.scale) if x.is_cuda else \
                 F.linear(x, lin1.module.weight.to(LOW)).float() * lin1.scale
+        elif x.is_cuda and lin1.module.bias is None and lin1.gain_ == 1.0 and x.shape[1] >= 8192:
+            x = native.linear_f32(x.float(), lin1.module.weight, lin1.scale)   # fp32 island: split-K forward
         else:
             x = lin1(x.float())
         x = act2.forward_cl(x)

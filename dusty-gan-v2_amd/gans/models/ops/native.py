@@ -985,6 +985,45 @@ def linear_low(x, weight, scale):
     return _LinearLow.apply(x, weight, float(scale))
 
 
+class _LinearF32(Function):
+    """y = (x @ W^T) * scale in fp32 for the 65536 -> 512 Linear of the discriminator's fp32 epilogue
+    (dusty_v2.py:381-383,394-395).  Forward: a skinny GEMM (M = batch) over K = 65536 runs the library's single-pass
+    kernel at 28 TFLOP/s (308 us at B = 128) because only 16 output tiles exist; as S = 32 strided-batched partial
+    GEMMs + one sum it fills the chip.  Backward: plain GEMMs (already near the fp32 MFMA rate)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale):
+        x = x.contiguous()
+        w = weight.detach()
+        Bn, K = x.shape
+        O = w.shape[0]
+        S = 32
+        if K % (S * 8) == 0 and K >= 8192:
+            kc = K // S
+            part = torch.bmm(x.view(Bn, S, kc).transpose(0, 1), w.view(O, S, kc).permute(1, 2, 0))
+            y = part.sum(0)
+        else:
+            y = torch.mm(x, w.t())
+        y.mul_(scale)
+        ctx.save_for_backward(x, weight)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        g = gy * ctx.scale
+        if torch.is_grad_enabled():   # create_graph=True (R1): differentiable ops
+            return g @ weight, g.t() @ x, None
+        gx = torch.mm(g, weight.detach()) if ctx.needs_input_grad[0] else None
+        gw = torch.mm(g.t(), x) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+def linear_f32(x, weight, scale):
+    return _LinearF32.apply(x, weight, float(scale))
+
+
 class _MbstdCat(Function):
     """[x | minibatch-stddev statistic | zero padding] (dgv2_mbstd_cat_fwd/_bwd): MinibatchStdDev + concat of the
     discriminator epilogue (common.py:226-250) in two launches forward and one backward; first order only."""
