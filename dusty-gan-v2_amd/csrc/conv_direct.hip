@@ -33,6 +33,7 @@ constexpr int DTW = 32;
 struct DConv {
   int B, Hin, Win, Cin;
   int Hg, Wg, O, Hy, Wy;
+  int ldy;          // channel stride of y / resid rows (>= O: the launch may write a channel range of a wider tensor)
   int in_stride, ioff_h, ioff_w;
   int out_stride, ooff_h, ooff_w;
   int ntaps, wtaps;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
           const int gw = w0 + (nf & 1) * 16 + lr;
           const bool live = gh < p.Hg && gw < p.Wg;
           const int yh = gh * p.out_stride + p.cls_ooh[c], yw = gw * p.out_stride + p.cls_oow[c];
-          T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.O;
+          T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.ldy;
           if (fast) {
             float f[MF][4];
 #pragma unroll
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(T* __restrict__ y, con
     const int gw = w0 + nf * 16 + lr;
     if (gw >= p.Wg) continue;
     const int yw = gw * p.out_stride + p.ooff_w;
-    T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.O;
+    T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.ldy;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       const int o = o0 + mf * 16 + lc * 4;
@@ -539,6 +540,13 @@ int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, hipStre
 
 }  // namespace
 
+extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg,
+                                 int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w,
+                                 int out_stride, int ncls, const int* cls_host, int ntaps, int wtaps,
+                                 const int* taps_host, int nextra, const int* extras_host, int hzero, int ring,
+                                 int accumulate, const float* bias, const void* resid, int act, float alpha,
+                                 float scale, int dtype, void* stream);
+
 // y[b, gh*out_stride+ooff_h(c), gw*out_stride+ooff_w(c), o] (=|+=) act( sum_{t in class c} sum_ch
 //     x[b, H(gh*in_stride+ioff_h+dy_t), W(gw*in_stride+ioff_w+dx_t), ch] * w[o, widx_t, ch] + resid + bias[o] )
 // for gh < Hg, gw < Wg and every output class c.  taps_host: HOST pointer to ntaps quadruples
@@ -554,7 +562,22 @@ extern "C" int dgv2_conv_taps_ex(void* y, const void* x, const void* w, int B, i
                                  const int* taps_host, int nextra, const int* extras_host, int hzero, int ring,
                                  int accumulate, const float* bias, const void* resid, int act, float alpha,
                                  float scale, int dtype, void* stream) {
-  if (!y || !x || !w || !taps_host || !cls_host || ntaps < 1 || ntaps > 9 || wtaps < 1) return DGV2_EINVAL;
+  return dgv2_conv_taps_ld(y, O, x, w, B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy, in_stride, ioff_h, ioff_w, out_stride, ncls,
+                           cls_host, ntaps, wtaps, taps_host, nextra, extras_host, hzero, ring, accumulate, bias, resid, act,
+                           alpha, scale, dtype, stream);
+}
+
+// dgv2_conv_taps_ex writing the O output channels into rows of ldy >= O channels (y / resid point at the first of them):
+// a launch may then produce a channel RANGE of a wider tensor -- the 528-channel data gradient of the discriminator's
+// epilogue conv runs as 512 + 16 channels instead of nine 64-channel slabs of which the last is three quarters empty.
+extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg,
+                                 int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w,
+                                 int out_stride, int ncls, const int* cls_host, int ntaps, int wtaps,
+                                 const int* taps_host, int nextra, const int* extras_host, int hzero, int ring,
+                                 int accumulate, const float* bias, const void* resid, int act, float alpha,
+                                 float scale, int dtype, void* stream) {
+  if (!y || !x || !w || !taps_host || !cls_host || ntaps < 1 || ntaps > 9 || wtaps < 1 || ldy < O) return DGV2_EINVAL;
+  if (ldy != O && (ldy % (dtype == DGV2_BF16 ? 8 : 4))) return DGV2_EINVAL;   // 16-byte stores stay aligned
   if (ncls != 1 && ncls != 4) return DGV2_EINVAL;
   if (nextra < 0 || nextra > 6 || (nextra > 0 && !extras_host)) return DGV2_EINVAL;
   if (B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Hg <= 0 || Wg <= 0 || O <= 0 || in_stride < 1 || out_stride < 1)
@@ -563,7 +586,7 @@ extern "C" int dgv2_conv_taps_ex(void* y, const void* x, const void* w, int B, i
   const int kstep = dtype == DGV2_BF16 ? 32 : 16;
   if (Cin % kstep || !aligned16(x) || !aligned16(w)) return DGV2_EINVAL;
   DConv p;
-  p.B = B; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hg = Hg; p.Wg = Wg; p.O = O; p.Hy = Hy; p.Wy = Wy;
+  p.B = B; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hg = Hg; p.Wg = Wg; p.O = O; p.Hy = Hy; p.Wy = Wy; p.ldy = ldy;
   p.in_stride = in_stride; p.ioff_h = ioff_h; p.ioff_w = ioff_w;
   p.out_stride = out_stride; p.ooff_h = cls_host[0]; p.ooff_w = cls_host[1];
   p.ntaps = ntaps; p.wtaps = wtaps;
@@ -612,7 +635,7 @@ extern "C" int dgv2_conv_taps_ex(void* y, const void* x, const void* w, int B, i
   p.bias = bias; p.resid = resid; p.ybase = y; p.act = act; p.alpha = alpha; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
-  if (dtype == DGV2_BF16 && ncls == 1 && in_stride == 1 && out_stride == 1 && ring && !accumulate && Hin == Hg &&
+  if (dtype == DGV2_BF16 && ldy == O && ncls == 1 && in_stride == 1 && out_stride == 1 && ring && !accumulate && Hin == Hg &&
       Win == Wg && Hy == Hg && Wy == Wg && ioff_h == 0 && ioff_w == 0 && cls_host[0] == 0 && cls_host[1] == 0 &&
       aligned16(y) && (!resid || aligned16(resid))) {
     // full-resolution 32 -> 32 channel layers: the strip-streaming kernel (conv_strip.hip)

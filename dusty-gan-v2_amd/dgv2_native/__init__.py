@@ -77,6 +77,8 @@ SIGNATURES = {
                                                                                _c_ptr],
     "dgv2_conv_taps_ex": [_c_ptr] * 3 + [_c_int] * 14 + [_c_ptr, _c_int, _c_int, _c_ptr, _c_int, _c_ptr] + [_c_int] * 3
     + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
+    "dgv2_conv_taps_ld": [_c_ptr, _c_int, _c_ptr, _c_ptr] + [_c_int] * 14 + [_c_ptr, _c_int, _c_int, _c_ptr, _c_int, _c_ptr] + [_c_int] * 3
+    + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_conv_wgrad_direct": [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr],
     "dgv2_bmm_tn_stream_scratch": [_c_ptr] + [_c_int] * 6,
     "dgv2_bmm_tn_stream": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 6 + [_c_ptr],

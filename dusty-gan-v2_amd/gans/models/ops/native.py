@@ -661,12 +661,22 @@ def _conv_taps(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, ooff, taps, hzero,
 _FUSED_DGRAD = os.environ.get("DGV2_NO_FUSED_DGRAD") is None   # A/B switch for benchmarking
 
 
-def _conv_taps_ex(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, classes, taps4, extras, hzero, resid=None):
+def _conv_taps_ex(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, classes, taps4, extras, hzero, resid=None, ch0=None):
     """dgv2_conv_taps_ex: output classes [(ooff_h, ooff_w)], taps [(dy, dx, widx, cls)] sorted by class, border
-    extras [(dy, dx, widx, cls, row)].  Returns False when the engine asks for the per-class fallback."""
+    extras [(dy, dx, widx, cls, row)].  Returns False when the engine asks for the per-class fallback.
+    ch0: write the O = w3.shape[0] output channels at channel offset ch0 of the wider tensor y (dgv2_conv_taps_ld)."""
     B, Hin, Win, Cin = x.shape
     O, wtaps, _ = w3.shape
-    _, Hy, Wy, _ = y.shape
+    _, Hy, Wy, ldy = y.shape
+    if ch0 is not None:
+        carr = (_ct.c_int * (2 * len(classes)))(*[v for c in classes for v in c])
+        tarr = (_ct.c_int * (4 * len(taps4)))(*[v for t in taps4 for v in t])
+        earr = (_ct.c_int * max(5 * len(extras), 1))(*[v for e in extras for v in e])
+        es = y.element_size()
+        rp = None if resid is None else resid.data_ptr() + ch0 * es
+        return N.try_call("dgv2_conv_taps_ld", y.data_ptr() + ch0 * es, ldy, N.ptr(x), N.ptr(w3), B, Hin, Win, Cin, Hg, Wg,
+                          O, Hy, Wy, in_stride, ioff[0], ioff[1], out_stride, len(classes), carr, len(taps4), wtaps,
+                          tarr, len(extras), earr, int(hzero), 1, 0, None, rp, 0, 0.2, 1.0, _dt(x), N.stream())
     carr = (_ct.c_int * (2 * len(classes)))(*[v for c in classes for v in c])
     tarr = (_ct.c_int * (4 * len(taps4)))(*[v for t in taps4 for v in t])
     earr = (_ct.c_int * max(5 * len(extras), 1))(*[v for e in extras for v in e])
@@ -722,6 +732,17 @@ def _conv_dgrad_direct(gy, wt3, g, xshape, resid=None):
         taps = [(1 - ky, 1 - kx, ky * 3 + kx) for ky in range(3) for kx in range(3)]
         # one launch: the replicate rows ride along as border extras of output rows 0 and H-1
         extras = [(0, 1 - kx, kx, 0, 0) for kx in range(3)] + [(0, 1 - kx, 6 + kx, 0, H - 1) for kx in range(3)]
+        tail = C % 64
+        if _FUSED_DGRAD and C > 128 and tail in (16, 32) and B * H * W <= 32768:
+            # a channel count just past a multiple of the 64-channel slab (the epilogue conv's 513 inputs padded to 528 /
+            # 544) costs a whole extra round of blocks for a slab that is three quarters empty: run the full slabs and
+            # the tail as two launches into channel ranges of gx
+            main = C - tail
+            t4 = [t + (0,) for t in taps]
+            if (_conv_taps_ex(gx, gy, wt3[:main], H, W, 1, (0, 0), 1, [(0, 0)], t4, extras, True, resid=resid, ch0=0)
+                    and _conv_taps_ex(gx, gy, wt3[main:], H, W, 1, (0, 0), 1, [(0, 0)], t4, extras, True, resid=resid,
+                                      ch0=main)):
+                return gx
         if _FUSED_DGRAD and _conv_taps_ex(gx, gy, wt3, H, W, 1, (0, 0), 1, [(0, 0)], [t + (0,) for t in taps], extras,
                                           True, resid=resid):
             return gx

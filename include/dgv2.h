@@ -423,6 +423,13 @@ int dgv2_conv_taps_ex(void* y, const void* x, const void* w, int B, int Hin, int
                       const int* taps_host, int nextra, const int* extras_host, int hzero, int ring,
                       int accumulate, const float* bias, const void* resid, int act, float alpha,
                       float scale, int dtype, void* stream);
+/* dgv2_conv_taps_ex whose O output channels are written into rows of ldy >= O channels (y / resid point at the first
+ * of them), so that one launch can produce a channel range of a wider tensor. */
+int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg,
+                      int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w, int out_stride, int ncls,
+                      const int* cls_host, int ntaps, int wtaps, const int* taps_host, int nextra,
+                      const int* extras_host, int hzero, int ring, int accumulate, const float* bias,
+                      const void* resid, int act, float alpha, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * discriminator stem in one pass: BlurVH -> 1x1 conv (2 -> O) -> bias + leaky ReLU, and its backward.

@@ -30,3 +30,20 @@ ta = bench._time_launches(lambda: torch.mm(xl, wl.t()), 10)
 tb = bench._time_launches(lambda: torch.mm(gl, wl), 10)
 tc = bench._time_launches(lambda: torch.mm(gl.t(), xl), 10)
 print(f"Linear fp32 torch: fwd {ta*1e6:7.1f} us ({fl/ta/1e12:5.0f} TF/s) dgrad {tb*1e6:7.1f} ({fl/tb/1e12:5.0f}) wgrad {tc*1e6:7.1f} ({fl/tc/1e12:5.0f})")
+# ---- where the fp32 data gradient of the epilogue conv spends its time
+dt = torch.float32
+g = native.ConvGeom(3, 3, 1, 1, True)
+H, W, C, O = 4, 32, 528, 512
+for Bx in (64, 128):
+    gy = torch.randn(Bx, H, W, O, device="cuda", dtype=dt)
+    wt3 = torch.randn(C, 9, O, device="cuda", dtype=dt)
+    gx = torch.empty(Bx, H, W, C, device="cuda", dtype=dt)
+    taps = [(1 - ky, 1 - kx, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+    fl = 2.0 * Bx * H * W * C * O * 9
+    t_full = bench._time_launches(lambda: native._conv_dgrad_direct(gy, wt3, g, (Bx, H, W, C)), 10)
+    t_plain = bench._time_launches(lambda: native._conv_taps(gx, gy, wt3, H, W, 1, (0, 0), 1, (0, 0), taps, True), 10)
+    wt512 = torch.randn(512, 9, O, device="cuda", dtype=dt)
+    gx512 = torch.empty(Bx, H, W, 512, device="cuda", dtype=dt)
+    t_512 = bench._time_launches(lambda: native._conv_taps(gx512, gy, wt512, H, W, 1, (0, 0), 1, (0, 0), taps, True), 10)
+    t_fwdlike = bench._time_launches(lambda: native._conv_taps(gx512, gy, wt512, H, W, 1, (0, 0), 1, (0, 0), taps, False), 10)
+    print(f"B={Bx}: dgrad with border extras {t_full*1e6:7.1f} us ({fl/t_full/1e12:4.0f} TF/s) | same taps, no extras {t_plain*1e6:7.1f} | 512 outputs {t_512*1e6:7.1f} | 512 outputs, clamp rows {t_fwdlike*1e6:7.1f}")

@@ -1004,3 +1004,24 @@ def test_fused_nsgan_loss_matches_ganloss(nat):
         if n_fake:
             assert abs(float(stats[2]) - float(yr[n_real:].mean())) < 1e-5
         assert float(stats[3]) == float(yr[:n_real].sign().sum())
+
+
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 528), (torch.bfloat16, 544), (torch.float32, 144)])
+def test_conv_data_gradient_in_channel_ranges(nat, dtype, C):
+    """The stride-1 3x3 data gradient of a conv whose input channel count sits just past a multiple of the 64-channel
+    slab (the discriminator epilogue's 513 inputs padded to 528 / 544) runs as full slabs + tail through
+    dgv2_conv_taps_ld: against the float64 autograd of F.conv2d on the ring-padded input, with and without residual."""
+    g = torch.Generator().manual_seed(C)
+    B, H, W, O = 3, 4, 32, 64
+    geom = nat.ConvGeom(3, 3, 1, 1, True)
+    x = torch.randint(-2, 3, (B, C, H, W), generator=g).double().requires_grad_(True)
+    w = torch.randint(-2, 3, (O, C, 3, 3), generator=g).double()
+    gy = torch.randint(-2, 3, (B, O, H, W), generator=g).double()
+    res = torch.randint(-3, 4, (B, C, H, W), generator=g).double()
+    y = _conv_oracle(x, w, 1, 1, True)
+    (want,) = torch.autograd.grad(y, x, gy)
+    wd = w.float().permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    got = nat._conv_dgrad_raw(cl(gy.float()).to(dtype), wd, geom, (B, H, W, C))
+    got_r = nat._conv_dgrad_raw(cl(gy.float()).to(dtype), wd, geom, (B, H, W, C), resid=cl(res.float()).to(dtype))
+    assert torch.equal(nchw(got).double(), want)
+    assert torch.equal(nchw(got_r).double(), want + res)
