@@ -49,6 +49,7 @@ SIGNATURES = {
     "dgv2_modconv_pe_fwd": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_modconv_pe_fwd_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                                _c_ptr],
+    "dgv2_kitti_project": [_c_ptr] * 4 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_nsgan_loss": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr],
     "dgv2_modconv_up_fwd": [_c_ptr] * 4 + [_c_int] * 9 + [_c_ptr] * 6 + [_c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                             _c_ptr],

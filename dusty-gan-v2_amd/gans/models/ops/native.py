@@ -1878,6 +1878,21 @@ class _ModGemmPrepared(Function):
 
 
 # ---------------------------------------------------------------------------------------
+# KITTI scan -> range image (dgv2_kitti_project; reference: gans/datasets/kitti.py:264-279,317-370)
+# ---------------------------------------------------------------------------------------
+def kitti_project(points, rows, H, W, Wout, min_depth, max_depth, apply_mask=True):
+    """points fp32 [n,4] CUDA; rows int32 [n] (scan-unfolding ring index per point) or None (pitch-angle rows).
+    -> fp32 [6, H, Wout]: x, y, z, reflectance, depth, mask of the nearest point of pixel (h, w * W / Wout)."""
+    n = points.shape[0]
+    out = torch.empty((6, H, Wout), device=points.device, dtype=torch.float32)
+    key = torch.empty(H * W, device=points.device, dtype=torch.int64)
+    N.check(points, rows)
+    N.call("dgv2_kitti_project", N.ptr(out), N.ptr(key), N.ptr(points), N.ptr(rows), n, H, W, Wout, float(min_depth),
+           float(max_depth), int(apply_mask), N.stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------
 # non-saturating GAN objective + logged statistics in one launch (dgv2_nsgan_loss)
 # ---------------------------------------------------------------------------------------
 class _NsganLoss(Function):

@@ -91,12 +91,30 @@ class Trainer:
         self.auxin = {"angle": self.coord.angle}  # [1,2,H,W]; kernels broadcast it over the batch
 
         # data
-        if cfg.dataset.name != "synthetic":
-            raise NotImplementedError(f"dataset.name={cfg.dataset.name}: the KITTI loader is outside this tier's scope "
-                                      "(SURVEY.md section 8f); set dataset.name=synthetic for in-HBM synthetic scans")
-        self.iter_train_loader = iter(SyntheticRangeImages(
-            self.resolution, cfg.dataset.min_depth, cfg.dataset.max_depth, self.B, self.device,
-            seed=cfg.random_seed + self.rank))
+        if cfg.dataset.name == "synthetic":
+            self.iter_train_loader = iter(SyntheticRangeImages(
+                self.resolution, cfg.dataset.min_depth, cfg.dataset.max_depth, self.B, self.device,
+                seed=cfg.random_seed + self.rank))
+        elif cfg.dataset.name == "kitti_raw":
+            # reference: trainer.py:98-119 -- KITTI Raw scans, rank-sharded infinite sampler; the projection runs on
+            # the GPU in this process (gans/datasets/kitti.py), hence no worker processes
+            from gans.datasets.kitti import KITTIRaw
+            from gans.utils import InfiniteSampler
+            if not os.path.isdir(cfg.dataset.root):
+                raise FileNotFoundError(f"dataset.root={cfg.dataset.root} does not exist (dataset.name=kitti_raw); "
+                                        "set dataset.name=synthetic for in-HBM synthetic scans")
+            self.train_dataset = KITTIRaw(root=cfg.dataset.root, split="train", shape=self.resolution,
+                                          min_depth=cfg.dataset.min_depth, max_depth=cfg.dataset.max_depth,
+                                          device=self.device)
+            self.train_dataset.datalist = [f for f in self.train_dataset.datalist if os.path.exists(f)] \
+                if cfg.dataset.get("skip_missing", False) else self.train_dataset.datalist
+            self.train_loader = torch.utils.data.DataLoader(
+                self.train_dataset, batch_size=self.B, num_workers=0, shuffle=False, drop_last=True,
+                sampler=InfiniteSampler(self.train_dataset, rank=self.rank, num_replicas=self.num_gpus,
+                                        seed=cfg.random_seed + self.rank))
+            self.iter_train_loader = iter(self.train_loader)
+        else:
+            raise NotImplementedError(f"dataset.name={cfg.dataset.name}: only kitti_raw and synthetic are built")
 
         # losses and lazy-regularisation corrected Adam (reference: trainer.py:121-171)
         self.adversarial_loss = GANLoss(cfg.training.gan_objective).to(self.device)

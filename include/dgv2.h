@@ -524,6 +524,19 @@ int dgv2_surface_normal(float* out, const float* points, int B, int H, int W, in
  * ------------------------------------------------------------------------- */
 int dgv2_nsgan_loss(float* stats, float* gy, const float* y, int n_real, int n_fake, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * KITTI scan -> range image (the front end of the real-data path)
+ * replaces: KITTIRaw.load_pts_as_img (scan-unfolding spherical projection, numba scatter after an argsort by depth)
+ *   and the nearest resize + mask of __getitem__, gans/datasets/kitti.py:264-279,317-370
+ * pts fp32 [n,4] (x, y, z, reflectance); row int32 [n] = ring index per point from the scan order (the host derives
+ * it from the quadrant sequence, :328-346; -1 means ring H-1 as in the reference) or NULL for rows from the pitch angle
+ * (:347-351); key = uint64 scratch [H*W]; out fp32 [6,H,Wout] = x, y, z, reflectance, depth, mask of the NEAREST point
+ * of pixel (h, w * W/Wout), multiplied by the mask (min_depth <= depth <= max_depth) when apply_mask (the item of
+ * __getitem__; 0 = the raw projection of load_pts_as_img).  W % Wout == 0.
+ * ------------------------------------------------------------------------- */
+int dgv2_kitti_project(float* out, unsigned long long* key, const float* pts, const int* row, int n, int H, int W,
+                       int Wout, float min_depth, float max_depth, int apply_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

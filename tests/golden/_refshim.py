@@ -58,6 +58,8 @@ def install():
             if "." in name:  # `import a.b.c as x` resolves c as an attribute of a.b
                 parent, _, leaf = name.rpartition(".")
                 object.__setattr__(sys.modules[parent], leaf, m)
+    # `@numba.jit` decorates without parentheses (gans/datasets/kitti.py:216): the function must come back unchanged
+    sys.modules["numba"].jit = lambda f=None, *a, **k: f if callable(f) else (lambda g: g)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
 

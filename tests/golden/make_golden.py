@@ -732,8 +732,28 @@ def golden_trainer():
     save("trainer_small.npz", out)
 
 
+
+# ----------------------------------------------------------------------------
+def golden_kitti():
+    """KITTIRaw.load_pts_as_img (gans/datasets/kitti.py:317-370) run by the reference on a synthetic scan written in
+    KITTI's .bin format: scan unfolding (with two rings more than H, which exercises the index -1 quirk) and the
+    pitch-angle rows; 16 x 256 grid to keep the fixture small."""
+    import tempfile
+
+    from gans.datasets.kitti import KITTIRaw
+    pts = recipe.synthetic_scan(3)
+    path = os.path.join(tempfile.mkdtemp(prefix="dgv2_golden_kitti_"), "0000000000.bin")
+    pts.tofile(path)
+    ds = KITTIRaw.__new__(KITTIRaw)
+    ds.min_depth, ds.max_depth = 1.45, 80.0
+    out = {"n_points": np.int64(len(pts))}
+    out["proj_unfold"] = ds.load_pts_as_img(path, True, H=16, W=256)
+    out["proj_pitch"] = ds.load_pts_as_img(path, False, H=16, W=256)
+    save("kitti.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer"]
+    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti"]
     if "ops" in which:
         golden_ops()
     if "coords" in which:
@@ -746,3 +766,5 @@ if __name__ == "__main__":
         golden_full()
     if "trainer" in which:
         golden_trainer()
+    if "kitti" in which:
+        golden_kitti()

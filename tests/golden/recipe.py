@@ -42,3 +42,25 @@ def raw_batches(seed, n, H, W, min_depth=1.45, max_depth=80.0):
     depth = torch.rand(n, 1, H, W, generator=g) * (1.1 * max_depth)
     mask = (torch.rand(n, 1, H, W, generator=g) < 0.85).float()
     return depth, mask
+
+
+def synthetic_scan(seed, rings=18, steps=220, drop=0.12):
+    """A spinning-lidar scan in KITTI's point order (ring by ring, azimuth increasing counter-clockwise from the +x
+    axis, so that every ring crosses from the 4th into the 1st quadrant exactly once at its start): [n,4] float32
+    (x, y, z, reflectance).  Depths come from a smooth random scene + noise and include returns below / beyond any
+    sensible [min_depth, max_depth]; `drop` of the returns are missing."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    pts = []
+    scene = 6.0 + 30.0 * (0.5 + 0.5 * np.sin(np.linspace(0, 4 * np.pi, steps) + rng.rand() * 6)) ** 2
+    for r in range(rings):
+        elev = np.deg2rad(2.0 - 26.8 * r / max(rings - 1, 1))
+        az = (np.arange(steps) + rng.rand(steps) * 0.3) / steps * 2 * np.pi * 0.999 + 1e-3
+        keep = rng.rand(steps) > drop
+        d = scene * (1 + 0.05 * rng.randn(steps)) / max(np.cos(elev), 0.2)
+        d[rng.rand(steps) < 0.03] = 0.5 + rng.rand() * 0.3          # too close
+        d[rng.rand(steps) < 0.03] = 100.0 + rng.rand() * 40.0       # too far
+        a, dd = az[keep], d[keep]
+        x, y, z = dd * np.cos(elev) * np.cos(a), dd * np.cos(elev) * np.sin(a), dd * np.sin(elev)
+        pts.append(np.stack([x, y, z, rng.rand(keep.sum())], axis=1))
+    return np.concatenate(pts).astype(np.float32)

@@ -373,3 +373,28 @@ def test_fp64_oracle_agrees_with_reference_and_shows_its_rounding_floor(g_full, 
     assert vals[len(vals) // 2] < 1e-3 and vals[int(len(vals) * 0.9)] < 3e-3
     worst = max(dev, key=dev.get)
     assert worst.endswith("head.heads.image.bias") and 1e-3 < dev[worst] < 2e-2, (worst, dev[worst])
+
+
+# ---------------------------------------------------------------------------- KITTI front end
+def test_kitti_projection_matches_reference():
+    """oracle.kitti.project against the reference's KITTIRaw.load_pts_as_img (tests/golden/kitti.npz: synthetic scan in
+    KITTI's point order, scan unfolding incl. the index -1 quirk of a scan with more rings than rows, and the
+    pitch-angle rows)."""
+    import os
+
+    import recipe
+    from conftest import GOLDEN
+    from oracle import kitti
+    d = np.load(os.path.join(GOLDEN, "kitti.npz"))
+    pts = recipe.synthetic_scan(3)
+    assert len(pts) == int(d["n_points"])
+    for unfold, key in ((True, "proj_unfold"), (False, "proj_pitch")):
+        got = kitti.project(pts, 16, 256, 1.45, 80.0, scan_unfolding=unfold)
+        want = d[key]
+        assert got.shape == want.shape == (16, 256, 6)
+        np.testing.assert_array_equal(got, want, err_msg=key)
+    rows = kitti.ring_rows(pts[:, 0], pts[:, 1], 16)
+    assert rows.min() == -1 and rows.max() == 15 and (rows == 0).sum() > 300     # 18 rings onto 16 rows
+    item = kitti.to_item(d["proj_unfold"], (16, 64))
+    assert item["depth"].shape == (1, 16, 64) and set(np.unique(item["mask"])) <= {0.0, 1.0}
+    assert np.all(item["depth"][item["mask"] == 0] == 0)
