@@ -537,6 +537,52 @@ int dgv2_nsgan_loss(float* stats, float* gy, const float* y, int n_real, int n_f
 int dgv2_kitti_project(float* out, unsigned long long* key, const float* pts, const int* row, int n, int H, int W,
                        int Wout, float min_depth, float max_depth, int apply_mask, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * point-cloud natives of the evaluation path
+ *
+ * furthest point sampling + gather
+ * replaces: fps.furthest_point_sampling / gather_points / gather_points_grad
+ *   gans/sampling/fps/furthest_point_sampling.cpp:26-112, furthest_point_sampling.cu:37-263
+ * xyz fp32 [B, n, 3]; idxs int32 [B, m]: idxs[:, 0] = 0, then m - 1 rounds of "the point with the largest distance to
+ * the selected set"; points with |p|^2 <= 1e-3 never take part; equal distances resolve in the order of the
+ * reference's 2^floor(log2 n) (<= 512)-thread block reduction, so the indices are the reference's.  temp: fp32
+ * scratch of dgv2_fps_scratch(B, n) floats (0 for n <= 32768, where the running distances live on chip; may be NULL then).
+ * gather: points fp32 [B, C, n], idx int32 [B, m] -> out [B, C, m]; grad: grad_out [B, C, m] -> grad_points [B, C, n]
+ * (zero-filled here, atomic adds for repeated indices).
+ * ------------------------------------------------------------------------- */
+int dgv2_fps_scratch(int64_t* floats, int B, int n);
+int dgv2_fps(int* idxs, float* temp, const float* xyz, int B, int n, int m, void* stream);
+int dgv2_gather_points(float* out, const float* points, const int* idx, int B, int C, int n, int m, void* stream);
+int dgv2_gather_points_grad(float* grad_points, const float* grad_out, const int* idx, int B, int C, int n, int m,
+                            void* stream);
+
+/* chamfer distance: nearest neighbour in both directions
+ * replaces: cd.forward_cuda / cd.backward_cuda (and the CPU twins cd.forward / cd.backward)
+ *   gans/metrics/distance/cd/chamfer_distance.cpp:18-144, chamfer_distance.cu:6-190
+ * xyz1 fp32 [B, n, 3], xyz2 fp32 [B, m, 3]; dist1 [B, n] = min_k |xyz1_j - xyz2_k|^2 with idx1 the FIRST minimiser
+ * (strict <), dist2 / idx2 [B, m] the other direction; the squared distance is ((dx*dx + dy*dy) + dz*dz) in fp32
+ * without contraction, i.e. bit-identical to the reference's CPU nnsearch.  bwd: gxyz1 / gxyz2 (zero-filled here)
+ * receive 2 g (a - b) at the point and -2 g (a - b) at its neighbour for both directions (float atomics).
+ * ------------------------------------------------------------------------- */
+int dgv2_chamfer_fwd(float* dist1, int* idx1, float* dist2, int* idx2, const float* xyz1, const float* xyz2, int B,
+                     int n, int m, void* stream);
+int dgv2_chamfer_bwd(float* gxyz1, float* gxyz2, const float* xyz1, const float* xyz2, const float* gdist1,
+                     const float* gdist2, const int* idx1, const int* idx2, int B, int n, int m, void* stream);
+
+/* earth mover's distance by approximate matching
+ * replaces: emd.approxmatch_forward / matchcost_forward / matchcost_backward
+ *   gans/metrics/distance/emd/earth_mover_distance.cpp:26-95, earth_mover_distance.cu:3-364
+ * xyz1 fp32 [B, n, 3], xyz2 fp32 [B, m, 3]; match fp32 [B, m, n] (written, not accumulated); temp fp32
+ * [B, 2 (n + m)] scratch; cost fp32 [B] = sum match[l, k] |xyz1_k - xyz2_l|; grad1 [B, n, 3], grad2 [B, m, 3] =
+ * d cost / d xyz for a FIXED match (the reference does not differentiate the matching).
+ * ------------------------------------------------------------------------- */
+int dgv2_emd_approxmatch(float* match, float* temp, const float* xyz1, const float* xyz2, int B, int n, int m,
+                         void* stream);
+int dgv2_emd_matchcost(float* cost, const float* match, const float* xyz1, const float* xyz2, int B, int n, int m,
+                       void* stream);
+int dgv2_emd_matchcost_grad(float* grad1, float* grad2, const float* match, const float* xyz1, const float* xyz2, int B,
+                            int n, int m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
