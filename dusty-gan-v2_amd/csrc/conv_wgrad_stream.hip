@@ -34,13 +34,18 @@ struct WSCfg {
   static constexpr int KS = TnFrag<T>::KS;
   static constexpr int CE = 16 / sizeof(T);
   static constexpr int TO = 16 * MFN, TC = 16 * NFN;
+  // LDS row lengths: a transposed fp32 fragment read touches 4 pixel rows x 16 consecutive channels per instruction;
+  // rows of 32 / 64 floats put those 4 rows on the same banks (2- / 4-way conflicts), +16 floats spreads them over
+  // all 64 banks
+  static constexpr int PAD = sizeof(T) == 4 ? 16 : 0;
+  static constexpr int RO = TO + PAD, RC = TC + PAD;
   static constexpr int WR = S == 1 ? 4 : 2;
   static constexpr int KK = K3 ? 3 : 1;
   static constexpr int IN_ROWS = (WR - 1) * S + KK, IN_COLS = 31 * S + KK;
   static constexpr int GV = TO / CE, XV = TC / CE;
   static constexpr int NG = (WR * 32 * GV + 255) / 256, NX = (IN_ROWS * IN_COLS * XV + 255) / 256;
   static constexpr int UNITS = (K3 ? 9 : 1) * NFN, UPW = (UNITS + 3) / 4;
-  static constexpr size_t LDS = sizeof(T) * ((size_t)WR * 32 * TO + (size_t)IN_ROWS * IN_COLS * TC);
+  static constexpr size_t LDS = sizeof(T) * ((size_t)WR * 32 * RO + (size_t)IN_ROWS * IN_COLS * RC);
 };
 
 template <typename T, int S, int MFN, int NFN, bool K3>
@@ -49,10 +54,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_kernel(float* __rest
   using Cf = WSCfg<T, S, MFN, NFN, K3>;
   constexpr int KS = Cf::KS, CE = Cf::CE, TO = Cf::TO, TC = Cf::TC, WR = Cf::WR;
   constexpr int GV = Cf::GV, XV = Cf::XV, NG = Cf::NG, NX = Cf::NX, UPW = Cf::UPW, UNITS = Cf::UNITS;
-  constexpr int IN_COLS = Cf::IN_COLS, KK = Cf::KK;
+  constexpr int IN_COLS = Cf::IN_COLS, KK = Cf::KK, RO = Cf::RO, RC = Cf::RC;
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   T* lds_gy = reinterpret_cast<T*>(smem);
-  T* lds_x = lds_gy + WR * 32 * TO;
+  T* lds_x = lds_gy + WR * 32 * RO;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_kernel(float* __rest
     u = u < UNITS ? u : 0;
     const int tap = u / NFN;
     const int ky = tap / KK, kx = tap - ky * KK;
-    uoff[ui] = (ky * IN_COLS + kx) * TC;
+    uoff[ui] = (ky * IN_COLS + kx) * RC;
     unf[ui] = (u % NFN) * 16;
   }
 
@@ -140,12 +145,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_kernel(float* __rest
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int id = tid + j * 256;
-      if (id < WR * 32 * GV) reinterpret_cast<uint4*>(lds_gy)[id] = rg[j];
+      if (id < WR * 32 * GV) *reinterpret_cast<uint4*>(lds_gy + (id / GV) * RO + (id % GV) * CE) = rg[j];
     }
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const int id = tid + j * 256;
-      if (id < n_x) reinterpret_cast<uint4*>(lds_x)[id] = rx[j];
+      if (id < n_x) *reinterpret_cast<uint4*>(lds_x + (id / XV) * RC + (id % XV) * CE) = rx[j];
     }
     if (t + 1 < t_end) issue();
     __syncthreads();
@@ -154,15 +159,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_kernel(float* __rest
 #pragma unroll
       for (int kb = 0; kb < 32 / KS; ++kb) {
         uint4 a[MFN];
-        const T* arow = lds_gy + (r * 32 + kb * KS) * TO;
-        const T* xrow = lds_x + (r * S * IN_COLS + kb * KS * S) * TC;
-        uint4 bnext = TnFrag<T>::template read<S * TC>(xrow + uoff[0], unf[0], lane);
+        const T* arow = lds_gy + (r * 32 + kb * KS) * RO;
+        const T* xrow = lds_x + (r * S * IN_COLS + kb * KS * S) * RC;
+        uint4 bnext = TnFrag<T>::template read<S * RC>(xrow + uoff[0], unf[0], lane);
 #pragma unroll
-        for (int mf = 0; mf < MFN; ++mf) a[mf] = TnFrag<T>::template read<TO>(arow, mf * 16, lane);
+        for (int mf = 0; mf < MFN; ++mf) a[mf] = TnFrag<T>::template read<RO>(arow, mf * 16, lane);
 #pragma unroll
         for (int ui = 0; ui < UPW; ++ui) {
           const uint4 bb = bnext;
-          if (ui + 1 < UPW) bnext = TnFrag<T>::template read<S * TC>(xrow + uoff[ui + 1], unf[ui + 1], lane);
+          if (ui + 1 < UPW) bnext = TnFrag<T>::template read<S * RC>(xrow + uoff[ui + 1], unf[ui + 1], lane);
 #pragma unroll
           for (int mf = 0; mf < MFN; ++mf) Mfma16<T>::run(acc[ui][mf], a[mf], bb);
         }
@@ -443,8 +448,10 @@ bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, in
   WSGeom& g = p.g;
   g = WSGeom{B, H, W, C, O, (H + 2 * pad - k) / stride + 1, (W + 2 * pad - k) / stride + 1, k, stride, pad, ring};
   if (g.Ho <= 0 || g.Wo <= 0) return false;
-  // fp32 is the parity mode: small tiles keep its staging registers in budget
-  const bool big = dtype == DGV2_BF16;
+  // fp32: the 64 x 64 tile (144 accumulator + 84 staging registers per lane) for the wide 3x3 stride-1 layers -- the
+  // fp32 island of D's epilogue, 528 -> 512 at 4 x 32 -- and the small tile for everything else (parity mode)
+  const bool wide32 = dtype == DGV2_F32 && k == 3 && stride == 1 && C >= 128 && O >= 128;
+  const bool big = dtype == DGV2_BF16 || wide32;
   p.mfn = (big && O > 32) ? 4 : 2;
   p.nfn = (big && C > 32) ? 4 : 2;
   const int wr = stride == 1 ? 4 : 2;
@@ -461,7 +468,7 @@ bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, in
   g.x_shared = 0;
   static const int blocks_big = getenv("DGV2_WS_BLOCKS_BIG") ? atoi(getenv("DGV2_WS_BLOCKS_BIG")) : 256;
   static const int blocks_small = getenv("DGV2_WS_BLOCKS_SMALL") ? atoi(getenv("DGV2_WS_BLOCKS_SMALL")) : 512;
-  int nsplit = ((p.mfn == 4 && p.nfn == 4) ? blocks_big : blocks_small) / pairs;
+  int nsplit = (wide32 ? 2 * blocks_big : (p.mfn == 4 && p.nfn == 4) ? blocks_big : blocks_small) / pairs;
   nsplit = nsplit < 1 ? 1 : (nsplit > g.ntiles ? g.ntiles : nsplit);
   g.tiles_per_split = (g.ntiles + nsplit - 1) / nsplit;
   p.nsplit = (g.ntiles + g.tiles_per_split - 1) / g.tiles_per_split;
@@ -507,6 +514,8 @@ int ws_dispatch(float* part, const void* gy, const void* x, const WSPlan& p, hip
     if (p.mfn == 4 && p.nfn == 4) return ws_launch<T, S, 4, 4, K3>(part, gy, x, p, st);
     if (p.mfn == 4) return ws_launch<T, S, 4, 2, K3>(part, gy, x, p, st);
     if (p.nfn == 4) return ws_launch<T, S, 2, 4, K3>(part, gy, x, p, st);
+  } else if constexpr (S == 1 && K3) {
+    if (p.mfn == 4 && p.nfn == 4) return ws_launch<T, S, 4, 4, K3>(part, gy, x, p, st);
   }
   return ws_launch<T, S, 2, 2, K3>(part, gy, x, p, st);
 }
