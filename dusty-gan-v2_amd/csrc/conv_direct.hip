@@ -221,6 +221,23 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
   __syncthreads();
   const int aswz = lc ^ ((lr >> 2) & 3);
 
+  // Taps that read only the zero rows above / below the image for this wave's output row(s) (hzero: the data
+  // gradient of a replicate-padded conv) contribute nothing: skipped, wave-uniformly.  Together with the border
+  // extras -- which exist for exactly those rows -- a border row costs what an interior row costs; for the 4-row
+  // maps (one row per wave) that removes a third of the MFMA time of waves 0 and 3, i.e. of the block.
+  unsigned dead[RW];
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+    const int gin = (h0 + wave * RW + rr) * p.in_stride + p.ioff_h;
+    unsigned m = 0;
+    for (int t = 0; t < p.ntaps; ++t)
+      if (p.hzero && (unsigned)(gin + p.dy[t]) >= (unsigned)p.Hin) m |= 1u << t;
+    dead[rr] = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+  }
+  unsigned dead_all = dead[0];
+#pragma unroll
+  for (int rr = 1; rr < RW; ++rr) dead_all &= dead[rr];
+
   // ---- pipeline over (tile, chunk) stages ----
   tile_offsets(tw0);
   issue_in(0);
@@ -254,6 +271,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       for (int t = s_t0[c]; t < s_t0[c + 1]; ++t) {
+        if ((dead_all >> t) & 1u) continue;
         uint4 a[MF], bb[NF];
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) a[mf] = lds_w[(t * TO + mf * 16 + lr) * 4 + aswz];
@@ -264,9 +282,11 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
           bb[nf] = lds_in[pix * 4 + (lc ^ ((pix >> 2) & 3))];
         }
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
+        for (int nf = 0; nf < NF; ++nf) {
+          if (RW > 1 && ((dead[nf >> 1] >> t) & 1u)) continue;
 #pragma unroll
-          for (int nf = 0; nf < NF; ++nf) Mfma16<T>::run(acc[c][mf][nf], a[mf], bb[nf]);
+          for (int mf = 0; mf < MF; ++mf) Mfma16<T>::run(acc[c][mf][nf], a[mf], bb[nf]);
+        }
       }
     }
     // border extras: only the wave rows that ARE the named output row take part (wave-uniform tests)
