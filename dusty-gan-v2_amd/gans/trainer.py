@@ -27,7 +27,7 @@ from gans.datasets.synthetic import SyntheticRangeImages
 from gans.models.builder import build_discriminator, build_generator
 from gans.models.loss import GANLoss
 from gans.models.ops.common import filter2d
-from gans.utils import set_requires_grad
+from gans.utils import set_requires_grad, tanh_to_sigmoid
 
 
 @torch.no_grad()
@@ -92,6 +92,7 @@ class Trainer:
 
         # data
         if cfg.dataset.name == "synthetic":
+            self.train_dataset = None
             self.iter_train_loader = iter(SyntheticRangeImages(
                 self.resolution, cfg.dataset.min_depth, cfg.dataset.max_depth, self.B, self.device,
                 seed=cfg.random_seed + self.rank))
@@ -412,8 +413,58 @@ class Trainer:
         model.eval()
         return model(self.z_fixed, **self.auxin)
 
-    def validation(self):
-        raise NotImplementedError("FPD/KPD validation (PointNet features) is outside this round's scope")
+    @torch.no_grad()
+    def pointnet_features(self, depth, pointnet):
+        """Generator / dataset output in [-1, 1] -> PointNet features of the normalised point cloud
+        (reference: get_pointnet_features, trainer.py:505-510)."""
+        depth = tanh_to_sigmoid(depth).clamp(0, 1)
+        points = self.coord.convert(depth, "inv_depth_norm", "point_set")
+        points = points / self.coord.max_depth
+        return pointnet(points.transpose(1, 2))
+
+    @torch.no_grad()
+    def validation(self, num_fakes=10_000, pointnet=None, max_reals=None):
+        """Feature-based validation scores (reference: trainer.py:495-549): Frechet and squared-MMD distances between
+        PointNet features of `num_fakes` EMA-generator samples and of the training set (features cached on the host
+        after the first call).  The features are computed on this rank's GPU, the two distances on the host in float64
+        like the reference.  `pointnet`: the feature extractor (default: pretrained_pointnet(), which needs
+        cls_model_39.pth on disk); `max_reals` bounds the real-data pass (the synthetic dataset is endless: it
+        contributes num_fakes samples)."""
+        from gans.metrics.fpd_kpd import compute_frechet_distance, compute_squared_mmd
+        from gans.metrics.pointnet import pretrained_pointnet
+        N = int(num_fakes)
+        B = self.B
+        net = (pretrained_pointnet() if pointnet is None else pointnet).to(self.device)
+        self.G_ema.eval()
+
+        if getattr(self, "val_real_feats", None) is None:
+            feats = []
+            if self.train_dataset is not None:   # one pass over the files, in order, rank-local like the reference
+                n_real = len(self.train_dataset) if max_reals is None else min(len(self.train_dataset), int(max_reals))
+                for lo in range(0, n_real, B):
+                    items = [self.train_dataset[i] for i in range(lo, min(lo + B, n_real))]
+                    batch = {k: torch.stack([it[k] for it in items]) for k in ("depth", "mask")}
+                    feats.append(self.pointnet_features(self.fetch_reals(batch)["image"], net).cpu())
+            else:
+                n_real = N if max_reals is None else int(max_reals)
+                for lo in range(0, n_real, B):
+                    x = self.fetch_reals(next(self.iter_train_loader))["image"][:n_real - lo]
+                    feats.append(self.pointnet_features(x, net).cpu())
+            self.val_real_feats = torch.cat(feats, dim=0)
+
+        fake = []
+        for lo in range(0, N, B):
+            bs = min(B, N - lo)
+            out = self.G_ema(self.sample_z(bs), **self.auxin)
+            fake.append(self.pointnet_features(out["image"], net).cpu())
+        fake = torch.cat(fake, dim=0)
+
+        tag = f"{N // 1000}k"
+        f1, f2 = fake.double().numpy(), self.val_real_feats.double().numpy()
+        return {
+            f"pointcloud/frechet_distance_{tag}": compute_frechet_distance(feats1=f1, feats2=f2),
+            f"pointcloud/squared_mmd_{tag}": compute_squared_mmd(feats1=f1, feats2=f2),
+        }
 
     def save_checkpoint(self, save_path, step):
         """Same keys as the reference (trainer.py:551-567)."""

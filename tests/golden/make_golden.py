@@ -752,8 +752,28 @@ def golden_kitti():
     save("kitti.npz", out)
 
 
+def golden_validation():
+    """The validation metrics (gans/trainer.py:495-549): the reference's PointNet1 (gans/metrics/pointnet.py) with
+    weights by recipe on seeded clouds, and its compute_frechet_distance / compute_squared_mmd (gans/metrics/
+    fpd_kpd.py) on seeded feature sets (numpy's global RNG seeded, as compute_squared_mmd draws subsets from it)."""
+    from gans.metrics.fpd_kpd import compute_frechet_distance, compute_squared_mmd
+    from gans.metrics.pointnet import PointNet1
+    net = PointNet1(k=16)
+    recipe.fill_pointnet(net.state_dict())
+    net.eval().requires_grad_(False)
+    out = {"keys": np.array(list(net.state_dict().keys()))}
+    for tag, (B, n) in {"a": (3, 500), "b": (2, 2048)}.items():
+        pts = recipe.point_clouds(11 + n, B, n)
+        out[f"feats_{tag}"] = net(pts.transpose(1, 2))
+    f1, f2 = recipe.feature_sets(5, 300, 260, 48)
+    out["frechet"] = np.float64(compute_frechet_distance(f1, f2))
+    np.random.seed(0)
+    out["squared_mmd"] = np.float64(compute_squared_mmd(f1, f2, num_subsets=7, max_subset_size=100))
+    save("validation.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti"]
+    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation"]
     if "ops" in which:
         golden_ops()
     if "coords" in which:
@@ -768,3 +788,5 @@ if __name__ == "__main__":
         golden_trainer()
     if "kitti" in which:
         golden_kitti()
+    if "validation" in which:
+        golden_validation()

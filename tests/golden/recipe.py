@@ -64,3 +64,35 @@ def synthetic_scan(seed, rings=18, steps=220, drop=0.12):
         x, y, z = dd * np.cos(elev) * np.cos(a), dd * np.cos(elev) * np.sin(a), dd * np.sin(elev)
         pts.append(np.stack([x, y, z, rng.rand(keep.sum())], axis=1))
     return np.concatenate(pts).astype(np.float32)
+
+
+def fill_pointnet(sd, seed=77):
+    """PointNet1 state dict by recipe (the pretrained cls_model_39.pth cannot be fetched): weights ~ N(0, 1/fan_in),
+    biases and running means ~ 0.1 N(0,1), batch-norm scales and running variances ~ U(0.5, 1.5); counters untouched."""
+    for key in sorted(sd.keys()):
+        t = sd[key]
+        if not t.is_floating_point():
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ seed) & 0x7FFFFFFF)
+        leaf = key.rsplit(".", 2)[-2]
+        if key.endswith("running_var") or (leaf.startswith("bn") and key.endswith("weight")):
+            v = torch.rand(t.shape, generator=g) + 0.5
+        elif key.endswith("weight"):
+            v = torch.randn(t.shape, generator=g) / float(t[0].numel()) ** 0.5
+        else:
+            v = torch.randn(t.shape, generator=g) * 0.1
+        with torch.no_grad():
+            t.copy_(v)
+    return sd
+
+
+def point_clouds(seed, B, n, scale=0.3):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, n, 3, generator=g) * scale
+
+
+def feature_sets(seed, n1, n2, d):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(n1, d, generator=g, dtype=torch.float64)
+    b = torch.randn(n2, d, generator=g, dtype=torch.float64) * 1.2 + 0.3
+    return a.numpy(), b.numpy()
