@@ -215,12 +215,12 @@ __global__ __launch_bounds__(256) void gather_points_grad_kernel(float* __restri
 template <int Q>
 __global__ __launch_bounds__(256) void chamfer_nn_kernel(float* __restrict__ dist, int* __restrict__ idx,
                                                          const float* __restrict__ a, const float* __restrict__ b,
-                                                         int n, int m) {
+                                                         int n, int m, int b_shared) {
   constexpr int TILE = 1024;
   __shared__ float4 tile[TILE];
   const int bi = blockIdx.y, tid = threadIdx.x;
   const float* pa = a + (size_t)bi * n * 3;
-  const float* pb = b + (size_t)bi * m * 3;
+  const float* pb = b + (b_shared ? 0 : (size_t)bi * m * 3);   // b_shared: ONE target set for every cloud
   float ax[Q], ay[Q], az[Q], best[Q];
   int besti[Q];
   const int j0 = blockIdx.x * 256 * Q + tid;
@@ -528,10 +528,19 @@ extern "C" int dgv2_gather_points_grad(float* grad_points, const float* grad_out
   DGV2_RETURN_LAST();
 }
 
-static int chamfer_nn(float* dist, int* idx, const float* a, const float* b, int B, int n, int m, hipStream_t st) {
-  if ((int64_t)B * ((n + 1023) / 1024) >= 512) chamfer_nn_kernel<4><<<dim3((n + 1023) / 1024, B), 256, 0, st>>>(dist, idx, a, b, n, m);
-  else chamfer_nn_kernel<1><<<dim3((n + 255) / 256, B), 256, 0, st>>>(dist, idx, a, b, n, m);
+static int chamfer_nn(float* dist, int* idx, const float* a, const float* b, int B, int n, int m, hipStream_t st,
+                      int b_shared = 0) {
+  if ((int64_t)B * ((n + 1023) / 1024) >= 512)
+    chamfer_nn_kernel<4><<<dim3((n + 1023) / 1024, B), 256, 0, st>>>(dist, idx, a, b, n, m, b_shared);
+  else chamfer_nn_kernel<1><<<dim3((n + 255) / 256, B), 256, 0, st>>>(dist, idx, a, b, n, m, b_shared);
   DGV2_RETURN_LAST();
+}
+
+extern "C" int dgv2_nn_search(float* dist, int* idx, const float* xyz, const float* ref, int B, int n, int m,
+                              int ref_shared, void* stream) {
+  if (!dist || !idx || !xyz || !ref || B < 0 || n <= 0 || m <= 0 || B > 65535) return DGV2_EINVAL;
+  if (B == 0) return 0;
+  return chamfer_nn(dist, idx, xyz, ref, B, n, m, (hipStream_t)stream, ref_shared != 0);
 }
 
 extern "C" int dgv2_chamfer_fwd(float* dist1, int* idx1, float* dist2, int* idx2, const float* xyz1, const float* xyz2,

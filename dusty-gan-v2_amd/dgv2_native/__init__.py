@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "dgv2_gather_points": [_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr],
     "dgv2_gather_points_grad": [_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr],
     "dgv2_chamfer_fwd": [_c_ptr] * 6 + [_c_int] * 3 + [_c_ptr],
+    "dgv2_nn_search": [_c_ptr] * 4 + [_c_int] * 4 + [_c_ptr],
     "dgv2_chamfer_bwd": [_c_ptr] * 8 + [_c_int] * 3 + [_c_ptr],
     "dgv2_emd_approxmatch": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_emd_matchcost": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],

@@ -566,6 +566,10 @@ int dgv2_gather_points_grad(float* grad_points, const float* grad_out, const int
  * ------------------------------------------------------------------------- */
 int dgv2_chamfer_fwd(float* dist1, int* idx1, float* dist2, int* idx2, const float* xyz1, const float* xyz2, int B,
                      int n, int m, void* stream);
+/* one direction of the above: nearest neighbour of every xyz point [B, n, 3] in ref [B, m, 3], or in ONE set ref [m, 3]
+ * shared by all clouds (ref_shared = 1: the occupancy-grid voting of the JSD metric, gans/metrics/jsd.py:46-62) */
+int dgv2_nn_search(float* dist, int* idx, const float* xyz, const float* ref, int B, int n, int m, int ref_shared,
+                   void* stream);
 int dgv2_chamfer_bwd(float* gxyz1, float* gxyz2, const float* xyz1, const float* xyz2, const float* gdist1,
                      const float* gdist2, const int* idx1, const int* idx2, int B, int n, int m, void* stream);
 

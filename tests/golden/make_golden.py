@@ -772,8 +772,60 @@ def golden_validation():
     save("validation.npz", out)
 
 
+def golden_metrics():
+    """Image / point-cloud set metrics run by the reference on CPU (gans/metrics/{jsd,swd,depth}.py): occupancy
+    histograms and the JSD, Laplacian pyramids, descriptors and the sliced Wasserstein distance for captured random
+    choices (torch.randperm / torch.randn are wrapped to record what the reference drew), depth summaries."""
+    from gans.metrics import depth as rdepth
+    from gans.metrics import jsd as rjsd
+    from gans.metrics import swd as rswd
+    out = {}
+    gen = recipe.point_clouds(71, 6, 256, 0.15).clamp(-0.28, 0.28)
+    ref = recipe.point_clouds(72, 5, 256, 0.12).clamp(-0.28, 0.28) + 0.02
+    ent, counters = rjsd.entropy_of_occupancy_grid(gen, 8, True, 128, False)
+    out["jsd_entropy"], out["jsd_counters"] = ent, counters
+    out["jsd"] = np.float64(rjsd.compute_jsd(gen, ref, resolution=8, verbose=False))
+    g = torch.Generator().manual_seed(9)
+    img1 = torch.randn(6, 1, 32, 64, generator=g)
+    img2 = torch.randn(6, 1, 32, 64, generator=g) * 0.8 + 0.1
+    pyr = rswd.laplacian_pyramid(img1.clone(), 2)
+    out["swd_pyr0"], out["swd_pyr1"] = pyr[0], pyr[1]
+    drawn = {"perm": [], "dirs": []}
+    real_perm, real_randn = torch.randperm, torch.randn
+
+    def perm(n, **kw):
+        v = real_perm(n, **kw)
+        drawn["perm"].append(v.clone())
+        return v
+
+    def randn(*a, **kw):
+        v = real_randn(*a, **kw)
+        drawn["dirs"].append(v.clone())
+        return v
+    torch.manual_seed(3)
+    rswd.torch.randperm, rswd.torch.randn = perm, randn
+    try:
+        res = rswd.compute_swd(img1.clone(), img2.clone(), num_levels=2, patch_size=7, num_patches=16, dir_repeats=2,
+                               dirs_per_repeat=8, batch_size=6)
+    finally:
+        rswd.torch.randperm, rswd.torch.randn = real_perm, real_randn
+    # draw order: per minibatch, image set 1 levels 0..1 then image set 2 levels 0..1; then per level 2 direction sets
+    out["swd_perm"] = torch.stack([p[:16] for p in drawn["perm"][:2]] + [p[:16] for p in drawn["perm"][2:4]])
+    out["swd_perm_sizes"] = np.array([len(p) for p in drawn["perm"]])
+    out["swd_dirs"] = torch.stack(drawn["dirs"])
+    for k, v in res.items():
+        out["swd_result_" + k] = np.float64(v)
+    d_ref = torch.rand(3, 1, 8, 16, generator=g) * 50 + 1
+    d_gen = d_ref * (1 + 0.3 * torch.randn(3, 1, 8, 16, generator=g)).clamp(0.2, 3)
+    mask = (torch.rand(3, 1, 8, 16, generator=g) > 0.2).float()
+    for k, v in {**rdepth.compute_depth_error(d_ref, d_gen, mask), **rdepth.compute_depth_accuracy(d_ref, d_gen, mask)}.items():
+        out["depth_" + k] = v
+    out["depth_ref"], out["depth_gen"], out["depth_mask"] = d_ref, d_gen, mask
+    save("metrics.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation"]
+    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation", "metrics"]
     if "ops" in which:
         golden_ops()
     if "coords" in which:
@@ -790,3 +842,5 @@ if __name__ == "__main__":
         golden_kitti()
     if "validation" in which:
         golden_validation()
+    if "metrics" in which:
+        golden_metrics()
