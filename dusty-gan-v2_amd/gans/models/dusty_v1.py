@@ -1,9 +1,9 @@
-"""Ray-drop measurement model (reference: gans/models/dusty_v1.py:7-25).  Only RayDropModel is on
-the dusty_v2 path; the dusty_v1 generator itself is out of scope."""
+"""Ray-drop measurement model and the dusty_v1 generator (reference: gans/models/dusty_v1.py:7-41): the DCGAN-style
+synthesis network of vanilla.py with an image and a ray-drop logit head, followed by the Gumbel-sigmoid ray drop."""
 import torch
 from torch import nn
 
-from . import ops
+from . import base, ops
 
 
 class RayDropModel(nn.Module):
@@ -29,3 +29,28 @@ class RayDropModel(nn.Module):
 
     def extra_repr(self):
         return f"raydrop_const={self.raydrop_const}"
+
+
+class Generator(base.Generator):
+    def __init__(self, synthesis_kwargs, measurement_kwargs):
+        from . import vanilla
+        super().__init__(
+            mapping_network=nn.Identity(),
+            synthesis_network=vanilla.SynthesisNetwork(**synthesis_kwargs),
+            measurement_model=RayDropModel(**measurement_kwargs),
+        )
+
+    def forward(self, z, angle=None, style_mixing=False, truncation_psi=1.0, input_w=False, noise=None):
+        """`noise`: {"gumbel_u": [B,1,H,W]} injects the uniforms of the Gumbel-sigmoid (parity tests)."""
+        u = None if not noise else noise.get("gumbel_u")
+        if u is None:
+            return super().forward(z, angle, style_mixing, truncation_psi, input_w)
+        gs = self.measurement_model.gumbel_sigmoid
+        keep, gs.injected_u = getattr(gs, "injected_u", None), u
+        try:
+            return super().forward(z, angle, style_mixing, truncation_psi, input_w)
+        finally:
+            gs.injected_u = keep
+
+    def forward_synthesis(self, w, angles=None):
+        return self.synthesis_network(w)

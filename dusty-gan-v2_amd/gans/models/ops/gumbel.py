@@ -17,6 +17,8 @@ class GumbelSigmoid(nn.Module):
 
     def forward(self, logits, u=None):
         if u is None:
+            u = getattr(self, "injected_u", None)   # uniforms handed in by the caller of the enclosing generator (tests)
+        if u is None:
             u = native.gumbel_uniform(logits.shape, logits.device)
         soft = torch.sigmoid((logits + u.log() - (-u).log1p()) / self.temperature)
         if not self.straight_through:

@@ -824,8 +824,71 @@ def golden_metrics():
     save("metrics.npz", out)
 
 
+def golden_baselines():
+    """The DCGAN-style baselines (gans/models/vanilla.py, dusty_v1.py) run by the reference on CPU at a small size:
+    generator forward in train mode (+ the Gumbel uniforms it drew), discriminator forward, the G-step gradients, the
+    D-step gradients on a real / fake pair and an R1 double backward through the vanilla discriminator; weights by
+    recipe.fill_state_dict."""
+    from torch.distributions import utils as dutils
+    out = {}
+    for arch in ("vanilla", "dusty_v1"):
+        gen_cfg, dis_cfg = recipe.baseline_cfg(arch)
+        G = build_generator(_refshim.to_attr(gen_cfg))
+        D = build_discriminator(_refshim.to_attr(dis_cfg))
+        recipe.fill_state_dict(G.state_dict(), seed=21)
+        recipe.fill_state_dict(D.state_dict(), seed=22)
+        G.train(), D.train()
+        out[f"{arch}.keys.G"] = np.array(list(G.state_dict().keys()))
+        out[f"{arch}.keys.D"] = np.array(list(D.state_dict().keys()))
+        g = torch.Generator().manual_seed(5)
+        z = torch.randn(4, 16, generator=g)
+        drawn = []
+        real_rand = torch.rand
+
+        def rand(*a, **kw):
+            v = real_rand(*a, **kw)
+            drawn.append(v.clone())
+            return v
+        torch.manual_seed(0)
+        torch.rand = rand
+        try:
+            o = G(z)
+        finally:
+            torch.rand = real_rand
+        if arch == "dusty_v1":
+            assert len(drawn) == 1
+            out[f"{arch}.gumbel_u"] = dutils.clamp_probs(drawn[0])
+            out[f"{arch}.raydrop_logit"], out[f"{arch}.raydrop_mask"] = o["raydrop_logit"], o["raydrop_mask"]
+            out[f"{arch}.image_orig"] = o["image_orig"]
+        out[f"{arch}.z"], out[f"{arch}.image"], out[f"{arch}.w_avg"] = z, o["image"], G.w_avg
+        y_fake = D(o["image"])
+        out[f"{arch}.y_fake"] = y_fake
+        loss_g = F.softplus(-y_fake).mean()
+        gg = torch.autograd.grad(loss_g, [p for p in G.parameters()], retain_graph=True)
+        for (n, _), v in zip(G.named_parameters(), gg):
+            out[f"{arch}.gG.{n}"] = v
+        x_real = torch.rand(4, 1, 32, 64, generator=g) * 2 - 1
+        out[f"{arch}.x_real"] = x_real
+        y_real = D(x_real)
+        loss_d = F.softplus(-y_real).mean() + F.softplus(D(o["image"].detach())).mean()
+        gd = torch.autograd.grad(loss_d, [p for p in D.parameters()])
+        out[f"{arch}.y_real"], out[f"{arch}.loss_d"] = y_real, loss_d
+        for (n, _), v in zip(D.named_parameters(), gd):
+            out[f"{arch}.gD.{n}"] = v
+        if arch == "vanilla":
+            xr = x_real.clone().requires_grad_(True)
+            (gx,) = torch.autograd.grad(D(xr).sum(), [xr], create_graph=True)
+            r1 = (gx ** 2).sum(dim=[1, 2, 3]).mean()
+            gr = torch.autograd.grad(r1, [p for p in D.parameters()], allow_unused=True)
+            out["vanilla.r1"], out["vanilla.r1_gx"] = r1, gx
+            for (n, _), v in zip(D.named_parameters(), gr):
+                if v is not None:
+                    out[f"vanilla.gR1.{n}"] = v
+    save("baselines.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation", "metrics"]
+    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation", "metrics", "baselines"]
     if "ops" in which:
         golden_ops()
     if "coords" in which:
@@ -844,3 +907,5 @@ if __name__ == "__main__":
         golden_validation()
     if "metrics" in which:
         golden_metrics()
+    if "baselines" in which:
+        golden_baselines()

@@ -96,3 +96,14 @@ def feature_sets(seed, n1, n2, d):
     a = torch.randn(n1, d, generator=g, dtype=torch.float64)
     b = torch.randn(n2, d, generator=g, dtype=torch.float64) * 1.2 + 0.3
     return a.numpy(), b.numpy()
+
+
+def baseline_cfg(arch):
+    """Small vanilla / dusty_v1 configuration (32 x 64, ch_base 4): every layer type, tiny tensors."""
+    out_ch = [dict(name="image", ch=1, act="nn.Tanh")]
+    if arch == "dusty_v1":
+        out_ch.append(dict(name="raydrop_logit", ch=1, act=None))
+    gen = dict(arch=arch, synthesis_kwargs=dict(in_ch=16, out_ch=out_ch, ch_base=4, ch_max=16, resolution=[32, 64], ring=True),
+               measurement_kwargs=dict(raydrop_const=-1.0, gumbel_temperature=1.0))
+    dis = dict(arch="vanilla", layer_kwargs=dict(in_ch=1, ch_base=4, ch_max=16, resolution=[32, 64], ring=True))
+    return gen, dis
