@@ -44,6 +44,8 @@ constexpr int S_ROWSLOTS = S_COLS * 4;   // 16-byte slots per ring row
 constexpr int S_GROUP = 8 * S_ROWSLOTS;  // slots per 8-row group (1088 = 17 wave pieces)
 constexpr int S_RING = 24;
 
+constexpr int NT_LD = 0;   // cache policy of the LDS-DMA loads: nontemporal (2) measured 5-10 % slower
+
 template <bool HZERO>
 __global__ __launch_bounds__(256, 3) void conv3x3_strip_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
                                                                const bf16_t* __restrict__ w, SGeom g) {
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_strip_kernel(bf16_t* __restric
       int r = 8 * grp - 7 + rowin[j];
       r = r < 0 ? 0 : (r >= g.H ? g.H - 1 : r);
       const bf16_t* src = xb + (int64_t)r * g.W * S_C + coloff[j];
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(base + j * 256 + wave * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(base + j * 256 + wave * 64), 16, 0, NT_LD);
     }
   };
 
@@ -197,7 +199,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_strip_kernel(bf16_t* __restric
           for (int e = 0; e < 8; ++e) a.set(e, a.get(e) + r.get(e));
           out = a.raw;
         }
-        *reinterpret_cast<uint4*>(y + o) = out;
+        if (!g.resid) {   // streaming store: the output (268 MB at B = 128) is far larger than L2 + MALL and is read next by
+                          // another kernel; measured -4 % (forward) / -10 % (data gradient).  With a residual operand
+                          // the same store was 25 % SLOWER (the resid lines it just read are evicted with it)
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+          u32x4 v = {out.x, out.y, out.z, out.w};
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(y + o));
+        } else {
+          *reinterpret_cast<uint4*>(y + o) = out;
+        }
       }
     }
   }
