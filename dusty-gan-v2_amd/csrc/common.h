@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dgv2.h"
 
@@ -32,6 +33,12 @@ template <typename T> struct vec16 {
   };
   __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const uint4*>(p); }
   __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  // streaming store for outputs far larger than L2 + MALL that another kernel reads next
+  __device__ __forceinline__ void store_nt(T* p) const {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const u32x4 v = {raw.x, raw.y, raw.z, raw.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+  }
   __device__ __forceinline__ float get(int i) const { return to_f32(e[i]); }
   __device__ __forceinline__ void set(int i, float v) { e[i] = from_f32<T>(v); }
 };
@@ -135,6 +142,12 @@ static inline hipError_t dgv2_zero_async(void* p, size_t bytes, hipStream_t st) 
   return hipGetLastError();
 }
 #define hipMemsetAsync(p, value, bytes, st) dgv2_zero_async((p), (bytes), (st))
+
+// Outputs of at least this many bytes leave with nontemporal stores (DGV2_NT_MIN_MB, default 64; 0 disables).
+static inline bool nt_output(int64_t bytes) {
+  static const int64_t min_mb = getenv("DGV2_NT_MIN_MB") ? atoll(getenv("DGV2_NT_MIN_MB")) : 64;
+  return min_mb > 0 && bytes >= (min_mb << 20);
+}
 
 static inline int grid_for(int64_t work, int block, int cap = 256 * 16) {
   int64_t g = (work + block - 1) / block;

@@ -184,29 +184,48 @@ __global__ __launch_bounds__(256, 3) void conv3x3_strip_kernel(bf16_t* __restric
       }
       // groups (0,1) and (2,3): lanes n and n+32 swap one packed quad each, leaving 8 consecutive channels per lane:
       // kg = 0 -> [own j, partner j] = channels 16*(j/2) + 0..7; kg = 1 -> [partner j+1, own j+1] = 16*(j/2) + 8..15
-      int64_t off = (((int64_t)b * g.H + ro) * g.W + w0 + n) * S_C;
+      uint4 out[2];
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {
         auto s0 = __builtin_amdgcn_permlane32_swap(pk[j][0], pk[j + 1][0], false, false);
         auto s1 = __builtin_amdgcn_permlane32_swap(pk[j][1], pk[j + 1][1], false, false);
-        uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-        const int64_t o = off + 8 * j + 8 * kg;
+        out[j >> 1] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+      // out[0] / out[1] are the 16-byte chunks (kg, 2 + kg) of pixel n: stored as they stand, each instruction would
+      // write HALF of every pixel's 64 bytes (32 segments of 32 B).  Exchanging the odd 16-lane rows of out[0] with the
+      // even rows of out[1] (v_permlane16_swap) regroups them so that instruction s writes pixels 16 s .. 16 s + 15
+      // COMPLETELY: one contiguous 1 KB run per instruction, whole 128-byte lines.
+      {
+        unsigned* a = reinterpret_cast<unsigned*>(&out[0]);
+        unsigned* c = reinterpret_cast<unsigned*>(&out[1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          auto r = __builtin_amdgcn_permlane16_swap(a[e], c[e], false, false);
+          a[e] = r[0];
+          c[e] = r[1];
+        }
+      }
+      const int rw = lane >> 4;
+      const int chunk = (rw & 1) * 2 + (rw >> 1);
+      const int64_t off = (((int64_t)b * g.H + ro) * g.W + w0 + (lane & 15)) * S_C + chunk * 8;
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        uint4 v = out[sidx];
+        const int64_t o = off + sidx * 16 * S_C;
         if (g.resid) {   // added on the packed run, as the generic engine's fast path does
-          vec16<bf16_t> a, r;
-          a.raw = out;
+          vec16<bf16_t> av, r;
+          av.raw = v;
           r.load(g.resid + o);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a.set(e, a.get(e) + r.get(e));
-          out = a.raw;
-        }
-        if (!g.resid) {   // streaming store: the output (268 MB at B = 128) is far larger than L2 + MALL and is read next by
-                          // another kernel; measured -4 % (forward) / -10 % (data gradient).  With a residual operand
-                          // the same store was 25 % SLOWER (the resid lines it just read are evicted with it)
-          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-          u32x4 v = {out.x, out.y, out.z, out.w};
-          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(y + o));
+          for (int e = 0; e < 8; ++e) av.set(e, av.get(e) + r.get(e));
+          v = av.raw;
+          *reinterpret_cast<uint4*>(y + o) = v;
         } else {
-          *reinterpret_cast<uint4*>(y + o) = out;
+          // streaming store: the output (268 MB at B = 128) is far larger than L2 + MALL and is read next by another
+          // kernel; with a residual operand the same store was 25 % SLOWER (the resid lines just read leave with it)
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+          const u32x4 q = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(q, reinterpret_cast<u32x4*>(y + o));
         }
       }
     }

@@ -293,11 +293,12 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
     int SHA, float* __restrict__ sumsq, const T* __restrict__ ref = nullptr, float alpha = 1.f, float ascale = 1.f,
     float* __restrict__ bias_partial = nullptr) {
 #ifdef DGV2_ABLATE   // benchmarking builds only (make ABLATE=1): wrong results by design, never in the shipped library
-  const int SH = SHA & 0xffff, ablate = SHA >> 16;   // DGV2_RS_ABLATE
+  const int SH = SHA & 0xffff, ablate = (SHA >> 16) & 0xff;   // DGV2_RS_ABLATE
 #else
   const int SH = SHA & 0xffff;
   constexpr int ablate = 0;
 #endif
+  const bool nt = (SHA >> 30) & 1;   // nontemporal output stores (host: output >= DGV2_NT_MIN_MB)
   __shared__ float red[16];
   float ss = 0.f;   // sum of squares of what this thread stores (sumsq != nullptr: one partial per block)
   constexpr int VN = vec16<T>::N;
@@ -416,7 +417,10 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
 #pragma unroll
         for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
       }
-      if (y) o.store(yp + (int64_t)ho * out_w * ldy);   // y == nullptr: statistic only (sum of squares of the result)
+      if (y) {   // y == nullptr: statistic only (sum of squares of the result)
+        if (nt) o.store_nt(yp + (int64_t)ho * out_w * ldy);
+        else o.store(yp + (int64_t)ho * out_w * ldy);
+      }
       if (sumsq) {
 #pragma unroll
         for (int j = 0; j < VN; ++j) ss = fmaf(o.get(j), o.get(j), ss);
@@ -562,7 +566,8 @@ extern "C" int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, co
       if (stat_only && !sq) return DGV2_ENOTSUP;
       if (sq) *sumsq_used = (int)blocks;
       rs_launch<T>(Ew, (int)blocks, st, (T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, B, C, ldx, ldy, in_h,
-                   in_w, out_h, out_w, SH | (rs_ablate << 16), sq);
+                   in_w, out_h, out_w,
+                   SH | (rs_ablate << 16) | ((y && nt_output((int64_t)B * out_h * out_w * C * sizeof(T))) ? (1 << 30) : 0), sq);
     } else if (!vec && (C == 1 || C == 2 || C == 4) && ldx == C && ldy == C &&
                (reinterpret_cast<uintptr_t>(x) % (sizeof(T) * C)) == 0 && (reinterpret_cast<uintptr_t>(y) % (sizeof(T) * C)) == 0) {
       const int g2 = grid_for((int64_t)B * out_h * out_w, 256, 256 * 64);
