@@ -41,6 +41,7 @@ struct DConv {
   int dymin, dxmin, rows, cols;
   int hzero, ring, accumulate;
   int tpb;          // tiles per block along W (pipelined kernel)
+  int nt;           // streaming output stores (outputs >= DGV2_NT_MIN_MB that no residual read revisits)
   // output classes: taps [cls_t0[c], cls_t0[c+1]) accumulate into class c, written at offsets (cls_ooh, cls_oow)
   // (one class = the plain conv; four = the parity classes of the stride-2 data gradient in ONE launch)
   int ncls, cls_t0[5], cls_ooh[4], cls_oow[4];
@@ -358,7 +359,13 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
                     for (int j = 0; j < 8; ++j) a.set(j, a.get(j) + r.get(j));
                     pk = a.raw;
                   }
-                  *reinterpret_cast<uint4*>(q) = pk;
+                  if (p.nt) {
+                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                    const u32x4 v4 = {pk.x, pk.y, pk.z, pk.w};
+                    __builtin_nontemporal_store(v4, reinterpret_cast<u32x4*>(q));
+                  } else {
+                    *reinterpret_cast<uint4*>(q) = pk;
+                  }
                 }
               }
             } else {
@@ -532,6 +539,7 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   tpb = tpb < 1 ? 1 : (tpb > tiles_w ? tiles_w : tpb);
   tpb = tpb > 8 ? 8 : tpb;
   p.tpb = tpb;
+  p.nt = (!p.resid && !p.accumulate && nt_output((int64_t)p.B * p.Hy * p.Wy * p.ldy * sizeof(T))) ? 1 : 0;
   dim3 grid((tiles_w + tpb - 1) / tpb, tiles_h * p.B, tiles_o);
   kern<<<grid, 256, lds, st>>>((T*)y, (const T*)x, (const T*)w, p);
   return 0;
@@ -606,6 +614,7 @@ extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w,
   const int kstep = dtype == DGV2_BF16 ? 32 : 16;
   if (Cin % kstep || !aligned16(x) || !aligned16(w)) return DGV2_EINVAL;
   DConv p;
+  p.nt = 0;
   p.B = B; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hg = Hg; p.Wg = Wg; p.O = O; p.Hy = Hy; p.Wy = Wy; p.ldy = ldy;
   p.in_stride = in_stride; p.ioff_h = ioff_h; p.ioff_w = ioff_w;
   p.out_stride = out_stride; p.ooff_h = cls_host[0]; p.ooff_w = cls_host[1];

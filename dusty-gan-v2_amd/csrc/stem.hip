@@ -19,6 +19,7 @@ namespace {
 struct StemGeom {
   int B, H, W, O, ring;
   float alpha, scale;
+  int nt;   // streaming output stores (outputs >= DGV2_NT_MIN_MB)
 };
 
 __device__ __forceinline__ int stem_wcoord(int w, int W, int ring) {
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(T* __restrict__ y, const 
       vec16<T> o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o.set(j, f[j]);
-      o.store(out);
+      if (g.nt) o.store_nt(out);
+      else o.store(out);
     } else {
       *reinterpret_cast<float4*>(out) = make_float4(f[0], f[1], f[2], f[3]);
       *reinterpret_cast<float4*>(out + 4) = make_float4(f[4], f[5], f[6], f[7]);
@@ -213,7 +215,7 @@ bool stem_ok(int B, int H, int W, int O) {
 extern "C" int dgv2_stem_fwd(void* y, const float* x, const float* w, const float* bias, int B, int H, int W, int O,
                              int ring, float alpha, float scale, int ydtype, void* stream) {
   if (!y || !x || !w || !stem_ok(B, H, W, O) || !aligned16(y)) return DGV2_EINVAL;
-  StemGeom g{B, H, W, O, ring, alpha, scale};
+  StemGeom g{B, H, W, O, ring, alpha, scale, nt_output((int64_t)B * H * W * O * (ydtype == DGV2_BF16 ? 2 : 4)) ? 1 : 0};
   const int64_t items = (int64_t)B * H * W * (O / 8);
   const int grid = grid_for(items, 256, 256 * 32);
   hipStream_t st = (hipStream_t)stream;
@@ -238,7 +240,7 @@ extern "C" int dgv2_stem_bwd(float* gx, float* gw, float* gb, float* scratch, in
   if (!aligned16(gy) || !aligned16(y) || !aligned16(scratch)) return DGV2_EINVAL;
   const int64_t need = (int64_t)STEM_BWD_BLOCKS * 3 * O + (int64_t)B * H * W * 2;
   if (scratch_elems < need) return DGV2_EINVAL;
-  StemGeom g{B, H, W, O, ring, alpha, scale};
+  StemGeom g{B, H, W, O, ring, alpha, scale, 0};
   const int64_t items = (int64_t)B * H * W * (O / 8);
   const int grid = grid_for(items, 256, STEM_BWD_BLOCKS);
   float* partial = scratch;
