@@ -46,11 +46,12 @@ constexpr int S_RING = 24;
 
 constexpr int NT_LD = 0;   // cache policy of the LDS-DMA loads: nontemporal (2) measured 5-10 % slower
 
-template <bool HZERO>
-__global__ __launch_bounds__(256, 3) void conv3x3_strip_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
+template <bool HZERO, bool RESID>
+__global__ __launch_bounds__(256, RESID ? 2 : 3) void conv3x3_strip_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
                                                                const bf16_t* __restrict__ w, SGeom g) {
   extern __shared__ __attribute__((aligned(16))) uint4 ring[];   // [24 rows][34 cols][4 chunks], chunk ^= (col>>2)&3
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it is a scalar branch
   const int n = lane & 31, kg = lane >> 5;
   const int strips = g.W >> 5;
   const int nb = gridDim.x;
@@ -109,6 +110,32 @@ __global__ __launch_bounds__(256, 3) void conv3x3_strip_kernel(bf16_t* __restric
   float* s_bias = reinterpret_cast<float*>(ring + S_RING * S_ROWSLOTS);
   if (tid < S_C) s_bias[tid] = g.bias ? g.bias[tid] : 0.f;
 
+  // ---- hand-issued LDS reads and residual loads --------------------------------------------------------------------
+  // With an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of every ds_read that follows it in program
+  // order (it cannot prove the read does not alias the DMA's destination) and in front of the first use of any ordinary
+  // global load: the loop below would wait for the group it has JUST requested, i.e. one group in flight per block
+  // instead of two.  So the B-fragment reads, the bias reads and the residual loads are asm with counted waits:
+  //   vmcnt  (in issue order per wave and iteration): [4 residual loads] [4-5 DMA pieces of group it+2] [4 stores]
+  //          top of iteration it: all but the 4 youngest (the stores of it-1) done  =>  group it+1 has landed;
+  //          before the epilogue: all but the DMA pieces done  =>  the residual values are in their registers
+  //   lgkmcnt: a ring of RD fragment registers, PF reads in flight ahead of the MFMA that consumes them
+  const unsigned lds_off = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ring;
+  unsigned baddr[3][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) baddr[d][h] = lds_off + (unsigned)bslot[d][h] * 16u;
+  const unsigned bias_addr = lds_off + (unsigned)(S_RING * S_ROWSLOTS) * 16u + (unsigned)kg * 16u;   // + 32 j bytes
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#define STRIP_DS_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define STRIP_DS_READ_OFF(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define STRIP_LGKM_WAIT(dst, cnt) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(dst) : "n"(cnt))
+
+  // this lane's position in the regrouped epilogue (see below): pixel (lane & 15) + 16 s of the row, 16-byte chunk
+  const int rw = lane >> 4;
+  const int chunk = (rw & 1) * 2 + (rw >> 1);
+  const int64_t lane_off = (int64_t)(w0 + (lane & 15)) * S_C + chunk * 8;
+
   const int nit = g.H >> 3;
   dma_group(0);
   dma_group(1);
@@ -118,64 +145,110 @@ __global__ __launch_bounds__(256, 3) void conv3x3_strip_kernel(bf16_t* __restric
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave's pieces landed; every wave is done with the group about to be refilled
     asm volatile("" ::: "memory");
-    if (it + 2 <= nit) dma_group(it + 2);
 
-    f32x16 acc[2];
+    const int ro0 = 8 * it + 2 * wave;                       // this wave's two output rows ro0, ro0 + 1
+    const int64_t row_off = ((int64_t)b * g.H + ro0) * g.W * S_C + lane_off;
+    u32x4 rs[RESID ? 2 : 1][2];                              // residual operand of the 4 stores
+    if (RESID) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+      for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
-      const int ro = 8 * it + 2 * wave + f;   // output row
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int ri = ro + dy;
-        if (HZERO && (ri < 0 || ri >= g.H)) continue;   // wave-uniform
-        const uint4* rowp = ring + ((ri + 7) % S_RING) * S_ROWSLOTS;
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            union { uint4 u; bf16x8 v; } ua, ub;
-            ua.u = A[(dy + 1) * 3 + d][h];
-            ub.u = rowp[bslot[d][h]];
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[f], 0, 0, 0);
-          }
-      }
-      if (HZERO && g.border && (ro == 0 || ro == g.H - 1)) {
-        // replicate-padding terms of the data gradient: output row 0 also sees gy row 0 through the ky = 0 weights
-        // (the taps of dy = +1), output row H-1 sees gy row H-1 through the ky = 2 weights (dy = -1)
-        const uint4* rowp = ring + ((ro + 7) % S_RING) * S_ROWSLOTS;
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            union { uint4 u; bf16x8 v; } ua, ub;
-            ub.u = rowp[bslot[d][h]];
-            if (ro == 0) {
-              ua.u = A[6 + d][h];
-              acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[f], 0, 0, 0);
-            }
-            if (ro == g.H - 1) {
-              ua.u = A[d][h];
-              acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[f], 0, 0, 0);
-            }
-          }
-      }
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          const bf16_t* rp = g.resid + row_off + (int64_t)f * g.W * S_C + sidx * 16 * S_C;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rs[f][sidx]) : "v"(rp) : "memory");
+        }
     }
+    const bool issued = it + 2 <= nit;
+    if (issued) dma_group(it + 2);
 
-    // ---- epilogue: lane (n, kg) holds channels 8j + 4kg .. +3 (j = 0..3) of pixel (ro, w0 + n) ----
+    // ---- 36 (read, MFMA) steps: step s = ((f * 3 + dyi) * 3 + d) * 2 + h ----
+    // Rows outside the image (data gradient only): the DMA left a CLAMPED copy there, which is exactly the operand of
+    // the replicate-padding term -- output row 0 sees gy row 0 through the ky = 0 weights (the taps of dy = +1), row
+    // H-1 sees gy row H-1 through the ky = 2 weights (dy = -1): the dead tap row is not skipped but re-weighted, so a
+    // border row costs what an interior row costs.  Without border terms (plain zero padding) it is skipped.
+    int mode_top = 0, mode_bot = 0;                          // 0 plain, 1 border weights, 2 skip (wave-uniform)
+    if (HZERO) {
+      if (ro0 == 0) mode_top = g.border ? 1 : 2;
+      if (ro0 + 1 == g.H - 1) mode_bot = g.border ? 1 : 2;
+    }
+    unsigned rb[2][3];                                       // ring row byte offsets of (f, dyi)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int dyi = 0; dyi < 3; ++dyi) rb[f][dyi] = (unsigned)((ro0 + f + dyi - 1 + 7) % S_RING) * (S_ROWSLOTS * 16u);
+
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-      const int ro = 8 * it + 2 * wave + f;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      {
+        constexpr int NS = 18, PF = RESID ? 3 : 4, RD = RESID ? 4 : 6;   // the residual operand needs 16 registers
+        u32x4 bf[RD];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+          const unsigned addr = baddr[(q / 2) % 3][q % 2] + rb[f][q / 6];
+          STRIP_DS_READ(bf[q % RD], addr);
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const int dyi = q / 6, d = (q / 2) % 3, h = q % 2;
+          const int inflight = (q + PF <= NS ? PF : NS - q) - 1;
+          switch (inflight) {
+            case 3: STRIP_LGKM_WAIT(bf[q % RD], 3); break;
+            case 2: STRIP_LGKM_WAIT(bf[q % RD], 2); break;
+            case 1: STRIP_LGKM_WAIT(bf[q % RD], 1); break;
+            default: STRIP_LGKM_WAIT(bf[q % RD], 0); break;
+          }
+          union { uint4 u; bf16x8 v; } ua;
+          union { u32x4 u; bf16x8 v; } ub;
+          ub.u = bf[q % RD];
+          if (HZERO && f == 0 && dyi == 0 && mode_top) {
+            if (mode_top == 1) {
+              ua.u = A[6 + d][h];
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
+            }
+          } else if (HZERO && f == 1 && dyi == 2 && mode_bot) {
+            if (mode_bot == 1) {
+              ua.u = A[d][h];
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
+            }
+          } else {
+            ua.u = A[dyi * 3 + d][h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
+          }
+          if (q + PF < NS) {
+            const int qn = q + PF;
+            const unsigned addr = baddr[(qn / 2) % 3][qn % 2] + rb[f][qn / 6];
+            STRIP_DS_READ(bf[qn % RD], addr);
+          }
+        }
+      }
+
+      // ---- epilogue: lane (n, kg) holds channels 8j + 4kg .. +3 (j = 0..3) of pixel (ro, w0 + n) ----
+      if (RESID && f == 0) {   // all but this iteration's DMA pieces done: the residual loads (older) have landed
+        if (!issued)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]));
+        else if (wave == 0)
+          asm volatile("s_waitcnt vmcnt(5)" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]));
+        else
+          asm volatile("s_waitcnt vmcnt(4)" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]));
+      }
       unsigned pk[4][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         union { uint2 u; bf16_t e[4]; } q;
-        const float4 b4 = *reinterpret_cast<const float4*>(s_bias + 8 * j + 4 * kg);
-        const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+        u32x4 bq;                                            // bias of channels 8j + 4kg .. +3
+        switch (j) {
+          case 0: STRIP_DS_READ_OFF(bq, bias_addr, 0); break;
+          case 1: STRIP_DS_READ_OFF(bq, bias_addr, 32); break;
+          case 2: STRIP_DS_READ_OFF(bq, bias_addr, 64); break;
+          default: STRIP_DS_READ_OFF(bq, bias_addr, 96); break;
+        }
+        STRIP_LGKM_WAIT(bq, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float t = acc[f][4 * j + r] + bq[r];
+          float t = acc[4 * j + r] + __uint_as_float(bq[r]);
           if (g.act == 3) t = fmaxf(t, t * g.alpha) * g.scale;   // leaky ReLU, 0 <= alpha <= 1
           q.e[r] = (bf16_t)t;
         }
@@ -205,31 +278,27 @@ __global__ __launch_bounds__(256, 3) void conv3x3_strip_kernel(bf16_t* __restric
           c[e] = r[1];
         }
       }
-      const int rw = lane >> 4;
-      const int chunk = (rw & 1) * 2 + (rw >> 1);
-      const int64_t off = (((int64_t)b * g.H + ro) * g.W + w0 + (lane & 15)) * S_C + chunk * 8;
 #pragma unroll
       for (int sidx = 0; sidx < 2; ++sidx) {
         uint4 v = out[sidx];
-        const int64_t o = off + sidx * 16 * S_C;
-        if (g.resid) {   // added on the packed run, as the generic engine's fast path does
+        const int64_t o = row_off + (int64_t)f * g.W * S_C + sidx * 16 * S_C;
+        if (RESID) {   // added on the packed run, as the generic engine's fast path does
           vec16<bf16_t> av, r;
           av.raw = v;
-          r.load(g.resid + o);
+          r.raw = make_uint4(rs[f][sidx][0], rs[f][sidx][1], rs[f][sidx][2], rs[f][sidx][3]);
 #pragma unroll
           for (int e = 0; e < 8; ++e) av.set(e, av.get(e) + r.get(e));
           v = av.raw;
-          *reinterpret_cast<uint4*>(y + o) = v;
-        } else {
-          // streaming store: the output (268 MB at B = 128) is far larger than L2 + MALL and is read next by another
-          // kernel; with a residual operand the same store was 25 % SLOWER (the resid lines just read leave with it)
-          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-          const u32x4 q = {v.x, v.y, v.z, v.w};
-          __builtin_nontemporal_store(q, reinterpret_cast<u32x4*>(y + o));
         }
+        // streaming store: the output (268 MB at B = 128) is far larger than L2 + MALL and is read next by another kernel
+        const u32x4 q = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(q, reinterpret_cast<u32x4*>(y + o));
       }
     }
   }
+#undef STRIP_DS_READ
+#undef STRIP_DS_READ_OFF
+#undef STRIP_LGKM_WAIT
 }
 
 }  // namespace
@@ -270,7 +339,9 @@ int dgv2_conv_strip_try(void* y, const void* x, const void* w, int B, int H, int
   g.bias = bias; g.resid = (const bf16_t*)resid; g.act = act; g.alpha = alpha; g.scale = scale;
   const size_t lds = sizeof(uint4) * S_RING * S_ROWSLOTS + sizeof(float) * S_C;   // 52,224 B ring + bias
   dim3 grid(B * (W >> 5));
-  if (hzero) conv3x3_strip_kernel<true><<<grid, 256, lds, st>>>((bf16_t*)y, (const bf16_t*)x, (const bf16_t*)w, g);
-  else conv3x3_strip_kernel<false><<<grid, 256, lds, st>>>((bf16_t*)y, (const bf16_t*)x, (const bf16_t*)w, g);
+  if (hzero && resid) conv3x3_strip_kernel<true, true><<<grid, 256, lds, st>>>((bf16_t*)y, (const bf16_t*)x, (const bf16_t*)w, g);
+  else if (hzero) conv3x3_strip_kernel<true, false><<<grid, 256, lds, st>>>((bf16_t*)y, (const bf16_t*)x, (const bf16_t*)w, g);
+  else if (resid) conv3x3_strip_kernel<false, true><<<grid, 256, lds, st>>>((bf16_t*)y, (const bf16_t*)x, (const bf16_t*)w, g);
+  else conv3x3_strip_kernel<false, false><<<grid, 256, lds, st>>>((bf16_t*)y, (const bf16_t*)x, (const bf16_t*)w, g);
   return 0;
 }
