@@ -41,6 +41,25 @@ struct MPGeom {
   const float* row_scale;   // optional fp32 [O]: y = act(acc * row_scale[o] + bias[o])
 };
 
+typedef __attribute__((ext_vector_type(4))) unsigned mp_u32x4;
+
+// xa fragments of one sample: fragment-shaped global loads straight to registers, issued as asm -- with an LDS-DMA in
+// flight the first use of an ordinary load is preceded by `s_waitcnt vmcnt(0)` (see the kernel); the caller waits with a
+// counted vmcnt before it touches `dst`.
+template <int NFW, int KA>
+__device__ __forceinline__ void mp_issue_xa(mp_u32x4 (&dst)[NFW][KA > 0 ? KA : 1], const bf16_t* __restrict__ xa, int b,
+                                            int P, int Ka, int p0, int lr, int lc) {
+#pragma unroll
+  for (int nf = 0; nf < NFW; ++nf) {
+    const int px = min(p0 + nf * 16 + lr, P - 1);
+#pragma unroll
+    for (int kc = 0; kc < KA; ++kc) {
+      const bf16_t* src = xa + ((int64_t)b * P + px) * Ka + kc * 32 + lc * 8;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[nf][kc]) : "v"(src) : "memory");
+    }
+  }
+}
+
 // MF = O / 16, NFW = 16-pixel fragments per wave, KA = Ka / 32, KS = Ks / 32 (compile-time: register arrays)
 template <int MF, int NFW, int KA, int KS>
 __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ xa,
@@ -85,7 +104,8 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) cs_r[mf][r] = g.row_scale ? g.row_scale[o_base + mf * 16 + lc * 4 + r] : 1.f;
   constexpr int KAR = KA > 0 ? KA : 1;
-  uint4 xr[2][NFW][KAR];            // xa fragments of samples b, b+1
+  typedef mp_u32x4 u32x4;
+  u32x4 xr[2][NFW][KAR];            // xa fragments of samples b, b+1
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef __attribute__((address_space(1))) const void gbl_void_t;
   // LDS-DMA of sample b's weights into buffer `buf`: piece j of wave `wave` lands at slots [j*512 + wave*64, +64);
@@ -102,28 +122,38 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     }
   };
   auto issue_x = [&](auto slot, int b) {
-    if constexpr (KA > 0) {
-#pragma unroll
-      for (int nf = 0; nf < NFW; ++nf) {
-        const int px = min(p0 + nf * 16 + lr, g.P - 1);
-        const int bc = min(b, b1 - 1);               // branch-free: the tail re-reads the last sample
-#pragma unroll
-        for (int kc = 0; kc < KA; ++kc)
-          xr[slot.value][nf][kc] =
-              *reinterpret_cast<const uint4*>(xa + ((int64_t)bc * g.P + px) * g.Ka + kc * 32 + lc * 8);
-      }
-    }
+    if constexpr (KA > 0)
+      mp_issue_xa<NFW, KA>(xr[decltype(slot)::value], xa, min(b, b1 - 1), g.P, g.Ka, p0, lr, lc);   // tail: re-reads the last sample
   };
   const int aswz = lc ^ ((lr >> 2) & 3);
 
   float ss = 0.f;
-  // one sample: weights of sample b are in rw, its xa fragments in ring slot `slot`
+  // Hand-issued LDS reads and counted waits.  With an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` before every
+  // ds_read that follows it in program order (it cannot prove the read does not alias the DMA's destination) and before
+  // the first use of an ordinary global load: left to the compiler, a sample's MFMA loop waits for the NEXT sample's
+  // weights and xa fragments, i.e. nothing overlaps.  Per wave and sample the vector-memory operations are issued in
+  // the order [NW weight pieces of b+1] [NFW*KA xa loads of b+1] [stores of b]; they retire in that order.
+  const unsigned lds_off = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_w;
+  const unsigned abase = lds_off + (unsigned)(lr * 4 + aswz) * 16u;
+  // stores a full wave certainly issues per sample (fragments with at least one live pixel); a partial tile drains
+  int nlive = 0;
+#pragma unroll
+  for (int nf = 0; nf < NFW; ++nf) nlive += (p0 + nf * 16 < g.P) ? 1 : 0;
+  const bool full_wave = __builtin_amdgcn_readfirstlane(nlive) == NFW;
+#define MP_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(abase_s), "n"(off))
+#define MP_LGKM_WAIT(dst, cnt) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(dst) : "n"(cnt))
+
+  // one sample: weights of sample b are in LDS buffer S, its xa fragments in ring slot S
   auto step = [&](auto slot, int b) {
     constexpr int S = decltype(slot)::value;
-    const uint4* wbuf = lds_w + S * WBUF;
-    // weights of sample b: this wave's DMA pieces were issued a sample ago, followed by NFW*KA xa loads
-    // (+ that sample's stores); in-order retirement makes vmcnt(NFW*KA) sufficient for the DMA
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFW * KAR) : "memory");
+    // everything but the stores of the previous sample (the youngest operations) has retired: the weights and the xa
+    // fragments of THIS sample have landed (first sample / partial tile: full drain)
+    if (b == b0 || !full_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFW * (MF / 2)) : "memory");
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+      for (int kc = 0; kc < KA; ++kc) asm volatile("" : "+v"(xr[S][nf][kc]));
     __builtin_amdgcn_s_barrier();   // all pieces landed; every wave is done with the other buffer
     asm volatile("" ::: "memory");
     if (!(MP_ABL & 4)) dma_w(min(b + 1, b1 - 1), S ^ 1);
@@ -134,17 +164,39 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
       for (int nf = 0; nf < NFW; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!(MP_ABL & 2))
+    if (!(MP_ABL & 2)) {
+      // A fragments: read q = kc * MF + mf  <-  slot (kc * O + mf * 16 + lr) * 4 + aswz of buffer S
+      constexpr int NR = KC * MF, PF = NR < 4 ? NR : 4, RD = 6;
+      const unsigned abase_s = abase + (unsigned)(S * WBUF * 16);   // the 16-bit offset field covers one buffer
+      u32x4 a[RD];
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      uint4 a[MF];
+      for (int q = 0; q < PF; ++q) MP_DS_READ(a[q % RD], ((q / MF) * O + (q % MF) * 16) * 64);
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) a[mf] = wbuf[(kc * O + mf * 16 + lr) * 4 + aswz];
+      for (int q = 0; q < NR; ++q) {
+        const int kc = q / MF, mf = q % MF;
+        const int inflight = (q + PF <= NR ? PF : NR - q) - 1;
+        switch (inflight) {
+          case 3: MP_LGKM_WAIT(a[q % RD], 3); break;
+          case 2: MP_LGKM_WAIT(a[q % RD], 2); break;
+          case 1: MP_LGKM_WAIT(a[q % RD], 1); break;
+          default: MP_LGKM_WAIT(a[q % RD], 0); break;
+        }
+        const uint4 av = make_uint4(a[q % RD][0], a[q % RD][1], a[q % RD][2], a[q % RD][3]);
 #pragma unroll
-      for (int nf = 0; nf < NFW; ++nf) {
-        const uint4 bf = kc < KA ? xr[S][nf][kc < KA ? kc : 0] : pe[nf][(KS > 0 && kc >= KA) ? kc - KA : 0];
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) Mfma16<bf16_t>::run(acc[mf][nf], a[mf], bf);
+        for (int nf = 0; nf < NFW; ++nf) {
+          uint4 bf;
+          if (kc < KA) {
+            const u32x4 t = xr[S][nf][kc < KA ? kc : 0];
+            bf = make_uint4(t[0], t[1], t[2], t[3]);
+          } else {
+            bf = pe[nf][(KS > 0 && kc >= KA) ? kc - KA : 0];
+          }
+          Mfma16<bf16_t>::run(acc[mf][nf], av, bf);
+        }
+        if (q + PF < NR) {
+          const int qn = q + PF;
+          MP_DS_READ(a[qn % RD], ((qn / MF) * O + (qn % MF) * 16) * 64);   // slot last read two reads ago
+        }
       }
     }
 
@@ -187,6 +239,8 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     step(std::integral_constant<int, 0>{}, b);
     if (b + 1 < b1) step(std::integral_constant<int, 1>{}, b + 1);
   }
+#undef MP_DS_READ
+#undef MP_LGKM_WAIT
   if (g.sumsq) {
     __shared__ float red[16];
     const float s = block_sum(ss, red);
