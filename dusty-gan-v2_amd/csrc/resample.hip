@@ -321,11 +321,14 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
   const int cv = live ? col - wo * cvecs : 0;
 
   const int nw = live ? cnt_w[wo] : 0;
+  // taps beyond the column's count (and every tap of a dead lane) load a valid address with coefficient 0: the row
+  // loads are unconditional -- no zero fill, no exec-masked branch per tap in the row loop
   int xo[EW];
   float cw[EW];
+  const int xo_any = nw > 0 ? idx_w[wo * Ew] * ldx + cv * VN : 0;
 #pragma unroll
   for (int c = 0; c < EW; ++c) {
-    xo[c] = -1;
+    xo[c] = xo_any;
     cw[c] = 0.f;
     if (c < nw) {
       xo[c] = idx_w[wo * Ew + c] * ldx + cv * VN;
@@ -361,10 +364,7 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
   auto issue = [&](int r) {
     const T* xr = xb + (int64_t)r * in_w * ldx;
 #pragma unroll
-    for (int c = 0; c < EW; ++c) {
-      pv[c].raw = make_uint4(0, 0, 0, 0);
-      if (xo[c] >= 0) pv[c].load(xr + xo[c]);
-    }
+    for (int c = 0; c < EW; ++c) pv[c].load(xr + xo[c]);
     pr = r;
   };
   for (int ho = ho0; ho < ho1; ++ho) {

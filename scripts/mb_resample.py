@@ -11,7 +11,8 @@ def t(fn, n=10):
     return s.elapsed_time(e)/n*1e3
 specs = {"blur": nat.ResampleSpec([1,3,3,1], ring=True), "up2": nat.ResampleSpec([1,3,3,1], up=(2,2), ring=True),
          "blur_down": nat.ResampleSpec([1,3,3,1], down=(2,2), ring=True, pads=(2,1))}
-cases = [("blur_down",128,64,512,32),("blur_down",128,32,256,64),("blur_down",128,16,128,128),("blur_down",128,8,64,256),
+cases = [("blur",128,64,512,32),("blur",128,32,256,64),("blur",128,16,128,128),("blur",64,64,512,32),
+         ("blur_down",128,64,512,32),("blur_down",128,32,256,64),("blur_down",128,16,128,128),("blur_down",128,8,64,256),
          ("blur_down",64,64,512,32),
          ("up2",64,32,256,64),("up2",64,16,128,128),("up2",64,8,64,256),("up2",64,4,32,512)]
 for name,B,H,W,C in cases:
