@@ -227,12 +227,16 @@ __global__ __launch_bounds__(256, RESID ? 2 : 3) void conv3x3_strip_kernel(bf16_
 
       // ---- epilogue: lane (n, kg) holds channels 8j + 4kg .. +3 (j = 0..3) of pixel (ro, w0 + n) ----
       if (RESID && f == 0) {   // all but this iteration's DMA pieces done: the residual loads (older) have landed
-        if (!issued)
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]));
-        else if (wave == 0)
-          asm volatile("s_waitcnt vmcnt(5)" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]));
-        else
-          asm volatile("s_waitcnt vmcnt(4)" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]));
+        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // the registers become usable HERE: tied to the wait itself the compiler may set the operands up with copies
+        // in front of it (it did: v_mov of registers whose data had not arrived), tied one by one behind it any
+        // copy lands after the wait
+#pragma unroll
+        for (int ff = 0; ff < 2; ++ff)
+#pragma unroll
+          for (int sidx = 0; sidx < 2; ++sidx) asm volatile("" : "+v"(rs[ff][sidx]));
       }
       unsigned pk[4][2];
 #pragma unroll

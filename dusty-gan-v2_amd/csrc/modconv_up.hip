@@ -166,10 +166,14 @@ __global__ __launch_bounds__(512, 2) void modconv_up_kernel(bf16_t* __restrict__
         v[j >> 1][4 + r] = __uint_as_float(s[1]);   // kg = 0: partner's group j | kg = 1: own group j + 1
       }
     // the taps are older than the NW DMA pieces just issued: all but the NW youngest operations done = taps landed
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(tap[0][0]), "+v"(tap[0][1]), "+v"(tap[1][0]), "+v"(tap[1][1]), "+v"(tap[2][0]), "+v"(tap[2][1]),
-                   "+v"(tap[3][0]), "+v"(tap[3][1])
-                 : "n"(NW));
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+    // tied one by one BEHIND the wait: tied to the wait itself, operand set-up copies could read the registers before
+    // their data has arrived (seen in conv_strip.hip)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      asm volatile("" : "+v"(tap[q][0]));
+      asm volatile("" : "+v"(tap[q][1]));
+    }
     const bool live = p0 + n < g.P;
     bf16_t* row = y + ((int64_t)b * g.P + px) * O;
 #pragma unroll

@@ -924,6 +924,27 @@ def test_conv_strip_kernel_forward_and_data_gradient(nat, B, H, W):
             assert_rel(nchw(got_gxr), want_gx + resq, 1.2e-2, "gx + resid")
 
 
+def test_conv_strip_kernel_under_load_matches_the_generic_engine(nat):
+    """The same three calls with enough blocks to fill the chip several times over (B = 48: 768 strips) and all three
+    row groups of the ring in flight: the hand-issued waits of conv_strip.hip are only exercised when the loads are slow.
+    (A wait tied to registers whose loads were still in flight passed every small case and failed from B = 8 up.)
+    Integer-valued operands: the fp32 run of the generic tap-list engine is exact and so is the bf16 strip kernel."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 48, 64, 512
+    geom = nat.ConvGeom(3, 3, 1, 1, True)
+    x = torch.randint(-2, 3, (B, H, W, 32), generator=g).float().to(DEV)
+    w = torch.randint(-2, 3, (32, 3, 3, 32), generator=g).float().to(DEV)
+    res = torch.randint(-3, 4, (B, H, W, 32), generator=g).float().to(DEV)
+    for _ in range(3):
+        got_y = nat._conv_fwd_raw(x.bfloat16(), w.bfloat16(), geom)
+        got_gx = nat._conv_dgrad_raw(x.bfloat16(), w.bfloat16(), geom, tuple(x.shape))
+        got_gxr = nat._conv_dgrad_raw(x.bfloat16(), w.bfloat16(), geom, tuple(x.shape), resid=res.bfloat16())
+    assert torch.equal(got_y.float(), nat._conv_fwd_raw(x, w, geom))
+    want_gx = nat._conv_dgrad_raw(x, w, geom, tuple(x.shape))
+    assert torch.equal(got_gx.float(), want_gx)
+    assert torch.equal(got_gxr.float(), want_gx + res)
+
+
 def test_modconv_up_commuted_upsampling_matches_cat_path(nat):
     """dgv2_modconv_up_fwd (conv1 of a generator level with the up-sampling commuted past the 1x1 contraction,
     csrc/modconv_up.hip) + its backward against (a) the float64 statement of the reference, act(c * ([up2(h) | PE] . W) +
