@@ -378,7 +378,9 @@ def main():
             "value": value, "unit": "range-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[2]: configs/gans/dusty_v2.yaml full G+D train step "
+            "config": {"workload": ("configs[2]" if args.res == "64x512" else
+                                    "configs[4] shape in bf16 (fp8 activations are not built)")
+                                   + ": configs/gans/dusty_v2.yaml full G+D train step "
                                    f"(G step + D step + lazy R1 + ADA + EMA + Adam), {args.res} synthetic",
                        "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
                        "parallelism": f"dp{world}", "ada_p": args.ada_p, "hip_graph": not args.no_graph,
