@@ -72,10 +72,12 @@ def test_checkpoint_roundtrip_in_memory():
         assert torch.equal(v, G2.state_dict()[k])
 
 
-def test_builder_rejects_out_of_scope_archs():
+def test_builder_rejects_unknown_archs():
+    """vanilla / dusty_v1 are built since round 2 (tests/test_baseline_layout.py); anything else is a ValueError as in
+    the reference (builder.py:19,31)."""
     from gans.config import to_config
-    from gans.models.builder import build_generator
-    with pytest.raises(NotImplementedError):
-        build_generator(to_config({"arch": "vanilla"}))
+    from gans.models.builder import build_discriminator, build_generator
     with pytest.raises(ValueError):
         build_generator(to_config({"arch": "nope"}))
+    with pytest.raises(ValueError):
+        build_discriminator(to_config({"arch": "nope"}))
