@@ -839,6 +839,14 @@ def _conv_wgrad_raw(gy, x, g, gscale=None):
         N.call("dgv2_conv_wgrad_direct", N.ptr(gw), N.ptr(gy), N.ptr(x), B, H, W, C, O, g.kh, g.stride, g.pad,
                g.ring, _dt(x), N.stream())
         return gw
+    if g.kh == 1 and g.kw == 1 and g.stride == 1 and g.pad == 0 and C <= 4 and gy.dtype == x.dtype:
+        # 1x1 conv of a <= 4-channel input (the discriminator's stem when it runs as composable ops: R1): the weight
+        # gradient is the heads' streaming column sum with the operands' roles swapped -- per[b, c, o] = sum_p
+        # x[b, p, c] gy[b, p, o] -- instead of a GEMM with 2 of its 16 rows in use (277 -> ~20 us at B = 64)
+        per = torch.empty((B, C, O), device=x.device, dtype=torch.float32)
+        if N.try_call("dgv2_bmm_tn_small", N.ptr(per), N.ptr(x), N.ptr(gy), B, H * W, O, C, _dt(x), N.stream()):
+            gw.copy_(per.sum(dim=0).t().reshape(O, 1, 1, C))
+            return gw
     N.call("dgv2_conv_wgrad", N.ptr(gw), N.ptr(gy), N.ptr(x), B, H, W, C, O, g.kh, g.kw, g.stride, g.pad, g.ring,
            _dt(x), N.stream())
     return gw
