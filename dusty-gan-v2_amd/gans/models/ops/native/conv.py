@@ -1,0 +1,695 @@
+"""native.conv: ring-padded dense convolution triple {fwd, dgrad, wgrad}, weight bank, fused conv nodes of the discriminator, minibatch-stddev concat, Linear.
+
+Part of gans.models.ops.native (autograd-aware wrappers around the libdgv2 C ABI, see the package docstring); the
+parts import each other in order, every name stays reachable as native.<name>.
+"""
+import math
+import os
+
+import torch
+from torch.autograd import Function
+
+import dgv2_native as N
+from .act_resample import *  # noqa: F401,F403
+from .modgemm import *  # noqa: F401,F403
+
+
+# ---------------------------------------------------------------------------------------
+# ring-padded dense convolution triple (reference: ops.Conv2d, common.py:187-210)
+# ---------------------------------------------------------------------------------------
+class ConvGeom:
+    def __init__(self, kh, kw, stride, pad, ring):
+        self.kh, self.kw, self.stride, self.pad, self.ring = kh, kw, stride, pad, int(bool(ring))
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
+
+
+def _kstep(t):
+    return 32 if t.dtype == torch.bfloat16 else 16
+
+
+def _conv_taps(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, ooff, taps, hzero, accumulate=False,
+               bias=None, act=0, alpha=0.2, scale=1.0, resid=None):
+    """Direct halo-tile conv with a tap list (dgv2_conv_taps).  x [B,Hin,Win,Cin]; w3 [O,wtaps,Cin];
+    y [B,Hy,Wy,O]; taps: list of (dy, dx, widx)."""
+    B, Hin, Win, Cin = x.shape
+    O, wtaps, _ = w3.shape
+    _, Hy, Wy, _ = y.shape
+    arr = (_ct.c_int * (3 * len(taps)))(*[v for t in taps for v in t])
+    N.call("dgv2_conv_taps", N.ptr(y), N.ptr(x), N.ptr(w3), B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy, in_stride,
+           ioff[0], ioff[1], out_stride, ooff[0], ooff[1], len(taps), wtaps, arr, int(hzero), 1, int(accumulate),
+           N.ptr(bias), N.ptr(resid), act, alpha, scale, _dt(x), N.stream())
+
+
+_FUSED_DGRAD = os.environ.get("DGV2_NO_FUSED_DGRAD") is None   # A/B switch for benchmarking
+
+
+def _conv_taps_ex(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, classes, taps4, extras, hzero, resid=None, ch0=None):
+    """dgv2_conv_taps_ex: output classes [(ooff_h, ooff_w)], taps [(dy, dx, widx, cls)] sorted by class, border
+    extras [(dy, dx, widx, cls, row)].  Returns False when the engine asks for the per-class fallback.
+    ch0: write the O = w3.shape[0] output channels at channel offset ch0 of the wider tensor y (dgv2_conv_taps_ld)."""
+    B, Hin, Win, Cin = x.shape
+    O, wtaps, _ = w3.shape
+    _, Hy, Wy, ldy = y.shape
+    if ch0 is not None:
+        carr = (_ct.c_int * (2 * len(classes)))(*[v for c in classes for v in c])
+        tarr = (_ct.c_int * (4 * len(taps4)))(*[v for t in taps4 for v in t])
+        earr = (_ct.c_int * max(5 * len(extras), 1))(*[v for e in extras for v in e])
+        es = y.element_size()
+        rp = None if resid is None else resid.data_ptr() + ch0 * es
+        return N.try_call("dgv2_conv_taps_ld", y.data_ptr() + ch0 * es, ldy, N.ptr(x), N.ptr(w3), B, Hin, Win, Cin, Hg, Wg,
+                          O, Hy, Wy, in_stride, ioff[0], ioff[1], out_stride, len(classes), carr, len(taps4), wtaps,
+                          tarr, len(extras), earr, int(hzero), 1, 0, None, rp, 0, 0.2, 1.0, _dt(x), N.stream())
+    carr = (_ct.c_int * (2 * len(classes)))(*[v for c in classes for v in c])
+    tarr = (_ct.c_int * (4 * len(taps4)))(*[v for t in taps4 for v in t])
+    earr = (_ct.c_int * max(5 * len(extras), 1))(*[v for e in extras for v in e])
+    return N.try_call("dgv2_conv_taps_ex", N.ptr(y), N.ptr(x), N.ptr(w3), B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy,
+                      in_stride, ioff[0], ioff[1], out_stride, len(classes), carr, len(taps4), wtaps, tarr,
+                      len(extras), earr, int(hzero), 1, 0, None, N.ptr(resid), 0, 0.2, 1.0, _dt(x), N.stream())
+
+
+def _direct_ok(g, cin):
+    """The direct engine handles the discriminator's geometries: ring padding, 3x3/pad 1 or 1x1/pad 0,
+    stride 1 or 2, input channels a multiple of the K-step."""
+    return bool(g.ring) and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2) and cin
+
+
+def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None):
+    B, H, W, C = x.shape
+    O = w.shape[0]
+    Ho, Wo = g.out_hw(H, W)
+    N.check(x, w, bias)
+    y = torch.empty((B, Ho, Wo, O), device=x.device, dtype=x.dtype)
+    if _direct_ok(g, C % _kstep(x) == 0):
+        taps = [(ky - g.pad, kx - g.pad, ky * g.kw + kx) for ky in range(g.kh) for kx in range(g.kw)]
+        _conv_taps(y, x, w.reshape(O, g.kh * g.kw, C), Ho, Wo, g.stride, (0, 0), 1, (0, 0), taps, False,
+                   bias=bias, act=act, alpha=alpha, scale=scale, resid=resid)
+        return y
+    if resid is not None:
+        raise RuntimeError("dgv2: fused residual needs the direct conv engine (ring padding, Cin % K-step == 0)")
+    N.call("dgv2_conv_fwd", N.ptr(y), N.ptr(x), N.ptr(w), B, H, W, C, O, g.kh, g.kw, g.stride, g.pad, g.ring,
+           N.ptr(bias), act, alpha, scale, _dt(x), N.stream())
+    return y
+
+
+def _axis_taps_s2(parity):
+    """Stride-2, pad-1, 3-tap transpose along one axis for output parity `parity`:
+    list of (offset into gy, kernel index)."""
+    return [(0, 1)] if parity == 0 else [(1, 0), (0, 2)]
+
+
+def _conv_dgrad_direct(gy, wt3, g, xshape, resid=None):
+    """Data gradient on the direct engine: gy [B,Ho,Wo,O], wt3 [C,kh*kw,O] -> gx [B,H,W,C] (+ resid, the gradient
+    of a sibling branch of the same input, added in the epilogue of the one-launch stride-1 path).
+    Circular W padding transposes to a wrap of the gy coordinate; the replicate rows of the H padding
+    add one-row border terms (accumulate launches)."""
+    if resid is not None and not (_FUSED_DGRAD and g.kh == 3 and g.stride == 1):
+        return _conv_dgrad_direct(gy, wt3, g, xshape) + resid
+    B, H, W, C = xshape
+    gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
+    k = g.kh
+    if k == 1:
+        _conv_taps(gx, gy, wt3, H, W, 1, (0, 0), 1, (0, 0), [(0, 0, 0)], True)
+        return gx
+    if g.stride == 1:
+        taps = [(1 - ky, 1 - kx, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+        # one launch: the replicate rows ride along as border extras of output rows 0 and H-1
+        extras = [(0, 1 - kx, kx, 0, 0) for kx in range(3)] + [(0, 1 - kx, 6 + kx, 0, H - 1) for kx in range(3)]
+        tail = C % 64
+        if _FUSED_DGRAD and C > 128 and tail in (16, 32) and B * H * W <= 32768:
+            # a channel count just past a multiple of the 64-channel slab (the epilogue conv's 513 inputs padded to 528 /
+            # 544) costs a whole extra round of blocks for a slab that is three quarters empty: run the full slabs and
+            # the tail as two launches into channel ranges of gx
+            main = C - tail
+            t4 = [t + (0,) for t in taps]
+            if (_conv_taps_ex(gx, gy, wt3[:main], H, W, 1, (0, 0), 1, [(0, 0)], t4, extras, True, resid=resid, ch0=0)
+                    and _conv_taps_ex(gx, gy, wt3[main:], H, W, 1, (0, 0), 1, [(0, 0)], t4, extras, True, resid=resid,
+                                      ch0=main)):
+                return gx
+        if _FUSED_DGRAD and _conv_taps_ex(gx, gy, wt3, H, W, 1, (0, 0), 1, [(0, 0)], [t + (0,) for t in taps], extras,
+                                          True, resid=resid):
+            return gx
+        if resid is not None:
+            return _conv_dgrad_direct(gy, wt3, g, xshape) + resid
+        _conv_taps(gx, gy, wt3, H, W, 1, (0, 0), 1, (0, 0), taps, True)
+        # replicate-padding rows: padded row -1 (-> h = 0) is read by ky = 0 of output row 0,
+        # padded row H (-> h = H-1) by ky = 2 of output row H-1
+        _conv_taps(gx, gy, wt3, 1, W, 1, (0, 0), 1, (0, 0), [(0, 1 - kx, kx) for kx in range(3)], True, True)
+        _conv_taps(gx, gy, wt3, 1, W, 1, (H - 1, 0), 1, (H - 1, 0), [(0, 1 - kx, 6 + kx) for kx in range(3)], True,
+                   True)
+        return gx
+    # stride 2: the four output parity classes (only the taps each class can see) and the top border in one launch
+    classes, taps4, extras = [], [], []
+    for ph in (0, 1):
+        for pw in (0, 1):
+            c = len(classes)
+            classes.append((ph, pw))
+            taps4 += [(dy, dx, ky * 3 + kx, c) for dy, ky in _axis_taps_s2(ph) for dx, kx in _axis_taps_s2(pw)]
+            if ph == 0:
+                extras += [(0, dx, kx, c, 0) for dx, kx in _axis_taps_s2(pw)]
+    if _FUSED_DGRAD and _conv_taps_ex(gx, gy, wt3, H // 2, W // 2, 1, (0, 0), 2, classes, taps4, extras, True):
+        return gx
+    for ph in (0, 1):
+        for pw in (0, 1):
+            taps = [(dy, dx, ky * 3 + kx) for dy, ky in _axis_taps_s2(ph) for dx, kx in _axis_taps_s2(pw)]
+            _conv_taps(gx, gy, wt3, H // 2, W // 2, 1, (0, 0), 2, (ph, pw), taps, True)
+    for pw in (0, 1):  # padded row -1 (-> h = 0) is read by ky = 0 of output row 0
+        taps = [(0, dx, kx) for dx, kx in _axis_taps_s2(pw)]
+        _conv_taps(gx, gy, wt3, 1, W // 2, 1, (0, 0), 2, (0, pw), taps, True, True)
+    return gx
+
+
+def _conv_dgrad_raw(gy, w, g, xshape, wt=None, resid=None):
+    """w [O,kh,kw,C] in gy's dtype, or wt = the prepared transposed weights [C, kh*kw, O] (weight bank)."""
+    B, H, W, C = xshape
+    O = gy.shape[3]
+    if wt is None:
+        wt = w.permute(3, 1, 2, 0).contiguous()
+    N.check(gy, wt, resid)
+    even = g.stride == 1 or (H % 2 == 0 and W % 2 == 0)
+    if _direct_ok(g, O % _kstep(gy) == 0) and even and not (g.kh == 1 and g.stride == 2):
+        return _conv_dgrad_direct(gy, wt.reshape(C, g.kh * g.kw, O), g, xshape, resid)
+    if resid is not None:
+        return _conv_dgrad_raw(gy, w, g, xshape, wt) + resid
+    gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
+    scratch = None
+    if g.pad > 0:
+        scratch = torch.empty((B, H + 2 * g.pad, W + 2 * g.pad, C), device=gy.device, dtype=gy.dtype)
+    N.call("dgv2_conv_dgrad", N.ptr(gx), N.ptr(scratch), N.ptr(gy), N.ptr(wt), B, H, W, C, O, g.kh, g.kw, g.stride,
+           g.pad, g.ring, _dt(gy), N.stream())
+    return gx
+
+
+_WGRAD_DIRECT_MAXC = int(os.environ.get("DGV2_WGRAD_DIRECT_MAXC", "64"))
+
+
+_WGRAD_STREAM = os.environ.get("DGV2_NO_WGRAD_STREAM") is None   # A/B switch for benchmarking
+
+
+_WGRAD_SCRATCH = {}
+
+
+_TN_STREAM = os.environ.get("DGV2_NO_TN_STREAM") is None           # A/B switch for benchmarking
+
+
+_TN_SCRATCH = {}
+
+
+_LIB_WGRAD = os.environ.get("DGV2_NO_LIB_WGRAD") is None         # A/B switch for benchmarking
+
+
+def _conv_wgrad_raw(gy, x, g, gscale=None):
+    """gw fp32 [O,kh,kw,C].  gscale: return scale * gw as a PERMUTED VIEW of a contiguous [O,C,kh,kw] buffer (the
+    parameter's layout): the permute-backward of a weight handle then hands the optimizer a contiguous gradient."""
+    B, H, W, C = x.shape
+    O = gy.shape[3]
+    N.check(gy, x)
+    stream_ok = (_WGRAD_STREAM and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2)
+                 and C % (16 // x.element_size()) == 0 and O % (16 // x.element_size()) == 0)
+    if gscale is not None:
+        if not stream_ok:
+            gp = _conv_wgrad_raw(gy, x, g).permute(0, 3, 1, 2)
+            return torch.mul(gp, gscale, out=torch.empty(gp.shape, device=x.device)).permute(0, 2, 3, 1)
+        gw = torch.empty((O, C, g.kh, g.kw), device=x.device, dtype=torch.float32)
+    else:
+        gw = torch.empty((O, g.kh, g.kw, C), device=x.device, dtype=torch.float32)
+    if _WGRAD_STREAM and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2) \
+            and C % (16 // x.element_size()) == 0 and O % (16 // x.element_size()) == 0:
+        key = (B, H, W, C, O, g.kh, g.stride, g.pad, _dt(x))
+        if key not in _WGRAD_SCRATCH:
+            n = _ct.c_int64(0)
+            N.call("dgv2_conv_wgrad_stream_scratch", _ct.addressof(n), B, H, W, C, O, g.kh, g.stride, g.pad, _dt(x))
+            _WGRAD_SCRATCH[key] = n.value
+        scratch = torch.empty(_WGRAD_SCRATCH[key], device=x.device, dtype=torch.float32)
+        N.call("dgv2_conv_wgrad_stream_pl", N.ptr(gw), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(x), B, H, W,
+               C, O, g.kh, g.stride, g.pad, g.ring, 1.0 if gscale is None else float(gscale), int(gscale is not None),
+               _dt(x), N.stream())
+        return gw if gscale is None else gw.permute(0, 2, 3, 1)
+    small = C % 32 == 0 and C <= _WGRAD_DIRECT_MAXC and O % 8 == 0 and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0))
+    if small and g.stride in (1, 2) and (x.dtype == torch.bfloat16 or g.stride == 1):
+        # small-channel / large-image layers: halo-tile engine (input staged once for all nine taps)
+        N.call("dgv2_conv_wgrad_direct", N.ptr(gw), N.ptr(gy), N.ptr(x), B, H, W, C, O, g.kh, g.stride, g.pad,
+               g.ring, _dt(x), N.stream())
+        return gw
+    if g.kh == 1 and g.kw == 1 and g.stride == 1 and g.pad == 0 and C <= 4 and gy.dtype == x.dtype:
+        # 1x1 conv of a <= 4-channel input (the discriminator's stem when it runs as composable ops: R1): the weight
+        # gradient is the heads' streaming column sum with the operands' roles swapped -- per[b, c, o] = sum_p
+        # x[b, p, c] gy[b, p, o] -- instead of a GEMM with 2 of its 16 rows in use (277 -> ~20 us at B = 64)
+        per = torch.empty((B, C, O), device=x.device, dtype=torch.float32)
+        if N.try_call("dgv2_bmm_tn_small", N.ptr(per), N.ptr(x), N.ptr(gy), B, H * W, O, C, _dt(x), N.stream()):
+            gw.copy_(per.sum(dim=0).t().reshape(O, 1, 1, C))
+            return gw
+    N.call("dgv2_conv_wgrad", N.ptr(gw), N.ptr(gy), N.ptr(x), B, H, W, C, O, g.kh, g.kw, g.stride, g.pad, g.ring,
+           _dt(x), N.stream())
+    return gw
+
+
+def _bank(w, x):
+    """(forward-layout, transposed) compute-dtype weights prepared by conv_weight_bank for this call, or (None, None)."""
+    wf, wt = getattr(w, "_dgv2_wf", None), getattr(w, "_dgv2_wt", None)
+    if wf is not None and wf.dtype == x.dtype:
+        return wf, wt
+    return None, None
+
+
+class _ConvFwd(Function):
+    @staticmethod
+    def forward(ctx, x, w, g):
+        x = x.contiguous()
+        wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
+        if wc is None:
+            wc = _values(w, x.dtype)
+        ctx.save_for_backward(x, w)
+        ctx.g = g
+        return _conv_fwd_raw(x, wc.reshape(w.shape), g)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+def _dgrad(gy, w, g, xshape, wt=None, resid=None, gscale=None):
+    return _ConvDgrad.apply(gy, w, g, xshape, wt, resid, gscale)
+
+
+class _ConvDgrad(Function):
+    """dgrad(gy, w) [+ resid]: resid = the gradient arriving from a sibling branch of the same input, summed in
+    the kernel's epilogue instead of by a separate elementwise add over the activation."""
+
+    @staticmethod
+    def forward(ctx, gy, w, g, xshape, wt, resid, gscale=None):
+        """gscale: `w` is a plain view of the parameter whose VALUE the kernels take from the weight bank as
+        gscale * parameter; gradients that flow to `w` carry that factor explicitly."""
+        gy = gy.contiguous()
+        ctx.save_for_backward(gy, w)
+        ctx.g, ctx.gscale = g, gscale
+        if resid is not None:
+            resid = resid.contiguous().to(gy.dtype)
+        if wt is not None and wt.dtype == gy.dtype:
+            return _conv_dgrad_raw(gy, None, g, xshape, wt=wt, resid=resid)
+        wc = _values(w, gy.dtype)
+        return _conv_dgrad_raw(gy, wc, g, xshape, resid=resid)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g_gy = _ConvFwd.apply(ggx, w, ctx.g) if ctx.needs_input_grad[0] else None
+        g_w = _ConvWgrad.apply(gy, ggx, ctx.g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w, None, None, None, (ggx if ctx.needs_input_grad[5] else None), None
+
+
+class _ConvWgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, x, g, gscale=None):
+        gy = gy.contiguous()
+        x = x.contiguous()
+        ctx.save_for_backward(gy, x)
+        ctx.g, ctx.gscale = g, gscale
+        return _conv_wgrad_raw(gy.to(x.dtype), x, g, gscale)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        if ctx.gscale is not None:   # out = gscale * wgrad(gy, x)
+            ggw = ggw * ctx.gscale
+        gy, x = ctx.saved_tensors
+        g_gy = _ConvFwd.apply(x, ggw, ctx.g) if ctx.needs_input_grad[0] else None
+        g_x = _dgrad(gy, ggw, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[1] else None
+        return g_gy, g_x, None, None
+
+
+def conv_ring(x, w, geom):
+    """x [B,H,W,C]; w fp32 master in channels-last filter layout [O,kh,kw,C]."""
+    return _ConvFwd.apply(x, w, geom)
+
+
+class _ConvAct(Function):
+    """lrelu(conv(x, w) + b) * scale, bias/activation fused into the conv epilogue; the backward is
+    composed of differentiable Functions so R1's double backward stays on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, alpha, scale):
+        x = x.contiguous()
+        wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
+        if wc is None:
+            wc = _values(w, x.dtype)
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
+        ctx.save_for_backward(x, w, out)
+        ctx.cfg = (g, alpha, scale, bias.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, out = ctx.saved_tensors
+        g, alpha, scale, size_b = ctx.cfg
+        gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        return gx, gw, gb, None, None, None
+
+
+class _LinearLow(Function):
+    """y = (x @ W^T) * scale with bf16 operands and fp32 accumulation / output (the 65536 -> 512 Linear of the
+    discriminator epilogue in "everything reduced" mode, dusty_v2.py:381-383 under the reference's AMP autocast).
+    Plain library GEMMs; the point of the Function is what it does NOT launch: the weight is cast once per pass and
+    reused by the backward, and the weight gradient leaves the GEMM in fp32 (no bf16 -> fp32 pass over 33.5 M values)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale):
+        x16 = x.to(torch.bfloat16).contiguous()
+        w16 = weight.detach().to(torch.bfloat16)
+        Bn, K = x16.shape
+        O = w16.shape[0]
+        S = 32
+        if K % (S * 8) == 0 and K >= 8192:
+            # a skinny GEMM (M = batch) over K = 65536: the library's single-pass kernel reads the 67 MB of weights at
+            # < 1 TB/s; as S strided-batched partial GEMMs + one sum it streams them (135 -> 28 us at B = 128)
+            kc = K // S
+            part = torch.bmm(x16.view(Bn, S, kc).transpose(0, 1), w16.view(O, S, kc).permute(1, 2, 0),
+                             out_dtype=torch.float32)
+            y = part.sum(0)
+        else:
+            y = torch.mm(x16, w16.t(), out_dtype=torch.float32)
+        y.mul_(scale)
+        ctx.save_for_backward(x, weight, w16)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, w16 = ctx.saved_tensors
+        if torch.is_grad_enabled():   # create_graph=True: the same gradients from differentiable ops
+            g16 = (gy * ctx.scale).to(torch.bfloat16)
+            return g16 @ weight.to(torch.bfloat16), (g16.t() @ x.to(torch.bfloat16)).float(), None
+        g16 = torch.mul(gy, ctx.scale).to(torch.bfloat16)
+        gx = torch.mm(g16, w16) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            x16 = x.to(torch.bfloat16).contiguous()
+            Bn, K = x16.shape
+            O = w16.shape[0]
+            if K % 8 == 0 and O % 8 == 0:
+                # gw = g^T x with the batch as the contraction: the TN engine (transposing LDS reads), fp32 out
+                gw = torch.empty((O, K), device=x.device, dtype=torch.float32)
+                N.check(g16, x16)
+                N.call("dgv2_bmm_tn", N.ptr(gw), N.ptr(g16), N.ptr(x16), 1, Bn, K, O, O, K, N.BF16, N.stream())
+            else:
+                gw = torch.mm(g16.t(), x16, out_dtype=torch.float32)
+        return gx, gw, None
+
+
+def linear_low(x, weight, scale):
+    return _LinearLow.apply(x, weight, float(scale))
+
+
+class _LinearF32(Function):
+    """y = (x @ W^T) * scale in fp32 for the 65536 -> 512 Linear of the discriminator's fp32 epilogue
+    (dusty_v2.py:381-383,394-395).  Forward: a skinny GEMM (M = batch) over K = 65536 runs the library's single-pass
+    kernel at 28 TFLOP/s (308 us at B = 128) because only 16 output tiles exist; as S = 32 strided-batched partial
+    GEMMs + one sum it fills the chip.  Backward: plain GEMMs (already near the fp32 MFMA rate)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale):
+        x = x.contiguous()
+        w = weight.detach()
+        Bn, K = x.shape
+        O = w.shape[0]
+        S = 32
+        if K % (S * 8) == 0 and K >= 8192:
+            kc = K // S
+            part = torch.bmm(x.view(Bn, S, kc).transpose(0, 1), w.view(O, S, kc).permute(1, 2, 0))
+            y = part.sum(0)
+        else:
+            y = torch.mm(x, w.t())
+        y.mul_(scale)
+        ctx.save_for_backward(x, weight)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        g = gy * ctx.scale
+        if torch.is_grad_enabled():   # create_graph=True (R1): differentiable ops
+            return g @ weight, g.t() @ x, None
+        gx = torch.mm(g, weight.detach()) if ctx.needs_input_grad[0] else None
+        gw = torch.mm(g.t(), x) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+def linear_f32(x, weight, scale):
+    return _LinearF32.apply(x, weight, float(scale))
+
+
+class _MbstdCat(Function):
+    """[x | minibatch-stddev statistic | zero padding] (dgv2_mbstd_cat_fwd/_bwd): MinibatchStdDev + concat of the
+    discriminator epilogue (common.py:226-250) in two launches forward and one backward; first order only."""
+
+    @staticmethod
+    def forward(ctx, x, group, splits, cpad):
+        x = x.contiguous()
+        N.check(x)
+        B, H, W, C = x.shape
+        out = torch.empty((B, H, W, cpad), device=x.device, dtype=x.dtype)
+        scratch = torch.empty(64 * max(1, B // group), device=x.device, dtype=torch.float32)
+        N.call("dgv2_mbstd_cat_fwd", N.ptr(out), N.ptr(scratch), N.ptr(x), B, H * W, C, cpad, splits, group, _dt(x),
+               N.stream())
+        ctx.save_for_backward(x)
+        ctx.cfg = (group, splits, cpad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        group, splits, cpad = ctx.cfg
+        B, H, W, C = x.shape
+        if torch.is_grad_enabled():
+            # create_graph=True (e.g. an R1 penalty taken through this path): the same gradient from differentiable ops
+            m = B // (splits * group)
+            xf, gf = x.float(), g.float()
+            y = xf.reshape(splits, group, m, H, W, C)
+            d = y - y.mean(1, keepdim=True)
+            sd = torch.sqrt((d * d).mean(1, keepdim=True) + 1e-8)
+            gst = gf[..., C].reshape(splits, group, m, H * W).sum(dim=(1, 3))
+            term = gst[:, None, :, None, None, None] / float(H * W * C) * d / (group * sd)
+            return (gf[..., :C] + term.reshape(B, H, W, C)).to(x.dtype), None, None, None
+        g = g.contiguous().to(x.dtype)
+        gx = torch.empty_like(x)
+        N.call("dgv2_mbstd_cat_bwd", N.ptr(gx), N.ptr(g), N.ptr(x), B, H * W, C, cpad, splits, group, _dt(x), N.stream())
+        return gx, None, None, None
+
+
+def mbstd_cat_ok(x, group, splits, features, cpad):
+    vn = 8 if x.dtype == torch.bfloat16 else 4
+    B, C = x.shape[0], x.shape[3]
+    g = min(B // splits, group)
+    return (x.is_cuda and features == 1 and x.dtype in (torch.bfloat16, torch.float32) and C % vn == 0 and cpad % vn == 0
+            and cpad > C and 1 <= g <= 8 and B % (splits * g) == 0)
+
+
+def mbstd_cat(x, group, splits, cpad):
+    """x [B,H,W,C] -> [B,H,W,cpad]: x, then the per-sample minibatch-stddev statistic in channel C, then zeros."""
+    g = min(x.shape[0] // splits, group)
+    return _MbstdCat.apply(x, g, splits, cpad)
+
+
+class _ScaledHandle(Function):
+    """Differentiable stand-in for `param * scale` laid out [O,kh,kw,C] whose VALUES are never read: with the
+    weight bank the conv kernels take the prepared compute-dtype copies, and this tensor only carries the autograd
+    edge back to the parameter (backward: grad * scale in parameter layout).  Saves the forward scaling launch."""
+
+    @staticmethod
+    def forward(ctx, param, scale, cpad):
+        ctx.scale, ctx.C = scale, param.shape[1]
+        O, C, kh, kw = param.shape
+        # uninitialised on purpose (no launch): see the class docstring; cpad >= C input channels (zero-padded K)
+        return torch.empty((O, kh, kw, max(C, cpad)), device=param.device, dtype=param.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        # contiguous result in the parameter's layout (one strided-read launch): AccumulateGrad can then adopt the
+        # tensor instead of cloning a permuted one
+        gp = g[..., :ctx.C].permute(0, 3, 1, 2)
+        out = torch.empty(gp.shape, device=g.device, dtype=g.dtype)
+        return torch.mul(gp, ctx.scale, out=out), None, None
+
+
+def scaled_handle(param, scale, cpad=0):
+    h = _ScaledHandle.apply(param, float(scale), int(cpad))
+    h._dgv2_handle = True
+    return h
+
+
+def conv_weight_bank(entries, dtype):
+    """entries: list of (param fp32 [O,C,kh,kw], scale, Cpad).  One launch; returns [(wf [O,kh*kw,Cpad], wt
+    [Cpad,kh*kw,O])] in `dtype` (views of two flat buffers)."""
+    L = len(entries)
+    dev = entries[0][0].device
+    dims = [(p.shape[0], p.shape[1], int(cp), p.shape[2] * p.shape[3]) for p, _, cp in entries]
+    sizes = [o * kk * cp for o, _, cp, kk in dims]
+    flat_f = torch.empty(sum(sizes), device=dev, dtype=dtype)
+    flat_t = torch.empty(sum(sizes), device=dev, dtype=dtype)
+    wfs, wts, off = [], [], 0
+    for (o, c, cp, kk), n in zip(dims, sizes):
+        wfs.append(flat_f[off:off + n].view(o, kk, cp))
+        wts.append(flat_t[off:off + n].view(cp, kk, o))
+        off += n
+    srcs = [p.detach() for p, _, _ in entries]
+    N.check(*srcs)
+    N.call("dgv2_conv_weight_bank", _ptr_array(wfs), _ptr_array(wts), _ptr_array(srcs), _int_array([d[0] for d in dims]),
+           _int_array([d[1] for d in dims]), _int_array([d[2] for d in dims]), _int_array([d[3] for d in dims]),
+           (_ct.c_float * L)(*[float(s) for _, s, _ in entries]), L, N.dtype_code(flat_f), N.stream())
+    return list(zip(wfs, wts))
+
+
+class _ConvActFork(Function):
+    """(lrelu(conv(x, w) + b) * scale, x): the second output hands the SAME input on to a sibling branch (the skip
+    path of ResidualBlock), so that in backward both gradients of x arrive here together and the sibling's is added
+    in the epilogue of this conv's data-gradient kernel -- no separate fork-point add over the activation."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, alpha, scale):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
+        if wc is None:
+            wc = _values(w, x.dtype)
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
+        ctx.save_for_backward(x, w, out)
+        ctx.cfg = (g, alpha, scale, bias.numel())
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gx_sibling):
+        x, w, out = ctx.saved_tensors
+        g, alpha, scale, size_b = ctx.cfg
+        if gy is None:   # only the sibling branch carries a gradient
+            return gx_sibling, None, None, None, None, None
+        gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        return gx, gw, gb, None, None, None
+
+
+def conv_ring_act_fork(x, w, bias, geom, alpha=0.2, scale=math.sqrt(2.0)):
+    return _ConvActFork.apply(x, w, bias, geom, float(alpha), float(scale))
+
+
+_ACTBWD_BLOCKS = {}
+
+
+_FUSED_ACTBWD = os.environ.get("DGV2_NO_FUSED_ACTBWD") is None   # A/B switch for benchmarking
+
+
+def _resample_actbwd(g, out, spec, in_hw, alpha, scale):
+    """(gpre, gb): adjoint of `spec` applied to g [B,Ho,Wo,C], then the backward of the bias + leaky-ReLU whose forward
+    output is `out` [B,H,W,C] -- one kernel (dgv2_resample_tab_actbwd); None where it does not apply."""
+    if not _FUSED_ACTBWD or g.dtype != out.dtype:
+        return None
+    B, H, W, C = out.shape
+    Ho, Wo = spec.out_size(H, W)
+    (ih_idx, ih_coef, ih_cnt, Eh), (iw_idx, iw_coef, iw_cnt, Ew) = spec.tables(H, W, True, g.device)
+    tabs = (N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt), Eh, N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew)
+    key = (B, H, W, C, Eh, Ew, _dt(g))
+    if key not in _ACTBWD_BLOCKS:
+        nb = _ct.c_int64(0)
+        ok = N.try_call("dgv2_resample_tab_actbwd", None, None, None, 0, _ct.addressof(nb), None, None, *tabs, B, C, Ho, Wo,
+                        H, W, alpha, scale, _dt(g), N.stream())
+        _ACTBWD_BLOCKS[key] = nb.value if ok else 0
+    nblk = _ACTBWD_BLOCKS[key]
+    if nblk == 0:
+        return None
+    g = g.contiguous()
+    N.check(g, out)
+    gpre = torch.empty_like(out)
+    gb = torch.empty(C, device=g.device, dtype=torch.float32)
+    scratch = torch.empty(nblk * C, device=g.device, dtype=torch.float32)
+    N.call("dgv2_resample_tab_actbwd", N.ptr(gpre), N.ptr(gb), N.ptr(scratch), scratch.numel(), None, N.ptr(g), N.ptr(out),
+           *tabs, B, C, Ho, Wo, H, W, alpha, scale, _dt(g), N.stream())
+    return gpre, gb
+
+
+class _ConvActDown(Function):
+    """resample(lrelu(conv(x, w) + b) * scale) [, x]: conv1 -> FusedLeakyReLU -> blur/down of ResidualBlock
+    (dusty_v2.py:325-345) as one autograd node, so that the backward can run the adjoint resampling and the
+    activation backward (+ bias gradient) in ONE pass over the full-resolution gradient instead of two, and (fork)
+    add the skip branch's gradient of x in the data-gradient epilogue.  First-order passes with the weight bank."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, alpha, scale, spec, fork):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
+        if wc is None:
+            wc = _values(w, x.dtype)
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
+        in_hw = (out.shape[1], out.shape[2])
+        y = _resample_raw(out, spec, False, in_hw)
+        ctx.save_for_backward(x, w, out)
+        ctx.cfg = (g, alpha, scale, bias.numel(), spec, in_hw)
+        return (y, x.view_as(x)) if fork else y
+
+    @staticmethod
+    def backward(ctx, gy, gx_sibling=None):
+        x, w, out = ctx.saved_tensors
+        g, alpha, scale, size_b, spec, in_hw = ctx.cfg
+        if gy is None:
+            return gx_sibling, None, None, None, None, None, None, None
+        fused = None if torch.is_grad_enabled() else _resample_actbwd(gy.to(out.dtype), out, spec, in_hw, alpha, scale)
+        if fused is not None:
+            gpre, gb = fused
+        else:   # composed (also the differentiable form for create_graph=True)
+            gh = _Resample.apply(gy, spec, True, in_hw)
+            gpre, gb = _BiasActBackward.apply(gh, out, True, alpha, scale, 1, size_b)
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale) if ctx.needs_input_grad[0] else gx_sibling
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        return gx, gw, gb, None, None, None, None, None
+
+
+def conv_ring_act_down(x, w, bias, geom, spec, alpha=0.2, scale=math.sqrt(2.0), fork=False):
+    return _ConvActDown.apply(x, w, bias, geom, float(alpha), float(scale), spec, bool(fork))
+
+
+class _ConvResid(Function):
+    """conv(x, w) + resid with the residual added in the conv epilogue (reference: the skip sum of
+    ResidualBlock.forward, dusty_v2.py:343-345)."""
+
+    @staticmethod
+    def forward(ctx, x, w, resid, g):
+        x = x.contiguous()
+        resid = resid.contiguous()
+        wc, ctx.wt = _bank(w, x)
+        ctx.gscale = getattr(w, "_dgv2_gscale", None)
+        if wc is None:
+            wc = _values(w, x.dtype)
+        ctx.save_for_backward(x, w)
+        ctx.g = g
+        return _conv_fwd_raw(x, wc.reshape(w.shape), g, resid=resid)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        return gx, gw, (gy if ctx.needs_input_grad[2] else None), None
+
+
+def conv_ring_resid(x, w, resid, geom):
+    return _ConvResid.apply(x, w, resid, geom)
+
+
+def conv_resid_ok(x, geom):
+    return _direct_ok(geom, x.shape[3] % _kstep(x) == 0)
+
+
+def conv_ring_act(x, w, bias, geom, alpha=0.2, scale=math.sqrt(2.0)):
+    return _ConvAct.apply(x, w, bias, geom, float(alpha), float(scale))
+
+__all__ = [n_ for n_ in dir() if not n_.startswith("__")]

@@ -1,0 +1,232 @@
+"""native.misc: KITTI projection, fused non-saturating objective, conv1 with the up-sampling commuted past the contraction.
+
+Part of gans.models.ops.native (autograd-aware wrappers around the libdgv2 C ABI, see the package docstring); the
+parts import each other in order, every name stays reachable as native.<name>.
+"""
+import math
+import os
+
+import torch
+from torch.autograd import Function
+
+import dgv2_native as N
+from .act_resample import *  # noqa: F401,F403
+from .modgemm import *  # noqa: F401,F403
+from .conv import *  # noqa: F401,F403
+from .stem_tail_ada import *  # noqa: F401,F403
+from .modlayer import *  # noqa: F401,F403
+
+
+# ---------------------------------------------------------------------------------------
+# KITTI scan -> range image (dgv2_kitti_project; reference: gans/datasets/kitti.py:264-279,317-370)
+# ---------------------------------------------------------------------------------------
+def kitti_project(points, rows, H, W, Wout, min_depth, max_depth, apply_mask=True):
+    """points fp32 [n,4] CUDA; rows int32 [n] (scan-unfolding ring index per point) or None (pitch-angle rows).
+    -> fp32 [6, H, Wout]: x, y, z, reflectance, depth, mask of the nearest point of pixel (h, w * W / Wout)."""
+    n = points.shape[0]
+    out = torch.empty((6, H, Wout), device=points.device, dtype=torch.float32)
+    key = torch.empty(H * W, device=points.device, dtype=torch.int64)
+    N.check(points, rows)
+    N.call("dgv2_kitti_project", N.ptr(out), N.ptr(key), N.ptr(points), N.ptr(rows), n, H, W, Wout, float(min_depth),
+           float(max_depth), int(apply_mask), N.stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# non-saturating GAN objective + logged statistics in one launch (dgv2_nsgan_loss)
+# ---------------------------------------------------------------------------------------
+class _NsganLoss(Function):
+    """loss = mean softplus(-y[:n_real]) + mean softplus(y[n_real:]); also returns (no gradient) the 4 statistics
+    [loss, mean y_real, mean y_fake, sum sign(y_real)].  First order only (the R1 penalty does not go through it)."""
+
+    @staticmethod
+    def forward(ctx, y, n_real):
+        yf = y.detach().float().contiguous().reshape(-1)
+        n = yf.numel()
+        stats = torch.empty(4, device=y.device, dtype=torch.float32)
+        gy = torch.empty(n, device=y.device, dtype=torch.float32)
+        N.check(yf)
+        N.call("dgv2_nsgan_loss", N.ptr(stats), N.ptr(gy), N.ptr(yf), int(n_real), n - int(n_real), N.stream())
+        ctx.save_for_backward(gy)
+        ctx.shape, ctx.dtype = y.shape, y.dtype
+        ctx.mark_non_differentiable(stats)
+        return stats[0].clone(), stats
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (gy,) = ctx.saved_tensors
+        return (gy * g).reshape(ctx.shape).to(ctx.dtype), None
+
+
+def nsgan_loss(y, n_real):
+    """(loss, stats[4]) for logits y [n,1] with the first n_real rows judged as real (see _NsganLoss)."""
+    return _NsganLoss.apply(y, n_real)
+
+
+# ---------------------------------------------------------------------------------------
+# conv1 of a generator level with the block's up-sampling COMMUTED past the contraction (csrc/modconv_up.hip):
+#   y = act(c * (W_a . up2(h) + W_s . PE) + bias)  ==  act(c * (up2(W_a . h) + W_s . PE) + bias)
+# forward: t = W_a . h at the previous level's resolution (dgv2_bmm_nn), then dgv2_modconv_up_fwd;
+# backward: g_acc = act'(gy) * c;  g_t = up2^T(g_acc) (adjoint FIR on O instead of Ka channels);  g_h = W_a^T g_t and
+#           dW_a = g_t^T h at the LOW resolution;  dW_s = g_acc^T PE as before.
+# ---------------------------------------------------------------------------------------
+_UP_COMMUTE = os.environ.get("DGV2_NO_UP_COMMUTE") is None   # A/B switch for benchmarking
+
+
+_UP_TABLES = {}
+
+
+def _up_tables(spec, hl, wl, device):
+    """Two-tap tables (low-res index, weight) per output row / column of an up-2 Resample, zero-padded to two taps."""
+    key = (id(spec), hl, wl, str(device))
+    if key not in _UP_TABLES:
+        (ih, ch, _, Eh), (iw, cw, _, Ew) = spec.tables(hl, wl, False, device)
+        if Eh > 2 or Ew > 2:
+            return None
+
+        def two(idx, coef, E):
+            if E == 2:
+                return idx.contiguous(), coef.contiguous()
+            return (torch.cat([idx, torch.zeros_like(idx)], dim=1).contiguous(),
+                    torch.cat([coef, torch.zeros_like(coef)], dim=1).contiguous())
+        _UP_TABLES[key] = two(ih, ch, Eh) + two(iw, cw, Ew)
+    return _UP_TABLES[key]
+
+
+def mod_up_ok(h, xs, wb, spec):
+    return bool(_UP_COMMUTE and h is not None and xs is not None and h.is_cuda and h.dtype == torch.bfloat16
+                and wb.shape[1] == 32 and xs.shape[3] == 512 and h.shape[3] % 8 == 0
+                and tuple(a[1] for a in spec.axes) == (2, 2) and tuple(a[2] for a in spec.axes) == (1, 1)
+                and spec.out_size(h.shape[1], h.shape[2]) == tuple(xs.shape[1:3]))
+
+
+def resample_sq_only(x, spec):
+    """fp32 partial sums of squares of resample(x, spec) WITHOUT materialising it (the input statistic of the
+    modulated conv, style.py:98-103, when the up-sampling itself was commuted away)."""
+    x = x.contiguous()
+    B, H, W = x.shape[:3]
+    Ho, Wo = spec.out_size(H, W)
+    (ih_idx, ih_coef, ih_cnt, Eh), (iw_idx, iw_coef, iw_cnt, Ew) = spec.tables(H, W, False, x.device)
+    sq = _sq_args(x.device)
+    C = x.shape[3]
+    N.check(x)
+    N.call("dgv2_resample_tab_sq", None, N.ptr(x), N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt), Eh, N.ptr(iw_idx),
+           N.ptr(iw_coef), N.ptr(iw_cnt), Ew, B, C, C, C, H, W, Ho, Wo, _dt(x), N.ptr(sq[0]), _SQ_CAP,
+           _ct.addressof(sq[1]), N.stream())
+    return sq[0][:sq[1].value]
+
+
+class _ModUpPrepared(Function):
+    @staticmethod
+    def forward(ctx, cfg, h, xs, bias, handle, wb, cvec, wt):
+        ctx.set_materialize_grads(False)
+        spec = cfg["spec"]
+        h = h.contiguous()
+        xs = xs.contiguous()
+        dt = h.dtype
+        B, Otot, I = wb.shape
+        hl, wl, Ka = h.shape[1:]
+        H, W_ = xs.shape[1:3]
+        Ks = xs.shape[3]
+        dev = h.device
+        act = 3 if cfg["act"] else 0
+        bias32 = None if bias is None else bias.detach().float().contiguous()
+        wa = wb[:, :, :Ka].contiguous()
+        t = _bmm_nn_raw(h.reshape(B, hl * wl, Ka), wa, dt)                       # [B, hl*wl, O]
+        ih, ch, iw, cw = _up_tables(spec, hl, wl, dev)
+        sq = _sq_args(dev) if (cfg["want_sq"] and _FUSED_SQ) else None
+        out = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
+        N.check(t, xs, wb, bias32, cvec)
+        N.call("dgv2_modconv_up_fwd", N.ptr(out), N.ptr(t), N.ptr(xs), N.ptr(wb), B, H, W_, hl, wl, Ks, Otot, I, Ka,
+               N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(cvec), N.ptr(bias32), act, cfg["alpha"], cfg["scale"],
+               _dt(h), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None,
+               N.stream())
+        ctx.cfg = dict(cfg, has_bias=bias is not None)
+        ctx.save_for_backward(h, xs, wb, out if cfg["act"] else None, cvec, wt)
+        if cfg["want_sq"]:
+            part = sq[0][:sq[1].value] if (sq is not None and sq[1].value > 0) else sum_squares(out)
+            ctx.mark_non_differentiable(part)
+            return out, part
+        return out
+
+    @staticmethod
+    def backward(ctx, gy, *rest):
+        cfg = ctx.cfg
+        if gy is None:
+            return (None,) * 8
+        h, xs, wb, out, cvec, wt = ctx.saved_tensors
+        spec = cfg["spec"]
+        B, Otot, I = wb.shape
+        dt = wb.dtype
+        gy = gy.contiguous()
+        H, W_ = gy.shape[1:3]
+        hl, wl, Ka = h.shape[1:]
+        P = H * W_
+        dev = gy.device
+        # accumulator gradient (c[o] applied) and bias gradient: the activation backward of _ModGemmPrepared
+        gb = None
+        vn = 8 if gy.dtype == torch.bfloat16 else 4
+        rows = gy.numel() // Otot
+        gpre = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
+        if cfg["act"] and gy.dtype == dt and Otot % vn == 0 and 256 % (Otot // vn) == 0:
+            gb = torch.empty(Otot, device=dev, dtype=torch.float32)
+            scratch = torch.empty(2048 * Otot, device=dev, dtype=torch.float32) if rows >= 65536 else None
+            N.call("dgv2_bias_act_bwd_rs", N.ptr(gpre), N.ptr(gb), N.ptr(gy), N.ptr(out), rows, Otot, cfg["alpha"],
+                   cfg["scale"], N.ptr(cvec), N.ptr(scratch), 0 if scratch is None else scratch.numel(), _dt(gy),
+                   N.stream())
+            if not cfg["has_bias"]:
+                gb = None
+        else:
+            g0 = gy
+            if cfg["act"]:
+                g0 = _bias_act_raw(gy, None, out, 1, cfg["alpha"], cfg["scale"], 1, Otot)
+            if cfg["has_bias"]:
+                gb = torch.empty(Otot, device=dev, dtype=torch.float32)
+                N.call("dgv2_bias_grad", N.ptr(gb), N.ptr(g0), g0.numel(), 1, Otot, _dt(g0), N.stream())
+            N.call("dgv2_scale_cast", N.ptr(gpre), N.ptr(g0), N.ptr(cvec), g0.numel(), Otot, _dt(g0), _dt(gpre),
+                   N.stream())
+        g3 = gpre.reshape(B, P, Otot)
+        need_h, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[4]
+        gh = gwb = None
+        if need_h or need_w:
+            gt = _resample_raw(gpre, spec, True, (hl, wl))                       # up2^T: [B, hl, wl, O]
+            gt3 = gt.reshape(B, hl * wl, Otot)
+            if need_h:
+                if wt is None:
+                    wt = wb[:, :, :Ka].transpose(1, 2).contiguous()
+                gh = _bmm_nn_raw(gt3, wt, h.dtype).reshape(h.shape)
+            if need_w:
+                h3 = h.reshape(B, hl * wl, Ka)
+                if _TN_STREAM and Ka % 8 == 0 and Otot % 8 == 0 and hl * wl >= 2048:
+                    gwa = _bmm_tn_stream(gt3, h, B, hl, wl, Ka, Otot)
+                else:
+                    gwa = torch.empty((B, Otot, Ka), device=dev, dtype=torch.float32)
+                    N.call("dgv2_bmm_tn", N.ptr(gwa), N.ptr(gt3), N.ptr(h3), B, hl * wl, Ka, Otot, Otot, Ka, _dt(h),
+                           N.stream())
+                gws = _mod_wgrad(g3, None, xs, B, H, W_, xs.shape[3], Otot, dt)   # PE columns at full resolution
+                gwb = torch.cat([gwa, gws], dim=2)
+        return None, gh, None, gb, gwb, None, None, None
+
+
+def mod_up_layer(h, xs, spec, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), want_sq=False,
+                 wt=None):
+    """conv1 of a generator level on the batch-shared PE, taking the level's LOW-resolution input h and the block's
+    up-2 Resample spec (see _ModUpPrepared); same result as mod_gemm_layer(resample(h), xs, ...)."""
+    cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0, want_sq=bool(want_sq), spec=spec)
+    return _ModUpPrepared.apply(cfg, h, xs, bias, handle, wb, cvec, wt)
+
+
+def mod_gemm_layer(xa, xs, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=None,
+                   want_sq=False, wt=None, fork=False, defer=None, upstream=None):
+    """defer: a dict shared with the ONE consumer of this layer's output (a head in fork form); when that consumer
+    ran this layer's activation backward inside its own data-gradient kernel it marks the dict and this layer's
+    backward skips its own pass.  upstream: the consumer's side of the same link (see _head_dgrad_actbwd).
+    The contraction of a modulated layer whose weights came from mod_prep_all (handle, wb) and whose
+    input-magnitude factor is cvec fp32 [Otot] (native.ema_update(..., cvec=...))."""
+    ref = xa if xa is not None else xs
+    cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0,
+               out_dtype=ref.dtype if out_dtype is None else out_dtype, want_sq=bool(want_sq),
+               fork=bool(fork and xa is not None and xa.requires_grad), defer=defer, upstream=upstream)
+    return _ModGemmPrepared.apply(cfg, xa, xs, bias, handle, wb, cvec, wt)
+
+__all__ = [n_ for n_ in dir() if not n_.startswith("__")]

@@ -1,0 +1,358 @@
+"""native.modgemm: style affines as one batched GEMM, level input (up-2 next to the PE), batched channel GEMM of the modulated 1x1 conv.
+
+Part of gans.models.ops.native (autograd-aware wrappers around the libdgv2 C ABI, see the package docstring); the
+parts import each other in order, every name stays reachable as native.<name>.
+"""
+import math
+import os
+
+import torch
+from torch.autograd import Function
+
+import dgv2_native as N
+from .act_resample import *  # noqa: F401,F403
+
+
+# ---------------------------------------------------------------------------------------
+# all style affines of the generator as one batched GEMM (reference: ModConv2d.mod, style.py:30,75)
+# ---------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    return (_ct.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def _int_array(vals):
+    return (_ct.c_int * len(vals))(*[int(v) for v in vals])
+
+
+class _Pack2d(Function):
+    """[L, Rmax, Cmax] zero-padded stack of the 2-D fp32 tensors `ts` (one launch); backward = _Unpack2d."""
+
+    @staticmethod
+    def forward(ctx, Rmax, Cmax, *ts):
+        ts = [t.detach().float().contiguous() for t in ts]
+        rows, cols = [t.shape[0] for t in ts], [t.shape[1] for t in ts]
+        out = torch.empty((len(ts), Rmax, Cmax), device=ts[0].device, dtype=torch.float32)
+        N.call("dgv2_pack2d", N.ptr(out), _ptr_array(ts), _int_array(rows), _int_array(cols), len(ts), Rmax, Cmax,
+               N.stream())
+        ctx.cfg = (rows, cols)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, cols = ctx.cfg
+        return (None, None) + tuple(_Unpack2d.apply(g, tuple(rows), tuple(cols)))
+
+
+class _Unpack2d(Function):
+    """The blocks [:rows[l], :cols[l]] of a packed [L, Rmax, Cmax] tensor as L contiguous tensors (one launch)."""
+
+    @staticmethod
+    def forward(ctx, packed, rows, cols):
+        packed = packed.contiguous()
+        L, Rmax, Cmax = packed.shape
+        outs = [torch.empty((rows[l], cols[l]), device=packed.device, dtype=torch.float32) for l in range(L)]
+        N.call("dgv2_unpack2d", _ptr_array(outs), N.ptr(packed), _int_array(rows), _int_array(cols), L, Rmax, Cmax,
+               N.stream())
+        ctx.cfg = (Rmax, Cmax, rows, cols)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        Rmax, Cmax, rows, cols = ctx.cfg
+        dev = next(g.device for g in gs if g is not None)
+        gs = [None if g is None else g.contiguous().float() for g in gs]
+        out = torch.empty((len(gs), Rmax, Cmax), device=dev, dtype=torch.float32)
+        N.call("dgv2_pack2d", N.ptr(out), _ptr_array(gs), _int_array(rows), _int_array(cols), len(gs), Rmax, Cmax,
+               N.stream())
+        return out, None, None
+
+
+_KIDX_CACHE = {}
+
+
+def style_affines(ws, weights, biases, kidx, scale):
+    """styles[l] = (ws[:, kidx[l]] @ weights[l].T) * scale + biases[l] for all l at once.
+    ws [B,S,K] fp32; weights[l] [I_l,K]; biases[l] [I_l] -> list of contiguous [B, I_l]."""
+    B, S, K = ws.shape
+    L = len(weights)
+    Is = [w.shape[0] for w in weights]
+    Imax = max(Is)
+    Wp = _Pack2d.apply(Imax, K, *weights)
+    bp = _Pack2d.apply(1, Imax, *[b.reshape(1, -1) for b in biases])
+    key = (tuple(kidx), str(ws.device))
+    if key not in _KIDX_CACHE:
+        _KIDX_CACHE[key] = torch.tensor(list(kidx), device=ws.device, dtype=torch.long)
+    X = ws.float().transpose(0, 1).index_select(0, _KIDX_CACHE[key])           # [L,B,K]
+    Sout = torch.baddbmm(bp, X, Wp.transpose(1, 2), alpha=float(scale))         # [L,B,Imax]
+    return list(_Unpack2d.apply(Sout, tuple([B] * L), tuple(Is)))
+
+
+def lerp_list(dst, src, weight):
+    """dst[i] <- lerp(dst[i], src[i], weight) for lists of fp32 tensors, 72 per launch (the G_ema update)."""
+    for i in range(0, len(dst), 72):
+        d, s_ = dst[i:i + 72], src[i:i + 72]
+        N.check(*d, *s_)
+        N.call("dgv2_lerp_list", _ptr_array(d), _ptr_array(s_), _int_array([t.numel() for t in d]), len(d),
+               float(weight), N.stream())
+
+
+def fused_adam_step(opt):
+    """One step of a torch.optim.Adam instance (single param group, no weight decay / amsgrad / maximize) on the
+    dgv2 kernels: the optimizer object, its hyper-parameters and its state_dict stay torch's, only the arithmetic
+    moves (1 + ceil(L/72) launches at HBM speed instead of torch's multi-tensor kernels).  The per-parameter
+    `step` entries alias ONE device counter."""
+    (group,) = opt.param_groups
+    if group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
+        raise RuntimeError("dgv2 fused Adam: unsupported optimizer options")
+    params = [p for p in group["params"] if p.grad is not None]
+    if not params:
+        return
+    dev = params[0].device
+    shared = getattr(opt, "_dgv2_step", None)
+    if shared is None:
+        shared = torch.zeros(1, device=dev, dtype=torch.float32)
+        opt._dgv2_step = shared
+        opt._dgv2_sc = torch.zeros(4, device=dev, dtype=torch.float32)
+    for p in params:
+        st = opt.state[p]
+        if len(st) == 0:
+            st["step"] = shared.view(())
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        elif st["step"].data_ptr() != shared.data_ptr():      # state came from load_state_dict: adopt its counter
+            shared.copy_(st["step"].reshape(1).to(dev, torch.float32))
+            st["step"] = shared.view(())
+    b1, b2 = group["betas"]
+    N.call("dgv2_adam_prep", N.ptr(opt._dgv2_sc), N.ptr(shared), float(b1), float(b2), N.stream())
+    for i in range(0, len(params), 72):
+        ch = params[i:i + 72]
+        ms = [opt.state[p]["exp_avg"] for p in ch]
+        vs = [opt.state[p]["exp_avg_sq"] for p in ch]
+        gs = [p.grad for p in ch]
+        N.check(*ch, *gs, *ms, *vs)
+        N.call("dgv2_adam_step", _ptr_array(ch), _ptr_array(gs), _ptr_array(ms), _ptr_array(vs),
+               _int_array([p.numel() for p in ch]), len(ch), N.ptr(opt._dgv2_sc), float(group["lr"]), float(b1),
+               float(b2), float(group["eps"]), N.stream())
+
+
+def ema_update(ema, sumsq, add, count, weight, update=True, cvec=None):
+    """ModConv2d's input-magnitude EMA (style.py:98-103) in one scalar launch: updates the 0-dim buffer `ema`
+    in place with lerp(ema, (sumsq + add) / count, weight) and returns a fresh [1] snapshot of its value.
+    cvec (fp32 [n], optional): filled with the layer's output factor 1/(sqrt(ema)+1e-8) instead (returns cvec)."""
+    snap = None if cvec is not None else torch.empty(1, device=ema.device, dtype=torch.float32)
+    N.call("dgv2_ema_scalar", N.ptr(ema), N.ptr(snap), N.ptr(sumsq), 0 if sumsq is None else sumsq.numel(), float(add),
+           1.0 / float(count), float(weight), int(update), N.ptr(cvec), 0 if cvec is None else cvec.numel(), N.stream())
+    return snap if cvec is None else cvec
+
+
+# ---------------------------------------------------------------------------------------
+# level input of the generator: FIR up-2 of h written next to the positional encoding
+# (reference: SynthesisBlock.forward, gans/models/dusty_v2.py:153-159 -- resample + cat)
+# ---------------------------------------------------------------------------------------
+class _UpCatPE(Function):
+    @staticmethod
+    def forward(ctx, h, spec, angle, shift, freqs2, phase, dtype, B):
+        F2 = 2 * phase.numel()
+        if h is None:
+            H, W = angle.shape[2:]
+            Cin = 0
+        else:
+            h = h.contiguous()
+            B = h.shape[0]
+            Cin = h.shape[3]
+            H, W = spec.out_size(h.shape[1], h.shape[2])
+        x1 = torch.empty((B, H, W, Cin + F2), device=angle.device, dtype=dtype)
+        if h is not None:
+            _resample_raw(h, spec, False, (h.shape[1], h.shape[2]), out=x1, ldy=Cin + F2)
+        fourier_feature_into(x1, Cin, angle, shift, freqs2, phase)
+        ctx.cfg = (spec, None if h is None else (h.shape[1], h.shape[2]), Cin)
+        return x1
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, in_hw, Cin = ctx.cfg
+        if in_hw is None:
+            return (None,) * 8
+        g = g.contiguous()
+        gh = _resample_raw(g, spec, True, in_hw, ldx=g.shape[3], C=Cin)
+        return gh, None, None, None, None, None, None, None
+
+
+def up_cat_pe(h, spec, angle, shift, freqs2, phase, dtype, B):
+    """[B,H,W,Cin+2F] = cat(FIR-up2(h), PE(angle (+shift on azimuth))) without a concat pass."""
+    return _UpCatPE.apply(h, spec, angle, shift, freqs2, phase, dtype, B)
+
+
+# ---------------------------------------------------------------------------------------
+# batched channel GEMM = contraction of the modulated 1x1 conv
+# (reference: grouped F.conv2d in ModConv2d.forward, gans/models/ops/style.py:105-118)
+# ---------------------------------------------------------------------------------------
+def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=None, row_scale=None, resid=None):
+    """x3 [B,P,I]; w3 [Bw,O,I] (Bw = B or 1) same dtype -> [B,P,O]; optional fused
+    bias (fp32 [O]) + leaky-ReLU epilogue.  sq = _sq_args(): sum-of-squares partials where the kernel has them."""
+    B, P, I = x3.shape
+    Bw, O, _ = w3.shape
+    N.check(x3, w3, bias)
+    y = torch.empty((B, P, O), device=x3.device, dtype=out_dtype)
+    if I <= 4 and Bw == B and bias is None and act == 0 and sq is None and row_scale is None and out_dtype == x3.dtype:
+        # contraction over the <= 4 channels of the output heads (their data gradient): outer-product stream
+        r = None if resid is None else resid.contiguous().to(out_dtype)
+        if N.try_call("dgv2_bmm_nn_small", N.ptr(y), N.ptr(x3), N.ptr(w3), N.ptr(r), B, P, I, O, _dt(x3), N.stream()):
+            return y
+    if (resid is None and _PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and P >= 4096
+            and (I, O) in ((64, 32), (32, 64), (128, 64), (64, 128), (32, 32), (64, 64))):
+        # streaming shapes of the two top levels: sample-walking kernel without a PE part
+        if sq is not None or row_scale is not None:
+            N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(row_scale),
+                   N.ptr(bias), act, alpha, scale, _dt(x3), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0,
+                   _ct.addressof(sq[1]) if sq else None, N.stream())
+            return y
+        N.call("dgv2_modconv_pe_fwd", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(bias), act, alpha,
+               scale, _dt(x3), N.stream())
+        return y
+    if sq is not None or row_scale is not None or resid is not None:
+        if resid is not None:
+            resid = resid.contiguous().to(out_dtype)
+            N.check(resid)
+        N.call("dgv2_bmm_nn_sq", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
+               N.ptr(row_scale), N.ptr(bias), act, alpha, scale, N.ptr(resid), _dt(x3), N.dtype_code(y),
+               N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None, N.stream())
+        return y
+    N.call("dgv2_bmm_nn", N.ptr(y), N.ptr(x3), N.ptr(w3), B, P, I, O, I, O, 0 if Bw == 1 else O * I,
+           N.ptr(bias), act, alpha, scale, _dt(x3), N.dtype_code(y), N.stream())
+    return y
+
+
+def _bmm_tn_raw(gy3, x3):
+    """gy3 [B,P,O], x3 [B,P,I] -> fp32 [B,O,I]."""
+    B, P, O = gy3.shape
+    I = x3.shape[2]
+    N.check(gy3, x3)
+    gw = torch.empty((B, O, I), device=x3.device, dtype=torch.float32)
+    N.call("dgv2_bmm_tn", N.ptr(gw), N.ptr(gy3), N.ptr(x3), B, P, I, O, O, I, _dt(x3), N.stream())
+    return gw
+
+
+class _ModGemm(Function):
+    """y[b,p,o] = sum_i x[b,p,i] w[b,o,i]; w is an fp32 master ([B,O,I] or shared [1,O,I])."""
+
+    @staticmethod
+    def forward(ctx, x, w, out_dtype):
+        shp = x.shape
+        x3 = x.contiguous().reshape(shp[0], -1, shp[-1])
+        wc = _values(w, x.dtype)
+        y = _bmm_nn_raw(x3, wc, out_dtype)
+        ctx.save_for_backward(x3, wc)
+        ctx.cfg = (shp, w.shape[0] == 1)
+        return y.reshape(*shp[:-1], w.shape[1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x3, wc = ctx.saved_tensors
+        shp, shared = ctx.cfg
+        gy3 = gy.contiguous().reshape(x3.shape[0], -1, wc.shape[1]).to(x3.dtype)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = wc.transpose(1, 2).contiguous()
+            gx = _bmm_nn_raw(gy3, wt, x3.dtype).reshape(shp)
+        if ctx.needs_input_grad[1]:
+            if shared:
+                gw = _bmm_tn_raw(gy3.reshape(1, -1, gy3.shape[2]), x3.reshape(1, -1, x3.shape[2]))
+            else:
+                gw = _bmm_tn_raw(gy3, x3)
+        return gx, gw, None
+
+
+def mod_gemm(x, w, out_dtype=None):
+    return _ModGemm.apply(x, w, x.dtype if out_dtype is None else out_dtype)
+
+
+class _ModGemmAct(Function):
+    """lrelu(x @ w^T + b) * scale with the bias/activation fused into the GEMM epilogue
+    (reference: ModConv2d followed by FusedLeakyReLU, gans/models/dusty_v2.py:161-170)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, alpha, scale):
+        shp = x.shape
+        x3 = x.contiguous().reshape(shp[0], -1, shp[-1])
+        wc = _values(w, x.dtype)
+        out = _bmm_nn_raw(x3, wc, x.dtype, bias.detach().float().contiguous(), 3, alpha, scale)
+        ctx.save_for_backward(x3, wc, out)
+        ctx.cfg = (shp, w.shape[0] == 1, alpha, scale, bias.numel())
+        return out.reshape(*shp[:-1], w.shape[1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x3, wc, out = ctx.saved_tensors
+        shp, shared, alpha, scale, size_b = ctx.cfg
+        gpre, gb = _BiasActBackward.apply(gy.contiguous().reshape(out.shape), out, True, alpha, scale, 1, size_b)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _bmm_nn_raw(gpre, wc.transpose(1, 2).contiguous(), x3.dtype).reshape(shp)
+        if ctx.needs_input_grad[1]:
+            if shared:
+                gw = _bmm_tn_raw(gpre.reshape(1, -1, gpre.shape[2]), x3.reshape(1, -1, x3.shape[2]))
+            else:
+                gw = _bmm_tn_raw(gpre, x3)
+        return gx, gw, gb, None, None
+
+
+def mod_gemm_act(x, w, bias, alpha=0.2, scale=math.sqrt(2.0)):
+    return _ModGemmAct.apply(x, w, bias, float(alpha), float(scale))
+
+
+class _ModGemmCatAct(Function):
+    """Level-input conv with a batch-shared positional encoding (dgv2_bmm_nn_cat / dgv2_bmm_tn_cat):
+    out = lrelu([xa | xs] @ w^T + b) * scale, xa [B,H,W,Ka] per sample (or None), xs [1,H,W,Ks] shared."""
+
+    @staticmethod
+    def forward(ctx, xa, xs, w, bias, alpha, scale):
+        B, O = w.shape[0], w.shape[1]
+        _, H, W_, Ks = xs.shape
+        Ka = 0 if xa is None else xa.shape[3]
+        xs = xs.contiguous()
+        xa = None if xa is None else xa.contiguous()
+        wc = w.detach().to(xs.dtype).contiguous()
+        bias32 = bias.detach().float().contiguous()
+        N.check(xa, xs, wc, bias32)
+        out = torch.empty((B, H, W_, O), device=xs.device, dtype=xs.dtype)
+        N.call("dgv2_bmm_nn_cat", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wc), B, H * W_, Ka, Ks, O, N.ptr(bias32),
+               3, alpha, scale, _dt(xs), _dt(xs), N.stream())
+        ctx.save_for_backward(xa, xs, wc, out)
+        ctx.cfg = (alpha, scale, Ka, Ks)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        xa, xs, wc, out = ctx.saved_tensors
+        alpha, scale, Ka, Ks = ctx.cfg
+        B, H, W_, O = out.shape
+        gpre, gb = _BiasActBackward.apply(gy.contiguous(), out, True, alpha, scale, 1, O)
+        gxa = gw = None
+        g3 = gpre.reshape(B, H * W_, O)
+        if xa is not None and ctx.needs_input_grad[0]:
+            wt = wc[:, :, :Ka].transpose(1, 2).contiguous()  # only the activation channels need a data gradient
+            gxa = _bmm_nn_raw(g3, wt, xa.dtype).reshape(xa.shape)
+        if ctx.needs_input_grad[2]:
+            gw = torch.empty((B, O, Ka + Ks), device=out.device, dtype=torch.float32)
+            N.call("dgv2_bmm_tn_cat", N.ptr(gw), N.ptr(g3), N.ptr(xa), N.ptr(xs), B, H * W_, Ka, Ks, O, _dt(xs),
+                   N.stream())
+        return gxa, None, gw, gb, None, None
+
+
+def mod_gemm_cat_act(xa, xs, w, bias, alpha=0.2, scale=math.sqrt(2.0)):
+    return _ModGemmCatAct.apply(xa, xs, w, bias, float(alpha), float(scale))
+
+
+_PE_FWD = os.environ.get("DGV2_NO_PE_FWD") is None               # A/B switch for benchmarking
+
+
+def _values(w, dtype):
+    """Compute-dtype VALUES of a conv weight; a weight-bank handle has none (its prepared copies did not match
+    this call: wrong dtype, or a second-order pass that must run with the bank off)."""
+    if getattr(w, "_dgv2_handle", False):
+        raise RuntimeError("conv weight handle without values: run this pass without the weight bank "
+                           "(Discriminator.forward(double_backward=True))")
+    return w.detach().to(dtype).contiguous()
+
+__all__ = [n_ for n_ in dir() if not n_.startswith("__")]
