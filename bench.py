@@ -207,6 +207,12 @@ def modconv_probe(args, reps=20):
                                         N.ptr(bias), 3, 0.2, 2.0 ** 0.5, N.BF16, None, 0, None, N.stream()), reps)
     sec_lo = _time_launches(lambda: native._bmm_nn_raw(h.reshape(B, hl * wl, Ka), w[:, :, :Ka].contiguous(), bf), reps)
     sec_sq = _time_launches(lambda: native.resample_sq_only(h, spec), reps)
+    # the same layer on the un-commuted kernel (dgv2_modconv_pe_fwd on a materialised up2(h): the full K = Ka + Ks
+    # contraction in one launch; levels 3 and 2 run this kernel in the training step)
+    hup = native._resample_raw(h, spec, False, (hl, wl))
+    sec_pe = _time_launches(lambda: N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(hup), N.ptr(xs), N.ptr(w), B, P, Ka, Ks, O,
+                                           N.ptr(cvec), N.ptr(bias), 3, 0.2, 2.0 ** 0.5, N.BF16, None, 0, None, N.stream()),
+                            reps)
     flops = 2.0 * B * P * Ks * O
     nbytes = (B * P * O + B * hl * wl * O + P * Ks + B * O * Ks) * 2
     ach = flops / sec / 1e12
@@ -218,7 +224,10 @@ def modconv_probe(args, reps=20):
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6,
             "algorithmic_hbm_GBps": nbytes / sec / 1e9,
             "layer_tflops": 2.0 * B * P * (Ka + Ks) * O / (sec + sec_lo + sec_sq) / 1e12,
-            "layer_us": {"modconv_up": sec * 1e6, "lowres_gemm": sec_lo * 1e6, "statistic_pass": sec_sq * 1e6}}
+            "layer_us": {"modconv_up": sec * 1e6, "lowres_gemm": sec_lo * 1e6, "statistic_pass": sec_sq * 1e6},
+            "uncommuted_modconv_pe_fwd": {"avg_launch_us": sec_pe * 1e6,
+                                          "tflops": 2.0 * B * P * (Ka + Ks) * O / sec_pe / 1e12,
+                                          "frac": 2.0 * B * P * (Ka + Ks) * O / sec_pe / 1e12 / MFMA_BF16_PEAK_TFLOPS}}
 
 
 def build_trainer(args, rank, world, d_epilogue=None):
