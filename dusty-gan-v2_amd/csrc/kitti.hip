@@ -63,6 +63,80 @@ __global__ __launch_bounds__(256) void kitti_gather_kernel(float* __restrict__ o
   }
 }
 
+// Ring index per point from the scan order (kitti.py:328-346): a ring starts where the azimuth passes from the 4th into
+// the 1st quadrant (quadrant of point i-1 minus quadrant of point i == 3, the sequence taken cyclically); with L
+// delimiters and seg = (number of delimiters at or before the point) - 1, the point's ring counted from the end is
+// back = (L - 1) - seg and its row (H - 1) - back; points before the first delimiter and rings older than the (H+1)-th
+// from the end get 0, the (H+1)-th gets -1 as in the reference.
+// Two launches over blocks of 4096 points: (1) delimiters per block, (2) every block adds up the counts of the blocks
+// before it (a few dozen values), scans its own lanes and writes the rows.  The quadrants of a block's points go
+// through LDS (coalesced loads, then each lane walks 16 consecutive points).
+constexpr int KR_BLOCK = 4096, KR_PER = 16;
+
+__device__ __forceinline__ int kitti_stage_and_count(unsigned char* s_q, const float* __restrict__ pts, int n, int base) {
+  for (int i = threadIdx.x; i <= KR_BLOCK; i += 256) {   // s_q[i] = quadrant of point base - 1 + i (cyclic)
+    int p = base - 1 + i;
+    p = p < 0 ? n - 1 : p;
+    unsigned char q = 0;
+    if (p < n) {
+      const float x = pts[4 * p], y = pts[4 * p + 1];
+      q = x >= 0.f ? (y >= 0.f ? 0 : 3) : (y >= 0.f ? 1 : 2);
+    }
+    s_q[i] = q;
+  }
+  __syncthreads();
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < KR_PER; ++j) {
+    const int i = threadIdx.x * KR_PER + j;
+    cnt += (base + i < n) && ((int)s_q[i] - (int)s_q[i + 1] == 3);
+  }
+  return cnt;
+}
+
+__global__ __launch_bounds__(256) void kitti_rows_count_kernel(int* __restrict__ counts, const float* __restrict__ pts, int n) {
+  __shared__ unsigned char s_q[KR_BLOCK + 1];
+  __shared__ int red[4];
+  int cnt = kitti_stage_and_count(s_q, pts, n, blockIdx.x * KR_BLOCK);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void kitti_rows_write_kernel(int* __restrict__ row, const int* __restrict__ counts,
+                                                               const float* __restrict__ pts, int n, int H) {
+  __shared__ unsigned char s_q[KR_BLOCK + 1];
+  __shared__ int wsum[4];
+  const int base = blockIdx.x * KR_BLOCK, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cnt = kitti_stage_and_count(s_q, pts, n, base);
+  int before = 0, L = 0;
+  for (int k = 0; k < (int)gridDim.x; ++k) {
+    const int c = counts[k];
+    before += k < (int)blockIdx.x ? c : 0;
+    L += c;
+  }
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int seen = before + inc - cnt;
+  for (int w = 0; w < wave; ++w) seen += wsum[w];
+#pragma unroll
+  for (int j = 0; j < KR_PER; ++j) {
+    const int i = threadIdx.x * KR_PER + j;
+    if (base + i >= n) break;
+    seen += ((int)s_q[i] - (int)s_q[i + 1] == 3);
+    const int seg = seen - 1, back = (L - 1) - seg;
+    row[base + i] = (seg >= 0 && back <= H) ? (H - 1) - back : 0;
+  }
+}
+
 __global__ void kitti_fill_kernel(unsigned long long* __restrict__ key, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) key[i] = ~0ull;
 }
@@ -78,5 +152,14 @@ extern "C" int dgv2_kitti_project(float* out, unsigned long long* key, const flo
   kitti_fill_kernel<<<grid_for((int64_t)H * W, 256, 1024), 256, 0, st>>>(key, (size_t)H * W);
   if (n > 0) kitti_scatter_kernel<<<grid_for(n, 256, 2048), 256, 0, st>>>(key, pts, row, n, H, W, row == nullptr);
   kitti_gather_kernel<<<grid_for((int64_t)H * Wout, 256, 1024), 256, 0, st>>>(out, key, pts, H, W, Wout, min_depth, max_depth, apply_mask);
+  DGV2_RETURN_LAST();
+}
+
+extern "C" int dgv2_kitti_rows(int* row, int* counts, const float* pts, int n, int H, void* stream) {
+  if (!row || !counts || !pts || n < 0 || H <= 0) return DGV2_EINVAL;
+  if (n == 0) return 0;
+  const int blocks = (n + KR_BLOCK - 1) / KR_BLOCK;
+  kitti_rows_count_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(counts, pts, n);
+  kitti_rows_write_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(row, counts, pts, n, H);
   DGV2_RETURN_LAST();
 }

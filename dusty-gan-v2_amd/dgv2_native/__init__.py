@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -49,6 +49,7 @@ SIGNATURES = {
     "dgv2_modconv_pe_fwd": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_modconv_pe_fwd_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                                _c_ptr],
+    "dgv2_kitti_rows": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr],
     "dgv2_kitti_project": [_c_ptr] * 4 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_fps_scratch": [_c_ptr, _c_int, _c_int],
     "dgv2_fps": [_c_ptr] * 3 + [_c_int] * 3 + [_c_ptr],

@@ -44,7 +44,7 @@ def project(points, shape=(64, 2048), min_depth=0.9, max_depth=120.0, scan_unfol
     """points [n,4] fp32 CUDA tensor -> [6, shape[0], shape[1]] (x, y, z, reflectance, depth, mask) * mask: the
     (H, W) projection of kitti.py:317-370 followed by the nearest resize + mask of :267-269."""
     points = points.float().contiguous()
-    rows = ring_rows(points[:, 0], points[:, 1], H) if scan_unfolding else None
+    rows = native.kitti_rows(points, H) if scan_unfolding else None   # one launch (ring_rows above: the same in tensor ops)
     h, w = int(shape[0]), int(shape[1])
     if W % w == 0:
         out = native.kitti_project(points, rows, H, W, w, min_depth, max_depth)
@@ -88,7 +88,7 @@ class KITTIRaw(torch.utils.data.Dataset):
     def load_pts_as_img(self, point_path, scan_unfolding=True, H=64, W=2048):
         """[H,W,6] numpy array like the reference's method (kitti.py:317-370; mask NOT applied to the other channels)."""
         pts = self.load_points(point_path)
-        rows = ring_rows(pts[:, 0], pts[:, 1], H) if scan_unfolding else None
+        rows = native.kitti_rows(pts.float().contiguous(), H) if scan_unfolding else None
         out = native.kitti_project(pts, rows, H, W, W, self.min_depth, self.max_depth, apply_mask=False)
         return out.permute(1, 2, 0).cpu().numpy()
 

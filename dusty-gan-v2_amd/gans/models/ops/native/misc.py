@@ -20,6 +20,17 @@ from .modlayer import *  # noqa: F401,F403
 # ---------------------------------------------------------------------------------------
 # KITTI scan -> range image (dgv2_kitti_project; reference: gans/datasets/kitti.py:264-279,317-370)
 # ---------------------------------------------------------------------------------------
+def kitti_rows(points, H):
+    """points fp32 [n,4] CUDA (file order) -> int32 [n] ring index per point (scan unfolding), see dgv2_kitti_rows."""
+    points = points.contiguous()
+    N.check(points)
+    n = points.shape[0]
+    rows = torch.empty(n, device=points.device, dtype=torch.int32)
+    counts = torch.empty((n + 4095) // 4096 + 1, device=points.device, dtype=torch.int32)
+    N.call("dgv2_kitti_rows", N.ptr(rows), N.ptr(counts), N.ptr(points), n, int(H), N.stream())
+    return rows
+
+
 def kitti_project(points, rows, H, W, Wout, min_depth, max_depth, apply_mask=True):
     """points fp32 [n,4] CUDA; rows int32 [n] (scan-unfolding ring index per point) or None (pitch-angle rows).
     -> fp32 [6, H, Wout]: x, y, z, reflectance, depth, mask of the nearest point of pixel (h, w * W / Wout)."""

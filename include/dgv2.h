@@ -534,6 +534,11 @@ int dgv2_nsgan_loss(float* stats, float* gy, const float* y, int n_real, int n_f
  * of pixel (h, w * W/Wout), multiplied by the mask (min_depth <= depth <= max_depth) when apply_mask (the item of
  * __getitem__; 0 = the raw projection of load_pts_as_img).  W % Wout == 0.
  * ------------------------------------------------------------------------- */
+/* ring index per point from the scan order (scan unfolding, gans/datasets/kitti.py:328-346): pts fp32 [n,4] in file order ->
+ * row int32 [n] as dgv2_kitti_project takes it (0 before the first ring boundary and for rings older than H + 1 from the
+ * end, -1 for the (H+1)-th from the end like the reference); counts: int32 scratch of ceil(n / 4096) entries (delimiters per
+ * block of 4096 points); two launches: count, then scan + write */
+int dgv2_kitti_rows(int* row, int* counts, const float* pts, int n, int H, void* stream);
 int dgv2_kitti_project(float* out, unsigned long long* key, const float* pts, const int* row, int n, int H, int W,
                        int Wout, float min_depth, float max_depth, int apply_mask, void* stream);
 

@@ -74,3 +74,18 @@ def test_dataset_and_trainer_on_a_kitti_tree(tmp_path):
     out = tr.step(1)
     assert all(torch.isfinite(torch.as_tensor(float(v))) for v in out.values())
     assert float(tr.x_real.min()) >= -1.0 and float(tr.x_real.max()) <= 1.0 and float((tr.x_real == -1).float().mean()) > 0.05
+
+
+@pytest.mark.parametrize("seed,rings,H", [(3, 18, 16), (4, 66, 64), (5, 70, 64), (6, 10, 64)])
+def test_ring_rows_kernel_matches_oracle_and_tensor_ops(seed, rings, H):
+    """dgv2_kitti_rows (one workgroup: count, block scan, write) against oracle/kitti.py::ring_rows (pinned to the
+    reference by kitti.npz) and the tensor-op version; more rings than H (the -1 quirk and the zero rows), fewer, equal."""
+    import recipe
+    from gans.datasets import kitti as K
+    from gans.models.ops import native
+    from oracle import kitti as o_kitti
+    p = recipe.synthetic_scan(seed, rings=rings, steps=700 if rings > 20 else 220)
+    pts = torch.from_numpy(p).to(DEV)
+    got = native.kitti_rows(pts, H).cpu().numpy()
+    np.testing.assert_array_equal(got, o_kitti.ring_rows(p[:, 0], p[:, 1], H))
+    np.testing.assert_array_equal(got, K.ring_rows(pts[:, 0], pts[:, 1], H).cpu().numpy())
