@@ -21,10 +21,12 @@ class RayDropModel(nn.Module):
         module.const_host = float(module.raydrop_const)
 
     def forward(self, h):
-        assert isinstance(h, dict) and ("image" in h) and ("raydrop_logit" in h)
-        h["raydrop_mask"] = self.gumbel_sigmoid(h["raydrop_logit"])
-        h["image_orig"] = h["image"]
-        h["image"] = h["image"].lerp(self.raydrop_const, 1 - h["raydrop_mask"])
+        """h: dict with "image" and "raydrop_logit" -> adds the straight-through drop mask, keeps the clean image as
+        "image_orig" and blends the dropped rays towards raydrop_const."""
+        assert isinstance(h, dict) and {"image", "raydrop_logit"} <= set(h)
+        keep = self.gumbel_sigmoid(h["raydrop_logit"])
+        clean = h["image"]
+        h.update(raydrop_mask=keep, image_orig=clean, image=clean.lerp(self.raydrop_const, 1 - keep))
         return h
 
     def extra_repr(self):
@@ -33,12 +35,9 @@ class RayDropModel(nn.Module):
 
 class Generator(base.Generator):
     def __init__(self, synthesis_kwargs, measurement_kwargs):
-        from . import vanilla
-        super().__init__(
-            mapping_network=nn.Identity(),
-            synthesis_network=vanilla.SynthesisNetwork(**synthesis_kwargs),
-            measurement_model=RayDropModel(**measurement_kwargs),
-        )
+        from .vanilla import SynthesisNetwork   # the DCGAN-style trunk with an image and a ray-drop logit head
+        trunk, raydrop = SynthesisNetwork(**synthesis_kwargs), RayDropModel(**measurement_kwargs)
+        super().__init__(mapping_network=nn.Identity(), synthesis_network=trunk, measurement_model=raydrop)
 
     def forward(self, z, angle=None, style_mixing=False, truncation_psi=1.0, input_w=False, noise=None):
         """`noise`: {"gumbel_u": [B,1,H,W]} injects the uniforms of the Gumbel-sigmoid (parity tests)."""
