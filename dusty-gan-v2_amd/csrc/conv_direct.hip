@@ -21,14 +21,56 @@
 //                       All per-slot address arithmetic is hoisted out of the stage loop.
 //   conv_direct_kernel  the simple synchronous version, kept as the fallback for geometries the pipelined
 //                       kernel's fixed register budget does not cover (very wide halos, Win < 32).
-// LDS images: input halo tile [pix][4 x 16 B] and weight slab [tap][TO][4 x 16 B], both with the
-// (row>>2)&3 XOR swizzle of gemm_core.h so every fragment is one conflict-free ds_read_b128.
+// LDS images of conv_pipe_kernel: four 16-byte PLANES per operand -- plane c holds bytes [16c, 16c+16) of every
+// pixel's (weight row's) 64-byte K chunk, rows consecutive, plane stride a multiple of 256 bytes.  A fragment read
+// (lane (lr, lc) takes row base + lr of plane lc) is then one conflict-free ds_read_b128 at ANY base -- a
+// ds_read_b128 is served in the lane groups {lc: lr 0-3, 12-15; lc+1: lr 4-11} etc., which cover 16 consecutive
+// 16-byte units modulo the plane stride -- and the address is LINEAR in the row: a tap is a constant byte offset,
+// for the full 3x3 grid an instruction immediate (F33), so the MFMA loop carries no address arithmetic at all.
+// (The pixel-major image with the (row>>2)&3 XOR of gemm_core.h that this replaces cost 5 VALU per fragment and
+// still conflicted on 37 % of its LDS cycles: profiles/round2_sq_counters.txt.)  Staging slot id -> row
+// (id>>5)*8 + (id&7), plane (id>>3)&3: a wave still loads 16 whole pixels per instruction and its ds_write_b128
+// lane groups (8 consecutive lanes) hit 8 consecutive units of one plane.
+// conv_direct_kernel keeps the pixel-major swizzled image.
+#include <type_traits>
+
 #include "gemm_core.h"
 
 namespace {
 
 constexpr int DTH = 4;
 constexpr int DTW = 32;
+
+// MFMA accumulating IN PLACE, as inline asm.  The unrolled-tap kernels issue MFMAs under wave-uniform branches (dead
+// taps); with the builtin the compiler gives every conditional MFMA a fresh destination and copies whole accumulator
+// sets around the branches (a second 64-register set, then spills).  The asm's "+v" keeps one set.  The compiler does
+// not see inside: fragments arrive through ordinary ds_reads (it places their lgkmcnt waits in front of the asm),
+// dependent MFMAs on the same accumulator are interlocked by the hardware, and the one software hazard -- an MFMA
+// result read by a VALU instruction -- is covered by mfma_drain() in front of the epilogue.
+template <typename T> struct MfmaAsm;
+template <> struct MfmaAsm<bf16_t> {
+  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; bf16x8 v; } ua, ub;
+    ua.u = a;
+    ub.u = b;
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ua.v), "v"(ub.v));
+  }
+};
+template <> struct MfmaAsm<float> {
+  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.x), "v"(b.x));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.y), "v"(b.y));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.z), "v"(b.z));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.w), "v"(b.w));
+  }
+};
+// every MFMA issued so far has written its accumulator when this returns (the longest of the shapes used here takes
+// 8 passes = 32 cycles; the fences keep the scheduler from moving accumulator reads in front of the wait)
+__device__ __forceinline__ void mfma_drain() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 struct DConv {
   int B, Hin, Win, Cin;
@@ -98,19 +140,25 @@ __device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, 
 // Pipelined kernel.  NI = input-tile staging slots (16 B each) per thread, NW = weight slots.
 // ---------------------------------------------------------------------------------------------
 // TO <= 32: a third wave per SIMD (<= 168 VGPRs) keeps more staging loads in flight on the HBM-bound small-channel layers
-template <typename T, int TO, int RW, int NI, int NC>
+// F33 != 0: the taps are the full 3x3 grid in (dy, dx) order at stride 1 and O is a multiple of TO (host-checked):
+// tap loop unrolled, every LDS offset an immediate, staging loads unconditional.  1 = rows clamp (forward convs),
+// 2 = rows outside the image are zero (data gradients): those rows are staged as whatever the clamped address holds,
+// because every tap that would read them is a dead tap of that output row and is skipped (the host checks that the
+// border extras read real rows).
+template <typename T, int TO, int RW, int NI, int NC, int F33>
 __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void conv_pipe_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                            const T* __restrict__ w, DConv p) {
   constexpr int CE = 16 / sizeof(T);
   constexpr int MF = TO / 16, NF = 2 * RW, TH = 4 * RW;
   constexpr int NW = (TO * 9 * 4 + 255) / 256;
+  constexpr int PIN = NI * 64, PW = NW * 64;   // rows per plane: exactly what the staging slots cover
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   __shared__ int s_widx[9], s_tapoff[9], s_t0[5], s_xoff[6], s_xslot[6], s_xcls[6], s_xrow[6];
   __shared__ __attribute__((aligned(16))) float s_bias[TO];
   const int npix = p.rows * p.cols;
   uint4* lds_in = smem;
-  uint4* lds_w = smem + npix * 4;
-  const int n_in = npix * 4, n_w = TO * p.ntaps * 4;
+  uint4* lds_w = smem + 4 * PIN;
+  const int n_wrows = TO * p.ntaps;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -145,17 +193,21 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
   __syncthreads();
 
   // ---- per-slot constants (once per block) ----
-  int woff[NW];   // element offset of the slot's 16 bytes in w at chunk 0, or -1
+  const int slot_row = ((tid >> 5) << 3) | (tid & 7);   // row (pixel / weight row) of this thread's slot 0; slot j: + 64 j
+  const int slot_ch = (tid >> 3) & 3;                   // its 16-byte plane
+  static_assert(F33 == 0 || TO == 64, "F33: weight slot j of a thread is tap j");
+  const unsigned wlane = ((o0 + slot_row) * p.wtaps) * p.Cin + slot_ch * CE;   // F33: element offset of this thread's weight row
+  int woff[F33 ? 1 : NW];   // element offset of the slot's 16 bytes in w at chunk 0, or -1
 #pragma unroll
-  for (int j = 0; j < NW; ++j) {
-    const int id = tid + j * 256;
-    const int t = id / (TO * 4), r = (id >> 2) & (TO - 1), ch = id & 3;
-    woff[j] = (id < n_w && o0 + r < p.O) ? ((o0 + r) * p.wtaps + s_widx[t < 9 ? t : 0]) * p.Cin + ch * CE : -1;
+  for (int j = 0; j < (F33 ? 0 : NW); ++j) {
+    const int row = slot_row + 64 * j;
+    const int t = row / TO, r = row & (TO - 1);
+    woff[j] = (row < n_wrows && o0 + r < p.O) ? ((o0 + r) * p.wtaps + s_widx[t < 9 ? t : 0]) * p.Cin + slot_ch * CE : -1;
   }
   int ipos[NI];   // (iy << 16) | ix of the slot's pixel inside the halo tile
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const int pix = (tid + j * 256) >> 2;
+    const int pix = slot_row + 64 * j;
     const int iy = (int)(((float)pix + 0.5f) * p.inv_cols);
     ipos[j] = (iy << 16) | (pix - iy * p.cols);
   }
@@ -166,7 +218,6 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
     const int gh_base = h0 * p.in_stride + p.ioff_h + p.dymin;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int id = tid + j * 256;
       int gh = gh_base + (ipos[j] >> 16);
       int hi = p.Hin, img0 = 0;
       if (p.hper) {   // image pair: halo row -> (image k of the pair, row inside that image)
@@ -175,9 +226,9 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
         hi = p.hper;
         img0 = k * p.hper;
       }
-      const bool zero = id >= n_in || (p.hzero && (gh < 0 || gh >= hi));
+      const bool zero = !F33 && (slot_row + 64 * j >= npix || (p.hzero && (gh < 0 || gh >= hi)));
       gh = gh < 0 ? 0 : (gh >= hi ? hi - 1 : gh);
-      grow[j] = zero ? -1 : (img0 + gh) * p.Win * p.Cin + (id & 3) * CE;
+      grow[j] = zero ? -1 : (img0 + gh) * p.Win * p.Cin + slot_ch * CE;
     }
   }
   int goff[NI];   // element offset inside image b of the slot's 16 bytes at chunk 0, or -1 (zero fill)
@@ -193,27 +244,37 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
       } else {
         gw = gw < 0 ? 0 : (gw >= p.Win ? p.Win - 1 : gw);
       }
-      goff[j] = grow[j] < 0 ? -1 : grow[j] + gw * p.Cin;
+      goff[j] = (!F33 && grow[j] < 0) ? -1 : grow[j] + gw * p.Cin;
     }
   };
 
-  uint4 rin[NI], rwt[NW];
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 rin[NI], rwt[NW];   // native vectors: as HIP's uint4 structs the unconditional F33 loads left both arrays in scratch
   auto issue_in = [&](int c0) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      rin[j] = make_uint4(0, 0, 0, 0);
-      if (goff[j] >= 0) rin[j] = *reinterpret_cast<const uint4*>(xb + goff[j] + c0);
+      if constexpr (F33 != 0) {
+        rin[j] = *reinterpret_cast<const u32x4*>(xb + c0 + (unsigned)goff[j]);
+      } else {
+        rin[j] = (u32x4){0u, 0u, 0u, 0u};
+        if (goff[j] >= 0) rin[j] = *reinterpret_cast<const u32x4*>(xb + goff[j] + c0);
+      }
     }
   };
   auto issue_w = [&](int c0) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      rwt[j] = make_uint4(0, 0, 0, 0);
-      if (woff[j] >= 0) rwt[j] = *reinterpret_cast<const uint4*>(w + woff[j] + c0);
+      if constexpr (F33 != 0) {   // uniform pointer of tap j's weights + this thread's 32-bit offset (TO = 64: slot j IS tap j)
+        const T* wu = w + (p.widx[0] + j * (p.widx[1] - p.widx[0])) * p.Cin + c0;
+        rwt[j] = *reinterpret_cast<const u32x4*>(wu + wlane);
+      } else {
+        rwt[j] = (u32x4){0u, 0u, 0u, 0u};
+        if (woff[j] >= 0) rwt[j] = *reinterpret_cast<const u32x4*>(w + woff[j] + c0);
+      }
     }
   };
-  // slot id -> swizzled LDS index; (pix>>2)&3 and (r>>2)&3 are both (id>>4)&3 (TO is a multiple of 16)
-  auto swz = [](int id) { return (id & ~3) | ((id & 3) ^ ((id >> 4) & 3)); };
+  uint4* const st_in = lds_in + slot_ch * PIN + slot_row;   // staging destinations of slot 0; slot j: + 64 j
+  uint4* const st_w = lds_w + slot_ch * PW + slot_row;
 
   f32x4 acc[NC][MF][NF];
 #pragma unroll
@@ -235,7 +296,8 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
   // every prefetch in flight) and without holding MF*4 registers through the MFMA loop
   if (tid < TO) s_bias[tid] = (p.bias && o0 + tid < p.O) ? p.bias[o0 + tid] : 0.f;
   __syncthreads();
-  const int aswz = lc ^ ((lr >> 2) & 3);
+  const uint4* const a_base = lds_w + lc * PW + lr;    // A fragment mf of tap t: a_base[t * TO + mf * 16]
+  const uint4* const b_base = lds_in + lc * PIN;       // B fragment nf of tap t: b_base[bpix[nf] + tapoff(t)]
 
   // Taps that read only the zero rows above / below the image for this wave's output row(s) (hzero: the data
   // gradient of a replicate-padded conv) contribute nothing: skipped, wave-uniformly.  Together with the border
@@ -265,16 +327,10 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
   for (int s = 0; s < nstage; ++s) {
     __syncthreads();                // every wave has finished reading stage s-1
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int id = tid + j * 256;
-      if (id < n_in) lds_in[swz(id)] = rin[j];
-    }
+    for (int j = 0; j < NI; ++j) *reinterpret_cast<u32x4*>(st_in + 64 * j) = rin[j];
     if (s == 0 || nchunks > 1) {
 #pragma unroll
-      for (int j = 0; j < NW; ++j) {
-        const int id = tid + j * 256;
-        if (id < n_w) lds_w[swz(id)] = rwt[j];
-      }
+      for (int j = 0; j < NW; ++j) *reinterpret_cast<u32x4*>(st_w + 64 * j) = rwt[j];
     }
     // prefetch stage s+1
     int ntile_i = tile, ncc = cc + 1;
@@ -286,24 +342,61 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
     }
     __syncthreads();                // stage s visible in LDS
 
+    if constexpr (F33) {
+      // The nine taps straight-line: immediate LDS offsets; a pixel fragment is re-read for tap t+1 as soon as its
+      // four MFMAs of tap t are issued (same registers), the weight fragments alternate between two sets, so every
+      // read has three quarters of a tap's MFMA time to land; dead taps are skipped under wave-uniform branches around
+      // in-place MFMAs.  The fences pin that order: left alone the scheduler hoists reads of several taps ahead and spills.
+      constexpr int COLS = DTW + 2;
+      constexpr int APG = MF / NF;   // A fragments re-read per pixel-fragment group
+      static_assert(MF % NF == 0, "A fragments are re-read in equal shares behind the pixel-fragment groups");
+      uint4 a[2][MF], bb[NF];
+      unsigned dd[RW];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      for (int t = s_t0[c]; t < s_t0[c + 1]; ++t) {
-        if ((dead_all >> t) & 1u) continue;
-        uint4 a[MF], bb[NF];
+      for (int rr = 0; rr < RW; ++rr) {
+        dd[rr] = F33 == 2 ? dead[rr] : 0u;
+        // the bit tests stay in the loop: hoisted, their 27 results live in SGPR pairs that spill
+        if constexpr (F33 == 2) asm volatile("" : "+s"(dd[rr]));
+      }
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) a[mf] = lds_w[(t * TO + mf * 16 + lr) * 4 + aswz];
-        const int tapoff = s_tapoff[t];
+      for (int mf = 0; mf < MF; ++mf) a[0][mf] = a_base[mf * 16];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) bb[nf] = b_base[bpix[nf]];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
-          const int pix = bpix[nf] + tapoff;
-          bb[nf] = lds_in[pix * 4 + (lc ^ ((pix >> 2) & 3))];
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(F33 == 2 && ((dd[nf >> 1] >> t) & 1u))) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[0][mf][nf], a[t & 1][mf], bb[nf]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < 9) {   // this group's pixel fragment is consumed: re-read it, and a share of the weights, for tap t+1
+            bb[nf] = b_base[bpix[nf] + ((t + 1) / 3) * COLS + (t + 1) % 3];
+#pragma unroll
+            for (int k = 0; k < APG; ++k) a[(t + 1) & 1][nf * APG + k] = a_base[(t + 1) * TO + (nf * APG + k) * 16];
+          }
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-          if (RW > 1 && ((dead[nf >> 1] >> t) & 1u)) continue;
+      for (int c = 0; c < NC; ++c) {
+        for (int t = s_t0[c]; t < s_t0[c + 1]; ++t) {
+          if ((dead_all >> t) & 1u) continue;
+          uint4 a[MF], bb[NF];
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) Mfma16<T>::run(acc[c][mf][nf], a[mf], bb[nf]);
+          for (int mf = 0; mf < MF; ++mf) a[mf] = a_base[t * TO + mf * 16];
+          const int tapoff = s_tapoff[t];
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) bb[nf] = b_base[bpix[nf] + tapoff];
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            if (RW > 1 && ((dead[nf >> 1] >> t) & 1u)) continue;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) Mfma16<T>::run(acc[c][mf][nf], a[mf], bb[nf]);
+          }
         }
       }
     }
@@ -315,25 +408,28 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
         if ((p.hper ? (h0 + wave * RW + rr) % p.hper : h0 + wave * RW + rr) != xrow) continue;
         uint4 a[MF], bb[2];
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) a[mf] = lds_w[(xslot * TO + mf * 16 + lr) * 4 + aswz];
+        for (int mf = 0; mf < MF; ++mf) a[mf] = a_base[xslot * TO + mf * 16];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int pix = bpix[rr * 2 + h] + xoff;
-          bb[h] = lds_in[pix * 4 + (lc ^ ((pix >> 2) & 3))];
-        }
+        for (int h = 0; h < 2; ++h) bb[h] = b_base[bpix[rr * 2 + h] + xoff];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           if (c != xcls) continue;
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) {
-            Mfma16<T>::run(acc[c][mf][rr * 2], a[mf], bb[0]);
-            Mfma16<T>::run(acc[c][mf][rr * 2 + 1], a[mf], bb[1]);
+            if constexpr (F33) {
+              MfmaAsm<T>::run(acc[c][mf][rr * 2], a[mf], bb[0]);
+              MfmaAsm<T>::run(acc[c][mf][rr * 2 + 1], a[mf], bb[1]);
+            } else {
+              Mfma16<T>::run(acc[c][mf][rr * 2], a[mf], bb[0]);
+              Mfma16<T>::run(acc[c][mf][rr * 2 + 1], a[mf], bb[1]);
+            }
           }
         }
       }
     }
 
     if (cc == nchunks - 1) {        // tile finished: epilogue, reset accumulators
+      if constexpr (F33) mfma_drain();
       const int w0 = (tw0 + tile) * DTW;
       // fast path (block-uniform): full channel tile, plain overwrite -- straight-line bias / lrelu / convert and,
       // for bf16, fragment pairs leaving as 16-byte stores; everything else takes the general store_frag
@@ -533,7 +629,7 @@ int launch_direct(void* y, const void* x, const void* w, DConv p, hipStream_t st
 }
 
 // returns -2 when the geometry does not fit this instantiation's register / LDS budget
-template <typename T, int TO, int RW, int NI, int NC>
+template <typename T, int TO, int RW, int NI, int NC, int F33 = 0>
 int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) {
   constexpr int TH = 4 * RW;
   constexpr int NW = (TO * 9 * 4 + 255) / 256;
@@ -548,9 +644,10 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   p.inv_cols = 1.0f / (float)p.cols;
   const int n_in = p.rows * p.cols * 4, n_w = TO * p.ntaps * 4;
   if (n_in > NI * 256 || n_w > NW * 256 || p.rows >= 32768 || p.cols >= 65536) return -2;
-  const size_t lds = sizeof(uint4) * ((size_t)n_in + n_w);
+  if (F33 && (p.cols != DTW + 2 || p.O % TO || (F33 == 1) != !p.hzero)) return -2;
+  const size_t lds = sizeof(uint4) * 4 * 64 * (size_t)(NI + NW);   // four planes of NI*64 pixels and NW*64 weight rows
   if (lds > 80 * 1024) return -2;   // two blocks per CU
-  auto kern = conv_pipe_kernel<T, TO, RW, NI, NC>;
+  auto kern = conv_pipe_kernel<T, TO, RW, NI, NC, F33>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -578,12 +675,24 @@ int dgv2_conv_strip_try(void* y, const void* x, const void* w, int B, int H, int
 namespace {
 
 template <typename T, int TO>
-int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, hipStream_t st) {
+int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, bool f33, hipStream_t st) {
   if (p.ncls == 4) {
     if constexpr (TO <= 32) return p.in_stride == 1 ? launch_pipe<T, TO, 1, 4, 4>(y, x, w, p, st) : -2;
     else return -2;
   }
   if (p.ncls != 1) return -2;
+  if constexpr (TO == 64) {   // the full 3x3 grid at stride 1 with >= 64 output channels: unrolled taps
+    if (f33 && p.O % TO == 0) {
+      if (p.hzero) {
+        if (p.hper) return launch_pipe<T, TO, 2, 7, 1, 2>(y, x, w, p, st);
+        if (p.Hg >= 8) return launch_pipe<T, TO, 2, 6, 1, 2>(y, x, w, p, st);
+        return launch_pipe<T, TO, 1, 4, 1, 2>(y, x, w, p, st);
+      }
+      if (p.hper) return launch_pipe<T, TO, 2, 7, 1, 1>(y, x, w, p, st);
+      if (p.Hg >= 8) return launch_pipe<T, TO, 2, 6, 1, 1>(y, x, w, p, st);
+      return launch_pipe<T, TO, 1, 4, 1, 1>(y, x, w, p, st);
+    }
+  }
   if (p.hper) return launch_pipe<T, TO, 2, 7, 1>(y, x, w, p, st);
   if (p.in_stride == 1 && p.Hg >= 8) return launch_pipe<T, TO, 2, 6, 1>(y, x, w, p, st);
   if (p.in_stride == 1) return launch_pipe<T, TO, 1, 4, 1>(y, x, w, p, st);
@@ -648,6 +757,17 @@ extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w,
   for (int c = 0; c < 4; ++c) {
     p.cls_ooh[c] = c < ncls ? cls_host[2 * c] : 0;
     p.cls_oow[c] = c < ncls ? cls_host[2 * c + 1] : 0;
+  }
+  // single-class launches: taps in (dy, dx) order (the sum does not depend on it; the full 3x3 grid then is tap
+  // t = (dy - dymin) * 3 + (dx - dxmin), which the unrolled kernel variant relies on)
+  int sorted[36];
+  if (ncls == 1) {
+    for (int t = 0; t < 4 * ntaps; ++t) sorted[t] = taps_host[t];
+    for (int i = 1; i < ntaps; ++i)
+      for (int j = i; j > 0 && (sorted[4 * j] < sorted[4 * j - 4] ||
+                                (sorted[4 * j] == sorted[4 * j - 4] && sorted[4 * j + 1] < sorted[4 * j - 3])); --j)
+        for (int k = 0; k < 4; ++k) { const int v = sorted[4 * j + k]; sorted[4 * j + k] = sorted[4 * j - 4 + k]; sorted[4 * j - 4 + k] = v; }
+    taps_host = sorted;
   }
   int dymin = 1 << 30, dymax = -(1 << 30), dxmin = 1 << 30, dxmax = -(1 << 30);
   int prev_cls = 0;
@@ -714,13 +834,19 @@ extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w,
   // the ring wrap of the pipelined kernel assumes -Win <= gw < 4*Win
   const bool wrap_ok = !ring || (ioff_w + dxmin >= -Win && in_stride * ((Wg + DTW - 1) / DTW * DTW) + ioff_w + dxmax < 4 * Win);
   const bool plain = ncls == 1 && nextra == 0;
+  static const bool no_f33 = getenv("DGV2_NO_F33") != nullptr;   // A/B switch for benchmarking
+  bool f33 = !no_f33 && ncls == 1 && in_stride == 1 && ntaps == 9 && p.rows == 3 && p.cols == 3;
+  for (int t = 0; f33 && t < 9; ++t) f33 = p.dy[t] == dymin + t / 3 && p.dx[t] == dxmin + t % 3;
+  for (int t = 2; f33 && t < 9; ++t) f33 = p.widx[t] - p.widx[t - 1] == p.widx[1] - p.widx[0];   // weight slots affine in t
+  for (int e = 0; f33 && hzero && e < nextra; ++e)   // zero rows are not staged as zeros there: extras must read real rows
+    f33 = (unsigned)(p.x_row[e] * in_stride + ioff_h + p.x_dy[e]) < (unsigned)Hin;
   DGV2_DISPATCH_DTYPE(dtype, {
     rc = -2;
     if ((!no_pipe || !plain) && wrap_ok) {
       // four output classes quadruple the accumulators: 32-channel tiles keep them in registers
-      if (O <= 16) rc = dispatch_pipe<T, 16>(y, x, w, p, st);
-      else if (O <= 32 || ncls == 4) rc = dispatch_pipe<T, 32>(y, x, w, p, st);
-      else rc = dispatch_pipe<T, 64>(y, x, w, p, st);
+      if (O <= 16) rc = dispatch_pipe<T, 16>(y, x, w, p, f33, st);
+      else if (O <= 32 || ncls == 4) rc = dispatch_pipe<T, 32>(y, x, w, p, f33, st);
+      else rc = dispatch_pipe<T, 64>(y, x, w, p, f33, st);
     }
     if (rc == -2) {
       if (!plain) return DGV2_ENOTSUP;
