@@ -627,6 +627,14 @@ CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     # strip-streaming kernel (conv_strip.hip: 32 -> 32 channels, H % 8 == 0, W % 32 == 0): several strips / images
     (3, 16, 96, 32, 32, 3, 1, 1, True),
     (2, 40, 64, 32, 32, 3, 1, 1, True),
+    # unrolled 3x3 variant of the halo-tile engine (O a multiple of 64, stride 1): 8-row tiles with a partial W tile and
+    # border extras / dead taps in the data gradient, two channel chunks and two output tiles, 4-row tiles, clamped W
+    # with ragged H, and image pairs on 4-row maps (taken from 512 blocks up)
+    (2, 16, 40, 32, 64, 3, 1, 1, True),
+    (2, 8, 64, 64, 128, 3, 1, 1, True),
+    (4, 4, 32, 64, 64, 3, 1, 1, True),
+    (2, 12, 33, 32, 64, 3, 1, 1, False),
+    (1024, 4, 32, 32, 64, 3, 1, 1, True),
 ]
 
 
