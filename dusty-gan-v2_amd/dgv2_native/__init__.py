@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -66,6 +66,11 @@ SIGNATURES = {
                             _c_ptr],
     "dgv2_resample_tab_actbwd": [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr] + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3
                                 + [_c_int] * 7 + [_c_f32, _c_f32, _c_int, _c_ptr],
+    "dgv2_fir_same_mfma_prep": [_c_ptr, _c_i64, _c_ptr] + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 3 + [_c_ptr],
+    "dgv2_fir_same_mfma": [_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr],
+    "dgv2_fir_same_mfma_actbwd": [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_int] * 4
+                                 + [_c_f32, _c_f32, _c_ptr],
+    "dgv2_fir_same_mfma_status": [],
     "dgv2_resample_tab_sq": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr, _c_int, _c_ptr, _c_ptr],
     "dgv2_bmm_tn_cat": [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr],
     "dgv2_lerp_list": [_c_ptr] * 3 + [_c_int, _c_f32, _c_ptr],

@@ -121,6 +121,7 @@ class ResampleSpec:
         self.taps_cpu = (taps if "h" in direction else one, taps if "w" in direction else one)
         self._dev = {}
         self._tab = {}
+        self._mfma = {}
 
     def taps(self, device):
         if device not in self._dev:
@@ -173,6 +174,44 @@ class ResampleSpec:
                 idx, coef, cnt, E = self._axis_rows(L, Lo, taps.tolist(), k, u, d, p0, wrap, adjoint)
                 tabs.append((idx.to(device), coef.to(device), cnt.to(device), E))
             self._tab[key] = tabs
+            # the MFMA FIR kernel (dgv2_fir_same_mfma) takes same-size tables whose entries stay inside its windows
+            # and whose coefficients are exact in bf16: checked here, once, on the host copies
+            ok = (Ho, Wo) == (H, W)
+            for axis, (L, (k, u, d, p0, _), wrap, taps) in enumerate(zip((H, W), self.axes, (False, self.ring), self.taps_cpu)):
+                if not ok:
+                    break
+                idx, coef, cnt, E = self._axis_rows(L, L, taps.tolist(), k, u, d, p0, wrap, adjoint)
+                o = torch.arange(L, dtype=torch.int32)[:, None]
+                live = torch.arange(E)[None, :] < cnt[:, None]
+                # the kernel sums the entries of a row that name the same input (border rows of an adjoint) before it
+                # rounds: those sums must be exact as well
+                dense = torch.zeros(L, L).index_put_((o.expand(L, E)[live].long(), idx[live].long()), coef[live], accumulate=True)
+                ok = ok and E <= 6 and L <= (128 if axis == 0 else 1 << 20) and bool((dense == dense.bfloat16().float()).all())
+                if axis == 0:
+                    ok = ok and bool(((idx - o).abs()[live] <= 4).all())
+                else:
+                    ok = ok and bool((((idx - o + 8) % L)[live] < 24).all())
+            self._mfma[key] = ok
+        return self._tab[key]
+
+    def mfma_ok(self, H, W, adjoint, device):
+        self.tables(H, W, adjoint, device)
+        return self._mfma[(H, W, bool(adjoint), str(device))]
+
+    def bands(self, H, W, adjoint, device):
+        """Band operands of the MFMA FIR kernel for this table set (dgv2_fir_same_mfma_prep), built once; None where the
+        kernel does not apply."""
+        key = (H, W, bool(adjoint), str(device), "bands")
+        if key not in self._tab:
+            self._tab[key] = None
+            if H % 8 == 0 and W % 32 == 0 and self.mfma_ok(H, W, adjoint, device):
+                (ih, chh, nh, Eh), (iw, cw, nw, Ew) = self.tables(H, W, adjoint, device)
+                need = _ct.c_int64(0)
+                tabs = (N.ptr(ih), N.ptr(chh), N.ptr(nh), Eh, N.ptr(iw), N.ptr(cw), N.ptr(nw), Ew, H, W)
+                if N.try_call("dgv2_fir_same_mfma_prep", None, 0, _ct.addressof(need), *tabs, N.stream()):
+                    buf = torch.empty(need.value, device=device, dtype=torch.uint8)
+                    N.call("dgv2_fir_same_mfma_prep", N.ptr(buf), buf.numel(), None, *tabs, N.stream())
+                    self._tab[key] = buf
         return self._tab[key]
 
 
@@ -180,6 +219,9 @@ _SQ_CAP = 8192   # capacity of a producer's sum-of-squares partial buffer (one s
 
 
 _FUSED_SQ = os.environ.get("DGV2_NO_FUSED_SUMSQ") is None
+
+
+_FIR_MFMA = os.environ.get("DGV2_NO_FIR_MFMA") is None   # A/B switch: same-size FIRs on the table-driven VALU kernel
 
 
 def _sq_args(dev):
@@ -201,6 +243,11 @@ def _resample_raw(x, spec, adjoint, in_hw, out=None, ldy=None, ldx=None, C=None,
         out = torch.empty((B, oh, ow, C), device=x.device, dtype=x.dtype)
         ldy = C
     (ih_idx, ih_coef, ih_cnt, Eh), (iw_idx, iw_coef, iw_cnt, Ew) = spec.tables(H, W, adjoint, x.device)
+    if (_FIR_MFMA and sq is None and x.dtype == torch.bfloat16 and ldx == C and ldy == C and (ih, iw) == (oh, ow)
+            and C % 32 == 0):
+        bands = spec.bands(H, W, adjoint, x.device)
+        if bands is not None and N.try_call("dgv2_fir_same_mfma", N.ptr(out), N.ptr(x), N.ptr(bands), B, C, oh, ow, N.stream()):
+            return out
     if sq is not None:
         N.call("dgv2_resample_tab_sq", N.ptr(out), N.ptr(x), N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt), Eh,
                N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew, B, C, ldx, ldy, ih, iw, oh, ow, _dt(x), N.ptr(sq[0]),

@@ -10,6 +10,7 @@ import torch
 from torch.autograd import Function
 
 import dgv2_native as N
+from . import act_resample as _act_resample
 from .act_resample import *  # noqa: F401,F403
 from .modgemm import *  # noqa: F401,F403
 
@@ -596,11 +597,18 @@ def _resample_actbwd(g, out, spec, in_hw, alpha, scale):
     Ho, Wo = spec.out_size(H, W)
     (ih_idx, ih_coef, ih_cnt, Eh), (iw_idx, iw_coef, iw_cnt, Ew) = spec.tables(H, W, True, g.device)
     tabs = (N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt), Eh, N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew)
-    key = (B, H, W, C, Eh, Ew, _dt(g))
+    bands = None
+    if _act_resample._FIR_MFMA and g.dtype == torch.bfloat16 and (Ho, Wo) == (H, W) and C % 32 == 0:
+        bands = spec.bands(H, W, True, g.device)
+    mfma = bands is not None
+    entry = "dgv2_fir_same_mfma_actbwd" if mfma else "dgv2_resample_tab_actbwd"
+    tabs = (N.ptr(bands),) if mfma else tabs
+    geo = (B, C, H, W) if mfma else (B, C, Ho, Wo, H, W)
+    tail = (alpha, scale) if mfma else (alpha, scale, _dt(g))
+    key = (entry, B, H, W, C, Eh, Ew, _dt(g))
     if key not in _ACTBWD_BLOCKS:
         nb = _ct.c_int64(0)
-        ok = N.try_call("dgv2_resample_tab_actbwd", None, None, None, 0, _ct.addressof(nb), None, None, *tabs, B, C, Ho, Wo,
-                        H, W, alpha, scale, _dt(g), N.stream())
+        ok = N.try_call(entry, None, None, None, 0, _ct.addressof(nb), None, None, *tabs, *geo, *tail, N.stream())
         _ACTBWD_BLOCKS[key] = nb.value if ok else 0
     nblk = _ACTBWD_BLOCKS[key]
     if nblk == 0:
@@ -610,8 +618,8 @@ def _resample_actbwd(g, out, spec, in_hw, alpha, scale):
     gpre = torch.empty_like(out)
     gb = torch.empty(C, device=g.device, dtype=torch.float32)
     scratch = torch.empty(nblk * C, device=g.device, dtype=torch.float32)
-    N.call("dgv2_resample_tab_actbwd", N.ptr(gpre), N.ptr(gb), N.ptr(scratch), scratch.numel(), None, N.ptr(g), N.ptr(out),
-           *tabs, B, C, Ho, Wo, H, W, alpha, scale, _dt(g), N.stream())
+    N.call(entry, N.ptr(gpre), N.ptr(gb), N.ptr(scratch), scratch.numel(), None, N.ptr(g), N.ptr(out), *tabs, *geo, *tail,
+           N.stream())
     return gpre, gb
 
 

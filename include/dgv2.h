@@ -135,6 +135,30 @@ int dgv2_resample_tab_actbwd(void* y, float* gb, float* scratch, int64_t scratch
                              int Ew, int B, int C, int in_h, int in_w, int out_h, int out_w, float alpha,
                              float scale, int dtype, void* stream);
 
+/* Same-size separable FIR (the blur in front of the discriminator's stride-2 convs, and its adjoint) on the MFMA cores,
+ * bf16, x / y [B,H,W,C] contiguous:  y = R x.  Each pass is one 16x16x32 MFMA per 16 outputs x 16 channels with the
+ * filter band as a constant operand (fir_mfma.hip).
+ * dgv2_fir_same_mfma_prep builds the band operands ONCE from sparse-row tables exactly as dgv2_resample_tab takes them
+ *   (bands: device buffer of >= *bytes_needed bytes, 16-byte aligned; bands == NULL only reports *bytes_needed).
+ *   Contract on the tables (a violation raises the flag dgv2_fir_same_mfma_status reports and the bands are unusable):
+ *   |idx_h[ho][a] - ho| <= 4,  (idx_w[wo][e] - wo + 8) mod W < 24,  every coefficient -- and every sum of the
+ *   coefficients of one row that name the same input -- exactly representable in bf16.  DGV2_ENOTSUP unless
+ *   H % 8 == 0 and W % 32 == 0.
+ * dgv2_fir_same_mfma / _actbwd: DGV2_ENOTSUP unless C % 32 == 0, H % 8 == 0, W % 32 == 0 (then: dgv2_resample_tab /
+ *   dgv2_resample_tab_actbwd, whose contracts they share: same scratch protocol for the bias gradient).
+ * dgv2_fir_same_mfma_status: 1 if a prep call met a contract violation since the last call (synchronises the device:
+ *   tests / debugging), 0 if not, < 0 on a runtime error.
+ * replaces: Blur / Resample(up = down = 1) (gans/models/ops/common.py:105-135) at gans/models/dusty_v2.py:325-345, its
+ *   adjoint, and FusedLeakyReLUFunctionBackward (gans/models/ops/fused_act/fused_act.py:22-45) behind it. */
+int dgv2_fir_same_mfma_prep(void* bands, int64_t bands_bytes, int64_t* bytes_needed, const int* idx_h, const float* coef_h,
+                            const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew,
+                            int H, int W, void* stream);
+int dgv2_fir_same_mfma(void* y, const void* x, const void* bands, int B, int C, int H, int W, void* stream);
+int dgv2_fir_same_mfma_actbwd(void* y, float* gb, float* scratch, int64_t scratch_elems, int64_t* blocks_needed,
+                              const void* x, const void* ref, const void* bands, int B, int C, int H, int W, float alpha,
+                              float scale, void* stream);
+int dgv2_fir_same_mfma_status(void);
+
 /* ---------------------------------------------------------------------------
  * Fourier features (positional encoding of the laser angles)
  * replaces: FourierFeature.forward, gans/models/ops/fourier.py:77-82

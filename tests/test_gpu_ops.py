@@ -1054,3 +1054,90 @@ def test_conv_data_gradient_in_channel_ranges(nat, dtype, C):
     got_r = nat._conv_dgrad_raw(cl(gy.float()).to(dtype), wd, geom, (B, H, W, C), resid=cl(res.float()).to(dtype))
     assert torch.equal(nchw(got).double(), want)
     assert torch.equal(nchw(got_r).double(), want + res)
+
+
+# ---------------------------------------------------------------------------------------
+# same-size FIR on the MFMA cores (fir_mfma.hip)
+def _dense_rows(idx, coef, cnt, L):
+    R = torch.zeros(idx.shape[0], L, dtype=torch.float64)
+    for r in range(idx.shape[0]):
+        for e in range(int(cnt[r])):
+            R[r, int(idx[r, e])] += float(coef[r, e])
+    return R
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 512, 32), (3, 16, 64, 64), (2, 8, 32, 128), (1, 24, 96, 32), (2, 128, 64, 32)])
+@pytest.mark.parametrize("adjoint", [False, True])
+def test_fir_same_size_on_mfma(nat, B, H, W, C, adjoint):
+    """Blur (and its adjoint) through dgv2_fir_same_mfma: against the dense resampling matrices in float64 and against
+    the table-driven kernel it replaces (same rounding points; only the fp32 summation order differs)."""
+    import dgv2_native as N
+    from gans.models.ops.native import act_resample as ar
+    spec = nat.ResampleSpec([1, 3, 3, 1])
+    assert spec.mfma_ok(H, W, adjoint, DEV)
+    g = torch.Generator().manual_seed(H * W + C + int(adjoint))
+    x = torch.randn(B, H, W, C, generator=g).bfloat16()
+    (ih, chh, nh, _), (iw, cw, nw, _) = spec.tables(H, W, adjoint, "cpu")
+    Rh, Rw = _dense_rows(ih, chh, nh, H), _dense_rows(iw, cw, nw, W)
+    want = torch.einsum("ph,bhwc,qw->bpqc", Rh, x.double(), Rw)
+    xd = x.to(DEV)
+    assert ar._FIR_MFMA
+    got = ar._resample_raw(xd, spec, adjoint, (H, W))
+    assert N.lib.dgv2_fir_same_mfma_status() == 0
+    ar._FIR_MFMA = False
+    try:
+        old = ar._resample_raw(xd, spec, adjoint, (H, W))
+    finally:
+        ar._FIR_MFMA = True
+    assert_rel(got.float().cpu(), want, 8e-3, "vs float64")
+    # bf16 neighbours at most, and only rarely
+    d = (got.float() - old.float()).abs()
+    assert float(d.max()) <= float(old.float().abs().max()) * 2 ** -7
+    assert float((d > 0).float().mean()) < 0.02
+
+
+def test_fir_same_size_with_activation_backward_on_mfma(nat):
+    """dgv2_fir_same_mfma_actbwd (adjoint blur + leaky-ReLU backward + bias gradient) against the composition."""
+    import dgv2_native as N
+    from gans.models.ops.native import act_resample as ar
+    from gans.models.ops.native import conv as cv
+    spec = nat.ResampleSpec([1, 3, 3, 1])
+    B, H, W, C = 3, 32, 128, 64
+    g = torch.Generator().manual_seed(5)
+    gy = torch.randn(B, H, W, C, generator=g).bfloat16().to(DEV)
+    out = torch.randn(B, H, W, C, generator=g).bfloat16().to(DEV)
+    gpre, gb = cv._resample_actbwd(gy, out, spec, (H, W), 0.2, 2.0 ** 0.5)
+    assert N.lib.dgv2_fir_same_mfma_status() == 0
+    gx = ar._resample_raw(gy, spec, True, (H, W)).float()
+    want = (torch.where(out.float() > 0, gx, gx * 0.2) * 2.0 ** 0.5).bfloat16()
+    assert torch.equal(gpre, want)
+    assert_rel(gb.cpu(), want.float().sum((0, 1, 2)).cpu(), 1e-4, "bias gradient")
+    ar._FIR_MFMA = False
+    try:
+        gpre2, gb2 = cv._resample_actbwd(gy, out, spec, (H, W), 0.2, 2.0 ** 0.5)
+    finally:
+        ar._FIR_MFMA = True
+    assert float((gpre.float() - gpre2.float()).abs().max()) <= float(gpre2.float().abs().max()) * 2 ** -7
+    assert_rel(gb.cpu(), gb2.cpu(), 2e-3, "bias gradient vs the table-driven kernel")
+
+
+def test_fir_mfma_flags_tables_outside_its_windows(nat):
+    """The table contract is checked on the device when the band operands are built: a decimating table handed to the
+    same-size prep raises the flag, a blur's does not."""
+    import ctypes
+    import dgv2_native as N
+
+    def prep(spec, Hin, Win, H, W):
+        (ih, chh, nh, Eh), (iw, cw, nw, Ew) = spec.tables(Hin, Win, False, DEV)
+        need = ctypes.c_int64(0)
+        tabs = (N.ptr(ih), N.ptr(chh), N.ptr(nh), Eh, N.ptr(iw), N.ptr(cw), N.ptr(nw), Ew, H, W)
+        N.call("dgv2_fir_same_mfma_prep", None, 0, ctypes.addressof(need), *tabs, N.stream())
+        assert need.value == 1024 * (H // 8 + 1 + W // 16)
+        buf = torch.empty(need.value, device=DEV, dtype=torch.uint8)
+        N.call("dgv2_fir_same_mfma_prep", N.ptr(buf), buf.numel(), None, *tabs, N.stream())
+        return N.lib.dgv2_fir_same_mfma_status()
+
+    assert prep(nat.ResampleSpec([1, 3, 3, 1]), 32, 64, 32, 64) == 0
+    # 32 x 64 outputs of a 64 x 128 decimation presented as a same-size problem: row ho reads inputs 2 ho - 1 ...
+    assert prep(nat.ResampleSpec([1, 3, 3, 1], down=(2, 2)), 64, 128, 32, 64) == 1
+    assert N.lib.dgv2_fir_same_mfma_status() == 0
