@@ -217,6 +217,16 @@ __global__ __launch_bounds__(256, 2) void fir_same_mfma_kernel(bf16_t* __restric
     if (s + 1 < nsteps) commit();          // rows of step s+1 (in registers since the previous step)
     if (s + 2 < nsteps) issue(s + 2);
     const uint4 th_next = bands_h[(int64_t)min(s + 1, nsteps) * 64 + lane];
+    // ACT: the activation outputs this step's epilogue needs, requested here so that they arrive under the H pass
+    vec16<bf16_t> fref[4];
+    if constexpr (ACT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        const int ho = min(max(s * FM_RS - 4 + (id >> 7), 0), g.H - 1);   // rows outside the image: any valid address
+        fref[i].load(g.ref + img + ((int64_t)ho * g.W + c0col + ((id >> 2) & 31)) * g.C + cb0 + (id & 3) * 8);
+      }
+    }
 
     // ---- H pass: pixels 8*wave .. 8*wave + 7 x 2 channel tiles (reads, MFMAs, writes: as in the W pass) ----
     {
@@ -262,12 +272,10 @@ __global__ __launch_bounds__(256, 2) void fir_same_mfma_kernel(bf16_t* __restric
       o.raw = *reinterpret_cast<const uint4*>(Ys + n * FM_YROW + px * 64 + o8 * 16);
       const int64_t off = img + ((int64_t)ho * g.W + c0col + px) * g.C + cb0 + o8 * 8;
       if constexpr (ACT) {
-        vec16<bf16_t> f;
-        f.load(g.ref + off);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float a = o.get(j);
-          o.set(j, (f.get(j) > 0.f ? a : a * g.alpha) * g.ascale);
+          o.set(j, (fref[i].get(j) > 0.f ? a : a * g.alpha) * g.ascale);
           bsum[j] += o.get(j);   // the reference sums the rounded gradient
         }
       }

@@ -1073,8 +1073,9 @@ def test_fir_same_size_on_mfma(nat, B, H, W, C, adjoint):
     the table-driven kernel it replaces (same rounding points; only the fp32 summation order differs)."""
     import dgv2_native as N
     from gans.models.ops.native import act_resample as ar
+    ar._FIR_MFMA_MIN_H = 8   # the router sends maps under 32 rows to the table-driven kernel; here the MFMA kernel runs them
     spec = nat.ResampleSpec([1, 3, 3, 1])
-    assert spec.mfma_ok(H, W, adjoint, DEV)
+    assert spec.mfma_ok(H, W, adjoint, DEV) and spec.bands(H, W, adjoint, DEV) is not None
     g = torch.Generator().manual_seed(H * W + C + int(adjoint))
     x = torch.randn(B, H, W, C, generator=g).bfloat16()
     (ih, chh, nh, _), (iw, cw, nw, _) = spec.tables(H, W, adjoint, "cpu")
