@@ -7,7 +7,7 @@ PKG := dusty-gan-v2_amd
 SRC := $(wildcard $(PKG)/csrc/*.hip)
 OBJ := $(patsubst $(PKG)/csrc/%.hip,build/%.o,$(SRC))
 LIB := $(PKG)/lib/libdgv2.so
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude $(if $(ABLATE),-DDGV2_ABLATE)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude $(if $(ABLATE),-DDGV2_ABLATE) $(if $(FIR_RS),-DDGV2_FIR_RS=$(FIR_RS))
 
 all: $(LIB)
 

@@ -33,11 +33,16 @@ namespace {
 constexpr int FM_CT = 32;             // output columns per block
 constexpr int FM_CB = 32;             // channels per block
 constexpr int FM_WIN = FM_CT + 16;    // staged input columns per row: [c0 - 8, c0 + 40)
-constexpr int FM_RS = 8;              // rows per step
+#ifndef DGV2_FIR_RS
+#define DGV2_FIR_RS 8
+#endif
+constexpr int FM_RS = DGV2_FIR_RS;    // rows per step (8 or 4)
+constexpr int FM_RING = 2 * FM_RS;    // ring rows: this step's and the previous step's
+static_assert(FM_RS == 8 || FM_RS == 4, "rows per step");
 constexpr int FM_XBYTES = FM_RS * FM_WIN * 64;
 constexpr int FM_ZROW = 2048 + 64;    // bytes per ring row: rows r and r+1 start 64 B apart modulo 256 (4 rows x 32 B of a
                                       // transposing read hit distinct banks), rows r and r+8 use opposite pixel halves
-constexpr int FM_ZBYTES = 16 * FM_ZROW;
+constexpr int FM_ZBYTES = FM_RING * FM_ZROW;
 constexpr int FM_YROW = 2048 + 16;    // rows 16 B apart modulo 256: the 8 rows one H-pass store writes hit distinct banks
 constexpr int FM_YBYTES = FM_RS * FM_YROW;
 constexpr int FM_NLD = FM_RS * FM_WIN * 4 / 256;   // 16-byte staging loads per thread and step (6)
@@ -79,16 +84,16 @@ __global__ __launch_bounds__(64) void fir_bands_kernel(uint4* __restrict__ bands
   for (int j = 0; j < 8; ++j) v[j] = 0.f;
   bool bad = false;
   if ((int)blockIdx.x < nh) {
-    const int s = blockIdx.x, ho = s * FM_RS - 4 + li;
-    if (li < 8 && ho >= 0 && ho < t.H) {
+    const int s = blockIdx.x, ho = s * FM_RS - FM_RS / 2 + li;
+    if (li < FM_RS && ho >= 0 && ho < t.H) {
       const int n = t.cnt_h[ho];
       for (int e = 0; e < n; ++e) {
         const int r = t.idx_h[ho * t.Eh + e];
         const float cf = t.coef_h[ho * t.Eh + e];
-        if (r < s * FM_RS - 8 || r >= s * FM_RS + 8 || r < 0 || r >= t.H) bad = true;
+        if (r < s * FM_RS - FM_RS || r >= s * FM_RS + FM_RS || r < 0 || r >= t.H) bad = true;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if ((r & 15) == 8 * kg + j) v[j] += cf;
+          if ((r & (FM_RING - 1)) == 8 * kg + j) v[j] += cf;
       }
     }
   } else {
@@ -180,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void fir_same_mfma_kernel(bf16_t* __restric
     // array to the compiler, which keeps reads behind writes it cannot tell apart -- written job by job the pass was a
     // serial chain of read -> MFMA -> write latencies.
     if (s < nsteps) {
-      uint4 af[8];
+      uint4 af[FM_RS];
 #pragma unroll
-      for (int job = 0; job < 8; ++job) {
+      for (int job = 0; job < FM_RS; ++job) {
         const int rr = job >> 2, ct = (job >> 1) & 1, wt = job & 1;
-        const int r = 2 * wave + rr;
+        const int r = (FM_RS / 4) * wave + rr;
         // A = X^T [c, w]: lane addresses window column 16 wt + 8 kg + q (+ 4), channels 16 ct + 4p .. + 3
         const int j = 16 * wt + 8 * kg + q;
         const int o8 = (2 * ct + (p >> 1)) ^ ((kg & 1) << 1);
@@ -194,16 +199,16 @@ __global__ __launch_bounds__(256, 2) void fir_same_mfma_kernel(bf16_t* __restric
         a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fm_lds_s16x4*)(a0 + 4 * 64));
         af[job] = a.u;
       }
-      f32x4 acc[8];
+      f32x4 acc[FM_RS];
 #pragma unroll
-      for (int job = 0; job < 8; ++job) {
+      for (int job = 0; job < FM_RS; ++job) {
         acc[job] = (f32x4){0.f, 0.f, 0.f, 0.f};
         Mfma16<bf16_t>::run(acc[job], af[job], tw[job & 1]);
       }
 #pragma unroll
-      for (int job = 0; job < 8; ++job) {
+      for (int job = 0; job < FM_RS; ++job) {
         const int rr = job >> 2, ct = (job >> 1) & 1, wt = job & 1;
-        const int slot = (s * FM_RS + 2 * wave + rr) & 15;
+        const int slot = (s * FM_RS + (FM_RS / 4) * wave + rr) & (FM_RING - 1);
         // D: lane (n = w' = li, kg) holds channels 16 ct + 4 kg .. + 3 of column 16 wt + li -> one 8-byte ring write.
         // Ring pixel = 64 B = 8 units of 4 channels; unit u sits at u ^ (wp >> 2) (16 lanes of a store: the four
         // pixels sharing wp & 3 take four different units) ^ 4 for ring rows 8..15 (see FM_ZROW)
@@ -218,12 +223,12 @@ __global__ __launch_bounds__(256, 2) void fir_same_mfma_kernel(bf16_t* __restric
     if (s + 2 < nsteps) issue(s + 2);
     const uint4 th_next = bands_h[(int64_t)min(s + 1, nsteps) * 64 + lane];
     // ACT: the activation outputs this step's epilogue needs, requested here so that they arrive under the H pass
-    vec16<bf16_t> fref[4];
+    vec16<bf16_t> fref[FM_RS / 2];
     if constexpr (ACT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < FM_RS / 2; ++i) {
         const int id = tid + 256 * i;
-        const int ho = min(max(s * FM_RS - 4 + (id >> 7), 0), g.H - 1);   // rows outside the image: any valid address
+        const int ho = min(max(s * FM_RS - FM_RS / 2 + (id >> 7), 0), g.H - 1);   // rows outside the image: any valid address
         fref[i].load(g.ref + img + ((int64_t)ho * g.W + c0col + ((id >> 2) & 31)) * g.C + cb0 + (id & 3) * 8);
       }
     }
@@ -235,8 +240,9 @@ __global__ __launch_bounds__(256, 2) void fir_same_mfma_kernel(bf16_t* __restric
       for (int job = 0; job < 16; ++job) {
         const int wp = 8 * wave + (job >> 1), ct = job & 1;
         // A = Z^T [c, slot]: lane addresses ring row 8 (kg & 1) + q (+ 4) (k groups 2, 3 re-read rows 0..15: coefficient 0)
-        const int slot = 8 * (kg & 1) + q;
-        const int u = (4 * ct + p) ^ ((wp >> 2) & 7) ^ ((kg & 1) << 2);
+        const int hi = FM_RS == 8 ? (kg & 1) : 0;   // 4-row steps: the ring has 8 rows, every k group re-reads them
+        const int slot = 8 * hi + q;
+        const int u = (4 * ct + p) ^ ((wp >> 2) & 7) ^ (hi << 2);
         const unsigned char* a0 = Zs + slot * FM_ZROW + wp * 64 + u * 8;
         union { uint4 u4; s16x4 h[2]; } a;
         a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fm_lds_s16x4*)a0);
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void fir_same_mfma_kernel(bf16_t* __restric
         Mfma16<bf16_t>::run(acc[job], af[job], th);
       }
       // D: lane (n = h' = li, kg) holds channels 16 ct + 4 kg .. + 3 of output row 8s - 4 + li at pixel wp
-      if (li < 8) {
+      if (li < FM_RS) {
 #pragma unroll
         for (int job = 0; job < 16; ++job) {
           const int wp = 8 * wave + (job >> 1), ct = job & 1;
@@ -263,10 +269,10 @@ __global__ __launch_bounds__(256, 2) void fir_same_mfma_kernel(bf16_t* __restric
 
     // ---- outputs: 8 rows x 32 pixels x 4 octets, one 16-byte store per unit, 2 KB contiguous per row ----
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FM_RS / 2; ++i) {
       const int id = tid + 256 * i;
       const int o8 = id & 3, px = (id >> 2) & 31, n = id >> 7;
-      const int ho = s * FM_RS - 4 + n;
+      const int ho = s * FM_RS - FM_RS / 2 + n;
       if (ho < 0 || ho >= g.H) continue;   // (inside the lambda's unrolled loop)
       vec16<bf16_t> o;
       o.raw = *reinterpret_cast<const uint4*>(Ys + n * FM_YROW + px * 64 + o8 * 16);
