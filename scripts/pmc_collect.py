@@ -15,7 +15,7 @@ def per_kernel(d, counter):
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 res = {}
-for key in ("conv_pipe_kernel", "conv3x3_strip_kernel", "modconv_pe_fwd_kernel", "modconv_up_kernel"):
+for key in (sys.argv[3:] or ("conv_pipe_kernel", "conv3x3_strip_kernel", "modconv_pe_fwd_kernel", "modconv_up_kernel")):
     fk = [k for k in fetch if key in k]
     wk = [k for k in write if key in k]
     if not fk or not wk:

@@ -1,0 +1,23 @@
+"""Launches the two kernels the end of round 2 added (5 launches each after a warm one) for FETCH_SIZE / WRITE_SIZE passes:
+the MFMA blur at D block 0 (128 x 64x512 x 32, algorithmic 268.4 MB in + 268.4 MB out) and the unrolled 3x3 conv at
+128 x 8x64, 256 -> 256 (algorithmic 33.6 MB in + 33.6 MB out + 1.2 MB of weights).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out_f -- python3 scripts/pmc_probe2.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out_w -- python3 scripts/pmc_probe2.py
+    python scripts/pmc_collect.py out_f out_w fir_same_mfma_kernel conv_pipe_kernel > profiles/round2_pmc_end.json
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dusty-gan-v2_amd")]
+import torch
+from gans.models.ops import native as nat
+sp = nat.ResampleSpec([1, 3, 3, 1], ring=True)
+x = torch.randn(128, 64, 512, 32, device="cuda", dtype=torch.bfloat16)
+for _ in range(6):
+    nat._resample_raw(x, sp, False, (64, 512))
+g = nat.ConvGeom(3, 3, 1, 1, True)
+x2 = torch.randn(128, 8, 64, 256, device="cuda", dtype=torch.bfloat16)
+w2 = torch.randn(256, 3, 3, 256, device="cuda", dtype=torch.bfloat16)
+for _ in range(6):
+    nat._conv_fwd_raw(x2, w2, g)
+torch.cuda.synchronize()
