@@ -238,7 +238,7 @@ __device__ __forceinline__ uint4 wz_tr_read(const char* p0, const char* p1) {
 }
 
 template <int S, int MFN, int NFN, bool K3>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_stream_bf16_kernel(float* __restrict__ part,
+__global__ __launch_bounds__(256, 2) void conv_wgrad_stream_bf16_kernel(float* __restrict__ part,
                                                                         const bf16_t* __restrict__ gy,
                                                                         const bf16_t* __restrict__ x, WSGeom g) {
   using Cf = WZCfg<S, MFN, NFN, K3>;
@@ -366,10 +366,26 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_bf16_kernel(float* _
         const uint4 bb = bnext;
         if (tap + 1 < NT) bnext = bread(tap + 1);
 #pragma unroll
-        for (int mw = 0; mw < MW; ++mw) Mfma16<bf16_t>::run(acc[tap][mw], a[mw], bb);
+        for (int mw = 0; mw < MW; ++mw) {
+          // 64 x 64 tiles in place (inline asm): with the builtin the compiler double-books the 144 accumulator registers
+          // (410 VGPRs + AGPRs: one wave per SIMD); in place the kernel fits two blocks per CU
+          if constexpr (MFN == 4 && NFN == 4) {
+            union { uint4 u; bf16x8 v; } ua, ub;
+            ua.u = a[mw];
+            ub.u = bb;
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[tap][mw]) : "v"(ua.v), "v"(ub.v));
+          } else {   // the smaller tiles have registers to spare and schedule better with the builtin
+            Mfma16<bf16_t>::run(acc[tap][mw], a[mw], bb);
+          }
+        }
       }
     }
   }
+  // every MFMA above has written its accumulator before the stores below read it (the hazard recogniser does not see
+  // inside the asm)
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
 
   // D layout: column (c) = lane & 15, rows (o) = 4 * (lane >> 4) + r
   const int lr = lane & 15, lc = lane >> 4;
@@ -466,9 +482,11 @@ bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, in
   g.ablate = abl;
 #endif
   g.x_shared = 0;
-  static const int blocks_big = getenv("DGV2_WS_BLOCKS_BIG") ? atoi(getenv("DGV2_WS_BLOCKS_BIG")) : 256;
+  // 64 x 64 bf16 tiles: two blocks per CU (the in-place MFMAs keep the kernel inside 256 registers) -- 512 blocks;
+  // measured against 256: 8x64 256->256 115 -> 85 us, 16x128 128->128 117 -> 90 us, 4x32 544->512 156 -> 103 us
+  static const int blocks_big = getenv("DGV2_WS_BLOCKS_BIG") ? atoi(getenv("DGV2_WS_BLOCKS_BIG")) : 512;
   static const int blocks_small = getenv("DGV2_WS_BLOCKS_SMALL") ? atoi(getenv("DGV2_WS_BLOCKS_SMALL")) : 512;
-  int nsplit = (wide32 ? 2 * blocks_big : (p.mfn == 4 && p.nfn == 4) ? blocks_big : blocks_small) / pairs;
+  int nsplit = (wide32 ? 512 : (p.mfn == 4 && p.nfn == 4) ? blocks_big : blocks_small) / pairs;
   nsplit = nsplit < 1 ? 1 : (nsplit > g.ntiles ? g.ntiles : nsplit);
   g.tiles_per_split = (g.ntiles + nsplit - 1) / nsplit;
   p.nsplit = (g.ntiles + g.tiles_per_split - 1) / g.tiles_per_split;
