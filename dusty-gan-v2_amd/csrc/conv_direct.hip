@@ -140,7 +140,7 @@ __device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, 
 // Pipelined kernel.  NI = input-tile staging slots (16 B each) per thread, NW = weight slots.
 // ---------------------------------------------------------------------------------------------
 // TO <= 32: a third wave per SIMD (<= 168 VGPRs) keeps more staging loads in flight on the HBM-bound small-channel layers
-// F33 != 0: the taps are the full 3x3 grid in (dy, dx) order at stride 1 and O is a multiple of TO (host-checked):
+// F33 != 0: the taps are the full 3x3 grid in (dy, dx) order (stride 1; 3: input stride 2) and O is a multiple of TO (host-checked):
 // tap loop unrolled, every LDS offset an immediate, staging loads unconditional.  1 = rows clamp (forward convs),
 // 2 = rows outside the image are zero (data gradients): those rows are staged as whatever the clamped address holds,
 // because every tap that would read them is a dead tap of that output row and is skipped (the host checks that the
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
       // four MFMAs of tap t are issued (same registers), the weight fragments alternate between two sets, so every
       // read has three quarters of a tap's MFMA time to land; dead taps are skipped under wave-uniform branches around
       // in-place MFMAs.  The fences pin that order: left alone the scheduler hoists reads of several taps ahead and spills.
-      constexpr int COLS = DTW + 2;
+      constexpr int COLS = F33 == 3 ? 2 * (DTW - 1) + 3 : DTW + 2;   // halo row length: stride 2 / stride 1
       constexpr int APG = MF / NF;   // A fragments re-read per pixel-fragment group
       static_assert(MF % NF == 0, "A fragments are re-read in equal shares behind the pixel-fragment groups");
       uint4 a[2][MF], bb[NF];
@@ -644,7 +644,8 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   p.inv_cols = 1.0f / (float)p.cols;
   const int n_in = p.rows * p.cols * 4, n_w = TO * p.ntaps * 4;
   if (n_in > NI * 256 || n_w > NW * 256 || p.rows >= 32768 || p.cols >= 65536) return -2;
-  if (F33 && (p.cols != DTW + 2 || p.O % TO || (F33 == 1) != !p.hzero)) return -2;
+  if (F33 && (p.cols != (F33 == 3 ? 2 * (DTW - 1) + 3 : DTW + 2) || p.O % TO || (F33 != 2) != !p.hzero)) return -2;
+  if ((F33 == 3) != (F33 && p.in_stride == 2)) return -2;
   const size_t lds = sizeof(uint4) * 4 * 64 * (size_t)(NI + NW);   // four planes of NI*64 pixels and NW*64 weight rows
   if (lds > 80 * 1024) return -2;   // two blocks per CU
   auto kern = conv_pipe_kernel<T, TO, RW, NI, NC, F33>;
@@ -681,8 +682,10 @@ int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, bool f3
     else return -2;
   }
   if (p.ncls != 1) return -2;
-  if constexpr (TO == 64) {   // the full 3x3 grid at stride 1 with >= 64 output channels: unrolled taps
-    if (f33 && p.O % TO == 0) {
+  if constexpr (TO == 64) {   // the full 3x3 grid with >= 64 output channels: unrolled taps
+    if (f33 && p.O % TO == 0 && p.in_stride == 2) {   // stride-2 forward (the conv behind a blur): 4 x 32 tiles
+      if (!p.hzero && !p.hper) return launch_pipe<T, TO, 1, 10, 1, 3>(y, x, w, p, st);
+    } else if (f33 && p.O % TO == 0) {
       if (p.hzero) {
         if (p.hper) return launch_pipe<T, TO, 2, 7, 1, 2>(y, x, w, p, st);
         if (p.Hg >= 8) return launch_pipe<T, TO, 2, 6, 1, 2>(y, x, w, p, st);
@@ -835,7 +838,8 @@ extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w,
   const bool wrap_ok = !ring || (ioff_w + dxmin >= -Win && in_stride * ((Wg + DTW - 1) / DTW * DTW) + ioff_w + dxmax < 4 * Win);
   const bool plain = ncls == 1 && nextra == 0;
   static const bool no_f33 = getenv("DGV2_NO_F33") != nullptr;   // A/B switch for benchmarking
-  bool f33 = !no_f33 && ncls == 1 && in_stride == 1 && ntaps == 9 && p.rows == 3 && p.cols == 3;
+  bool f33 = !no_f33 && ncls == 1 && (in_stride == 1 || (in_stride == 2 && out_stride == 1 && !hzero)) && ntaps == 9 &&
+             p.rows == 3 && p.cols == 3;
   for (int t = 0; f33 && t < 9; ++t) f33 = p.dy[t] == dymin + t / 3 && p.dx[t] == dxmin + t % 3;
   for (int t = 2; f33 && t < 9; ++t) f33 = p.widx[t] - p.widx[t - 1] == p.widx[1] - p.widx[0];   // weight slots affine in t
   for (int e = 0; f33 && hzero && e < nextra; ++e)   // zero rows are not staged as zeros there: extras must read real rows
