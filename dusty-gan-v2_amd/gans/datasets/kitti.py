@@ -7,9 +7,10 @@ the ring index of every point comes from a prefix sum over the quadrant sequence
 nearest point per pixel from ONE pass of 64-bit atomic-min, and the winners are decoded straight into the decimated
 [6, H, Wout] item (dgv2_kitti_project, csrc/kitti.hip).  Items are CUDA tensors; use `num_workers=0`.
 
-Splits: train / val follow the odometry-to-raw mapping of the reference (:194-213; KITTI devkit data).  "test" lists
-every `*_sync` drive under `root` that is not a train/val drive (the reference restricts it to its city / road /
-residential tables, :246-252)."""
+Splits: train / val follow the odometry-to-raw mapping of the reference (:194-213; KITTI devkit data).  "test" is the
+city / road / residential drives of KITTI Raw that are not train/val drives, in the reference's order (:246-252; the
+drive table is data: kitti_raw_categories.json, category -> date -> drive numbers)."""
+import json
 from pathlib import Path
 
 import numpy as np
@@ -27,6 +28,16 @@ _ODOMETRY_TO_RAW = {
     10: ("2011_09_30_drive_0034_sync", 0, 1200),
 }
 _SPLITS = {"train": [0, 1, 2, 3, 4, 5, 6, 7, 9, 10], "val": [8]}
+_TEST_CATEGORIES = ("city", "road", "residential")          # kitti.py:247
+
+
+def test_drives():
+    """The reference's test split: drives of the three categories, category by category, minus train/val drives."""
+    with open(Path(__file__).with_name("kitti_raw_categories.json")) as f:
+        table = json.load(f)
+    trainval = {v[0] for v in _ODOMETRY_TO_RAW.values()}
+    names = [f"{date}_drive_{n:04d}_sync" for cat in _TEST_CATEGORIES for date, nums in table[cat].items() for n in nums]
+    return [n for n in names if n not in trainval]
 
 
 def ring_rows(x, y, H):
@@ -65,7 +76,6 @@ class KITTIRaw(torch.utils.data.Dataset):
         self.min_depth, self.max_depth, self.flip, self.scan_unfolding = min_depth, max_depth, flip, scan_unfolding
         self.device = torch.device("cuda") if device is None else torch.device(device)
         self.datalist = []
-        trainval = {v[0] for v in _ODOMETRY_TO_RAW.values()}
         if split in _SPLITS:
             for seq in _SPLITS[split]:
                 if seq == 3:
@@ -74,9 +84,8 @@ class KITTIRaw(torch.utils.data.Dataset):
                 for i in range(first, last + 1):
                     self.datalist.append(self.root / name[:10] / name / "velodyne_points" / "data" / f"{i:010d}.bin")
         else:
-            for drive in sorted(self.root.glob("*/*_sync")):
-                if drive.name not in trainval:
-                    self.datalist += sorted((drive / "velodyne_points" / "data").glob("*.bin"))
+            for name in test_drives():
+                self.datalist += sorted((self.root / name[:10] / name / "velodyne_points" / "data").glob("*.bin"))
 
     def __len__(self):
         return len(self.datalist)

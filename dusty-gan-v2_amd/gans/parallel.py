@@ -64,16 +64,24 @@ class FlatGradSync:
         for p in self.params:
             p.grad = None
 
-    def collect(self):
+    def collect(self, accumulate=False, scale=1.0):
         """End of the body: pack the fresh gradients into the flat buffer with one multi-tensor copy and
-        re-attach the views (stable addresses for the captured optimizer graphs and the all-reduce)."""
+        re-attach the views (stable addresses for the captured optimizer graphs and the all-reduce).
+        Gradient accumulation (reference: trainer.py:255-257,296): the chunk's gradients are scaled by
+        `scale` = 1 / num_accumulation (the reference divides the loss) and, from the second chunk on
+        (`accumulate`), ADDED to what the buffer holds."""
         views = self._views()
         dst = [v for v, p in zip(views, self.params) if p.grad is not None]
         src = [p.grad for p in self.params if p.grad is not None]
         if dst:
-            torch._foreach_copy_(dst, src)
+            if accumulate:
+                torch._foreach_add_(dst, src, alpha=scale)
+            else:
+                torch._foreach_copy_(dst, src)
+                if scale != 1.0:
+                    torch._foreach_mul_(dst, scale)
         for v, p in zip(views, self.params):
-            if p.grad is None:
+            if p.grad is None and not accumulate:
                 v.zero_()
             p.grad = v
 

@@ -7,8 +7,10 @@ quick_demo.py:24-34, test_gan.py:47-49,92, trainer.py:551-567):
 The published files pickle `cfg` as an OmegaConf DictConfig.  omegaconf is not a dependency here, so the file is read
 with a RESTRICTED unpickler: tensors / storages and plain containers load normally, every class under `omegaconf.` is
 replaced by an inert stand-in that only receives its pickled attribute dict, and the node tree (DictConfig._content ->
-{key: node}, ListConfig._content -> [node], value nodes ._val) is converted to `gans.config.Config`.  Anything else
-(arbitrary globals) is refused, so a checkpoint cannot run code on load.  Checkpoints written by this build (cfg is a
+{key: node}, ListConfig._content -> [node], value nodes ._val) is converted to `gans.config.Config`.  A global is
+resolved ONLY through an exact (module, name) table (`ALLOWED_GLOBALS`: the tensor / storage rebuild functions, dtypes,
+plain containers, typing.Any & co., the OmegaConf class names); the file never makes this process import or look up
+anything by a name of its choosing, so a checkpoint cannot run code on load.  Checkpoints written by this build (cfg is a
 `gans.config.Config`) load through the same function.  There is no network here: release names resolve to
 $DGV2_CKPT_DIR/<file> if that file exists."""
 import os
@@ -48,24 +50,91 @@ def _stand_in(module, name):
     return type(name, (_OmegaStandIn,), {"_dgv2_cls": f"{module}.{name}", "__module__": __name__})
 
 
-_SAFE_PREFIXES = ("torch", "collections", "numpy", "_codecs", "typing", "enum", "pathlib", "copyreg")
-_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
-                  "complex", "slice", "range", "object", "NoneType", "getattr"}
+# ---------------------------------------------------------------------------------------------------------------
+# The allow-list.  `find_class` NEVER resolves a name the file supplies by importing it: it looks the exact
+# (module, name) pair up in the tables below and returns the object stored there.  Dotted names (protocol 4 resolves
+# "os.getcwd" under module "torch" attribute by attribute) are therefore not reachable, nor is anything merely
+# importable from torch / numpy (torch.utils.collect_env.run, torch.load, torch.hub, torch.storage._load_from_bytes).
+def _numpy_globals():
+    import numpy as np
+    try:
+        from numpy._core import multiarray as ma     # numpy >= 2
+    except ImportError:                              # pragma: no cover
+        from numpy.core import multiarray as ma
+    out = {}
+    for mod in ("numpy.core.multiarray", "numpy._core.multiarray"):      # either spelling, whichever numpy wrote the file
+        out[(mod, "_reconstruct")] = ma._reconstruct
+        out[(mod, "scalar")] = ma.scalar
+    out[("numpy", "ndarray")] = np.ndarray
+    out[("numpy", "dtype")] = np.dtype
+    return out
+
+
+def _torch_globals():
+    import collections
+    import _codecs
+    out = {
+        ("torch._utils", "_rebuild_tensor_v2"): torch._utils._rebuild_tensor_v2,
+        ("torch._utils", "_rebuild_tensor"): torch._utils._rebuild_tensor,
+        ("torch._utils", "_rebuild_parameter"): torch._utils._rebuild_parameter,
+        ("torch", "Size"): torch.Size,
+        ("torch", "device"): torch.device,
+        ("torch.storage", "UntypedStorage"): torch.UntypedStorage,
+        ("torch", "UntypedStorage"): torch.UntypedStorage,
+        ("collections", "OrderedDict"): collections.OrderedDict,
+        ("collections", "defaultdict"): collections.defaultdict,   # OmegaConf's Metadata.resolver_cache
+        ("_codecs", "encode"): _codecs.encode,                      # numpy arrays / bytes in protocol-2 pickles
+    }
+    for n in ("Double", "Float", "Half", "BFloat16", "Long", "Int", "Short", "Char", "Byte", "Bool",
+              "ComplexFloat", "ComplexDouble"):
+        out[("torch", n + "Storage")] = getattr(torch, n + "Storage")
+    for n in dir(torch):                                            # dtypes pickle as the global `torch.<name>`
+        if isinstance(getattr(torch, n), torch.dtype):
+            out[("torch", n)] = getattr(torch, n)
+    return out
+
+
+_BUILTINS = ("dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
+             "complex", "slice", "range", "object")
+_TYPING = ("Any", "Dict", "List", "Tuple", "Union", "Optional")       # Metadata.ref_type / key_type / element_type
+# every class an OmegaConf 2.x config tree pickles (omegaconf/{dictconfig,listconfig,base,nodes}.py); each becomes an
+# inert stand-in (no code of omegaconf runs, it is not even importable here)
+OMEGACONF_CLASSES = (
+    ("omegaconf.dictconfig", "DictConfig"), ("omegaconf.listconfig", "ListConfig"),
+    ("omegaconf.base", "ContainerMetadata"), ("omegaconf.base", "Metadata"),
+    ("omegaconf.nodes", "AnyNode"), ("omegaconf.nodes", "IntegerNode"), ("omegaconf.nodes", "FloatNode"),
+    ("omegaconf.nodes", "StringNode"), ("omegaconf.nodes", "BooleanNode"), ("omegaconf.nodes", "BytesNode"),
+    ("omegaconf.nodes", "PathNode"), ("omegaconf.nodes", "EnumNode"), ("omegaconf.nodes", "InterpolationResultNode"),
+)
+
+
+def _build_allowed():
+    import builtins
+    import typing
+    table = {}
+    table.update(_torch_globals())
+    table.update(_numpy_globals())
+    for n in _BUILTINS:
+        table[("builtins", n)] = getattr(builtins, n)
+    for n in _TYPING:
+        table[("typing", n)] = getattr(typing, n)
+    for mod, n in OMEGACONF_CLASSES:
+        table[(mod, n)] = _stand_in(mod, n)
+    table[("gans.config", "Config")] = Config
+    return table
+
+
+ALLOWED_GLOBALS = _build_allowed()
 
 
 class _RestrictedUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         module = {"__builtin__": "builtins", "copy_reg": "copyreg"}.get(module, module)   # protocol-2 pickles
-        root = module.split(".")[0]
-        if root == "omegaconf":
-            return _stand_in(module, name)
-        if module == "gans.config" and name == "Config":
-            return Config
-        if module == "builtins" and name in _SAFE_BUILTINS:
-            return super().find_class(module, name)
-        if root in _SAFE_PREFIXES and not (root == "torch" and name in ("load", "hub")):
-            return super().find_class(module, name)
-        raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}: refused by the restricted loader")
+        try:
+            return ALLOWED_GLOBALS[(module, name)]
+        except KeyError:
+            raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}: refused by the restricted loader "
+                                         "(gans.pretrained.ALLOWED_GLOBALS lists what a checkpoint may name)") from None
 
 
 class _RestrictedPickle:

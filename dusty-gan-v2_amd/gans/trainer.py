@@ -58,12 +58,14 @@ class Trainer:
         self.resolution = cfg.model.generator.synthesis_kwargs.resolution
         self.B = int(cfg.training.get("batch_size_per_gpu", cfg.training.batch_size // self.num_gpus))
         self.batch_size = int(cfg.training.batch_size)
-        if self.batch_size != self.B * self.num_gpus:
-            # train_gan.py:183-185 derives batch_size_per_gpu = batch_size // num_gpus and the loader hands out exactly
-            # one chunk of that size per step, so the reference's accumulation loop (trainer.py:255-257) always runs
-            # once; EMA, warm-up and the resume arithmetic all assume the global batch is what one step processed
-            raise ValueError(f"training.batch_size ({self.batch_size}) must equal batch_size_per_gpu ({self.B}) x "
-                             f"num_gpus ({self.num_gpus}): gradient accumulation over several chunks is not built")
+        # gradient accumulation (reference: trainer.py:255-257, context_manager.py:21-35): a rank's share of the global
+        # batch is processed in `num_accumulation` chunks of batch_size_per_gpu; gradients are exchanged once, after
+        # the last chunk.  (train_gan.py:183-185 always derives batch_size_per_gpu = batch_size // num_gpus, i.e. one
+        # chunk; a config that sets both keys gets the loop.)
+        if self.batch_size % (self.B * self.num_gpus) != 0:
+            raise ValueError(f"training.batch_size ({self.batch_size}) must be a multiple of batch_size_per_gpu "
+                             f"({self.B}) x num_gpus ({self.num_gpus})")
+        self.num_accumulation = self.batch_size // (self.B * self.num_gpus)
         if cfg.training.gan_objective in ("ragan", "rahinge", "ralsgan"):
             raise NotImplementedError(f"gan_objective={cfg.training.gan_objective}: the relativistic objectives need "
                                       "D(A(real)) in the generator step (trainer.py:283-287), which is not built")
@@ -143,7 +145,9 @@ class Trainer:
         # resume
         self.start_iteration = 0
         if cfg.training.get("resume") is not None:
-            sd = torch.load(cfg.training.resume, map_location="cpu", weights_only=False)
+            # the reference's checkpoints pickle cfg as an OmegaConf tree: read through the restricted loader
+            from gans.pretrained import load_checkpoint
+            sd = load_checkpoint(cfg.training.resume, map_location="cpu")
             self.start_iteration = sd["step"] // self.batch_size
             self.G.load_state_dict(sd["G"])
             self.D.load_state_dict(sd["D"])
@@ -208,6 +212,8 @@ class Trainer:
         if self._wu_n > 0:
             x = filter2d(x, self._wu_taps, normalize=False)
         if keep is None:
+            if float(self.cfg.training.warmup.dropout_init_ratio) == 0.0:
+                return x                      # blur-only warm-up: no mask to draw, nothing to blend
             keep = (torch.rand_like(x) < (1 - self._wu_ratio)).to(x.dtype)
         return keep * x + (1 - keep) * float(self.cfg.dataset.raydrop_const)
 
@@ -250,7 +256,7 @@ class Trainer:
     # Each sub-step is split into a forward/backward body (`*_fb`), the gradient all-reduce (eager,
     # RCCL) and the optimizer body, so that the bodies can be replayed as hipGraphs while the
     # collectives stay ordinary stream work between them.
-    def g_fb(self, scalars):
+    def g_fb(self, j, scalars):
         set_requires_grad(self.G, True)
         self.g_sync.begin()
         z = self._z("g")
@@ -261,11 +267,11 @@ class Trainer:
         else:
             loss_gan = self.adversarial_loss(None, y_fake, "G")
         (self.cfg.training.loss.gan * loss_gan).backward()
-        self.g_sync.collect()
+        self.g_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
         set_requires_grad(self.G, False)
         scalars["loss/G/adversarial"] = loss_gan.detach()
 
-    def d_fb(self, x_real, scalars):
+    def d_fb(self, x_real, j, scalars):
         set_requires_grad(self.D, True)
         self.d_sync.begin()
         z = self._z("d")
@@ -287,12 +293,12 @@ class Trainer:
             loss_gan = self.adversarial_loss(y_real, y_fake, "D")
             out_real, out_fake = y_real.mean().detach(), y_fake.mean().detach()
         (self.cfg.training.loss.gan * loss_gan).backward()
-        self.d_sync.collect()
+        self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
         scalars["loss/D/output/real"] = out_real
         scalars["loss/D/output/fake"] = out_fake
         scalars["loss/D/adversarial"] = loss_gan.detach()
 
-    def r1_fb(self, x_real, scalars):
+    def r1_fb(self, x_real, j, scalars):
         """lazy R1 (reference: trainer.py:419-451): double backward through D and ADA."""
         set_requires_grad(self.D, True)
         self.d_sync.begin()
@@ -302,7 +308,7 @@ class Trainer:
         r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
         loss = (self.gp_weight / 2) * r1 + 0.0 * y_real.squeeze()[0]
         loss.backward()
-        self.d_sync.collect()
+        self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
         scalars["loss/D/gradient_penalty"] = r1.detach()
 
     def ema_decay(self, iteration):
@@ -325,6 +331,8 @@ class Trainer:
             return scalars
         if self._warm() and not name.endswith("_opt"):
             name = name + "/warmup"   # the fade-in regime has its own captures (extra blur / dropout work)
+        if self._injected is not None and not name.endswith("_opt"):
+            name = name + "/inj"      # bodies that read injected draws are different graphs than the sampling ones
         if name not in self._graphs:
             if self._graph_warm.get(name, 0) < 2:  # allocator / autotune warm-up before capture
                 self._graph_warm[name] = self._graph_warm.get(name, 0) + 1
@@ -368,19 +376,52 @@ class Trainer:
             opt.step()
 
     # ------------------------------------------------------------------ one iteration
+    def _acc_name(self, name, j):
+        # chunk 0 overwrites the flat gradient buffer, later chunks add to it: two different captured bodies
+        return name if j == 0 else name + "/acc"
+
     def step(self, iteration):
         self.G.train()
         self.set_warmup_params(iteration)
-        scalars = {}
-        self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
+        nacc = self.num_accumulation
+        per_chunk = defaultdict(list)
 
-        parallel.sync_buffers(self.G)
-        scalars.update(self._run("g_fb", self.g_fb))
+        def log(sc):
+            for k, v in sc.items():
+                # under graph replay the body's scalar tensors are static buffers: keep a copy per chunk
+                per_chunk[k].append(v.clone() if nacc > 1 else v)
+
+        # a rank's share of the global batch, chunk by chunk (reference: trainer.py:253-257)
+        if nacc == 1:
+            self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
+            reals = [self.x_real]
+        else:
+            reals = [self.fetch_reals(next(self.iter_train_loader))["image"] for _ in range(nacc)]
+
+        def real(j):
+            if nacc > 1:
+                self.x_real.copy_(reals[j])
+            return self.x_real
+
+        # DDP(broadcast_buffers=True) re-broadcasts rank 0's buffers before a forward of the wrapped G whenever the
+        # PREVIOUS forward ran with grad mode on and outside `no_sync` (torch DDP: require_forward_param_sync).  The
+        # reference's D step calls G with grad mode on (trainer.py:379, only requires_grad is off), so both G forwards
+        # of an iteration are preceded by a broadcast -- between the two this rank's forward has moved ema_var / w_avg,
+        # the second one is not redundant -- while the later chunks of an accumulation loop (their predecessors ran
+        # under no_sync) are not.  Exactly that is kept.
+        for j in range(nacc):
+            if j == 0:
+                parallel.sync_buffers(self.G)
+            log(self._run(self._acc_name("g_fb", j), self.g_fb, j))
+        # nothing on this rank is independent of G's reduced gradient (the D step starts with a forward of the updated
+        # G), so this 17.5 MB reduction is synchronous
         self.g_sync.all_reduce()
         self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
 
-        parallel.sync_buffers(self.G)
-        scalars.update(self._run("d_fb", self.d_fb, self.x_real))
+        for j in range(nacc):
+            if j == 0:
+                parallel.sync_buffers(self.G)
+            log(self._run(self._acc_name("d_fb", j), self.d_fb, real(j), j))
         # the 154 MB gradient reduction of D runs on the communication stream while the EMA generator is updated
         # (G is final for this iteration: nothing below touches it)
         pending = self.d_sync.all_reduce(async_op=True)
@@ -390,11 +431,14 @@ class Trainer:
         self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
 
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
-            scalars.update(self._run("r1_fb", self.r1_fb, self.x_real))
+            for j in range(nacc):
+                log(self._run(self._acc_name("r1_fb", j), self.r1_fb, real(j), j))
             self.d_sync.all_reduce()
             self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
         set_requires_grad(self.D, False)
 
+        scalars = {k: (v[0] if len(v) == 1 else torch.stack([t.reshape(()) for t in v]).mean())
+                   for k, v in per_chunk.items()}          # mean over the chunks (reference: trainer.py:471-476)
         if iteration % self.lazy_ada == 0:
             scalars["stats/ada_rt"] = self.A.update_p().reshape(())
             scalars["stats/ada_p"] = self.A.p.detach().clone()
@@ -406,6 +450,11 @@ class Trainer:
         out["stats/warmup_blur_sigma"] = self.blur_sigma
         out["stats/warmup_dropout_ratio"] = self.dropout_ratio
         return out
+
+    def graphs_live(self):
+        """name -> True (captured, replaying) / False (capture failed: that body runs eagerly).  bench.py asserts that
+        no body silently fell back."""
+        return {k: v is not None for k, v in self._graphs.items()}
 
     @torch.no_grad()
     def sample(self, ema=False):
@@ -467,7 +516,7 @@ class Trainer:
         }
 
     def save_checkpoint(self, save_path, step):
-        """Same keys as the reference (trainer.py:551-567)."""
+        """Same keys as the reference (trainer.py:551-567); `cfg` is stored as plain containers (see `plain`)."""
         def optim_state(opt):
             # the fused Adam kernel keeps ONE device step counter that every per-parameter `step` entry views; a
             # checkpoint carries independent copies so that stock torch.optim.Adam can resume from it
@@ -477,8 +526,17 @@ class Trainer:
                     st["step"] = st["step"].detach().clone().reshape(())
             return sd
 
+        def plain(o):
+            # cfg as plain dicts / lists: loadable anywhere without this package (the reference's consumers wrap it
+            # with OmegaConf.create(ckpt["cfg"]); gans.pretrained.load_checkpoint turns it back into a Config)
+            if isinstance(o, dict):
+                return {k: plain(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [plain(v) for v in o]
+            return o
+
         ckpt = {
-            "cfg": self.cfg, "step": step, "angle": self.coord.angle.detach().cpu(),
+            "cfg": plain(self.cfg), "step": step, "angle": self.coord.angle.detach().cpu(),
             "G": self.G.state_dict(), "D": self.D.state_dict(), "G_ema": self.G_ema.state_dict(),
             "A": self.A.state_dict(), "optim_G": optim_state(self.optim_G), "optim_D": optim_state(self.optim_D),
         }

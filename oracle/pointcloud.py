@@ -5,9 +5,12 @@ torch.utils.cpp_extension.load (gans/sampling/fps/furthest_point_sampling.py:10-
 earth_mover_distance.py:7-14); there is no CUDA device or nvcc here, the reference ships no golden vectors for them,
 so these restatements follow the kernel text and are cross-checked only against literal thread-by-thread simulations
 (tests/test_oracle_pointcloud.py) and independent solvers (scipy's optimal assignment as a lower bound for the EMD).
-The chamfer restatement follows the reference's own CPU path (chamfer_distance.cpp:42-144, plain C loops); building
-that file into oracle/_ref was tried and is not possible on this image (it includes c10/cuda/CUDAGuard.h, whose
-cuda_cmake_macros.h does not exist in a ROCm torch), so it is cross-checked against scipy.spatial.cKDTree instead.
+The chamfer restatement follows the reference's own CPU path (chamfer_distance.cpp:42-144, plain C loops) and IS
+PINNED: the file as a whole is not buildable on this image (it includes c10/cuda/CUDAGuard.h, whose generated
+cuda_cmake_macros.h does not exist in a ROCm torch), but its neighbour search `nnsearch` (:42-65) is header-free C;
+oracle/build_ref.py compiles that function from the reference file into oracle/_ref (git-ignored) and
+tests/golden/chamfer.npz holds its outputs (distances and first-minimum indices reproduced bit for bit,
+tests/test_oracle_pointcloud.py); scipy.spatial.cKDTree stays as an independent cross-check.
 
 numpy; fp32 arithmetic where the selected indices depend on it, float64 for the EMD (compared with a tolerance).
 """

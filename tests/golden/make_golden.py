@@ -887,8 +887,42 @@ def golden_baselines():
     save("baselines.npz", out)
 
 
+def chamfer_inputs():
+    """Seeded cloud pairs for chamfer.npz: scan-like random clouds of ragged sizes, a batch, a single point, and integer
+    lattices (many exactly tied distances: the first minimum must win)."""
+    rng = np.random.default_rng(20261003)
+    cases = {}
+    for name, (B, n, m) in {"tiny": (1, 1, 1), "ragged": (2, 37, 101), "batch": (3, 256, 64), "wide": (2, 700, 900)}.items():
+        r1 = rng.uniform(1.5, 80.0, size=(B, n, 1))
+        r2 = rng.uniform(1.5, 80.0, size=(B, m, 1))
+        u1, u2 = rng.standard_normal((B, n, 3)), rng.standard_normal((B, m, 3))
+        cases[name] = ((r1 * u1 / np.linalg.norm(u1, axis=-1, keepdims=True)).astype(np.float32),
+                       (r2 * u2 / np.linalg.norm(u2, axis=-1, keepdims=True)).astype(np.float32))
+    cases["lattice"] = (rng.integers(-2, 3, size=(2, 300, 3)).astype(np.float32),
+                        rng.integers(-2, 3, size=(2, 500, 3)).astype(np.float32))
+    return cases
+
+
+def golden_chamfer():
+    """The reference's CPU neighbour search (gans/metrics/distance/cd/chamfer_distance.cpp:42-65) COMPILED from the
+    reference file by oracle/build_ref.py (g++; the function is header-free C), run both ways as
+    chamfer_distance_forward does (:68-86)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import build_ref
+    build_ref.build_chamfer()
+    out = {}
+    for name, (a, b) in chamfer_inputs().items():
+        d1, i1 = build_ref.ref_nnsearch(a, b)
+        d2, i2 = build_ref.ref_nnsearch(b, a)
+        out.update({f"{name}.xyz1": a, f"{name}.xyz2": b, f"{name}.dist1": d1, f"{name}.dist2": d2,
+                    f"{name}.idx1": i1, f"{name}.idx2": i2})
+    save("chamfer.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation", "metrics", "baselines"]
+    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation", "metrics", "baselines", "chamfer"]
+    if "chamfer" in which:
+        golden_chamfer()
     if "ops" in which:
         golden_ops()
     if "coords" in which:

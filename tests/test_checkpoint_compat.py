@@ -52,6 +52,112 @@ def test_restricted_loader_refuses_code():
         load_checkpoint(buf)
 
 
+def _payload_refused(data):
+    from gans.pretrained import _RestrictedUnpickler
+    with pytest.raises(pickle.UnpicklingError):
+        _RestrictedUnpickler(io.BytesIO(data)).load()
+
+
+def test_restricted_loader_resolves_nothing_by_name(tmp_path):
+    """The two bypasses of the former prefix filter (advisor, round 2), with benign payloads: a dotted name under an
+    allowed root (protocol 4 resolves 'os.getcwd' attribute by attribute from the module `torch`), and a function
+    merely importable from torch that runs a shell command.  Plus the other ways out of a prefix filter."""
+    marker = tmp_path / "ran"
+    dotted = (b"\x80\x04\x8c\x05torch\x8c\tos.getcwd\x93)R.")     # STACK_GLOBAL torch 'os.getcwd'; REDUCE ()
+    assert pickle.loads(dotted) == os.getcwd()                       # the payload is live for stock pickle
+    _payload_refused(dotted)
+
+    import torch.utils.collect_env as ce
+
+    class RunsShell:
+        def __reduce__(self):
+            return (ce.run, (f"touch {marker}",))
+    _payload_refused(pickle.dumps(RunsShell()))
+    assert not marker.exists()
+
+    class Getattr:
+        def __reduce__(self):
+            return (getattr, (torch.Tensor, "numpy"))
+    _payload_refused(pickle.dumps(Getattr()))
+    for mod, name in (("torch", "load"), ("torch.hub", "load"), ("torch.storage", "_load_from_bytes"),
+                      ("numpy", "load"), ("numpy.lib.npyio", "load"), ("pathlib", "Path"), ("builtins", "eval"),
+                      ("builtins", "getattr"), ("builtins", "__import__"), ("copyreg", "_reconstructor"),
+                      ("omegaconf", "OmegaConf"), ("omegaconf.dictconfig", "DictConfig.__init__")):
+        _payload_refused(b"\x80\x02c" + mod.encode() + b"\n" + name.encode() + b"\n.")
+    # through torch.load as well (the zip container's data.pkl goes through the same find_class)
+    from gans.pretrained import load_checkpoint
+    buf = io.BytesIO()
+    torch.save({"cfg": {"a": 1}, "x": RunsShell()}, buf)
+    buf.seek(0)
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint(buf)
+    assert not marker.exists()
+
+
+def test_every_allowed_global_round_trips():
+    """The allow-list is exact: each (module, name) a published checkpoint may carry -- the tensor rebuild functions,
+    storages, dtypes, containers, typing.Any & co. and every OmegaConf 2.x class of a pickled DictConfig tree --
+    resolves to the object stored in the table, and a tree built from all the OmegaConf names converts to Config."""
+    import collections
+    import typing
+
+    import numpy as np
+    from gans.config import Config
+    from gans.pretrained import ALLOWED_GLOBALS, OMEGACONF_CLASSES, _OmegaStandIn, _plain, _RestrictedUnpickler
+    for (mod, name), obj in ALLOWED_GLOBALS.items():
+        got = _RestrictedUnpickler(io.BytesIO(b"c" + mod.encode() + b"\n" + name.encode() + b"\n.")).load()
+        assert got is obj
+        assert "." not in name
+    for need in (("typing", "Any"), ("builtins", "dict"), ("builtins", "list"), ("collections", "defaultdict"),
+                 ("omegaconf.dictconfig", "DictConfig"), ("omegaconf.listconfig", "ListConfig"),
+                 ("omegaconf.base", "ContainerMetadata"), ("omegaconf.base", "Metadata"),
+                 ("omegaconf.nodes", "AnyNode"), ("omegaconf.nodes", "IntegerNode"), ("omegaconf.nodes", "FloatNode"),
+                 ("omegaconf.nodes", "StringNode"), ("omegaconf.nodes", "BooleanNode")):
+        assert need in ALLOWED_GLOBALS, need
+    assert ALLOWED_GLOBALS[("typing", "Any")] is typing.Any
+    # a hand-assembled pickle that names EVERY OmegaConf class: object per class (NEWOBJ + BUILD with omegaconf's
+    # attribute layout), metadata carrying typing.Any / builtins.dict / a defaultdict(dict) resolver cache
+    def glob(mod, name):
+        return b"c" + mod.encode() + b"\n" + name.encode() + b"\n"
+    meta_state = (b"}(" + b"X\x08\x00\x00\x00ref_type" + glob("typing", "Any")
+                  + b"X\x0b\x00\x00\x00object_type" + glob("builtins", "dict")
+                  + b"X\x0e\x00\x00\x00resolver_cache" + glob("collections", "defaultdict") + glob("builtins", "dict")
+                  + b"\x85R" + b"u")
+    for mod, name in OMEGACONF_CLASSES:
+        body = b"\x80\x02" + glob(mod, name) + b")\x81"
+        if name in ("DictConfig", "ListConfig"):
+            content = b"}X\x01\x00\x00\x00kK\x07s" if name == "DictConfig" else b"]K\x07a"
+            state = (b"}(X\t\x00\x00\x00_metadata" + glob("omegaconf.base", "ContainerMetadata") + b")\x81" + meta_state
+                     + b"bX\x07\x00\x00\x00_parentNX\x08\x00\x00\x00_content" + content + b"u")
+        elif name.endswith("Metadata"):
+            state = meta_state
+        else:
+            state = (b"}(X\t\x00\x00\x00_metadata" + glob("omegaconf.base", "Metadata") + b")\x81" + meta_state
+                     + b"bX\x07\x00\x00\x00_parentNX\x04\x00\x00\x00_valK\x07u")
+        obj = _RestrictedUnpickler(io.BytesIO(body + state + b"b.")).load()
+        assert isinstance(obj, _OmegaStandIn) and obj._dgv2_cls == f"{mod}.{name}"
+        if name == "DictConfig":
+            assert _plain(obj) == Config({"k": 7}) and isinstance(obj._metadata.resolver_cache, collections.defaultdict)
+        elif name == "ListConfig":
+            assert _plain(obj) == [7]
+        elif not name.endswith("Metadata"):
+            assert _plain(obj) == 7
+    # numpy arrays and scalars written by either numpy generation
+    for v in (np.arange(3.0), np.float32(2.5)):
+        got = _RestrictedUnpickler(io.BytesIO(pickle.dumps(v, protocol=2))).load()
+        assert np.array_equal(got, v)
+
+
+def test_trainer_resume_goes_through_the_restricted_loader():
+    """gans/trainer.py resume branch: a reference checkpoint (cfg = OmegaConf tree) must load without omegaconf and
+    without plain pickle (advisor, round 2)."""
+    import inspect
+
+    import gans.trainer as T
+    src = inspect.getsource(T.Trainer.__init__)
+    assert "load_checkpoint(cfg.training.resume" in src and "weights_only=False" not in src
+
+
 def test_release_names_resolve_locally(tmp_path, monkeypatch):
     from gans.pretrained import PRETRAINED_CKPTS, autoload_ckpt, is_available_model
     assert is_available_model("dusty_v2") and PRETRAINED_CKPTS["dusty_v2"].endswith("dustyv2_kitti_64x512_25M.pth")

@@ -123,6 +123,44 @@ def test_chamfer_forward_is_bit_exact(B, n, m):
     np.testing.assert_array_equal(d2.cpu().numpy(), w2)
 
 
+def _chamfer_golden():
+    import os
+
+    from conftest import GOLDEN
+    d = np.load(os.path.join(GOLDEN, "chamfer.npz"))
+    return d, sorted({k.split(".")[0] for k in d.files})
+
+
+def test_chamfer_matches_the_compiled_reference_fixture():
+    """tests/golden/chamfer.npz: outputs of the reference's own `nnsearch` (chamfer_distance.cpp:42-65) compiled from
+    the reference file (oracle/build_ref.py).  Distances and first-minimum indices are bit-exact, both directions."""
+    from gans.metrics.distance import chamfer_distance
+    d, names = _chamfer_golden()
+    assert names == ["batch", "lattice", "ragged", "tiny", "wide"]
+    for name in names:
+        d1, d2, i1, i2 = chamfer_distance(dev(d[f"{name}.xyz1"]), dev(d[f"{name}.xyz2"]))
+        for got, key in ((d1, "dist1"), (d2, "dist2"), (i1, "idx1"), (i2, "idx2")):
+            np.testing.assert_array_equal(got.cpu().numpy(), d[f"{name}.{key}"], err_msg=f"{name}.{key}")
+
+
+def test_chamfer_at_the_evaluation_size_against_the_compiled_reference():
+    """2048 x 2048 clouds (the size cov_mmd_1nna uses) against oracle/_ref's compiled reference function run here on the
+    host.  oracle/_ref travels with the snapshot; without it (a checkout that never ran oracle/build_ref.py) the
+    fixture test above is the pin."""
+    from gans.metrics.distance import chamfer_distance
+    from oracle import build_ref
+    if build_ref.load_chamfer() is None:
+        pytest.skip("oracle/_ref not built")
+    a, b = clouds(11, 2, 2048), clouds(12, 2, 2048)
+    d1, d2, i1, i2 = chamfer_distance(dev(a), dev(b))
+    w1, j1 = build_ref.ref_nnsearch(a, b)
+    w2, j2 = build_ref.ref_nnsearch(b, a)
+    np.testing.assert_array_equal(i1.cpu().numpy(), j1)
+    np.testing.assert_array_equal(i2.cpu().numpy(), j2)
+    np.testing.assert_array_equal(d1.cpu().numpy(), w1)
+    np.testing.assert_array_equal(d2.cpu().numpy(), w2)
+
+
 def test_chamfer_first_minimum_wins_on_a_lattice():
     from gans.metrics.distance import chamfer_distance
     from oracle import pointcloud as pc

@@ -63,7 +63,10 @@ def test_checkpoint_roundtrip(tmp_path):
     tr.step(1)
     path = pathlib.Path(tmp_path) / "models" / "checkpoint_0000000008.pth"
     tr.save_checkpoint(path, 8)
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    raw = torch.load(path, map_location="cpu", weights_only=True)   # plain containers + tensors only
+    assert type(raw["cfg"]) is dict and type(raw["cfg"]["model"]) is dict
+    from gans.pretrained import load_checkpoint
+    ck = load_checkpoint(path)
     assert set(ck) == {"cfg", "step", "angle", "G", "D", "G_ema", "A", "optim_G", "optim_D"}  # reference keys
     assert ck["angle"].shape == (1, 2, 16, 64) and ck["step"] == 8
     from gans.models.builder import build_generator
@@ -150,7 +153,7 @@ def test_iterations_match_reference_trainer(tag, hip_graph):
     if hip_graph:
         for it in range(1, 7):     # two eager warm runs + capture of every body (R1 runs on even iterations)
             _run_fixture_iteration(tr, d, tag, it, n)
-        suffix = "/warmup" if tag == "w." else ""
+        suffix = ("/warmup" if tag == "w." else "") + "/inj"    # bodies reading injected draws are their own graphs
         assert {"g_fb" + suffix, "d_fb" + suffix, "r1_fb" + suffix, "g_opt", "d_opt"} <= set(tr._graphs)
         assert all(v is not None for v in tr._graphs.values()), "a body fell back to eager"
         _reset(tr, hp, sdG, sdD)
@@ -305,3 +308,57 @@ def test_full_size_bf16_graph_replay_equals_eager():
         n_frac = _state_mismatch(state_first[name], me.state_dict())
         g_frac = _state_mismatch(me.state_dict(), mg.state_dict())
         assert g_frac <= 3 * n_frac + 1e-4, (name, g_frac, n_frac)
+
+
+# ---------------------------------------------------------------------------- gradient accumulation
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_gradient_accumulation_equals_the_mean_of_the_chunks(hip_graph):
+    """reference: trainer.py:253-257,296 + context_manager.py:21-35 -- batch_size = 2 x batch_size_per_gpu x num_gpus
+    runs every body twice per iteration, each chunk's loss divided by the number of chunks, ONE optimizer step.  With
+    the draws and reals of fixture iterations 1 and 2 injected as chunk 0 and chunk 1, the flat gradient buffer after
+    the loop must be the mean of the two chunks' gradients (taken from a one-chunk trainer), eagerly and when both
+    chunk bodies are hipGraph replays."""
+    from helpers import trainer_fixture_draws, trainer_fixture_reals
+    d = _load_trainer_fixture()
+    tag = "t."
+    one, hp, sdG, sdD = _fixture_trainer(d, tag, False)
+    two, _, _, _ = _fixture_trainer(d, tag, hip_graph)
+    two.batch_size, two.num_accumulation = 16, 2          # what Trainer.__init__ derives from batch_size = 16
+    x = []
+    for j in (1, 2):
+        depth, mask = trainer_fixture_reals(tag, j)
+        x.append(one.fetch_reals({"depth": depth.cuda(), "mask": mask.cuda()})["image"])
+    draws = [trainer_fixture_draws(d, tag, j) for j in (1, 2)]
+
+    def chunk(tr, fb, j, acc_j):
+        tr.G.load_state_dict(sdG)          # same ema_var / w_avg history on both trainers
+        tr.set_draws(draws[j])
+        if fb == "g_fb":
+            tr._run(tr._acc_name(fb, acc_j), tr.g_fb, acc_j)
+        else:
+            tr.x_real.copy_(x[j])
+            tr._run(tr._acc_name(fb, acc_j), getattr(tr, fb), tr.x_real, acc_j)
+
+    for fb, sync in (("g_fb", "g_sync"), ("d_fb", "d_sync"), ("r1_fb", "d_sync")):
+        _reset(one, hp, sdG, sdD)
+        _reset(two, hp, sdG, sdD)
+        want = []
+        for j in range(2):
+            chunk(one, fb, j, 0)
+            want.append(getattr(one, sync).flat.clone())
+        want = 0.5 * (want[0] + want[1])
+        for rep in range(4 if hip_graph else 1):          # graphs: two warm runs, the capture, one replay
+            for j in range(2):
+                chunk(two, fb, j, j)
+        if hip_graph:
+            assert two._graphs.get(fb + "/inj") is not None and two._graphs.get(fb + "/acc/inj") is not None
+        got = getattr(two, sync).flat
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err < 2e-5, (fb, err)
+
+    # whole iterations through Trainer.step with the loop: finite scalars (chunk means), ONE optimizer step per phase
+    two.set_draws(None)
+    for it in range(1, 6):
+        out = two.step(it)
+    assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
+    assert int(next(iter(two.optim_G.state.values()))["step"]) == 5

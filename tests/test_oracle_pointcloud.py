@@ -115,6 +115,31 @@ def test_chamfer_oracle_against_a_kd_tree(n, m):
             assert (ix == nn).mean() > 0.99      # equal up to fp32 near-ties
 
 
+def test_chamfer_oracle_is_pinned_to_the_compiled_reference():
+    """tests/golden/chamfer.npz = outputs of the reference's `nnsearch` (chamfer_distance.cpp:42-65) compiled from the
+    reference file by oracle/build_ref.py.  The restatement reproduces distances and indices bit for bit; where
+    oracle/_ref is present (build container, GPU box) the compiled function is also run on fresh clouds."""
+    import os
+
+    from conftest import GOLDEN
+    from oracle import build_ref
+    d = np.load(os.path.join(GOLDEN, "chamfer.npz"))
+    names = sorted({k.split(".")[0] for k in d.files})
+    assert names == ["batch", "lattice", "ragged", "tiny", "wide"]
+    for name in names:
+        got = pc.chamfer_forward(d[f"{name}.xyz1"], d[f"{name}.xyz2"])
+        for g, key in zip(got, ("dist1", "dist2", "idx1", "idx2")):
+            np.testing.assert_array_equal(g, d[f"{name}.{key}"], err_msg=f"{name}.{key}")
+    if build_ref.load_chamfer() is not None:
+        rng = np.random.default_rng(5)
+        a = rng.standard_normal((2, 513, 3)).astype(np.float32) * 20
+        b = rng.standard_normal((2, 300, 3)).astype(np.float32) * 20
+        w, j = build_ref.ref_nnsearch(a, b)
+        g, i = pc.nnsearch(a, b)
+        np.testing.assert_array_equal(i, j)
+        np.testing.assert_array_equal(g, w)
+
+
 def test_chamfer_first_minimum_wins():
     a = np.zeros((1, 3, 3), dtype=F32)
     b = np.array([[[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]]], dtype=F32)      # all at distance 1
