@@ -179,10 +179,12 @@ def roofline_probe(args, reps=20):
 def modconv_probe(args, reps=20):
     """The MFMA kernel north_star names: the modulated 1x1 conv at its heaviest site, generator level-4 conv1
     (B x 32768 pixels, K = 64 + 512 shared-PE channels, O = 32, bias + lrelu) as the training step runs it:
-      dgv2_bmm_nn          t = W_a . h at 32x256 (the xa columns, commuted past the up-sampling: a quarter of the pixels)
-      dgv2_modconv_up_fwd  y = act(c * (up2(t) + W_s . PE) + bias)   <- the kernel reported (csrc/modconv_up.hip)
-    `achieved` = the kernel's own algorithmic FLOPs 2*B*P*Ks*O over its launch time; `layer_tflops` = the whole layer's
-    2*B*P*(Ka+Ks)*O (604 MMAC/img) over both launches + the statistic-only pass of training mode.
+      dgv2_modconv_up_t    T = W_a . h at 32x256 (the xa columns, commuted past the up-sampling: a quarter of the pixels)
+      dgv2_up2_lag_sumsq   the layer's input statistic sum up2(h)^2 as a quadratic form of h (training mode)
+      dgv2_modconv_up_fwd  y = act(c * (up2(T) + W_s . PE) + bias)   <- the kernel reported (csrc/modconv_up.hip)
+    `achieved` = the kernel's own algorithmic FLOPs 2*B*P*Ks*O over its launch time (the four up-sampling K-steps it
+    also runs are not counted); `layer_tflops` = the whole layer's 2*B*P*(Ka+Ks)*O (604 MMAC/img) over all
+    three launches.
     Compulsory HBM bytes of the kernel = y out + t in (the PE is batch-shared, the weights per-sample 37 KB)."""
     if args.dtype != "bf16":
         return None
@@ -200,13 +202,17 @@ def modconv_probe(args, reps=20):
     bias = torch.randn(O, device="cuda")
     cvec = torch.ones(O, device="cuda")
     y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
-    t = native._bmm_nn_raw(h.reshape(B, hl * wl, Ka), w[:, :, :Ka].contiguous(), bf)
+    t = torch.empty(B, hl * wl // 8, O, 8, device="cuda", dtype=bf)
+    wimg = torch.empty(B, Ks // 16, 2, O, 8, device="cuda", dtype=bf)
+
+    def lowres():
+        N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), 2.0 ** 0.5 * 0.6, B, hl * wl, Ka, Ks, O, Ka + Ks, Ka, N.BF16, N.stream())
+    lowres()
     ih, ch, iw, cw = native._up_tables(spec, hl, wl, h.device)
-    sec = _time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(xs), N.ptr(w), B, H, W, hl, wl, Ks,
-                                        O, Ka + Ks, Ka, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(cvec),
-                                        N.ptr(bias), 3, 0.2, 2.0 ** 0.5, N.BF16, None, 0, None, N.stream()), reps)
-    sec_lo = _time_launches(lambda: native._bmm_nn_raw(h.reshape(B, hl * wl, Ka), w[:, :, :Ka].contiguous(), bf), reps)
-    sec_sq = _time_launches(lambda: native.resample_sq_only(h, spec), reps)
+    sec = _time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(xs), N.ptr(wimg), B, H, W, hl, wl, Ks,
+                                        O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, 2.0 ** 0.5, N.BF16, None, 0, None, N.stream()), reps)
+    sec_lo = _time_launches(lowres, reps)
+    sec_sq = _time_launches(lambda: native.up2_lag_sumsq(h, spec), reps)
     # the same layer on the un-commuted kernel (dgv2_modconv_pe_fwd on a materialised up2(h): the full K = Ka + Ks
     # contraction in one launch; levels 3 and 2 run this kernel in the training step)
     hup = native._resample_raw(h, spec, False, (hl, wl))
@@ -217,14 +223,14 @@ def modconv_probe(args, reps=20):
     nbytes = (B * P * O + B * hl * wl * O + P * Ks + B * O * Ks) * 2
     ach = flops / sec / 1e12
     return {"kernel": "modconv_up_kernel (dgv2_modconv_up_fwd: G level-4 conv1, B x 32768 px, PE K=512, O=32, "
-                      "up2 of the low-res xa part in the epilogue)",
+                      "up2 of the low-res xa part as 4 more K-steps)",
             "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": _pmc_traffic("modconv_up_kernel"),
             "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6,
             "algorithmic_hbm_GBps": nbytes / sec / 1e9,
             "layer_tflops": 2.0 * B * P * (Ka + Ks) * O / (sec + sec_lo + sec_sq) / 1e12,
-            "layer_us": {"modconv_up": sec * 1e6, "lowres_gemm": sec_lo * 1e6, "statistic_pass": sec_sq * 1e6},
+            "layer_us": {"modconv_up": sec * 1e6, "lowres_t": sec_lo * 1e6, "statistic_lag_sumsq": sec_sq * 1e6},
             "uncommuted_modconv_pe_fwd": {"avg_launch_us": sec_pe * 1e6,
                                           "tflops": 2.0 * B * P * (Ka + Ks) * O / sec_pe / 1e12,
                                           "frac": 2.0 * B * P * (Ka + Ks) * O / sec_pe / 1e12 / MFMA_BF16_PEAK_TFLOPS}}

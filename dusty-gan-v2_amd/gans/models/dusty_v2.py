@@ -163,12 +163,15 @@ class SynthesisBlock(nn.Module):
         if (conv._prep is not None and hin is not None and isinstance(self.resample, ops.Resample) and link is None
                 and native.mod_up_ok(hin, pe0, conv._prep[1], self.resample.spec)):
             # the up-sampling commutes with the 1x1 contraction: the xa columns run at this block's INPUT resolution
-            # and up2(h) is never materialised (csrc/modconv_up.hip); its statistic comes from a read-only pass
+            # and up2(h) is never materialised (csrc/modconv_up.hip); its statistic sum up2(h)^2 is a quadratic form of
+            # h, evaluated at h's own resolution (dgv2_up2_lag_sumsq)
             handle, wb, cvec, wt = conv._prep
             cin = hin.shape[3]
             if conv.training:
                 pe_sq = float(self.pe.out_ch // 2) * B * H * W
-                sumsq = native.resample_sq_only(hin, self.resample.spec)
+                sumsq = native.up2_lag_sumsq(hin, self.resample.spec)
+                if sumsq is None:
+                    sumsq = native.resample_sq_only(hin, self.resample.spec)
             conv.update_ema(sumsq, B * H * W * (cin + self.pe.out_ch), pe_sq, cvec)
             act = self.bias_act1
             want = want_sq and (self.head.training if self.is_first else self.conv2.training)

@@ -77,7 +77,8 @@ def nsgan_loss(y, n_real):
 # ---------------------------------------------------------------------------------------
 # conv1 of a generator level with the block's up-sampling COMMUTED past the contraction (csrc/modconv_up.hip):
 #   y = act(c * (W_a . up2(h) + W_s . PE) + bias)  ==  act(c * (up2(W_a . h) + W_s . PE) + bias)
-# forward: t = W_a . h at the previous level's resolution (dgv2_bmm_nn), then dgv2_modconv_up_fwd;
+# forward: T = W_a . h at the previous level's resolution, channel-major (dgv2_modconv_up_t), then dgv2_modconv_up_fwd
+#          (up2 as four more K-steps of its MFMA chain);
 # backward: g_acc = act'(gy) * c;  g_t = up2^T(g_acc) (adjoint FIR on O instead of Ka channels);  g_h = W_a^T g_t and
 #           dW_a = g_t^T h at the LOW resolution;  dW_s = g_acc^T PE as before.
 # ---------------------------------------------------------------------------------------
@@ -100,15 +101,72 @@ def _up_tables(spec, hl, wl, device):
                 return idx.contiguous(), coef.contiguous()
             return (torch.cat([idx, torch.zeros_like(idx)], dim=1).contiguous(),
                     torch.cat([coef, torch.zeros_like(coef)], dim=1).contiguous())
-        _UP_TABLES[key] = two(ih, ch, Eh) + two(iw, cw, Ew)
+        ih, ch, iw, cw = two(ih, ch, Eh) + two(iw, cw, Ew)
+        # contract of dgv2_modconv_up_fwd on the tables (they live on the device: checked here, once per table set):
+        # both W taps of output column X inside the aligned window [(X & ~31) / 2 - 8, +32) mod Win
+        wo = iw.shape[0]
+        X = torch.arange(wo, device=iw.device)[:, None]
+        rel = (iw.long() - ((X // 32) * 16 - 8)) % wl
+        ok = wo % 32 == 0 and wl % 8 == 0 and wl >= 32 and bool(((rel < 32) | (cw == 0)).all())
+        _UP_TABLES[key] = (ih, ch, iw, cw) if ok else None
     return _UP_TABLES[key]
+
+
+_UP_GRAM = {}
+
+
+def _up_gram(spec, hl, wl, device):
+    """Diagonal / first off-diagonal of the Gram matrices Uh^T Uh, Uw^T Uw of an up-2 Resample's axis factors (fp32
+    device vectors ghd, gho [hl], gwd, gwo [wl]; the W axis is a ring: gwo[j] couples j and (j + 1) % wl), or None when
+    a Gram matrix is not tridiagonal (then the statistic needs the pass at the up-sampled size)."""
+    key = (id(spec), hl, wl, str(device))
+    if key not in _UP_GRAM:
+        (ih, ch, _, _), (iw, cw, _, _) = spec.tables(hl, wl, False, device)
+
+        def gram(idx, coef, n, ring):
+            U = torch.zeros(idx.shape[0], n, dtype=torch.float64)
+            U.scatter_add_(1, idx.long().cpu(), coef.double().cpu())
+            G = U.T @ U
+            d = torch.diagonal(G).clone()
+            o = torch.zeros(n, dtype=torch.float64)
+            o[:n - 1] = torch.diagonal(G, 1)
+            rest = G - torch.diag(d) - torch.diag(o[:n - 1], 1) - torch.diag(o[:n - 1], -1)
+            if ring and n > 2:
+                o[n - 1] = G[n - 1, 0]
+                rest[n - 1, 0] = rest[0, n - 1] = 0.0
+            return (d, o) if float(rest.abs().max()) == 0.0 else None
+        gh, gw = gram(ih, ch, hl, False), gram(iw, cw, wl, True)
+        _UP_GRAM[key] = None if gh is None or gw is None else tuple(
+            t.float().to(device).contiguous() for t in (gh[0], gh[1], gw[0], gw[1]))
+    return _UP_GRAM[key]
+
+
+def up2_lag_sumsq(x, spec):
+    """fp32 partial sums of squares of resample(x, spec) (an up-2 Resample) from x at its OWN resolution: the quadratic
+    form h^T (Gh (x) Gw) h evaluated with the 2 x 2 neighbourhood products of h (dgv2_up2_lag_sumsq).  None where it
+    does not apply (the caller then falls back to resample_sq_only)."""
+    if x.dtype != torch.bfloat16 or x.shape[3] % 8 or 256 % (x.shape[3] // 8):
+        return None
+    B, H, W, C = x.shape
+    gram = _up_gram(spec, H, W, x.device)
+    if gram is None:
+        return None
+    x = x.contiguous()
+    sq = _sq_args(x.device)
+    N.check(x)
+    if not N.try_call("dgv2_up2_lag_sumsq", N.ptr(x), N.ptr(gram[0]), N.ptr(gram[1]), N.ptr(gram[2]), N.ptr(gram[3]), B,
+                      H, W, C, _dt(x), N.ptr(sq[0]), _SQ_CAP, _ct.addressof(sq[1]), N.stream()):
+        return None
+    return sq[0][:sq[1].value]
 
 
 def mod_up_ok(h, xs, wb, spec):
     return bool(_UP_COMMUTE and h is not None and xs is not None and h.is_cuda and h.dtype == torch.bfloat16
                 and wb.shape[1] == 32 and xs.shape[3] == 512 and h.shape[3] % 8 == 0
                 and tuple(a[1] for a in spec.axes) == (2, 2) and tuple(a[2] for a in spec.axes) == (1, 1)
-                and spec.out_size(h.shape[1], h.shape[2]) == tuple(xs.shape[1:3]))
+                and h.shape[3] in (64, 128) and (h.shape[1] * h.shape[2]) % 32 == 0
+                and spec.out_size(h.shape[1], h.shape[2]) == tuple(xs.shape[1:3])
+                and _up_tables(spec, h.shape[1], h.shape[2], h.device) is not None)
 
 
 def resample_sq_only(x, spec):
@@ -142,14 +200,19 @@ class _ModUpPrepared(Function):
         dev = h.device
         act = 3 if cfg["act"] else 0
         bias32 = None if bias is None else bias.detach().float().contiguous()
-        wa = wb[:, :, :Ka].contiguous()
-        t = _bmm_nn_raw(h.reshape(B, hl * wl, Ka), wa, dt)                       # [B, hl*wl, O]
+        t = torch.empty((B, hl * wl // 8, Otot, 8), device=dev, dtype=dt)        # W_a . h in 8-pixel units
+        wimg = torch.empty((B, Ks // 16, 2, Otot, 8), device=dev, dtype=dt)     # W_s as the MFMA operand image
+        N.check(h, wb, cvec)
+        # T and the image carry c[o] * gain, the kernel puts gain on the bias and runs the leaky ReLU as f' + k |f'|
+        gain = cfg["scale"] * 0.5 * (1.0 + cfg["alpha"]) if cfg["act"] else 1.0
+        N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(wb), N.ptr(cvec), gain, B, hl * wl, Ka, Ks,
+               Otot, I, Ka, _dt(h), N.stream())
         ih, ch, iw, cw = _up_tables(spec, hl, wl, dev)
         sq = _sq_args(dev) if (cfg["want_sq"] and _FUSED_SQ) else None
         out = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
-        N.check(t, xs, wb, bias32, cvec)
-        N.call("dgv2_modconv_up_fwd", N.ptr(out), N.ptr(t), N.ptr(xs), N.ptr(wb), B, H, W_, hl, wl, Ks, Otot, I, Ka,
-               N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(cvec), N.ptr(bias32), act, cfg["alpha"], cfg["scale"],
+        N.check(t, xs, wimg, bias32, cvec)
+        N.call("dgv2_modconv_up_fwd", N.ptr(out), N.ptr(t), N.ptr(xs), N.ptr(wimg), B, H, W_, hl, wl, Ks, Otot,
+               N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias32), act, cfg["alpha"], cfg["scale"],
                _dt(h), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None,
                N.stream())
         ctx.cfg = dict(cfg, has_bias=bias is not None)

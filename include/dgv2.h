@@ -209,18 +209,45 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
                     int O, const float* bias, int act, float alpha, float scale, int dtype, int ydtype,
                     void* stream);
 /* The same level-input conv with the block's up-sampling COMMUTED past the contraction (a 1x1 conv acts per pixel, the
- * FIR per channel): W_a . up2(h) == up2(W_a . h), so the xa columns run at a quarter of the pixels (t = W_a . h, a
- * dgv2_bmm_nn at the previous level's resolution) and this entry evaluates
- *   y[b,p,:O] = act( row_scale * ( up2(t)[b,p,:] + sum_{k<Ks} xs[p,k] w[b,:,koff+k] ) + bias )      (bf16)
- * t [B,Hin,Win,O]; up2 given as two-tap tables idx/coef [Hout][2], [Wout][2] (low-resolution index, weight: the sparse
- * rows of Resample(up=2), gans/models/ops/common.py:105-135, with its ring / replicate extension); xs [Hout*Wout,Ks];
- * w [B,O,I] (PE columns start at koff).  O = 32, Ks = 512 (generator level 4); DGV2_ENOTSUP otherwise.
+ * FIR per channel): W_a . up2(h) == up2(W_a . h), so the xa columns run at a quarter of the pixels (T = W_a . h at the
+ * previous level's resolution, dgv2_modconv_up_t below) and this entry evaluates
+ *   y[b,p,:O] = act( row_scale * ( up2(W_a h)[b,p,:] + sum_{k<Ks} xs[p,k] w[b,:,koff+k] ) + bias )      (bf16)
+ * with row_scale and gain = scale (1 + alpha) / 2 (act 3; 1 for act 0: the leaky ReLU is then the single fma
+ * f' + |f'| (1 - alpha) / (1 + alpha)) already inside T and the weight image, the bias as one more K-step (exact to
+ * 2^-17: hi + lo bf16 halves against a row of ones), and up2 as four more K-steps of the same MFMA chain (A = the wave's window of T, B = the constant interpolation
+ * matrix of its 32 pixels, built in registers from the tables).
+ * t [B,Hin*Win/8,O,8]: row_scale * gain * T in 8-pixel units (unit u, channel o: pixels 8u..8u+7) and
+ * wimg [B,Ks/16,2,O,8]: row_scale * gain * the PE columns of the prepared per-sample weights as the MFMA operand image
+ * -- both written by dgv2_modconv_up_t (the caller passes it that gain), so that
+ * every LDS-DMA piece of the sample walk is one contiguous 1 KB; up2 given as two-tap tables idx/coef [Hout][2],
+ * [Wout][2] (low-resolution index, weight: the sparse rows of Resample(up=2), gans/models/ops/common.py:105-135, with
+ * its ring / replicate extension); xs [Hout*Wout,Ks].  O = 32, Ks = 512 (generator level 4), Wout % 32 == 0,
+ * Win % 8 == 0, Win >= 32; DGV2_ENOTSUP otherwise.  Contract on the (device-resident) tables, checked by the caller
+ * once per table set: both W taps of output column X lie in the window [(X & ~31) / 2 - 8, +32) mod Win.
+ * sumsq: per-block partial sums of squares of the stored y.
  * replaces: Resample(up=2) + torch.cat([h, pe]) + ModConv2d contraction + FusedLeakyReLU,
  *   gans/models/dusty_v2.py:153-162, gans/models/ops/style.py:105-118. */
-int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const void* w, int B, int Hout, int Wout, int Hin,
-                        int Win, int Ks, int O, int I, int koff, const int* idx_h, const float* coef_h,
-                        const int* idx_w, const float* coef_w, const float* row_scale, const float* bias, int act,
-                        float alpha, float scale, int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
+int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const void* wimg, int B, int Hout, int Wout, int Hin,
+                        int Win, int Ks, int O, const int* idx_h, const float* coef_h, const int* idx_w,
+                        const float* coef_w, const float* bias, int act, float alpha, float scale, int dtype,
+                        float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
+/* The low-resolution xa part of the commuted level-input conv and the operand images of dgv2_modconv_up_fwd:
+ *   tcm [B,Plow/8,O,8]: T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units, f[o] = row_scale[o] * gain
+ *   (row_scale fp32 [O] or NULL = 1: the input-magnitude factor of ModConv2d, style.py:98-103);
+ *   wimg [B,Ks/16,2,O,8] (or NULL): f[o] w[b][o][koff + 16 kc + 8 half + j] at [b][kc][half][o][j].
+ * h [B,Plow,Ka], w [B,O,I] (bf16); O = 32, Ka in {64, 128}, Plow % 32 == 0, Ks % 16 == 0.
+ * replaces: the xa columns of the ModConv2d contraction, gans/models/ops/style.py:105-118. */
+int dgv2_modconv_up_t(void* tcm, void* wimg, const void* h, const void* w, const float* row_scale, float gain, int B,
+                      int Plow, int Ka, int Ks, int O, int I, int koff, int dtype, void* stream);
+/* Per-block partial sums of sum_{b,p,c} up2(h)[b,p,c]^2 taken from h at its own (low) resolution: with U = Uh (x) Uw
+ * the up-2 operator, sum (U h)^2 = h^T (Gh (x) Gw) h with tridiagonal Gram matrices Gh = Uh^T Uh, Gw = Uw^T Uw (ring axis:
+ * circulant).  ghd / gho [Hin]: diagonal and (i, i+1) entries of Gh (gho[Hin-1] = 0); gwd / gwo [Win]: diagonal and
+ * (j, j+1 mod Win) entries of Gw.  h [B,Hin,Win,C] bf16, C % 8 == 0, 256 % (C/8) == 0.  sumsq / cap / used as in
+ * dgv2_resample_tab_sq (DGV2_ENOTSUP when cap is too small).
+ * replaces: the statistic mean(x^2) of ModConv2d's ema_var update on the up-sampled input, gans/models/ops/style.py:98-103
+ *   (x = Resample(up=2)(h), gans/models/dusty_v2.py:153-155), without a pass at the up-sampled size. */
+int dgv2_up2_lag_sumsq(const void* h, const float* ghd, const float* gho, const float* gwd, const float* gwo, int B,
+                       int Hin, int Win, int C, int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 /* dgv2_bmm_nn / dgv2_bmm_nn_cat that also leave per-block partial sums of squares of the stored outputs
  * (contract as in dgv2_resample_tab_sq), with an optional per-output-channel factor ahead of the bias:
  * y = act(acc * row_scale[o] + bias[o]) (row_scale fp32 [O] or NULL) -- the input-magnitude factor of

@@ -23,18 +23,26 @@ y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
 t_rs = bench._time_launches(lambda: native._resample_raw(h, spec, False, (hl, wl), sq=native._sq_args(h.device)), 20)
 t_pe = bench._time_launches(lambda: N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(hup), N.ptr(pe), N.ptr(wb), B, H * W, Ka, Ks, O, N.ptr(cvec), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
 y0 = y.clone()
-wa = wb[:, :, :Ka].contiguous()
-t = native._bmm_nn_raw(h.reshape(B, hl * wl, Ka), wa, bf)
+t = torch.empty(B, hl * wl // 8, O, 8, device="cuda", dtype=bf)
+wimg = torch.empty(B, Ks // 16, 2, O, 8, device="cuda", dtype=bf)
+
+
+def lowres():
+    N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(wb), N.ptr(cvec), 2.0 ** 0.5 * 0.6, B, hl * wl, Ka, Ks, O, Ka + Ks, Ka, N.BF16, N.stream())
+
+
+lowres()
 ih, ch, iw, cw = native._up_tables(spec, hl, wl, h.device)
-t_sq = bench._time_launches(lambda: native.resample_sq_only(h, spec), 20)
-t_lo = bench._time_launches(lambda: native._bmm_nn_raw(h.reshape(B, hl * wl, Ka), wb[:, :, :Ka].contiguous(), bf), 20)
-t_up = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pe), N.ptr(wb), B, H, W, hl, wl, Ks, O, Ka + Ks, Ka, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(cvec), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
-y1 = y.clone()
-wimg = wb[:, :, Ka:].reshape(B, O, Ks // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
-t_img = bench._time_launches(lambda: wb[:, :, Ka:].reshape(B, O, Ks // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous(), 20)
-t_up2 = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pe), N.ptr(wimg), B, H, W, hl, wl, Ks, O, 0, 0, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(cvec), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
-print(f"modconv_up on the weight image: {t_up2*1e6:6.1f} us (+ repack {t_img*1e6:5.1f} us), same result: {bool(torch.equal(y, y1))}")
+t_sq_old = bench._time_launches(lambda: native.resample_sq_only(h, spec), 20)
+t_sq = bench._time_launches(lambda: native.up2_lag_sumsq(h, spec), 20)
+t_lo = bench._time_launches(lowres, 20)
+t_up = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pe), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
+sq = native._sq_args(h.device)
+import ctypes
+t_up_sq = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pe), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, N.ptr(sq[0]), native._SQ_CAP, ctypes.addressof(sq[1]), N.stream()), 20)
 fl = 2.0 * B * H * W * (Ka + Ks) * O
+a, b_ = native.resample_sq_only(h, spec).sum().item(), native.up2_lag_sumsq(h, spec).sum().item()
+print(f"statistic: pass at the up-sampled size {t_sq_old*1e6:6.1f} us -> quadratic form at low resolution {t_sq*1e6:6.1f} us (rel diff {abs(a-b_)/a:.2e})")
 print(f"cat path : resample_sq {t_rs*1e6:6.1f} + modconv_pe {t_pe*1e6:6.1f} = {(t_rs+t_pe)*1e6:6.1f} us  (kernel {fl/t_pe/1e12:5.0f} TF/s, layer {fl/(t_rs+t_pe)/1e12:5.0f} TF/s)")
-print(f"commuted : stat-only {t_sq*1e6:6.1f} + low-res gemm {t_lo*1e6:6.1f} + modconv_up {t_up*1e6:6.1f} = {(t_sq+t_lo+t_up)*1e6:6.1f} us  (kernel {2.0*B*H*W*Ks*O/t_up/1e12:5.0f} TF/s own FLOPs, layer {fl/(t_sq+t_lo+t_up)/1e12:5.0f} TF/s)")
+print(f"commuted : statistic {t_sq*1e6:6.1f} + low-res T {t_lo*1e6:6.1f} + modconv_up {t_up*1e6:6.1f} (with sumsq partials {t_up_sq*1e6:6.1f}) = {(t_sq+t_lo+t_up)*1e6:6.1f} us  (kernel {2.0*B*H*W*Ks*O/t_up/1e12:5.0f} TF/s own FLOPs, layer {fl/(t_sq+t_lo+t_up)/1e12:5.0f} TF/s)")
 print("max |diff| vs cat path:", float((y.float() - y0.float()).abs().max()), "of", float(y0.float().abs().max()))

@@ -51,7 +51,8 @@ def test_two_ranks_identical_and_equal_to_one_process(tmp_path, graph):
     assert torch.equal(r0["p"], r1["p"])
     assert all(torch.equal(a, b) for a, b in zip(r0["optD_v"], r1["optD_v"]))
     if graph:
-        assert {"g_fb", "g_opt", "d_fb", "d_opt", "r1_fb"} <= set(r0["graphs"]), r0["graphs"]
+        # the children inject their draws: those bodies are the "/inj" captures
+        assert {"g_fb/inj", "g_opt", "d_fb/inj", "d_opt", "r1_fb/inj"} <= set(r0["graphs"]), r0["graphs"]
     # ranks see different samples: their local losses differ, the logged (all-reduced) scalars do not
     assert r0["scalars"] == r1["scalars"]
     (one,) = _run(tmp_path, 1, iters, graph, {"DGV2_TEST_WORLD_TOTAL": "2"})

@@ -996,6 +996,9 @@ def test_modconv_up_commuted_upsampling_matches_cat_path(nat):
                 assert_rel(sq_y.sum().cpu(), y.detach().float().square().sum().cpu(), 2e-3, "sum of squares of y")
                 sq_only = nat.resample_sq_only(hh.detach(), spec)
                 assert_rel(sq_only.sum().cpu(), sq_ref.sum().cpu(), 1e-5, "statistic of up2(h) without materialising it")
+                sq_lag = nat.up2_lag_sumsq(hh.detach(), spec)     # the quadratic form at h's own resolution
+                assert sq_lag is not None
+                assert_rel(sq_lag.sum().cpu(), sq_ref.sum().cpu(), 1e-5, "statistic of up2(h) as a quadratic form of h")
             if act:
                 res[mode] = [y.detach().float().cpu(), None, wb.detach()]
             else:
@@ -1013,6 +1016,76 @@ def test_modconv_up_commuted_upsampling_matches_cat_path(nat):
     assert_rel(res["up"][0], res["cat"][0], 1.5e-2, "y")
     for a, b, name in zip(res["up"][1], res["cat"][1], ("gh", "gW", "gs", "gb")):
         assert_rel(a, b, 1.5e-2, name)
+
+
+@pytest.mark.parametrize("B,hl,wl,Ka", [(2, 32, 256, 64), (3, 8, 32, 64), (1, 4, 64, 128), (2, 16, 96, 64)])
+def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
+    """The three launches of the commuted level-input conv through the C ABI, each against a float64 statement:
+    dgv2_modconv_up_t (T = W_a . h, channel-major), dgv2_up2_lag_sumsq (sum up2(h)^2 from h's 2 x 2 neighbourhood
+    products) and dgv2_modconv_up_fwd (up2 of T as four K-steps of the MFMA chain) -- the latter also BIT-EXACT on
+    small-integer data, which pins the fragment maps of the window / interpolation-matrix operands at every column
+    phase, the ring seam and the replicate rows (reference: Resample common.py:105-135, ModConv2d style.py:105-118)."""
+    import ctypes
+    import dgv2_native as N
+    from gans.models.ops.common import Resample
+    g = torch.Generator().manual_seed(5 + hl)
+    spec = Resample(up=2, window=[1, 3, 3, 1], ring=True).spec
+    Ks, O = 512, 32
+    H, W = 2 * hl, 2 * wl
+    bf = torch.bfloat16
+    tabs = nat._up_tables(spec, hl, wl, torch.device(DEV))
+    assert tabs is not None
+    ih, ch, iw, cw = tabs
+    for exact in (True, False):
+        if exact:   # integers small enough that every product and partial sum is exact in bf16 / fp32
+            h = torch.randint(-2, 3, (B, hl, wl, Ka), generator=g).float()
+            w = torch.randint(-1, 2, (B, O, Ka + Ks), generator=g).float()
+            pe = torch.randint(-1, 2, (1, H, W, Ks), generator=g).float()
+            pe = pe * (torch.rand(1, H, W, Ks, generator=g) < 0.05)     # sparse: sums stay below 2^8
+            w[:, :, :Ka] *= (torch.rand(B, O, Ka, generator=g) < 0.1)
+        else:
+            h = torch.randn(B, hl, wl, Ka, generator=g)
+            w = torch.randn(B, O, Ka + Ks, generator=g) / 16
+            pe = torch.randn(1, H, W, Ks, generator=g)
+        h, w, pe = h.to(DEV, bf), w.to(DEV, bf), pe.to(DEV, bf)
+        bias = torch.randn(O, generator=g).to(DEV) if not exact else torch.zeros(O, device=DEV)
+        cvec = (torch.rand(O, generator=g) + 0.5).to(DEV) if not exact else torch.ones(O, device=DEV)
+        t8 = torch.empty(B, hl * wl // 8, O, 8, device=DEV, dtype=bf)
+        wimg = torch.empty(B, Ks // 16, 2, O, 8, device=DEV, dtype=bf)
+        act, scale = (0, 1.0) if exact else (3, math.sqrt(2.0))
+        gain = scale * 0.5 * (1 + 0.2) if act else 1.0             # the contract of dgv2_modconv_up_fwd
+        N.call("dgv2_modconv_up_t", N.ptr(t8), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), gain, B, hl * wl, Ka, Ks, O,
+               Ka + Ks, Ka, N.BF16, N.stream())
+        t = t8.permute(0, 2, 1, 3).reshape(B, O, hl * wl)           # units of 8 pixels -> [B, O, pixels]
+        f = (cvec * gain)[None, :, None]                            # the layer's c[o] * gain rides in T and the image
+        assert torch.equal(wimg.permute(0, 3, 1, 2, 4).reshape(B, O, Ks), (w[:, :, Ka:].float() * f).to(bf))
+        want_t = torch.einsum("bpc,boc->bop", h.double().reshape(B, hl * wl, Ka), w.double()[:, :, :Ka]) * f.double()
+        if exact:
+            assert torch.equal(t.double(), want_t)
+        else:
+            assert_rel(t.float().cpu(), want_t.cpu(), 6e-3, "T")
+        y = torch.empty(B, H, W, O, device=DEV, dtype=bf)
+        sq = nat._sq_args(torch.device(DEV))
+        N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t8), N.ptr(pe), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih),
+               N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), act, 0.2, scale, N.BF16, N.ptr(sq[0]),
+               nat._SQ_CAP, ctypes.addressof(sq[1]), N.stream())
+        # float64: up2 of the bf16 T the kernel read, plus the PE contraction with the image the kernel read
+        tup = o.resample(t.double().cpu().reshape(B, O, hl, wl), (1, 3, 3, 1), up=2, ring=True).permute(0, 2, 3, 1)
+        ws = wimg.permute(0, 3, 1, 2, 4).reshape(B, O, Ks).double().cpu()
+        pre = (tup + torch.einsum("hwk,bok->bhwo", pe.double().cpu()[0], ws) + bias.double().cpu() * gain) / gain * scale
+        want = pre if exact else torch.where(pre > 0, pre, pre * 0.2)
+        if exact:
+            # up2 coefficients are k/16: 16 * y is an integer; everything is exactly representable
+            assert float(want.abs().max()) < 256
+            assert torch.equal(y.double().cpu(), want.to(bf).double())
+        else:
+            assert_rel(y.float().cpu(), want, 6e-3, "y")
+        assert sq[1].value > 0
+        assert_rel(sq[0][:sq[1].value].sum().cpu(), y.float().square().sum().cpu(), 2e-3, "sum of squares of y")
+        # the statistic of up2(h) from h's own resolution
+        lag = nat.up2_lag_sumsq(h, spec)
+        hup = o.resample(h.double().cpu().permute(0, 3, 1, 2), (1, 3, 3, 1), up=2, ring=True)
+        assert_rel(lag.double().sum().cpu(), hup.square().sum(), 1e-5, "sum up2(h)^2")
 
 
 def test_fused_nsgan_loss_matches_ganloss(nat):
