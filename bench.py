@@ -37,7 +37,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=64)
-    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "fp32", "fp8"], default="bf16",
+                    help="bf16: bf16 trunks (the BASELINE metric); fp32: parity mode; fp8: bf16 trunks with the branch "
+                         "operands of the discriminator's ResidualBlocks as OCP e4m3 on v_mfma_f32_16x16x32_fp8_fp8 "
+                         "(BASELINE configs[4], quoted at --res 128x1024 --batch-per-gpu 32; DESIGN.md)")
     ap.add_argument("--ada-p", type=float, default=0.6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
@@ -59,7 +62,7 @@ def parse():
 def make_cfg(args, rank, world):
     from gans.config import load_config
     cfg = load_config()
-    n16 = -1 if args.dtype == "bf16" else 0
+    n16 = -1 if args.dtype in ("bf16", "fp8") else 0
     cfg.model.generator.synthesis_kwargs.num_fp16_layers = n16
     cfg.model.discriminator.layer_kwargs.num_fp16_layers = n16
     cfg.dataset.name = "synthetic"
@@ -135,7 +138,7 @@ def _time_launches(fn, reps):
     return s.elapsed_time(e) * 1e-3 / reps
 
 
-PMC_FILE = os.path.join("profiles", "round2_pmc.json")
+PMC_FILE = os.path.join("profiles", "round3_pmc.json")
 
 
 def _pmc_traffic(kernel_key):
@@ -150,9 +153,36 @@ def _pmc_traffic(kernel_key):
     return None if rec is None else rec.get("traffic_bytes_per_launch")
 
 
+def dominant_probe(args, reps=20):
+    """`roofline`: the kernel INSTANCE with the largest share of GPU time in the committed graph kernel statistics
+    (profiles/round*_bench_graph_kernel_stats.csv): conv_pipe_kernel<bf16, TO = 32, four output classes> = the
+    stride-2 3x3 data gradient of the first ResidualBlock's conv2 in the D step (reference: the cuDNN dgrad of
+    ops.Conv2d(32, 64, 3, 2, 1, ring), gans/models/dusty_v2.py:331-333): gy [2B, 32, 256, 64] -> gx [2B, 64, 512, 32],
+    the four parity classes of the transposed conv and the replicate-row border terms in ONE launch
+    (dgv2_conv_taps_ex).  HBM-bound (22 FLOP per byte): algorithmic bytes = gy read once + gx written once."""
+    from gans.models.ops import native
+    if args.dtype == "fp32":
+        return None
+    dt = torch.bfloat16
+    B, H, W, C, O = 2 * args.batch_per_gpu, 64, 512, 32, 64
+    g = native.ConvGeom(3, 3, 2, 1, True)
+    gy = torch.randn(B, H // 2, W // 2, O, device="cuda", dtype=dt)
+    wt3 = (torch.randn(C, 9, O, device="cuda") / 24).to(dt)
+    sec = _time_launches(lambda: native._conv_dgrad_direct(gy, wt3, g, (B, H, W, C)), reps)
+    nbytes = (B * (H // 2) * (W // 2) * O + B * H * W * C + C * 9 * O) * 2
+    flops = 2.0 * B * (H // 2) * (W // 2) * 9 * C * O
+    ach = nbytes / sec / 1e9
+    return {"kernel": "conv_pipe_kernel<bf16, TO=32, 4 classes> (dgv2_conv_taps_ex: D block-0 conv2 data gradient, "
+                      "2B x 32x256x64 -> 64x512x32, 3x3 stride 2 ring, one launch)",
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+            "traffic": _pmc_traffic("conv_pipe_kernel_s2dgrad"), "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
+            "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12,
+            "selected_by": "largest Percentage among kernel instances in profiles/round3_bench_graph_kernel_stats.csv"}
+
+
 def roofline_probe(args, reps=20):
-    """Roofline of the conv engine (largest share of GPU time in profiles/round*_kernel_stats.csv) at its most
-    expensive call site -- the first ResidualBlock's conv1 in the D step (real + fake = 2 x batch images, 64 x 512,
+    """`roofline_strip` (round 2's headline probe, kept for continuity): the conv engine at its heaviest HBM-bound
+    forward site -- the first ResidualBlock's conv1 in the D step (real + fake = 2 x batch images, 64 x 512,
     32 -> 32 channels, 3x3, ring padding, bias + lrelu fused): dgv2_conv_taps, which runs conv3x3_strip_kernel
     (csrc/conv_strip.hip) for this geometry (conv_pipe_kernel with DGV2_NO_STRIP=1).
     HBM-bound: algorithmic bytes per image = H*W*(C + O)*2 B = 4.19 MB, per launch
@@ -186,7 +216,7 @@ def modconv_probe(args, reps=20):
     also runs are not counted); `layer_tflops` = the whole layer's 2*B*P*(Ka+Ks)*O (604 MMAC/img) over all
     three launches.
     Compulsory HBM bytes of the kernel = y out + t in (the PE is batch-shared, the weights per-sample 37 KB)."""
-    if args.dtype != "bf16":
+    if args.dtype == "fp32":
         return None
     import dgv2_native as N
     from gans.models.ops import native
@@ -241,6 +271,7 @@ def build_trainer(args, rank, world, d_epilogue=None):
     cfg = make_cfg(args, rank, world)
     trainer = Trainer(cfg, sync_scalars=False)
     trainer.D.epilogue_dtype = d_epilogue or args.d_epilogue
+    trainer.D.fp8_branches = args.dtype == "fp8"
     return cfg, trainer
 
 
@@ -375,9 +406,15 @@ def main():
         extra["value_ada_p0"] = 8 * args.batch_per_gpu * world / max_over_ranks(timed_steps(trainer, 1, 8, barrier))[0]
         trainer.A.p.copy_(p_keep)
 
-    roof = roofline_probe(args) if rank == 0 else None
+    # no step body may have fallen back to eager (Trainer._run warns and continues): a bench line must say so
+    graphs_live = trainer.graphs_live()
+    extra["graphs_live"] = graphs_live
+    if cfg.training.hip_graph:
+        assert graphs_live and all(graphs_live.values()), f"a step body is not replaying as a hipGraph: {graphs_live}"
+    roof = dominant_probe(args) if rank == 0 else None
+    roof_strip = roofline_probe(args) if rank == 0 else None
     roof_mod = modconv_probe(args) if rank == 0 else None
-    if not args.no_extra and world == 1 and args.dtype == "bf16":
+    if not args.no_extra and world == 1 and args.dtype == "bf16" and args.res == "64x512":
         # the same step with the discriminator epilogue in bf16 (opt-in; NOT what `value` is quoted on)
         other = "bf16" if args.d_epilogue == "fp32" else "fp32"
         del trainer
@@ -392,9 +429,11 @@ def main():
             "metric": f"range-images/sec (G+D step) on dusty_v2 {args.res}",
             "value": value, "unit": "range-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype if args.dtype != "fp8" else "fp8 (e4m3 branch operands of D's ResidualBlocks) + bf16",
+            "data": "synthetic",
             "config": {"workload": ("configs[2]" if args.res == "64x512" else
-                                    "configs[4] shape in bf16 (fp8 activations are not built)")
+                                    ("configs[4] (fp8: e4m3 operands of the discriminator's decimating branch convs)"
+                                     if args.dtype == "fp8" else "configs[4] shape in bf16"))
                                    + ": configs/gans/dusty_v2.yaml full G+D train step "
                                    f"(G step + D step + lazy R1 + ADA + EMA + Adam), {args.res} synthetic",
                        "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
@@ -408,6 +447,7 @@ def main():
             "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3 if args.res == "64x512" else None,
             "extra": extra,
             "roofline": roof,
+            "roofline_strip": roof_strip,
             "roofline_modconv": roof_mod,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -65,6 +65,27 @@ __device__ __forceinline__ int pack_pair_bf16(const float (&va)[4], const float 
   return odd ? 16 + 4 * (lc - 1) : 4 * lc;
 }
 
+// ---- fp8 (OCP e4m3fn, the gfx950 encoding; max finite 448) ----
+struct fp8_t { uint8_t v; };   // storage tag: 16 elements per 16-byte operand chunk
+#define DGV2_FP8_MAX 448.0f
+// 8 floats -> 8 e4m3 bytes (round to nearest even, saturating at +-448)
+__device__ __forceinline__ uint2 pack_fp8x8(const float (&f)[8]) {
+  float c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c[i] = fminf(fmaxf(f[i], -DGV2_FP8_MAX), DGV2_FP8_MAX);
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  return make_uint2((unsigned)lo, (unsigned)hi);
+}
+// 4 e4m3 bytes of a dword -> 4 floats (exact)
+__device__ __forceinline__ void unpack_fp8x4(unsigned w, float (&f)[4]) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  const f32x2_ a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+  f[0] = a[0]; f[1] = a[1]; f[2] = b[0]; f[3] = b[1];
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Floor division / modulo for possibly negative numerators (b > 0).

@@ -56,6 +56,14 @@ template <> struct MfmaAsm<bf16_t> {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ua.v), "v"(ub.v));
   }
 };
+template <> struct MfmaAsm<fp8_t> {   // see Mfma16<fp8_t>
+  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a0), "v"(b0));
+    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a1), "v"(b1));
+  }
+};
 template <> struct MfmaAsm<float> {
   __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.x), "v"(b.x));
@@ -96,6 +104,8 @@ struct DConv {
   int nx, x_dy[6], x_dx[6], x_slot[6], x_cls[6], x_row[6];
   float inv_cols;   // 1 / cols
   const float* bias;
+  const float* acc_scale;   // device scalar multiplied onto the accumulators ahead of the residual / bias (e4m3 weights:
+                            // EqualLR factor / the tensor's power-of-two scale, fp8.hip), or nullptr
   void* ybase;         // = y (lets the epilogue address resid at the same offset)
   const void* resid;   // optional residual, same layout as y: added before bias / activation
   int act;
@@ -107,12 +117,12 @@ struct DConv {
 // prefetch in flight with vmcnt(0) before each tile's stores), or nullptr
 template <typename T>
 __device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, int o, f32x4 v,
-                                           const float* bias4 = nullptr) {
+                                           const float* bias4 = nullptr, float ws = 1.f) {
   const T* rrow = p.resid ? reinterpret_cast<const T*>(p.resid) + (row - reinterpret_cast<T*>(p.ybase)) : nullptr;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (o + r >= p.O) continue;
-    float f = v[r];
+    float f = v[r] * ws;
     if (p.accumulate) f += to_f32(row[o + r]);
     if (rrow) f += to_f32(rrow[o + r]);
     if (bias4) f += bias4[r];
@@ -145,10 +155,12 @@ __device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, 
 // 2 = rows outside the image are zero (data gradients): those rows are staged as whatever the clamped address holds,
 // because every tap that would read them is a dead tap of that output row and is skipped (the host checks that the
 // border extras read real rows).
-template <typename T, int TO, int RW, int NI, int NC, int F33>
-__global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void conv_pipe_kernel(T* __restrict__ y, const T* __restrict__ x,
+// TY: type of y / resid (= T, or bf16 for e4m3 operands T = fp8_t)
+template <typename T, typename TY, int TO, int RW, int NI, int NC, int F33>
+__global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void conv_pipe_kernel(TY* __restrict__ y, const T* __restrict__ x,
                                                            const T* __restrict__ w, DConv p) {
   constexpr int CE = 16 / sizeof(T);
+  const float ws = p.acc_scale ? *p.acc_scale : 1.f;   // uniform address: a scalar load, long before the first epilogue
   constexpr int MF = TO / 16, NF = 2 * RW, TH = 4 * RW;
   constexpr int NW = (TO * 9 * 4 + 255) / 256;
   constexpr int PIN = NI * 64, PW = NW * 64;   // rows per plane: exactly what the staging slots cover
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
       // fast path (block-uniform): full channel tile, plain overwrite -- straight-line bias / lrelu / convert and,
       // for bf16, fragment pairs leaving as 16-byte stores; everything else takes the general store_frag
       const bool fast = !p.accumulate && o0 + TO <= p.O && (p.O & 7) == 0;
-      const T* rbase = reinterpret_cast<const T*>(p.resid);   // optional residual, same layout as y
+      const TY* rbase = reinterpret_cast<const TY*>(p.resid);   // optional residual, same layout as y
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
           const int gw = w0 + (nf & 1) * 16 + lr;
           const bool live = gh < p.Hg && gw < p.Wg;
           const int yh = gh * p.out_stride + p.cls_ooh[c], yw = gw * p.out_stride + p.cls_oow[c];
-          T* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.ldy;
+          TY* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.ldy;
           if (fast) {
             float f[MF][4];
 #pragma unroll
@@ -452,20 +464,20 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
               const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                float t = acc[c][mf][nf][r] + bq[r];
+                float t = fmaf(acc[c][mf][nf][r], ws, bq[r]);
                 if (p.act == 3) t = fmaxf(t, t * p.alpha) * p.scale;   // leaky ReLU, 0 <= alpha <= 1
                 f[mf][r] = t;
               }
             }
-            if constexpr (sizeof(T) == 2 && MF >= 2) {
+            if constexpr (sizeof(TY) == 2 && MF >= 2) {
 #pragma unroll
               for (int mf = 0; mf < MF; mf += 2) {
                 uint4 pk;
                 const int co = pack_pair_bf16(f[mf], f[mf + 1], lc, pk);   // every lane takes part in the exchange
                 if (live) {
-                  T* q = row + o0 + mf * 16 + co;
+                  TY* q = row + o0 + mf * 16 + co;
                   if (rbase) {   // residual added on the packed 8-channel run (one 16-byte read)
-                    vec16<T> a, r;
+                    vec16<TY> a, r;
                     a.raw = pk;
                     r.load(rbase + (q - y));
 #pragma unroll
@@ -485,12 +497,12 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 #pragma unroll
               for (int mf = 0; mf < MF; ++mf) {
                 if (!live) continue;
-                T* q = row + o0 + mf * 16 + lc * 4;
+                TY* q = row + o0 + mf * 16 + lc * 4;
                 if (rbase) {
 #pragma unroll
                   for (int r = 0; r < 4; ++r) f[mf][r] += to_f32(rbase[(q - y) + r]);
                 }
-                if constexpr (sizeof(T) == 4) {
+                if constexpr (sizeof(TY) == 4) {
                   *reinterpret_cast<float4*>(q) = make_float4(f[mf][0], f[mf][1], f[mf][2], f[mf][3]);
                 } else {
                   union { uint2 u; bf16_t e[4]; } pk;
@@ -504,7 +516,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
               const int o = o0 + mf * 16 + lc * 4;
-              if (o < p.O) store_frag<T>(p, row, o, acc[c][mf][nf], &s_bias[mf * 16 + lc * 4]);
+              if (o < p.O) store_frag<TY>(p, row, o, acc[c][mf][nf], &s_bias[mf * 16 + lc * 4], ws);
             }
           }
 #pragma unroll
@@ -629,7 +641,7 @@ int launch_direct(void* y, const void* x, const void* w, DConv p, hipStream_t st
 }
 
 // returns -2 when the geometry does not fit this instantiation's register / LDS budget
-template <typename T, int TO, int RW, int NI, int NC, int F33 = 0>
+template <typename T, typename TY, int TO, int RW, int NI, int NC, int F33 = 0>
 int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) {
   constexpr int TH = 4 * RW;
   constexpr int NW = (TO * 9 * 4 + 255) / 256;
@@ -648,7 +660,7 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   if ((F33 == 3) != (F33 && p.in_stride == 2)) return -2;
   const size_t lds = sizeof(uint4) * 4 * 64 * (size_t)(NI + NW);   // four planes of NI*64 pixels and NW*64 weight rows
   if (lds > 80 * 1024) return -2;   // two blocks per CU
-  auto kern = conv_pipe_kernel<T, TO, RW, NI, NC, F33>;
+  auto kern = conv_pipe_kernel<T, TY, TO, RW, NI, NC, F33>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -660,9 +672,9 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   tpb = tpb < 1 ? 1 : (tpb > tiles_w ? tiles_w : tpb);
   tpb = tpb > 8 ? 8 : tpb;
   p.tpb = tpb;
-  p.nt = (!p.resid && !p.accumulate && nt_output((int64_t)p.B * p.Hy * p.Wy * p.ldy * sizeof(T))) ? 1 : 0;
+  p.nt = (!p.resid && !p.accumulate && nt_output((int64_t)p.B * p.Hy * p.Wy * p.ldy * sizeof(TY))) ? 1 : 0;
   dim3 grid((tiles_w + tpb - 1) / tpb, tiles_h * p.B, tiles_o);
-  kern<<<grid, 256, lds, st>>>((T*)y, (const T*)x, (const T*)w, p);
+  kern<<<grid, 256, lds, st>>>((TY*)y, (const T*)x, (const T*)w, p);
   return 0;
 }
 
@@ -675,31 +687,31 @@ int dgv2_conv_strip_try(void* y, const void* x, const void* w, int B, int H, int
 
 namespace {
 
-template <typename T, int TO>
+template <typename T, int TO, typename TY = T>
 int dispatch_pipe(void* y, const void* x, const void* w, const DConv& p, bool f33, hipStream_t st) {
   if (p.ncls == 4) {
-    if constexpr (TO <= 32) return p.in_stride == 1 ? launch_pipe<T, TO, 1, 4, 4>(y, x, w, p, st) : -2;
+    if constexpr (TO <= 32) return p.in_stride == 1 ? launch_pipe<T, TY, TO, 1, 4, 4>(y, x, w, p, st) : -2;
     else return -2;
   }
   if (p.ncls != 1) return -2;
   if constexpr (TO == 64) {   // the full 3x3 grid with >= 64 output channels: unrolled taps
     if (f33 && p.O % TO == 0 && p.in_stride == 2) {   // stride-2 forward (the conv behind a blur): 4 x 32 tiles
-      if (!p.hzero && !p.hper) return launch_pipe<T, TO, 1, 10, 1, 3>(y, x, w, p, st);
+      if (!p.hzero && !p.hper) return launch_pipe<T, TY, TO, 1, 10, 1, 3>(y, x, w, p, st);
     } else if (f33 && p.O % TO == 0) {
       if (p.hzero) {
-        if (p.hper) return launch_pipe<T, TO, 2, 7, 1, 2>(y, x, w, p, st);
-        if (p.Hg >= 8) return launch_pipe<T, TO, 2, 6, 1, 2>(y, x, w, p, st);
-        return launch_pipe<T, TO, 1, 4, 1, 2>(y, x, w, p, st);
+        if (p.hper) return launch_pipe<T, TY, TO, 2, 7, 1, 2>(y, x, w, p, st);
+        if (p.Hg >= 8) return launch_pipe<T, TY, TO, 2, 6, 1, 2>(y, x, w, p, st);
+        return launch_pipe<T, TY, TO, 1, 4, 1, 2>(y, x, w, p, st);
       }
-      if (p.hper) return launch_pipe<T, TO, 2, 7, 1, 1>(y, x, w, p, st);
-      if (p.Hg >= 8) return launch_pipe<T, TO, 2, 6, 1, 1>(y, x, w, p, st);
-      return launch_pipe<T, TO, 1, 4, 1, 1>(y, x, w, p, st);
+      if (p.hper) return launch_pipe<T, TY, TO, 2, 7, 1, 1>(y, x, w, p, st);
+      if (p.Hg >= 8) return launch_pipe<T, TY, TO, 2, 6, 1, 1>(y, x, w, p, st);
+      return launch_pipe<T, TY, TO, 1, 4, 1, 1>(y, x, w, p, st);
     }
   }
-  if (p.hper) return launch_pipe<T, TO, 2, 7, 1>(y, x, w, p, st);
-  if (p.in_stride == 1 && p.Hg >= 8) return launch_pipe<T, TO, 2, 6, 1>(y, x, w, p, st);
-  if (p.in_stride == 1) return launch_pipe<T, TO, 1, 4, 1>(y, x, w, p, st);
-  return launch_pipe<T, TO, 1, 10, 1>(y, x, w, p, st);
+  if (p.hper) return launch_pipe<T, TY, TO, 2, 7, 1>(y, x, w, p, st);
+  if (p.in_stride == 1 && p.Hg >= 8) return launch_pipe<T, TY, TO, 2, 6, 1>(y, x, w, p, st);
+  if (p.in_stride == 1) return launch_pipe<T, TY, TO, 1, 4, 1>(y, x, w, p, st);
+  return launch_pipe<T, TY, TO, 1, 10, 1>(y, x, w, p, st);
 }
 
 }  // namespace
@@ -734,22 +746,23 @@ extern "C" int dgv2_conv_taps_ex(void* y, const void* x, const void* w, int B, i
 // dgv2_conv_taps_ex writing the O output channels into rows of ldy >= O channels (y / resid point at the first of them):
 // a launch may then produce a channel RANGE of a wider tensor -- the 528-channel data gradient of the discriminator's
 // epilogue conv runs as 512 + 16 channels instead of nine 64-channel slabs of which the last is three quarters empty.
-extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg,
-                                 int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w,
-                                 int out_stride, int ncls, const int* cls_host, int ntaps, int wtaps,
-                                 const int* taps_host, int nextra, const int* extras_host, int hzero, int ring,
-                                 int accumulate, const float* bias, const void* resid, int act, float alpha,
-                                 float scale, int dtype, void* stream) {
+static int conv_taps_impl(void* y, int ldy, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg,
+                          int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w,
+                          int out_stride, int ncls, const int* cls_host, int ntaps, int wtaps,
+                          const int* taps_host, int nextra, const int* extras_host, int hzero, int ring,
+                          int accumulate, const float* bias, const void* resid, int act, float alpha,
+                          float scale, int dtype, const float* acc_scale, void* stream) {
   if (!y || !x || !w || !taps_host || !cls_host || ntaps < 1 || ntaps > 9 || wtaps < 1 || ldy < O) return DGV2_EINVAL;
-  if (ldy != O && (ldy % (dtype == DGV2_BF16 ? 8 : 4))) return DGV2_EINVAL;   // 16-byte stores stay aligned
+  if (ldy != O && (ldy % (dtype == DGV2_F32 ? 4 : 8))) return DGV2_EINVAL;   // 16-byte stores stay aligned
   if (ncls != 1 && ncls != 4) return DGV2_EINVAL;
   if (nextra < 0 || nextra > 6 || (nextra > 0 && !extras_host)) return DGV2_EINVAL;
   if (B <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Hg <= 0 || Wg <= 0 || O <= 0 || in_stride < 1 || out_stride < 1)
     return DGV2_EINVAL;
   if (act != 0 && act != 3) return DGV2_EINVAL;
-  const int kstep = dtype == DGV2_BF16 ? 32 : 16;
+  const int kstep = dtype == DGV2_FP8 ? 64 : (dtype == DGV2_BF16 ? 32 : 16);   // one 64-byte K-chunk
   if (Cin % kstep || !aligned16(x) || !aligned16(w)) return DGV2_EINVAL;
   DConv p;
+  p.acc_scale = acc_scale;
   p.nt = 0;
   p.hper = 0; p.hrows = 0;
   p.B = B; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hg = Hg; p.Wg = Wg; p.O = O; p.Hy = Hy; p.Wy = Wy; p.ldy = ldy;
@@ -844,6 +857,14 @@ extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w,
   for (int t = 2; f33 && t < 9; ++t) f33 = p.widx[t] - p.widx[t - 1] == p.widx[1] - p.widx[0];   // weight slots affine in t
   for (int e = 0; f33 && hzero && e < nextra; ++e)   // zero rows are not staged as zeros there: extras must read real rows
     f33 = (unsigned)(p.x_row[e] * in_stride + ioff_h + p.x_dy[e]) < (unsigned)Hin;
+  if (dtype == DGV2_FP8) {
+    // e4m3 operands, bf16 result / residual: the forward convs behind the FIRs (>= 64 output channels, one class)
+    if (ncls != 1 || nextra || accumulate || O < 64 || !wrap_ok) return DGV2_ENOTSUP;
+    rc = dispatch_pipe<fp8_t, 64, bf16_t>(y, x, w, p, f33, st);
+    if (rc == -2) return DGV2_ENOTSUP;
+    if (rc) return rc;
+    DGV2_RETURN_LAST();
+  }
   DGV2_DISPATCH_DTYPE(dtype, {
     rc = -2;
     if ((!no_pipe || !plain) && wrap_ok) {
@@ -861,6 +882,39 @@ extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w,
   });
   if (rc) return rc;
   DGV2_RETURN_LAST();
+}
+
+extern "C" int dgv2_conv_taps_ld(void* y, int ldy, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg,
+                                 int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w,
+                                 int out_stride, int ncls, const int* cls_host, int ntaps, int wtaps,
+                                 const int* taps_host, int nextra, const int* extras_host, int hzero, int ring,
+                                 int accumulate, const float* bias, const void* resid, int act, float alpha,
+                                 float scale, int dtype, void* stream) {
+  if (dtype != DGV2_F32 && dtype != DGV2_BF16) return DGV2_EINVAL;
+  return conv_taps_impl(y, ldy, x, w, B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy, in_stride, ioff_h, ioff_w, out_stride, ncls,
+                        cls_host, ntaps, wtaps, taps_host, nextra, extras_host, hzero, ring, accumulate, bias, resid, act,
+                        alpha, scale, dtype, nullptr, stream);
+}
+
+// dgv2_conv_taps (single class, no extras, overwrite) on e4m3 operands: x8 [B,Hin,Win,Cin] and w8 [O,wtaps,Cin] are OCP
+// e4m3 bytes (x at unit scale, w scaled by a per-tensor power of two: dgv2_fp8_quant_weights), contracted by
+// v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation;
+//   y (bf16) = act( acc * acc_scale[0] + resid + bias ) * scale,   acc_scale: DEVICE scalar (EqualLR factor / weight scale).
+// Cin % 64 == 0 (one 64-byte K-chunk = 64 channels), O >= 64; DGV2_ENOTSUP otherwise (callers then run the bf16 conv).
+extern "C" int dgv2_conv_taps_fp8(void* y, const void* x8, const void* w8, const float* acc_scale, int B, int Hin,
+                                  int Win, int Cin, int Hg, int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h,
+                                  int ioff_w, int ntaps, int wtaps, const int* taps_host, int ring, const float* bias,
+                                  const void* resid, int act, float alpha, float scale, void* stream) {
+  if (!taps_host || ntaps < 1 || ntaps > 9 || !acc_scale) return DGV2_EINVAL;
+  if (Cin % 64) return DGV2_ENOTSUP;
+  int taps4[36];
+  for (int t = 0; t < ntaps; ++t) {
+    taps4[4 * t] = taps_host[3 * t]; taps4[4 * t + 1] = taps_host[3 * t + 1]; taps4[4 * t + 2] = taps_host[3 * t + 2];
+    taps4[4 * t + 3] = 0;
+  }
+  const int cls[2] = {0, 0};
+  return conv_taps_impl(y, O, x8, w8, B, Hin, Win, Cin, Hg, Wg, O, Hy, Wy, in_stride, ioff_h, ioff_w, 1, 1, cls, ntaps,
+                        wtaps, taps4, 0, nullptr, 0, ring, 0, bias, resid, act, alpha, scale, DGV2_FP8, acc_scale, stream);
 }
 
 // The single-class, no-extras form (taps_host: ntaps triples (dy, dx, widx)).

@@ -53,6 +53,7 @@ struct FMGeom {
   const bf16_t* ref;      // ACT: forward output of the activation, laid out like y
   float alpha, ascale;
   float* partial;         // ACT: [B * W/32][C] column sums of the stored values
+  uint8_t* y8;            // !ACT: the result as e4m3 (unit scale) instead of bf16 (y is then not written)
 };
 
 struct FMTabs {
@@ -293,6 +294,15 @@ __global__ __launch_bounds__(256, 2) void fir_same_mfma_kernel(bf16_t* __restric
           bsum[j] += o.get(j);   // the reference sums the rounded gradient
         }
       }
+      if constexpr (!ACT) {
+        if (g.y8) {   // e4m3 output (fp8.hip): 8 bytes per unit; a pixel's 32 channels of this block are 32 contiguous bytes
+          float f[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = o.get(j);
+          *reinterpret_cast<uint2*>(g.y8 + off) = pack_fp8x8(f);
+          continue;
+        }
+      }
       if (g.nt) o.store_nt(y + off);
       else o.store(y + off);
     }
@@ -375,13 +385,29 @@ extern "C" int dgv2_fir_same_mfma(void* y, const void* x, const void* bands, int
   if (!y || !x || !bands) return DGV2_EINVAL;
   if (!fm_covers(B, C, H, W)) return DGV2_ENOTSUP;
   if (!aligned16(x) || !aligned16(y) || !aligned16(bands)) return DGV2_EINVAL;
-  FMGeom g{B, C, H, W, nt_output((int64_t)B * H * W * C * 2) ? 1 : 0, (const uint4*)bands, nullptr, 1.f, 1.f, nullptr};
+  FMGeom g{B, C, H, W, nt_output((int64_t)B * H * W * C * 2) ? 1 : 0, (const uint4*)bands, nullptr, 1.f, 1.f, nullptr, nullptr};
   auto kern = fir_same_mfma_kernel<false>;
   if (FM_LDS > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FM_LDS);
     if (e != hipSuccess) return (int)e;
   }
   kern<<<dim3(W / FM_CT, C / FM_CB, B), 256, FM_LDS, (hipStream_t)stream>>>((bf16_t*)y, (const bf16_t*)x, g);
+  DGV2_RETURN_LAST();
+}
+
+// dgv2_fir_same_mfma with the result stored as e4m3 (OCP fp8, unit scale, saturating): y8 [B,H,W,C] bytes.  The values
+// are the bf16 kernel's (rounded to bf16 where it rounds), then rounded once more to e4m3 at the store.
+extern "C" int dgv2_fir_same_mfma_q8(void* y8, const void* x, const void* bands, int B, int C, int H, int W, void* stream) {
+  if (!y8 || !x || !bands) return DGV2_EINVAL;
+  if (!fm_covers(B, C, H, W)) return DGV2_ENOTSUP;
+  if (!aligned16(x) || (reinterpret_cast<uintptr_t>(y8) & 7) || !aligned16(bands)) return DGV2_EINVAL;
+  FMGeom g{B, C, H, W, 0, (const uint4*)bands, nullptr, 1.f, 1.f, nullptr, (uint8_t*)y8};
+  auto kern = fir_same_mfma_kernel<false>;
+  if (FM_LDS > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FM_LDS);
+    if (e != hipSuccess) return (int)e;
+  }
+  kern<<<dim3(W / FM_CT, C / FM_CB, B), 256, FM_LDS, (hipStream_t)stream>>>((bf16_t*)nullptr, (const bf16_t*)x, g);
   DGV2_RETURN_LAST();
 }
 
@@ -397,7 +423,7 @@ extern "C" int dgv2_fir_same_mfma_actbwd(void* y, float* gb, float* scratch, int
   if (!scratch) return blocks_needed ? 0 : DGV2_EINVAL;
   if (!y || !gb || !x || !ref || !bands) return DGV2_EINVAL;
   if (scratch_elems < blocks * C || !aligned16(x) || !aligned16(y) || !aligned16(ref) || !aligned16(bands)) return DGV2_EINVAL;
-  FMGeom g{B, C, H, W, 0, (const uint4*)bands, (const bf16_t*)ref, alpha, scale, scratch};
+  FMGeom g{B, C, H, W, 0, (const uint4*)bands, (const bf16_t*)ref, alpha, scale, scratch, nullptr};
   auto kern = fir_same_mfma_kernel<true>;
   if (FM_LDS > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FM_LDS);

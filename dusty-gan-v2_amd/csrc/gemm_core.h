@@ -27,6 +27,18 @@ template <> struct Mfma16<bf16_t> {
   }
 };
 
+// e4m3 operands: a 16-byte chunk is 16 elements = two K = 32 steps of v_mfma_f32_16x16x32_fp8_fp8 (8 bytes per lane
+// each).  Which k a lane's bytes stand for is the same permutation on both operands, so the low / high halves of the
+// chunks pair up and the two steps together contract the 64 channels of a 64-byte K-chunk.
+template <> struct Mfma16<fp8_t> {
+  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    const long a0 = (long)(((unsigned long)a.y << 32) | a.x), a1 = (long)(((unsigned long)a.w << 32) | a.z);
+    const long b0 = (long)(((unsigned long)b.y << 32) | b.x), b1 = (long)(((unsigned long)b.w << 32) | b.z);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc, 0, 0, 0);
+  }
+};
+
 template <> struct Mfma16<float> {
   __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
     union { uint4 u; float f[4]; } ua, ub;

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
     const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
     const int* __restrict__ cnt_w, int Ew, int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
     int SHA, float* __restrict__ sumsq, const T* __restrict__ ref = nullptr, float alpha = 1.f, float ascale = 1.f,
-    float* __restrict__ bias_partial = nullptr) {
+    float* __restrict__ bias_partial = nullptr, uint8_t* __restrict__ y8 = nullptr) {
 #ifdef DGV2_ABLATE   // benchmarking builds only (make ABLATE=1): wrong results by design, never in the shipped library
   const int SH = SHA & 0xffff, ablate = (SHA >> 16) & 0xff;   // DGV2_RS_ABLATE
 #else
@@ -417,9 +417,17 @@ __global__ __launch_bounds__(256) void resample_stream_kernel(
 #pragma unroll
         for (int j = 0; j < VN; ++j) o.set(j, acc[j]);
       }
-      if (y) {   // y == nullptr: statistic only (sum of squares of the result)
+      if (y) {   // y == nullptr: statistic only (sum of squares of the result) / e4m3 output only
         if (nt) o.store_nt(yp + (int64_t)ho * out_w * ldy);
         else o.store(yp + (int64_t)ho * out_w * ldy);
+      }
+      if constexpr (!ACT && sizeof(T) == 2) {
+        if (y8) {   // the result as e4m3 (unit scale), same [B, out_h, out_w, ldy] element layout: 8 bytes per thread
+          float f[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = acc[j];
+          *reinterpret_cast<uint2*>(y8 + ((int64_t)b * out_h + ho) * out_w * ldy + (int64_t)wo * ldy + cv * VN) = pack_fp8x8(f);
+        }
       }
       if (sumsq) {
 #pragma unroll
@@ -529,6 +537,37 @@ extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const
                                  void* stream) {
   return dgv2_resample_tab_sq(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h,
                               out_w, dtype, nullptr, 0, nullptr, stream);
+}
+
+// dgv2_resample_tab with the result stored as e4m3 (OCP fp8, unit scale, saturating at +-448) instead of bf16:
+// y8 [B,out_h,out_w,C] bytes.  x bf16, C % 8 == 0, Ew <= 4, Eh <= 64 (the streaming kernel); DGV2_ENOTSUP otherwise.
+// The FIR arithmetic is the bf16 kernel's (fp32 accumulation, W pass rounded to bf16 in the ring); only the final
+// store differs.  fp8.hip says which tensors are kept like this.
+extern "C" int dgv2_resample_tab_q8(void* y8, const void* x, const int* idx_h, const float* coef_h, const int* cnt_h,
+                                    int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew, int B,
+                                    int C, int in_h, int in_w, int out_h, int out_w, void* stream) {
+  if (!y8 || !x || !idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w) return DGV2_EINVAL;
+  if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || Eh <= 0 || Ew <= 0) return DGV2_EINVAL;
+  if ((C & 7) || Ew > 4 || Eh > 64 || !aligned16(x) || (reinterpret_cast<uintptr_t>(y8) & 7)) return DGV2_ENOTSUP;
+  typedef bf16_t T;
+  int SH = out_h >= 32 ? 16 : (out_h >= 8 ? 8 : out_h);
+  while (SH > 1 && SH * Eh > 64) SH >>= 1;
+  const int64_t blocks = (int64_t)B * ((out_h + SH - 1) / SH) * (((int64_t)out_w * (C / 8) + 255) / 256);
+  if (blocks >= (1LL << 31)) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t* q = (uint8_t*)y8;
+#define DGV2_RS_Q8(EW)                                                                                                   \
+  resample_stream_kernel<T, EW><<<(int)blocks, 256, 0, st>>>((T*)nullptr, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w,   \
+                                                            coef_w, cnt_w, Ew, B, C, C, C, in_h, in_w, out_h, out_w, SH,  \
+                                                            nullptr, nullptr, 1.f, 1.f, nullptr, q)
+  switch (Ew) {
+    case 1: DGV2_RS_Q8(1); break;
+    case 2: DGV2_RS_Q8(2); break;
+    case 3: DGV2_RS_Q8(3); break;
+    default: DGV2_RS_Q8(4); break;
+  }
+#undef DGV2_RS_Q8
+  DGV2_RETURN_LAST();
 }
 
 extern "C" int dgv2_resample_tab_sq(void* y, const void* x, const int* idx_h, const float* coef_h, const int* cnt_h,

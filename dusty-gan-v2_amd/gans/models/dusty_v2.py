@@ -512,7 +512,33 @@ class ResidualBlock(nn.Module):
         return [(self.conv1, self.conv1.bank_entry()), (self.conv2, self.conv2.bank_entry()),
                 (self.skip, self.skip.bank_entry(wscale=c if fused else None))]
 
-    def forward_cl(self, x, bank=None):
+    def fp8_entries(self, vec):
+        """(conv, (parameter, runtime scale)) of the two convs that take e4m3 operands (native.fp8), as forward_cl will
+        call them; [] where the block's shape does not allow it (whole 64-channel K-chunks, >= 64 output channels)."""
+        if self.conv2.in_ch % 64 or self.conv2.out_ch < 64 or self.skip.in_ch % vec or self.skip._params_bias()[0] is not None:
+            return []
+        c = 1.0 / math.sqrt(2)
+        return [(self.conv2, self.conv2.bank_entry()[:2]), (self.skip, self.skip.bank_entry(wscale=c)[:2])]
+
+    def _forward_fp8(self, x, bank, fp8):
+        """The block with its two branch operands in e4m3 (csrc/fp8.hip): hd = blur(act(conv1(x))) and
+        xs = blur_down(x) leave their FIR kernels as e4m3, conv2 and the skip conv contract e4m3 x e4m3 on
+        v_mfma_f32_16x16x32_fp8_fp8; the residual stream x, both activation outputs and every gradient stay bf16."""
+        spec = self.resample.spec
+        if x.requires_grad:
+            hd_h, hd8, x = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank, fork=True, down=spec, q8=True)
+        else:
+            hd_h, hd8 = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank, down=spec, q8=True)
+        c = 1.0 / math.sqrt(2)
+        xs = native.resample_q8(x, self.blur_down)
+        h = self.conv2.forward_cl((hd_h, hd8), act=self.bias_act2, act_scale=self.bias_act2.scale * c, bank=bank,
+                                  fp8=fp8[self.conv2])
+        return self.skip.forward_cl(xs, geom=self.skip_geom, resid=h, wscale=c, bank=bank, fp8=fp8[self.skip])
+
+    def forward_cl(self, x, bank=None, fp8=None):
+        if (fp8 is not None and self.conv2 in fp8 and bank is not None and bank.get(self.conv1) is not None
+                and isinstance(self.resample, ops.Resample) and native.fp8_ok(x, self.conv2.out_ch)):
+            return self._forward_fp8(x, bank, fp8)
         hd = None   # conv1's activation after the blur/down
         if bank is not None and bank.get(self.conv1) is not None and isinstance(self.resample, ops.Resample):
             # conv1 -> act -> blur/down as one autograd node (one fused pass in backward); it also hands x on to the skip
@@ -559,6 +585,10 @@ class Discriminator(nn.Module):
         # "bf16" (opt-in: attribute, or DGV2_D_EPILOGUE=bf16) runs the conv and the 65536->512 Linear with bf16
         # operands and fp32 accumulation when num_fp16_layers == -1.
         self.epilogue_dtype = os.environ.get("DGV2_D_EPILOGUE", "fp32")
+        # BASELINE configs[4] ("fp8 activations"): the branch operands of every ResidualBlock from 64 channels up as OCP
+        # e4m3 (csrc/fp8.hip, native.fp8) in first-order passes of the reduced-precision trunk.  Opt-in: attribute or
+        # DGV2_FP8=1; the reference has no such mode (its switch is the fp16 autocast, dusty_v2.py:388-394).
+        self.fp8_branches = os.environ.get("DGV2_FP8", "0") == "1"
         c_in = in_ch * 2 if pre_blur else in_ch
         layers = [ops.BlurVH(ring=ring)] if pre_blur else []
         layers += [ops.Conv2d(c_in, ch(0), 1, 1, 0, **kw)]
@@ -603,6 +633,18 @@ class Discriminator(nn.Module):
             bank[conv] = (epi[1][1], epi[1][2], wf, wt)
         return bank
 
+    def _fp8_bank(self):
+        """{conv: (e4m3 weights [O,kh*kw,C], device descale)} of the convs that take e4m3 operands: per-tensor
+        power-of-two scales from this step's weights, one launch pair (native.fp8_quant_weights)."""
+        items = []
+        for layer in self.layers:
+            if isinstance(layer, ResidualBlock):
+                items += layer.fp8_entries(32)
+        if not items or len(items) > 16:
+            return None
+        prepared = native.fp8_quant_weights([e for _, e in items])
+        return {m: wd for (m, _), wd in zip(items, prepared)}
+
     def _epilogue_dtype(self):
         if self.epilogue_dtype not in ("fp32", "bf16"):
             raise ValueError(f"epilogue_dtype must be 'fp32' or 'bf16', got {self.epilogue_dtype!r}")
@@ -626,6 +668,7 @@ class Discriminator(nn.Module):
         layers = list(self.layers)
         i = 0
         bank = None if (double_backward or not h.is_cuda) else self._weight_bank()
+        fp8 = self._fp8_bank() if (bank is not None and self.fp8_branches and self.num_fp16_layers == -1) else None
         fused = (not double_backward and h.is_cuda and h.shape[1] == 1 and len(layers) > 3
                  and isinstance(layers[0], ops.BlurVH) and isinstance(layers[1], ops.Conv2d)
                  and isinstance(layers[2], ops.FusedLeakyReLU) and layers[2].bias is not None
@@ -645,7 +688,7 @@ class Discriminator(nn.Module):
                 x = layer.forward_cl(x, act=nxt)  # stem conv + its bias/lrelu in one kernel
                 i += 2
             elif isinstance(layer, ResidualBlock):
-                x = layer.forward_cl(x, bank=bank)
+                x = layer.forward_cl(x, bank=bank, fp8=fp8)
                 i += 1
             else:
                 x = layer.forward_cl(x)

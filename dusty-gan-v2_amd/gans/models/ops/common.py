@@ -161,11 +161,13 @@ class Conv2d(nn.Sequential):
         return (p, s * (1.0 if wscale is None else wscale), cpad)
 
     def forward_cl(self, x, pad_in_to=None, act=None, geom=None, act_scale=None, resid=None, wscale=None, bank=None,
-                   fork=False, down=None):
+                   fork=False, down=None, fp8=None, q8=False):
         """act: a FusedLeakyReLU module fused into the conv epilogue; geom overrides the stride
         (used when the caller has already decimated the input).  bank: {conv: (scale, cpad, wf, wt)} from
         Discriminator's weight bank: the prepared compute-dtype weights ride along on `w` (which stays the
-        differentiable fp32 handle) when they were built with this call's scale and padding."""
+        differentiable fp32 handle) when they were built with this call's scale and padding.
+        fp8 = (w8, descale) from native.fp8_quant_weights: `x` is then (bf16 handle, e4m3 payload) and the contraction
+        runs on e4m3 operands (native.fp8); q8 (with `down`): the blurred activation leaves as such a pair."""
         geom = self.geom if geom is None else geom
         ent = None if bank is None else bank.get(self)
         if ent is not None:
@@ -190,13 +192,22 @@ class Conv2d(nn.Sequential):
                 w = F.pad(w, (0, pad_in_to - w.shape[3]))
             if wscale is not None:
                 w = w * wscale
+        if fp8 is not None:   # e4m3 operands: x = (handle, payload); the bank's handle carries the bf16 backward operands
+            assert ent is not None and b is None and not fork and down is None
+            handle, x8 = x
+            if resid is not None:
+                assert act is None
+                return native.conv_ring_resid_fp8(handle, x8, w, fp8[0], fp8[1], resid, geom)
+            assert act is not None and act.bias is not None
+            return native.conv_ring_act_fp8(handle, x8, w, fp8[0], fp8[1], act.bias, geom, act.negative_slope,
+                                            act.scale if act_scale is None else act_scale)
         if resid is not None:   # conv(x, w) + resid in one launch (bias-free, activation-free skip conv)
             assert b is None and act is None
             return native.conv_ring_resid(x, w if ent is not None else w.contiguous(), resid, geom)
         if down is not None:   # conv + act + blur/down as one node (native._ConvActDown); -> y or (y, x) with fork
             assert act is not None and b is None and act.bias is not None and resid is None and ent is not None
             return native.conv_ring_act_down(x, w, act.bias, geom, down, act.negative_slope,
-                                             act.scale if act_scale is None else act_scale, fork=fork)
+                                             act.scale if act_scale is None else act_scale, fork=fork, q8=q8)
         if fork:   # -> (activation, x handed on to the sibling branch); see native._ConvActFork
             assert act is not None and b is None and act.bias is not None and resid is None
             return native.conv_ring_act_fork(x, w if ent is not None else w.contiguous(), act.bias, geom,

@@ -12,6 +12,7 @@ its masked form -- so double backward never leaves the HIP kernels.
 from .act_resample import *  # noqa: F401,F403
 from .modgemm import *  # noqa: F401,F403
 from .conv import *  # noqa: F401,F403
+from .fp8 import *  # noqa: F401,F403
 from .stem_tail_ada import *  # noqa: F401,F403
 from .modlayer import *  # noqa: F401,F403
 from .misc import *  # noqa: F401,F403

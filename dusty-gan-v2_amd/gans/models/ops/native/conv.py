@@ -630,7 +630,9 @@ class _ConvActDown(Function):
     add the skip branch's gradient of x in the data-gradient epilogue.  First-order passes with the weight bank."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, g, alpha, scale, spec, fork):
+    def forward(ctx, x, w, bias, g, alpha, scale, spec, fork, q8=False):
+        """q8: the blurred activation leaves as e4m3 (native.fp8): -> (bf16 handle carrying the autograd edge, e4m3
+        payload[, x])."""
         ctx.set_materialize_grads(False)
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
@@ -639,17 +641,27 @@ class _ConvActDown(Function):
             wc = _values(w, x.dtype)
         out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
         in_hw = (out.shape[1], out.shape[2])
-        y = _resample_raw(out, spec, False, in_hw)
         ctx.save_for_backward(x, w, out)
         ctx.cfg = (g, alpha, scale, bias.numel(), spec, in_hw)
+        ctx.q8 = bool(q8)
+        if q8:
+            from .fp8 import _handle, _resample_q8_raw
+            y8 = _resample_q8_raw(out, spec, in_hw)
+            if y8 is None:
+                raise RuntimeError("dgv2: no e4m3 resampling kernel covers this shape (check native.fp8_ok first)")
+            ctx.mark_non_differentiable(y8)
+            return (_handle(y8.shape, x.device), y8) + ((x.view_as(x),) if fork else ())
+        y = _resample_raw(out, spec, False, in_hw)
         return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, gy, gx_sibling=None):
+    def backward(ctx, gy, *rest):
         x, w, out = ctx.saved_tensors
         g, alpha, scale, size_b, spec, in_hw = ctx.cfg
+        rest = rest[1:] if ctx.q8 else rest          # q8: rest[0] is the (absent) gradient of the e4m3 payload
+        gx_sibling = rest[0] if rest else None
         if gy is None:
-            return gx_sibling, None, None, None, None, None, None, None
+            return gx_sibling, None, None, None, None, None, None, None, None
         fused = None if torch.is_grad_enabled() else _resample_actbwd(gy.to(out.dtype), out, spec, in_hw, alpha, scale)
         if fused is not None:
             gpre, gb = fused
@@ -658,11 +670,11 @@ class _ConvActDown(Function):
             gpre, gb = _BiasActBackward.apply(gh, out, True, alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale) if ctx.needs_input_grad[0] else gx_sibling
         gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
-def conv_ring_act_down(x, w, bias, geom, spec, alpha=0.2, scale=math.sqrt(2.0), fork=False):
-    return _ConvActDown.apply(x, w, bias, geom, float(alpha), float(scale), spec, bool(fork))
+def conv_ring_act_down(x, w, bias, geom, spec, alpha=0.2, scale=math.sqrt(2.0), fork=False, q8=False):
+    return _ConvActDown.apply(x, w, bias, geom, float(alpha), float(scale), spec, bool(fork), bool(q8))
 
 
 class _ConvResid(Function):

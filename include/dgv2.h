@@ -28,6 +28,7 @@ extern "C" {
 
 #define DGV2_F32 0
 #define DGV2_BF16 1
+#define DGV2_FP8 2 /* OCP e4m3fn bytes; only where an entry says so (the *_fp8 / *_q8 entries) */
 #define DGV2_EINVAL (-1)
 #define DGV2_ENOTSUP (-3) /* valid request that this build's kernels do not cover: use the documented fallback */
 
@@ -642,6 +643,39 @@ int dgv2_emd_matchcost(float* cost, const float* match, const float* xyz1, const
                        void* stream);
 int dgv2_emd_matchcost_grad(float* grad1, float* grad2, const float* match, const float* xyz1, const float* xyz2, int B,
                             int n, int m, void* stream);
+
+/* ---- fp8 (OCP e4m3) operands for the decimating branch convs of the discriminator (BASELINE configs[4]) --------------
+ * The two tensors of a ResidualBlock (gans/models/dusty_v2.py:325-345) that exist only as MFMA operands -- the blurred
+ * activation in front of the 3x3 stride-2 conv2 and the blur-decimated block input in front of the 1x1 skip conv -- are
+ * written as e4m3 (unit scale) by the FIR kernels that produce them, the two convs' weights as e4m3 with a per-tensor
+ * power-of-two scale; v_mfma_f32_16x16x32_fp8_fp8 contracts them with fp32 accumulation.  The residual stream and the
+ * activation outputs read by a backward pass stay bf16; the weight-gradient stream reads the saved e4m3 tensor through
+ * dgv2_fp8_dequant.  The reference's reduced-precision switch: gans/models/dusty_v2.py:388-394 (fp16 autocast). */
+/* y8 [B,H,W,C] (e4m3 bytes) = R x for a same-size separable resampling: dgv2_fir_same_mfma with the result rounded to
+ * e4m3 (saturating at +-448) at the store.  replaces: Resample(up = down = 1) / Blur, gans/models/ops/common.py:105-135. */
+int dgv2_fir_same_mfma_q8(void* y8, const void* x, const void* bands, int B, int C, int H, int W, void* stream);
+/* dgv2_resample_tab (x bf16, tables as there) with the result stored as e4m3 bytes y8 [B,out_h,out_w,C]; C % 8 == 0,
+ * Ew <= 4, Eh <= 64, else DGV2_ENOTSUP.  replaces: Resample, gans/models/ops/common.py:105-135. */
+int dgv2_resample_tab_q8(void* y8, const void* x, const int* idx_h, const float* coef_h, const int* cnt_h, int Eh,
+                         const int* idx_w, const float* coef_w, const int* cnt_w, int Ew, int B, int C, int in_h,
+                         int in_w, int out_h, int out_w, void* stream);
+/* n <= 16 conv weights in one launch pair: w8[l] [O,kk,C] = e4m3(src[l] [O,C,kk] fp32 * 2^k_l), 2^k_l the largest power of
+ * two with max|src[l]| * 2^k_l <= 448; descale[l] (device, fp32) = eq[l] / 2^k_l -- the factor the conv epilogue puts on
+ * its accumulator (eq = the EqualLR factor).  amax: n words of device scratch.  w8 / src / O / C / kk / eq: HOST arrays.
+ * C % 8 == 0.  replaces: the `weight * scale` operand of ops.Conv2d, gans/models/ops/common.py:158-210. */
+int dgv2_fp8_quant_weights(void* const* w8, const void* const* src, const int* O, const int* C, const int* kk,
+                           const float* eq, int n, float* descale, void* amax, void* stream);
+/* y (bf16) = x (e4m3) * scale for n elements, n % 16 == 0: the saved e4m3 activations as the bf16 operand of the
+ * weight-gradient stream (dgv2_conv_wgrad_stream). */
+int dgv2_fp8_dequant(void* y, const void* x, int64_t n, float scale, void* stream);
+/* dgv2_conv_taps (single class, no extras, overwrite) on e4m3 operands x8 [B,Hin,Win,Cin], w8 [O,wtaps,Cin]:
+ *   y (bf16) = act( acc * acc_scale[0] + resid + bias ) * scale,  acc_scale a DEVICE scalar (dgv2_fp8_quant_weights).
+ * Cin % 64 == 0, O >= 64; DGV2_ENOTSUP otherwise.  replaces: ops.Conv2d forward (gans/models/ops/common.py:187-210) of
+ * ResidualBlock.conv2 / .skip (gans/models/dusty_v2.py:331-345). */
+int dgv2_conv_taps_fp8(void* y, const void* x8, const void* w8, const float* acc_scale, int B, int Hin, int Win, int Cin,
+                       int Hg, int Wg, int O, int Hy, int Wy, int in_stride, int ioff_h, int ioff_w, int ntaps, int wtaps,
+                       const int* taps_host, int ring, const float* bias, const void* resid, int act, float alpha,
+                       float scale, void* stream);
 
 #ifdef __cplusplus
 }

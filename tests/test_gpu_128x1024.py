@@ -2,7 +2,11 @@
 evaluated in float64 on the same inputs -- G step (outputs, loss, every gradient whole) and D step -- and the bf16
 training loop (hipGraph replay) for finiteness at that size.  No reference fixture exists at this size (the oracle is
 pinned at 16 x 64 and 64 x 512, tests/test_oracle_golden.py); the path is resolution-generic, this test holds it to
-that.  fp8 activations (the rest of configs[4]) are not built.  Run with -m gpu."""
+that.  The fp8 part of configs[4] (e4m3 operands of the discriminator's decimating branch convs, csrc/fp8.hip) runs at
+the config's per-GPU batch, B = 32: against the bf16 evaluation of the same discriminator within the stated e4m3
+tolerance (tests/test_gpu_fp8.py) and as hipGraph replays of the whole training loop.  Run with -m gpu."""
+import math
+
 import pytest
 import torch
 
@@ -110,3 +114,50 @@ def test_bf16_training_iterations_replay_as_graphs_at_128x1024():
     assert set(tr._graphs) >= {"g_fb", "g_opt", "d_fb", "d_opt", "r1_fb"}
     assert len({round(v, 5) for v in seen}) > 4
     assert tuple(tr.sample(ema=True)["image"].shape) == (4, 1, 128, 1024)
+
+
+def test_e4m3_branches_at_128x1024_batch_32():
+    """BASELINE configs[4] at its per-GPU batch: the full-width discriminator (five ResidualBlocks, four of them from 64
+    channels up) with e4m3 branch operands against its bf16 evaluation on B = 32 range images -- trunk features
+    rel-L2 within 3 % x sqrt(2 x 4 blocks), logits within 5 % of their spread, gradient direction -- then the training
+    loop (G step, D step, R1, ADA, Adam) at B = 32 as hipGraph replays with the e4m3 discriminator: finite, moving,
+    every body a live graph."""
+    from gans.trainer import Trainer
+    B = 32
+    G, D = build_models(cfg_at(True), DEV)
+    assert D._fp8_bank() is not None and len(D._fp8_bank()) == 8          # conv2 + skip of blocks 1..4
+    x = torch.randn(B, 1, *RES, device=DEV).clamp(-1, 1)
+    D.requires_grad_(True)
+    res = {}
+    for mode in (False, True):
+        D.fp8_branches = mode
+        feats = D(x, features_only=True).float().detach()
+        y = D(x)
+        gs = torch.autograd.grad(F.softplus(-y).mean(), list(D.parameters()))
+        res[mode] = (feats, y.detach().float(), torch.cat([g.float().reshape(-1) for g in gs]))
+    rel = float((res[True][0] - res[False][0]).norm() / res[False][0].norm())
+    assert 1e-3 < rel < 0.03 * math.sqrt(2 * 4), rel
+    spread = float(res[False][1].std()) + 1e-6
+    assert float((res[True][1] - res[False][1]).abs().max()) < 0.05 * spread + 0.02
+    cos = float((res[True][2] * res[False][2]).sum() / (res[True][2].norm() * res[False][2].norm()))
+    assert cos > 0.99 and bool(torch.isfinite(res[True][2]).all()), cos
+    del G, D, res
+    torch.cuda.empty_cache()
+
+    cfg = cfg_at(True)
+    cfg.dataset.name = "synthetic"
+    cfg.training.update(rank=0, num_gpus=1, batch_size=B, batch_size_per_gpu=B, resume=None, hip_graph=True)
+    cfg.training.lazy.gp = 4
+    cfg.training.warmup.fade_kimg = 0
+    torch.manual_seed(0)
+    tr = Trainer(cfg, sync_scalars=False)
+    tr.D.fp8_branches = True
+    seen = []
+    for it in range(1, 13):   # R1 every 4th iteration: two eager runs, the capture, one replay
+        out = tr.step(it)
+        vals = {k: float(v) for k, v in out.items() if torch.is_tensor(v)}
+        assert all(v == v and abs(v) < 1e6 for v in vals.values()), vals
+        seen.append(vals["loss/D/adversarial"])
+    live = tr.graphs_live()
+    assert set(live) >= {"g_fb", "g_opt", "d_fb", "d_opt", "r1_fb"} and all(live.values()), live
+    assert len({round(v, 5) for v in seen}) > 4
