@@ -15,9 +15,13 @@ def per_kernel(d, counter):
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 res = {}
-for key in (sys.argv[3:] or ("conv_pipe_kernel", "conv3x3_strip_kernel", "modconv_pe_fwd_kernel", "modconv_up_kernel")):
-    fk = [k for k in fetch if key in k]
-    wk = [k for k in write if key in k]
+# "alias=substring": record under `alias` the kernel whose name contains `substring`
+for key in (sys.argv[3:] or ("conv_pipe_kernel_s2dgrad=conv_pipe_kernel", "conv3x3_strip_kernel", "modconv_pe_fwd_kernel",
+                             "modconv_up_kernel", "modconv_up_t_kernel", "up2_lag_sumsq_kernel")):
+    key, _, sub = key.partition("=")
+    sub = sub or key
+    fk = [k for k in fetch if sub in k and (sub != "modconv_up_kernel" or "modconv_up_t" not in k)]
+    wk = [k for k in write if sub in k and (sub != "modconv_up_kernel" or "modconv_up_t" not in k)]
     if not fk or not wk:
         continue
     fv, wv = fetch[fk[0]], write[wk[0]]

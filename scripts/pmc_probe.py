@@ -3,7 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out_f -- python3 scripts/pmc_probe.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out_w -- python3 scripts/pmc_probe.py
-    python scripts/pmc_collect.py out_f out_w > profiles/round1_pmc.json
+    python scripts/pmc_collect.py out_f out_w > profiles/round3_pmc.json
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,5 +13,6 @@ import torch
 import bench
 
 args = argparse.Namespace(batch_per_gpu=64, dtype="bf16")
+print(bench.dominant_probe(args, reps=5))     # the only conv_pipe_kernel launches of this script
 print(bench.roofline_probe(args, reps=5))
 print(bench.modconv_probe(args, reps=5))
