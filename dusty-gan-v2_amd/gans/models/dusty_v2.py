@@ -265,6 +265,52 @@ class SynthesisBlock(nn.Module):
             o = o + self.resample.forward_cl(skip)
         return h, o
 
+    def forward_composable(self, h, skip, ws, angle, shift, B):
+        """The block from ops whose gradients can be differentiated again (reference: SynthesisBlock.forward,
+        dusty_v2.py:142-180): the differentiable torch-op weight preparation of ModConv2d.sample_weights (with the
+        azimuth shift as a rotation of the PE columns, see _conv1_shared_pe), the contraction as native.cat_gemm
+        (closed under differentiation, native/second_order.py), native.bias_act and native.resample (closed as the
+        discriminator's R1 path needs them).  Batch-shared angle grid only.  Used by the path-length regulariser."""
+        dt = self.compute_dtype
+        H, W = angle.shape[2:]
+        pe0 = self.pe.encoded(angle, dt)
+        hup = None if h is None else self.resample.forward_cl(h.to(dt))
+        cin = 0 if hup is None else hup.shape[3]
+        conv = self.conv1
+        sumsq = None
+        if conv.training:
+            with torch.no_grad():   # sum of squares of cat(hup, PE): sin^2 + cos^2 = 1 per frequency pair
+                sumsq = torch.full((), float(self.pe.out_ch // 2) * B * H * W, device=angle.device)
+                if hup is not None:
+                    sumsq = sumsq + hup.float().square().sum()
+        wb = conv.sample_weights(ws[0], sumsq, B * H * W * (cin + self.pe.out_ch))
+        if shift is not None:
+            nf = self.pe.out_ch // 2
+            d = shift[:, None] * self.pe.freqs2[:, 1][None, :]  # [B,F]
+            cd, sd = torch.cos(d)[:, None, :], torch.sin(d)[:, None, :]
+            w_s, w_c = wb[:, :, cin:cin + nf], wb[:, :, cin + nf:]
+            wb = torch.cat([wb[:, :, :cin], w_s * cd - w_c * sd, w_s * sd + w_c * cd], dim=2)
+        a1 = self.bias_act1
+        h = native.bias_act(native.cat_gemm(hup, pe0, wb), a1.bias, a1.negative_slope, a1.scale)
+        nxt = 1
+        if not self.is_first:
+            a2 = self.bias_act2
+            with torch.no_grad():
+                ss = h.float().square().sum() if self.conv2.training else None
+            wb2 = self.conv2.sample_weights(ws[1], ss, h.numel())
+            h = native.bias_act(native.cat_gemm(h, None, wb2), a2.bias, a2.negative_slope, a2.scale)
+            nxt = 2
+        with torch.no_grad():
+            ssh = h.float().square().sum() if self.head.training else None
+        outs = []
+        for head in self.head.heads.values():
+            wbh = head.sample_weights(ws[nxt], ssh, h.numel())
+            outs.append(native.cat_gemm(h, None, wbh, out_dtype=torch.float32) + head.bias.reshape(1, 1, 1, -1))
+        o = torch.cat(outs, dim=3)
+        if skip is not None:
+            o = o + self.resample.forward_cl(skip)
+        return h, o
+
     def extra_repr(self):
         return f"use_fp16={self.use_fp16}"
 
@@ -309,9 +355,10 @@ class SynthesisNetwork(nn.Module):
                 or not isinstance(self.output_acts["raydrop_logit"], nn.Identity):
             raise NotImplementedError("the fused output stage implements heads (image: tanh, raydrop_logit: id)")
 
-    def synthesize(self, ws, angle, shifts="auto"):
+    def synthesize(self, ws, angle, shifts="auto", composable=False):
         """Trunk of the network: returns (skip fp32 [B,H,W,2] before the output stage, shift or None).
-        shifts: "auto" draws the training-time azimuth shift (dusty_v2.py:267-274); a tensor injects it."""
+        shifts: "auto" draws the training-time azimuth shift (dusty_v2.py:267-274); a tensor injects it.
+        composable: build the pass from twice-differentiable ops (SynthesisBlock.forward_composable)."""
         B, N, _ = ws.shape
         assert N == self.num_styles, f"{self.num_styles} != {N}"
         shift = None
@@ -351,6 +398,13 @@ class SynthesisNetwork(nn.Module):
                 s = None
                 pyramid.insert(0, (a, None))
         h, skip, i = None, None, 0
+        if composable:
+            if angle.shape[0] != 1 or diff:
+                raise RuntimeError("the twice-differentiable pass needs the batch-shared, constant angle grid")
+            for layer, (a, s) in zip(self.layers, pyramid):
+                h, skip = layer.forward_composable(h, skip, (ws[:, i], ws[:, i + 1], ws[:, min(i + 2, N - 1)]), a, s, B)
+                i += layer.num_conv
+            return skip, shift
         cached = self._batched_styles(ws) if (ws.is_cuda and angle.shape[0] == 1) else []
         if cached and _BATCHED_PREP:
             self._batched_weights(cached, shift)
@@ -452,6 +506,20 @@ class SynthesisNetwork(nn.Module):
 class Generator(base.Generator):
     """reference: dusty_v2.py:311-322 (+ base.Generator.forward, base.py:26-63)."""
 
+    def _output_stage_composable(self, skip, shift, u, w):
+        """Shift cancel, output scale, tanh, Gumbel ray-drop (dusty_v2.py:290-306, dusty_v1.py:20-25, gumbel.py:23-29)
+        in torch ops (twice differentiable), for the second_order pass."""
+        mm = self.measurement_model
+        v = skip.permute(0, 3, 1, 2)
+        if shift is not None:
+            v = _ring_shift(v, shift)
+        v = v * self.synthesis_network.output_scale
+        image_orig, logit = torch.tanh(v[:, :1]), v[:, 1:2]
+        soft = torch.sigmoid((logit + u.log() - (-u).log1p()) / mm.gumbel_sigmoid.temperature)
+        mask = ((soft > 0.5).to(soft.dtype) - soft).detach() + soft
+        image = image_orig + (1.0 - mask) * (mm.const_host - image_orig)
+        return {"image": image, "raydrop_logit": logit, "w": w, "raydrop_mask": mask, "image_orig": image_orig}
+
     def __init__(self, mapping_kwargs, synthesis_kwargs, measurement_kwargs):
         super().__init__(
             mapping_network=MappingNetwork(**mapping_kwargs),
@@ -463,10 +531,13 @@ class Generator(base.Generator):
         angle = self.angle if angle is None else angle
         return self.synthesis_network(w, angle)
 
-    def forward(self, z, angle=None, style_mixing=False, truncation_psi=1.0, input_w=False, noise=None):
+    def forward(self, z, angle=None, style_mixing=False, truncation_psi=1.0, input_w=False, noise=None,
+                second_order=False):
         """Fused path: synthesis trunk + ONE output-stage kernel (shift cancel, scale, tanh, Gumbel
         ray-drop).  `noise` optionally injects {"shifts": [B], "gumbel_u": [B,1,H,W]} (parity tests).
-        Falls back to the modular reference flow when forward hooks watch the GumbelSigmoid module."""
+        Falls back to the modular reference flow when forward hooks watch the GumbelSigmoid module.
+        second_order: the same map from ops whose gradients can be differentiated again (the path-length regulariser
+        differentiates d image / d w; reference: gans/trainer.py:308-365)."""
         mm = self.measurement_model
         if len(mm.gumbel_sigmoid._forward_hooks) > 0:
             return super().forward(z, angle, style_mixing, truncation_psi, input_w)
@@ -478,14 +549,30 @@ class Generator(base.Generator):
             w = self.truncation_trick(w, truncation_psi)
         angle = self.angle if angle is None else angle
         noise = noise or {}
-        skip, shift = self.synthesis_network.synthesize(w, angle, noise.get("shifts", "auto"))
+        skip, shift = self.synthesis_network.synthesize(w, angle, noise.get("shifts", "auto"), composable=second_order)
         B, H, W, _ = skip.shape
         u = noise.get("gumbel_u")
         u = native.gumbel_uniform((B, 1, H, W), skip.device) if u is None else u.float().contiguous()
+        if second_order:
+            return self._output_stage_composable(skip, shift, u, w)
         image, image_orig, logit, mask = native.gen_tail(
             skip, shift, u, self.synthesis_network.output_scale, mm.const_host,
             mm.gumbel_sigmoid.temperature)
         return {"image": image, "raydrop_logit": logit, "w": w, "raydrop_mask": mask, "image_orig": image_orig}
+
+
+def _ring_shift(v, shift_rad):
+    """out[..., j] = bilinear(v circular along W, j + s / (2 pi) * W): the closed form of the translation-only
+    affine_grid + grid_sample(bilinear, align_corners=False) on cat([v, v], 3)[..., :W] with which the reference cancels
+    the azimuth shift (dusty_v2.py:252-259,291-297); torch ops, differentiable to any order in v."""
+    B, C, H, W = v.shape
+    pos = torch.arange(W, dtype=torch.float32, device=v.device)[None, :] + (shift_rad / (2 * math.pi))[:, None] * W
+    j0 = pos.floor()
+    f = (pos - j0)[:, None, None, :]
+    j0 = j0.long()
+    i0 = (j0 % W)[:, None, None, :].expand(B, C, H, W)
+    i1 = ((j0 + 1) % W)[:, None, None, :].expand(B, C, H, W)
+    return v.gather(3, i0) * (1 - f) + v.gather(3, i1) * f
 
 
 class ResidualBlock(nn.Module):

@@ -16,3 +16,4 @@ from .fp8 import *  # noqa: F401,F403
 from .stem_tail_ada import *  # noqa: F401,F403
 from .modlayer import *  # noqa: F401,F403
 from .misc import *  # noqa: F401,F403
+from .second_order import *  # noqa: F401,F403

@@ -128,9 +128,17 @@ class Trainer:
         if cfg.training.loss.get("gp", 0) > 0.0:
             self.gp_weight = float(cfg.training.loss.gp) * self.lazy_gp
             ratio_D = self.lazy_gp / (self.lazy_gp + 1.0)
+        # path-length regulariser (reference: trainer.py:148-152,308-365; off in dusty_v2.yaml: loss.pl 0).  The reference
+        # block cannot run (it passes `angles=` to a forward that takes `angle` and reads a "styles" output that does not
+        # exist); what it sets out to do is built: see pl_fb.
+        self.pl_weight = 0.0
+        self.lazy_pl = int(cfg.training.lazy.get("pl", 4))
+        self.pl_ema = torch.zeros((), device=self.device)
         if cfg.training.loss.get("pl", 0) > 0.0:
-            raise NotImplementedError("path-length regularisation is disabled in dusty_v2.yaml (loss.pl: 0) and "
-                                      "its reference block is broken (SURVEY.md section 3B.4)")
+            if cfg.model.generator.arch != "dusty_v2":
+                raise NotImplementedError("path-length regularisation is built for the dusty_v2 generator")
+            self.pl_weight = float(cfg.training.loss.pl) * self.lazy_pl
+            ratio_G = self.lazy_pl / (self.lazy_pl + 1.0)
         lg, ld = cfg.training.lr.generator, cfg.training.lr.discriminator
         # hipGraph replay of the step bodies (training.hip_graph: true); Adam must then keep its step
         # counters on the device
@@ -153,6 +161,8 @@ class Trainer:
             self.D.load_state_dict(sd["D"])
             self.G_ema.load_state_dict(sd["G_ema"])
             self.A.load_state_dict(sd["A"])
+            if self.pl_weight > 0.0 and "pl_ema" in sd:
+                self.pl_ema.copy_(sd["pl_ema"].to(self.device).reshape(()))
             self.optim_G.load_state_dict(sd["optim_G"])
             self.optim_D.load_state_dict(sd["optim_D"])
             self.g_sync.rebind()
@@ -311,6 +321,39 @@ class Trainer:
         self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
         scalars["loss/D/gradient_penalty"] = r1.detach()
 
+    def pl_fb(self, j, scalars):
+        """Path-length regulariser (what the reference's block sets out to do, trainer.py:308-365): half a batch of
+        fakes, y ~ N(0, 1 / HW), J^T y = d(image . y) / dw for the styles w = mapping(z) [B/2, num_styles, D] (taken
+        with create_graph through the generator's twice-differentiable pass, Generator.forward(second_order=True)),
+        lengths |J^T y| per (sample, style), their running mean pl_ema (lerp 0.01), penalty mean((|J^T y| - pl_ema)^2)
+        weighted by loss.pl * lazy.pl; its backward is the double backward through the generator."""
+        set_requires_grad(self.G, True)
+        self.g_sync.begin()
+        B_pl = max(self.B // 2, 1)
+        z = self._z("pl")[:B_pl]
+        w = self.G.forward_mapping(z)
+        out = self.G(w, input_w=True, noise=self._g_noise_pl(B_pl), second_order=True, **self.auxin)
+        image = out["image"]
+        y = self._draw("pl.noise")
+        y = torch.randn_like(image) if y is None else y[:B_pl]
+        y = y / float(np.sqrt(np.prod(image.shape[2:])))
+        (grads,) = torch.autograd.grad(outputs=[(image * y).sum()], inputs=[w], create_graph=True)
+        lengths = grads.pow(2).sum(dim=-1).sqrt()
+        with torch.no_grad():
+            self.pl_ema.lerp_(lengths.mean().detach(), 0.01)
+        penalty = (lengths - self.pl_ema).pow(2).mean()
+        loss = self.pl_weight * penalty + 0.0 * image[0, 0, 0, 0]
+        loss.backward()
+        self.g_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
+        set_requires_grad(self.G, False)
+        scalars["loss/G/path_length/baseline"] = self.pl_ema.detach().clone()
+        scalars["loss/G/path_length"] = penalty.detach()
+
+    def _g_noise_pl(self, n):
+        if self._injected is None:
+            return None
+        return {"shifts": self._injected["pl.shifts"][:n], "gumbel_u": self._injected["pl.u"][:n]}
+
     def ema_decay(self, iteration):
         ema_imgs = int(self.cfg.training.ema_kimg * 1e3)
         if self.cfg.training.ema_rampup is not None:
@@ -417,6 +460,14 @@ class Trainer:
         # G), so this 17.5 MB reduction is synchronous
         self.g_sync.all_reduce()
         self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
+
+        if self.pl_weight > 0.0 and iteration % self.lazy_pl == 0:
+            for j in range(nacc):
+                if j == 0:
+                    parallel.sync_buffers(self.G)
+                log(self._run(self._acc_name("pl_fb", j), self.pl_fb, j))
+            self.g_sync.all_reduce()
+            self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
 
         for j in range(nacc):
             if j == 0:
@@ -540,5 +591,7 @@ class Trainer:
             "G": self.G.state_dict(), "D": self.D.state_dict(), "G_ema": self.G_ema.state_dict(),
             "A": self.A.state_dict(), "optim_G": optim_state(self.optim_G), "optim_D": optim_state(self.optim_D),
         }
+        if self.pl_weight > 0.0:
+            ckpt["pl_ema"] = self.pl_ema.detach().cpu()
         save_path.parent.mkdir(parents=True, exist_ok=True)
         torch.save(ckpt, save_path)

@@ -59,6 +59,29 @@ def g_step(sdG, sdD, z, angle, shifts, gumbel_u, ada=None, keep_mask=None):
                                                          "x_aug": x.detach()}
 
 
+def pl_step(sdG, z, angle, shifts, gumbel_u, noise, pl_ema, pl_weight, ema_lerp=0.01, training=True,
+            output="image"):
+    """Path-length regulariser as the reference's block sets out to compute it (gans/trainer.py:308-365; the block
+    itself cannot run: it passes `angles=` and reads a "styles" output that does not exist): w = mapping(z) expanded to
+    the styles, image = G(w), y = noise / sqrt(HW), g = d(image . y)/dw (create_graph), lengths = sqrt(sum_d g^2) per
+    (sample, style), pl_ema <- lerp(pl_ema, mean lengths, 0.01), penalty = mean((lengths - pl_ema)^2),
+    loss = pl_weight * penalty.  Returns (penalty, new pl_ema, grads over G parameters, lengths)."""
+    G = with_grad(sdG, G_BUFFER_SUFFIXES)
+    L = model.num_levels(G)
+    w = model.mapping_network(G, z)[:, None, :].expand(-1, 2 * L, -1)
+    out, _ = model.generator(G, w, angle, training=training, shifts=shifts, gumbel_u=gumbel_u, input_w=True)
+    image = out[output]
+    y = noise / math.sqrt(image.shape[2] * image.shape[3])
+    (g,) = torch.autograd.grad((image * y).sum(), w, create_graph=True)
+    lengths = g.pow(2).sum(dim=-1).sqrt()
+    new_ema = pl_ema + ema_lerp * (lengths.mean().detach() - pl_ema)
+    penalty = (lengths - new_ema).pow(2).mean()
+    loss = pl_weight * penalty
+    keys = [k for k, v in G.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [G[k] for k in keys], allow_unused=True)
+    return penalty.detach(), new_ema, dict(zip(keys, grads)), lengths.detach()
+
+
 def d_step(sdG, sdD, z, angle, shifts, gumbel_u, x_real, ada_real=None, ada_fake=None,
            keep_real=None, keep_fake=None):
     """Returns (loss, grads over D parameters, new G buffers, extras)."""
