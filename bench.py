@@ -153,10 +153,41 @@ def _pmc_traffic(kernel_key):
     return None if rec is None else rec.get("traffic_bytes_per_launch")
 
 
-def dominant_probe(args, reps=20):
+MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_*_f32, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def dominant_probe(args, reps=10):
     """`roofline`: the kernel INSTANCE with the largest share of GPU time in the committed graph kernel statistics
-    (profiles/round*_bench_graph_kernel_stats.csv): conv_pipe_kernel<bf16, TO = 32, four output classes> = the
-    stride-2 3x3 data gradient of the first ResidualBlock's conv2 in the D step (reference: the cuDNN dgrad of
+    (profiles/round3_bench_graph_kernel_stats.csv: conv_wgrad_stream_kernel<float, 1, 4, 4, true>, 5.74 %): the weight
+    gradient of the discriminator's fp32 epilogue conv (reference: autograd of ops.Conv2d(513, 512, 3, 1, 1, ring) at
+    gans/models/dusty_v2.py:377, run in fp32 as the reference does, :394-395) in the D step: x [2B, 4, 32, 528] (513
+    channels padded to whole K-chunks), gy [2B, 4, 32, 512] -> gw [512, 3, 3, 528], exact fp32 on v_mfma_f32_16x16x4_f32.
+    MFMA-bound: 308 FLOP per byte of its operands.  `achieved` counts the algorithmic 513 input channels."""
+    from gans.models.ops import native
+    if args.dtype == "fp32":
+        return None
+    B, H, W, C, Cp, O = 2 * args.batch_per_gpu, 4, 32, 513, 528, 512
+    g = native.ConvGeom(3, 3, 1, 1, True)
+    x = torch.randn(B, H, W, Cp, device="cuda")
+    x[..., C:] = 0
+    gy = torch.randn(B, H, W, O, device="cuda")
+    sec = _time_launches(lambda: native._conv_wgrad_raw(gy, x, g, 0.01), reps)
+    flops = 2.0 * B * H * W * 9 * C * O
+    nbytes = (B * H * W * (Cp + O) + O * 9 * Cp) * 4
+    ach = flops / sec / 1e12
+    return {"kernel": "conv_wgrad_stream_kernel<float, 1, 4, 4, true> + wgrad_reduce_kernel (dgv2_conv_wgrad_stream_pl: "
+                      "D epilogue conv weight gradient, 2B x 4x32, 513(528)->512, 3x3 ring, fp32)",
+            "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic("conv_wgrad_stream_kernel_f32"),
+            "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)", "algorithmic_bytes_per_launch": nbytes,
+            "avg_launch_us": sec * 1e6,
+            "selected_by": "largest Percentage among kernel instances in profiles/round3_bench_graph_kernel_stats.csv"}
+
+
+def s2dgrad_probe(args, reps=20):
+    """`roofline_conv_s2dgrad`: the second largest instance of the committed statistics and the largest of the bf16 conv
+    engine (conv_pipe_kernel<bf16, TO = 32, four output classes>, 5.3 %: every stride-2 data gradient of D) at its
+    heaviest site, the stride-2 3x3 data gradient of the first ResidualBlock's conv2 in the D step (reference: the cuDNN dgrad of
     ops.Conv2d(32, 64, 3, 2, 1, ring), gans/models/dusty_v2.py:331-333): gy [2B, 32, 256, 64] -> gx [2B, 64, 512, 32],
     the four parity classes of the transposed conv and the replicate-row border terms in ONE launch
     (dgv2_conv_taps_ex).  HBM-bound (22 FLOP per byte): algorithmic bytes = gy read once + gx written once."""
@@ -176,8 +207,7 @@ def dominant_probe(args, reps=20):
                       "2B x 32x256x64 -> 64x512x32, 3x3 stride 2 ring, one launch)",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
             "traffic": _pmc_traffic("conv_pipe_kernel_s2dgrad"), "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
-            "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12,
-            "selected_by": "largest Percentage among kernel instances in profiles/round3_bench_graph_kernel_stats.csv"}
+            "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12}
 
 
 def roofline_probe(args, reps=20):
@@ -412,6 +442,7 @@ def main():
     if cfg.training.hip_graph:
         assert graphs_live and all(graphs_live.values()), f"a step body is not replaying as a hipGraph: {graphs_live}"
     roof = dominant_probe(args) if rank == 0 else None
+    roof_s2 = s2dgrad_probe(args) if rank == 0 else None
     roof_strip = roofline_probe(args) if rank == 0 else None
     roof_mod = modconv_probe(args) if rank == 0 else None
     if not args.no_extra and world == 1 and args.dtype == "bf16" and args.res == "64x512":
@@ -447,6 +478,7 @@ def main():
             "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3 if args.res == "64x512" else None,
             "extra": extra,
             "roofline": roof,
+            "roofline_conv_s2dgrad": roof_s2,
             "roofline_strip": roof_strip,
             "roofline_modconv": roof_mod,
         }

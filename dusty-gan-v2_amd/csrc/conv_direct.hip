@@ -91,6 +91,14 @@ struct DConv {
   int dymin, dxmin, rows, cols;
   int hzero, ring, accumulate;
   int tpb;          // tiles per block along W (pipelined kernel)
+#ifdef DGV2_ABLATE   // benchmarking builds only (make ABLATE=1): wrong results by design, never in the shipped library
+  int ablate;       // DGV2_CP_ABLATE: 1 skip stores, 2 skip the MFMA loops, 4 skip input loads, 8 skip weight loads, 16 skip epilogue
+#define CP_ABL (p.ablate)
+#else
+#define CP_ABL 0
+#endif
+  int s2d;          // four classes = the canonical stride-2 3x3 data gradient (host-checked tap list): unrolled taps
+  int wres;         // tap-list kernels, 2 K-chunks: both chunks' weight slabs stay in LDS for the block's whole walk
   int nt;           // streaming output stores (outputs >= DGV2_NT_MIN_MB that no residual read revisits)
   // image pairs (4-row maps): the launch sees B/2 stacked pairs of `hper`-row images as 2*hper-row maps, so an 8-row
   // tile covers two images and the weight slab is staged once for both; rows clamp / zero-fill per image and each image
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   u32x4 rin[NI], rwt[NW];   // native vectors: as HIP's uint4 structs the unconditional F33 loads left both arrays in scratch
   auto issue_in = [&](int c0) {
+    if (CP_ABL & 4) return;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       if constexpr (F33 != 0) {
@@ -274,6 +283,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
     }
   };
   auto issue_w = [&](int c0) {
+    if (CP_ABL & 8) return;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       if constexpr (F33 != 0) {   // uniform pointer of tap j's weights + this thread's 32-bit offset (TO = 64: slot j IS tap j)
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
   // every prefetch in flight) and without holding MF*4 registers through the MFMA loop
   if (tid < TO) s_bias[tid] = (p.bias && o0 + tid < p.O) ? p.bias[o0 + tid] : 0.f;
   __syncthreads();
-  const uint4* const a_base = lds_w + lc * PW + lr;    // A fragment mf of tap t: a_base[t * TO + mf * 16]
+  const uint4* const a_base0 = lds_w + lc * PW + lr;   // A fragment mf of tap t: a_base[t * TO + mf * 16]
   const uint4* const b_base = lds_in + lc * PIN;       // B fragment nf of tap t: b_base[bpix[nf] + tapoff(t)]
 
   // Taps that read only the zero rows above / below the image for this wave's output row(s) (hzero: the data
@@ -331,16 +341,27 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
   for (int rr = 1; rr < RW; ++rr) dead_all &= dead[rr];
 
   // ---- pipeline over (tile, chunk) stages ----
+  // wres (host: tap-list form, exactly two K-chunks, LDS to spare): the weight slabs of BOTH chunks are staged once,
+  // side by side, and stay for every tile the block walks -- re-staging the slab per (tile, chunk) stage was 36 of
+  // the 62 KB a stage of the stride-2 data gradients moved through L2 -> LDS.
+  const bool wres = !F33 && p.wres;
+  if (wres) {
+    for (int c = 0; c < 2; ++c) {
+      issue_w(c * kchunk);
+#pragma unroll
+      for (int j = 0; j < NW; ++j) *reinterpret_cast<u32x4*>(st_w + c * 4 * PW + 64 * j) = rwt[j];
+    }
+  }
   tile_offsets(tw0);
   issue_in(0);
-  issue_w(0);
+  if (!wres) issue_w(0);
   int tile = 0, cc = 0;             // stage being computed
   const int nstage = ntile * nchunks;
   for (int s = 0; s < nstage; ++s) {
     __syncthreads();                // every wave has finished reading stage s-1
 #pragma unroll
     for (int j = 0; j < NI; ++j) *reinterpret_cast<u32x4*>(st_in + 64 * j) = rin[j];
-    if (s == 0 || nchunks > 1) {
+    if (!wres && (s == 0 || nchunks > 1)) {
 #pragma unroll
       for (int j = 0; j < NW; ++j) *reinterpret_cast<u32x4*>(st_w + 64 * j) = rwt[j];
     }
@@ -350,9 +371,10 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
     if (s + 1 < nstage) {
       if (ncc == 0) tile_offsets(tw0 + ntile_i);
       issue_in(ncc * kchunk);
-      if (nchunks > 1) issue_w(ncc * kchunk);
+      if (!wres && nchunks > 1) issue_w(ncc * kchunk);
     }
     __syncthreads();                // stage s visible in LDS
+    const uint4* const a_base = a_base0 + (wres ? cc * 4 * PW : 0);
 
     if constexpr (F33) {
       // The nine taps straight-line: immediate LDS offsets; a pixel fragment is re-read for tap t+1 as soon as its
@@ -392,7 +414,29 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    } else {
+    } else if (NC == 4 && p.s2d && !(CP_ABL & 2)) {
+      // The stride-2 3x3 data gradient, taps straight-line: class (ph, pw) of the output parities sees the gy pixels
+      // (dy, dx) in {0, 1}^2 with dy <= ph, dx <= pw -- 1 / 2 / 2 / 4 taps in the host's order below; every LDS offset
+      // is an immediate.
+      if constexpr (NC == 4) {
+        constexpr int COLS = DTW + 1;
+        constexpr int TDY[9] = {0, 0, 0, 1, 0, 1, 1, 0, 0}, TDX[9] = {0, 1, 0, 0, 0, 1, 0, 1, 0}, TCL[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          // no dead-tap branch: the rows below the image are staged as zeros in this (tap-list) form, so the three
+          // taps the last gy row cannot see multiply zeros -- straight-line builtin MFMAs, hazards left to the compiler
+          uint4 a[MF], bb[NF];
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) a[mf] = a_base[t * TO + mf * 16];
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) bb[nf] = b_base[bpix[nf] + TDY[t] * COLS + TDX[t]];
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) Mfma16<T>::run(acc[TCL[t]][mf][nf], a[mf], bb[nf]);
+        }
+      }
+    } else if (!(CP_ABL & 2)) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         for (int t = s_t0[c]; t < s_t0[c + 1]; ++t) {
@@ -440,22 +484,24 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
       }
     }
 
-    if (cc == nchunks - 1) {        // tile finished: epilogue, reset accumulators
+    if (cc == nchunks - 1 && !(CP_ABL & 16)) {        // tile finished: epilogue, reset accumulators
       if constexpr (F33) mfma_drain();
       const int w0 = (tw0 + tile) * DTW;
       // fast path (block-uniform): full channel tile, plain overwrite -- straight-line bias / lrelu / convert and,
       // for bf16, fragment pairs leaving as 16-byte stores; everything else takes the general store_frag
       const bool fast = !p.accumulate && o0 + TO <= p.O && (p.O & 7) == 0;
       const TY* rbase = reinterpret_cast<const TY*>(p.resid);   // optional residual, same layout as y
+      // pixel fragment outermost: its 64-bit row address is formed once, the classes add (ooh * Wy + oow) * ldy
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
+      for (int nf = 0; nf < NF; ++nf) {
+        const int gh = h0 + wave * RW + (nf >> 1);
+        const int gw = w0 + (nf & 1) * 16 + lr;
+        const bool live0 = gh < p.Hg && gw < p.Wg;
+        TY* const row0 = y + (((int64_t)b * p.Hy + gh * p.out_stride) * p.Wy + gw * p.out_stride) * p.ldy;
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-          const int gh = h0 + wave * RW + (nf >> 1);
-          const int gw = w0 + (nf & 1) * 16 + lr;
-          const bool live = gh < p.Hg && gw < p.Wg;
-          const int yh = gh * p.out_stride + p.cls_ooh[c], yw = gw * p.out_stride + p.cls_oow[c];
-          TY* row = y + (((int64_t)b * p.Hy + yh) * p.Wy + yw) * p.ldy;
+        for (int c = 0; c < NC; ++c) {
+          const bool live = live0 && !((CP_ABL & 1) && acc[c][0][nf][0] != 12345.678f);
+          TY* row = row0 + (p.cls_ooh[c] * p.Wy + p.cls_oow[c]) * p.ldy;
           if (fast) {
             float f[MF][4];
 #pragma unroll
@@ -658,7 +704,13 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   if (n_in > NI * 256 || n_w > NW * 256 || p.rows >= 32768 || p.cols >= 65536) return -2;
   if (F33 && (p.cols != (F33 == 3 ? 2 * (DTW - 1) + 3 : DTW + 2) || p.O % TO || (F33 != 2) != !p.hzero)) return -2;
   if ((F33 == 3) != (F33 && p.in_stride == 2)) return -2;
-  const size_t lds = sizeof(uint4) * 4 * 64 * (size_t)(NI + NW);   // four planes of NI*64 pixels and NW*64 weight rows
+  size_t lds = sizeof(uint4) * 4 * 64 * (size_t)(NI + NW);   // four planes of NI*64 pixels and NW*64 weight rows
+  static const bool no_wres = getenv("DGV2_NO_WRES") != nullptr;   // A/B switch for benchmarking
+  p.wres = 0;
+  if (!F33 && !no_wres && p.Cin == 8 * (int)(16 / sizeof(T)) && lds + sizeof(uint4) * 4 * 64 * (size_t)NW <= 64 * 1024) {
+    p.wres = 1;                      // two K-chunks, at least two blocks per CU
+    lds += sizeof(uint4) * 4 * 64 * (size_t)NW;
+  }
   if (lds > 80 * 1024) return -2;   // two blocks per CU
   auto kern = conv_pipe_kernel<T, TY, TO, RW, NI, NC, F33>;
   if (lds > 64 * 1024) {
@@ -668,9 +720,13 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   const int tiles_w = (p.Wg + DTW - 1) / DTW, tiles_h = (p.Hg + TH - 1) / TH, tiles_o = (p.O + TO - 1) / TO;
   // walk several tiles per block while the grid still holds >= ~4 blocks per CU slot
   const int64_t tiles = (int64_t)tiles_w * tiles_h * p.B * tiles_o;
-  int tpb = (int)(tiles / 2048);
+  // (four-class launches: two blocks per CU and a heavy per-block prologue -> 1024 blocks = two full rounds; measured at
+  // D block 0's stride-2 data gradient: 1 / 2 / 4 / 8 tiles per block = 171 / 151 / 134 / 129 us)
+  int tpb = (int)(tiles / (NC == 4 ? 1024 : 2048));
   tpb = tpb < 1 ? 1 : (tpb > tiles_w ? tiles_w : tpb);
   tpb = tpb > 8 ? 8 : tpb;
+  static const int tpb_env = getenv("DGV2_CONV_TPB") ? atoi(getenv("DGV2_CONV_TPB")) : 0;   // experiments
+  if (tpb_env > 0) tpb = tpb_env > tiles_w ? tiles_w : tpb_env;
   p.tpb = tpb;
   p.nt = (!p.resid && !p.accumulate && nt_output((int64_t)p.B * p.Hy * p.Wy * p.ldy * sizeof(TY))) ? 1 : 0;
   dim3 grid((tiles_w + tpb - 1) / tpb, tiles_h * p.B, tiles_o);
@@ -821,7 +877,10 @@ static int conv_taps_impl(void* y, int ldy, const void* x, const void* w, int B,
   p.rows = dymax - dymin + 1;   // tap extents; the launchers add the tile extent
   p.cols = dxmax - dxmin + 1;
   p.hzero = hzero; p.ring = ring; p.accumulate = accumulate;
-  p.tpb = 1; p.inv_cols = 0.f;
+  p.tpb = 1; p.inv_cols = 0.f; p.wres = 0; p.s2d = 0;
+#ifdef DGV2_ABLATE
+  p.ablate = getenv("DGV2_CP_ABLATE") ? atoi(getenv("DGV2_CP_ABLATE")) : 0;
+#endif
   p.bias = bias; p.resid = resid; p.ybase = y; p.act = act; p.alpha = alpha; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
@@ -864,6 +923,15 @@ static int conv_taps_impl(void* y, int ldy, const void* x, const void* w, int B,
     if (rc == -2) return DGV2_ENOTSUP;
     if (rc) return rc;
     DGV2_RETURN_LAST();
+  }
+  static const bool no_s2d = getenv("DGV2_NO_S2D") != nullptr;   // A/B switch for benchmarking
+  if (!no_s2d && ncls == 4 && ntaps == 9 && in_stride == 1 && out_stride == 2 && hzero && dymin == 0 && dxmin == 0 &&
+      p.rows == 2 && p.cols == 2) {
+    static const int dy9[9] = {0, 0, 0, 1, 0, 1, 1, 0, 0}, dx9[9] = {0, 1, 0, 0, 0, 1, 0, 1, 0}, cl9[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+    bool ok = true;
+    for (int t = 0; t < 9; ++t) ok = ok && p.dy[t] == dy9[t] && p.dx[t] == dx9[t] && taps_host[4 * t + 3] == cl9[t];
+    for (int c = 0; c < 4; ++c) ok = ok && p.cls_ooh[c] == (c >> 1) && p.cls_oow[c] == (c & 1);
+    p.s2d = ok ? 1 : 0;
   }
   DGV2_DISPATCH_DTYPE(dtype, {
     rc = -2;

@@ -13,6 +13,7 @@ import torch
 import bench
 
 args = argparse.Namespace(batch_per_gpu=64, dtype="bf16")
-print(bench.dominant_probe(args, reps=5))     # the only conv_pipe_kernel launches of this script
+print(bench.dominant_probe(args, reps=5))
+print(bench.s2dgrad_probe(args, reps=5))      # the only conv_pipe_kernel launches of this script
 print(bench.roofline_probe(args, reps=5))
 print(bench.modconv_probe(args, reps=5))

@@ -638,6 +638,9 @@ CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     # ... and its stride-2 forward form (the convs behind the blurs): 4-row tiles with a partial one, two chunks
     (2, 24, 80, 64, 128, 3, 2, 1, True),
     (3, 8, 64, 32, 64, 3, 2, 1, False),
+    # the stride-2 data gradient's unrolled four-class path with two K-chunks of gy (both weight slabs resident in LDS)
+    (2, 16, 72, 32, 64, 3, 2, 1, True),
+    (3, 8, 64, 64, 64, 3, 2, 1, True),
 ]
 
 
