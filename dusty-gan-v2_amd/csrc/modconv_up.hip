@@ -34,7 +34,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 struct MUGeom {
   int B, P, Wout, Hin, Win;   // output pixels P = Hout * Wout; T is [B, 32, Hin * Win]
-  int Ks;                     // w is the per-sample MFMA image [B][Ks/16][2][32 o][8 k] (dgv2_modconv_up_t)
+  int Ks;                     // w is the per-sample MFMA image [B][Ks/32][2 mt][4 kq][16 o][8 k] (dgv2_modconv_up_t)
   int samples_per_block;
   const int* idx_h;           // [Hout][2] low-res rows of the two taps, coef_h [Hout][2]
   const float* coef_h;
@@ -50,51 +50,55 @@ struct MUGeom {
 #endif
 };
 
-constexpr int UP16 = 4;       // K-steps of the up-sampling part: 2 low-res rows x 32 window columns
+constexpr int UP32 = 2;       // K-steps (of 32) of the up-sampling part: 2 low-res rows x 32 window columns
 
-template <int KS16, bool LRELU>   // Ks / 16; leaky ReLU or no activation
+// v_mfma_f32_16x16x32_bf16 form (round 3, late): M = 2 tiles of 16 output channels, N = 2 tiles of 16 pixels per wave,
+// K-steps of 32.  Same LDS traffic per FLOP as the 32x32x16 form (two A-fragment reads per 32 k), the same operand
+// registers, but the 16x16 shape holds a higher clock under load on this part (guide: +12...15 % FLOP/s at equal cycles)
+// and its C input may differ from its destination: the first MFMA of every chain takes the bias registers as C, so the
+// bias costs nothing (no K-step, no accumulator fill).  Fragment maps (cdna_hip_programming.md, section 3): A lane l =
+// row l % 16, k = 8 (l / 16) + j; B lane l = column l % 16, same k; C/D column l % 16, rows 4 (l / 16) + r.
+template <int KS32, bool LRELU>   // Ks / 32; leaky ReLU or no activation
 __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ tcm,
                                                             const bf16_t* __restrict__ xs, const bf16_t* __restrict__ w,
                                                             MUGeom g) {
   constexpr int O = 32;
-  constexpr int KT = KS16 + UP16;
-  constexpr int WBUF = KS16 * 64;                   // 16-byte slots of one sample's weights: [KS16][2][32 o]
-  constexpr int TBUF = UP16 * 64;                   // ... of one wave's T window: [UP16][2][32 o]
-  constexpr int NW = WBUF / 512;                    // weight DMA pieces per thread (KS16 % 8 == 0)
+  constexpr int KT = KS32 + UP32;                   // K-steps per sample
+  constexpr int WBUF = KS32 * 128;                  // 16-byte slots of one sample's weights: [KS32][2 mt][4 kq][16 o]
+  constexpr int TBUF = UP32 * 128;                  // ... of one wave's T window: [UP32][2 mt][4 kq][16 o]
+  constexpr int NW = WBUF / 512;                    // weight DMA pieces per thread
+  constexpr int NTP = TBUF / 64;                    // T-window pieces per wave (one per (row tap, M tile))
   constexpr int TOFF = 2 * WBUF;                    // T windows behind the two weight buffers: [2][8 waves][TBUF]
   extern __shared__ __attribute__((aligned(16))) uint4 lds_w[];
   const unsigned lds_off = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_w;   // LDS byte address
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it is wave-uniform
-  const int n = lane & 31, kg = lane >> 5;
+  const int n16 = lane & 15, kq = lane >> 4;
   const int p0 = blockIdx.x * 256 + wave * 32;      // P % 32 == 0: a wave is all live or all dead
   const int b0 = blockIdx.y * g.samples_per_block;
   const int b1 = min(b0 + g.samples_per_block, g.B);
   const bool live = p0 < g.P;
   const int pw = live ? p0 : 0;                     // a dead wave computes pixel tile 0 and stores nothing
-  const int px = pw + n;
   const int Y = pw / g.Wout, X0 = pw - Y * g.Wout;  // Wout % 32 == 0: the wave's pixels are one row segment
   const int winbase = floormod((X0 >> 1) - 8, g.Win);
 
   const int iy[2] = {g.idx_h[2 * Y], g.idx_h[2 * Y + 1]};
   const float wy[2] = {g.coef_h[2 * Y], g.coef_h[2 * Y + 1]};
-  int ix0 = g.idx_w[2 * (X0 + n)], ix1 = g.idx_w[2 * (X0 + n) + 1];
-  float wx0 = g.coef_w[2 * (X0 + n)], wx1 = g.coef_w[2 * (X0 + n) + 1];
-  float bias_n = g.bias ? g.bias[n] : 0.f;
-  // per-lane source offsets of the wave's T window: piece s, lane (kg, o = n): 8 low-res pixels of channel o
-  int toff[UP16];
+  // per-lane source offsets of the wave's T window: piece q = (row tap s, M tile mt), lane (kq, o16): the 8 low-res
+  // pixels of window unit kq, channel 16 mt + o16.  T is [B][Hin*Win/8][32 o][8 px]: four 256-byte runs per piece
+  int toff[NTP];
 #pragma unroll
-  for (int s = 0; s < UP16; ++s) {
-    int c = winbase + 8 * (2 * (s & 1) + kg);
+  for (int q = 0; q < NTP; ++q) {
+    int c = winbase + 8 * kq;
     c = c >= g.Win ? c - g.Win : c;
-    toff[s] = (((iy[s >> 1] * g.Win + c) >> 3) * O + n) * 8;   // T is [B][Hin*Win/8][32 o][8 px]: 1 KB per piece
+    toff[q] = (((iy[q >> 1] * g.Win + c) >> 3) * O + 16 * (q & 1) + n16) * 8;
   }
 
-  // LDS slot L = kc * 64 + half * 32 + o  <-  image slot L of sample b: every piece is one contiguous 1 KB (a piece
-  // gathered from 64 different lines costs the address path 8x the cycles; with eight such pieces per wave and
-  // sample the waves queued at ISSUE and the transfer did not overlap the MFMA loop).  Piece q of a sample:
-  // q < NW weights, then the wave's T window.
+  // LDS slot L = ((s * 2 + mt) * 4 + kq) * 16 + o16  <-  image slot L of sample b: every piece is one contiguous 1 KB
+  // (a piece gathered from 64 different lines costs the address path 8x the cycles; with eight such pieces per wave and
+  // sample the waves queued at ISSUE and the transfer did not overlap the MFMA loop).  Piece q of a sample: q < NW
+  // weights, then the wave's T window.
   auto dma_piece = [&](int q, int b, int buf) {
 #ifdef DGV2_ABLATE
     if ((g.ablate & 1) || (q >= NW && (g.ablate & 16))) return;
@@ -106,96 +110,91 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(tcm + (int64_t)b * O * g.Hin * g.Win + toff[q - NW]),
                                        (lds_void_t*)(lds_w + TOFF + (buf * 8 + wave) * TBUF + (q - NW) * 64), 16, 0, 0);
   };
-  constexpr int NQ = NW + UP16;
+  constexpr int NQ = NW + NTP;
 
-  // (Measured on one box and dropped: the first sample's DMA issued ahead of the PE loads, +4 %; PE loads hand-issued
-  // and awaited one by one in the first sample's K-steps, no gain.)
-  uint4 bf[KT];
-  // ---- B operands (column n = pixel, k = 8 * kg + i), registers for the whole walk: PE, then U ----
+  // ---- B operands (column = pixel 16 nt + n16, k = 8 kq + j), registers for the whole walk: PE, then U ----
+  uint4 bf[KT][2];
 #pragma unroll
-  for (int kc = 0; kc < KS16; ++kc)
-    bf[kc] = *reinterpret_cast<const uint4*>(xs + (int64_t)px * g.Ks + kc * 16 + kg * 8);
+  for (int nt = 0; nt < 2; ++nt) {
+    const bf16_t* pe = xs + (int64_t)(pw + 16 * nt + n16) * g.Ks + 8 * kq;
+#pragma unroll
+    for (int s = 0; s < KS32; ++s) bf[s][nt] = *reinterpret_cast<const uint4*>(pe + 32 * s);
+    const int X = X0 + 16 * nt + n16;
+    const int ix0 = g.idx_w[2 * X], ix1 = g.idx_w[2 * X + 1];
+    const float wx0 = g.coef_w[2 * X], wx1 = g.coef_w[2 * X + 1];
+#pragma unroll
+    for (int s = 0; s < UP32; ++s) {   // K index of element j: low-res row tap s, window column 8 kq + j
+      vec16<bf16_t> u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int c = winbase + 8 * kq + j;
+        c = c >= g.Win ? c - g.Win : c;
+        u.set(j, wy[s] * ((c == ix0 ? wx0 : 0.f) + (c == ix1 ? wx1 : 0.f)));
+      }
+      bf[KS32 + s][nt] = u.raw;
+    }
+  }
   if (b0 < b1) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) dma_piece(q, b0, 0);
   }
-  {
-#pragma unroll
-    for (int s = 0; s < UP16; ++s) {
-      // K index of element j: low-res row tap r = s / 2, window column 8 * (2 * (s % 2) + kg) + j
-      vec16<bf16_t> u;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int c = winbase + 8 * (2 * (s & 1) + kg) + j;
-        c = c >= g.Win ? c - g.Win : c;
-        const float wx = (c == ix0 ? wx0 : 0.f) + (c == ix1 ? wx1 : 0.f);
-        u.set(j, wy[s >> 1] * wx);
-      }
-      bf[KS16 + s] = u.raw;
-    }
-  }
-  // ---- bias as one more K-step: A[o][k = 0, 1] = (hi, lo) halves of bias * gain, B[k = 0, 1][p] = 1 (the factor
-  //      c * gain itself arrives inside T and the weight image, dgv2_modconv_up_t) ----
+  // ---- bias * gain as the C input of the first MFMA of each chain: this lane's rows 16 mt + 4 kq + r ----
   const float gain = LRELU ? g.scale * 0.5f * (1.f + g.alpha) : 1.f;   // see the epilogue
-  bf16x8 bias_a, ones_b;
+  f32x4 bias_c[2];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bias_a[e] = (bf16_t)0.f;
-    ones_b[e] = (bf16_t)(e < 2 ? 1.f : 0.f);
-  }
-  if (kg == 0) {
-    const float bv = bias_n * gain;
-    bias_a[0] = (bf16_t)bv;
-    bias_a[1] = (bf16_t)(bv - (float)bias_a[0]);
-  }
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias_c[mt][r] = g.bias ? g.bias[16 * mt + 4 * kq + r] * gain : 0.f;
 
   float ss = 0.f;
   const float lr_k = (1.f - g.alpha) / (1.f + g.alpha);
-  // The epilogue of sample b - 1 (exchange, leaky ReLU, statistic, bf16 pack, two 16-byte stores: ~6 vector
-  // instructions per output value) rides in the MFMA loop of sample b, a few instructions per K-step: an MFMA holds the
-  // vector issue for 8 of its 32 cycles, so the loop has room for 6 per step and the epilogue costs no time of its own.
+  // The epilogue of sample b - 1 rides in the MFMA loop of sample b, a few instructions per K-step: an MFMA holds the
+  // vector issue for a part of its cycles only, so the loop has room for them and the epilogue costs no time of its own.
   // Two accumulator sets alternate (the sample loop is unrolled by two), so nothing is copied between samples.
-  // part j = 0, 2: exchange accumulator groups j, j + 1 in place: this lane then owns channels [8 j + 8 kg, +8) in
-  // registers 4 j .. 4 j + 7; part 1, 3: activation, statistic, pack, store of those 8 channels.
-  auto epi_part = [&](f32x16& v, int part, int bprev) {
+  // part nt: the two M tiles of pixel tile nt (this lane: pixel 16 nt + n16, channels 4 kq + r and 16 + 4 kq + r):
+  // leaky ReLU as ONE fma -- with s = scale (1 + alpha) / 2 folded into T, the weights and the bias,
+  // act(f) scale = max(f, alpha f) scale = f' + k |f'|, f' = s f, k = (1 - alpha) / (1 + alpha) -- bf16 pack, statistic
+  // of the ROUNDED pairs (v_dot2c_f32_bf16), one v_permlane16_swap round (lanes kq and kq ^ 1 trade a packed quad:
+  // an even kq then owns channels [4 kq, 4 kq + 8), an odd one [16 + 4 (kq - 1), + 8)) and ONE 16-byte store.
+  // (Measured on one box: fmaxf() form 114 us, mul + fma 97, v_pk_mul + asm v_max 121 -- the asm operands cost copies.)
+  const int px = pw + n16;
+  const int co = (kq & 1) ? 16 + 4 * (kq - 1) : 4 * kq;
+  auto epi_part = [&](f32x4 (&v)[2][2], int nt, int bprev) {
 #ifdef DGV2_ABLATE
     if (g.ablate & 4) {
-      if (part == 0 && v[0] == 123.456f) y[0] = (bf16_t)v[3];   // keeps the accumulators alive
+      if (nt == 0 && v[0][0][0] == 123.456f) y[0] = (bf16_t)v[1][1][3];   // keeps the accumulators alive
       return;
     }
 #endif
-    const int j = part & ~1;
-    if (!(part & 1)) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    union { unsigned u[2]; bf16x2 p[2]; } qa, qb;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * j + r]), __float_as_uint(v[4 * (j + 1) + r]),
-                                                   false, false);
-        v[4 * j + r] = __uint_as_float(sw[0]);            // kg = 0: own group j      | kg = 1: partner's group j + 1
-        v[4 * (j + 1) + r] = __uint_as_float(sw[1]);      // kg = 0: partner's group j | kg = 1: own group j + 1
+    for (int h = 0; h < 2; ++h) {
+      float a0 = v[0][nt][2 * h], a1 = v[0][nt][2 * h + 1], c0 = v[1][nt][2 * h], c1 = v[1][nt][2 * h + 1];
+      if (LRELU) {
+        a0 = fmaf(fabsf(a0), lr_k, a0);
+        a1 = fmaf(fabsf(a1), lr_k, a1);
+        c0 = fmaf(fabsf(c0), lr_k, c0);
+        c1 = fmaf(fabsf(c1), lr_k, c1);
       }
-    } else {
-      // per PAIR of values: two v_fma_f32 (the leaky ReLU, see below), v_cvt_pk_bf16_f32, v_dot2c_f32_bf16 (statistic
-      // of the ROUNDED pair) = 2 instructions per value.  Leaky ReLU: with s = scale (1 + alpha) / 2 folded into T, the
-      // weights and the bias, act(f) scale = max(f, alpha f) scale = f' + k |f'|, f' = s f, k = (1 - alpha) / (1 + alpha):
-      // ONE fma with a free |.| modifier.  (Measured on one box: fmaxf() form 114 us, mul + fma 97, this 8x-leaner form
-      // issued as v_pk_mul + asm v_max: 121 -- the asm operands cost copies.)
-      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-      union { uint4 raw; bf16x2 p[4]; } o;
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        float f0 = v[4 * j + e], f1 = v[4 * j + e + 1];
-        if (LRELU) {
-          f0 = fmaf(fabsf(f0), lr_k, f0);
-          f1 = fmaf(fabsf(f1), lr_k, f1);
-        }
-        o.p[e >> 1] = bf16x2{(bf16_t)f0, (bf16_t)f1};
-        ss = __builtin_amdgcn_fdot2_f32_bf16(o.p[e >> 1], o.p[e >> 1], ss, false);
-      }
-      if (live) *reinterpret_cast<uint4*>(y + ((int64_t)bprev * g.P + px) * O + 8 * j + 8 * kg) = o.raw;
+      qa.p[h] = bf16x2{(bf16_t)a0, (bf16_t)a1};
+      qb.p[h] = bf16x2{(bf16_t)c0, (bf16_t)c1};
+      ss = __builtin_amdgcn_fdot2_f32_bf16(qa.p[h], qa.p[h], ss, false);
+      ss = __builtin_amdgcn_fdot2_f32_bf16(qb.p[h], qb.p[h], ss, false);
     }
+    // odd 16-lane rows of qa <-> even rows of qb
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      auto r = __builtin_amdgcn_permlane16_swap(qa.u[h], qb.u[h], false, false);
+      qa.u[h] = r[0];
+      qb.u[h] = r[1];
+    }
+    // even kq: qa = own block-A quad, qb = the block-A quad of kq + 1;  odd kq: qa = block-B quad of kq - 1, qb = own
+    if (live)
+      *reinterpret_cast<uint4*>(y + ((int64_t)bprev * g.P + px + 16 * nt) * O + co) = make_uint4(qa.u[0], qa.u[1], qb.u[0], qb.u[1]);
   };
 
-  auto step = [&](auto has_prev, f32x16& acc, f32x16& prev, int buf, int b) {
+  auto step = [&](auto has_prev, f32x4 (&acc)[2][2], f32x4 (&prev)[2][2], int buf, int b) {
     constexpr bool HP = decltype(has_prev)::value;
     // this sample's weights and T window were issued during the previous step, the last piece AFTER that step's two
     // stores: vector-memory operations retire in issue order, so a full drain waits for nothing but the DMA itself
@@ -207,64 +206,63 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
     asm volatile("" ::: "memory");
     const int bn = min(b + 1, b1 - 1);
 
-    // A fragments: row m = lane % 32 = output channel, k = 8 * (lane / 32) + i  <-  slot kc * 64 + kg * 32 + n.
+    // A fragments: row = lane % 16 (channel 16 mt + row), k = 8 (lane / 16) + j  <-  slot (s * 2 + mt) * 64 + lane.
     // The reads are issued as asm (ring of RD registers, PF reads in flight, explicit lgkmcnt): left to the compiler,
     // every ds_read that follows an LDS-DMA in program order is preceded by `s_waitcnt vmcnt(0)` (it cannot prove the
     // read does not alias the DMA's destination), which parks the whole MFMA loop behind the NEXT sample's transfer.
 #ifdef DGV2_ABLATE
     if (g.ablate & 2) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = bias_c[mt];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) dma_piece(q, bn, buf ^ 1);
       return;
     }
 #endif
     {
+      constexpr int NR = 2 * KT;          // A-fragment reads per sample: (K-step, M tile)
       constexpr int PF = 4, RD = 6;
-      const unsigned abase = lds_off + (unsigned)(buf * WBUF + kg * 32 + n) * 16u;
-      const unsigned tbase = lds_off + (unsigned)(TOFF + (buf * 8 + wave) * TBUF + kg * 32 + n) * 16u;
+      const unsigned abase = lds_off + (unsigned)(buf * WBUF + lane) * 16u;
+      const unsigned tbase = lds_off + (unsigned)(TOFF + (buf * 8 + wave) * TBUF + lane) * 16u;
       u32x4 a[RD];
-#define DGV2_DS_READ(dst, kc)                                                                                    \
+#define DGV2_DS_READ(dst, i)                                                                                     \
   do {                                                                                                           \
-    if ((kc) < KS16) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(abase), "n"(((kc) % KS16) * 1024)); \
-    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(tbase), "n"((((kc) >= KS16 ? (kc) - KS16 : 0)) * 1024)); \
+    if ((i) < 2 * KS32) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(abase), "n"(((i) % (2 * KS32)) * 1024)); \
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(tbase), "n"((((i) >= 2 * KS32 ? (i) - 2 * KS32 : 0)) * 1024)); \
   } while (0)
 #define DGV2_LGKM_WAIT(dst, cnt) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(dst) : "n"(cnt))
 #pragma unroll
-      for (int kc = 0; kc < PF; ++kc) DGV2_DS_READ(a[kc % RD], kc);
-      // the chain starts from the bias: no zero fill of the accumulators
-      {
-        f32x16 z;
+      for (int i = 0; i < PF; ++i) DGV2_DS_READ(a[i % RD], i);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) z[i] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bias_a, ones_b, z, 0, 0, 0);
-      }
-#pragma unroll
-      for (int kc = 0; kc < KT; ++kc) {
-        // reads return in order: all but the (issued - kc - 1) youngest are back
-        const int inflight = (kc + PF <= KT ? PF : KT - kc) - 1;
+      for (int i = 0; i < NR; ++i) {
+        const int s = i >> 1, mt = i & 1;
+        // reads return in order: all but the (issued - i - 1) youngest are back
+        const int inflight = (i + PF <= NR ? PF : NR - i) - 1;
         switch (inflight) {
-          case 3: DGV2_LGKM_WAIT(a[kc % RD], 3); break;
-          case 2: DGV2_LGKM_WAIT(a[kc % RD], 2); break;
-          case 1: DGV2_LGKM_WAIT(a[kc % RD], 1); break;
-          default: DGV2_LGKM_WAIT(a[kc % RD], 0); break;
+          case 3: DGV2_LGKM_WAIT(a[i % RD], 3); break;
+          case 2: DGV2_LGKM_WAIT(a[i % RD], 2); break;
+          case 1: DGV2_LGKM_WAIT(a[i % RD], 1); break;
+          default: DGV2_LGKM_WAIT(a[i % RD], 0); break;
         }
         union { u32x4 u; bf16x8 v; } ua;
-        union { uint4 u; bf16x8 v; } ub;
-        ua.u = a[kc % RD];
-        ub.u = bf[kc];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
-        if (kc + PF < KT) DGV2_DS_READ(a[(kc + PF) % RD], kc + PF);   // slot last read two MFMAs ago
-        // riders of this K-step: the previous sample's epilogue (steps 1..12, stores at 6 and 12), then the next
-        // sample's DMA pieces (steps 14, 16, ..: behind the stores in issue order)
-        if constexpr (HP) {
-          if (kc == 1) epi_part(prev, 0, b - 1);
-          if (kc == 4) epi_part(prev, 1, b - 1);
-          if (kc == 7) epi_part(prev, 2, b - 1);
-          if (kc == 10) epi_part(prev, 3, b - 1);
+        ua.u = a[i % RD];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          union { uint4 u; bf16x8 v; } ub;
+          ub.u = bf[s][nt];
+          // the chain starts from the bias (C input != destination): no zero fill, no bias K-step
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, s == 0 ? bias_c[mt] : acc[mt][nt], 0, 0, 0);
         }
-        if (kc >= 14 && ((kc - 14) & 1) == 0 && (kc - 14) / 2 < NQ) dma_piece((kc - 14) / 2, bn, buf ^ 1);
+        if (i + PF < NR) DGV2_DS_READ(a[(i + PF) % RD], i + PF);   // slot last read two groups ago
+        // riders of this read group: the previous sample's epilogue (groups 3 and 11), then the next sample's DMA
+        // pieces (groups 20, 22, ..: behind the stores in issue order)
+        if constexpr (HP) {
+          if (i == 3) epi_part(prev, 0, b - 1);
+          if (i == 11) epi_part(prev, 1, b - 1);
+        }
+        if (i >= 20 && ((i - 20) & 1) == 0 && (i - 20) / 2 < NQ) dma_piece((i - 20) / 2, bn, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
 #undef DGV2_DS_READ
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
   };
 
   if (b0 < b1) {
-    f32x16 accA, accB;
+    f32x4 accA[2][2], accB[2][2];
     step(std::false_type{}, accA, accB, 0, b0);
     int b = b0 + 1;
     for (; b + 1 < b1; b += 2) {
@@ -282,11 +280,11 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
     }
     if (b < b1) {
       step(std::true_type{}, accB, accA, (b - b0) & 1, b);
-#pragma unroll
-      for (int part = 0; part < 4; ++part) epi_part(accB, part, b1 - 1);
+      epi_part(accB, 0, b1 - 1);
+      epi_part(accB, 1, b1 - 1);
     } else {
-#pragma unroll
-      for (int part = 0; part < 4; ++part) epi_part(accA, part, b1 - 1);
+      epi_part(accA, 0, b1 - 1);
+      epi_part(accA, 1, b1 - 1);
     }
   }
   if (g.sumsq) {
@@ -311,12 +309,13 @@ __global__ __launch_bounds__(512) void modconv_up_t_kernel(bf16_t* __restrict__ 
   const int n = lane & 31, kg = lane >> 5;
   const int b = blockIdx.y;
   if (blockIdx.x == 0 && wimg) {
-    // image slot L = kc * 64 + half * 32 + o  <-  w[b][o][koff + kc * 16 + half * 8 .. + 8]
-    const int slots = (Ks >> 4) * 64;
+    // image slot L = ((s * 2 + mt) * 4 + kq) * 16 + o16  <-  w[b][16 mt + o16][koff + 32 s + 8 kq .. + 8]: the A fragments of
+    // v_mfma_f32_16x16x32_bf16, one contiguous 1 KB per (K-step, M tile)
+    const int slots = (Ks >> 5) * 128;
     for (int L = tid; L < slots; L += 512) {
-      const int o = L & 31, half = (L >> 5) & 1, kc = L >> 6;
+      const int o = ((L >> 6) & 1) * 16 + (L & 15), kq4 = (L >> 4) & 3, s32 = L >> 7;
       vec16<bf16_t> v;
-      v.raw = *reinterpret_cast<const uint4*>(w + ((int64_t)b * O + o) * I + koff + kc * 16 + half * 8);
+      v.raw = *reinterpret_cast<const uint4*>(w + ((int64_t)b * O + o) * I + koff + s32 * 32 + kq4 * 8);
       const float c = (row_scale ? row_scale[o] : 1.f) * gain;
       if (c != 1.f) {
 #pragma unroll
@@ -428,7 +427,7 @@ __global__ __launch_bounds__(256) void up2_lag_sumsq_kernel(const bf16_t* __rest
 //   layer's input-magnitude factor row_scale[o] times gain = scale (1 + alpha) / 2 for act 3, 1 for act 0 (this entry
 //   puts the same gain on the bias; the leaky ReLU is then one fma, see the kernel):
 //   t [B,Hin*Win/8,32,8] = row_scale * gain * W_a . h at the previous level's resolution in 8-pixel units and
-//   wimg [B,Ks/16,2,32,8] = the PE columns row_scale * gain * W_s of the prepared per-sample weights as the MFMA image,
+//   wimg [B,Ks/32,2,4,16,8] = the PE columns row_scale * gain * W_s of the prepared per-sample weights as the MFMA image,
 //   both from dgv2_modconv_up_t; up2 by the
 //   two-tap tables idx/coef [Hout][2], [Wout][2] (native.ResampleSpec.tables of the block's up-2 Resample, zero-padded to
 //   two taps); xs [Hout*Wout, Ks] batch-shared PE.
@@ -458,9 +457,9 @@ extern "C" int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const
   nsplit = (B + g.samples_per_block - 1) / g.samples_per_block;
   if (g.sumsq && sumsq_used && tiles * nsplit <= sumsq_cap) *sumsq_used = tiles * nsplit;
   else g.sumsq = nullptr;
-  constexpr int KS16 = 32;
-  const size_t lds = sizeof(uint4) * (2 * KS16 * 64 + 2 * 8 * UP16 * 64);
-  auto kern = act == 3 ? modconv_up_kernel<KS16, true> : modconv_up_kernel<KS16, false>;
+  constexpr int KS32 = 16;
+  const size_t lds = sizeof(uint4) * (2 * KS32 * 128 + 2 * 8 * UP32 * 128);
+  auto kern = act == 3 ? modconv_up_kernel<KS32, true> : modconv_up_kernel<KS32, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid(tiles, nsplit);
@@ -471,14 +470,14 @@ extern "C" int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const
 // The low-resolution part of the commuted level-input conv and the operand images of dgv2_modconv_up_fwd:
 //   tcm [B,Plow/8,32,8]:  T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units (unit u, channel o: pixels
 //                         8u..8u+7), f[o] = row_scale[o] (1 if NULL) * gain
-//   wimg [B,Ks/16,2,32,8] (or NULL): f[o] w[b][o][koff + 16 kc + 8 half + j] at [b][kc][half][o][j]
-// h [B,Plow,Ka], w [B,O,I] prepared per-sample weights (bf16); O = 32, Ka in {64, 128}, Plow % 32 == 0, Ks % 16 == 0.
+//   wimg [B,Ks/32,2,4,16,8] (or NULL): f[o] w[b][16 mt + o16][koff + 32 s + 8 kq + j] at [b][s][mt][kq][o16][j]
+// h [B,Plow,Ka], w [B,O,I] prepared per-sample weights (bf16); O = 32, Ka in {64, 128}, Plow % 32 == 0, Ks % 32 == 0.
 // replaces: the xa columns of the ModConv2d contraction, gans/models/ops/style.py:105-118.
 extern "C" int dgv2_modconv_up_t(void* tcm, void* wimg, const void* h, const void* w, const float* row_scale, float gain,
                                  int B, int Plow, int Ka, int Ks, int O, int I, int koff, int dtype, void* stream) {
   if (!tcm || !h || !w || B <= 0 || Plow <= 0) return DGV2_EINVAL;
   if (dtype != DGV2_BF16 || O != 32 || (Ka != 64 && Ka != 128) || (Plow & 31) || (I & 7) || I < Ka ||
-      (wimg && ((Ks & 15) || (koff & 7) || koff + Ks > I)))
+      (wimg && ((Ks & 31) || (koff & 7) || koff + Ks > I)))
     return DGV2_ENOTSUP;
   if (!aligned16(tcm) || !aligned16(h) || !aligned16(w) || (wimg && !aligned16(wimg))) return DGV2_EINVAL;
   dim3 grid((Plow + 255) / 256, B);

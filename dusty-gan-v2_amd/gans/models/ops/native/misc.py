@@ -201,7 +201,7 @@ class _ModUpPrepared(Function):
         act = 3 if cfg["act"] else 0
         bias32 = None if bias is None else bias.detach().float().contiguous()
         t = torch.empty((B, hl * wl // 8, Otot, 8), device=dev, dtype=dt)        # W_a . h in 8-pixel units
-        wimg = torch.empty((B, Ks // 16, 2, Otot, 8), device=dev, dtype=dt)     # W_s as the MFMA operand image
+        wimg = torch.empty((B, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)   # W_s as the MFMA operand image
         N.check(h, wb, cvec)
         # T and the image carry c[o] * gain, the kernel puts gain on the bias and runs the leaky ReLU as f' + k |f'|
         gain = cfg["scale"] * 0.5 * (1.0 + cfg["alpha"]) if cfg["act"] else 1.0

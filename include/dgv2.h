@@ -214,11 +214,11 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
  * previous level's resolution, dgv2_modconv_up_t below) and this entry evaluates
  *   y[b,p,:O] = act( row_scale * ( up2(W_a h)[b,p,:] + sum_{k<Ks} xs[p,k] w[b,:,koff+k] ) + bias )      (bf16)
  * with row_scale and gain = scale (1 + alpha) / 2 (act 3; 1 for act 0: the leaky ReLU is then the single fma
- * f' + |f'| (1 - alpha) / (1 + alpha)) already inside T and the weight image, the bias as one more K-step (exact to
- * 2^-17: hi + lo bf16 halves against a row of ones), and up2 as four more K-steps of the same MFMA chain (A = the wave's window of T, B = the constant interpolation
+ * f' + |f'| (1 - alpha) / (1 + alpha)) already inside T and the weight image, the bias (fp32, times gain) as the C input
+ * of each chain's first MFMA, and up2 as two more K-steps (of 32) of the same v_mfma_f32_16x16x32_bf16 chain (A = the wave's window of T, B = the constant interpolation
  * matrix of its 32 pixels, built in registers from the tables).
  * t [B,Hin*Win/8,O,8]: row_scale * gain * T in 8-pixel units (unit u, channel o: pixels 8u..8u+7) and
- * wimg [B,Ks/16,2,O,8]: row_scale * gain * the PE columns of the prepared per-sample weights as the MFMA operand image
+ * wimg [B,Ks/32,2,4,16,8]: row_scale * gain * the PE columns of the prepared per-sample weights as the MFMA operand image
  * -- both written by dgv2_modconv_up_t (the caller passes it that gain), so that
  * every LDS-DMA piece of the sample walk is one contiguous 1 KB; up2 given as two-tap tables idx/coef [Hout][2],
  * [Wout][2] (low-resolution index, weight: the sparse rows of Resample(up=2), gans/models/ops/common.py:105-135, with
@@ -235,8 +235,9 @@ int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const void* wimg
 /* The low-resolution xa part of the commuted level-input conv and the operand images of dgv2_modconv_up_fwd:
  *   tcm [B,Plow/8,O,8]: T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units, f[o] = row_scale[o] * gain
  *   (row_scale fp32 [O] or NULL = 1: the input-magnitude factor of ModConv2d, style.py:98-103);
- *   wimg [B,Ks/16,2,O,8] (or NULL): f[o] w[b][o][koff + 16 kc + 8 half + j] at [b][kc][half][o][j].
- * h [B,Plow,Ka], w [B,O,I] (bf16); O = 32, Ka in {64, 128}, Plow % 32 == 0, Ks % 16 == 0.
+ *   wimg [B,Ks/32,2,4,16,8] (or NULL): f[o] w[b][16 mt + o16][koff + 32 s + 8 kq + j] at [b][s][mt][kq][o16][j] (the A
+ *   fragments of v_mfma_f32_16x16x32_bf16: one contiguous 1 KB per (K-step, M tile)).
+ * h [B,Plow,Ka], w [B,O,I] (bf16); O = 32, Ka in {64, 128}, Plow % 32 == 0, Ks % 32 == 0.
  * replaces: the xa columns of the ModConv2d contraction, gans/models/ops/style.py:105-118. */
 int dgv2_modconv_up_t(void* tcm, void* wimg, const void* h, const void* w, const float* row_scale, float gain, int B,
                       int Plow, int Ka, int Ks, int O, int I, int koff, int dtype, void* stream);

@@ -24,7 +24,7 @@ t_rs = bench._time_launches(lambda: native._resample_raw(h, spec, False, (hl, wl
 t_pe = bench._time_launches(lambda: N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(hup), N.ptr(pe), N.ptr(wb), B, H * W, Ka, Ks, O, N.ptr(cvec), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
 y0 = y.clone()
 t = torch.empty(B, hl * wl // 8, O, 8, device="cuda", dtype=bf)
-wimg = torch.empty(B, Ks // 16, 2, O, 8, device="cuda", dtype=bf)
+wimg = torch.empty(B, Ks // 32, 2, 4, 16, 8, device="cuda", dtype=bf)
 
 
 def lowres():
