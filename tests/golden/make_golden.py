@@ -887,6 +887,32 @@ def golden_baselines():
     save("baselines.npz", out)
 
 
+def golden_full_b4():
+    """The discriminator of the full configuration at B = 4, so that MinibatchStdDev runs with its configured group of 4
+    at full width (model_full.npz is B = 2: group 2): weights by recipe (as golden_full), four synthetic reals by recipe
+    (synthetic_reals seed 23), logits, D-step gradient norms / leading slices of every parameter for the non-saturating
+    loss on y_real alone.  Reference: Discriminator.forward, gans/models/dusty_v2.py:387-396, MinibatchStdDev
+    gans/models/ops/common.py:226-250."""
+    cfg = _refshim.load_cfg()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    D = build_discriminator(cfg.model.discriminator)
+    recipe.fill_state_dict(D.state_dict(), 4321)
+    cb = CoordBridge(num_ring=64, num_points=512, min_depth=1.45, max_depth=80.0,
+                     angle_file=_refshim.REFERENCE_ROOT + "/data/coords/kitti_raw.npy")
+    x = synthetic_reals(cb, 4, 64, 512, 23)
+    D.requires_grad_(True)
+    y = D(x)
+    loss = F.softplus(-y).mean()
+    params = dict(D.named_parameters())
+    grads = torch.autograd.grad(loss, list(params.values()))
+    out = dict(x=x, y=y, loss=loss)
+    for k, g in zip(params, grads):
+        out[f"gradnorm.{k}"] = g.double().norm()
+        out[f"gradslice.{k}"] = g.flatten()[:32].clone()
+    save("model_full_b4.npz", out)
+
+
 def chamfer_inputs():
     """Seeded cloud pairs for chamfer.npz: scan-like random clouds of ragged sizes, a batch, a single point, and integer
     lattices (many exactly tied distances: the first minimum must win)."""
@@ -920,9 +946,11 @@ def golden_chamfer():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation", "metrics", "baselines", "chamfer"]
+    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation", "metrics", "baselines", "chamfer", "full_b4"]
     if "chamfer" in which:
         golden_chamfer()
+    if "full_b4" in which:
+        golden_full_b4()
     if "ops" in which:
         golden_ops()
     if "coords" in which:

@@ -161,6 +161,30 @@ def test_fp32_d_step_and_r1_match_reference(g_full, angle, truth):
     check_vs_fixture(got, d, "r1_", truth["grads_r1"], 2e-3, floor=2e-3 * 1e-4 * topn)
 
 
+def test_fp32_discriminator_at_batch_4_matches_reference():
+    """The HIP discriminator (fp32 parity mode) on tests/golden/model_full_b4.npz: full width, B = 4, so the minibatch
+    standard deviation runs with its configured group of 4 (dgv2_mbstd_cat_fwd/_bwd): logits, loss and every parameter
+    gradient (norm and leading slice) within 1e-3 of the reference's CPU run."""
+    from conftest import load_golden
+    from helpers import build_models, full_cfg
+    import recipe
+    d = load_golden("model_full_b4.npz")
+    _, D = build_models(full_cfg(), DEV)
+    D.load_state_dict(recipe.fill_state_dict({k: v.clone().cpu() for k, v in D.state_dict().items()}, 4321))
+    D.requires_grad_(True)
+    y = D(d["x"].to(DEV))
+    want = d["y"]
+    assert float((y.cpu() - want).abs().max()) <= 1e-3 * float(want.abs().max())
+    loss = torch.nn.functional.softplus(-y).mean()
+    assert abs(float(loss) - float(d["loss"])) <= 1e-4 * abs(float(d["loss"]))
+    params = dict(D.named_parameters())
+    grads = dict(zip(params, torch.autograd.grad(loss, list(params.values()))))
+    for k, g in grads.items():
+        wn, sl = float(d[f"gradnorm.{k}"]), d[f"gradslice.{k}"]
+        assert abs(float(g.double().norm()) - wn) <= 2e-3 * wn, (k, float(g.double().norm()), wn)
+        assert float((g.flatten()[:32].cpu() - sl).abs().max()) <= 2e-3 * float(sl.abs().max()) + 2e-3 * wn / max(1.0, g.numel() ** 0.5), k
+
+
 @pytest.mark.parametrize("low", [False, True])
 def test_eval_forwards_match_reference(g_full, angle, low):
     """BASELINE configs[0] (quick_demo.py: eval, B = 1, truncation_psi = 0.7) and the configs[1] shape (B = 32, which is
