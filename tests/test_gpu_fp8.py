@@ -7,8 +7,8 @@ Tolerance statement.  e4m3 keeps 3 mantissa bits: one rounding is a relative err
 contraction of K products whose two operands were rounded independently has an error of about sqrt(2) x 1.8 % of the
 rms of its terms' sum whatever K is (the errors are relative and independent): 2.5-3 % of a conv output's rms, plus
 the weights' scale granularity.  The residual stream stays bf16 and each block adds two such branches, so trunk
-features of an n-block discriminator are asserted to rel-L2 <= 3 % x sqrt(2 n) against the bf16 run, logits to 5 % of
-their spread, parameter gradients to cosine >= 0.98 per tensor (0.995 over all)."""
+features of an n-block discriminator are asserted to rel-L2 <= 3 % x sqrt(2 n) against the bf16 run, logits to 0.05
+absolute, parameter gradients to cosine >= 0.98 per tensor (0.995 over all)."""
 import math
 
 import numpy as np
@@ -133,7 +133,7 @@ def test_e4m3_branches_track_the_bf16_and_fp32_discriminator(nat):
     operands.  Features, logits and every parameter gradient of the e4m3 run against the bf16 run within the bounds
     of the tolerance statement above; the bf16 run against fp32 as the yardstick of what reduced precision costs at all."""
     B, res = 8, (32, 128)
-    x = torch.randn(B, 1, *res, device=DEV)
+    x = torch.randn(B, 1, *res, generator=torch.Generator().manual_seed(5)).to(DEV)
     D32, D16, D8 = _disc(False, False, res), _disc(False, True, res), _disc(True, True, res)
     D16.load_state_dict(D32.state_dict())
     D8.load_state_dict(D32.state_dict())
@@ -153,8 +153,8 @@ def test_e4m3_branches_track_the_bf16_and_fp32_discriminator(nat):
     e8 = rel(feats["e4m3"], feats["bf16"])
     assert base < 2e-2, base
     assert 1e-3 < e8 < 0.03 * math.sqrt(2 * nblocks), (e8, base)     # really lower precision, and within the bound
-    spread = float(logits["bf16"].std()) + 1e-6
-    assert float((logits["e4m3"] - logits["bf16"]).abs().max()) < 0.05 * spread + 0.02, (logits["e4m3"], logits["bf16"])
+    # logits of a freshly initialised discriminator are a near-cancelling sum (|y| ~ 0.2): an absolute bound
+    assert float((logits["e4m3"] - logits["bf16"]).abs().max()) < 0.05, (logits["e4m3"], logits["bf16"])
     cos_all_n = sum(float((a * b).sum()) for a, b in zip(grads["e4m3"], grads["bf16"]))
     cos_all_d = math.sqrt(sum(float(a.square().sum()) for a in grads["e4m3"]) * sum(float(b.square().sum()) for b in grads["bf16"]))
     assert cos_all_n / cos_all_d > 0.995
