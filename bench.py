@@ -262,11 +262,11 @@ def modconv_probe(args, reps=20):
     bias = torch.randn(O, device="cuda")
     cvec = torch.ones(O, device="cuda")
     y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
-    t = torch.empty(B, hl * wl // 8, O, 8, device="cuda", dtype=bf)
+    t = torch.empty(B, hl, 2, wl // 8, 16, 8, device="cuda", dtype=bf)
     wimg = torch.empty(B, Ks // 32, 2, 4, 16, 8, device="cuda", dtype=bf)
 
     def lowres():
-        N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), 2.0 ** 0.5 * 0.6, B, hl * wl, Ka, Ks, O, Ka + Ks, Ka, N.BF16, N.stream())
+        N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), 2.0 ** 0.5 * 0.6, B, hl, wl, Ka, Ks, O, Ka + Ks, Ka, N.BF16, N.stream())
     lowres()
     ih, ch, iw, cw = native._up_tables(spec, hl, wl, h.device)
     sec = _time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(xs), N.ptr(wimg), B, H, W, hl, wl, Ks,

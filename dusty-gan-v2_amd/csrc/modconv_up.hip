@@ -86,13 +86,15 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
   const int iy[2] = {g.idx_h[2 * Y], g.idx_h[2 * Y + 1]};
   const float wy[2] = {g.coef_h[2 * Y], g.coef_h[2 * Y + 1]};
   // per-lane source offsets of the wave's T window: piece q = (row tap s, M tile mt), lane (kq, o16): the 8 low-res
-  // pixels of window unit kq, channel 16 mt + o16.  T is [B][Hin*Win/8][32 o][8 px]: four 256-byte runs per piece
+  // pixels of window unit kq, channel 16 mt + o16.  T is [B][Hin][2 mt][Win/8][16 o][8 px]: the four units of a piece
+  // are ONE contiguous 1 KB (two runs where the window wraps around the ring) -- as four 256-byte runs of a
+  // [pixel unit][32 o] layout the T pieces cost 13 of 90 us, the equally large contiguous weight pieces nothing
   int toff[NTP];
 #pragma unroll
   for (int q = 0; q < NTP; ++q) {
     int c = winbase + 8 * kq;
     c = c >= g.Win ? c - g.Win : c;
-    toff[q] = (((iy[q >> 1] * g.Win + c) >> 3) * O + 16 * (q & 1) + n16) * 8;
+    toff[q] = (((iy[q >> 1] * 2 + (q & 1)) * (g.Win >> 3) + (c >> 3)) * 16 + n16) * 8;
   }
 
   // LDS slot L = ((s * 2 + mt) * 4 + kq) * 16 + o16  <-  image slot L of sample b: every piece is one contiguous 1 KB
@@ -256,13 +258,14 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, s == 0 ? bias_c[mt] : acc[mt][nt], 0, 0, 0);
         }
         if (i + PF < NR) DGV2_DS_READ(a[(i + PF) % RD], i + PF);   // slot last read two groups ago
-        // riders of this read group: the previous sample's epilogue (groups 3 and 11), then the next sample's DMA
-        // pieces (groups 20, 22, ..: behind the stores in issue order)
+        // riders of this read group: the next sample's DMA pieces from the very first groups on (issued at groups
+        // 20..34 the last ones had not landed at the next barrier: the T pieces alone cost 13 of 90 us), the previous
+        // sample's epilogue in between
+        if ((i & 1) == 0 && i / 2 < NQ) dma_piece(i / 2, bn, buf ^ 1);
         if constexpr (HP) {
-          if (i == 3) epi_part(prev, 0, b - 1);
-          if (i == 11) epi_part(prev, 1, b - 1);
+          if (i == 17) epi_part(prev, 0, b - 1);
+          if (i == 25) epi_part(prev, 1, b - 1);
         }
-        if (i >= 20 && ((i - 20) & 1) == 0 && (i - 20) / 2 < NQ) dma_piece((i - 20) / 2, bn, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
 #undef DGV2_DS_READ
@@ -303,7 +306,7 @@ template <int KA16>   // Ka / 16
 __global__ __launch_bounds__(512) void modconv_up_t_kernel(bf16_t* __restrict__ tcm, bf16_t* __restrict__ wimg,
                                                            const bf16_t* __restrict__ h, const bf16_t* __restrict__ w,
                                                            const float* __restrict__ row_scale, float gain, int Plow,
-                                                           int I, int koff, int Ks) {
+                                                           int Wlow, int I, int koff, int Ks) {
   constexpr int O = 32, Ka = KA16 * 16;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = lane & 31, kg = lane >> 5;
@@ -344,8 +347,10 @@ __global__ __launch_bounds__(512) void modconv_up_t_kernel(bf16_t* __restrict__ 
     ub.u = fb[s];
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
   }
-  // lane (o = n, kg) holds pixels 8j + 4kg .. +3 (j = 0..3) -> two runs of 8 consecutive pixels (= two units)
-  bf16_t* dst = tcm + (((int64_t)b * Plow + p0) >> 3) * (O * 8) + n * 8;
+  // lane (o = n, kg) holds pixels 8j + 4kg .. +3 (j = 0..3) -> two runs of 8 consecutive pixels (= two units);
+  // layout [B][Hlow][2 mt][Wlow/8][16 o][8 px] (Wlow % 32 == 0: the wave's 32 pixels lie in one row)
+  const int trow = p0 / Wlow, tcol = p0 - trow * Wlow;
+  bf16_t* dst = tcm + (int64_t)b * Plow * O + ((((int64_t)trow * 2 + (n >> 4)) * (Wlow >> 3) + (tcol >> 3)) * 16 + (n & 15)) * 8;
   const float c = (row_scale ? row_scale[n] : 1.f) * gain;
 #pragma unroll
   for (int j = 0; j < 4; j += 2) {
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(512) void modconv_up_t_kernel(bf16_t* __restrict__ 
       o.set(r, __uint_as_float(s[0]) * c);
       o.set(4 + r, __uint_as_float(s[1]) * c);
     }
-    *reinterpret_cast<uint4*>(dst + (j + kg) * (O * 8)) = o.raw;
+    *reinterpret_cast<uint4*>(dst + (j + kg) * (16 * 8)) = o.raw;
   }
 }
 
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(256) void up2_lag_sumsq_kernel(const bf16_t* __rest
 // y[b,p,:32] = act( up2(T)[b,p,:] + sum_{k<Ks} xs[p,k] W_s[b,:,k] + bias )   (bf16 in / out), T and W_s carrying the
 //   layer's input-magnitude factor row_scale[o] times gain = scale (1 + alpha) / 2 for act 3, 1 for act 0 (this entry
 //   puts the same gain on the bias; the leaky ReLU is then one fma, see the kernel):
-//   t [B,Hin*Win/8,32,8] = row_scale * gain * W_a . h at the previous level's resolution in 8-pixel units and
+//   t [B,Hin,2,Win/8,16,8] = row_scale * gain * W_a . h at the previous level's resolution in 8-pixel units and
 //   wimg [B,Ks/32,2,4,16,8] = the PE columns row_scale * gain * W_s of the prepared per-sample weights as the MFMA image,
 //   both from dgv2_modconv_up_t; up2 by the
 //   two-tap tables idx/coef [Hout][2], [Wout][2] (native.ResampleSpec.tables of the block's up-2 Resample, zero-padded to
@@ -468,25 +473,28 @@ extern "C" int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const
 }
 
 // The low-resolution part of the commuted level-input conv and the operand images of dgv2_modconv_up_fwd:
-//   tcm [B,Plow/8,32,8]:  T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units (unit u, channel o: pixels
-//                         8u..8u+7), f[o] = row_scale[o] (1 if NULL) * gain
+//   tcm [B,Hlow,2,Wlow/8,16,8]:  T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units, per low-res row the
+//                         units of channels 0..15 then those of channels 16..31 (the four units a T piece of
+//                         dgv2_modconv_up_fwd reads are then one contiguous 1 KB), f[o] = row_scale[o] (1 if NULL) * gain
 //   wimg [B,Ks/32,2,4,16,8] (or NULL): f[o] w[b][16 mt + o16][koff + 32 s + 8 kq + j] at [b][s][mt][kq][o16][j]
-// h [B,Plow,Ka], w [B,O,I] prepared per-sample weights (bf16); O = 32, Ka in {64, 128}, Plow % 32 == 0, Ks % 32 == 0.
+// h [B,Hlow*Wlow,Ka], w [B,O,I] prepared per-sample weights (bf16); O = 32, Ka in {64, 128}, Wlow % 32 == 0, Ks % 32 == 0.
 // replaces: the xa columns of the ModConv2d contraction, gans/models/ops/style.py:105-118.
 extern "C" int dgv2_modconv_up_t(void* tcm, void* wimg, const void* h, const void* w, const float* row_scale, float gain,
-                                 int B, int Plow, int Ka, int Ks, int O, int I, int koff, int dtype, void* stream) {
-  if (!tcm || !h || !w || B <= 0 || Plow <= 0) return DGV2_EINVAL;
-  if (dtype != DGV2_BF16 || O != 32 || (Ka != 64 && Ka != 128) || (Plow & 31) || (I & 7) || I < Ka ||
+                                 int B, int Hlow, int Wlow, int Ka, int Ks, int O, int I, int koff, int dtype,
+                                 void* stream) {
+  const int Plow = Hlow * Wlow;
+  if (!tcm || !h || !w || B <= 0 || Hlow <= 0 || Wlow <= 0) return DGV2_EINVAL;
+  if (dtype != DGV2_BF16 || O != 32 || (Ka != 64 && Ka != 128) || (Wlow & 31) || (I & 7) || I < Ka ||
       (wimg && ((Ks & 31) || (koff & 7) || koff + Ks > I)))
     return DGV2_ENOTSUP;
   if (!aligned16(tcm) || !aligned16(h) || !aligned16(w) || (wimg && !aligned16(wimg))) return DGV2_EINVAL;
   dim3 grid((Plow + 255) / 256, B);
   if (Ka == 64)
     modconv_up_t_kernel<4><<<grid, 512, 0, (hipStream_t)stream>>>((bf16_t*)tcm, (bf16_t*)wimg, (const bf16_t*)h,
-                                                                 (const bf16_t*)w, row_scale, gain, Plow, I, koff, Ks);
+                                                                 (const bf16_t*)w, row_scale, gain, Plow, Wlow, I, koff, Ks);
   else
     modconv_up_t_kernel<8><<<grid, 512, 0, (hipStream_t)stream>>>((bf16_t*)tcm, (bf16_t*)wimg, (const bf16_t*)h,
-                                                                 (const bf16_t*)w, row_scale, gain, Plow, I, koff, Ks);
+                                                                 (const bf16_t*)w, row_scale, gain, Plow, Wlow, I, koff, Ks);
   DGV2_RETURN_LAST();
 }
 

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGV2_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -70,7 +70,7 @@ SIGNATURES = {
     "dgv2_fp8_quant_weights": [_c_ptr] * 6 + [_c_int] + [_c_ptr] * 3,
     "dgv2_fp8_dequant": [_c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr],
     "dgv2_conv_taps_fp8": [_c_ptr] * 4 + [_c_int] * 14 + [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_ptr],
-    "dgv2_modconv_up_t": [_c_ptr] * 5 + [_c_f32] + [_c_int] * 8 + [_c_ptr],
+    "dgv2_modconv_up_t": [_c_ptr] * 5 + [_c_f32] + [_c_int] * 9 + [_c_ptr],
     "dgv2_up2_lag_sumsq": [_c_ptr] * 5 + [_c_int] * 5 + [_c_ptr, _c_int, _c_ptr, _c_ptr],
     "dgv2_resample_tab_actbwd": [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr] + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3
                                 + [_c_int] * 7 + [_c_f32, _c_f32, _c_int, _c_ptr],

@@ -164,7 +164,7 @@ def mod_up_ok(h, xs, wb, spec):
     return bool(_UP_COMMUTE and h is not None and xs is not None and h.is_cuda and h.dtype == torch.bfloat16
                 and wb.shape[1] == 32 and xs.shape[3] == 512 and h.shape[3] % 8 == 0
                 and tuple(a[1] for a in spec.axes) == (2, 2) and tuple(a[2] for a in spec.axes) == (1, 1)
-                and h.shape[3] in (64, 128) and (h.shape[1] * h.shape[2]) % 32 == 0
+                and h.shape[3] in (64, 128) and h.shape[2] % 32 == 0
                 and spec.out_size(h.shape[1], h.shape[2]) == tuple(xs.shape[1:3])
                 and _up_tables(spec, h.shape[1], h.shape[2], h.device) is not None)
 
@@ -200,12 +200,12 @@ class _ModUpPrepared(Function):
         dev = h.device
         act = 3 if cfg["act"] else 0
         bias32 = None if bias is None else bias.detach().float().contiguous()
-        t = torch.empty((B, hl * wl // 8, Otot, 8), device=dev, dtype=dt)        # W_a . h in 8-pixel units
+        t = torch.empty((B, hl, 2, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
         wimg = torch.empty((B, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)   # W_s as the MFMA operand image
         N.check(h, wb, cvec)
         # T and the image carry c[o] * gain, the kernel puts gain on the bias and runs the leaky ReLU as f' + k |f'|
         gain = cfg["scale"] * 0.5 * (1.0 + cfg["alpha"]) if cfg["act"] else 1.0
-        N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(wb), N.ptr(cvec), gain, B, hl * wl, Ka, Ks,
+        N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(wb), N.ptr(cvec), gain, B, hl, wl, Ka, Ks,
                Otot, I, Ka, _dt(h), N.stream())
         ih, ch, iw, cw = _up_tables(spec, hl, wl, dev)
         sq = _sq_args(dev) if (cfg["want_sq"] and _FUSED_SQ) else None

@@ -217,7 +217,7 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
  * f' + |f'| (1 - alpha) / (1 + alpha)) already inside T and the weight image, the bias (fp32, times gain) as the C input
  * of each chain's first MFMA, and up2 as two more K-steps (of 32) of the same v_mfma_f32_16x16x32_bf16 chain (A = the wave's window of T, B = the constant interpolation
  * matrix of its 32 pixels, built in registers from the tables).
- * t [B,Hin*Win/8,O,8]: row_scale * gain * T in 8-pixel units (unit u, channel o: pixels 8u..8u+7) and
+ * t [B,Hin,2,Win/8,16,8]: row_scale * gain * T in 8-pixel units (row, channel half, unit u, channel: pixels 8u..8u+7) and
  * wimg [B,Ks/32,2,4,16,8]: row_scale * gain * the PE columns of the prepared per-sample weights as the MFMA operand image
  * -- both written by dgv2_modconv_up_t (the caller passes it that gain), so that
  * every LDS-DMA piece of the sample walk is one contiguous 1 KB; up2 given as two-tap tables idx/coef [Hout][2],
@@ -233,14 +233,15 @@ int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const void* wimg
                         const float* coef_w, const float* bias, int act, float alpha, float scale, int dtype,
                         float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 /* The low-resolution xa part of the commuted level-input conv and the operand images of dgv2_modconv_up_fwd:
- *   tcm [B,Plow/8,O,8]: T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units, f[o] = row_scale[o] * gain
+ *   tcm [B,Hlow,2,Wlow/8,16,8]: T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units (per row: the units
+ *   of channels 0..15, then those of channels 16..31), f[o] = row_scale[o] * gain
  *   (row_scale fp32 [O] or NULL = 1: the input-magnitude factor of ModConv2d, style.py:98-103);
  *   wimg [B,Ks/32,2,4,16,8] (or NULL): f[o] w[b][16 mt + o16][koff + 32 s + 8 kq + j] at [b][s][mt][kq][o16][j] (the A
  *   fragments of v_mfma_f32_16x16x32_bf16: one contiguous 1 KB per (K-step, M tile)).
- * h [B,Plow,Ka], w [B,O,I] (bf16); O = 32, Ka in {64, 128}, Plow % 32 == 0, Ks % 32 == 0.
+ * h [B,Hlow*Wlow,Ka], w [B,O,I] (bf16); O = 32, Ka in {64, 128}, Wlow % 32 == 0, Ks % 32 == 0.
  * replaces: the xa columns of the ModConv2d contraction, gans/models/ops/style.py:105-118. */
 int dgv2_modconv_up_t(void* tcm, void* wimg, const void* h, const void* w, const float* row_scale, float gain, int B,
-                      int Plow, int Ka, int Ks, int O, int I, int koff, int dtype, void* stream);
+                      int Hlow, int Wlow, int Ka, int Ks, int O, int I, int koff, int dtype, void* stream);
 /* Per-block partial sums of sum_{b,p,c} up2(h)[b,p,c]^2 taken from h at its own (low) resolution: with U = Uh (x) Uw
  * the up-2 operator, sum (U h)^2 = h^T (Gh (x) Gw) h with tridiagonal Gram matrices Gh = Uh^T Uh, Gw = Uw^T Uw (ring axis:
  * circulant).  ghd / gho [Hin]: diagonal and (i, i+1) entries of Gh (gho[Hin-1] = 0); gwd / gwo [Win]: diagonal and

@@ -23,12 +23,12 @@ y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
 t_rs = bench._time_launches(lambda: native._resample_raw(h, spec, False, (hl, wl), sq=native._sq_args(h.device)), 20)
 t_pe = bench._time_launches(lambda: N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(hup), N.ptr(pe), N.ptr(wb), B, H * W, Ka, Ks, O, N.ptr(cvec), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
 y0 = y.clone()
-t = torch.empty(B, hl * wl // 8, O, 8, device="cuda", dtype=bf)
+t = torch.empty(B, hl, 2, wl // 8, 16, 8, device="cuda", dtype=bf)
 wimg = torch.empty(B, Ks // 32, 2, 4, 16, 8, device="cuda", dtype=bf)
 
 
 def lowres():
-    N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(wb), N.ptr(cvec), 2.0 ** 0.5 * 0.6, B, hl * wl, Ka, Ks, O, Ka + Ks, Ka, N.BF16, N.stream())
+    N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(wb), N.ptr(cvec), 2.0 ** 0.5 * 0.6, B, hl, wl, Ka, Ks, O, Ka + Ks, Ka, N.BF16, N.stream())
 
 
 lowres()

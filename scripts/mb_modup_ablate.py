@@ -16,7 +16,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     wb = torch.randn(B, O, Ka + Ks, device="cuda", dtype=bf) / 16
     bias = torch.randn(O, device="cuda"); cvec = torch.ones(O, device="cuda")
     y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
-    t = torch.randn(B, hl * wl // 8, O, 8, device="cuda", dtype=bf)
+    t = torch.randn(B, hl, 2, wl // 8, 16, 8, device="cuda", dtype=bf)
     wimg = torch.randn(B, Ks // 32, 2, 4, 16, 8, device="cuda", dtype=bf) / 16
     ih, ch, iw, cw = native._up_tables(spec, hl, wl, pe.device)
     sec = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pe), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 30)

@@ -1053,13 +1053,13 @@ def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
         h, w, pe = h.to(DEV, bf), w.to(DEV, bf), pe.to(DEV, bf)
         bias = torch.randn(O, generator=g).to(DEV) if not exact else torch.zeros(O, device=DEV)
         cvec = (torch.rand(O, generator=g) + 0.5).to(DEV) if not exact else torch.ones(O, device=DEV)
-        t8 = torch.empty(B, hl * wl // 8, O, 8, device=DEV, dtype=bf)
+        t8 = torch.empty(B, hl, 2, wl // 8, 16, 8, device=DEV, dtype=bf)
         wimg = torch.empty(B, Ks // 32, 2, 4, 16, 8, device=DEV, dtype=bf)
         act, scale = (0, 1.0) if exact else (3, math.sqrt(2.0))
         gain = scale * 0.5 * (1 + 0.2) if act else 1.0             # the contract of dgv2_modconv_up_fwd
-        N.call("dgv2_modconv_up_t", N.ptr(t8), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), gain, B, hl * wl, Ka, Ks, O,
+        N.call("dgv2_modconv_up_t", N.ptr(t8), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), gain, B, hl, wl, Ka, Ks, O,
                Ka + Ks, Ka, N.BF16, N.stream())
-        t = t8.permute(0, 2, 1, 3).reshape(B, O, hl * wl)           # units of 8 pixels -> [B, O, pixels]
+        t = t8.permute(0, 2, 4, 1, 3, 5).reshape(B, O, hl * wl)     # [b, row, mt, unit, o16, px] -> [B, O, pixels]
         f = (cvec * gain)[None, :, None]                            # the layer's c[o] * gain rides in T and the image
         assert torch.equal(wimg.permute(0, 2, 4, 1, 3, 5).reshape(B, O, Ks), (w[:, :, Ka:].float() * f).to(bf))   # [b,s,mt,kq,o16,j]
         want_t = torch.einsum("bpc,boc->bop", h.double().reshape(B, hl * wl, Ka), w.double()[:, :, :Ka]) * f.double()
