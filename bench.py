@@ -269,7 +269,8 @@ def modconv_probe(args, reps=20):
         N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), 2.0 ** 0.5 * 0.6, B, hl, wl, Ka, Ks, O, Ka + Ks, Ka, N.BF16, N.stream())
     lowres()
     ih, ch, iw, cw = native._up_tables(spec, hl, wl, h.device)
-    sec = _time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(xs), N.ptr(wimg), B, H, W, hl, wl, Ks,
+    xsf = native.pe_frag16(xs)
+    sec = _time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(xsf), N.ptr(wimg), B, H, W, hl, wl, Ks,
                                         O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, 2.0 ** 0.5, N.BF16, None, 0, None, N.stream()), reps)
     sec_lo = _time_launches(lowres, reps)
     sec_sq = _time_launches(lambda: native.up2_lag_sumsq(h, spec), reps)

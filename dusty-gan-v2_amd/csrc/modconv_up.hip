@@ -118,9 +118,12 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
   uint4 bf[KT][2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    const bf16_t* pe = xs + (int64_t)(pw + 16 * nt + n16) * g.Ks + 8 * kq;
+    // xs is the FRAGMENT image of the PE: [P/16][Ks/32][4 kq][16 pixels][8 k] -- a wave's load of one fragment is one
+    // contiguous 1 KB (from the pixel-major [P, Ks] tensor every load touched 16 half lines: the prologue, 33.5 MB per
+    // sample half, was 18 of the kernel's 77 us)
+    const uint4* pe = reinterpret_cast<const uint4*>(xs) + (int64_t)((pw >> 4) + nt) * (KS32 * 64) + lane;
 #pragma unroll
-    for (int s = 0; s < KS32; ++s) bf[s][nt] = *reinterpret_cast<const uint4*>(pe + 32 * s);
+    for (int s = 0; s < KS32; ++s) bf[s][nt] = pe[s * 64];
     const int X = X0 + 16 * nt + n16;
     const int ix0 = g.idx_w[2 * X], ix1 = g.idx_w[2 * X + 1];
     const float wx0 = g.coef_w[2 * X], wx1 = g.coef_w[2 * X + 1];
@@ -435,7 +438,8 @@ __global__ __launch_bounds__(256) void up2_lag_sumsq_kernel(const bf16_t* __rest
 //   wimg [B,Ks/32,2,4,16,8] = the PE columns row_scale * gain * W_s of the prepared per-sample weights as the MFMA image,
 //   both from dgv2_modconv_up_t; up2 by the
 //   two-tap tables idx/coef [Hout][2], [Wout][2] (native.ResampleSpec.tables of the block's up-2 Resample, zero-padded to
-//   two taps); xs [Hout*Wout, Ks] batch-shared PE.
+//   two taps); xs: the batch-shared PE [Hout*Wout, Ks] as the fragment image [Hout*Wout/16][Ks/32][4][16][8]
+//   (pixel tile of 16, K-step, k quarter, pixel, 8 k: element [p][k] of the PE at [p/16][k/32][(k%32)/8][p%16][k%8]).
 //   Contract on the tables (the caller checks it once per table set, they live on the device): Wout % 32 == 0,
 //   Win % 8 == 0, Win >= 32, and for every output column X both W taps lie in the aligned 32-column window
 //   [(X & ~31) / 2 - 8, +32) mod Win (true for every up-2 FIR with at most 4 taps).  Ks in {512}.

@@ -160,6 +160,26 @@ def up2_lag_sumsq(x, spec):
     return sq[0][:sq[1].value]
 
 
+_PE_FRAG = {}
+
+
+def pe_frag16(xs):
+    """The batch-shared PE [1,H,W,Ks] as the B-fragment image of dgv2_modconv_up_fwd, [H*W/16][Ks/32][4][16][8]: element
+    [p][k] at [p/16][k/32][(k%32)/8][p%16][k%8].  The PE is a constant of the run (FourierFeature.encoded caches it), so
+    the image is built once per PE tensor object and version (never inside a graph capture)."""
+    key = id(xs)
+    ent = _PE_FRAG.get(key)
+    if ent is not None and ent[0] is xs and ent[1] == xs._version:
+        return ent[2]
+    P, Ks = xs.shape[1] * xs.shape[2], xs.shape[3]
+    img = xs.reshape(P // 16, 16, Ks // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+    if not (xs.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if len(_PE_FRAG) > 16:
+            _PE_FRAG.clear()
+        _PE_FRAG[key] = (xs, xs._version, img)
+    return img
+
+
 def mod_up_ok(h, xs, wb, spec):
     return bool(_UP_COMMUTE and h is not None and xs is not None and h.is_cuda and h.dtype == torch.bfloat16
                 and wb.shape[1] == 32 and xs.shape[3] == 512 and h.shape[3] % 8 == 0
@@ -210,8 +230,9 @@ class _ModUpPrepared(Function):
         ih, ch, iw, cw = _up_tables(spec, hl, wl, dev)
         sq = _sq_args(dev) if (cfg["want_sq"] and _FUSED_SQ) else None
         out = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
-        N.check(t, xs, wimg, bias32, cvec)
-        N.call("dgv2_modconv_up_fwd", N.ptr(out), N.ptr(t), N.ptr(xs), N.ptr(wimg), B, H, W_, hl, wl, Ks, Otot,
+        xsf = pe_frag16(xs)
+        N.check(t, xsf, wimg, bias32, cvec)
+        N.call("dgv2_modconv_up_fwd", N.ptr(out), N.ptr(t), N.ptr(xsf), N.ptr(wimg), B, H, W_, hl, wl, Ks, Otot,
                N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias32), act, cfg["alpha"], cfg["scale"],
                _dt(h), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None,
                N.stream())

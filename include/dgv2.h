@@ -222,7 +222,9 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
  * -- both written by dgv2_modconv_up_t (the caller passes it that gain), so that
  * every LDS-DMA piece of the sample walk is one contiguous 1 KB; up2 given as two-tap tables idx/coef [Hout][2],
  * [Wout][2] (low-resolution index, weight: the sparse rows of Resample(up=2), gans/models/ops/common.py:105-135, with
- * its ring / replicate extension); xs [Hout*Wout,Ks].  O = 32, Ks = 512 (generator level 4), Wout % 32 == 0,
+ * its ring / replicate extension); xs: the PE [Hout*Wout,Ks] as the MFMA fragment image [Hout*Wout/16][Ks/32][4][16][8]
+ * (element [p][k] at [p/16][k/32][(k%32)/8][p%16][k%8]; a constant of the run, laid out once).  O = 32, Ks = 512
+ * (generator level 4), Wout % 32 == 0,
  * Win % 8 == 0, Win >= 32; DGV2_ENOTSUP otherwise.  Contract on the (device-resident) tables, checked by the caller
  * once per table set: both W taps of output column X lie in the window [(X & ~31) / 2 - 8, +32) mod Win.
  * sumsq: per-block partial sums of squares of the stored y.

@@ -33,13 +33,14 @@ def lowres():
 
 lowres()
 ih, ch, iw, cw = native._up_tables(spec, hl, wl, h.device)
+pef = native.pe_frag16(pe)
 t_sq_old = bench._time_launches(lambda: native.resample_sq_only(h, spec), 20)
 t_sq = bench._time_launches(lambda: native.up2_lag_sumsq(h, spec), 20)
 t_lo = bench._time_launches(lowres, 20)
-t_up = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pe), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
+t_up = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pef), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
 sq = native._sq_args(h.device)
 import ctypes
-t_up_sq = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pe), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, N.ptr(sq[0]), native._SQ_CAP, ctypes.addressof(sq[1]), N.stream()), 20)
+t_up_sq = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pef), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, N.ptr(sq[0]), native._SQ_CAP, ctypes.addressof(sq[1]), N.stream()), 20)
 fl = 2.0 * B * H * W * (Ka + Ks) * O
 a, b_ = native.resample_sq_only(h, spec).sum().item(), native.up2_lag_sumsq(h, spec).sum().item()
 print(f"statistic: pass at the up-sampled size {t_sq_old*1e6:6.1f} us -> quadratic form at low resolution {t_sq*1e6:6.1f} us (rel diff {abs(a-b_)/a:.2e})")

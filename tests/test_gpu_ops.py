@@ -1069,7 +1069,7 @@ def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
             assert_rel(t.float().cpu(), want_t.cpu(), 6e-3, "T")
         y = torch.empty(B, H, W, O, device=DEV, dtype=bf)
         sq = nat._sq_args(torch.device(DEV))
-        N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t8), N.ptr(pe), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih),
+        N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t8), N.ptr(nat.pe_frag16(pe)), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih),
                N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), act, 0.2, scale, N.BF16, N.ptr(sq[0]),
                nat._SQ_CAP, ctypes.addressof(sq[1]), N.stream())
         # float64: up2 of the bf16 T the kernel read, plus the PE contraction with the image the kernel read
