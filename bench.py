@@ -239,12 +239,12 @@ def roofline_probe(args, reps=20):
 def modconv_probe(args, reps=20):
     """The MFMA kernel north_star names: the modulated 1x1 conv at its heaviest site, generator level-4 conv1
     (B x 32768 pixels, K = 64 + 512 shared-PE channels, O = 32, bias + lrelu) as the training step runs it:
-      dgv2_modconv_up_t    T = W_a . h at 32x256 (the xa columns, commuted past the up-sampling: a quarter of the pixels)
-      dgv2_up2_lag_sumsq   the layer's input statistic sum up2(h)^2 as a quadratic form of h (training mode)
-      dgv2_modconv_up_fwd  y = act(c * (up2(T) + W_s . PE) + bias)   <- the kernel reported (csrc/modconv_up.hip)
+      dgv2_modconv_up_t_lag  T = W_a . h at 32x256 (the xa columns, commuted past the up-sampling: a quarter of the
+                             pixels) AND the layer's input statistic sum up2(h)^2 as a quadratic form of h, one read of h
+      dgv2_modconv_up_fwd    y = act(c * (up2(T) + W_s . PE) + bias)   <- the kernel reported (csrc/modconv_up.hip)
     `achieved` = the kernel's own algorithmic FLOPs 2*B*P*Ks*O over its launch time (the four up-sampling K-steps it
-    also runs are not counted); `layer_tflops` = the whole layer's 2*B*P*(Ka+Ks)*O (604 MMAC/img) over all
-    three launches.
+    also runs are not counted); `layer_tflops` = the whole layer's 2*B*P*(Ka+Ks)*O (604 MMAC/img) over both
+    launches (`layer_us.separate_*`: the two-launch form of the low-resolution part it replaced).
     Compulsory HBM bytes of the kernel = y out + t in (the PE is batch-shared, the weights per-sample 37 KB)."""
     if args.dtype == "fp32":
         return None
@@ -271,9 +271,11 @@ def modconv_probe(args, reps=20):
     ih, ch, iw, cw = native._up_tables(spec, hl, wl, h.device)
     xsf = native.pe_frag16(xs)
     sec = _time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(xsf), N.ptr(wimg), B, H, W, hl, wl, Ks,
-                                        O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, 2.0 ** 0.5, N.BF16, None, 0, None, N.stream()), reps)
+                                        O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), N.ptr(cvec), 3, 0.2, 2.0 ** 0.5,
+                                        N.BF16, None, 0, None, N.stream()), reps)
     sec_lo = _time_launches(lowres, reps)
     sec_sq = _time_launches(lambda: native.up2_lag_sumsq(h, spec), reps)
+    sec_tl = _time_launches(lambda: native.mod_up_prepare(h, xs, w, spec, True, 0.2, 2.0 ** 0.5, want_stat=True), reps)
     # the same layer on the un-commuted kernel (dgv2_modconv_pe_fwd on a materialised up2(h): the full K = Ka + Ks
     # contraction in one launch; levels 3 and 2 run this kernel in the training step)
     hup = native._resample_raw(h, spec, False, (hl, wl))
@@ -290,8 +292,9 @@ def modconv_probe(args, reps=20):
             "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6,
             "algorithmic_hbm_GBps": nbytes / sec / 1e9,
-            "layer_tflops": 2.0 * B * P * (Ka + Ks) * O / (sec + sec_lo + sec_sq) / 1e12,
-            "layer_us": {"modconv_up": sec * 1e6, "lowres_t": sec_lo * 1e6, "statistic_lag_sumsq": sec_sq * 1e6},
+            "layer_tflops": 2.0 * B * P * (Ka + Ks) * O / (sec + sec_tl) / 1e12,
+            "layer_us": {"modconv_up": sec * 1e6, "lowres_t_and_statistic": sec_tl * 1e6,
+                         "separate_lowres_t": sec_lo * 1e6, "separate_statistic_lag_sumsq": sec_sq * 1e6},
             "uncommuted_modconv_pe_fwd": {"avg_launch_us": sec_pe * 1e6,
                                           "tflops": 2.0 * B * P * (Ka + Ks) * O / sec_pe / 1e12,
                                           "frac": 2.0 * B * P * (Ka + Ks) * O / sec_pe / 1e12 / MFMA_BF16_PEAK_TFLOPS}}

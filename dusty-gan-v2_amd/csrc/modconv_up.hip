@@ -41,6 +41,7 @@ struct MUGeom {
   const int* idx_w;           // [Wout][2]
   const float* coef_w;
   const float* bias;
+  const float* in_scale;      // device scalar (or NULL): the layer's input-magnitude factor c, applied to the B operands
   int act;
   float alpha, scale;
   float* sumsq;
@@ -142,6 +143,23 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
   if (b0 < b1) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) dma_piece(q, b0, 0);
+  }
+  // The layer's input-magnitude factor c (a scalar that exists only after THIS step's statistic has been folded into the
+  // running mean, i.e. after the helper that wrote T and the weight image has read h) rides on the B operands: every
+  // term of the chain is (A operand) x (PE or U), so c * acc costs 288 multiplies per lane ONCE per block instead of a
+  // multiply per output value, and T / the image need not wait for the statistic.
+  if (g.in_scale) {
+    const float cin = *g.in_scale;
+#pragma unroll
+    for (int s = 0; s < KT; ++s)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        vec16<bf16_t> v;
+        v.raw = bf[s][nt];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.set(e, v.get(e) * cin);
+        bf[s][nt] = v.raw;
+      }
   }
   // ---- bias * gain as the C input of the first MFMA of each chain: this lane's rows 16 mt + 4 kq + r ----
   const float gain = LRELU ? g.scale * 0.5f * (1.f + g.alpha) : 1.f;   // see the epilogue
@@ -369,6 +387,120 @@ __global__ __launch_bounds__(512) void modconv_up_t_kernel(bf16_t* __restrict__ 
   }
 }
 
+// dgv2_modconv_up_t and dgv2_up2_lag_sumsq as ONE pass over h (round 3, late): a wave owns a 32-column segment and walks
+// RS rows down it.  Row i's fragments (lane = pixel n, 8 channels per K-step half) feed the T chain as above; the same
+// registers, the fragments of the pixel one column to the right (their own loads: the lines are the neighbour lanes')
+// and the two of row i + 1 (which become row i's on the next trip) give the five neighbourhood products of the
+// quadratic form with v_dot2_f32_bf16 on the packed pairs.  h is read once (+ one halo row per RS) instead of twice.
+template <int KA16, bool STAT>
+__global__ __launch_bounds__(512) void modconv_up_tl_kernel(bf16_t* __restrict__ tcm, bf16_t* __restrict__ wimg,
+                                                            const bf16_t* __restrict__ h, const bf16_t* __restrict__ w,
+                                                            float gain, const float* __restrict__ ghd,
+                                                            const float* __restrict__ gho, const float* __restrict__ gwd,
+                                                            const float* __restrict__ gwo, int Hlow, int Wlow, int I,
+                                                            int koff, int Ks, int RS, float* __restrict__ partial) {
+  constexpr int O = 32, Ka = KA16 * 16;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = lane & 31, kg = lane >> 5;
+  const int b = blockIdx.y;
+  if (blockIdx.x == 0 && wimg) {   // the PE columns of the sample's weights as the MFMA image (see modconv_up_t_kernel)
+    const int slots = (Ks >> 5) * 128;
+    for (int L = tid; L < slots; L += 512) {
+      const int o = ((L >> 6) & 1) * 16 + (L & 15), kq4 = (L >> 4) & 3, s32 = L >> 7;
+      vec16<bf16_t> v;
+      v.raw = *reinterpret_cast<const uint4*>(w + ((int64_t)b * O + o) * I + koff + s32 * 32 + kq4 * 8);
+      if (gain != 1.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.set(e, v.get(e) * gain);
+      }
+      *reinterpret_cast<uint4*>(wimg + ((int64_t)b * slots + L) * 8) = v.raw;
+    }
+  }
+  const int segs = Wlow >> 5;
+  const int wg = blockIdx.x * 8 + wave;
+  const int rg = wg / segs, seg = wg - rg * segs;
+  const int i0 = rg * RS;
+  float st = 0.f;
+  if (i0 < Hlow) {
+    const int iend = min(i0 + RS, Hlow);
+    const int col = seg * 32 + n, col1 = col + 1 == Wlow ? 0 : col + 1;
+    const bf16_t* hb = h + (int64_t)b * Hlow * Wlow * Ka + kg * 8;
+    const bf16_t* wp = w + ((int64_t)b * O + n) * I + kg * 8;
+    uint4 fb[KA16], a[KA16], bq[KA16], c[KA16], d[KA16];
+#pragma unroll
+    for (int s = 0; s < KA16; ++s) {
+      a[s] = *reinterpret_cast<const uint4*>(hb + ((int64_t)i0 * Wlow + col) * Ka + s * 16);
+      if (STAT) bq[s] = *reinterpret_cast<const uint4*>(hb + ((int64_t)i0 * Wlow + col1) * Ka + s * 16);
+    }
+#pragma unroll
+    for (int s = 0; s < KA16; ++s) fb[s] = *reinterpret_cast<const uint4*>(wp + s * 16);
+    const float wd = STAT ? gwd[col] : 0.f, wo = STAT ? gwo[col] : 0.f;
+    bf16_t* dst0 = tcm + (int64_t)b * Hlow * Wlow * O + ((int64_t)((n >> 4) * (Wlow >> 3) + (seg * 4)) * 16 + (n & 15)) * 8;
+    for (int i = i0; i < iend; ++i) {
+      const int i1 = min(i + 1, Hlow - 1);
+      if (STAT || i + 1 < iend) {
+#pragma unroll
+        for (int s = 0; s < KA16; ++s) {
+          c[s] = *reinterpret_cast<const uint4*>(hb + ((int64_t)i1 * Wlow + col) * Ka + s * 16);
+          if (STAT) d[s] = *reinterpret_cast<const uint4*>(hb + ((int64_t)i1 * Wlow + col1) * Ka + s * 16);
+        }
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KA16; ++s) {
+        union { uint4 u; bf16x8 v; } ua, ub;
+        ua.u = a[s];
+        ub.u = fb[s];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
+      }
+      // [B][Hlow][2 mt][Wlow/8][16 o][8 px]: row i, units 4 seg + (j + kg)
+      bf16_t* dst = dst0 + (int64_t)i * 2 * (Wlow >> 3) * 128;
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        vec16<bf16_t> o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[4 * j + r]), __float_as_uint(acc[4 * (j + 1) + r]),
+                                                     false, false);
+          o.set(r, __uint_as_float(sw[0]) * gain);
+          o.set(4 + r, __uint_as_float(sw[1]) * gain);
+        }
+        *reinterpret_cast<uint4*>(dst + (j + kg) * (16 * 8)) = o.raw;
+      }
+      if (STAT) {
+        float aa = 0.f, ab = 0.f, ac = 0.f, x = 0.f;
+#pragma unroll
+        for (int s = 0; s < KA16; ++s) {
+          union { uint4 u; bf16x2 p[4]; } qa, qb, qc, qd;
+          qa.u = a[s]; qb.u = bq[s]; qc.u = c[s]; qd.u = d[s];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            aa = __builtin_amdgcn_fdot2_f32_bf16(qa.p[k], qa.p[k], aa, false);
+            ab = __builtin_amdgcn_fdot2_f32_bf16(qa.p[k], qb.p[k], ab, false);
+            ac = __builtin_amdgcn_fdot2_f32_bf16(qa.p[k], qc.p[k], ac, false);
+            x = __builtin_amdgcn_fdot2_f32_bf16(qa.p[k], qd.p[k], x, false);
+            x = __builtin_amdgcn_fdot2_f32_bf16(qb.p[k], qc.p[k], x, false);
+          }
+        }
+        st += ghd[i] * (wd * aa + 2.f * wo * ab) + 2.f * gho[i] * (wd * ac + wo * x);
+      }
+#pragma unroll
+      for (int s = 0; s < KA16; ++s) {
+        a[s] = c[s];
+        if (STAT) bq[s] = d[s];
+      }
+    }
+  }
+  if (STAT) {
+    __shared__ float red[16];
+    const float tot = block_sum(st, red);
+    if (tid == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
 // Sum of squares of up2(h) WITHOUT up-sampling: with U = Uh (x) Uw the up-2 operator, sum (U h)^2 = h^T (Gh (x) Gw) h,
 // Gh = Uh^T Uh and Gw = Uw^T Uw tridiagonal (a 4-tap FIR at up = 2 has two taps per output and axis; ring: circulant).
 // Per low-res pixel (i, j) and channel:
@@ -446,8 +578,9 @@ __global__ __launch_bounds__(256) void up2_lag_sumsq_kernel(const bf16_t* __rest
 //   sumsq: one partial per block (of the stored, bf16-rounded values).
 extern "C" int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const void* wimg, int B, int Hout, int Wout,
                                    int Hin, int Win, int Ks, int O, const int* idx_h, const float* coef_h,
-                                   const int* idx_w, const float* coef_w, const float* bias, int act, float alpha,
-                                   float scale, int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream) {
+                                   const int* idx_w, const float* coef_w, const float* bias, const float* in_scale,
+                                   int act, float alpha, float scale, int dtype, float* sumsq, int sumsq_cap,
+                                   int* sumsq_used, void* stream) {
   if (sumsq_used) *sumsq_used = 0;
   if (!y || !t || !xs || !wimg || !idx_h || !coef_h || !idx_w || !coef_w || B <= 0 || Hout <= 0 || Wout <= 0) return DGV2_EINVAL;
   if (dtype != DGV2_BF16 || (act != 0 && act != 3) || O != 32 || Ks != 512 || (Wout & 31) || (Win & 7) || Win < 32 ||
@@ -455,7 +588,7 @@ extern "C" int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const
     return DGV2_ENOTSUP;
   if (!aligned16(y) || !aligned16(t) || !aligned16(xs) || !aligned16(wimg)) return DGV2_EINVAL;
   const int P = Hout * Wout;
-  MUGeom g{B, P, Wout, Hin, Win, Ks, 1, idx_h, coef_h, idx_w, coef_w, bias, act, alpha, scale, sumsq};
+  MUGeom g{B, P, Wout, Hin, Win, Ks, 1, idx_h, coef_h, idx_w, coef_w, bias, in_scale, act, alpha, scale, sumsq};
 #ifdef DGV2_ABLATE
   g.ablate = getenv("DGV2_MU_ABLATE") ? atoi(getenv("DGV2_MU_ABLATE")) : 0;
 #endif
@@ -499,6 +632,49 @@ extern "C" int dgv2_modconv_up_t(void* tcm, void* wimg, const void* h, const voi
   else
     modconv_up_t_kernel<8><<<grid, 512, 0, (hipStream_t)stream>>>((bf16_t*)tcm, (bf16_t*)wimg, (const bf16_t*)h,
                                                                  (const bf16_t*)w, row_scale, gain, Plow, Wlow, I, koff, Ks);
+  DGV2_RETURN_LAST();
+}
+
+// dgv2_modconv_up_t (with row_scale = NULL: T and the image carry `gain` only) and, when ghd != NULL, dgv2_up2_lag_sumsq
+// of the same h in ONE pass: the layer's input statistic must be folded into its running mean BEFORE the factor c
+// exists, so c cannot ride in T when T and the statistic share a pass -- dgv2_modconv_up_fwd takes it as `in_scale`.
+// Contract of sumsq / cap / used as in dgv2_resample_tab_sq (one partial per block); Gram vectors as dgv2_up2_lag_sumsq.
+// replaces: the xa columns of the ModConv2d contraction and its ema_var statistic, gans/models/ops/style.py:98-118.
+extern "C" int dgv2_modconv_up_t_lag(void* tcm, void* wimg, const void* h, const void* w, float gain, const float* ghd,
+                                     const float* gho, const float* gwd, const float* gwo, int B, int Hlow, int Wlow,
+                                     int Ka, int Ks, int O, int I, int koff, int dtype, float* sumsq, int sumsq_cap,
+                                     int* sumsq_used, void* stream) {
+  if (sumsq_used) *sumsq_used = 0;
+  if (!tcm || !h || !w || B <= 0 || Hlow <= 0 || Wlow <= 0) return DGV2_EINVAL;
+  const bool stat = ghd != nullptr;
+  if (stat && (!gho || !gwd || !gwo || !sumsq || !sumsq_used)) return DGV2_EINVAL;
+  if (dtype != DGV2_BF16 || O != 32 || (Ka != 64 && Ka != 128) || (Wlow & 31) || (I & 7) || I < Ka ||
+      (wimg && ((Ks & 31) || (koff & 7) || koff + Ks > I)))
+    return DGV2_ENOTSUP;
+  if (!aligned16(tcm) || !aligned16(h) || !aligned16(w) || (wimg && !aligned16(wimg))) return DGV2_EINVAL;
+  const char* rs_env = getenv("DGV2_TL_ROWS");   // rows a wave walks (A/B benchmarking)
+  // 8 rows per wave where that still leaves a block per CU (B = 64 at 32 x 256: 1 / 2 / 4 / 8 / 16 rows measured
+  // 51 / 35 / 28 / 23 / 37 us; the two separate passes 29 + 16)
+  const int segs = Wlow >> 5;
+  int RS = (int)((int64_t)Hlow * segs * B / 2048);
+  RS = RS < 1 ? 1 : (RS > 8 ? 8 : RS);
+  if (rs_env && atoi(rs_env) > 0) RS = atoi(rs_env);
+  const int groups = (Hlow + RS - 1) / RS;
+  dim3 grid((segs * groups + 7) / 8, B);
+  if (stat) {
+    if ((int64_t)grid.x * grid.y > sumsq_cap) return DGV2_ENOTSUP;
+    *sumsq_used = (int)(grid.x * grid.y);
+  }
+#define DGV2_TL(KA16, ST)                                                                                              \
+  modconv_up_tl_kernel<KA16, ST><<<grid, 512, 0, (hipStream_t)stream>>>((bf16_t*)tcm, (bf16_t*)wimg, (const bf16_t*)h,  \
+                                                                        (const bf16_t*)w, gain, ghd, gho, gwd, gwo, Hlow, \
+                                                                        Wlow, I, koff, Ks, RS, sumsq)
+  if (Ka == 64) {
+    if (stat) DGV2_TL(4, true); else DGV2_TL(4, false);
+  } else {
+    if (stat) DGV2_TL(8, true); else DGV2_TL(8, false);
+  }
+#undef DGV2_TL
   DGV2_RETURN_LAST();
 }
 

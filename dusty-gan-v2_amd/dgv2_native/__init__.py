@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGV2_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -63,8 +63,9 @@ SIGNATURES = {
     "dgv2_emd_matchcost": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_emd_matchcost_grad": [_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr],
     "dgv2_nsgan_loss": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr],
-    "dgv2_modconv_up_fwd": [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr] * 5 + [_c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
+    "dgv2_modconv_up_fwd": [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr] * 6 + [_c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                             _c_ptr],
+    "dgv2_modconv_up_t_lag": [_c_ptr] * 4 + [_c_f32] + [_c_ptr] * 4 + [_c_int] * 9 + [_c_ptr, _c_int, _c_ptr, _c_ptr],
     "dgv2_fir_same_mfma_q8": [_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr],
     "dgv2_resample_tab_q8": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr],
     "dgv2_fp8_quant_weights": [_c_ptr] * 6 + [_c_int] + [_c_ptr] * 3,

@@ -167,16 +167,20 @@ class SynthesisBlock(nn.Module):
             # h, evaluated at h's own resolution (dgv2_up2_lag_sumsq)
             handle, wb, cvec, wt = conv._prep
             cin = hin.shape[3]
+            act = self.bias_act1
+            # T = W_a . h and the statistic share ONE read of h (dgv2_modconv_up_t_lag), ahead of the EMA update: the
+            # factor c that update produces reaches the kernel as a device scalar
+            pre = native.mod_up_prepare(hin, pe0, wb, self.resample.spec, act=True, alpha=act.negative_slope,
+                                        scale=act.scale, want_stat=conv.training)
             if conv.training:
                 pe_sq = float(self.pe.out_ch // 2) * B * H * W
-                sumsq = native.up2_lag_sumsq(hin, self.resample.spec)
+                sumsq = pre[2] if pre is not None else native.up2_lag_sumsq(hin, self.resample.spec)
                 if sumsq is None:
                     sumsq = native.resample_sq_only(hin, self.resample.spec)
             conv.update_ema(sumsq, B * H * W * (cin + self.pe.out_ch), pe_sq, cvec)
-            act = self.bias_act1
             want = want_sq and (self.head.training if self.is_first else self.conv2.training)
             return native.mod_up_layer(hin, pe0, self.resample.spec, handle, wb, cvec, bias=act.bias, act=True,
-                                       alpha=act.negative_slope, scale=act.scale, want_sq=want, wt=wt)
+                                       alpha=act.negative_slope, scale=act.scale, want_sq=want, wt=wt, pre=pre)
         if hin is not None and conv.training and isinstance(self.resample, ops.Resample):
             hup, sumsq = native.resample_sq(hin, self.resample.spec)   # the statistic leaves the same kernel
         elif hin is not None:

@@ -205,9 +205,37 @@ def resample_sq_only(x, spec):
     return sq[0][:sq[1].value]
 
 
+def mod_up_prepare(h, xs, wb, spec, act=True, alpha=0.2, scale=math.sqrt(2.0), want_stat=False):
+    """The low-resolution pass of the commuted level-input conv, AHEAD of the layer's EMA update (dgv2_modconv_up_t_lag):
+    T = gain * W_a . h in 8-pixel units, the PE columns of the per-sample weights as the MFMA image, and -- with
+    want_stat -- the partial sums of sum up2(h)^2 (the layer's input statistic, style.py:98-103) from the SAME read of
+    h.  The input-magnitude factor c, which exists only after that statistic has been folded into the running mean,
+    then reaches dgv2_modconv_up_fwd as a device scalar (mod_up_layer(..., pre=...)).  Returns (t, wimg, partials or
+    None); None when the statistic is wanted but the up-2 operator's Gram matrices are not tridiagonal."""
+    B, Otot, I = wb.shape
+    hl, wl, Ka = h.shape[1:]
+    Ks = xs.shape[3]
+    dev, dt = h.device, h.dtype
+    gram = _up_gram(spec, hl, wl, dev) if want_stat else None
+    if want_stat and gram is None:
+        return None
+    h = h.contiguous()
+    t = torch.empty((B, hl, 2, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
+    wimg = torch.empty((B, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)      # W_s as the MFMA operand image
+    gain = float(scale) * 0.5 * (1.0 + float(alpha)) if act else 1.0
+    sq = _sq_args(dev) if want_stat else None
+    N.check(h, wb)
+    if not N.try_call("dgv2_modconv_up_t_lag", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(wb), gain,
+                      *(N.ptr(g) for g in (gram if gram is not None else (None,) * 4)), B, hl, wl, Ka, Ks, Otot, I, Ka,
+                      _dt(h), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0,
+                      _ct.addressof(sq[1]) if sq else None, N.stream()):
+        return None
+    return t, wimg, (sq[0][:sq[1].value] if sq else None)
+
+
 class _ModUpPrepared(Function):
     @staticmethod
-    def forward(ctx, cfg, h, xs, bias, handle, wb, cvec, wt):
+    def forward(ctx, cfg, h, xs, bias, handle, wb, cvec, wt, t, wimg):
         ctx.set_materialize_grads(False)
         spec = cfg["spec"]
         h = h.contiguous()
@@ -220,22 +248,26 @@ class _ModUpPrepared(Function):
         dev = h.device
         act = 3 if cfg["act"] else 0
         bias32 = None if bias is None else bias.detach().float().contiguous()
-        t = torch.empty((B, hl, 2, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
-        wimg = torch.empty((B, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)   # W_s as the MFMA operand image
-        N.check(h, wb, cvec)
-        # T and the image carry c[o] * gain, the kernel puts gain on the bias and runs the leaky ReLU as f' + k |f'|
-        gain = cfg["scale"] * 0.5 * (1.0 + cfg["alpha"]) if cfg["act"] else 1.0
-        N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(wb), N.ptr(cvec), gain, B, hl, wl, Ka, Ks,
-               Otot, I, Ka, _dt(h), N.stream())
+        in_scale = None
+        if t is not None:
+            in_scale = cvec          # T / the image from mod_up_prepare carry the gain only: c rides on the B operands
+        else:
+            t = torch.empty((B, hl, 2, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
+            wimg = torch.empty((B, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)   # W_s as the MFMA operand image
+            N.check(h, wb, cvec)
+            # T and the image carry c[o] * gain, the kernel puts gain on the bias and runs the leaky ReLU as f' + k |f'|
+            gain = cfg["scale"] * 0.5 * (1.0 + cfg["alpha"]) if cfg["act"] else 1.0
+            N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(wb), N.ptr(cvec), gain, B, hl, wl, Ka, Ks,
+                   Otot, I, Ka, _dt(h), N.stream())
         ih, ch, iw, cw = _up_tables(spec, hl, wl, dev)
         sq = _sq_args(dev) if (cfg["want_sq"] and _FUSED_SQ) else None
         out = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
         xsf = pe_frag16(xs)
         N.check(t, xsf, wimg, bias32, cvec)
         N.call("dgv2_modconv_up_fwd", N.ptr(out), N.ptr(t), N.ptr(xsf), N.ptr(wimg), B, H, W_, hl, wl, Ks, Otot,
-               N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias32), act, cfg["alpha"], cfg["scale"],
-               _dt(h), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0, _ct.addressof(sq[1]) if sq else None,
-               N.stream())
+               N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias32), N.ptr(in_scale), act, cfg["alpha"],
+               cfg["scale"], _dt(h), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0,
+               _ct.addressof(sq[1]) if sq else None, N.stream())
         ctx.cfg = dict(cfg, has_bias=bias is not None)
         ctx.save_for_backward(h, xs, wb, out if cfg["act"] else None, cvec, wt)
         if cfg["want_sq"]:
@@ -248,7 +280,7 @@ class _ModUpPrepared(Function):
     def backward(ctx, gy, *rest):
         cfg = ctx.cfg
         if gy is None:
-            return (None,) * 8
+            return (None,) * 10
         h, xs, wb, out, cvec, wt = ctx.saved_tensors
         spec = cfg["spec"]
         B, Otot, I = wb.shape
@@ -300,15 +332,18 @@ class _ModUpPrepared(Function):
                            N.stream())
                 gws = _mod_wgrad(g3, None, xs, B, H, W_, xs.shape[3], Otot, dt)   # PE columns at full resolution
                 gwb = torch.cat([gwa, gws], dim=2)
-        return None, gh, None, gb, gwb, None, None, None
+        return None, gh, None, gb, gwb, None, None, None, None, None
 
 
 def mod_up_layer(h, xs, spec, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), want_sq=False,
-                 wt=None):
+                 wt=None, pre=None):
     """conv1 of a generator level on the batch-shared PE, taking the level's LOW-resolution input h and the block's
-    up-2 Resample spec (see _ModUpPrepared); same result as mod_gemm_layer(resample(h), xs, ...)."""
+    up-2 Resample spec (see _ModUpPrepared); same result as mod_gemm_layer(resample(h), xs, ...).
+    pre: (t, wimg, ...) of mod_up_prepare(h, xs, wb, spec, act, alpha, scale) -- the low-resolution pass already done
+    (ahead of the EMA update that produced cvec, whose common value is then applied inside the kernel)."""
     cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0, want_sq=bool(want_sq), spec=spec)
-    return _ModUpPrepared.apply(cfg, h, xs, bias, handle, wb, cvec, wt)
+    t, wimg = (None, None) if pre is None else pre[:2]
+    return _ModUpPrepared.apply(cfg, h, xs, bias, handle, wb, cvec, wt, t, wimg)
 
 
 def mod_gemm_layer(xa, xs, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=None,

@@ -227,13 +227,16 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
  * (generator level 4), Wout % 32 == 0,
  * Win % 8 == 0, Win >= 32; DGV2_ENOTSUP otherwise.  Contract on the (device-resident) tables, checked by the caller
  * once per table set: both W taps of output column X lie in the window [(X & ~31) / 2 - 8, +32) mod Win.
+ * in_scale (device fp32 scalar or NULL): a factor c on the whole contraction, y = act(c (up2(T) + W_s PE) + bias) -- the
+ * layer's input-magnitude factor when T and the image came from dgv2_modconv_up_t_lag (which cannot know it yet: the
+ * statistic it emits is what updates the running mean c derives from); applied once per block to the B operands.
  * sumsq: per-block partial sums of squares of the stored y.
  * replaces: Resample(up=2) + torch.cat([h, pe]) + ModConv2d contraction + FusedLeakyReLU,
  *   gans/models/dusty_v2.py:153-162, gans/models/ops/style.py:105-118. */
 int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const void* wimg, int B, int Hout, int Wout, int Hin,
                         int Win, int Ks, int O, const int* idx_h, const float* coef_h, const int* idx_w,
-                        const float* coef_w, const float* bias, int act, float alpha, float scale, int dtype,
-                        float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
+                        const float* coef_w, const float* bias, const float* in_scale, int act, float alpha, float scale,
+                        int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 /* The low-resolution xa part of the commuted level-input conv and the operand images of dgv2_modconv_up_fwd:
  *   tcm [B,Hlow,2,Wlow/8,16,8]: T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units (per row: the units
  *   of channels 0..15, then those of channels 16..31), f[o] = row_scale[o] * gain
@@ -244,6 +247,13 @@ int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const void* wimg
  * replaces: the xa columns of the ModConv2d contraction, gans/models/ops/style.py:105-118. */
 int dgv2_modconv_up_t(void* tcm, void* wimg, const void* h, const void* w, const float* row_scale, float gain, int B,
                       int Hlow, int Wlow, int Ka, int Ks, int O, int I, int koff, int dtype, void* stream);
+/* dgv2_modconv_up_t (row_scale = NULL) and dgv2_up2_lag_sumsq (when ghd != NULL; Gram vectors and sumsq contract as
+ * there) in ONE pass over h: a wave walks a 32-column segment down the rows, its T fragments double as the operands of
+ * the quadratic form's neighbourhood products.  The factor c then goes to dgv2_modconv_up_fwd as in_scale.
+ * replaces: the xa columns of the ModConv2d contraction and its ema_var statistic, gans/models/ops/style.py:98-118. */
+int dgv2_modconv_up_t_lag(void* tcm, void* wimg, const void* h, const void* w, float gain, const float* ghd,
+                          const float* gho, const float* gwd, const float* gwo, int B, int Hlow, int Wlow, int Ka, int Ks,
+                          int O, int I, int koff, int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 /* Per-block partial sums of sum_{b,p,c} up2(h)[b,p,c]^2 taken from h at its own (low) resolution: with U = Uh (x) Uw
  * the up-2 operator, sum (U h)^2 = h^T (Gh (x) Gw) h with tridiagonal Gram matrices Gh = Uh^T Uh, Gw = Uw^T Uw (ring axis:
  * circulant).  ghd / gho [Hin]: diagonal and (i, i+1) entries of Gh (gho[Hin-1] = 0); gwd / gwo [Win]: diagonal and

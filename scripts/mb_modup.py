@@ -37,13 +37,22 @@ pef = native.pe_frag16(pe)
 t_sq_old = bench._time_launches(lambda: native.resample_sq_only(h, spec), 20)
 t_sq = bench._time_launches(lambda: native.up2_lag_sumsq(h, spec), 20)
 t_lo = bench._time_launches(lowres, 20)
-t_up = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pef), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
+t_up = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pef), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), None, 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
 sq = native._sq_args(h.device)
 import ctypes
-t_up_sq = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pef), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, N.ptr(sq[0]), native._SQ_CAP, ctypes.addressof(sq[1]), N.stream()), 20)
+t_up_sq = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pef), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), None, 3, 0.2, math.sqrt(2.0), N.BF16, N.ptr(sq[0]), native._SQ_CAP, ctypes.addressof(sq[1]), N.stream()), 20)
 fl = 2.0 * B * H * W * (Ka + Ks) * O
 a, b_ = native.resample_sq_only(h, spec).sum().item(), native.up2_lag_sumsq(h, spec).sum().item()
 print(f"statistic: pass at the up-sampled size {t_sq_old*1e6:6.1f} us -> quadratic form at low resolution {t_sq*1e6:6.1f} us (rel diff {abs(a-b_)/a:.2e})")
 print(f"cat path : resample_sq {t_rs*1e6:6.1f} + modconv_pe {t_pe*1e6:6.1f} = {(t_rs+t_pe)*1e6:6.1f} us  (kernel {fl/t_pe/1e12:5.0f} TF/s, layer {fl/(t_rs+t_pe)/1e12:5.0f} TF/s)")
 print(f"commuted : statistic {t_sq*1e6:6.1f} + low-res T {t_lo*1e6:6.1f} + modconv_up {t_up*1e6:6.1f} (with sumsq partials {t_up_sq*1e6:6.1f}) = {(t_sq+t_lo+t_up)*1e6:6.1f} us  (kernel {2.0*B*H*W*Ks*O/t_up/1e12:5.0f} TF/s own FLOPs, layer {fl/(t_sq+t_lo+t_up)/1e12:5.0f} TF/s)")
+for rs in (1, 2, 4, 8, 16):
+    os.environ["DGV2_TL_ROWS"] = str(rs)
+    t_tl = bench._time_launches(lambda: native.mod_up_prepare(h, pe, wb, spec, True, 0.2, math.sqrt(2.0), want_stat=True), 20)
+    t_t0 = bench._time_launches(lambda: native.mod_up_prepare(h, pe, wb, spec, True, 0.2, math.sqrt(2.0), want_stat=False), 20)
+    print(f"one pass over h, {rs:2d} rows per wave: T + statistic {t_tl*1e6:6.1f} us (T alone {t_t0*1e6:6.1f}) -> layer {fl/(t_tl+t_up)/1e12:5.0f} TF/s")
+del os.environ["DGV2_TL_ROWS"]
+pre = native.mod_up_prepare(h, pe, wb, spec, True, 0.2, math.sqrt(2.0), want_stat=True)
+print(f"  statistic rel diff {abs(pre[2].sum().item()-a)/a:.2e}")
+N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(pre[0]), N.ptr(pef), N.ptr(pre[1]), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), N.ptr(cvec), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream())
 print("max |diff| vs cat path:", float((y.float() - y0.float()).abs().max()), "of", float(y0.float().abs().max()))

@@ -20,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     wimg = torch.randn(B, Ks // 32, 2, 4, 16, 8, device="cuda", dtype=bf) / 16
     ih, ch, iw, cw = native._up_tables(spec, hl, wl, pe.device)
     pef = native.pe_frag16(pe)
-    sec = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pef), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 30)
+    sec = bench._time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(pef), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), None, 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 30)
     print(f"DGV2_MU_ABLATE={os.environ.get('DGV2_MU_ABLATE', '0'):>3}: {sec * 1e6:7.1f} us")
 else:
     for a in (sys.argv[1:] or ["0", "1", "16", "2", "4", "8", "3", "5", "6", "7", "15"]):

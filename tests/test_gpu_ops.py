@@ -1070,7 +1070,7 @@ def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
         y = torch.empty(B, H, W, O, device=DEV, dtype=bf)
         sq = nat._sq_args(torch.device(DEV))
         N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t8), N.ptr(nat.pe_frag16(pe)), N.ptr(wimg), B, H, W, hl, wl, Ks, O, N.ptr(ih),
-               N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), act, 0.2, scale, N.BF16, N.ptr(sq[0]),
+               N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), None, act, 0.2, scale, N.BF16, N.ptr(sq[0]),
                nat._SQ_CAP, ctypes.addressof(sq[1]), N.stream())
         # float64: up2 of the bf16 T the kernel read, plus the PE contraction with the image the kernel read
         tup = o.resample(t.double().cpu().reshape(B, O, hl, wl), (1, 3, 3, 1), up=2, ring=True).permute(0, 2, 3, 1)
@@ -1089,6 +1089,34 @@ def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
         lag = nat.up2_lag_sumsq(h, spec)
         hup = o.resample(h.double().cpu().permute(0, 3, 1, 2), (1, 3, 3, 1), up=2, ring=True)
         assert_rel(lag.double().sum().cpu(), hup.square().sum(), 1e-5, "sum up2(h)^2")
+        # T and the statistic from ONE read of h (dgv2_modconv_up_t_lag), the factor c as the kernel's in_scale
+        pre2 = nat.mod_up_prepare(h, pe, w, spec, act=bool(act), alpha=0.2, scale=scale, want_stat=True)
+        assert pre2 is not None
+        t2, wimg2, part = pre2
+        assert_rel(part.double().sum().cpu(), hup.square().sum(), 1e-5, "sum up2(h)^2 (fused pass)")
+        t2f = t2.permute(0, 2, 4, 1, 3, 5).reshape(B, O, hl * wl)
+        want_t2 = torch.einsum("bpc,boc->bop", h.double().reshape(B, hl * wl, Ka), w.double()[:, :, :Ka]) * gain
+        assert torch.equal(wimg2.permute(0, 2, 4, 1, 3, 5).reshape(B, O, Ks), (w[:, :, Ka:].float() * gain).to(bf))
+        if exact:
+            assert torch.equal(t2f.double(), want_t2)
+        else:
+            assert_rel(t2f.float().cpu(), want_t2.cpu(), 6e-3, "T (fused pass)")
+        nostat = nat.mod_up_prepare(h, pe, w, spec, act=bool(act), alpha=0.2, scale=scale, want_stat=False)
+        assert nostat[2] is None and torch.equal(nostat[0], t2) and torch.equal(nostat[1], wimg2)
+        cin = 2.0 if exact else 1.3        # a power of two keeps the scaled B operands exact
+        cdev = torch.full((O,), cin, device=DEV)
+        y2 = torch.empty(B, H, W, O, device=DEV, dtype=bf)
+        N.call("dgv2_modconv_up_fwd", N.ptr(y2), N.ptr(t2), N.ptr(nat.pe_frag16(pe)), N.ptr(wimg2), B, H, W, hl, wl, Ks, O,
+               N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), N.ptr(cdev), act, 0.2, scale, N.BF16, None, 0,
+               None, N.stream())
+        tup2 = o.resample(t2f.double().cpu().reshape(B, O, hl, wl), (1, 3, 3, 1), up=2, ring=True).permute(0, 2, 3, 1)
+        ws2 = wimg2.permute(0, 2, 4, 1, 3, 5).reshape(B, O, Ks).double().cpu()
+        pre = (cin * (tup2 + torch.einsum("hwk,bok->bhwo", pe.double().cpu()[0], ws2)) + bias.double().cpu() * gain) / gain * scale
+        want2 = pre if exact else torch.where(pre > 0, pre, pre * 0.2)
+        if exact:
+            assert torch.equal(y2.double().cpu(), want2.to(bf).double())
+        else:
+            assert_rel(y2.float().cpu(), want2, 8e-3, "y (c on the B operands)")
 
 
 def test_fused_nsgan_loss_matches_ganloss(nat):
