@@ -749,9 +749,26 @@ class Discriminator(nn.Module):
         return native.stem(h, w, act.bias, blur.blur_h.spec.ring, act.negative_slope, act.scale,
                            LOW if low else torch.float32)
 
-    def forward(self, h, splits=1, double_backward=False, features_only=False):
+    _cut = None
+
+    def head_parameters(self):
+        """Parameters behind the cut of forward(cut=True): the two Linear layers and the bias between them
+        (reference dusty_v2.py:381-387) -- 134 of D's 154 MB, the first gradients a backward pass produces."""
+        return [p for m in self.epilogue[4:] for p in m.parameters()]
+
+    def take_cut(self):
+        """(trunk side, head side) of the last forward(cut=True): the flattened feature tensor with its autograd
+        graph, and the detached leaf the head ran on (its .grad, after the head's backward, is what the trunk's
+        backward starts from)."""
+        cut, self._cut = self._cut, None
+        return cut
+
+    def forward(self, h, splits=1, double_backward=False, features_only=False, cut=False):
         """h [B,C,H,W] (C = 1 on the dusty_v2 path) -> logits [B,1]  (features_only: the trunk's output [B,H/16,W/16,C]
-        channels-last, before the fp32 epilogue -- used by the precision tests).  `splits` = number of independent
+        channels-last, before the fp32 epilogue -- used by the precision tests).
+        cut: detach the graph in front of the 65536 -> 512 Linear, so that the caller can run the backward in two
+        pieces (head first: its gradients are 87 % of D's bytes and can be exchanged while the trunk's backward runs);
+        the two sides are handed out by take_cut().  `splits` = number of independent
         sub-batches stacked along dim 0 (minibatch statistics are computed per sub-batch), so that
         D(real) and D(fake) of the discriminator step can share one pass over the weights.
         `double_backward`: the caller will differentiate the input gradient again (R1); the fused stem is
@@ -801,6 +818,10 @@ class Discriminator(nn.Module):
             x = mb.forward_cl(x.float(), pad_to=cpad, splits=splits).to(edt)
         x = conv.forward_cl(x, pad_in_to=cpad, act=act1, bank=bank)
         x = ops.from_cl(x).flatten(1)  # NCHW flatten order of the reference's nn.Flatten
+        if cut:
+            leaf = x.detach().requires_grad_(True)
+            self._cut = (x, leaf)
+            x = leaf
         if edt == LOW and lin1.module.bias is None and lin1.gain_ == 1.0:
             # epilogue_dtype == "bf16": the 65536 -> 512 Linear (8.6 GFLOP at B = 128, 134 MB of fp32 weights) with
             # bf16 operands and fp32 accumulation

@@ -85,12 +85,19 @@ def nsgan_loss(y, n_real):
 _UP_COMMUTE = os.environ.get("DGV2_NO_UP_COMMUTE") is None   # A/B switch for benchmarking
 
 
-_UP_TABLES = {}
+def _spec_cache(spec, name):
+    """A per-spec dict (an id()-keyed module dict would hand a dead spec's tables to a new object at its address)."""
+    c = spec.__dict__.get(name)
+    if c is None:
+        c = {}
+        setattr(spec, name, c)
+    return c
 
 
 def _up_tables(spec, hl, wl, device):
     """Two-tap tables (low-res index, weight) per output row / column of an up-2 Resample, zero-padded to two taps."""
-    key = (id(spec), hl, wl, str(device))
+    key = (hl, wl, str(device))
+    _UP_TABLES = _spec_cache(spec, "_dgv2_up_tables")
     if key not in _UP_TABLES:
         (ih, ch, _, Eh), (iw, cw, _, Ew) = spec.tables(hl, wl, False, device)
         if Eh > 2 or Ew > 2:
@@ -112,14 +119,12 @@ def _up_tables(spec, hl, wl, device):
     return _UP_TABLES[key]
 
 
-_UP_GRAM = {}
-
-
 def _up_gram(spec, hl, wl, device):
     """Diagonal / first off-diagonal of the Gram matrices Uh^T Uh, Uw^T Uw of an up-2 Resample's axis factors (fp32
     device vectors ghd, gho [hl], gwd, gwo [wl]; the W axis is a ring: gwo[j] couples j and (j + 1) % wl), or None when
     a Gram matrix is not tridiagonal (then the statistic needs the pass at the up-sampled size)."""
-    key = (id(spec), hl, wl, str(device))
+    key = (hl, wl, str(device))
+    _UP_GRAM = _spec_cache(spec, "_dgv2_up_gram")
     if key not in _UP_GRAM:
         (ih, ch, _, _), (iw, cw, _, _) = spec.tables(hl, wl, False, device)
 
@@ -160,23 +165,18 @@ def up2_lag_sumsq(x, spec):
     return sq[0][:sq[1].value]
 
 
-_PE_FRAG = {}
-
-
 def pe_frag16(xs):
     """The batch-shared PE [1,H,W,Ks] as the B-fragment image of dgv2_modconv_up_fwd, [H*W/16][Ks/32][4][16][8]: element
     [p][k] at [p/16][k/32][(k%32)/8][p%16][k%8].  The PE is a constant of the run (FourierFeature.encoded caches it), so
-    the image is built once per PE tensor object and version (never inside a graph capture)."""
-    key = id(xs)
-    ent = _PE_FRAG.get(key)
-    if ent is not None and ent[0] is xs and ent[1] == xs._version:
-        return ent[2]
+    the image is built once per PE tensor and version and lives ON that tensor (captured graphs read it for as long as
+    the PE exists; a process-wide cache with eviction would free it under them).  Built inside a capture it is not kept."""
+    ent = getattr(xs, "_dgv2_frag16", None)
+    if ent is not None and ent[0] == xs._version:
+        return ent[1]
     P, Ks = xs.shape[1] * xs.shape[2], xs.shape[3]
     img = xs.reshape(P // 16, 16, Ks // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
     if not (xs.is_cuda and torch.cuda.is_current_stream_capturing()):
-        if len(_PE_FRAG) > 16:
-            _PE_FRAG.clear()
-        _PE_FRAG[key] = (xs, xs._version, img)
+        xs._dgv2_frag16 = (xs._version, img)
     return img
 
 

@@ -30,14 +30,21 @@ def world_size():
 class FlatGradSync:
     """Owns the gradients of `module`: p.grad are views of self.flat (fp32)."""
 
-    def __init__(self, module, payload_dtype=None):
+    def __init__(self, module, payload_dtype=None, first=None):
         """payload_dtype: torch.bfloat16 sends the gradients as bf16 (half the xGMI bytes; one cast pass each way, the
         sum itself is then rounded to bf16 -- NOT what the reference's fp32 DDP buckets do, hence opt-in:
-        training.grad_payload: bf16).  None / torch.float32: the flat fp32 buffer itself is reduced in place."""
+        training.grad_payload: bf16).  None / torch.float32: the flat fp32 buffer itself is reduced in place.
+        first: parameters whose gradients exist EARLY in the backward pass (the layers nearest the loss); they are laid
+        out at the front of the flat buffer so that segment "first" can be reduced while the rest of the backward
+        still runs (DDP does the same with its reverse-order buckets, reference trainer.py:76-79)."""
         self.module = module
         self.payload_dtype = None if payload_dtype in (None, torch.float32) else payload_dtype
         self._payload = None
-        self.params = [p for p in module.parameters()]
+        first = list(first) if first is not None else []
+        ids = {id(p) for p in first}
+        self.params = first + [p for p in module.parameters() if id(p) not in ids]
+        self.n_first_params = len(first)
+        self.n_first = sum(p.numel() for p in first)
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -64,15 +71,31 @@ class FlatGradSync:
         for p in self.params:
             p.grad = None
 
-    def collect(self, accumulate=False, scale=1.0):
+    def _part(self, part):
+        """(parameter range, element range) of a segment: None = everything, "first" / "rest" as laid out by __init__."""
+        n, ne = len(self.params), self.flat.numel()
+        if part is None:
+            return (0, n), (0, ne)
+        if part == "first":
+            return (0, self.n_first_params), (0, self.n_first)
+        if part == "rest":
+            return (self.n_first_params, n), (self.n_first, ne)
+        raise ValueError(part)
+
+    def collect(self, accumulate=False, scale=1.0, part=None):
         """End of the body: pack the fresh gradients into the flat buffer with one multi-tensor copy and
         re-attach the views (stable addresses for the captured optimizer graphs and the all-reduce).
         Gradient accumulation (reference: trainer.py:255-257,296): the chunk's gradients are scaled by
         `scale` = 1 / num_accumulation (the reference divides the loss) and, from the second chunk on
-        (`accumulate`), ADDED to what the buffer holds."""
-        views = self._views()
-        dst = [v for v, p in zip(views, self.params) if p.grad is not None]
-        src = [p.grad for p in self.params if p.grad is not None]
+        (`accumulate`), ADDED to what the buffer holds.  part: only that segment's parameters."""
+        (lo, hi), _ = self._part(part)
+        views = self._views()[lo:hi]
+        params = self.params[lo:hi]
+        self._collect(views, params, accumulate, scale)
+
+    def _collect(self, views, params, accumulate, scale):
+        dst = [v for v, p in zip(views, params) if p.grad is not None]
+        src = [p.grad for p in params if p.grad is not None]
         if dst:
             if accumulate:
                 torch._foreach_add_(dst, src, alpha=scale)
@@ -80,7 +103,7 @@ class FlatGradSync:
                 torch._foreach_copy_(dst, src)
                 if scale != 1.0:
                     torch._foreach_mul_(dst, scale)
-        for v, p in zip(views, self.params):
+        for v, p in zip(views, params):
             if p.grad is None and not accumulate:
                 v.zero_()
             p.grad = v
@@ -101,38 +124,42 @@ class FlatGradSync:
         finally:
             self._sync = old
 
-    def all_reduce(self, async_op=False):
-        """Average the flat gradient over ranks (no-op for one process or inside no_sync).  async_op: start the
-        reduction on the communication stream and return a handle for wait(); work issued in between overlaps it."""
+    def all_reduce(self, async_op=False, part=None):
+        """Average the flat gradient (or one segment of it) over ranks (no-op for one process or inside no_sync).
+        async_op: start the reduction on the communication stream and return a handle for wait(); work issued in
+        between overlaps it."""
         if not (self._sync and is_dist()):
             return None
         avg = _avg_supported(self.flat.device)
-        buf = self.flat
+        _, (lo, hi) = self._part(part)
+        if hi <= lo:
+            return None
+        buf = self.flat[lo:hi]
         if self.payload_dtype is not None:
             if self._payload is None:
                 self._payload = torch.empty_like(self.flat, dtype=self.payload_dtype)
-            self._payload.copy_(self.flat)
-            buf = self._payload
+            self._payload[lo:hi].copy_(buf)
+            buf = self._payload[lo:hi]
         # RCCL averages inside the reduction: no extra pass over the 154 MB buffer
         work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
         if async_op:
-            return (work, avg)
-        self._finish(avg)
+            return (work, avg, lo, hi)
+        self._finish(avg, lo, hi)
         return None
 
-    def _finish(self, avg):
+    def _finish(self, avg, lo, hi):
         if self.payload_dtype is not None:
-            self.flat.copy_(self._payload)
+            self.flat[lo:hi].copy_(self._payload[lo:hi])
         if not avg:
-            self.flat.mul_(1.0 / dist.get_world_size())
+            self.flat[lo:hi].mul_(1.0 / dist.get_world_size())
 
     def wait(self, handle):
         """Complete an all_reduce(async_op=True): the current stream waits for the reduction."""
         if handle is None:
             return
-        work, avg = handle
+        work, avg, lo, hi = handle
         work.wait()
-        self._finish(avg)
+        self._finish(avg, lo, hi)
 
 
 _AVG_OK = None

@@ -88,7 +88,14 @@ class Trainer:
             m.requires_grad_(False)
         payload = {"fp32": None, "bf16": torch.bfloat16}[str(cfg.training.get("grad_payload", "fp32"))]
         self.g_sync = parallel.FlatGradSync(self.G, payload)
-        self.d_sync = parallel.FlatGradSync(self.D, payload)
+        # D's backward in two pieces (training.overlap_d_reduce; default: whenever there is someone to exchange with):
+        # the head's gradients -- the 65536 -> 512 Linear, 134 of 154 MB -- are complete after the first few kernels of
+        # the backward pass and travel while the trunk's backward runs (what DDP's reverse-order buckets do for the
+        # reference, trainer.py:76-79)
+        ov = cfg.training.get("overlap_d_reduce", None)
+        self.split_d = parallel.is_dist() if ov is None else bool(ov)
+        self.split_d = self.split_d and hasattr(self.D, "head_parameters")
+        self.d_sync = parallel.FlatGradSync(self.D, payload, first=self.D.head_parameters() if self.split_d else None)
         self.ddp_models = (self.g_sync, self.d_sync)
         self.auxin = {"angle": self.coord.angle}  # [1,2,H,W]; kernels broadcast it over the batch
 
@@ -281,7 +288,7 @@ class Trainer:
         set_requires_grad(self.G, False)
         scalars["loss/G/adversarial"] = loss_gan.detach()
 
-    def d_fb(self, x_real, j, scalars):
+    def d_fb(self, x_real, j, scalars, cut=False):
         set_requires_grad(self.D, True)
         self.d_sync.begin()
         z = self._z("d")
@@ -291,7 +298,7 @@ class Trainer:
             x_fake_aug = self.A(self.warmup(x_fake, self._draw("d.keep_fake")), draws=self._ada("d.ada_fake"))
         # D(real) and D(fake) in ONE pass over the discriminator (minibatch-stddev per half), instead of
         # the reference's two calls (trainer.py:391-392): same result, half the launches / weight reads
-        y = self.D(torch.cat([x_real_aug, x_fake_aug], dim=0), splits=2)
+        y = self.D(torch.cat([x_real_aug, x_fake_aug], dim=0), splits=2, **({"cut": True} if cut else {}))
         y_real, y_fake = y[:self.B], y[self.B:]
         if self.adversarial_loss.can_fuse(y):
             # objective, its gradient, both output means and ADA's sign statistic from one launch
@@ -303,10 +310,28 @@ class Trainer:
             loss_gan = self.adversarial_loss(y_real, y_fake, "D")
             out_real, out_fake = y_real.mean().detach(), y_fake.mean().detach()
         (self.cfg.training.loss.gan * loss_gan).backward()
-        self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
+        if cut:
+            # the head's gradients are final; the trunk's backward is d_fb_tail
+            self._d_cut = self.D.take_cut()
+            self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation, part="first")
+        else:
+            self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
         scalars["loss/D/output/real"] = out_real
         scalars["loss/D/output/fake"] = out_fake
         scalars["loss/D/adversarial"] = loss_gan.detach()
+
+    def d_fb_head(self, x_real, j, scalars):
+        """D step up to and including the backward of the head (the two Linear layers behind Discriminator's cut)."""
+        self.d_fb(x_real, j, scalars, cut=True)
+
+    def d_fb_tail(self, j, scalars):
+        """The rest of D's backward, from the gradient the head left at the cut.  Under hipGraphs this is a second
+        capture: its kernels read the activations the first capture's replay wrote (each graph has its own pool, the
+        saved tensors stay allocated in the first one's)."""
+        feat, leaf = self._d_cut
+        self._d_cut = None
+        feat.backward(leaf.grad)
+        self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation, part="rest")
 
     def r1_fb(self, x_real, j, scalars):
         """lazy R1 (reference: trainer.py:419-451): double backward through D and ADA."""
@@ -411,6 +436,14 @@ class Trainer:
             torch.cuda.synchronize()
         return scalars
 
+    def _link_graphs(self, head, tail):
+        """The tail of a split body needs the autograd graph its head built: if either capture failed, both run
+        eagerly from now on."""
+        names = [n for n in self._graphs if n.split("/")[0] in (head.split("/")[0], tail.split("/")[0])]
+        if any(self._graphs[n] is None for n in names):
+            for n in names:
+                self._graphs[n] = None
+
     def _opt_step(self, opt):
         if self.device.type == "cuda" and os.environ.get("DGV2_TORCH_ADAM") is None:
             from gans.models.ops import native
@@ -469,16 +502,27 @@ class Trainer:
             self.g_sync.all_reduce()
             self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
 
+        pending = []
         for j in range(nacc):
             if j == 0:
                 parallel.sync_buffers(self.G)
-            log(self._run(self._acc_name("d_fb", j), self.d_fb, real(j), j))
-        # the 154 MB gradient reduction of D runs on the communication stream while the EMA generator is updated
+            if self.split_d:
+                head, tail = self._acc_name("d_fb_head", j), self._acc_name("d_fb_tail", j)
+                log(self._run(head, self.d_fb_head, real(j), j))
+                if j == nacc - 1:
+                    # 134 of D's 154 MB leave now, on the communication stream, under the trunk's backward
+                    pending.append(self.d_sync.all_reduce(async_op=True, part="first"))
+                self._run(tail, self.d_fb_tail, j)
+                self._link_graphs(head, tail)
+            else:
+                log(self._run(self._acc_name("d_fb", j), self.d_fb, real(j), j))
+        # the (rest of the) gradient reduction of D runs on the communication stream while the EMA generator is updated
         # (G is final for this iteration: nothing below touches it)
-        pending = self.d_sync.all_reduce(async_op=True)
+        pending.append(self.d_sync.all_reduce(async_op=True, part="rest" if self.split_d else None))
         decay = self.ema_decay(iteration)
         ema_inplace(self.G_ema, self.G, decay)
-        self.d_sync.wait(pending)
+        for h in pending:
+            self.d_sync.wait(h)
         self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
 
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:

@@ -52,7 +52,7 @@ def test_two_ranks_identical_and_equal_to_one_process(tmp_path, graph):
     assert all(torch.equal(a, b) for a, b in zip(r0["optD_v"], r1["optD_v"]))
     if graph:
         # the children inject their draws: those bodies are the "/inj" captures
-        assert {"g_fb/inj", "g_opt", "d_fb/inj", "d_opt", "r1_fb/inj"} <= set(r0["graphs"]), r0["graphs"]
+        assert {"g_fb/inj", "g_opt", "d_fb_head/inj", "d_fb_tail/inj", "d_opt", "r1_fb/inj"} <= set(r0["graphs"]), r0["graphs"]
     # ranks see different samples: their local losses differ, the logged (all-reduced) scalars do not
     assert r0["scalars"] == r1["scalars"]
     (one,) = _run(tmp_path, 1, iters, graph, {"DGV2_TEST_WORLD_TOTAL": "2"})

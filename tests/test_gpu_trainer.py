@@ -86,13 +86,15 @@ def _load_trainer_fixture():
     return {k: ([str(x) for x in d[k]] if ".keys." in k else torch.from_numpy(d[k])) for k in d.files}
 
 
-def _fixture_trainer(d, tag, hip_graph, low_precision=False):
+def _fixture_trainer(d, tag, hip_graph, low_precision=False, overlap_d_reduce=None):
     from gans.trainer import Trainer
     from helpers import trainer_fixture_hp, trainer_fixture_state
     hp = trainer_fixture_hp(d, tag)
     cfg = small_cfg(low_precision)
     cfg.dataset.name = "synthetic"
     cfg.training.update(rank=0, num_gpus=1, batch_size=8, batch_size_per_gpu=8, resume=None, hip_graph=hip_graph)
+    if overlap_d_reduce is not None:
+        cfg.training.update(overlap_d_reduce=overlap_d_reduce)
     cfg.training.lazy.update(gp=hp["lazy_gp"], ada=hp["lazy_ada"])
     cfg.training.augment.update(p_init=hp["p_init"], kimg=hp["ada_kimg"])
     cfg.training.warmup.update(fade_kimg=hp["fade_kimg"], blur_init_sigma=hp["blur_init_sigma"],
@@ -362,3 +364,56 @@ def test_gradient_accumulation_equals_the_mean_of_the_chunks(hip_graph):
         out = two.step(it)
     assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
     assert int(next(iter(two.optim_G.state.values()))["step"]) == 5
+
+
+# ---------------------------------------------------------------------------- D's backward in two pieces
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_split_d_backward_equals_the_single_pass(hip_graph):
+    """training.overlap_d_reduce (the multi-GPU default): the D step runs as d_fb_head (forward, loss, backward of the
+    two Linear layers behind Discriminator's cut -- their gradients lie at the FRONT of the flat buffer and can be
+    exchanged at once) and d_fb_tail (the trunk's backward from the gradient at the cut).  Same weights, draws and reals
+    as a one-body trainer: every parameter's gradient must agree (the same kernels run in the same order; fp32 atomics
+    in the weight-gradient reductions are the only noise), eagerly and as two hipGraph replays; whole iterations then
+    run with finite scalars and both bodies live."""
+    from helpers import trainer_fixture_draws, trainer_fixture_reals
+    d = _load_trainer_fixture()
+    tag = "t."
+    one, hp, sdG, sdD = _fixture_trainer(d, tag, False)
+    two, _, _, _ = _fixture_trainer(d, tag, hip_graph, overlap_d_reduce=True)
+    assert two.split_d and not one.split_d
+    head = two.D.head_parameters()
+    assert two.d_sync.n_first == sum(p.numel() for p in head) > 0
+    assert all(a is b for a, b in zip(two.d_sync.params[:len(head)], head))
+    depth, mask = trainer_fixture_reals(tag, 1)
+    x = one.fetch_reals({"depth": depth.cuda(), "mask": mask.cuda()})["image"]
+    draws = trainer_fixture_draws(d, tag, 1)
+    for tr in (one, two):
+        _reset(tr, hp, sdG, sdD)
+        tr.set_draws(draws)
+        tr.x_real.copy_(x)
+    one._run("d_fb", one.d_fb, one.x_real, 0)
+    want = {n: p.grad.clone() for n, p in one.D.named_parameters()}
+    for rep in range(4 if hip_graph else 1):          # graphs: two warm runs, the captures, one replay
+        two.G.load_state_dict(sdG)
+        two.D.load_state_dict(sdD)
+        with torch.no_grad():
+            two.A.sign_cum.zero_()
+            two.A.n_pred_cum.zero_()
+        two.d_sync.flat.fill_(float("nan"))
+        two._run("d_fb_head", two.d_fb_head, two.x_real, 0)
+        n1 = two.d_sync.n_first
+        assert torch.isfinite(two.d_sync.flat[:n1]).all() and torch.isnan(two.d_sync.flat[n1:]).all()
+        two._run("d_fb_tail", two.d_fb_tail, 0)
+        two._link_graphs("d_fb_head", "d_fb_tail")
+    if hip_graph:
+        assert two._graphs.get("d_fb_head/inj") is not None and two._graphs.get("d_fb_tail/inj") is not None
+    for n, p in two.D.named_parameters():
+        err = float((p.grad - want[n]).abs().max() / (want[n].abs().max() + 1e-12))
+        assert err < 2e-5, (n, err)
+    two.set_draws(None)
+    for it in range(1, 6):
+        out = two.step(it)
+    assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
+    live = two.graphs_live()
+    if hip_graph:
+        assert {"d_fb_head", "d_fb_tail", "g_fb"} <= set(live) and all(live.values()), live

@@ -94,6 +94,68 @@ def test_two_rank_data_parallel_plumbing():
     assert r0[8] == r1[8] == (15.0, 0.0, 15.0)              # begin/collect: mean of (10, 20); untouched slice zeroed
 
 
+def _worker_segments(rank, world, tmp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{tmp}/init", world_size=world, rank=rank)
+    from gans import parallel
+    from gans.models.builder import build_discriminator
+    from helpers import small_cfg
+    torch.manual_seed(0)
+    D = build_discriminator(small_cfg().model.discriminator)
+    head = D.head_parameters()
+    sync = parallel.FlatGradSync(D, first=head)
+    n1 = sync.n_first
+    ok_layout = all(a is b for a, b in zip(sync.params, head)) and n1 == sum(p.numel() for p in head) \
+        and len({id(p) for p in sync.params}) == len(list(D.parameters()))
+    # the trainer's split D step: head gradients collected and sent first, the rest later; nothing may leak across
+    sync.begin()
+    for p in head:
+        p.grad = torch.full_like(p, float(rank + 1))
+    sync.flat.fill_(-7.0)
+    sync.collect(part="first")
+    untouched = float(sync.flat[n1:].max()) == -7.0 and all(p.grad is None for p in sync.params[len(head):])
+    h1 = sync.all_reduce(async_op=True, part="first")
+    for p in sync.params[len(head):]:
+        p.grad = torch.full_like(p, float(10 * (rank + 1)))
+    sync.collect(part="rest")
+    h2 = sync.all_reduce(async_op=True, part="rest")
+    sync.wait(h1)
+    sync.wait(h2)
+    vals = (float(sync.flat[:n1].min()), float(sync.flat[:n1].max()), float(sync.flat[n1:].min()), float(sync.flat[n1:].max()))
+    views = all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in D.parameters())
+    # accumulation into one segment only
+    sync.begin()
+    for p in head:
+        p.grad = torch.ones_like(p)
+    sync.collect(accumulate=True, scale=0.5, part="first")
+    acc = (float(sync.flat[0]), float(sync.flat[-1]))
+    q.put((rank, ok_layout, untouched, vals, views, acc, n1, sync.flat.numel()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_segmented_gradient_exchange():
+    """FlatGradSync(first=...): the head parameters of D (the Linear layers behind Discriminator's cut) lie at the
+    front of the flat buffer; the two segments are collected and reduced independently (the trainer sends the first
+    while the trunk's backward still runs: Trainer.d_fb_head / d_fb_tail)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = [ctx.Process(target=_worker_segments, args=(r, world, tmp, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2] and r[4]
+        assert r[3] == (1.5, 1.5, 15.0, 15.0)      # means of (1, 2) and (10, 20), each in its own segment
+        assert r[5] == (2.0, 15.0)                 # 1.5 + 0.5 * 1 in the first segment, the rest untouched
+        assert 0 < r[6] < r[7]
+
+
 def test_infinite_sampler_ranks_interleave_the_single_stream():
     """With a shared seed, rank r of n yields every n-th element of the one-replica stream
     (reference: gans/utils.py:238-271)."""
