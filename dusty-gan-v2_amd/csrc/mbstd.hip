@@ -16,6 +16,31 @@ struct MbGeom {
   int B, P, C, Cp, S, g, m, NS;
 };
 
+// N consecutive elements of T as floats (N * sizeof(T) is 16 or 32 bytes, 16-byte aligned)
+template <typename T, int N> __device__ __forceinline__ void ldN(const T* p, float (&f)[N]) {
+  constexpr int V = vec16<T>::N;
+#pragma unroll
+  for (int h = 0; h < N / V; ++h) {
+    vec16<T> v;
+    v.load(p + h * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) f[h * V + j] = v.get(j);
+  }
+}
+template <typename T, int N> __device__ __forceinline__ void stN(T* p, const float (&f)[N]) {
+  constexpr int V = vec16<T>::N;
+#pragma unroll
+  for (int h = 0; h < N / V; ++h) {
+    vec16<T> v;
+#pragma unroll
+    for (int j = 0; j < V; ++j) v.set(j, f[h * V + j]);
+    v.store(p + h * V);
+  }
+}
+template <typename TA, typename TB> struct mb_vn {
+  static constexpr int value = vec16<TA>::N > vec16<TB>::N ? vec16<TA>::N : vec16<TB>::N;
+};
+
 // partial[sm, split] = sum over this split's (p, c) positions of sd
 template <typename T>
 __global__ __launch_bounds__(256) void mbstd_partial_kernel(float* __restrict__ partial, const T* __restrict__ x, MbGeom q) {
@@ -58,40 +83,42 @@ __global__ __launch_bounds__(256) void mbstd_partial_kernel(float* __restrict__ 
   if (threadIdx.x == 0) partial[sm * q.NS + split] = t;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void mbstd_cat_kernel(T* __restrict__ out, const T* __restrict__ x,
+// TX -> TY: the cast of the reference's x.float() ahead of its fp32 epilogue (dusty_v2.py:394-395) rides in this pass
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void mbstd_cat_kernel(TY* __restrict__ out, const TX* __restrict__ x,
                                                         const float* __restrict__ partial, MbGeom q) {
-  constexpr int VN = vec16<T>::N;
+  constexpr int VN = mb_vn<TX, TY>::value;
   const int cvp = q.Cp / VN, cvx = q.C / VN;
   const int64_t total = (int64_t)q.B * q.P * cvp;
   const float inv = 1.f / ((float)q.P * q.C);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int cv = (int)(i % cvp);
     const int64_t bp = i / cvp;
-    vec16<T> o;
+    float o[VN];
     if (cv < cvx) {
-      o.load(x + bp * q.C + cv * VN);
+      ldN<TX, VN>(x + bp * q.C + cv * VN, o);
     } else {
-      o.raw = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < VN; ++j) o[j] = 0.f;
       if (cv == cvx) {
         const int b = (int)(bp / q.P);
         const int sg = b / q.m, mi = b - sg * q.m, s = sg / q.g;   // b = (s*g + gi)*m + mi
         float st = 0.f;
         for (int k = 0; k < q.NS; ++k) st += partial[(s * q.m + mi) * q.NS + k];
-        o.set(0, st * inv);
+        o[0] = st * inv;
       }
     }
-    o.store(out + bp * q.Cp + cv * VN);
+    stN<TY, VN>(out + bp * q.Cp + cv * VN, o);
   }
 }
 
 // gx[b, p, c] = gout[b, p, c] + gst[s, mi] / (P C) * (x_gi - mu) / (g sd),   gst = sum_{gi, p} gout[b, p, C]
-template <typename T>
-__global__ __launch_bounds__(256) void mbstd_bwd_kernel(T* __restrict__ gx, const T* __restrict__ gout,
-                                                        const T* __restrict__ x, MbGeom q) {
+template <typename TX, typename TG>
+__global__ __launch_bounds__(256) void mbstd_bwd_kernel(TX* __restrict__ gx, const TG* __restrict__ gout,
+                                                        const TX* __restrict__ x, MbGeom q) {
   __shared__ float red[16];
   __shared__ float s_gst;
-  constexpr int VN = vec16<T>::N;
+  constexpr int VN = mb_vn<TX, TG>::value;
   const int sm = blockIdx.x, split = blockIdx.y;
   const int s = sm / q.m, mi = sm - s * q.m;
   const int64_t PC = (int64_t)q.P * q.C;
@@ -110,7 +137,7 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(T* __restrict__ gx, cons
   for (int64_t v = (int64_t)split * 256 + threadIdx.x; v < nvec; v += (int64_t)q.NS * 256) {
     const int64_t p = v / cvx;
     const int cv = (int)(v - p * cvx);
-    vec16<T> a[MB_G];
+    float a[MB_G][VN];
     float mu[VN];
 #pragma unroll
     for (int j = 0; j < VN; ++j) mu[j] = 0.f;
@@ -118,9 +145,9 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(T* __restrict__ gx, cons
     for (int gi = 0; gi < MB_G; ++gi) {
       if (gi < q.g) {
         const int b = (s * q.g + gi) * q.m + mi;
-        a[gi].load(x + (int64_t)b * PC + v * VN);
+        ldN<TX, VN>(x + (int64_t)b * PC + v * VN, a[gi]);
 #pragma unroll
-        for (int j = 0; j < VN; ++j) mu[j] += a[gi].get(j);
+        for (int j = 0; j < VN; ++j) mu[j] += a[gi][j];
       }
     }
     const float ig = 1.f / q.g;
@@ -132,7 +159,7 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(T* __restrict__ gx, cons
 #pragma unroll
       for (int gi = 0; gi < MB_G; ++gi)
         if (gi < q.g) {
-          const float d = a[gi].get(j) - mu[j];
+          const float d = a[gi][j] - mu[j];
           var = fmaf(d, d, var);
         }
       coef[j] = k / sqrtf(var * ig + 1e-8f);
@@ -141,11 +168,11 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(T* __restrict__ gx, cons
     for (int gi = 0; gi < MB_G; ++gi) {
       if (gi < q.g) {
         const int b = (s * q.g + gi) * q.m + mi;
-        vec16<T> go, o;
-        go.load(gout + ((int64_t)b * q.P + p) * q.Cp + cv * VN);
+        float go[VN], o[VN];
+        ldN<TG, VN>(gout + ((int64_t)b * q.P + p) * q.Cp + cv * VN, go);
 #pragma unroll
-        for (int j = 0; j < VN; ++j) o.set(j, go.get(j) + coef[j] * (a[gi].get(j) - mu[j]));
-        o.store(gx + (int64_t)b * PC + v * VN);
+        for (int j = 0; j < VN; ++j) o[j] = go[j] + coef[j] * (a[gi][j] - mu[j]);
+        stN<TX, VN>(gx + (int64_t)b * PC + v * VN, o);
       }
     }
   }
@@ -166,34 +193,64 @@ int mb_splits(const MbGeom& q, int vn) {
 
 }  // namespace
 
-// x [B, P, C], out [B, P, Cp] (same dtype), scratch fp32 [>= 64 * B / group]; B = splits * group * m.
-extern "C" int dgv2_mbstd_cat_fwd(void* out, float* scratch, const void* x, int B, int P, int C, int Cp, int splits,
-                                  int group, int dtype, void* stream) {
+// x [B, P, C] (xdtype), out [B, P, Cp] (ydtype: the same, or fp32 from a bf16 x -- the epilogue's cast in the same
+// pass), scratch fp32 [>= 64 * B / group]; B = splits * group * m.
+extern "C" int dgv2_mbstd_cat_fwd_x(void* out, float* scratch, const void* x, int B, int P, int C, int Cp, int splits,
+                                    int group, int xdtype, int ydtype, void* stream) {
   if (!out || !scratch || !x || splits < 1 || group < 1 || B % (splits * group)) return DGV2_EINVAL;
+  if (xdtype != ydtype && !(xdtype == DGV2_BF16 && ydtype == DGV2_F32)) return DGV2_ENOTSUP;
   MbGeom q{B, P, C, Cp, splits, group, B / (splits * group), 1};
-  const int vn = dtype == DGV2_BF16 ? 8 : 4;
-  if (!mb_ok(q, vn) || !aligned16(out) || !aligned16(x)) return DGV2_EINVAL;
-  q.NS = mb_splits(q, vn);
+  const int vx = xdtype == DGV2_BF16 ? 8 : 4;
+  if (!mb_ok(q, vx) || !aligned16(out) || !aligned16(x)) return DGV2_EINVAL;
+  q.NS = mb_splits(q, vx);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(q.S * q.m, q.NS);
-  const int64_t total = (int64_t)B * P * (Cp / vn);
-  DGV2_DISPATCH_DTYPE(dtype, {
-    mbstd_partial_kernel<T><<<grid, 256, 0, st>>>(scratch, (const T*)x, q);
-    mbstd_cat_kernel<T><<<grid_for(total, 256, 4096), 256, 0, st>>>((T*)out, (const T*)x, scratch, q);
-  });
+  const int64_t total = (int64_t)B * P * (Cp / vx);
+  const int gc = grid_for(total, 256, 4096);
+  if (xdtype == DGV2_F32) {
+    mbstd_partial_kernel<float><<<grid, 256, 0, st>>>(scratch, (const float*)x, q);
+    mbstd_cat_kernel<float, float><<<gc, 256, 0, st>>>((float*)out, (const float*)x, scratch, q);
+  } else if (xdtype == DGV2_BF16) {
+    mbstd_partial_kernel<bf16_t><<<grid, 256, 0, st>>>(scratch, (const bf16_t*)x, q);
+    if (ydtype == DGV2_BF16)
+      mbstd_cat_kernel<bf16_t, bf16_t><<<gc, 256, 0, st>>>((bf16_t*)out, (const bf16_t*)x, scratch, q);
+    else
+      mbstd_cat_kernel<bf16_t, float><<<gc, 256, 0, st>>>((float*)out, (const bf16_t*)x, scratch, q);
+  } else {
+    return DGV2_EINVAL;
+  }
   DGV2_RETURN_LAST();
 }
 
-// gx [B, P, C] from gout [B, P, Cp] (gradient of the concatenated tensor; the padding channels carry none) and x.
-extern "C" int dgv2_mbstd_cat_bwd(void* gx, const void* gout, const void* x, int B, int P, int C, int Cp, int splits,
+extern "C" int dgv2_mbstd_cat_fwd(void* out, float* scratch, const void* x, int B, int P, int C, int Cp, int splits,
                                   int group, int dtype, void* stream) {
+  return dgv2_mbstd_cat_fwd_x(out, scratch, x, B, P, C, Cp, splits, group, dtype, dtype, stream);
+}
+
+// gx [B, P, C] (xdtype, as x) from gout [B, P, Cp] (gdtype: gradient of the concatenated tensor; the padding channels
+// carry none) and x.  gdtype == xdtype, or fp32 gout with bf16 x / gx (the adjoint of the fused cast).
+extern "C" int dgv2_mbstd_cat_bwd_x(void* gx, const void* gout, const void* x, int B, int P, int C, int Cp, int splits,
+                                    int group, int xdtype, int gdtype, void* stream) {
   if (!gx || !gout || !x || splits < 1 || group < 1 || B % (splits * group)) return DGV2_EINVAL;
+  if (xdtype != gdtype && !(xdtype == DGV2_BF16 && gdtype == DGV2_F32)) return DGV2_ENOTSUP;
   MbGeom q{B, P, C, Cp, splits, group, B / (splits * group), 1};
-  const int vn = dtype == DGV2_BF16 ? 8 : 4;
-  if (!mb_ok(q, vn) || !aligned16(gx) || !aligned16(gout) || !aligned16(x)) return DGV2_EINVAL;
-  q.NS = mb_splits(q, vn);
+  const int vx = xdtype == DGV2_BF16 ? 8 : 4;
+  if (!mb_ok(q, vx) || !aligned16(gx) || !aligned16(gout) || !aligned16(x)) return DGV2_EINVAL;
+  q.NS = mb_splits(q, vx);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(q.S * q.m, q.NS);
-  DGV2_DISPATCH_DTYPE(dtype, { mbstd_bwd_kernel<T><<<grid, 256, 0, st>>>((T*)gx, (const T*)gout, (const T*)x, q); });
+  if (xdtype == DGV2_F32)
+    mbstd_bwd_kernel<float, float><<<grid, 256, 0, st>>>((float*)gx, (const float*)gout, (const float*)x, q);
+  else if (xdtype == DGV2_BF16 && gdtype == DGV2_BF16)
+    mbstd_bwd_kernel<bf16_t, bf16_t><<<grid, 256, 0, st>>>((bf16_t*)gx, (const bf16_t*)gout, (const bf16_t*)x, q);
+  else if (xdtype == DGV2_BF16)
+    mbstd_bwd_kernel<bf16_t, float><<<grid, 256, 0, st>>>((bf16_t*)gx, (const float*)gout, (const bf16_t*)x, q);
+  else
+    return DGV2_EINVAL;
   DGV2_RETURN_LAST();
+}
+
+extern "C" int dgv2_mbstd_cat_bwd(void* gx, const void* gout, const void* x, int B, int P, int C, int Cp, int splits,
+                                  int group, int dtype, void* stream) {
+  return dgv2_mbstd_cat_bwd_x(gx, gout, x, B, P, C, Cp, splits, group, dtype, dtype, stream);
 }

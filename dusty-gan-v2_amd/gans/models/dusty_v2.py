@@ -806,18 +806,19 @@ class Discriminator(nn.Module):
         mb, conv, act1, _, lin1, act2, lin2 = self.epilogue
         # fp32 island of the reference (dusty_v2.py:394-395) unless epilogue_dtype == "bf16" was asked for
         edt = self._epilogue_dtype()
-        x = x.to(edt)
         cin = x.shape[3] + mb.features
         vec = 32 if edt == LOW else 16
         cpad = (cin + vec - 1) // vec * vec  # whole 64-byte K-steps for the direct conv engine
-        if (not double_backward and x.dtype == edt and cpad > x.shape[3]
-                and native.mbstd_cat_ok(x, mb.group, splits, mb.features, cpad)):
-            # statistic in fp32 on the stored values (= x.float() of the reference), concat + padding in the same pass
-            x = native.mbstd_cat(x, mb.group, splits, cpad)
+        if (not double_backward and cpad > x.shape[3]
+                and native.mbstd_cat_ok(x, mb.group, splits, mb.features, cpad, out_dtype=edt)):
+            # statistic in fp32 on the stored values (= x.float() of the reference), concat + padding and the cast to
+            # the epilogue's dtype in the same pass
+            x = native.mbstd_cat(x, mb.group, splits, cpad, out_dtype=edt)
         else:
-            x = mb.forward_cl(x.float(), pad_to=cpad, splits=splits).to(edt)
+            x = mb.forward_cl(x.to(edt).float(), pad_to=cpad, splits=splits).to(edt)
         x = conv.forward_cl(x, pad_in_to=cpad, act=act1, bank=bank)
-        x = ops.from_cl(x).flatten(1)  # NCHW flatten order of the reference's nn.Flatten
+        # NCHW flatten order of the reference's nn.Flatten
+        x = native.flatten_nchw(x) if (x.is_cuda and not double_backward) else ops.from_cl(x).flatten(1)
         if cut:
             leaf = x.detach().requires_grad_(True)
             self._cut = (x, leaf)

@@ -408,11 +408,32 @@ def linear_low(x, weight, scale):
     return _LinearLow.apply(x, weight, float(scale))
 
 
+_X3 = os.environ.get("DGV2_NO_GEMM_X3") is None   # A/B switch for benchmarking
+
+
+def gemm_x3(a, b, a_trans, b_trans, I, J, T, scale=1.0, splits=1, out=None):
+    """C [I, J] = scale * sum_t A(i, t) B(j, t) in fp32-equivalent arithmetic on the bf16 matrix cores
+    (dgv2_gemm_x3: three-plane split, six products).  a / b fp32, contiguous 2-D; *_trans: the operand is stored
+    [T, rows].  None when the shape is not supported."""
+    if out is None:
+        out = torch.empty((I, J), device=a.device, dtype=torch.float32)
+    scratch = torch.empty(splits * I * J, device=a.device, dtype=torch.float32) if splits > 1 else None
+    N.check(a, b, out)
+    ok = N.try_call("dgv2_gemm_x3", N.ptr(out), N.ptr(scratch), 0 if scratch is None else scratch.numel(), N.ptr(a),
+                    N.ptr(b), I, J, T, int(a_trans), int(b_trans), a.shape[1], b.shape[1], J, splits, float(scale),
+                    N.stream())
+    return out if ok else None
+
+
 class _LinearF32(Function):
     """y = (x @ W^T) * scale in fp32 for the 65536 -> 512 Linear of the discriminator's fp32 epilogue
-    (dusty_v2.py:381-383,394-395).  Forward: a skinny GEMM (M = batch) over K = 65536 runs the library's single-pass
-    kernel at 28 TFLOP/s (308 us at B = 128) because only 16 output tiles exist; as S = 32 strided-batched partial
-    GEMMs + one sum it fills the chip.  Backward: plain GEMMs (already near the fp32 MFMA rate)."""
+    (dusty_v2.py:381-383,394-395).  The three GEMMs run on the bf16 matrix cores through the three-plane split of
+    dgv2_gemm_x3 (fp32-equivalent: its error is below what the library's fp32-MFMA GEMM leaves on the same operands),
+    the forward as split-K over the chip.  Measured (scripts/mb_linear_x3.py, M = 128): forward 84-88 us (library
+    split-K bmm + sum: 80), data gradient 77 (76), weight gradient 93 (89) -- parity, not a win: six bf16 products at the
+    ~1.5 GHz the part holds under bf16 MFMA load cost about what one fp32 product costs at its higher fp32-MFMA clock.
+    What it buys: the weight gradient is written straight into the parameter's slice of the flat gradient buffer when
+    FlatGradSync offers one (`_dgv2_grad_out`: no 268 MB pack copy), and no library GEMM in D's step."""
 
     @staticmethod
     def forward(ctx, x, weight, scale):
@@ -420,14 +441,20 @@ class _LinearF32(Function):
         w = weight.detach()
         Bn, K = x.shape
         O = w.shape[0]
-        S = 32
-        if K % (S * 8) == 0 and K >= 8192:
-            kc = K // S
-            part = torch.bmm(x.view(Bn, S, kc).transpose(0, 1), w.view(O, S, kc).permute(1, 2, 0))
-            y = part.sum(0)
-        else:
-            y = torch.mm(x, w.t())
-        y.mul_(scale)
+        y = None
+        # (at a batch of 64 the 64-row tile halves the MFMAs per fragment read: 68 us against the library's 43 -- that
+        # shape keeps the library's split-K form)
+        if _X3 and Bn % 128 == 0 and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous():
+            y = gemm_x3(x, w, False, False, Bn, O, K, scale=scale, splits=max(1, 256 // max(1, O // 128)))
+        if y is None:
+            S = 32
+            if K % (S * 8) == 0 and K >= 8192:
+                kc = K // S
+                part = torch.bmm(x.view(Bn, S, kc).transpose(0, 1), w.view(O, S, kc).permute(1, 2, 0))
+                y = part.sum(0)
+            else:
+                y = torch.mm(x, w.t())
+            y.mul_(scale)
         ctx.save_for_backward(x, weight)
         ctx.scale = scale
         return y
@@ -435,11 +462,26 @@ class _LinearF32(Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        g = gy * ctx.scale
         if torch.is_grad_enabled():   # create_graph=True (R1): differentiable ops
+            g = gy * ctx.scale
             return g @ weight, g.t() @ x, None
-        gx = torch.mm(g, weight.detach()) if ctx.needs_input_grad[0] else None
-        gw = torch.mm(g.t(), x) if ctx.needs_input_grad[1] else None
+        Bn, K = x.shape
+        O = weight.shape[0]
+        gx = gw = None
+        g = gy.contiguous()
+        w = weight.detach()
+        use = _X3 and g.dtype == torch.float32 and w.is_contiguous()
+        if ctx.needs_input_grad[0]:
+            gx = gemm_x3(g, w, False, True, Bn, K, O, scale=ctx.scale) if use else None
+            if gx is None:
+                gx = torch.mm(g * ctx.scale, w)
+        if ctx.needs_input_grad[1]:
+            out = getattr(weight, "_dgv2_grad_out", None)
+            if out is not None:
+                out = out.view_as(out)   # a fresh alias: autograd adopts a gradient tensor nobody else holds
+            gw = gemm_x3(g, x, True, True, O, K, Bn, scale=ctx.scale, out=out) if use else None
+            if gw is None:
+                gw = torch.mm((g * ctx.scale).t(), x)
         return gx, gw, None
 
 
@@ -448,26 +490,29 @@ def linear_f32(x, weight, scale):
 
 
 class _MbstdCat(Function):
-    """[x | minibatch-stddev statistic | zero padding] (dgv2_mbstd_cat_fwd/_bwd): MinibatchStdDev + concat of the
-    discriminator epilogue (common.py:226-250) in two launches forward and one backward; first order only."""
+    """[x | minibatch-stddev statistic | zero padding] (dgv2_mbstd_cat_fwd_x/_bwd_x): MinibatchStdDev + concat of the
+    discriminator epilogue (common.py:226-250) in two launches forward and one backward; first order only.
+    out_dtype fp32 on a bf16 x: the reference's x.float() ahead of its fp32 epilogue (dusty_v2.py:394-395) happens in
+    the same pass (and its adjoint, the cast of the gradient back to bf16, in the backward kernel)."""
 
     @staticmethod
-    def forward(ctx, x, group, splits, cpad):
+    def forward(ctx, x, group, splits, cpad, out_dtype):
         x = x.contiguous()
         N.check(x)
         B, H, W, C = x.shape
-        out = torch.empty((B, H, W, cpad), device=x.device, dtype=x.dtype)
+        out_dtype = x.dtype if out_dtype is None else out_dtype
+        out = torch.empty((B, H, W, cpad), device=x.device, dtype=out_dtype)
         scratch = torch.empty(64 * max(1, B // group), device=x.device, dtype=torch.float32)
-        N.call("dgv2_mbstd_cat_fwd", N.ptr(out), N.ptr(scratch), N.ptr(x), B, H * W, C, cpad, splits, group, _dt(x),
-               N.stream())
+        N.call("dgv2_mbstd_cat_fwd_x", N.ptr(out), N.ptr(scratch), N.ptr(x), B, H * W, C, cpad, splits, group, _dt(x),
+               _dt(out), N.stream())
         ctx.save_for_backward(x)
-        ctx.cfg = (group, splits, cpad)
+        ctx.cfg = (group, splits, cpad, out_dtype)
         return out
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        group, splits, cpad = ctx.cfg
+        group, splits, cpad, out_dtype = ctx.cfg
         B, H, W, C = x.shape
         if torch.is_grad_enabled():
             # create_graph=True (e.g. an R1 penalty taken through this path): the same gradient from differentiable ops
@@ -478,25 +523,59 @@ class _MbstdCat(Function):
             sd = torch.sqrt((d * d).mean(1, keepdim=True) + 1e-8)
             gst = gf[..., C].reshape(splits, group, m, H * W).sum(dim=(1, 3))
             term = gst[:, None, :, None, None, None] / float(H * W * C) * d / (group * sd)
-            return (gf[..., :C] + term.reshape(B, H, W, C)).to(x.dtype), None, None, None
-        g = g.contiguous().to(x.dtype)
+            return (gf[..., :C] + term.reshape(B, H, W, C)).to(x.dtype), None, None, None, None
+        g = g.contiguous().to(out_dtype)
         gx = torch.empty_like(x)
-        N.call("dgv2_mbstd_cat_bwd", N.ptr(gx), N.ptr(g), N.ptr(x), B, H * W, C, cpad, splits, group, _dt(x), N.stream())
-        return gx, None, None, None
+        N.call("dgv2_mbstd_cat_bwd_x", N.ptr(gx), N.ptr(g), N.ptr(x), B, H * W, C, cpad, splits, group, _dt(x), _dt(g),
+               N.stream())
+        return gx, None, None, None, None
 
 
-def mbstd_cat_ok(x, group, splits, features, cpad):
+def mbstd_cat_ok(x, group, splits, features, cpad, out_dtype=None):
     vn = 8 if x.dtype == torch.bfloat16 else 4
     B, C = x.shape[0], x.shape[3]
     g = min(B // splits, group)
+    mixed_ok = out_dtype in (None, x.dtype) or (x.dtype == torch.bfloat16 and out_dtype == torch.float32)
     return (x.is_cuda and features == 1 and x.dtype in (torch.bfloat16, torch.float32) and C % vn == 0 and cpad % vn == 0
-            and cpad > C and 1 <= g <= 8 and B % (splits * g) == 0)
+            and cpad > C and 1 <= g <= 8 and B % (splits * g) == 0 and mixed_ok)
 
 
-def mbstd_cat(x, group, splits, cpad):
-    """x [B,H,W,C] -> [B,H,W,cpad]: x, then the per-sample minibatch-stddev statistic in channel C, then zeros."""
+def mbstd_cat(x, group, splits, cpad, out_dtype=None):
+    """x [B,H,W,C] -> [B,H,W,cpad] (out_dtype, default x's): x, then the per-sample minibatch-stddev statistic in
+    channel C, then zeros."""
     g = min(x.shape[0] // splits, group)
-    return _MbstdCat.apply(x, g, splits, cpad)
+    return _MbstdCat.apply(x, g, splits, cpad, out_dtype)
+
+
+class _FlattenNCHW(Function):
+    """[B,H,W,C] -> [B, C*H*W] in the NCHW order of the reference's nn.Flatten (dusty_v2.py:380): a batched tile
+    transpose (dgv2_transpose_list) each way instead of a strided permute copy."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        out = torch.empty((B, C * H * W), device=x.device, dtype=x.dtype)
+        N.check(x)
+        N.call("dgv2_transpose_list", _ptr_array([out]), _ptr_array([x]), _int_array([H * W]), _int_array([C]),
+               _int_array([C]), 1, B, x.element_size(), N.stream())
+        ctx.shape = (B, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C = ctx.shape
+        if torch.is_grad_enabled():
+            return g.reshape(B, C, H, W).permute(0, 2, 3, 1).contiguous()
+        g = g.contiguous()
+        gx = torch.empty((B, H, W, C), device=g.device, dtype=g.dtype)
+        N.call("dgv2_transpose_list", _ptr_array([gx]), _ptr_array([g]), _int_array([C]), _int_array([H * W]),
+               _int_array([H * W]), 1, B, g.element_size(), N.stream())
+        return gx
+
+
+def flatten_nchw(x):
+    return _FlattenNCHW.apply(x)
 
 
 class _ScaledHandle(Function):

@@ -64,12 +64,16 @@ class FlatGradSync:
             off += p.numel()
         return views
 
-    def begin(self):
+    def begin(self, direct=True):
         """Start of a forward/backward body: detach the views so that autograd hands each parameter a fresh
         gradient tensor instead of read-modify-writing the flat buffer (one add_ launch per parameter, ~140 per
-        step, plus the zero fill)."""
-        for p in self.params:
+        step, plus the zero fill).  direct: backward kernels that can write a parameter's whole gradient themselves
+        (the 134 MB weight gradient of D's Linear) are offered its slice of the flat buffer as `p._dgv2_grad_out`;
+        collect() then finds the gradient already in place.  Not when this body ACCUMULATES into the buffer."""
+        views = self._views() if direct else None
+        for i, p in enumerate(self.params):
             p.grad = None
+            p._dgv2_grad_out = views[i] if direct else None
 
     def _part(self, part):
         """(parameter range, element range) of a segment: None = everything, "first" / "rest" as laid out by __init__."""
@@ -94,19 +98,23 @@ class FlatGradSync:
         self._collect(views, params, accumulate, scale)
 
     def _collect(self, views, params, accumulate, scale):
-        dst = [v for v, p in zip(views, params) if p.grad is not None]
-        src = [p.grad for p in params if p.grad is not None]
+        inplace = [v for v, p in zip(views, params) if p.grad is not None and p.grad.data_ptr() == v.data_ptr()]
+        dst = [v for v, p in zip(views, params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        src = [p.grad for v, p in zip(views, params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if accumulate and inplace:
+            raise RuntimeError("a backward wrote into the flat gradient buffer of an accumulating body")
         if dst:
             if accumulate:
                 torch._foreach_add_(dst, src, alpha=scale)
             else:
                 torch._foreach_copy_(dst, src)
-                if scale != 1.0:
-                    torch._foreach_mul_(dst, scale)
+        if not accumulate and scale != 1.0 and (dst or inplace):
+            torch._foreach_mul_(dst + inplace, scale)
         for v, p in zip(views, params):
             if p.grad is None and not accumulate:
                 v.zero_()
             p.grad = v
+            p._dgv2_grad_out = None
 
     def rebind(self):
         """Re-attach the views (after optimizer.zero_grad(set_to_none=True) or a state-dict load)."""

@@ -275,7 +275,7 @@ class Trainer:
     # collectives stay ordinary stream work between them.
     def g_fb(self, j, scalars):
         set_requires_grad(self.G, True)
-        self.g_sync.begin()
+        self.g_sync.begin(direct=j == 0)
         z = self._z("g")
         x_fake = self.G(z, noise=self._g_noise("g"), **self.auxin)["image"]
         y_fake = self.D(self.A(self.warmup(x_fake, self._draw("g.keep")), draws=self._ada("g.ada")))
@@ -290,7 +290,7 @@ class Trainer:
 
     def d_fb(self, x_real, j, scalars, cut=False):
         set_requires_grad(self.D, True)
-        self.d_sync.begin()
+        self.d_sync.begin(direct=j == 0)
         z = self._z("d")
         with torch.no_grad():
             x_fake = self.G(z, noise=self._g_noise("d"), **self.auxin)["image"]
@@ -336,7 +336,7 @@ class Trainer:
     def r1_fb(self, x_real, j, scalars):
         """lazy R1 (reference: trainer.py:419-451): double backward through D and ADA."""
         set_requires_grad(self.D, True)
-        self.d_sync.begin()
+        self.d_sync.begin(direct=False)
         x = x_real.detach().requires_grad_(True)
         y_real = self.D(self.A(self.warmup(x, self._draw("r1.keep")), draws=self._ada("r1.ada")), double_backward=True)
         (grads,) = torch.autograd.grad(outputs=[y_real.sum()], inputs=[x], create_graph=True)
@@ -353,7 +353,7 @@ class Trainer:
         lengths |J^T y| per (sample, style), their running mean pl_ema (lerp 0.01), penalty mean((|J^T y| - pl_ema)^2)
         weighted by loss.pl * lazy.pl; its backward is the double backward through the generator."""
         set_requires_grad(self.G, True)
-        self.g_sync.begin()
+        self.g_sync.begin(direct=False)
         B_pl = max(self.B // 2, 1)
         z = self._z("pl")[:B_pl]
         w = self.G.forward_mapping(z)

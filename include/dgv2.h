@@ -390,6 +390,25 @@ int dgv2_mbstd_cat_fwd(void* out, float* scratch, const void* x, int B, int P, i
                        int group, int dtype, void* stream);
 int dgv2_mbstd_cat_bwd(void* gx, const void* gout, const void* x, int B, int P, int C, int Cp, int splits,
                        int group, int dtype, void* stream);
+/* C[i, j] = scale * sum_{t < T} A(i, t) B(j, t) in fp32-equivalent arithmetic on the bf16 matrix cores: every operand
+ * value is split into three bf16 planes (x = h + m + l, residual <= 2^-26 |x|) while its tile is staged into LDS and a
+ * product is taken as six bf16 products with fp32 accumulation (the dropped terms are below 2^-25 of the product).
+ * a_trans == 0: A [I, lda], t contiguous; != 0: A [T, lda], i contiguous (same for B).  C [I, ldo].  I % 64 == 0,
+ * J % 128 == 0, T % 32 == 0, lda / ldb % 4 == 0 (DGV2_ENOTSUP otherwise).  splits > 1: split-K through
+ * scratch [splits * I * J] (ldo == J) and a summing launch.
+ * replaces: F.linear and its autograd GEMMs for EqualLR(nn.Linear(65536, 512)) of the discriminator's fp32 epilogue,
+ *   gans/models/dusty_v2.py:381-383,394-395 (forward: both direct, split-K; dgrad: W transposed; wgrad: both
+ *   transposed). */
+int dgv2_gemm_x3(float* c, float* scratch, int64_t scratch_elems, const float* a, const float* b, int I, int J,
+                 int64_t T, int a_trans, int b_trans, int64_t lda, int64_t ldb, int64_t ldo, int splits, float scale,
+                 void* stream);
+/* The same with the epilogue's cast folded in: x / gx in xdtype, out (ydtype) / gout (gdtype) the same or fp32 for a
+ * bf16 x -- x.float() of the reference's fp32 epilogue (gans/models/dusty_v2.py:394-395) and its adjoint without their
+ * own passes over the activation. */
+int dgv2_mbstd_cat_fwd_x(void* out, float* scratch, const void* x, int B, int P, int C, int Cp, int splits, int group,
+                         int xdtype, int ydtype, void* stream);
+int dgv2_mbstd_cat_bwd_x(void* gx, const void* gout, const void* x, int B, int P, int C, int Cp, int splits, int group,
+                         int xdtype, int gdtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * dense convolution with ring padding (discriminator)

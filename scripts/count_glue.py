@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dusty-gan-v2_amd")]
 import torch
 import bench
-args = argparse.Namespace(batch_per_gpu=64, dtype="bf16", ada_p=0.6, no_graph=True)
+args = argparse.Namespace(batch_per_gpu=64, dtype="bf16", ada_p=0.6, no_graph=True, res="64x512", d_epilogue="fp32")
 from gans.trainer import Trainer
 from gans.utils import init_random_seed
 init_random_seed(0, 0)

@@ -5,7 +5,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "dusty-gan-v2_amd")]
 import torch
 import bench
 from torch.profiler import profile, ProfilerActivity
-args = argparse.Namespace(batch_per_gpu=64, dtype="bf16", ada_p=0.6, no_graph=True)
+args = argparse.Namespace(batch_per_gpu=64, dtype="bf16", ada_p=0.6, no_graph=True, res="64x512", d_epilogue="fp32")
 from gans.trainer import Trainer
 from gans.utils import init_random_seed
 init_random_seed(0, 0)
@@ -30,6 +30,10 @@ print(f"total device us {tot:.0f}")
 for t, c, k, sh in rows[:90]:
     print(f"{t:9.0f}us x{c:4d} {k[:44]:44s} {sh}")
 
+print("---- every ATen op with device time, by shape ----")
+for t, c, k, sh in rows:
+    if k.startswith("aten::"):
+        print(f"{t:9.0f}us x{c:4d} {k[:28]:28s} {sh}")
 print("---- ATen ops by name ----")
 agg = {}
 for e in prof.key_averages():

@@ -325,6 +325,106 @@ def test_mbstd_cat_matches_composed_reference(nat, dtype, tol, B, splits, group)
     assert_rel(gx.float().cpu(), gref, tol, "gx")
 
 
+@pytest.mark.parametrize("B,splits,group", [(8, 1, 4), (16, 2, 4)])
+def test_mbstd_cat_with_the_epilogue_cast_folded_in(nat, B, splits, group):
+    """dgv2_mbstd_cat_fwd_x/_bwd_x with a bf16 x and fp32 out (x.float() of the reference's fp32 epilogue,
+    dusty_v2.py:394-395, in the same pass; its adjoint -- the gradient back in bf16 -- in the backward kernel): equal to
+    the cast followed by the fp32 kernels (values exact, statistic to summation order), one bf16 rounding backward."""
+    g = torch.Generator().manual_seed(19)
+    H, W, C, cpad = 4, 8, 16, 32
+    x = torch.randn(B, H, W, C, generator=g).to(DEV).bfloat16()
+    gout = torch.randn(B, H, W, cpad, generator=g).to(DEV)
+    xf = x.float().requires_grad_(True)
+    want = nat.mbstd_cat(xf, group, splits, cpad)
+    (gwant,) = torch.autograd.grad(want, xf, gout)
+    xd = x.clone().requires_grad_(True)
+    assert nat.mbstd_cat_ok(xd, group, splits, 1, cpad, out_dtype=torch.float32)
+    out = nat.mbstd_cat(xd, group, splits, cpad, out_dtype=torch.float32)
+    # the values and the padding are exact; the statistic sums the same terms in another order (8 instead of 4 per lane)
+    assert out.dtype == torch.float32 and torch.equal(out[..., :C], want[..., :C])
+    assert torch.equal(out[..., C + 1:], want[..., C + 1:])
+    assert_rel(out[..., C].detach().cpu(), want[..., C].detach().cpu(), 1e-6, "statistic")
+    (gx,) = torch.autograd.grad(out, xd, gout)
+    assert gx.dtype == torch.bfloat16
+    assert_rel(gx.float().cpu(), gwant.cpu(), 4e-3, "gx (one bf16 rounding)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flatten_nchw_is_the_reference_flatten(nat, dtype):
+    """native.flatten_nchw ([B,H,W,C] -> the NCHW order of nn.Flatten, dusty_v2.py:380) and its adjoint: tile transposes
+    instead of strided permute copies -- exact."""
+    g = torch.Generator().manual_seed(2)
+    B, H, W, C = 5, 4, 32, 72
+    x = torch.randn(B, H, W, C, generator=g).to(DEV).to(dtype).requires_grad_(True)
+    y = nat.flatten_nchw(x)
+    assert torch.equal(y, x.permute(0, 3, 1, 2).flatten(1))
+    gy = torch.randn(B, C * H * W, generator=g).to(DEV).to(dtype)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    assert torch.equal(gx, gy.reshape(B, C, H, W).permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("a_trans,b_trans,I,J,T,splits", [
+    (False, False, 128, 512, 4096, 16),     # the Linear's forward: both K-contiguous, split-K
+    (False, False, 64, 128, 96, 1),
+    (False, True, 128, 1024, 512, 1),       # data gradient: W as the transposed operand
+    (False, True, 64, 256, 64, 1),
+    (True, True, 512, 1024, 128, 1),        # weight gradient: both transposed
+    (True, True, 128, 128, 64, 1),
+    (True, False, 64, 128, 160, 3),
+])
+def test_gemm_x3_is_fp32_equivalent(nat, a_trans, b_trans, I, J, T, splits):
+    """dgv2_gemm_x3 (fp32 GEMM on the bf16 matrix cores: three-plane split, six products per multiply) against float64
+    on data with a wide dynamic range (e^(2 N(0,1)) magnitudes), the error taken per element relative to sum |a||b|:
+    it must not exceed what the library's fp32-MFMA GEMM leaves on the same operands (measured: 0.7e-6 vs 1.1e-6 at
+    T = 4096, both a few 2^-24 -- the matrix cores align the products of one instruction to the largest of them).
+    Also bit-exact on small integers."""
+    g = torch.Generator().manual_seed(I + J + int(T))
+    def mk(rows, trans, exact):
+        shape = (T, rows) if trans else (rows, T)
+        if exact:
+            return torch.randint(-3, 4, shape, generator=g).float().to(DEV)
+        return (torch.randn(shape, generator=g) * torch.exp(2.0 * torch.randn(shape, generator=g))).to(DEV)
+    for exact in (True, False):
+        a, b = mk(I, a_trans, exact), mk(J, b_trans, exact)
+        c = nat.gemm_x3(a, b, a_trans, b_trans, I, J, T, scale=0.5, splits=splits)
+        assert c is not None
+        A = (a.t() if a_trans else a).double()
+        Bm = (b.t() if b_trans else b).double()
+        want = 0.5 * A @ Bm.t()
+        if exact:
+            assert torch.equal(c.double(), want)
+        else:
+            bound = 0.5 * A.abs() @ Bm.abs().t()
+            err = float(((c.double() - want).abs() / bound).max())
+            lib = 0.5 * ((a.t() if a_trans else a) @ (b.t() if b_trans else b).t())     # the library's fp32 GEMM
+            err_lib = float(((lib.double() - want).abs() / bound).max())
+            print(f"gemm_x3 {a_trans} {b_trans} {I}x{J}x{T}: err / sum|a||b| = {err:.2e} (library fp32: {err_lib:.2e})")
+            assert err < 1.5 * err_lib + 4 * 2.0 ** -24, (err, err_lib)
+    # unsupported shapes are refused, not mis-computed
+    assert nat.gemm_x3(torch.zeros(48, 64, device=DEV), torch.zeros(128, 64, device=DEV), False, False, 48, 128, 64) is None
+
+
+def test_linear_f32_matches_float64(nat):
+    """native.linear_f32 (EqualLR Linear of D's fp32 epilogue, dusty_v2.py:381-383) forward / data gradient / weight
+    gradient through dgv2_gemm_x3 against float64, incl. the weight gradient written in place into a caller-provided
+    slice (FlatGradSync's `_dgv2_grad_out`)."""
+    g = torch.Generator().manual_seed(4)
+    Bn, K, O = 64, 8192, 128
+    x = torch.randn(Bn, K, generator=g).to(DEV).requires_grad_(True)
+    w = torch.nn.Parameter(torch.randn(O, K, generator=g).to(DEV))
+    gy = torch.randn(Bn, O, generator=g).to(DEV)
+    scale = 1.0 / math.sqrt(K)
+    slot = torch.full((O, K), float("nan"), device=DEV)
+    w._dgv2_grad_out = slot
+    y = nat.linear_f32(x, w, scale)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+    assert gw.data_ptr() == slot.data_ptr()
+    xd, wd, gd = x.detach().double(), w.detach().double(), gy.double()
+    assert_rel(y.detach().cpu(), (xd @ wd.t() * scale).cpu(), 2e-6, "y")
+    assert_rel(gx.cpu(), (gd @ wd * scale).cpu(), 2e-6, "gx")
+    assert_rel(gw.cpu(), (gd.t() @ xd * scale).cpu(), 2e-6, "gw")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_adjoint_resample_fused_with_activation_backward(nat, dtype):
     """dgv2_resample_tab_actbwd (adjoint blur/down + bias/leaky-ReLU backward + bias gradient in one pass) against the
