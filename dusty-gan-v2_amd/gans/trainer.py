@@ -13,6 +13,7 @@ What is different is the plumbing, chosen for MI355X:
   * real batches: synthetic generator in HBM when no dataset is present (benchmarks).
 """
 import copy
+import gc
 import os
 from collections import defaultdict
 
@@ -414,6 +415,11 @@ class Trainer:
             # were captured (lazy R1, shared optimizer graph), which a shared pool does not allow; HBM is
             # not the constraint here (288 GB)
             # thread_local: API calls of other threads (the RCCL watchdog polls events) must not invalidate the capture
+            # no cyclic garbage collection while the stream is capturing: a collection (it can start on the autograd
+            # thread) that frees device memory or a CUDAGraph of an earlier, unreachable Trainer issues calls the
+            # capture forbids -- the destructor throws and the process aborts (torch.cuda.graph collects once on entry)
+            gc_was_enabled = gc.isenabled()
+            gc.disable()
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     fn(*args, scalars)
@@ -422,9 +428,14 @@ class Trainer:
                 torch.cuda.synchronize()
                 warnings.warn(f"hipGraph capture of '{name}' failed ({type(e).__name__}: {e}); running it eagerly")
                 self._graphs[name] = None
+                if gc_was_enabled:
+                    gc.enable()
                 scalars = {}
                 fn(*args, scalars)
                 return scalars
+            finally:
+                if gc_was_enabled:
+                    gc.enable()
             self._graphs[name] = (g, scalars)
         if self._graphs[name] is None:
             scalars = {}
