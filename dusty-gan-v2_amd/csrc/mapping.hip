@@ -130,139 +130,6 @@ __global__ __launch_bounds__(64) void map_bwd_w_kernel(float* __restrict__ gw, f
   if (gb && k == 0) gb[o] = sb * c2;
 }
 
-// ------------------------------------------------------------------------------------------------
-// The style affines of every modulated conv in one launch (reference: the EqualLR(nn.Linear(mod_ch, in_ch)) inside each
-// ModConv2d, gans/models/ops/style.py:60-66,88-90): s_l[b, i] = scale * sum_k ws[b, kidx_l, k] W_l[i, k] + bias_l[i]
-// for the L = 19 layers of the generator, weights and outputs through pointer tables (no packed copy of the 40 MB of
-// weights, no unpack of the results).  Backward: weight / bias gradients per layer in one launch, the gradient of ws in
-// another (summed over the layers that read the same style vector).
-// ------------------------------------------------------------------------------------------------
-constexpr int SA_MAX = 48;
-
-struct SAArgs {
-  const float* w[SA_MAX];   // [I_l, K]
-  const float* b[SA_MAX];   // [I_l]
-  float* out[SA_MAX];       // forward: s_l [B, I_l]; backward: gW_l [I_l, K]
-  float* out2[SA_MAX];      // backward: gb_l [I_l]
-  const float* gs[SA_MAX];  // backward: gradient of s_l [B, I_l]
-  int I[SA_MAX], kidx[SA_MAX];
-  int L, B, S, K;
-  float scale;
-};
-
-// grid (ceil(Imax / 64), ceil(B / 4), L), 64 threads: thread = output channel, the samples' style rows in LDS
-__global__ __launch_bounds__(64) void style_affine_fwd_kernel(const float* __restrict__ ws, SAArgs a_by_value) {
-  const SAArgs& a = *(const SAArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(void*));
-  extern __shared__ __attribute__((aligned(16))) float xs[];   // [MAP_SPB][K]
-  const int l = blockIdx.z, lane = threadIdx.x;
-  const int I = a.I[l], K = a.K;
-  if ((int)blockIdx.x * 64 >= I) return;
-  const int s0 = blockIdx.y * MAP_SPB;
-#pragma unroll
-  for (int s = 0; s < MAP_SPB; ++s) {
-    const int sb = s0 + s < a.B ? s0 + s : a.B - 1;
-    const float* src = ws + ((int64_t)sb * a.S + a.kidx[l]) * K;
-    for (int k = lane * 4; k < K; k += 256) *reinterpret_cast<float4*>(xs + s * K + k) = *reinterpret_cast<const float4*>(src + k);
-  }
-  __syncthreads();
-  const int i = blockIdx.x * 64 + lane;
-  if (i >= I) return;
-  float acc[MAP_SPB];
-#pragma unroll
-  for (int s = 0; s < MAP_SPB; ++s) acc[s] = 0.f;
-  const float* wr = a.w[l] + (int64_t)i * K;
-  for (int k = 0; k < K; k += 4) {
-    const float4 wv = *reinterpret_cast<const float4*>(wr + k);
-#pragma unroll
-    for (int s = 0; s < MAP_SPB; ++s) {
-      const float4 xv = *reinterpret_cast<const float4*>(xs + s * K + k);
-      acc[s] = fmaf(wv.x, xv.x, acc[s]);
-      acc[s] = fmaf(wv.y, xv.y, acc[s]);
-      acc[s] = fmaf(wv.z, xv.z, acc[s]);
-      acc[s] = fmaf(wv.w, xv.w, acc[s]);
-    }
-  }
-  const float bi = a.b[l][i];
-#pragma unroll
-  for (int s = 0; s < MAP_SPB; ++s)
-    if (s0 + s < a.B) a.out[l][(int64_t)(s0 + s) * I + i] = fmaf(acc[s], a.scale, bi);
-}
-
-// gW_l[i, k] = scale * sum_b gs_l[b, i] ws[b, kidx_l, k], gb_l[i] = sum_b gs_l[b, i]: grid (K / 256, Imax, L)
-__global__ __launch_bounds__(64) void style_affine_bwd_w_kernel(const float* __restrict__ ws, SAArgs a_by_value) {
-  const SAArgs& a = *(const SAArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(void*));
-  const int l = blockIdx.z, i = blockIdx.y;
-  const int I = a.I[l], K = a.K;
-  if (i >= I) return;
-  const int k = (blockIdx.x * 64 + threadIdx.x) * 4;
-  if (k >= K) return;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float sb = 0.f;
-  const float* x = ws + (int64_t)a.kidx[l] * K + k;
-  const float* g = a.gs[l] + i;
-  for (int b = 0; b < a.B; ++b) {
-    const float gv = g[(int64_t)b * I];
-    const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)b * a.S * K);
-    acc.x = fmaf(gv, xv.x, acc.x);
-    acc.y = fmaf(gv, xv.y, acc.y);
-    acc.z = fmaf(gv, xv.z, acc.z);
-    acc.w = fmaf(gv, xv.w, acc.w);
-    sb += gv;
-  }
-  acc.x *= a.scale; acc.y *= a.scale; acc.z *= a.scale; acc.w *= a.scale;
-  *reinterpret_cast<float4*>(a.out[l] + (int64_t)i * K + k) = acc;
-  if (k == 0) a.out2[l][i] = sb;
-}
-
-// gws[b, s, k] = scale * sum_{l: kidx_l == s} sum_i gs_l[b, i] W_l[i, k]: grid (K / 64, ceil(B / 4), S); thread = k
-__global__ __launch_bounds__(64) void style_affine_bwd_x_kernel(float* __restrict__ gws, SAArgs a_by_value) {
-  const SAArgs& a = *(const SAArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(void*));
-  extern __shared__ __attribute__((aligned(16))) float gsh[];   // [MAP_SPB][Imax]
-  const int st = blockIdx.z, lane = threadIdx.x;
-  const int K = a.K, s0 = blockIdx.y * MAP_SPB;
-  const int k = blockIdx.x * 64 + lane;
-  float acc[MAP_SPB];
-#pragma unroll
-  for (int s = 0; s < MAP_SPB; ++s) acc[s] = 0.f;
-  for (int l = 0; l < a.L; ++l) {
-    if (a.kidx[l] != st) continue;           // uniform over the block
-    const int I = a.I[l];
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < MAP_SPB; ++s)
-      for (int i = lane; i < I; i += 64) gsh[s * I + i] = s0 + s < a.B ? a.gs[l][(int64_t)(s0 + s) * I + i] : 0.f;
-    __syncthreads();
-    if (k < K) {
-      const float* wl = a.w[l] + k;
-      for (int i = 0; i < I; ++i) {
-        const float wv = wl[(int64_t)i * K];
-#pragma unroll
-        for (int s = 0; s < MAP_SPB; ++s) acc[s] = fmaf(gsh[s * I + i], wv, acc[s]);
-      }
-    }
-  }
-  if (k < K) {
-#pragma unroll
-    for (int s = 0; s < MAP_SPB; ++s)
-      if (s0 + s < a.B) gws[((int64_t)(s0 + s) * a.S + st) * K + k] = acc[s] * a.scale;
-  }
-}
-
-bool sa_fill(SAArgs& a, const float* const* w, const float* const* b, const int* I, const int* kidx, int L, int B, int S,
-             int K, float scale, int& imax) {
-  if (L < 1 || L > SA_MAX || B < 1 || S < 1 || K < 4 || (K & 3) || K > 4096) return false;
-  imax = 0;
-  for (int l = 0; l < L; ++l) {
-    if (!w[l] || !b[l] || I[l] < 1 || kidx[l] < 0 || kidx[l] >= S || !aligned16(w[l])) return false;
-    a.w[l] = w[l]; a.b[l] = b[l]; a.I[l] = I[l]; a.kidx[l] = kidx[l];
-    a.out[l] = nullptr; a.out2[l] = nullptr; a.gs[l] = nullptr;
-    imax = I[l] > imax ? I[l] : imax;
-  }
-  a.L = L; a.B = B; a.S = S; a.K = K; a.scale = scale;
-  return true;
-}
-
-
 }  // namespace
 
 // One layer of the mapping network, forward: y [B, O] = lrelu(c1 * xh W^T + c2 * b), xh = PixelNorm(x) when norm != 0
@@ -296,47 +163,5 @@ extern "C" int dgv2_map_layer_bwd(float* gx, float* gw, float* gb, float* gp, co
   map_bwd_x_kernel<<<gridx, 64, sizeof(float) * MAP_SPB * O, st>>>(gx, gp, gy, y, w, B, K, O, c1, alpha);
   dim3 gridw((K / 4 + 63) / 64, O);
   map_bwd_w_kernel<<<gridw, 64, 0, st>>>(gw, gb, gp, x, B, K, O, c1, c2);
-  DGV2_RETURN_LAST();
-}
-
-// s_l[b, i] = scale * sum_k ws[b, kidx[l], k] * w[l][i, k] + bias[l][i] for l < L <= 48 (fp32).  ws [B, S, K]; w, bias, out:
-// HOST arrays of L device pointers ([I_l, K], [I_l], [B, I_l]); K % 4 == 0, K <= 4096, I_l <= 4096.
-// replaces: the EqualLR(nn.Linear(mod_ch, in_ch)) style affine of every ModConv2d, gans/models/ops/style.py:60-66,88-90.
-extern "C" int dgv2_style_affines_fwd(float* const* out, const float* ws, const float* const* w, const float* const* bias,
-                                      const int* I, const int* kidx, int L, int B, int S, int K, float scale,
-                                      void* stream) {
-  if (!out || !ws || !w || !bias || !I || !kidx || !aligned16(ws)) return DGV2_EINVAL;
-  SAArgs a;
-  int imax;
-  if (!sa_fill(a, w, bias, I, kidx, L, B, S, K, scale, imax) || imax > 4096) return DGV2_EINVAL;
-  for (int l = 0; l < L; ++l) {
-    if (!out[l]) return DGV2_EINVAL;
-    a.out[l] = out[l];
-  }
-  dim3 grid((imax + 63) / 64, (B + MAP_SPB - 1) / MAP_SPB, L);
-  style_affine_fwd_kernel<<<grid, 64, sizeof(float) * MAP_SPB * K, (hipStream_t)stream>>>(ws, a);
-  DGV2_RETURN_LAST();
-}
-
-// The backward: gw[l] [I_l, K] = scale * gs[l]^T ws[:, kidx[l]], gb[l] [I_l] = sum_b gs[l], and (gws != NULL)
-// gws [B, S, K] = scale * sum over the layers of each style index of gs[l] w[l] (style indices no layer reads get zeros).
-extern "C" int dgv2_style_affines_bwd(float* const* gw, float* const* gb, float* gws, const float* const* gs,
-                                      const float* ws, const float* const* w, const int* I, const int* kidx, int L, int B,
-                                      int S, int K, float scale, void* stream) {
-  if (!gw || !gb || !gs || !ws || !w || !I || !kidx || !aligned16(ws) || (K & 63)) return DGV2_EINVAL;
-  SAArgs a;
-  int imax;
-  if (!sa_fill(a, w, w, I, kidx, L, B, S, K, scale, imax) || imax > 4096) return DGV2_EINVAL;
-  for (int l = 0; l < L; ++l) {
-    if (!gw[l] || !gb[l] || !gs[l] || !aligned16(gw[l])) return DGV2_EINVAL;
-    a.out[l] = gw[l]; a.out2[l] = gb[l]; a.gs[l] = gs[l]; a.b[l] = nullptr;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  dim3 gridw((K / 4 + 63) / 64, imax, L);
-  style_affine_bwd_w_kernel<<<gridw, 64, 0, st>>>(ws, a);
-  if (gws) {
-    dim3 gridx(K / 64, (B + MAP_SPB - 1) / MAP_SPB, S);
-    style_affine_bwd_x_kernel<<<gridx, 64, sizeof(float) * MAP_SPB * imax, st>>>(gws, a);
-  }
   DGV2_RETURN_LAST();
 }

@@ -70,8 +70,9 @@ class _Unpack2d(Function):
 _KIDX_CACHE = {}
 
 
-def _style_affines_lib(ws, weights, biases, kidx, scale):
-    """The packed-baddbmm form (library GEMM; differentiable to any order)."""
+def style_affines(ws, weights, biases, kidx, scale):
+    """styles[l] = (ws[:, kidx[l]] @ weights[l].T) * scale + biases[l] for all l at once.
+    ws [B,S,K] fp32; weights[l] [I_l,K]; biases[l] [I_l] -> list of contiguous [B, I_l]."""
     B, S, K = ws.shape
     L = len(weights)
     Is = [w.shape[0] for w in weights]
@@ -84,68 +85,6 @@ def _style_affines_lib(ws, weights, biases, kidx, scale):
     X = ws.float().transpose(0, 1).index_select(0, _KIDX_CACHE[key])           # [L,B,K]
     Sout = torch.baddbmm(bp, X, Wp.transpose(1, 2), alpha=float(scale))         # [L,B,Imax]
     return list(_Unpack2d.apply(Sout, tuple([B] * L), tuple(Is)))
-
-
-class _StyleAffines(Function):
-    """All style affines in one launch through pointer tables (dgv2_style_affines_fwd / _bwd, csrc/mapping.hip): no
-    packed copy of the 40 MB of weights, no unpack; backward = one launch for every weight / bias gradient, one for the
-    gradient of the style vectors."""
-
-    @staticmethod
-    def forward(ctx, ws, kidx, scale, *params):
-        L = len(params) // 2
-        weights, biases = params[:L], params[L:]
-        ws = ws.contiguous()
-        B, S, K = ws.shape
-        Is = [w.shape[0] for w in weights]
-        outs = [torch.empty((B, i), device=ws.device, dtype=torch.float32) for i in Is]
-        wd = [w.detach() for w in weights]
-        bd = [b.detach() for b in biases]
-        N.check(ws, *wd, *bd)
-        N.call("dgv2_style_affines_fwd", _ptr_array(outs), N.ptr(ws), _ptr_array(wd), _ptr_array(bd), _int_array(Is),
-               _int_array(kidx), L, B, S, K, float(scale), N.stream())
-        ctx.kidx, ctx.scale, ctx.L = tuple(kidx), float(scale), L
-        ctx.save_for_backward(ws, *weights)
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *gs):
-        L, kidx, scale = ctx.L, ctx.kidx, ctx.scale
-        ws, weights = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        B, S, K = ws.shape
-        Is = [w.shape[0] for w in weights]
-        gs = [torch.zeros((B, i), device=ws.device, dtype=torch.float32) if g is None else g.contiguous().float()
-              for g, i in zip(gs, Is)]
-        if torch.is_grad_enabled():   # create_graph=True (path-length regulariser): differentiable ops
-            gws = torch.zeros_like(ws) if ctx.needs_input_grad[0] else None
-            gw, gb = [], []
-            for l in range(L):
-                gw.append(gs[l].t() @ ws[:, kidx[l]] * scale)
-                gb.append(gs[l].sum(0))
-                if gws is not None:
-                    gws = gws.index_add(1, torch.tensor([kidx[l]], device=ws.device), (gs[l] @ weights[l] * scale)[:, None])
-            return (gws, None, None, *gw, *gb)
-        gw = [torch.empty_like(w) for w in weights]
-        gb = [torch.empty(i, device=ws.device, dtype=torch.float32) for i in Is]
-        gws = torch.empty_like(ws) if ctx.needs_input_grad[0] else None
-        wd = [w.detach() for w in weights]
-        N.call("dgv2_style_affines_bwd", _ptr_array(gw), _ptr_array(gb), N.ptr(gws), _ptr_array(gs), N.ptr(ws),
-               _ptr_array(wd), _int_array(Is), _int_array(kidx), L, B, S, K, scale, N.stream())
-        return (gws, None, None, *gw, *gb)
-
-
-_STYLE_FUSED = os.environ.get("DGV2_NO_STYLE_FUSED") is None   # A/B switch for benchmarking
-
-
-def style_affines(ws, weights, biases, kidx, scale):
-    """styles[l] = (ws[:, kidx[l]] @ weights[l].T) * scale + biases[l] for all l at once.
-    ws [B,S,K] fp32; weights[l] [I_l,K]; biases[l] [I_l] -> list of contiguous [B, I_l]."""
-    B, S, K = ws.shape
-    if (_STYLE_FUSED and ws.is_cuda and ws.dtype == torch.float32 and K % 64 == 0 and K <= 4096 and len(weights) <= 48
-            and all(w.dtype == torch.float32 and w.is_contiguous() and w.shape[0] <= 4096 for w in weights)
-            and all(b.is_contiguous() for b in biases)):
-        return list(_StyleAffines.apply(ws, tuple(int(k) for k in kidx), float(scale), *weights, *biases))
-    return _style_affines_lib(ws, weights, biases, kidx, scale)
 
 
 def lerp_list(dst, src, weight):

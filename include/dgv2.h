@@ -413,18 +413,6 @@ int dgv2_map_layer_fwd(float* y, float* xh_out, const float* x, const float* w, 
  * gb [O] = c2 * sum_s gp (NULL: no bias).  x: the operand the forward contracted.  K % 64 == 0, O % 4 == 0, O <= 4096. */
 int dgv2_map_layer_bwd(float* gx, float* gw, float* gb, float* gp, const float* gy, const float* y, const float* x,
                        const float* w, int B, int K, int O, float c1, float c2, float alpha, void* stream);
-/* The style affines of every modulated conv in one launch: s_l[b,i] = scale * sum_k ws[b,kidx[l],k] w[l][i,k] + bias[l][i],
- * l < L <= 48, fp32.  ws [B,S,K]; out / w / bias: HOST arrays of L device pointers ([B,I_l], [I_l,K], [I_l]).
- * K % 4 == 0 (backward: % 64), K <= 4096, I_l <= 4096.
- * replaces: the EqualLR(nn.Linear(mod_ch, in_ch)) of each ModConv2d, gans/models/ops/style.py:60-66,88-90 (19 small
- *   GEMMs per generator pass; as one batched library GEMM they needed a packed copy of the 40 MB of weights). */
-int dgv2_style_affines_fwd(float* const* out, const float* ws, const float* const* w, const float* const* bias,
-                           const int* I, const int* kidx, int L, int B, int S, int K, float scale, void* stream);
-/* Backward: gw[l] [I_l,K] = scale * gs[l]^T ws[:,kidx[l]]; gb[l] [I_l] = sum_b gs[l]; gws [B,S,K] (or NULL) = scale * sum
- * over the layers of each style index of gs[l] w[l] (zeros for style indices no layer reads). */
-int dgv2_style_affines_bwd(float* const* gw, float* const* gb, float* gws, const float* const* gs, const float* ws,
-                           const float* const* w, const int* I, const int* kidx, int L, int B, int S, int K, float scale,
-                           void* stream);
 /* The same with the epilogue's cast folded in: x / gx in xdtype, out (ydtype) / gout (gdtype) the same or fp32 for a
  * bf16 x -- x.float() of the reference's fp32 epilogue (gans/models/dusty_v2.py:394-395) and its adjoint without their
  * own passes over the activation. */

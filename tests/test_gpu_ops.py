@@ -434,41 +434,6 @@ def test_fused_mapping_network_matches_the_module(nat, B, ch, depth, monkeypatch
     assert_rel(y.detach().cpu(), y2.detach().cpu(), 1e-5, "fused vs library path")
 
 
-@pytest.mark.parametrize("B", [64, 6])
-def test_fused_style_affines_match_float64(nat, B):
-    """dgv2_style_affines_fwd/_bwd (every ModConv2d's EqualLR style Linear in one launch through pointer tables;
-    reference: style.py:60-66,88-90) against float64: outputs, weight / bias gradients, and the gradient of the style
-    vectors summed over the layers that share a style index (two indices unread: their gradient must be zero)."""
-    g = torch.Generator().manual_seed(B)
-    S, K = 10, 512
-    Is = [512, 512, 1024, 256, 2, 640, 1, 128, 64]
-    kidx = [0, 1, 1, 3, 4, 4, 4, 8, 9]           # styles 2, 5, 6, 7 are not read by any layer
-    ws = torch.randn(B, S, K, generator=g).to(DEV).requires_grad_(True)
-    weights = [torch.randn(i, K, generator=g).to(DEV).requires_grad_(True) for i in Is]
-    biases = [torch.randn(i, generator=g).to(DEV).requires_grad_(True) for i in Is]
-    gouts = [torch.randn(B, i, generator=g).to(DEV) for i in Is]
-    scale = 1.0 / math.sqrt(K)
-    outs = nat.style_affines(ws, weights, biases, kidx, scale)
-    assert type(outs[0].grad_fn).__name__ == "_StyleAffinesBackward"
-    grads = torch.autograd.grad(outs, [ws] + weights + biases, gouts)
-    wsd = ws.detach().double().requires_grad_(True)
-    wd = [w.detach().double().requires_grad_(True) for w in weights]
-    bd = [b.detach().double().requires_grad_(True) for b in biases]
-    ref = [wsd[:, k] @ w.t() * scale + b for k, w, b in zip(kidx, wd, bd)]
-    gref = torch.autograd.grad(ref, [wsd] + wd + bd, [x.double() for x in gouts])
-    for a, b in zip(outs, ref):
-        assert_rel(a.detach().cpu(), b.detach().cpu(), 2e-6, "style")
-    names = ["gws"] + [f"gw{l}" for l in range(len(Is))] + [f"gb{l}" for l in range(len(Is))]
-    for n, a, b in zip(names, grads, gref):
-        assert_rel(a.cpu(), b.cpu(), 5e-6, n)
-    assert float(grads[0][:, [2, 5, 6, 7]].abs().max()) == 0.0
-    # second order (the path-length regulariser differentiates the style gradient again): differentiable fallback
-    outs2 = nat.style_affines(ws, weights, biases, kidx, scale)
-    (gw,) = torch.autograd.grad(outs2, [ws], gouts, create_graph=True)
-    (gg,) = torch.autograd.grad(gw.square().sum(), [weights[1]])
-    assert torch.isfinite(gg).all() and float(gg.abs().max()) > 0
-
-
 def test_linear_f32_matches_float64(nat):
     """native.linear_f32 (EqualLR Linear of D's fp32 epilogue, dusty_v2.py:381-383) forward / data gradient / weight
     gradient through dgv2_gemm_x3 against float64, incl. the weight gradient written in place into a caller-provided
