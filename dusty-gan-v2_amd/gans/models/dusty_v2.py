@@ -48,15 +48,6 @@ class MappingNetwork(nn.Sequential):
             ch = out_ch
         super().__init__(*layers)
 
-    def forward(self, z):
-        if z.is_cuda and z.dtype == torch.float32 and os.environ.get("DGV2_NO_MAP_FUSED") is None:
-            # PixelNorm and every [EqualLR Linear + LeakyReLU] pair as one launch each (csrc/mapping.hip)
-            lay = [(m[0].module.weight, m[0].module.bias, m[0].scale * m[0].gain_, m[0].gain_) for m in list(self)[1:]]
-            w = native.mapping_fused(z, lay, self[1][1].negative_slope)
-            if w is not None:
-                return w
-        return super().forward(z)
-
 
 _BATCHED_PREP = os.environ.get("DGV2_NO_BATCHED_PREP") is None
 

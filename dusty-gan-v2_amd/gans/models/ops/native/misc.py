@@ -360,83 +360,5 @@ def mod_gemm_layer(xa, xs, handle, wb, cvec, bias=None, act=True, alpha=0.2, sca
     return _ModGemmPrepared.apply(cfg, xa, xs, bias, handle, wb, cvec, wt)
 
 
-# ---------------------------------------------------------------------------------------
-# mapping network (reference: dusty_v2.py:13-29): PixelNorm + depth x [EqualLR Linear + LeakyReLU] as one launch per
-# layer forward, two per layer backward (csrc/mapping.hip)
-# ---------------------------------------------------------------------------------------
-class _MappingFused(Function):
-    @staticmethod
-    def forward(ctx, z, alpha, cfg, *params):
-        """cfg: per layer (c1, c2); params: (w, b) per layer (b may be None)."""
-        z = z.contiguous()
-        B = z.shape[0]
-        L = len(cfg)
-        xs, ys = [], []
-        h = z
-        for i in range(L):
-            w, b = params[2 * i], params[2 * i + 1]
-            O, K = w.shape
-            y = torch.empty((B, O), device=z.device, dtype=torch.float32)
-            xh = torch.empty_like(h) if i == 0 else None
-            N.check(h, w, b)
-            N.call("dgv2_map_layer_fwd", N.ptr(y), N.ptr(xh), N.ptr(h), N.ptr(w.detach()), None if b is None else N.ptr(b.detach()),
-                   B, K, O, cfg[i][0], cfg[i][1], alpha, 1 if i == 0 else 0, N.stream())
-            xs.append(xh if i == 0 else h)
-            ys.append(y)
-            h = y
-        ctx.alpha, ctx.cfg, ctx.L = alpha, cfg, L
-        ctx.save_for_backward(*xs, *ys, *[p for p in params if p is not None])
-        ctx.has_b = [params[2 * i + 1] is not None for i in range(L)]
-        return h
-
-    @staticmethod
-    def backward(ctx, g):
-        L, alpha, cfg = ctx.L, ctx.alpha, ctx.cfg
-        sv = ctx.saved_tensors
-        xs, ys = sv[:L], sv[L:2 * L]
-        rest = list(sv[2 * L:])
-        ws, bs = [], []
-        for i in range(L):
-            ws.append(rest.pop(0))
-            bs.append(rest.pop(0) if ctx.has_b[i] else None)
-        grads = [None] * (2 * L)
-        g = g.contiguous().float()
-        B = g.shape[0]
-        for i in reversed(range(L)):
-            w = ws[i]
-            O, K = w.shape
-            c1, c2 = cfg[i]
-            if torch.is_grad_enabled():   # create_graph=True: the same gradients from differentiable ops
-                gp = g * torch.where(ys[i] > 0, 1.0, alpha)
-                gx = (gp @ w) * c1 if i > 0 else None
-                grads[2 * i] = (gp.t() @ xs[i]) * c1
-                grads[2 * i + 1] = gp.sum(0) * c2 if ctx.has_b[i] else None
-            else:
-                gp = torch.empty((B, O), device=g.device, dtype=torch.float32)
-                gx = torch.empty((B, K), device=g.device, dtype=torch.float32) if i > 0 else None
-                gw = torch.empty_like(w)
-                gb = torch.empty(O, device=g.device, dtype=torch.float32) if ctx.has_b[i] else None
-                N.call("dgv2_map_layer_bwd", N.ptr(gx), N.ptr(gw), N.ptr(gb), N.ptr(gp), N.ptr(g), N.ptr(ys[i]), N.ptr(xs[i]),
-                       N.ptr(w.detach()), B, K, O, c1, c2, alpha, N.stream())
-                grads[2 * i], grads[2 * i + 1] = gw, gb
-            g = gx
-        return (None, None, None, *grads)
-
-
-def mapping_fused(z, layers, alpha):
-    """layers: [(weight [O,K], bias [O] or None, c1, c2)] of the EqualLR Linear layers behind the PixelNorm; -> [B, O_last]
-    fp32, or None when the shapes are outside the kernels' range."""
-    if not (z.is_cuda and z.dtype == torch.float32 and z.ndim == 2):
-        return None
-    k = z.shape[1]
-    for w, b, _, _ in layers:
-        if (w.dtype != torch.float32 or w.shape[1] != k or k % 64 or w.shape[0] % 64 or k > 4096 or w.shape[0] > 4096
-                or not w.is_contiguous()):
-            return None
-        k = w.shape[0]
-    cfg = tuple((float(c1), float(c2)) for _, _, c1, c2 in layers)
-    params = [t for w, b, _, _ in layers for t in (w, b)]
-    return _MappingFused.apply(z, float(alpha), cfg, *params)
-
 
 __all__ = [n_ for n_ in dir() if not n_.startswith("__")]

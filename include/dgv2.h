@@ -402,17 +402,6 @@ int dgv2_mbstd_cat_bwd(void* gx, const void* gout, const void* x, int B, int P, 
 int dgv2_gemm_x3(float* c, float* scratch, int64_t scratch_elems, const float* a, const float* b, int I, int J,
                  int64_t T, int a_trans, int b_trans, int64_t lda, int64_t ldb, int64_t ldo, int splits, float scale,
                  void* stream);
-/* One layer of the generator's mapping network: y [B,O] = lrelu(c1 * xh W^T + c2 * b, alpha) with xh = PixelNorm(x)
- * (x / sqrt(mean_k x^2 + 1e-8)) when norm != 0 -- then also stored to xh_out [B,K] when non-NULL -- else x.  fp32;
- * K % 4 == 0, O % 64 == 0, K <= 4096.  c1 = EqualLR scale * gain * lr_mul, c2 = gain * lr_mul.
- * replaces: ops.PixelNorm + EqualLR(nn.Linear) + nn.LeakyReLU, gans/models/dusty_v2.py:13-29,
- *   gans/models/ops/common.py:158-184,213-223 (five + two launches per layer as library calls). */
-int dgv2_map_layer_fwd(float* y, float* xh_out, const float* x, const float* w, const float* b, int B, int K, int O,
-                       float c1, float c2, float alpha, int norm, void* stream);
-/* Its backward: gp [B,O] = gy * lrelu'(y); gx [B,K] = c1 * gp W (NULL: not wanted); gw [O,K] = c1 * gp^T x;
- * gb [O] = c2 * sum_s gp (NULL: no bias).  x: the operand the forward contracted.  K % 64 == 0, O % 4 == 0, O <= 4096. */
-int dgv2_map_layer_bwd(float* gx, float* gw, float* gb, float* gp, const float* gy, const float* y, const float* x,
-                       const float* w, int B, int K, int O, float c1, float c2, float alpha, void* stream);
 /* The same with the epilogue's cast folded in: x / gx in xdtype, out (ydtype) / gout (gdtype) the same or fp32 for a
  * bf16 x -- x.float() of the reference's fp32 epilogue (gans/models/dusty_v2.py:394-395) and its adjoint without their
  * own passes over the activation. */

@@ -404,36 +404,6 @@ def test_gemm_x3_is_fp32_equivalent(nat, a_trans, b_trans, I, J, T, splits):
     assert nat.gemm_x3(torch.zeros(48, 64, device=DEV), torch.zeros(128, 64, device=DEV), False, False, 48, 128, 64) is None
 
 
-@pytest.mark.parametrize("B,ch,depth", [(64, 512, 2), (37, 512, 2), (3, 128, 3)])
-def test_fused_mapping_network_matches_the_module(nat, B, ch, depth, monkeypatch):
-    """csrc/mapping.hip (PixelNorm + [EqualLR Linear + LeakyReLU] x depth, one launch per layer forward, two backward)
-    against the same module computed in float64 from its composed ops (reference: dusty_v2.py:13-29,
-    common.py:158-184,213-223): output and every parameter gradient; ragged batch; and against the module's own
-    unfused path."""
-    import copy
-    from gans.models.dusty_v2 import MappingNetwork
-    torch.manual_seed(B + ch)
-    net = MappingNetwork(ch, ch, depth).to(DEV)
-    with torch.no_grad():
-        for m in list(net)[1:]:
-            m[0].module.bias.normal_()          # the reference initialises the biases to 0: make them count
-    z = torch.randn(B, ch, device=DEV)
-    gy = torch.randn(B, ch, device=DEV)
-    y = net(z)
-    assert type(y.grad_fn).__name__ == "_MappingFusedBackward"
-    grads = torch.autograd.grad(y, list(net.parameters()), gy)
-    ref = copy.deepcopy(net).double()
-    monkeypatch.setenv("DGV2_NO_MAP_FUSED", "1")
-    yr = ref(z.double())
-    gref = torch.autograd.grad(yr, list(ref.parameters()), gy.double())
-    assert_rel(y.detach().cpu(), yr.detach().cpu(), 2e-6, "w")
-    for (n, _), a, b in zip(net.named_parameters(), grads, gref):
-        assert_rel(a.cpu(), b.cpu(), 5e-6, n)
-    y2 = net(z)                                   # the module's library path in fp32
-    assert type(y2.grad_fn).__name__ != "_MappingFusedBackward"
-    assert_rel(y.detach().cpu(), y2.detach().cpu(), 1e-5, "fused vs library path")
-
-
 def test_linear_f32_matches_float64(nat):
     """native.linear_f32 (EqualLR Linear of D's fp32 epilogue, dusty_v2.py:381-383) forward / data gradient / weight
     gradient through dgv2_gemm_x3 against float64, incl. the weight gradient written in place into a caller-provided
