@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGV2_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -36,6 +36,8 @@ SIGNATURES = {
     "dgv2_mbstd_cat_bwd": [_c_ptr] * 3 + [_c_int] * 7 + [_c_ptr],
     "dgv2_gemm_x3": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_i64,
                      _c_int, _c_f32, _c_ptr],
+    "dgv2_pe_wgrad_scratch": [_c_ptr] + [_c_int] * 4,
+    "dgv2_pe_wgrad": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 4 + [_c_i64, _c_int, _c_ptr],
     "dgv2_mbstd_cat_fwd_x": [_c_ptr] * 3 + [_c_int] * 8 + [_c_ptr],
     "dgv2_mbstd_cat_bwd_x": [_c_ptr] * 3 + [_c_int] * 8 + [_c_ptr],
     "dgv2_scale_cast": [_c_ptr] * 3 + [_c_i64, _c_int, _c_int, _c_int, _c_ptr],

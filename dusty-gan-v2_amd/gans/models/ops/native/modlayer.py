@@ -144,7 +144,9 @@ class _ModLayer(Function):
                 parts.append(_bmm_tn_stream(g3, xa, B, H, W_, Ka, Otot))   # own streaming engine, per sample
             elif xa is not None:
                 parts.append(torch.bmm(gT, xa.reshape(B, P, Ka), out_dtype=torch.float32))
-            parts.append(torch.bmm(gT, xs.reshape(1, P, -1).expand(B, P, xs.shape[3]), out_dtype=torch.float32))
+            gws = pe_wgrad(g3, xs.reshape(P, -1))   # several samples share a staged PE tile (csrc/pe_wgrad.hip)
+            parts.append(gws if gws is not None else
+                         torch.bmm(gT, xs.reshape(1, P, -1).expand(B, P, xs.shape[3]), out_dtype=torch.float32))
             gwb = torch.cat(parts, dim=2) if len(parts) > 1 else parts[0]
         if gwb is not None:
             pass
@@ -422,6 +424,31 @@ _PE_TN_STREAM = os.environ.get("DGV2_PE_TN_STREAM") is not None
 _PE_TN_MINP = int(os.environ.get("DGV2_PE_TN_MINP", "16384"))
 
 
+_PE_WGRAD = os.environ.get("DGV2_NO_PE_WGRAD") is None   # A/B switch for benchmarking
+_PE_WGRAD_MINP = int(os.environ.get("DGV2_PE_WGRAD_MINP", "2048"))
+
+
+def pe_wgrad(g3, xs):
+    """gw fp32 [B, O, Ks] = g3^T pe per sample on dgv2_pe_wgrad (several samples share a staged PE tile); None where the
+    shape is outside the kernel's range."""
+    B, P, O = g3.shape
+    Ks = xs.shape[-1]
+    # measured (B = 64, Ks = 512; scripts/mb_pewgrad2.py): P = 32768, O = 32: 113 us against the library's 243;
+    # P = 8192, O = 64: 68 / 70; P = 2048, O = 128: 41 / 31 (10 us lost there; smaller maps use dgv2_bmm_tn_cat)
+    if not (_PE_WGRAD and g3.dtype == torch.bfloat16 and xs.dtype == torch.bfloat16 and (P >= _PE_WGRAD_MINP)):
+        return None
+    n = _ct.c_int64(0)
+    if N.lib.dgv2_pe_wgrad_scratch(_ct.byref(n), B, P, O, Ks) != 0 or n.value == 0:
+        return None
+    g3 = g3.contiguous()
+    xs = xs.contiguous()
+    out = torch.empty((B, O, Ks), device=g3.device, dtype=torch.float32)
+    scratch = torch.empty(n.value, device=g3.device, dtype=torch.float32)
+    N.check(g3, xs)
+    N.call("dgv2_pe_wgrad", N.ptr(out), N.ptr(scratch), n.value, N.ptr(g3), N.ptr(xs), B, P, O, Ks, Ks, 0, N.stream())
+    return out
+
+
 def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
     """gwb fp32 [B,Otot,I] = per-sample g3^T [xa | xs] (the engine choice of _ModLayer.backward)."""
     P = H * W_
@@ -433,7 +460,10 @@ def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
             parts.append(_bmm_tn_stream(g3, xa, B, H, W_, Ka, Otot))
         elif xa is not None:
             parts.append(torch.bmm(gT, xa.reshape(B, P, Ka), out_dtype=torch.float32))
-        if _PE_TN_STREAM and Otot % 8 == 0 and P >= _PE_TN_MINP:
+        gws = pe_wgrad(g3, xs.reshape(P, -1))
+        if gws is not None:
+            parts.append(gws)
+        elif _PE_TN_STREAM and Otot % 8 == 0 and P >= _PE_TN_MINP:
             parts.append(_bmm_tn_stream(g3, xs.contiguous(), B, H, W_, xs.shape[3], Otot, shared=True))
         else:
             parts.append(torch.bmm(gT, xs.reshape(1, P, -1).expand(B, P, xs.shape[3]), out_dtype=torch.float32))

@@ -402,6 +402,16 @@ int dgv2_mbstd_cat_bwd(void* gx, const void* gout, const void* x, int B, int P, 
 int dgv2_gemm_x3(float* c, float* scratch, int64_t scratch_elems, const float* a, const float* b, int I, int J,
                  int64_t T, int a_trans, int b_trans, int64_t lda, int64_t ldb, int64_t ldo, int splits, float scale,
                  void* stream);
+/* Weight gradient of the batch-shared positional-encoding columns of the modulated 1x1 convs:
+ *   gw[b, o, col0 + k] = sum_p g[b, p, o] * pe[p, k], k < Ks      (gw fp32 [B, O, ldo]; g [B, P, O], pe [P, Ks] bf16)
+ * 128 / O samples share a block's M tile, so one staged PE tile feeds several samples' accumulators (as a batched
+ * library GEMM the encoding is re-read per sample); the pixel axis is split over blocks through `scratch`
+ * (>= dgv2_pe_wgrad_scratch elements).  O divides 128, O % 8 == 0, B * O % 128 == 0, Ks % 128 == 0, P % 32 == 0.
+ * replaces: the PE columns of ModConv2d's weight gradient (autograd of gans/models/ops/style.py:105-118 on the
+ *   concatenated input of gans/models/dusty_v2.py:153-162). */
+int dgv2_pe_wgrad_scratch(int64_t* elems, int B, int P, int O, int Ks);
+int dgv2_pe_wgrad(float* gw, float* scratch, int64_t scratch_elems, const void* g, const void* pe, int B, int P, int O,
+                  int Ks, int64_t ldo, int col0, void* stream);
 /* The same with the epilogue's cast folded in: x / gx in xdtype, out (ydtype) / gout (gdtype) the same or fp32 for a
  * bf16 x -- x.float() of the reference's fp32 epilogue (gans/models/dusty_v2.py:394-395) and its adjoint without their
  * own passes over the activation. */

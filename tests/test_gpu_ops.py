@@ -404,6 +404,32 @@ def test_gemm_x3_is_fp32_equivalent(nat, a_trans, b_trans, I, J, T, splits):
     assert nat.gemm_x3(torch.zeros(48, 64, device=DEV), torch.zeros(128, 64, device=DEV), False, False, 48, 128, 64) is None
 
 
+@pytest.mark.parametrize("B,P,O,Ks", [(8, 2048, 32, 512), (4, 1024, 64, 256), (3, 512, 128, 128), (16, 4096, 32, 512)])
+def test_pe_wgrad_against_float64(nat, B, P, O, Ks, monkeypatch):
+    """dgv2_pe_wgrad (PE columns of the modulated conv's weight gradient, 128 / O samples per M tile so that one staged
+    PE tile feeds several samples; autograd of style.py:105-118) against float64: bit-exact on small integers (pins the
+    sample / channel packing of the M tile, both transposing fragment reads and the split over the pixel axis), bf16
+    operand rounding only on random data."""
+    from gans.models.ops.native import modlayer
+    monkeypatch.setattr(modlayer, "_PE_WGRAD_MINP", 0)     # the wrapper's size gate is a speed policy, not a limit
+    g = torch.Generator().manual_seed(B + P + O)
+    for exact in (True, False):
+        if exact:
+            gy = torch.randint(-2, 3, (B, P, O), generator=g).float()
+            pe = torch.randint(-1, 2, (P, Ks), generator=g).float() * (torch.rand(P, Ks, generator=g) < 0.25)
+        else:
+            gy, pe = torch.randn(B, P, O, generator=g), torch.randn(P, Ks, generator=g)
+        gy, pe = gy.to(DEV).bfloat16(), pe.to(DEV).bfloat16()
+        got = modlayer.pe_wgrad(gy, pe)
+        assert got is not None and got.shape == (B, O, Ks) and got.dtype == torch.float32
+        want = torch.einsum("bpo,pk->bok", gy.double(), pe.double())
+        if exact:
+            assert torch.equal(got.double(), want)
+        else:
+            assert_rel(got.cpu(), want.cpu(), 2e-6, "gw")
+    assert modlayer.pe_wgrad(torch.zeros(2, 64, 24, device=DEV).bfloat16(), torch.zeros(64, 128, device=DEV).bfloat16()) is None
+
+
 def test_linear_f32_matches_float64(nat):
     """native.linear_f32 (EqualLR Linear of D's fp32 epilogue, dusty_v2.py:381-383) forward / data gradient / weight
     gradient through dgv2_gemm_x3 against float64, incl. the weight gradient written in place into a caller-provided
