@@ -13,7 +13,7 @@ from torch.nn.modules.utils import _pair, _quadruple
 from . import native
 
 __all__ = ["Pad", "filter2d", "Resample", "BlurVH", "EqualLR", "Conv2d", "PixelNorm", "MinibatchStdDev",
-           "to_cl", "from_cl"]
+           "Dilation", "init_weights", "to_cl", "from_cl"]
 
 
 def to_cl(x):
@@ -291,3 +291,59 @@ def filter2d(x, kernel, gain=1, normalize=True):
     x = F.pad(x, (0, 0, p0, p1), mode="replicate")
     x = (x.unfold(3, k, 1) * kernel.to(x.dtype)).sum(-1)
     return (x.unfold(2, k, 1) * kernel.to(x.dtype)).sum(-1)
+
+
+class Dilation(nn.Module):
+    """reference: common.py:256-271 (unused by the shipped configs) -- every input pixel lands on a grid of pitch
+    dilation + 1 and the `dilation` positions around it (a (2 d + 1)^2 window) receive `value` times it; the output
+    is that transposed convolution cropped by one pixel per border: [(H - 1)(d + 1) + 2 d - 1] rows.
+    Here: a strided placement (no convolution at all when value == 0) plus, for value != 0, the window sums as two
+    separable cumulative-sum differences."""
+
+    def __init__(self, dilation=1, value=0):
+        super().__init__()
+        self.dilation, self.value = int(dilation), value
+        self.stride = self.dilation + 1
+        # kept for state-dict compatibility with the reference module (a [1,1,2d+1,2d+1] buffer named "kernel")
+        k = torch.full((1, 1, 2 * self.dilation + 1, 2 * self.dilation + 1), float(value))
+        k[0, 0, self.dilation, self.dilation] = 1.0
+        self.register_buffer("kernel", k)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        d, s = self.dilation, self.stride
+        Hf, Wf = (H - 1) * s + 2 * d + 1, (W - 1) * s + 2 * d + 1      # un-cropped transposed-conv size
+        full = x.new_zeros(B, C, Hf, Wf)
+        full[:, :, d::s, d::s][:, :, :H, :W] = x
+        if self.value != 0:
+            # every pixel also spreads value * x over its (2 d + 1)^2 window (centre excluded: it carries x itself)
+            win = full
+            for dim in (2, 3):
+                c = torch.cumsum(F.pad(win, (d + 1, d, 0, 0) if dim == 3 else (0, 0, d + 1, d)), dim=dim)
+                n = win.shape[dim]
+                win = c.narrow(dim, 2 * d + 1, n) - c.narrow(dim, 0, n)
+            full = full + self.value * (win - full)
+        return full[:, :, 1:Hf - 1, 1:Wf - 1]
+
+    def extra_repr(self):
+        return f"dilation={self.dilation}, value={self.value}"
+
+
+def init_weights(layer, mode, gain=1.0):
+    """reference: common.py:274-292 -- re-initialise every Conv2d / Linear below `layer` ("ortho", "N02", "glorot" /
+    "xavier"; biases to zero) and, for "N02", the affine parameters of modules whose NAME contains "BatchNorm"."""
+    inits = {
+        "ortho": lambda w: nn.init.orthogonal_(w, gain),
+        "N02": lambda w: nn.init.normal_(w, 0.0, 0.02),
+        "glorot": lambda w: nn.init.xavier_uniform_(w, gain),
+        "xavier": lambda w: nn.init.xavier_uniform_(w, gain),
+    }
+    for name, m in layer.named_modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            if mode in inits:      # (the reference evaluates `NotImplementedError` without raising: unknown modes are a no-op)
+                inits[mode](m.weight)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif "BatchNorm" in name and mode == "N02":
+            nn.init.normal_(m.weight, 1.0, 0.02)
+            nn.init.zeros_(m.bias)

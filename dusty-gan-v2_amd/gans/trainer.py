@@ -67,9 +67,9 @@ class Trainer:
             raise ValueError(f"training.batch_size ({self.batch_size}) must be a multiple of batch_size_per_gpu "
                              f"({self.B}) x num_gpus ({self.num_gpus})")
         self.num_accumulation = self.batch_size // (self.B * self.num_gpus)
-        if cfg.training.gan_objective in ("ragan", "rahinge", "ralsgan"):
-            raise NotImplementedError(f"gan_objective={cfg.training.gan_objective}: the relativistic objectives need "
-                                      "D(A(real)) in the generator step (trainer.py:283-287), which is not built")
+        # the relativistic objectives compare every logit with the mean logit of the OTHER class: the generator step
+        # then also needs D(A(real)) (reference: trainer.py:262,279-287)
+        self.use_real_in_g = cfg.training.gan_objective in ("ragan", "rahinge", "ralsgan")
 
         # models (rank 0's initial weights are broadcast, as DDP's constructor does)
         self.G = build_generator(cfg.model.generator).to(self.device)
@@ -266,7 +266,7 @@ class Trainer:
         return {"shifts": self._injected[site + ".shifts"], "gumbel_u": self._injected[site + ".u"]}
 
     def _ada(self, site):
-        if self._injected is None:
+        if self._injected is None or site + ".G" not in self._injected:
             return None
         return {"G": self._injected[site + ".G"], "C": self._injected[site + ".C"]}
 
@@ -274,20 +274,29 @@ class Trainer:
     # Each sub-step is split into a forward/backward body (`*_fb`), the gradient all-reduce (eager,
     # RCCL) and the optimizer body, so that the bodies can be replayed as hipGraphs while the
     # collectives stay ordinary stream work between them.
-    def g_fb(self, j, scalars):
+    def g_fb(self, j, scalars, x_real=None):
         set_requires_grad(self.G, True)
         self.g_sync.begin(direct=j == 0)
         z = self._z("g")
         x_fake = self.G(z, noise=self._g_noise("g"), **self.auxin)["image"]
         y_fake = self.D(self.A(self.warmup(x_fake, self._draw("g.keep")), draws=self._ada("g.ada")))
+        y_real = None
+        if x_real is not None:   # relativistic objectives only (trainer.py:279-285: the augmented reals are detached)
+            with torch.no_grad():
+                x_real_aug = self.A(self.warmup(x_real, self._draw("g.keep_real")), draws=self._ada("g.ada_real"))
+            y_real = self.D(x_real_aug)
         if self.adversarial_loss.can_fuse(y_fake):
             loss_gan, _ = self.adversarial_loss.fused_nsgan(y_fake, len(y_fake))   # softplus(-y_fake).mean(), one launch
         else:
-            loss_gan = self.adversarial_loss(None, y_fake, "G")
+            loss_gan = self.adversarial_loss(y_real, y_fake, "G")
         (self.cfg.training.loss.gan * loss_gan).backward()
         self.g_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
         set_requires_grad(self.G, False)
         scalars["loss/G/adversarial"] = loss_gan.detach()
+
+    def g_fb_rel(self, x_real, j, scalars):
+        """G step of a relativistic objective: also D(A(real)) (argument order of the other bodies that take reals)."""
+        self.g_fb(j, scalars, x_real)
 
     def d_fb(self, x_real, j, scalars, cut=False):
         set_requires_grad(self.D, True)
@@ -499,7 +508,10 @@ class Trainer:
         for j in range(nacc):
             if j == 0:
                 parallel.sync_buffers(self.G)
-            log(self._run(self._acc_name("g_fb", j), self.g_fb, j))
+            if self.use_real_in_g:
+                log(self._run(self._acc_name("g_fb", j), self.g_fb_rel, real(j), j))
+            else:
+                log(self._run(self._acc_name("g_fb", j), self.g_fb, j))
         # nothing on this rank is independent of G's reduced gradient (the D step starts with a forward of the updated
         # G), so this 17.5 MB reduction is synchronous
         self.g_sync.all_reduce()

@@ -417,3 +417,56 @@ def test_split_d_backward_equals_the_single_pass(hip_graph):
     live = two.graphs_live()
     if hip_graph:
         assert {"d_fb_head", "d_fb_tail", "g_fb"} <= set(live) and all(live.values()), live
+
+
+# ---------------------------------------------------------------------------- relativistic objectives
+@pytest.mark.parametrize("objective", ["ragan", "rahinge", "ralsgan"])
+def test_relativistic_objectives_use_the_reals_in_the_generator_step(objective):
+    """reference: trainer.py:262,279-287 + loss.py:53-61,77-85 -- with a relativistic objective the G step also runs
+    D(A(warmup(real))) (the augmented reals detached) and the loss compares every logit with the mean logit of the
+    other class.  The G-step loss the trainer reports must equal GANLoss("...")(D(A(real)), D(A(fake)), "G") composed
+    by hand from the same draws, and whole iterations must run as hipGraph replays."""
+    from gans.models.loss import GANLoss
+    from gans.trainer import Trainer
+    cfg = small_cfg(False)
+    cfg.dataset.name = "synthetic"
+    cfg.training.update(rank=0, num_gpus=1, batch_size=8, batch_size_per_gpu=8, resume=None, hip_graph=False,
+                        gan_objective=objective)
+    cfg.training.warmup.fade_kimg = 0          # no warm-up blur / dropout: every draw of the step is injected below
+    tr = Trainer(cfg, sync_scalars=False)
+    assert tr.use_real_in_g
+    B, H, W = 8, 16, 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    draws = {"g.z": torch.randn(B, tr.cfg.model.generator.mapping_kwargs.in_ch, device="cuda", generator=g),
+             "g.shifts": torch.rand(B, device="cuda", generator=g) * 6.2831853,
+             "g.u": torch.rand(B, 1, H, W, device="cuda", generator=g).clamp(1e-6, 1 - 1e-6)}
+    for site in ("g.ada", "g.ada_real"):
+        draws[site + ".G"] = tr.A.sample_affine(B, H, W, device="cuda")
+        draws[site + ".C"] = tr.A.sample_color(B, device="cuda")
+    tr.set_draws(draws)
+    x_real = tr.fetch_reals(next(tr.iter_train_loader))["image"]
+    tr.x_real.copy_(x_real)
+    tr.G.train()
+    tr.set_warmup_params(1)
+    sdG = {k: v.clone() for k, v in tr.G.state_dict().items()}
+    sc = {}
+    tr.g_fb_rel(tr.x_real, 0, sc)
+    got = float(sc["loss/G/adversarial"])
+    gnorm = float(tr.g_sync.flat.abs().sum())
+    # by hand, same draws and the same (pre-step) buffers
+    tr.G.load_state_dict(sdG)
+    with torch.no_grad():
+        x_fake = tr.G(draws["g.z"], noise={"shifts": draws["g.shifts"], "gumbel_u": draws["g.u"]}, **tr.auxin)["image"]
+        y_fake = tr.D(tr.A(tr.warmup(x_fake, None), draws={"G": draws["g.ada.G"], "C": draws["g.ada.C"]}))
+        y_real = tr.D(tr.A(tr.warmup(tr.x_real, None), draws={"G": draws["g.ada_real.G"], "C": draws["g.ada_real.C"]}))
+        want = float(GANLoss(objective).to("cuda")(y_real, y_fake, "G"))
+    assert abs(got - want) <= 1e-4 * abs(want) + 1e-6, (got, want)
+    assert gnorm > 0 and gnorm == gnorm and gnorm != float("inf")
+    # whole iterations as replays
+    cfg.training.update(hip_graph=True)
+    tg = Trainer(cfg, sync_scalars=False)
+    for it in range(1, 7):
+        out = tg.step(it)
+    assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
+    live = tg.graphs_live()
+    assert "g_fb" in live and all(live.values()), live

@@ -45,3 +45,31 @@ def test_flat_gradient_buffer_accumulates_chunks():
     m[0].weight.grad = None
     sync.collect()
     assert float(sync.flat[:12].abs().max()) == 0.0 and float(sync.flat[12:].abs().max()) > 0
+
+
+def test_dilation_and_init_weights_operator_api():
+    """ops.Dilation (reference common.py:256-271: a grouped transposed conv with a one-hot-plus-`value` kernel, stride
+    dilation + 1, padding 1) built as a strided placement + window sums, against that definition; ops.init_weights
+    (common.py:274-292)."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from gans.models import ops
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 5, 7)
+    for d, v in ((1, 0), (2, 0), (1, 0.5), (3, -0.25)):
+        m = ops.Dilation(d, v)
+        k = F.pad(torch.ones(1, 1, 1, 1), (d,) * 4, value=v).repeat(3, 1, 1, 1)
+        want = F.conv_transpose2d(x, k, stride=d + 1, padding=1, groups=3)
+        got = m(x)
+        assert got.shape == want.shape and float((got - want).abs().max()) < 1e-6
+        assert tuple(m.state_dict()["kernel"].shape) == (1, 1, 2 * d + 1, 2 * d + 1)
+    net = nn.Sequential(nn.Conv2d(4, 8, 3), nn.Linear(8, 8))
+    ops.init_weights(net, "ortho", gain=2.0)
+    w = net[1].weight
+    assert float((w @ w.t() - 4.0 * torch.eye(8)).abs().max()) < 1e-4 and float(net[0].bias.abs().max()) == 0.0
+    ops.init_weights(net, "N02")
+    assert 0.005 < float(net[0].weight.std()) < 0.04
+    ops.init_weights(net, "glorot")
+    bound = (6.0 / (8 + 8)) ** 0.5
+    assert float(net[1].weight.abs().max()) <= bound + 1e-6
