@@ -443,6 +443,7 @@ def main():
     # no step body may have fallen back to eager (Trainer._run warns and continues): a bench line must say so
     graphs_live = trainer.graphs_live()
     extra["graphs_live"] = graphs_live
+    extra["overlap_d_reduce"] = bool(getattr(trainer, "split_d", False))   # D's backward in two graphs, head reduced under the tail
     if cfg.training.hip_graph and not (graphs_live and all(graphs_live.values())):
         msg = f"a step body is not replaying as a hipGraph: {graphs_live}"
         if world == 1:

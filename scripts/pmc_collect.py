@@ -17,7 +17,7 @@ write = per_kernel(sys.argv[2], "WRITE_SIZE")
 res = {}
 # "alias=substring": record under `alias` the kernel whose name contains `substring`
 for key in (sys.argv[3:] or ("conv_wgrad_stream_kernel_f32=conv_wgrad_stream_kernel", "conv_pipe_kernel_s2dgrad=conv_pipe_kernel", "conv3x3_strip_kernel", "modconv_pe_fwd_kernel",
-                             "modconv_up_kernel", "modconv_up_t_kernel", "up2_lag_sumsq_kernel")):
+                             "modconv_up_kernel", "modconv_up_tl_kernel", "modconv_up_t_kernel", "up2_lag_sumsq_kernel")):
     key, _, sub = key.partition("=")
     sub = sub or key
     fk = [k for k in fetch if sub in k and (sub != "modconv_up_kernel" or "modconv_up_t" not in k)]
