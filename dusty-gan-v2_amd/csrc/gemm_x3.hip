@@ -75,12 +75,14 @@ template <bool TR, int BI> struct X3Op {
 };
 
 template <bool AT, bool BT, int MF, int NF>   // a wave owns (16 MF) x (16 NF) of C; 2 x 2 waves per block
-__global__ __launch_bounds__(256) void gemm_x3_kernel(float* __restrict__ out, const float* __restrict__ A,
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(float* __restrict__ out, const float* __restrict__ A,
                                                       const float* __restrict__ B, X3Geom g) {
   constexpr int BI = 32 * MF, BJ = 32 * NF;
   using OA = X3Op<AT, BI>;
   using OB = X3Op<BT, BJ>;
-  constexpr int BUF = 3 * (OA::PLANE + OB::PLANE);        // bf16 elements per stage
+  // ONE LDS stage of three planes per operand (48-52 KB): two or three blocks per CU hide each other's phases.  (With
+  // two stages and one block per CU -- the split riding inside the MFMA loop -- the data gradient took 78 us instead of
+  // 61, the weight gradient 97 instead of 68.)
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
 
@@ -107,8 +109,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(float* __restrict__ out, c
     lb[s] = OB::loff(tid + s * 256);
   }
   // Two register sets: the tile of step st + 2 is requested at the top of step st and split into LDS at the end of
-  // step st + 1 -- with one wave per SIMD nothing else hides the latency of these loads (distance 1: 88 us forward
-  // against the library's 80; the MFMA work is 21 us).
+  // step st + 1.
   uint4 ra[2][OA::SLOTS], rb[2][OB::SLOTS];
   auto gload = [&](auto set, int64_t t0) {
     constexpr int S = decltype(set)::value;
@@ -119,29 +120,26 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(float* __restrict__ out, c
 #pragma unroll
     for (int s = 0; s < OB::SLOTS; ++s) rb[S][s] = *reinterpret_cast<const uint4*>(bp + gb[s]);
   };
-  // one 16-byte slot of register set S -> its three planes in LDS stage `buf` (slot q < SLOTS of A, then those of B)
-  auto lstore_slot = [&](auto set, int buf, int q) {
+  auto lstore = [&](auto set) {
     constexpr int S = decltype(set)::value;
-    bf16_t* pa = lds + buf * BUF;
+    bf16_t* pa = lds;
     bf16_t* pb = pa + 3 * OA::PLANE;
-    uint2 h, m, l;
-    if (q < OA::SLOTS) {
-      split3(ra[S][q], h, m, l);
-      *reinterpret_cast<uint2*>(pa + la[q]) = h;
-      *reinterpret_cast<uint2*>(pa + OA::PLANE + la[q]) = m;
-      *reinterpret_cast<uint2*>(pa + 2 * OA::PLANE + la[q]) = l;
-    } else {
-      const int s = q - OA::SLOTS;
+#pragma unroll
+    for (int s = 0; s < OA::SLOTS; ++s) {
+      uint2 h, m, l;
+      split3(ra[S][s], h, m, l);
+      *reinterpret_cast<uint2*>(pa + la[s]) = h;
+      *reinterpret_cast<uint2*>(pa + OA::PLANE + la[s]) = m;
+      *reinterpret_cast<uint2*>(pa + 2 * OA::PLANE + la[s]) = l;
+    }
+#pragma unroll
+    for (int s = 0; s < OB::SLOTS; ++s) {
+      uint2 h, m, l;
       split3(rb[S][s], h, m, l);
       *reinterpret_cast<uint2*>(pb + lb[s]) = h;
       *reinterpret_cast<uint2*>(pb + OB::PLANE + lb[s]) = m;
       *reinterpret_cast<uint2*>(pb + 2 * OB::PLANE + lb[s]) = l;
     }
-  };
-  constexpr int NSLOT = OA::SLOTS + OB::SLOTS;
-  auto lstore = [&](auto set, int buf) {
-#pragma unroll
-    for (int q = 0; q < NSLOT; ++q) lstore_slot(set, buf, q);
   };
 
   f32x4 acc[MF][NF];
@@ -150,13 +148,9 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(float* __restrict__ out, c
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // The MFMA loop of a step with the split of the NEXT tile riding in it: a wave issues in order, and with one wave per
-  // SIMD the ~35 VALU instructions per slot (three roundings, two exact subtractions per value, the packing) would
-  // otherwise all run after the last MFMA -- 1.8 us per step against 0.7 us of MFMA time.  The six products of an
-  // (mf, nf) fragment are issued product-major over the MF independent accumulators; after every group of MF MFMAs the
-  // source places one slot of the split (NSLOT slots over 6 NF groups) and a scheduling barrier pins it there.
-  auto compute = [&](int cur, auto set_next, bool store_next) {
-    const bf16_t* pa = lds + cur * BUF;
+  // the six products of an (mf, nf) fragment are issued product-major over the MF independent accumulators
+  auto compute = [&]() {
+    const bf16_t* pa = lds;
     const bf16_t* pb = pa + 3 * OA::PLANE;
     union U { uint4 u; bf16x8 v; };
     U a[3][MF];
@@ -165,38 +159,35 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(float* __restrict__ out, c
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) a[p][mf].u = OA::frag(pa + p * OA::PLANE, wi * MF + mf, lane);
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
-    constexpr int GROUPS = 6 * NF, EVERY = GROUPS / NSLOT;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       U b[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) b[p].u = OB::frag(pb + p * OB::PLANE, wj * NF + nf, lane);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < 6; ++k)
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
           acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[k]][mf].v, b[PB[k]].v, acc[mf][nf], 0, 0, 0);
-        const int grp = nf * 6 + k;
-        if (store_next && grp % EVERY == 0 && grp / EVERY < NSLOT) lstore_slot(set_next, cur ^ 1, grp / EVERY);
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  // tile t lives in register set t & 1 and LDS stage t & 1
+  // tile t lives in register set t & 1; its split is written to LDS between two barriers
   auto step = [&](auto set_cur, int st) {
     constexpr int C = decltype(set_cur)::value;
     using SC = std::integral_constant<int, C>;
     using SN = std::integral_constant<int, C ^ 1>;
     if (st + 2 < steps) gload(SC{}, t_begin + (int64_t)(st + 2) * 32);   // set C is free: tile st went to LDS a step ago
-    compute(C, SN{}, st + 1 < steps);
+    compute();
+    __syncthreads();
+    if (st + 1 < steps) lstore(SN{});
     __syncthreads();
   };
   if (steps > 0) {
     gload(S0{}, t_begin);
     if (steps > 1) gload(S1{}, t_begin + 32);
-    lstore(S0{}, 0);
+    lstore(S0{});
   }
   __syncthreads();
   int st = 0;
@@ -239,7 +230,7 @@ int x3_launch(float* out, const float* A, const float* B, const X3Geom& g, int s
   constexpr int NF = 4;
   using OA = X3Op<AT, 32 * MF>;
   using OB = X3Op<BT, 32 * NF>;
-  const size_t lds = 2 * 3 * (size_t)(OA::PLANE + OB::PLANE) * sizeof(bf16_t);
+  const size_t lds = 3 * (size_t)(OA::PLANE + OB::PLANE) * sizeof(bf16_t);
   auto kern = gemm_x3_kernel<AT, BT, MF, NF>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -429,11 +429,11 @@ class _LinearF32(Function):
     """y = (x @ W^T) * scale in fp32 for the 65536 -> 512 Linear of the discriminator's fp32 epilogue
     (dusty_v2.py:381-383,394-395).  The three GEMMs run on the bf16 matrix cores through the three-plane split of
     dgv2_gemm_x3 (fp32-equivalent: its error is below what the library's fp32-MFMA GEMM leaves on the same operands),
-    the forward as split-K over the chip.  Measured (scripts/mb_linear_x3.py, M = 128): forward 84-88 us (library
-    split-K bmm + sum: 80), data gradient 77 (76), weight gradient 93 (89) -- parity, not a win: six bf16 products at the
-    ~1.5 GHz the part holds under bf16 MFMA load cost about what one fp32 product costs at its higher fp32-MFMA clock.
-    What it buys: the weight gradient is written straight into the parameter's slice of the flat gradient buffer when
-    FlatGradSync offers one (`_dgv2_grad_out`: no 268 MB pack copy), and no library GEMM in D's step."""
+    the forward as split-K over the chip.  Measured (scripts/mb_linear_x3.py, M = 128): forward 84 us (library split-K
+    bmm + sum: 79), data gradient 61 (75), weight gradient 68 (90) -- six bf16 products at the ~1.5 GHz the part holds
+    under bf16 MFMA load cost about what one fp32 product costs at its higher fp32-MFMA clock, so the gain is modest.
+    The weight gradient is written straight into the parameter's slice of the flat gradient buffer when FlatGradSync
+    offers one (`_dgv2_grad_out`: no 268 MB pack copy), and D's step has no library GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight, scale):
