@@ -3,6 +3,7 @@
 Part of gans.models.ops.native (autograd-aware wrappers around the libdgv2 C ABI, see the package docstring); the
 parts import each other in order, every name stays reachable as native.<name>.
 """
+import contextlib
 import math
 import os
 
@@ -28,6 +29,31 @@ def _bias_act_raw(x, bias, ref, grad, alpha, scale, step_b, size_b):
     N.call("dgv2_fused_bias_act", N.ptr(y), N.ptr(x), N.ptr(bias), N.ptr(ref), x.numel(), step_b, size_b,
            3, grad, alpha, scale, _dt(x), N.stream())
     return y
+
+
+# ---------------------------------------------------------------------------------------
+# Input gradients only.  ctx.needs_input_grad of a Python autograd Function is fixed at FORWARD time (does the input
+# require grad at all), not per backward call: torch.autograd.grad(y, inputs=[x], create_graph=True) -- the first pass of
+# R1 (reference trainer.py:429-433) and of the path-length regulariser -- makes every Function compute its weight and
+# bias gradients too, to throw them away (a third of a backward pass: the fp32 epilogue conv's weight gradient alone is
+# 415 us at B = 64).  The trainer brackets exactly that call with input_grads_only(); the backward methods ask
+# want_param_grad(ctx, i) instead of ctx.needs_input_grad[i] for parameter inputs.
+# ---------------------------------------------------------------------------------------
+_INPUT_GRADS_ONLY = [False]
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    old = _INPUT_GRADS_ONLY[0]
+    _INPUT_GRADS_ONLY[0] = True
+    try:
+        yield
+    finally:
+        _INPUT_GRADS_ONLY[0] = old
+
+
+def want_param_grad(ctx, i):
+    return ctx.needs_input_grad[i] and not _INPUT_GRADS_ONLY[0]
 
 
 class _BiasActBackward(Function):
@@ -78,7 +104,7 @@ class _BiasAct(Function):
     def backward(ctx, gy):
         (out,) = ctx.saved_tensors
         has_bias, alpha, scale, step_b, size_b = ctx.cfg
-        gx, gb = _BiasActBackward.apply(gy, out, has_bias, alpha, scale, step_b, size_b)
+        gx, gb = _BiasActBackward.apply(gy, out, has_bias and want_param_grad(ctx, 1), alpha, scale, step_b, size_b)
         return gx, (None if gb is None else gb.to(gy.dtype)), None, None, None
 
 

@@ -270,7 +270,7 @@ class _ConvFwd(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if want_param_grad(ctx, 1) else None
         return gx, gw, None
 
 
@@ -348,9 +348,9 @@ class _ConvAct(Function):
     def backward(ctx, gy):
         x, w, out = ctx.saved_tensors
         g, alpha, scale, size_b = ctx.cfg
-        gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
+        gpre, gb = _BiasActBackward.apply(gy, out, want_param_grad(ctx, 2), alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if want_param_grad(ctx, 1) else None
         return gx, gw, gb, None, None, None
 
 
@@ -464,7 +464,7 @@ class _LinearF32(Function):
         x, weight = ctx.saved_tensors
         if torch.is_grad_enabled():   # create_graph=True (R1): differentiable ops
             g = gy * ctx.scale
-            return g @ weight, g.t() @ x, None
+            return g @ weight, (g.t() @ x if want_param_grad(ctx, 1) else None), None
         Bn, K = x.shape
         O = weight.shape[0]
         gx = gw = None
@@ -776,7 +776,7 @@ class _ConvResid(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if want_param_grad(ctx, 1) else None
         return gx, gw, (gy if ctx.needs_input_grad[2] else None), None
 
 

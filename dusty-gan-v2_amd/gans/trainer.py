@@ -28,6 +28,7 @@ from gans.datasets.synthetic import SyntheticRangeImages
 from gans.models.builder import build_discriminator, build_generator
 from gans.models.loss import GANLoss
 from gans.models.ops.common import filter2d
+from gans.models.ops.native import input_grads_only
 from gans.utils import set_requires_grad, tanh_to_sigmoid
 
 
@@ -349,7 +350,10 @@ class Trainer:
         self.d_sync.begin(direct=False)
         x = x_real.detach().requires_grad_(True)
         y_real = self.D(self.A(self.warmup(x, self._draw("r1.keep")), draws=self._ada("r1.ada")), double_backward=True)
-        (grads,) = torch.autograd.grad(outputs=[y_real.sum()], inputs=[x], create_graph=True)
+        # (only the gradient w.r.t. the input is taken here: the Functions skip their weight / bias gradients, which
+        # ctx.needs_input_grad alone would make them compute and discard)
+        with input_grads_only():
+            (grads,) = torch.autograd.grad(outputs=[y_real.sum()], inputs=[x], create_graph=True)
         r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
         loss = (self.gp_weight / 2) * r1 + 0.0 * y_real.squeeze()[0]
         loss.backward()
