@@ -93,6 +93,7 @@ class _BiasActBackward(Function):
 class _BiasAct(Function):
     @staticmethod
     def forward(ctx, x, bias, alpha, scale, step_b):
+        ctx.set_materialize_grads(False)   # an absent cotangent stays absent (see conv._ConvAct)
         x = x.contiguous()
         size_b = 1 if bias is None else bias.numel()
         out = _bias_act_raw(x, None if bias is None else bias.contiguous(), None, 0, alpha, scale, step_b, size_b)
@@ -102,6 +103,8 @@ class _BiasAct(Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return None, None, None, None, None
         (out,) = ctx.saved_tensors
         has_bias, alpha, scale, step_b, size_b = ctx.cfg
         gx, gb = _BiasActBackward.apply(gy, out, has_bias and want_param_grad(ctx, 1), alpha, scale, step_b, size_b)

@@ -355,7 +355,15 @@ class Trainer:
         with input_grads_only():
             (grads,) = torch.autograd.grad(outputs=[y_real.sum()], inputs=[x], create_graph=True)
         r1 = (grads ** 2).sum(dim=[1, 2, 3]).mean()
-        loss = (self.gp_weight / 2) * r1 + 0.0 * y_real.squeeze()[0]
+        # The reference adds `0.0 * y_real.squeeze()[0]` (trainer.py:441) so that every parameter of D receives a
+        # gradient under DDP: an exactly-zero cotangent pushed through D's forward graph from the top, i.e. a data and a
+        # weight gradient OF ZEROS through the two Linear layers and the fp32 epilogue conv (the only real second-order
+        # path into the forward graph, minibatch-stddev's backward, enters below them).  collect() zero-fills the slices
+        # of parameters without a gradient, which is what the term produces for them: same flat gradient, same Adam
+        # step.  (DGV2_R1_ZERO_TERM restores the literal form for A/B runs.)
+        loss = (self.gp_weight / 2) * r1
+        if os.environ.get("DGV2_R1_ZERO_TERM"):
+            loss = loss + 0.0 * y_real.squeeze()[0]
         loss.backward()
         self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
         scalars["loss/D/gradient_penalty"] = r1.detach()
