@@ -91,6 +91,9 @@ def test_r1_double_backward_through_the_vanilla_discriminator():
     for (n, _), v in zip(D.named_parameters(), gr):
         key = f"vanilla.gR1.{n}"
         if key in d.files:
+            if v is None:   # no path to this parameter: the reference's gradient for it must be exactly zero
+                assert not np.asarray(d[key]).any(), key
+                v = torch.zeros(d[key].shape, device=DEV)
             close(v, d[key], tol=5e-4, what=key)
             seen += 1
     assert seen >= 5
