@@ -143,6 +143,40 @@ def test_d_step_and_r1_gradients(models, g_small):
         assert abs(float(g.norm()) - want_norm) <= 2e-3 * want_norm + 1e-4 * top, k
 
 
+def test_r1_is_unchanged_by_skipping_discarded_gradients(models, g_small):
+    """native.input_grads_only() around R1's first pass (only the gradient w.r.t. the input is taken: reference
+    trainer.py:429-433) and absent-stays-absent cotangents in the second: the penalty's parameter gradients must be
+    the ones the plain composition gives (the same kernels on the same data: only discarded work and all-zero passes are gone;
+    a parameter the penalty cannot reach may come back as None instead of zeros)."""
+    from gans.models.ops import native
+    cfg, G, D, A = models
+    load(G, D, g_small, "G1buf.")
+    D = D.train().requires_grad_(True)
+    x = g_small["x_real"].to(DEV)
+
+    def r1_grads(skip):
+        xin = x.clone().requires_grad_(True)
+        y = D(xin, double_backward=True)
+        if skip:
+            with native.input_grads_only():
+                (gx,) = torch.autograd.grad(y.sum(), xin, create_graph=True)
+            loss = (gx ** 2).sum(dim=[1, 2, 3]).mean()
+        else:
+            (gx,) = torch.autograd.grad(y.sum(), xin, create_graph=True)
+            loss = (gx ** 2).sum(dim=[1, 2, 3]).mean() + 0.0 * y.squeeze()[0]
+        return torch.autograd.grad(loss, list(D.parameters()), allow_unused=True)
+
+    a, b = r1_grads(False), r1_grads(True)
+    top = max(float(g.abs().max()) for g in a if g is not None)
+    for (n, _), ga, gb in zip(D.named_parameters(), a, b):
+        if gb is None:
+            assert ga is None or not bool(ga.any()), n
+        else:   # the same kernels on the same data up to the summation order of the bias / weight-gradient reductions
+            #     (R1's bias gradients are cancelling sums many orders below the weight gradients: absolute floor)
+            assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-7 * top, n
+    D.requires_grad_(False)
+
+
 def test_discriminator_stacked_sub_batches(models, g_small):
     """D(cat(real, fake), splits=2) == cat(D(real), D(fake)): the one-pass form used by the D step."""
     cfg, G, D, A = models
