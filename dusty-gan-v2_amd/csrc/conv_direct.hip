@@ -100,6 +100,10 @@ struct DConv {
   int s2d;          // four classes = the canonical stride-2 3x3 data gradient (host-checked tap list): unrolled taps
   int wres;         // tap-list kernels, 2 K-chunks: both chunks' weight slabs stay in LDS for the block's whole walk
   int nt;           // streaming output stores (outputs >= DGV2_NT_MIN_MB that no residual read revisits)
+  // XCD-aware block order (1-D launch): workgroup n runs on XCD n % 8 (each XCD has its own L2), so the gz blocks that
+  // share one pixel tile's input -- one per output-channel tile -- are given ids 8 apart: same XCD, dispatched back to
+  // back, the halo tile is fetched into that L2 once instead of once per channel tile from HBM / MALL
+  int xcd, gx, gy, gz;
   // image pairs (4-row maps): the launch sees B/2 stacked pairs of `hper`-row images as 2*hper-row maps, so an 8-row
   // tile covers two images and the weight slab is staged once for both; rows clamp / zero-fill per image and each image
   // brings its own `hrows` halo rows
@@ -185,10 +189,19 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
   const int lr = lane & 15, lc = lane >> 4;
   const int tiles_h = (p.Hg + TH - 1) / TH;
   const int tiles_w = (p.Wg + DTW - 1) / DTW;
-  const int b = blockIdx.y / tiles_h;
-  const int h0 = (blockIdx.y % tiles_h) * TH;
-  const int o0 = blockIdx.z * TO;
-  const int tw0 = blockIdx.x * p.tpb;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd) {
+    const int n = blockIdx.x, q = n >> 3;
+    const int pt = (q / p.gz) * 8 + (n & 7);      // pixel tile (x fastest); the grid is padded to whole groups of 8
+    if (pt >= p.gx * p.gy) return;
+    bz = q % p.gz;
+    bx = pt % p.gx;
+    by = pt / p.gx;
+  }
+  const int b = by / tiles_h;
+  const int h0 = (by % tiles_h) * TH;
+  const int o0 = bz * TO;
+  const int tw0 = bx * p.tpb;
   const int ntile = min(p.tpb, tiles_w - tw0);
   const T* xb = x + (int64_t)b * p.Hin * p.Win * p.Cin;
   const int kchunk = 4 * CE;
@@ -730,6 +743,14 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   p.tpb = tpb;
   p.nt = (!p.resid && !p.accumulate && nt_output((int64_t)p.B * p.Hy * p.Wy * p.ldy * sizeof(TY))) ? 1 : 0;
   dim3 grid((tiles_w + tpb - 1) / tpb, tiles_h * p.B, tiles_o);
+  static const bool no_xcd = getenv("DGV2_CONV_NO_XCD") != nullptr;   // A/B switch for benchmarking
+  p.xcd = 0;
+  if (!no_xcd && tiles_o >= 2) {
+    p.xcd = 1;
+    p.gx = grid.x; p.gy = grid.y; p.gz = grid.z;
+    const int64_t npt = ((int64_t)grid.x * grid.y + 7) / 8 * 8;
+    grid = dim3((unsigned)(npt * grid.z), 1, 1);
+  }
   kern<<<grid, 256, lds, st>>>((TY*)y, (const T*)x, (const T*)w, p);
   return 0;
 }
@@ -877,7 +898,7 @@ static int conv_taps_impl(void* y, int ldy, const void* x, const void* w, int B,
   p.rows = dymax - dymin + 1;   // tap extents; the launchers add the tile extent
   p.cols = dxmax - dxmin + 1;
   p.hzero = hzero; p.ring = ring; p.accumulate = accumulate;
-  p.tpb = 1; p.inv_cols = 0.f; p.wres = 0; p.s2d = 0;
+  p.tpb = 1; p.inv_cols = 0.f; p.wres = 0; p.s2d = 0; p.xcd = 0; p.gx = p.gy = p.gz = 1;
 #ifdef DGV2_ABLATE
   p.ablate = getenv("DGV2_CP_ABLATE") ? atoi(getenv("DGV2_CP_ABLATE")) : 0;
 #endif
