@@ -19,6 +19,7 @@ struct PWGeom {
   int pchunk;               // pixels per split (multiple of 32)
   int64_t part_stride;      // B * O * Ks
   int64_t ldo;              // row pitch of the output (Ks for the partials of a split launch)
+  int nz;                   // splits
 };
 
 constexpr int PW_ROW = 128 + 16;   // bf16 elements per LDS row: 288 bytes = 8 dwords mod 64 (see gemm_x3.hip)
@@ -34,9 +35,17 @@ __global__ __launch_bounds__(256) void pe_wgrad_kernel(float* __restrict__ part,
   __shared__ __attribute__((aligned(16))) bf16_t lds[2][2 * PW_PLANE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wi = wave >> 1, wj = wave & 1;
-  const int n0 = blockIdx.x * 128;
-  const int row0 = blockIdx.y * 128;          // row = b * O + o
-  const int p_begin = blockIdx.z * q.pchunk;
+  // XCD-aware block order (1-D launch; workgroup n runs on XCD n % 8): the Ks / 128 blocks that contract the SAME rows
+  // of g over the same pixels get ids 8 apart, i.e. one XCD's L2 fetches that slice of g once for all of them
+  const int nid = blockIdx.x, qid = nid >> 3;
+  const int nk = q.Ks >> 7;
+  const int rest = (qid / nk) * 8 + (nid & 7);       // (row tile, split), row tile fastest
+  const int ny = q.B * q.O / 128;
+  if (rest >= ny * q.nz) return;
+  const int n0 = (qid % nk) * 128;
+  const int row0 = (rest % ny) * 128;         // row = b * O + o
+  const int bz = rest / ny;
+  const int p_begin = bz * q.pchunk;
   const int p_end = min(p_begin + q.pchunk, q.P);
   const int steps = (p_end - p_begin) / 32;
 
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256) void pe_wgrad_kernel(float* __restrict__ part,
   if (st < steps) step(S0{}, st);
 
   // D layout: column (k) = lane & 15, rows = 4 (lane >> 4) + r
-  float* ob = part + (int64_t)blockIdx.z * q.part_stride;
+  float* ob = part + (int64_t)bz * q.part_stride;
   const int lr = lane & 15, lc = lane >> 4;
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf)
@@ -182,9 +191,10 @@ extern "C" int dgv2_pe_wgrad(float* gw, float* scratch, int64_t scratch_elems, c
   splits = (P + pchunk - 1) / pchunk;
   const int64_t n = (int64_t)B * O * Ks;
   if (scratch_elems < (int64_t)splits * n) return DGV2_EINVAL;
-  PWGeom q{B, P, O, Ks, pchunk, n, splits > 1 ? (int64_t)Ks : ldo};
+  PWGeom q{B, P, O, Ks, pchunk, n, splits > 1 ? (int64_t)Ks : ldo, splits};
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(Ks / 128, B * O / 128, splits);
+  const int64_t rest = ((int64_t)(B * O / 128) * splits + 7) / 8 * 8;
+  dim3 grid((unsigned)(rest * (Ks / 128)), 1, 1);
   if (splits == 1) {   // enough tiles to fill the chip: every block writes its finished tile
     pe_wgrad_kernel<<<grid, 256, 0, st>>>(gw + col0, (const bf16_t*)g, (const bf16_t*)pe, q);
     DGV2_RETURN_LAST();
