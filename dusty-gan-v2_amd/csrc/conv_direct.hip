@@ -745,7 +745,7 @@ int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) 
   dim3 grid((tiles_w + tpb - 1) / tpb, tiles_h * p.B, tiles_o);
   static const bool no_xcd = getenv("DGV2_CONV_NO_XCD") != nullptr;   // A/B switch for benchmarking
   p.xcd = 0;
-  if (!no_xcd && tiles_o >= 2) {
+  if (!no_xcd && tiles_o >= 2 && sizeof(T) < 4) {   // (the MFMA-bound fp32 instances gain nothing: 673 vs 681 us)
     p.xcd = 1;
     p.gx = grid.x; p.gy = grid.y; p.gz = grid.z;
     const int64_t npt = ((int64_t)grid.x * grid.y + 7) / 8 * 8;
