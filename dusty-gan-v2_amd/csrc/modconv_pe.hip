@@ -241,6 +241,17 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   }
 #undef MP_DS_READ
 #undef MP_LGKM_WAIT
+  // The last step issued one more round of xa loads (a re-read of the last sample) that nothing consumes.  They are
+  // asm-issued: the compiler takes their destination registers for dead past the loop and would hand them to the
+  // reduction below while the loads are still in flight -- a late return then overwrites a partial sum.  Drain, and keep
+  // the registers allocated up to the drain.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+      for (int kc = 0; kc < KAR; ++kc) asm volatile("" : "+v"(xr[s2][nf][kc]));
   if (g.sumsq) {
     __shared__ float red[16];
     const float s = block_sum(ss, red);

@@ -230,6 +230,36 @@ def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
                 assert_rel(y.float().cpu(), want, 8e-3)
 
 
+@pytest.mark.parametrize("P,I,O", [(32768, 32, 32), (32768, 64, 32), (8192, 64, 64)])
+def test_modconv_pe_sumsq_partials_are_reproducible(nat, P, I, O):
+    """The per-block sum-of-squares partials of dgv2_modconv_pe_fwd_sq (the EMA variance of the next layer's
+    input-magnitude factor, dusty_v2.py:118-126 / style.py:84-93) are a function of the inputs alone: 400 launches on
+    the same operands give the same bits, and the partials add up to the sum of squares of the stored output.
+    Regression: the sample walk's last step pre-issues (asm) fragment loads that nothing consumes; without a drain their
+    destination registers were reused by the block reduction and a late return overwrote a partial (about one launch in
+    200 at these sizes: partials off by tens of per cent, the output itself always right)."""
+    g = torch.Generator().manual_seed(5)
+    B = 64
+    x = torch.randn(B, P, I, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(B, O, I, generator=g) / 8).to(DEV).bfloat16()
+    bias, cvec = torch.randn(O, generator=g).to(DEV), torch.ones(O, device=DEV)
+
+    def run():
+        sq = nat._sq_args(x.device)
+        y = nat._bmm_nn_raw(x, w, torch.bfloat16, bias=bias, act=3, alpha=0.2, scale=math.sqrt(2.0), sq=sq, row_scale=cvec)
+        return y, sq[0][:sq[1].value].clone()
+
+    y0, p0 = run()
+    assert p0.numel() > 0
+    want = float(y0.double().square().sum())
+    assert abs(float(p0.double().sum()) - want) <= 1e-5 * want
+    bad = 0
+    for _ in range(400):
+        y, p = run()
+        bad += int(not (torch.equal(p, p0) and torch.equal(y, y0)))
+    assert bad == 0, f"{bad} of 400 launches differ from the first"
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_batched_weight_preparation_matches_per_layer_path(nat, dtype, tol):
     """dgv2_mod_prep_all_fwd/_bwd + GEMM row scale (all layers of a pass prepared in one launch, the input-magnitude
