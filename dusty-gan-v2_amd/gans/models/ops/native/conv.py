@@ -165,8 +165,13 @@ def _conv_dgrad_raw(gy, w, g, xshape, wt=None, resid=None):
     """w [O,kh,kw,C] in gy's dtype, or wt = the prepared transposed weights [C, kh*kw, O] (weight bank)."""
     B, H, W, C = xshape
     O = gy.shape[3]
-    if wt is None:
-        wt = w.permute(3, 1, 2, 0).contiguous()
+    if wt is None:   # cached on the values tensor (see modgemm._values): first and second pass of R1 share it
+        c = getattr(w, "_dgv2_wt", None)
+        if c is not None and c[0] == w._version:
+            wt = c[1]
+        else:
+            wt = w.permute(3, 1, 2, 0).contiguous()
+            w._dgv2_wt = (w._version, wt)
     N.check(gy, wt, resid)
     even = g.stride == 1 or (H % 2 == 0 and W % 2 == 0)
     if _direct_ok(g, O % _kstep(gy) == 0) and even and not (g.kh == 1 and g.stride == 2):

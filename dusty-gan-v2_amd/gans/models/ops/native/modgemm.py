@@ -353,6 +353,16 @@ def _values(w, dtype):
     if getattr(w, "_dgv2_handle", False):
         raise RuntimeError("conv weight handle without values: run this pass without the weight bank "
                            "(Discriminator.forward(double_backward=True))")
-    return w.detach().to(dtype).contiguous()
+    # one conversion per weight tensor and pass: the second-order passes of R1 (bank off) use each effective weight in
+    # the forward conv, the data gradient and the conv of the double backward -- the copy rides on the tensor object
+    # (a fresh `weight * gain` per forward; `_version` guards a parameter used directly)
+    if w.dtype == dtype and w.is_contiguous():
+        return w.detach()
+    c = getattr(w, "_dgv2_vals", None)
+    if c is not None and c[0] == w._version and c[1].dtype == dtype:
+        return c[1]
+    v = w.detach().to(dtype).contiguous()
+    w._dgv2_vals = (w._version, v)
+    return v
 
 __all__ = [n_ for n_ in dir() if not n_.startswith("__")]

@@ -27,8 +27,18 @@ class Census(TorchDispatchMode):
             shp = tuple(tuple(t.shape) for t in a[:2] if isinstance(t, torch.Tensor))
             counts[(name, site, shp if site == "autograd-engine" else ())] += 1
         return func(*a, **(k or {}))
+IT = int(sys.argv[1]) if len(sys.argv) > 1 else 3   # 16: an R1 iteration
+if IT % 16 == 0:
+    tr.step(IT - 1)
+base = None
+if IT % 16 == 0:   # census of a plain iteration first, printed as the difference
+    with Census():
+        tr.step(IT + 3)
+    base, counts = counts, collections.Counter()
 with Census():
-    tr.step(3)
+    tr.step(IT)
+if base:
+    counts = counts - base
 torch.cuda.synchronize()
 for (n, site, shp), c in sorted(counts.items(), key=lambda kv: -kv[1])[:110]:
     print(f"x{c:4d} {n:30s} {site} {shp if shp else ''}")

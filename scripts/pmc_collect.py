@@ -20,6 +20,14 @@ for key in (sys.argv[3:] or ("conv_wgrad_stream_kernel_f32=conv_wgrad_stream_ker
                              "modconv_up_kernel", "modconv_up_tl_kernel", "modconv_up_t_kernel", "up2_lag_sumsq_kernel")):
     key, _, sub = key.partition("=")
     sub = sub or key
+    if sub.endswith("*"):   # every instance whose name contains the substring, each under its own name
+        for k in sorted(k for k in fetch if sub[:-1] in k and k in write):
+            fv, wv = fetch[k], write[k]
+            f_raw, w_raw = sum(fv) / len(fv), sum(wv) / len(wv)
+            res[k[:150]] = {"launches": len(fv), "FETCH_SIZE_KB_raw": f_raw, "WRITE_SIZE_KB_raw": w_raw,
+                            "fetch_bytes_corrected": 2 * f_raw * 1024, "write_bytes": w_raw * 1024,
+                            "traffic_bytes_per_launch": 2 * f_raw * 1024 + w_raw * 1024}
+        continue
     fk = [k for k in fetch if sub in k and (sub != "modconv_up_kernel" or "modconv_up_t" not in k)]
     wk = [k for k in write if sub in k and (sub != "modconv_up_kernel" or "modconv_up_t" not in k)]
     if not fk or not wk:

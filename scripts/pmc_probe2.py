@@ -20,4 +20,13 @@ x2 = torch.randn(128, 8, 64, 256, device="cuda", dtype=torch.bfloat16)
 w2 = torch.randn(256, 3, 3, 256, device="cuda", dtype=torch.bfloat16)
 for _ in range(6):
     nat._conv_fwd_raw(x2, w2, g)
+# round 3: the stride-2 forward convs of D's blocks (as scripts/mb_conv_s2.py runs them): 128 x 32x256 x 64 -> 16x128 x 128
+# (algorithmic 134.2 MB in + 67.1 MB out) and 128 x 8x64 x 256 -> 4x32 x 512 (33.6 MB in + 16.8 MB out + 2.4 MB of weights)
+if len(sys.argv) > 1 and sys.argv[1] == "s2":
+    g2 = nat.ConvGeom(3, 3, 2, 1, True)
+    for (H, W, C, O) in ((32, 256, 64, 128), (8, 64, 256, 512)):
+        xs = torch.randn(128, H, W, C, device="cuda", dtype=torch.bfloat16)
+        ws = torch.randn(O, 3, 3, C, device="cuda", dtype=torch.bfloat16)
+        for _ in range(6):
+            nat._conv_fwd_raw(xs, ws, g2)
 torch.cuda.synchronize()
