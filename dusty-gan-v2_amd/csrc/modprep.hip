@@ -544,6 +544,52 @@ extern "C" int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, 
   DGV2_RETURN_LAST();
 }
 
+// The same update for a GROUP of layers that share their input (the output heads of a level, dusty_v2.py:32-57: one
+// ModConv2d per output, each with its own ema_var buffer): block i updates emas[i] and fills rows[i] entries of cvec
+// behind those of the blocks before it.  One launch instead of one per head.
+struct EmaGroup {
+  float* ema[8];
+  int rows[8];
+};
+static __global__ void ema_scalar_group_kernel(EmaGroup grp, const float* sumsq, int nsum, float add, float inv_count,
+                                               float weight, int update, float* cvec) {
+  float s = 0.f;
+  if (sumsq) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // the summation order of ema_scalar_kernel: same bits
+    int k = threadIdx.x;
+    for (; k + 192 < nsum; k += 256) {
+      s0 += sumsq[k];
+      s1 += sumsq[k + 64];
+      s2 += sumsq[k + 128];
+      s3 += sumsq[k + 192];
+    }
+    for (; k < nsum; k += 64) s0 += sumsq[k];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  s = wave_sum(s);
+  const int i = blockIdx.x;
+  float v = grp.ema[i][0];
+  if (update) v += weight * ((s + add) * inv_count - v);
+  if (threadIdx.x == 0 && update) grp.ema[i][0] = v;
+  int off = 0;
+  for (int j = 0; j < i; ++j) off += grp.rows[j];
+  const float c = 1.f / (sqrtf(v) + 1e-8f);
+  for (int r = threadIdx.x; r < grp.rows[i]; r += 64) cvec[off + r] = c;
+}
+
+extern "C" int dgv2_ema_scalar_group(float* const* emas, const int* rows, int n, const float* sumsq, int nsum, float add,
+                                     float inv_count, float weight, int update, float* cvec, void* stream) {
+  if (!emas || !rows || n < 1 || n > 8 || nsum < 0 || !cvec) return DGV2_EINVAL;
+  EmaGroup grp;
+  for (int i = 0; i < 8; ++i) {
+    grp.ema[i] = i < n ? emas[i] : nullptr;
+    grp.rows[i] = i < n ? rows[i] : 0;
+    if (i < n && (!emas[i] || rows[i] < 0)) return DGV2_EINVAL;
+  }
+  ema_scalar_group_kernel<<<n, 64, 0, (hipStream_t)stream>>>(grp, sumsq, nsum, add, inv_count, weight, update, cvec);
+  DGV2_RETURN_LAST();
+}
+
 // Forward.  stats: fp32 [2 + 2B] scratch (filled here when demod); dsave: fp32 [B,O] (saved for backward).
 extern "C" int dgv2_mod_prep_fwd(void* wb, float* dsave, float* stats, const float* W, const float* s,
                                  const float* ema_var, const float* shift, const float* fw, int B, int O, int I,

@@ -186,7 +186,8 @@ template <typename T, int CC>
 __global__ __launch_bounds__(256) void resample_tab_smallc_kernel(
     T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
     const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
-    const int* __restrict__ cnt_w, int Ew, int B, int in_h, int in_w, int out_h, int out_w) {
+    const int* __restrict__ cnt_w, int Ew, int B, int in_h, int in_w, int out_h, int out_w,
+    const T* __restrict__ resid = nullptr) {
   struct alignas(sizeof(T) * CC) Px { T e[CC]; };
   const int64_t total = (int64_t)B * out_h * out_w;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -210,8 +211,14 @@ __global__ __launch_bounds__(256) void resample_tab_smallc_kernel(
       }
     }
     Px o;
+    if (resid) {   // y = resid + resample(x): the running image of the generator's skip pyramid (dusty_v2.py:179-180)
+      const Px rv = reinterpret_cast<const Px*>(resid)[t];
 #pragma unroll
-    for (int j = 0; j < CC; ++j) o.e[j] = from_f32<T>(acc[j]);
+      for (int j = 0; j < CC; ++j) o.e[j] = from_f32<T>(to_f32(rv.e[j]) + to_f32(from_f32<T>(acc[j])));
+    } else {
+#pragma unroll
+      for (int j = 0; j < CC; ++j) o.e[j] = from_f32<T>(acc[j]);
+    }
     reinterpret_cast<Px*>(y)[t] = o;
   }
 }
@@ -537,6 +544,29 @@ extern "C" int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const
                                  void* stream) {
   return dgv2_resample_tab_sq(y, x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C, ldx, ldy, in_h, in_w, out_h,
                               out_w, dtype, nullptr, 0, nullptr, stream);
+}
+
+// y = resid + resample(x) for packed few-channel images (C in {1, 2, 4}, ld = C): the generator's output pyramid,
+// `o + self.resample(skip)` of SynthesisBlock.forward (dusty_v2.py:179-180), in the resampler's own store -- same bits
+// as the two-launch form (the resampled value is rounded to the storage type before the add).  DGV2_ENOTSUP otherwise.
+extern "C" int dgv2_resample_tab_add(void* y, const void* x, const void* resid, const int* idx_h, const float* coef_h,
+                                     const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w,
+                                     int Ew, int B, int C, int in_h, int in_w, int out_h, int out_w, int dtype,
+                                     void* stream) {
+  if (!y || !x || !resid || !idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w) return DGV2_EINVAL;
+  if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || Eh <= 0 || Ew <= 0) return DGV2_EINVAL;
+  if (!(C == 1 || C == 2 || C == 4)) return DGV2_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  DGV2_DISPATCH_DTYPE(dtype, {
+    const uintptr_t al = sizeof(T) * C;
+    if (reinterpret_cast<uintptr_t>(x) % al || reinterpret_cast<uintptr_t>(y) % al || reinterpret_cast<uintptr_t>(resid) % al)
+      return DGV2_ENOTSUP;
+    const int g2 = grid_for((int64_t)B * out_h * out_w, 256, 256 * 64);
+    if (C == 1) resample_tab_smallc_kernel<T, 1><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w, (const T*)resid);
+    else if (C == 2) resample_tab_smallc_kernel<T, 2><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w, (const T*)resid);
+    else resample_tab_smallc_kernel<T, 4><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w, (const T*)resid);
+  });
+  DGV2_RETURN_LAST();
 }
 
 // dgv2_resample_tab with the result stored as e4m3 (OCP fp8, unit scale, saturating at +-448) instead of bf16:

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGV2_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     "dgv2_upfirdn2d": [_c_ptr] * 3 + [_c_int] * 15 + [_c_ptr],
     "dgv2_resample": [_c_ptr] * 4 + [_c_int] * 19 + [_c_ptr],
     "dgv2_resample_tab": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr],
+    "dgv2_resample_tab_add": [_c_ptr] * 6 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 8 + [_c_ptr],
     "dgv2_fourier_feature": [_c_ptr] * 5 + [_c_int] * 8 + [_c_ptr],
     "dgv2_downsample_angle": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr],
     "dgv2_bmm_nn": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr],
@@ -94,6 +95,7 @@ SIGNATURES = {
     "dgv2_pack2d": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_unpack2d": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_ema_scalar": [_c_ptr] * 3 + [_c_int] + [_c_f32] * 3 + [_c_int, _c_ptr, _c_int, _c_ptr],
+    "dgv2_ema_scalar_group": [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_int] + [_c_f32] * 3 + [_c_int, _c_ptr, _c_ptr],
     "dgv2_bmm_nn_small": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr],
     "dgv2_bmm_nn_small_act": [_c_ptr] * 4 + [_c_int] * 4 + [_c_ptr, _c_ptr, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int,
                               _c_ptr],

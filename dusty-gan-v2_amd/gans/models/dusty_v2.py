@@ -72,13 +72,23 @@ class Head(nn.Module):
         if sumsq is None and self.training:
             sumsq = native.sum_squares(x)
         heads = list(self.heads.values())
-        bias = torch.cat([head.bias.reshape(-1) for head in heads])
+        bias = getattr(heads[0], "_bias_cat", None)   # this pass's slice of the all-level concatenation (_batched_weights)
+        if bias is None:
+            bias = torch.cat([head.bias.reshape(-1) for head in heads])
         if heads[0]._prep is not None:   # weights of the whole pass prepared up front (SynthesisNetwork._batched_weights)
             handle, wb, cvec, wt = heads[0]._prep
-            off = 0
-            for head in heads:
-                head.update_ema(sumsq, x.numel(), 0.0, cvec[off:off + head.out_ch])
-                off += head.out_ch
+            h0 = heads[0]   # all heads see the same input: their EMA updates (style.py:98-103) are one launch
+            same = all(h.ema == h0.ema and h.ema_decay == h0.ema_decay for h in heads)
+            if same and len(heads) <= 8:
+                upd = h0.ema and h0.training and sumsq is not None
+                with torch.no_grad():
+                    native.ema_update_group([h.ema_var for h in heads], [h.out_ch for h in heads], sumsq, 0.0,
+                                            x.numel() if upd else 1, 1 - h0.ema_decay, upd, cvec)
+            else:
+                off = 0
+                for head in heads:
+                    head.update_ema(sumsq, x.numel(), 0.0, cvec[off:off + head.out_ch])
+                    off += head.out_ch
             # fork: also return x for the NEXT consumer (the following block), so that both gradients of x meet in
             # this layer's data-gradient GEMM
             return native.mod_gemm_layer(x, None, handle, wb, cvec, bias=bias, act=False, out_dtype=torch.float32, wt=wt,
@@ -265,8 +275,8 @@ class SynthesisBlock(nn.Module):
         o = self.head.forward_cl(h, ws[nxt], sumsq=sq_h, fork=True, upstream=up)
         if isinstance(o, tuple):
             o, h = o
-        if skip is not None:
-            o = o + self.resample.forward_cl(skip)
+        if skip is not None:   # o + up(skip) in the resampler's store (dusty_v2.py:179-180)
+            o = native.resample_add(skip, o, self.resample.spec)
         return h, o
 
     def forward_composable(self, h, skip, ws, angle, shift, B):
@@ -420,6 +430,7 @@ class SynthesisNetwork(nn.Module):
             for m in cached:
                 m._style_cache = None
                 m._prep = None
+                m._bias_cat = None
         return skip, shift
 
     def _batched_weights(self, mods, shift):
@@ -460,6 +471,11 @@ class SynthesisNetwork(nn.Module):
             handle, wb, wt = prepared[k]
             # single-layer groups see their own rows; the heads of a block share the group's vector
             mod._prep = (handle, wb, cflat[coff[k]:coff[k + 1]], wt)
+        # the stacked head biases of every level from ONE concatenation (split's backward is one concatenation too)
+        hb = [list(blk.head.heads.values()) for blk in self.layers]
+        parts = torch.cat([h.bias.reshape(-1) for hs in hb for h in hs]).split([sum(h.out_ch for h in hs) for hs in hb])
+        for hs, part in zip(hb, parts):
+            hs[0]._bias_cat = part
 
     def _angle_pyramid(self, angle):
         """[coarsest ... finest] unshifted angle grids of a batch-shared grid; cached like FourierFeature.encoded (the

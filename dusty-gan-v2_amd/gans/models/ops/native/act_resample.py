@@ -340,6 +340,39 @@ def resample(x, spec):
     return _Resample.apply(x, spec, False, (x.shape[1], x.shape[2]))
 
 
+class _ResampleAdd(Function):
+    """resid + resample(x) for packed few-channel images in the resampler's store (dgv2_resample_tab_add)."""
+
+    @staticmethod
+    def forward(ctx, x, resid, spec):
+        x, resid = x.contiguous(), resid.contiguous()
+        N.check(x, resid)
+        B, H, W, C = x.shape
+        Ho, Wo = spec.out_size(H, W)
+        (ih_idx, ih_coef, ih_cnt, Eh), (iw_idx, iw_coef, iw_cnt, Ew) = spec.tables(H, W, False, x.device)
+        out = torch.empty((B, Ho, Wo, C), device=x.device, dtype=x.dtype)
+        N.call("dgv2_resample_tab_add", N.ptr(out), N.ptr(x), N.ptr(resid), N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt),
+               Eh, N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew, B, C, H, W, Ho, Wo, _dt(x), N.stream())
+        ctx.cfg = (spec, (H, W))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, in_hw = ctx.cfg
+        gx = _Resample.apply(g, spec, True, in_hw) if ctx.needs_input_grad[0] else None
+        return gx, (g if ctx.needs_input_grad[1] else None), None
+
+
+def resample_add(x, resid, spec):
+    """resid + resample(x), x [B,H,W,C] channels-last; one launch for the generator's packed 1 / 2 / 4-channel images
+    (same bits as the two-launch form), the composed form otherwise."""
+    Ho, Wo = spec.out_size(x.shape[1], x.shape[2])
+    if (x.shape[3] in (1, 2, 4) and x.dtype == resid.dtype and tuple(resid.shape) == (x.shape[0], Ho, Wo, x.shape[3])
+            and x.dtype in (torch.float32, torch.bfloat16)):
+        return _ResampleAdd.apply(x, resid, spec)
+    return resid + resample(x, spec)
+
+
 # ---------------------------------------------------------------------------------------
 # Fourier features / angle pyramid (no gradient: angles are inputs of the training path)
 # ---------------------------------------------------------------------------------------

@@ -145,6 +145,18 @@ def ema_update(ema, sumsq, add, count, weight, update=True, cvec=None):
     return snap if cvec is None else cvec
 
 
+def ema_update_group(emas, rows, sumsq, add, count, weight, update, cvec):
+    """ema_update for up to 8 layers that share their input (the output heads of a level, dusty_v2.py:32-57) in ONE
+    launch: emas[i] is updated as ema_update would, and rows[i] entries of cvec (behind those of the layers before it)
+    get that layer's output factor."""
+    assert 1 <= len(emas) <= 8 and cvec is not None and cvec.numel() >= sum(rows)
+    N.check(*emas, cvec, sumsq)
+    N.call("dgv2_ema_scalar_group", _ptr_array(emas), _int_array(rows), len(emas), N.ptr(sumsq),
+           0 if sumsq is None else sumsq.numel(), float(add), 1.0 / float(count), float(weight), int(update), N.ptr(cvec),
+           N.stream())
+    return cvec
+
+
 # ---------------------------------------------------------------------------------------
 # level input of the generator: FIR up-2 of h written next to the positional encoding
 # (reference: SynthesisBlock.forward, gans/models/dusty_v2.py:153-159 -- resample + cat)

@@ -113,6 +113,13 @@ int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const float* coe
                       int B, int C, int ldx, int ldy, int in_h, int in_w, int out_h, int out_w,
                       int dtype, void* stream);
 
+/* y = resid + dgv2_resample_tab(x) for packed few-channel images (C in {1, 2, 4}, ld = C; y, x, resid of `dtype`):
+ * `o + self.resample(skip)` of SynthesisBlock.forward (dusty_v2.py:179-180) in one launch, bit-equal to the two-launch
+ * form.  DGV2_ENOTSUP for other channel counts / misaligned pointers. */
+int dgv2_resample_tab_add(void* y, const void* x, const void* resid, const int* idx_h, const float* coef_h,
+                          const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew,
+                          int B, int C, int in_h, int in_w, int out_h, int out_w, int dtype, void* stream);
+
 /* dgv2_resample_tab that can also leave the sum of squares of what it wrote (the next modulated conv's input
  * statistic, ModConv2d.forward style.py:98-103: x.square().mean() for the EMA) as per-block partials, saving a
  * separate pass over the activation: sumsq fp32 [sumsq_cap] device buffer (NULL = plain dgv2_resample_tab);
@@ -337,6 +344,11 @@ int dgv2_unpack2d(float* const* dst, const float* packed, const int* rows, const
  * (row_scale of the GEMM entries below); snapshot may then be NULL. */
 int dgv2_ema_scalar(float* ema, float* snapshot, const float* sumsq, int nsum, float add, float inv_count,
                     float weight, int update, float* cvec, int ncvec, void* stream);
+/* The same update for n <= 8 layers that share their input -- the output heads of one generator level
+ * (dusty_v2.py:32-57, one ModConv2d per output with its own ema_var): emas / rows are HOST arrays (device pointers /
+ * row counts, by value in the launch); layer i fills rows[i] entries of cvec behind those of the layers before it. */
+int dgv2_ema_scalar_group(float* const* emas, const int* rows, int n, const float* sumsq, int nsum, float add,
+                          float inv_count, float weight, int update, float* cvec, void* stream);
 int dgv2_mod_prep_fwd(void* wb, float* dsave, float* stats, const float* W, const float* s,
                       const float* ema_var, const float* shift, const float* fw, int B, int O, int I,
                       int Otot, int row_off, int demod, int cin, int F, int wb_dtype, void* stream);

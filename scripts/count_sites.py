@@ -12,13 +12,15 @@ init_random_seed(0, 0)
 tr = Trainer(bench.make_cfg(args, 0, 1), sync_scalars=False)
 for it in (16, 1, 2):
     tr.step(it)
-SKIP = ("view", "reshape", "detach", "empty", "as_strided", "slice", "select", "transpose", "permute", "t.default", "expand",
-        "unsqueeze", "squeeze", "alias", "is_", "stride", "size", "unbind", "split", "_unsafe_view", "lift_fresh", "numel", "dim")
+SKIP = {"view", "reshape", "detach", "empty", "empty_like", "empty_strided", "as_strided", "slice", "select", "transpose", "permute", "t", "expand",
+        "unsqueeze", "squeeze", "alias", "stride", "size", "unbind", "split", "split_with_sizes", "_unsafe_view", "lift_fresh", "numel", "dim",
+        "is_contiguous", "is_pinned", "sym_size", "sym_stride", "sym_numel", "sym_storage_offset", "unfold", "narrow", "chunk", "view_as_real", "new_empty",
+        "_local_scalar_dense", "is_same_size", "is_nonzero", "new_empty_strided", "result_type"}
 counts = collections.Counter()
 class Census(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, a=(), k=None):
         name = str(func)
-        if not any(s in name for s in SKIP):
+        if name.split(".")[1] not in SKIP:
             site = "autograd-engine"
             for fr in reversed(traceback.extract_stack(limit=40)):
                 if "dusty-gan-v2_amd" in fr.filename and "count_sites" not in fr.filename:
@@ -40,6 +42,6 @@ with Census():
 if base:
     counts = counts - base
 torch.cuda.synchronize()
-for (n, site, shp), c in sorted(counts.items(), key=lambda kv: -kv[1])[:110]:
+for (n, site, shp), c in sorted(counts.items(), key=lambda kv: -kv[1])[:170]:
     print(f"x{c:4d} {n:30s} {site} {shp if shp else ''}")
 print("total", sum(counts.values()))

@@ -260,6 +260,46 @@ def test_modconv_pe_sumsq_partials_are_reproducible(nat, P, I, O):
     assert bad == 0, f"{bad} of 400 launches differ from the first"
 
 
+@pytest.mark.parametrize("C,dtype", [(2, torch.float32), (1, torch.float32), (4, torch.bfloat16), (2, torch.bfloat16)])
+def test_resample_add_is_the_two_launch_form(nat, C, dtype):
+    """dgv2_resample_tab_add: `o + self.resample(skip)` of the generator's output pyramid (dusty_v2.py:179-180) in the
+    resampler's store -- bit-equal to resample followed by the add, gradients included."""
+    g = torch.Generator().manual_seed(3)
+    spec = nat.ResampleSpec([1, 3, 3, 1], up=(2, 2))
+    x = torch.randn(3, 8, 32, C, generator=g).to(DEV).to(dtype).requires_grad_()
+    r = torch.randn(3, 16, 64, C, generator=g).to(DEV).to(dtype).requires_grad_()
+    gy = torch.randn(3, 16, 64, C, generator=g).to(DEV).to(dtype)
+    y = nat.resample_add(x, r, spec)
+    gx, gr = torch.autograd.grad(y, [x, r], gy)
+    y2 = r + nat.resample(x, spec)
+    gx2, gr2 = torch.autograd.grad(y2, [x, r], gy)
+    assert torch.equal(y, y2) and torch.equal(gx, gx2) and torch.equal(gr, gr2)
+    # a channel count outside the packed-image kernel takes the composed form
+    x3 = torch.randn(2, 4, 8, 3, generator=g).to(DEV)
+    r3 = torch.randn(2, 8, 16, 3, generator=g).to(DEV)
+    assert torch.equal(nat.resample_add(x3, r3, spec), r3 + nat.resample(x3, spec))
+
+
+def test_grouped_ema_update_equals_one_launch_per_layer(nat):
+    """dgv2_ema_scalar_group (the output heads of a level share their input, dusty_v2.py:32-57: one launch updates every
+    head's ema_var, style.py:98-103) against dgv2_ema_scalar per head: same bits in the EMAs and in the factor rows."""
+    g = torch.Generator().manual_seed(4)
+    part = torch.rand(700, generator=g).to(DEV) * 50
+    rows = [1, 2, 5]
+    for update in (True, False):
+        e1 = [torch.rand((), generator=g).to(DEV) + 0.5 for _ in rows]
+        e2 = [e.clone() for e in e1]
+        c1 = torch.full((sum(rows) + 2,), -1.0, device=DEV)
+        c2 = c1.clone()
+        nat.ema_update_group(e1, rows, part if update else None, 0.0, 12345 if update else 1, 1 - 0.9989, update, c1)
+        off = 0
+        for e, n in zip(e2, rows):
+            nat.ema_update(e, part if update else None, 0.0, 12345 if update else 1, 1 - 0.9989, update, cvec=c2[off:off + n])
+            off += n
+        assert all(torch.equal(a, b) for a, b in zip(e1, e2)) and torch.equal(c1, c2)
+        assert float(c1[-1]) == -1.0 and float(c1[0]) > 0
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_batched_weight_preparation_matches_per_layer_path(nat, dtype, tol):
     """dgv2_mod_prep_all_fwd/_bwd + GEMM row scale (all layers of a pass prepared in one launch, the input-magnitude
