@@ -355,13 +355,28 @@ def gfwd_probe_roofline(args, sec_per_batch):
             "traffic": None}
 
 
+def _emit(line, fd):
+    """The ONE JSON line of the contract, on the process's real stdout."""
+    os.write(fd, (line + "\n").encode())
+
+
 def main():
     args = parse()
+    # stdout carries the JSON line and nothing else: RCCL prints a version banner on stdout when its first communicator
+    # is created (seen with 2.26.6), libraries may print more.  File descriptor 1 points at stderr for the duration of
+    # the run; the line goes out on a duplicate of the original.
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1:
+    # DGV2_DIST_WORLD1=1 (see gans/parallel.py): the launcher path and every collective on RCCL with ONE rank -- a
+    # functional check of the N > 1 code on a one-GPU box, never a measurement of scaling
+    dist_on = world > 1 or bool(os.environ.get("DGV2_DIST_WORLD1"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # DGV2_DIST_SMOKE=1: functional test of the N > 1 path on a ONE-GPU box (every rank on cuda:0, gloo
         # collectives); never a measurement
         if os.environ.get("DGV2_DIST_SMOKE"):
@@ -378,13 +393,13 @@ def main():
     cfg, trainer = build_trainer(args, rank, world)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(dt):
         """(max over ranks, list of every rank's own time)"""
-        if world == 1:
+        if not dist_on:
             return dt, [dt]
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
@@ -413,7 +428,7 @@ def main():
             barrier()
         dt, every = max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
-            print(json.dumps({
+            _emit(json.dumps({
                 "metric": f"range-images/sec (generator forward) on dusty_v2 {args.res}",
                 "value": args.steps * args.batch_per_gpu * world / dt, "unit": "range-images/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -422,8 +437,8 @@ def main():
                            "global_batch": args.batch_per_gpu * world, "per_gpu_batch": args.batch_per_gpu,
                            "parallelism": f"dp{world}", "hip_graph": graph is not None},
                 "roofline": gfwd_probe_roofline(args, dt / args.steps) if args.res == "64x512" else None,
-                "roofline_modconv": modconv_probe(args)}))
-        if world > 1:
+                "roofline_modconv": modconv_probe(args)}), out_fd)
+        if dist_on:
             dist.barrier()   # leave together: rank 0 may still be printing
             dist.destroy_process_group()
         return
@@ -443,8 +458,8 @@ def main():
 
     extra = {"r1_iterations_in_timed_region": r1_in_region, "first_timed_iteration": first_it,
              "per_rank_images_per_s": [args.steps * args.batch_per_gpu / t for t in every],
-             "world_size_seen": dist.get_world_size() if world > 1 else 1,
-             "backend": dist.get_backend() if world > 1 else None}
+             "world_size_seen": dist.get_world_size() if dist_on else 1,
+             "backend": dist.get_backend() if dist_on else None}
     if not args.no_extra:
         # plain and R1 iterations timed on their own (every rank takes part: the steps contain collectives)
         t_plain = max_over_ranks(timed_steps(trainer, 1, 6, barrier))[0] / 6
@@ -515,8 +530,8 @@ def main():
             chosen, selected_by=f"largest Percentage among the probed kernel instances in {STATS_FILE}: {pct} % ({key})")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
-        print(json.dumps(out))
-    if world > 1:
+        _emit(json.dumps(out), out_fd)
+    if dist_on:
         dist.barrier()   # the other ranks wait for rank 0's roofline probes, then everybody tears down together
         dist.destroy_process_group()
 

@@ -15,12 +15,20 @@ Here the exchanges are explicit and sized for xGMI:
 """
 from contextlib import contextmanager
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
+# DGV2_DIST_WORLD1 (test switch): treat an initialised process group of ONE rank as distributed, so that a one-GPU box
+# drives every collective of the N > 1 path through RCCL itself (RCCL refuses two ranks on one device; the two-rank
+# tests therefore run on gloo).  Averaging over one rank is the identity: results must equal the plain run.
+_WORLD1 = os.environ.get("DGV2_DIST_WORLD1") is not None
+
+
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _WORLD1)
 
 
 def world_size():

@@ -51,6 +51,9 @@ def main():
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif os.environ.get("DGV2_DIST_WORLD1"):   # one rank, RCCL itself: every collective of the N > 1 path runs (see parallel.py)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     import recipe
     from gans.trainer import Trainer
     from helpers import build_models
@@ -71,7 +74,7 @@ def main():
         tr.G.load_state_dict(recipe.fill_state_dict(G0.state_dict(), 7))
         tr.D.load_state_dict(recipe.fill_state_dict(D0.state_dict(), 8))
         tr.G_ema.load_state_dict(tr.G.state_dict())
-    if world > 1:
+    if dist.is_initialized():
         from gans import parallel
         for m in (tr.G, tr.D, tr.G_ema):
             parallel.broadcast_module(m)
@@ -89,12 +92,13 @@ def main():
         scal.append({k: float(v) for k, v in out.items()})
     state = {"G": tr.G.state_dict(), "D": tr.D.state_dict(), "G_ema": tr.G_ema.state_dict(), "p": tr.A.p, "scalars": scal,
              "optD_v": [tr.optim_D.state[p]["exp_avg_sq"] for p in tr.D.parameters()],
-             "graphs": sorted(k for k, v in tr._graphs.items() if v is not None)}
+             "graphs": sorted(k for k, v in tr._graphs.items() if v is not None),
+             "backend": dist.get_backend() if dist.is_initialized() else None, "split_d": bool(tr.split_d)}
     state = {k: ({a: b.detach().cpu() for a, b in v.items()} if isinstance(v, dict) else
                  ([t.detach().cpu() for t in v] if k == "optD_v" else (v.detach().cpu() if torch.is_tensor(v) else v)))
              for k, v in state.items()}
     torch.save(state, os.path.join(out_dir, f"rank{rank}_of{world}.pt"))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

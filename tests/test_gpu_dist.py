@@ -66,3 +66,35 @@ def test_two_ranks_identical_and_equal_to_one_process(tmp_path, graph):
             bad += int((err > 1e-3 * float(v.abs().max()) + 1e-6).sum())
             tot += v.numel()
         assert bad <= 2e-3 * tot, (key, bad, tot)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_one_rank_on_rccl_equals_the_plain_run(tmp_path, graph):
+    """Every collective of the N > 1 path on RCCL itself (backend "nccl"): RCCL refuses two ranks on one device, so
+    ONE rank runs the data-parallel Trainer with DGV2_DIST_WORLD1 (parallel.is_dist() true for a group of one): the flat
+    gradient all-reduces (asynchronous, on the communication stream, between the two hipGraphs of the split D step),
+    the buffer broadcasts, the scalar reduction and the ReduceOp.AVG probe all go through the library.  Averaging over
+    one rank is the identity, so the run must reproduce the plain single-process run: first iteration to rounding, the
+    rest to what the float atomics allow."""
+    iters = 8 if graph else 4
+    (tmp_path / "rccl").mkdir()
+    (tmp_path / "plain").mkdir()
+    (r,) = _run(tmp_path / "rccl", 1, iters, graph, {"DGV2_DIST_WORLD1": "1"})
+    assert r["backend"] == "nccl" and r["split_d"]
+    if graph:
+        assert {"g_fb/inj", "g_opt", "d_fb_head/inj", "d_fb_tail/inj", "d_opt", "r1_fb/inj"} <= set(r["graphs"]), r["graphs"]
+    (one,) = _run(tmp_path / "plain", 1, iters, graph)
+    assert one["backend"] is None
+    for k in one["scalars"][0]:
+        a, b = one["scalars"][0][k], r["scalars"][0][k]
+        assert abs(a - b) <= 1e-5 * abs(a) + 1e-7, ("iteration 1", k, a, b)
+    for it, (a, b) in enumerate(zip(one["scalars"], r["scalars"]), 1):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 5e-3 * abs(a[k]) + 1e-4, (it, k, a[k], b[k])
+    for key in ("G", "D", "G_ema"):
+        bad = tot = 0
+        for k, v in one[key].items():
+            err = (v.float() - r[key][k].float()).abs()
+            bad += int((err > 1e-3 * float(v.abs().max()) + 1e-6).sum())
+            tot += v.numel()
+        assert bad <= 2e-3 * tot, (key, bad, tot)
