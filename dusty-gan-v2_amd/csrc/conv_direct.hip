@@ -114,6 +114,12 @@ struct DConv {
   // border extras: tap (x_dy, x_dx, weight slot x_slot) added to class x_cls for output row x_row only
   // (the replicate-padding rows of the data gradient, formerly separate one-row accumulate launches)
   int nx, x_dy[6], x_dx[6], x_slot[6], x_cls[6], x_row[6];
+  // The six extras are exactly the replicate-row terms of the stride-1 3x3 data gradient (host-checked: border_ok).
+  // The unrolled-tap data-gradient instances (F33 = 2) then run WITHOUT extras (border = 1, nx = 0): the term of a dead
+  // tap (dy = -1 at output row 0, dy = +1 at the last row) is the border row itself through the weights of the tap
+  // mirrored in dy, so it is issued next to THAT tap's MFMAs (weights in registers, one more pixel-fragment read: tap
+  // (0, dx)).  A border row costs what an interior row costs and the per-chunk extras loop is gone.
+  int border_ok, border;
   float inv_cols;   // 1 / cols
   const float* bias;
   const float* acc_scale;   // device scalar multiplied onto the accumulators ahead of the residual / bias (e4m3 weights:
@@ -418,6 +424,19 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[0][mf][nf], a[t & 1][mf], bb[nf]);
           }
+          if constexpr (F33 == 2 && NI <= 6) {   // (the image-pair instances, NI = 7, are at their register limit: extras)
+            // replicate-row border term (p.border): the row this group belongs to has its MIRRORED tap dead (t - 6 at the
+            // first row, t + 6 at the last) -- that tap's operand would be the clamped copy of the border row, i.e. the
+            // pixel fragment of tap (0, dx) = t -+ 3, and its weights are the ones in registers right now
+            if (t < 3 || t >= 6) {
+              const int tm = t < 3 ? t + 6 : t - 6;
+              if (p.border && ((dd[nf >> 1] >> tm) & 1u)) {
+                const uint4 bx = b_base[bpix[nf] + COLS + t % 3];
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[0][mf][nf], a[t & 1][mf], bx);
+              }
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
           if (t + 1 < 9) {   // this group's pixel fragment is consumed: re-read it, and a share of the weights, for tap t+1
             bb[nf] = b_base[bpix[nf] + ((t + 1) / 3) * COLS + (t + 1) % 3];
@@ -703,6 +722,11 @@ int launch_direct(void* y, const void* x, const void* w, DConv p, hipStream_t st
 template <typename T, typename TY, int TO, int RW, int NI, int NC, int F33 = 0>
 int launch_pipe(void* y, const void* x, const void* w, DConv p, hipStream_t st) {
   constexpr int TH = 4 * RW;
+  p.border = 0;
+  if (F33 == 2 && NI <= 6 && p.border_ok) {   // see DConv::border
+    p.border = 1;
+    p.nx = 0;
+  }
   constexpr int NW = (TO * 9 * 4 + 255) / 256;
   if (p.hper) {   // image pairs: two blocks of (hper - 1 + tap extent) halo rows (in_stride 1, host-checked)
     if (TH != 2 * p.hper) return -2;
@@ -937,6 +961,21 @@ static int conv_taps_impl(void* y, int ldy, const void* x, const void* w, int B,
   for (int t = 2; f33 && t < 9; ++t) f33 = p.widx[t] - p.widx[t - 1] == p.widx[1] - p.widx[0];   // weight slots affine in t
   for (int e = 0; f33 && hzero && e < nextra; ++e)   // zero rows are not staged as zeros there: extras must read real rows
     f33 = (unsigned)(p.x_row[e] * in_stride + ioff_h + p.x_dy[e]) < (unsigned)Hin;
+  {
+    // border_ok: the extras are the replicate-row terms of the same-size stride-1 3x3 data gradient -- at output row 0
+    // the taps (0, dx) with the weights of the taps (+1, dx), at the last row with those of (-1, dx)
+    static const bool no_border = getenv("DGV2_NO_BORDER_REWEIGHT") != nullptr;   // A/B switch for benchmarking
+    const int hrows_img = p.hper ? p.hper : p.Hg;
+    bool ok = !no_border && f33 && hzero && nextra == 6 && in_stride == 1 && out_stride == 1 && ioff_h == 0 && dymin == -1 &&
+              hrows_img >= 2 && (p.hper ? true : Hin == Hg);
+    unsigned seen = 0;
+    for (int e = 0; ok && e < 6; ++e) {
+      const int top = p.x_row[e] == 0, bot = p.x_row[e] == hrows_img - 1, j = p.x_dx[e] - dxmin;
+      ok = (top || bot) && p.x_dy[e] == 0 && p.x_cls[e] == 0 && j >= 0 && j < 3 && p.x_slot[e] == (top ? 6 + j : j);
+      seen |= 1u << ((top ? 0 : 3) + (j & 3));
+    }
+    p.border_ok = (ok && seen == 63u) ? 1 : 0;
+  }
   if (dtype == DGV2_FP8) {
     // e4m3 operands, bf16 result / residual: the forward convs behind the FIRs (>= 64 output channels, one class)
     if (ncls != 1 || nextra || accumulate || O < 64 || !wrap_ok) return DGV2_ENOTSUP;

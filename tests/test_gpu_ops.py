@@ -831,6 +831,13 @@ CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     (4, 4, 32, 64, 64, 3, 1, 1, True),
     (2, 12, 33, 32, 64, 3, 1, 1, False),
     (1024, 4, 32, 32, 64, 3, 1, 1, True),
+    # data gradients on the unrolled variant (input channels a multiple of 64) with the border rows re-weighted instead
+    # of extras: borders in different blocks / the same block / the same wave pair, 2-row map, image pairs, clamped W
+    (2, 16, 40, 64, 64, 3, 1, 1, True),
+    (3, 24, 64, 64, 128, 3, 1, 1, True),
+    (2, 2, 32, 64, 64, 3, 1, 1, True),
+    (1024, 4, 32, 64, 64, 3, 1, 1, True),
+    (2, 12, 33, 64, 64, 3, 1, 1, False),
     # ... and its stride-2 forward form (the convs behind the blurs): 4-row tiles with a partial one, two chunks
     (2, 24, 80, 64, 128, 3, 2, 1, True),
     (3, 8, 64, 32, 64, 3, 2, 1, False),
