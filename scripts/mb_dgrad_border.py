@@ -24,3 +24,21 @@ for (H, W, C) in ((32, 256, 64), (16, 128, 128), (8, 64, 256)):
     b = t(lambda: cv._conv_taps_ex(gx, gy, wt3, H, W, 1, (0, 0), 1, [(0, 0)], taps, [], True))
     c = t(lambda: cv._conv_taps_ex(gx, gy, wt3, H, W, 1, (0, 0), 1, [(0, 0)], taps, [], False))
     print(f"{H}x{W} C{C}: dgrad {a:6.1f} us | without extras {b:6.1f} | clamp rows (forward instance) {c:6.1f}")
+
+# stride-2 data gradient (four parity classes in one launch): the top-border extras of the classes with ph = 0
+print("stride-2 data gradients (B = 128): shipped launch | without the 3 border extras (timing only)")
+for (H, W, C, O) in ((64, 512, 32, 64), (32, 256, 64, 128), (16, 128, 128, 256), (8, 64, 256, 512)):
+    gy = torch.randn(B, H // 2, W // 2, O, device="cuda", dtype=torch.bfloat16)
+    wt3 = torch.randn(C, 9, O, device="cuda", dtype=torch.bfloat16)
+    gx = torch.empty(B, H, W, C, device="cuda", dtype=torch.bfloat16)
+    classes, taps4, extras = [], [], []
+    for ph in (0, 1):
+        for pw in (0, 1):
+            c = len(classes)
+            classes.append((ph, pw))
+            taps4 += [(dy, dx, ky * 3 + kx, c) for dy, ky in cv._axis_taps_s2(ph) for dx, kx in cv._axis_taps_s2(pw)]
+            if ph == 0:
+                extras += [(0, dx, kx, c, 0) for dx, kx in cv._axis_taps_s2(pw)]
+    a = t(lambda: cv._conv_taps_ex(gx, gy, wt3, H // 2, W // 2, 1, (0, 0), 2, classes, taps4, extras, True))
+    b = t(lambda: cv._conv_taps_ex(gx, gy, wt3, H // 2, W // 2, 1, (0, 0), 2, classes, taps4, [], True))
+    print(f"{H}x{W} C{C}<-O{O}: {a:6.1f} us | {b:6.1f} us")
