@@ -295,3 +295,41 @@ def test_bf16_gradients_track_fp32_per_tensor():
     flat = lambda gs: torch.cat([gs[k].double().flatten().cpu() for k in sorted(gs)])
     assert _cos(flat(res[True][2]), flat(res[False][2])) > 0.99
     assert _cos(flat(res[True][3]), flat(res[False][3])) > 0.98
+
+
+def test_training_forward_of_the_generator_is_reproducible():
+    """The timed configuration's generator forward (bf16 trunks, B = 64, training mode: every ModConv2d updates its
+    input-magnitude EMA from statistic partials the producing kernels leave, style.py:98-103) run 150 times from the same
+    state on the same inputs: images, ray-drop logits and every ema_var must come out with the same bits -- the forward
+    has no float atomics, so any difference is a race.  (It was one: a hand-issued load left in flight past the sample
+    loop of modconv_pe overwrote a partial sum about once in 20 forwards)"""
+    import recipe
+    from oracle import coords as o_coords
+    from gans.coords import synthetic_angle_grid
+    B, H, W = 64, 64, 512
+    g = torch.Generator().manual_seed(7)
+    G, _ = build_models(full_cfg(True), "cpu")
+    G.load_state_dict(recipe.fill_state_dict({k: v.clone() for k, v in G.state_dict().items()}, 99))
+    G = G.to(DEV).train()
+    z = torch.randn(B, 512, generator=g).to(DEV)
+    noise = {"shifts": (torch.rand(B, generator=g) * 6.28).to(DEV),
+             "gumbel_u": torch.rand(B, 1, H, W, generator=g).clamp(1e-6, 1 - 1e-6).to(DEV)}
+    ang = torch.from_numpy(o_coords.resample_angle_grid(synthetic_angle_grid(64), H, W)).to(DEV)
+    state0 = {k: v.clone() for k, v in G.state_dict().items()}
+
+    def run():
+        G.load_state_dict(state0)
+        with torch.no_grad():
+            o = G(z, angle=ang, noise=noise)
+        bufs = {k: v.clone() for k, v in G.state_dict().items() if k.endswith("ema_var") or k.endswith("w_avg")}
+        return o["image_orig"].clone(), o["raydrop_logit"].clone(), bufs
+
+    img0, logit0, b0 = run()
+    assert len(b0) > 10
+    bad = []
+    for i in range(150):
+        img, logit, b = run()
+        diff = [k for k in b0 if not torch.equal(b0[k], b[k])]
+        if diff or not torch.equal(img, img0) or not torch.equal(logit, logit0):
+            bad.append((i, diff[:4]))
+    assert not bad, f"{len(bad)} of 150 forwards differ from the first: {bad[:3]}"
