@@ -333,3 +333,21 @@ def test_training_forward_of_the_generator_is_reproducible():
         if diff or not torch.equal(img, img0) or not torch.equal(logit, logit0):
             bad.append((i, diff[:4]))
     assert not bad, f"{len(bad)} of 150 forwards differ from the first: {bad[:3]}"
+
+
+def test_forward_of_the_discriminator_is_reproducible():
+    """The same for the discriminator's forward at the D step's size (2B = 128 images, bf16 trunks, fp32 epilogue): 100
+    runs, same logits bit for bit (strip-streaming and halo-tile convs, MFMA blurs, decimating FIRs, minibatch-stddev
+    statistic, the three-plane Linear)."""
+    import recipe
+    B, H, W = 64, 64, 512
+    _, D = build_models(full_cfg(True), "cpu")
+    D.load_state_dict(recipe.fill_state_dict({k: v.clone() for k, v in D.state_dict().items()}, 98))
+    D = D.to(DEV).train()
+    t = torch.linspace(0, 6.28, W)[None, None, None, :] * torch.arange(1, 2 * B + 1)[:, None, None, None]
+    xin = (torch.sin(t + torch.linspace(0, 3, H)[None, None, :, None]) * 0.8).to(DEV)
+    with torch.no_grad():
+        y0 = D(xin, splits=2).clone()
+        assert torch.isfinite(y0).all()
+        bad = sum(int(not torch.equal(D(xin, splits=2), y0)) for _ in range(100))
+    assert bad == 0, f"{bad} of 100 forwards differ from the first"
