@@ -1,4 +1,4 @@
-"""400 training iterations under hipGraph replay: losses, parameter finiteness and the input-magnitude EMAs every 50."""
+"""N (default 400) training iterations under hipGraph replay: losses, parameter finiteness and the input-magnitude EMAs every 50."""
 import os, sys, argparse
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dusty-gan-v2_amd")]
@@ -10,9 +10,10 @@ from gans.utils import init_random_seed
 init_random_seed(0, 0)
 tr = Trainer(bench.make_cfg(args, 0, 1), sync_scalars=False)
 hist = []
-for it in range(1, 401):
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+for it in range(1, N + 1):
     out = tr.step(it)
-    if it % 50 == 0:
+    if it % max(N // 10, 1) == 0:
         vals = {k: float(v) for k, v in out.items() if hasattr(v, "item") or isinstance(v, float)}
         finite = all(torch.isfinite(p).all().item() for p in list(tr.G.parameters()) + list(tr.D.parameters()))
         ev = [float(b) for n, b in tr.G.named_buffers() if n.endswith("ema_var")][:4]
