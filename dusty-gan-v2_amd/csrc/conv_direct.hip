@@ -47,6 +47,9 @@ constexpr int DTW = 32;
 // not see inside: fragments arrive through ordinary ds_reads (it places their lgkmcnt waits in front of the asm),
 // dependent MFMAs on the same accumulator are interlocked by the hardware, and the one software hazard -- an MFMA
 // result read by a VALU instruction -- is covered by mfma_drain() in front of the epilogue.
+#ifndef DGV2_S2D_ASM
+#define DGV2_S2D_ASM 0
+#endif
 template <typename T> struct MfmaAsm;
 template <> struct MfmaAsm<bf16_t> {
   __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
@@ -465,7 +468,13 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) Mfma16<T>::run(acc[TCL[t]][mf][nf], a[mf], bb[nf]);
+            for (int mf = 0; mf < MF; ++mf) {
+#if DGV2_S2D_ASM   // experiment builds: the in-place asm form; 1 = no drain in front of the epilogue, 2 = drained
+              MfmaAsm<T>::run(acc[TCL[t]][mf][nf], a[mf], bb[nf]);
+#else
+              Mfma16<T>::run(acc[TCL[t]][mf][nf], a[mf], bb[nf]);
+#endif
+            }
         }
       }
     } else if (!(CP_ABL & 2)) {
@@ -518,6 +527,9 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 
     if (cc == nchunks - 1 && !(CP_ABL & 16)) {        // tile finished: epilogue, reset accumulators
       if constexpr (F33) mfma_drain();
+#if DGV2_S2D_ASM == 2
+      if constexpr (NC == 4) mfma_drain();
+#endif
       const int w0 = (tw0 + tile) * DTW;
       // fast path (block-uniform): full channel tile, plain overwrite -- straight-line bias / lrelu / convert and,
       // for bf16, fragment pairs leaving as 16-byte stores; everything else takes the general store_frag

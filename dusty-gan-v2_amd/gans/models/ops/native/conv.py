@@ -495,6 +495,10 @@ class _LinearF32(Function):
                 gx = torch.mm(g * ctx.scale, w)
         if ctx.needs_input_grad[1]:
             out = getattr(weight, "_dgv2_grad_out", None)
+            if out is not None and out.data_ptr() % 16:
+                out = None               # dgv2_gemm_x3 stores 16-byte rows: an unaligned slice of the flat buffer (a layout
+                                         # whose preceding parameters do not add up to a multiple of 4 elements) is not
+                                         # offered to it -- the kernel allocates and collect() packs as for any other gradient
             if out is not None:
                 out = out.view_as(out)   # a fresh alias: autograd adopts a gradient tensor nobody else holds
             gw = gemm_x3(g, x, True, True, O, K, Bn, scale=ctx.scale, out=out) if use else None

@@ -180,6 +180,33 @@ def load_checkpoint(path, map_location="cpu"):
     return ckpt
 
 
+def to_upstream(ckpt, create=None):
+    """A checkpoint written by THIS build stores `cfg` as plain dicts / lists (Trainer.save_checkpoint): readable
+    anywhere, but the reference's own tools index it by attribute -- `ckpt["cfg"].model.generator.mapping_kwargs.in_ch`
+    (quick_demo.py:25, test_gan.py:48-52, demo_inversion.py:57-60, demo_interpolation.py:116-119) and splat its nodes as
+    keyword arguments (models/builder.py:4-32) -- which a plain dict does not offer.  This returns a shallow copy whose
+    `cfg` is re-wrapped with `create` (default: omegaconf.OmegaConf.create, i.e. exactly the node type the reference's
+    trainer pickles, trainer.py:551-567); run it where omegaconf is installed (scripts/ckpt_to_upstream.py) before
+    handing a file to upstream code.  Reading a checkpoint with THIS package needs no conversion (load_checkpoint)."""
+    if create is None:
+        try:
+            from omegaconf import OmegaConf
+        except ImportError as e:
+            raise ImportError("to_upstream() re-wraps cfg with omegaconf.OmegaConf.create: install omegaconf (the "
+                              "reference's own dependency, environment.yaml) or pass create=...") from e
+        create = OmegaConf.create
+    out = dict(ckpt)
+
+    def plain(o):
+        if isinstance(o, dict):
+            return {k: plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [plain(v) for v in o]
+        return o
+    out["cfg"] = create(plain(ckpt["cfg"]))
+    return out
+
+
 def autoload_ckpt(ckpt_name: str):
     """reference: gans/pretrained.py:26-33 (the download is replaced by a local lookup: no network)."""
     if is_available_model(ckpt_name):

@@ -373,7 +373,8 @@ class Trainer:
         fakes, y ~ N(0, 1 / HW), J^T y = d(image . y) / dw for the styles w = mapping(z) [B/2, num_styles, D] (taken
         with create_graph through the generator's twice-differentiable pass, Generator.forward(second_order=True)),
         lengths |J^T y| per (sample, style), their running mean pl_ema (lerp 0.01), penalty mean((|J^T y| - pl_ema)^2)
-        weighted by loss.pl * lazy.pl; its backward is the double backward through the generator."""
+        on the un-detached new mean exactly as the reference writes it (trainer.py:349-353), weighted by
+        loss.pl * lazy.pl; its backward is the double backward through the generator."""
         set_requires_grad(self.G, True)
         self.g_sync.begin(direct=False)
         B_pl = max(self.B // 2, 1)
@@ -386,9 +387,11 @@ class Trainer:
         y = y / float(np.sqrt(np.prod(image.shape[2:])))
         (grads,) = torch.autograd.grad(outputs=[(image * y).sum()], inputs=[w], create_graph=True)
         lengths = grads.pow(2).sum(dim=-1).sqrt()
-        with torch.no_grad():
-            self.pl_ema.lerp_(lengths.mean().detach(), 0.01)
-        penalty = (lengths - self.pl_ema).pow(2).mean()
+        # reference trainer.py:349-353: the NEW running mean enters the penalty un-detached (the gradient also flows
+        # through its 0.01 * mean(lengths) term); only the stored buffer is detached
+        ema_new = self.pl_ema.lerp(lengths.mean(), 0.01)
+        self.pl_ema.copy_(ema_new.detach())
+        penalty = (lengths - ema_new).pow(2).mean()
         loss = self.pl_weight * penalty + 0.0 * image[0, 0, 0, 0]
         loss.backward()
         self.g_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
@@ -657,8 +660,12 @@ class Trainer:
             return sd
 
         def plain(o):
-            # cfg as plain dicts / lists: loadable anywhere without this package (the reference's consumers wrap it
-            # with OmegaConf.create(ckpt["cfg"]); gans.pretrained.load_checkpoint turns it back into a Config)
+            # cfg as plain dicts / lists: loadable anywhere (weights_only=True) and by gans.pretrained.load_checkpoint,
+            # which turns it back into an attribute-accessible Config.  NOT directly by the reference's own tools: they
+            # index ckpt["cfg"].model.generator... by attribute (quick_demo.py:25, test_gan.py:48) because the reference
+            # pickles its OmegaConf node (trainer.py:551-567); omegaconf is not a dependency here, so a file meant for
+            # upstream code goes through gans.pretrained.to_upstream / scripts/ckpt_to_upstream.py (OmegaConf.create)
+            # in an environment that has it
             if isinstance(o, dict):
                 return {k: plain(v) for k, v in o.items()}
             if isinstance(o, (list, tuple)):

@@ -65,7 +65,9 @@ def pl_step(sdG, z, angle, shifts, gumbel_u, noise, pl_ema, pl_weight, ema_lerp=
     itself cannot run: it passes `angles=` and reads a "styles" output that does not exist): w = mapping(z) expanded to
     the styles, image = G(w), y = noise / sqrt(HW), g = d(image . y)/dw (create_graph), lengths = sqrt(sum_d g^2) per
     (sample, style), pl_ema <- lerp(pl_ema, mean lengths, 0.01), penalty = mean((lengths - pl_ema)^2),
-    loss = pl_weight * penalty.  Returns (penalty, new pl_ema, grads over G parameters, lengths)."""
+    loss = pl_weight * penalty.  As in the reference (trainer.py:349-353) the NEW running mean enters the penalty
+    un-detached -- the gradient also flows through its 0.01 * mean(lengths) term -- and only the stored buffer is
+    detached.  Returns (penalty, new pl_ema, grads over G parameters, lengths)."""
     G = with_grad(sdG, G_BUFFER_SUFFIXES)
     L = model.num_levels(G)
     w = model.mapping_network(G, z)[:, None, :].expand(-1, 2 * L, -1)
@@ -74,12 +76,12 @@ def pl_step(sdG, z, angle, shifts, gumbel_u, noise, pl_ema, pl_weight, ema_lerp=
     y = noise / math.sqrt(image.shape[2] * image.shape[3])
     (g,) = torch.autograd.grad((image * y).sum(), w, create_graph=True)
     lengths = g.pow(2).sum(dim=-1).sqrt()
-    new_ema = pl_ema + ema_lerp * (lengths.mean().detach() - pl_ema)
+    new_ema = pl_ema + ema_lerp * (lengths.mean() - pl_ema)     # torch.lerp(pl_ema, mean, w), not detached
     penalty = (lengths - new_ema).pow(2).mean()
     loss = pl_weight * penalty
     keys = [k for k, v in G.items() if v.requires_grad]
     grads = torch.autograd.grad(loss, [G[k] for k in keys], allow_unused=True)
-    return penalty.detach(), new_ema, dict(zip(keys, grads)), lengths.detach()
+    return penalty.detach(), new_ema.detach(), dict(zip(keys, grads)), lengths.detach()
 
 
 def d_step(sdG, sdD, z, angle, shifts, gumbel_u, x_real, ada_real=None, ada_fake=None,

@@ -29,4 +29,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "s2":
         ws = torch.randn(O, 3, 3, C, device="cuda", dtype=torch.bfloat16)
         for _ in range(6):
             nat._conv_fwd_raw(xs, ws, g2)
+# round 4: the bf16 weight-gradient stream of the same stride-2 convs (conv_wgrad_stream_bf16_kernel), all four blocks
+if len(sys.argv) > 1 and sys.argv[1] == "s2w":
+    g2 = nat.ConvGeom(3, 3, 2, 1, True)
+    for (H, W, C, O) in ((64, 512, 32, 64), (32, 256, 64, 128), (16, 128, 128, 256), (8, 64, 256, 512)):
+        xs = torch.randn(128, H, W, C, device="cuda", dtype=torch.bfloat16)
+        gys = torch.randn(128, H // 2, W // 2, O, device="cuda", dtype=torch.bfloat16)
+        for _ in range(6):
+            nat._conv_wgrad_raw(gys, xs, g2)
 torch.cuda.synchronize()

@@ -1,0 +1,81 @@
+"""Inline-asm MFMAs are invisible to hipcc's hazard recogniser: a compiler-generated VALU write into a
+register an asm-issued MFMA is still reading goes unpadded.  scripts/audit_asm_mfma.py scans the ISA for exactly that;
+here it is checked on the pattern that broke the stride-2 data gradient's asm form, and run over the ISA of every
+shipped source file that issues MFMAs as asm.  CPU only (hipcc cross-compiles)."""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+BROKEN = """
+kern_bad:
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[78:81], v[218:221], v[42:45], v[78:81]
+	;;#ASMEND
+	v_mov_b64_e32 v[42:43], v[110:111]
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[42:45], v[46:49], v[222:225], v[42:45]
+	;;#ASMEND
+kern_padded:
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[78:81], v[218:221], v[42:45], v[78:81]
+	;;#ASMEND
+	s_nop 4
+	v_mov_b64_e32 v[42:43], v[110:111]
+kern_branch:
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[78:81], v[218:221], v[42:45], v[78:81]
+	;;#ASMEND
+	s_branch .LBB0_2
+.LBB0_1:
+	v_mov_b64_e32 v[42:43], v[110:111]
+.LBB0_2:
+	v_mov_b64_e32 v[218:219], v[110:111]
+kern_behind_an_mfma:
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[78:81], v[218:221], v[42:45], v[78:81]
+	;;#ASMEND
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[82:85], v[218:221], v[46:49], v[82:85]
+	;;#ASMEND
+	v_mov_b64_e32 v[42:43], v[110:111]
+"""
+
+
+def test_auditor_on_the_pattern_that_broke_the_stride2_data_gradient(tmp_path, capsys):
+    import audit_asm_mfma as au
+    p = tmp_path / "x.s"
+    p.write_text(BROKEN)
+    assert au.main(str(p)) == 2           # kern_bad (B overwritten behind its MFMA) and kern_branch's target (A overwritten)
+    out = capsys.readouterr().out
+    assert "kern_bad: 2 asm MFMAs, 1 VALU" in out and "kern_padded: 1 asm MFMAs, 0 VALU" in out
+    assert "kern_branch: 1 asm MFMAs, 1 VALU" in out and "kern_behind_an_mfma: 2 asm MFMAs, 0 VALU" in out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_shipped_kernels_with_asm_mfmas_have_no_unpadded_source_overwrite():
+    import audit_asm_mfma as au
+    csrc = os.path.join(ROOT, "dusty-gan-v2_amd", "csrc")
+    files = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip")
+             and 'asm volatile("v_mfma' in open(os.path.join(csrc, f)).read()]
+    assert files, "no source issues MFMAs as inline asm any more: drop this test"
+    with tempfile.TemporaryDirectory() as d:
+        def isa(f):
+            out = os.path.join(d, f[:-4] + ".s")
+            subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                            "--cuda-device-only", "-S", os.path.join(csrc, f), "-o", out], check=True,
+                           stderr=subprocess.DEVNULL)
+            return out
+        with ThreadPoolExecutor(4) as ex:
+            outs = list(ex.map(isa, files))
+        for f, o in zip(files, outs):
+            assert au.main(o) == 0, f

@@ -168,3 +168,47 @@ def test_release_names_resolve_locally(tmp_path, monkeypatch):
     assert autoload_ckpt("dusty_v2")["step"] == 32
     with pytest.raises(ValueError):
         autoload_ckpt("no_such_model")
+
+
+def test_written_cfg_serves_the_reference_access_pattern_after_to_upstream():
+    """Trainer.save_checkpoint stores cfg as plain containers; the reference's consumers use attribute access and
+    keyword splats on it (quick_demo.py:25-28, test_gan.py:48-57,91,112,118, demo_inversion.py:57-81,
+    demo_interpolation.py:116-145, models/builder.py:4-32).  gans.pretrained.to_upstream re-wraps it (OmegaConf.create
+    where omegaconf exists; here a stand-in with the same two properties) and this walks exactly those accesses."""
+    from gans.config import load_config, to_config
+    from gans.models.builder import build_discriminator, build_generator
+    from gans.pretrained import to_upstream
+    full = load_config()
+
+    def plain(o):
+        if isinstance(o, dict):
+            return {k: plain(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [plain(v) for v in o]
+        return o
+    written = {"cfg": plain(full), "step": 8, "G_ema": {}}
+    assert type(written["cfg"]) is dict
+    with pytest.raises(AttributeError):       # what an upstream tool would hit on the raw file
+        written["cfg"].model
+    try:
+        import omegaconf  # noqa: F401
+        create = None
+    except ImportError:
+        with pytest.raises(ImportError, match="omegaconf"):
+            to_upstream(written)
+        create = to_config
+    cfg = to_upstream(written, create=create)["cfg"]
+    assert type(written["cfg"]) is dict       # the input is left alone
+    assert cfg.model.generator.mapping_kwargs.in_ch == 512                       # quick_demo.py:25
+    H, W = cfg.model.generator.synthesis_kwargs.resolution                        # test_gan.py:52
+    assert (H, W) == (64, 512)
+    assert cfg.dataset.min_depth == 1.45 and cfg.dataset.max_depth == 80.0 and isinstance(cfg.dataset.root, str)
+    assert f"data/coords/{cfg.dataset.name}.npy".endswith(".npy")                 # test_gan.py:86
+    assert cfg.model.generator.measurement_kwargs.raydrop_const == -1              # test_gan.py:112
+    assert cfg.validation.num_points > 0                                          # test_gan.py:118
+    small = to_config(plain(cfg))
+    small.model.generator.synthesis_kwargs.ch_base, small.model.generator.synthesis_kwargs.ch_max = 4, 16
+    small.model.discriminator.layer_kwargs.ch_base, small.model.discriminator.layer_kwargs.ch_max = 4, 16
+    G = build_generator(small.model.generator)                                    # test_gan.py:91, builder.py:14-19
+    D = build_discriminator(small.model.discriminator)                            # builder.py:28-29 (**layer_kwargs)
+    assert G.synthesis_network.num_styles == 10 and sum(p.numel() for p in D.parameters()) > 0

@@ -25,12 +25,14 @@ def test_pl_step_gradient_is_the_derivative_of_its_penalty():
                 torch.randn(B, 1, 16, 64, generator=torch.Generator().manual_seed(0)).double(), torch.tensor(0.02))
 
         def penalty(sd):
-            # eval-mode statistics, a frozen baseline and the image before the ray-drop mask: training mode updates ema_var
-            # from the activations and pl_ema from the lengths under no_grad, and the mask is a straight-through
-            # estimator -- dependencies a finite difference sees and the gradient (by definition) does not follow
-            return o_step.pl_step(sd, *args, pl_weight=1.0, ema_lerp=0.0, training=False, output="image_orig")
+            # eval-mode statistics and the image before the ray-drop mask: training mode updates ema_var from the
+            # activations under no_grad, and the mask is a straight-through estimator -- dependencies a finite
+            # difference sees and the gradient (by definition) does not follow.  The running mean pl_ema is NOT such a
+            # dependency: like the reference (trainer.py:349-353) the penalty uses the un-detached lerp, so the 0.5
+            # weight here (exaggerated from 0.01 to make the term visible) is followed by the gradient too
+            return o_step.pl_step(sd, *args, pl_weight=1.0, ema_lerp=0.5, training=False, output="image_orig")
         pen, ema, grads, lengths = penalty(sdG)
-        assert float(ema) == 0.02 and lengths.shape == (B, 6) and float(pen) > 0
+        assert abs(float(ema) - (0.01 + 0.5 * float(lengths.mean()))) < 1e-12 and lengths.shape == (B, 6) and float(pen) > 0
         g = torch.Generator().manual_seed(1)
         keys = [k for k, v in grads.items() if v is not None and float(v.abs().max()) > 0]
         assert any(k.startswith("mapping_network") for k in keys) and any("conv1.weight" in k for k in keys)
