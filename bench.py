@@ -141,13 +141,17 @@ def _time_launches(fn, reps):
 PMC_FILE = os.path.join("profiles", "round3_pmc.json")
 
 
-def _pmc_traffic(kernel_key):
+PMC_BATCH_PER_GPU = 64   # scripts/pmc_probe.py launches the probes at this --batch-per-gpu
+
+
+def _pmc_traffic(kernel_key, batch_per_gpu=PMC_BATCH_PER_GPU):
     """HBM bytes per launch of the probe's launch from the COMMITTED PMC passes (separate `rocprofv3 --pmc FETCH_SIZE`
     / `--pmc WRITE_SIZE` runs of scripts/pmc_probe.py, which issues exactly the launches the probes below time;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  A counter pass cannot run inside this process,
-    so the figure is read from the file and labelled with its source; None when no matching record is committed."""
+    so the figure is read from the file and labelled with its source; None when no matching record is committed or when
+    this run's launch size differs from the one the counters were collected on (--batch-per-gpu != 64)."""
     path = os.path.join(ROOT, PMC_FILE)
-    if not os.path.exists(path):
+    if not os.path.exists(path) or batch_per_gpu != PMC_BATCH_PER_GPU:
         return None
     rec = json.load(open(path)).get(kernel_key)
     return None if rec is None else rec.get("traffic_bytes_per_launch")
@@ -197,7 +201,7 @@ def dominant_probe(args, reps=10):
     return {"kernel": "conv_wgrad_stream_kernel<float, 1, 4, 4, true> + wgrad_reduce_kernel (dgv2_conv_wgrad_stream_pl: "
                       "D epilogue conv weight gradient, 2B x 4x32, 513(528)->512, 3x3 ring, fp32)",
             "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic("conv_wgrad_stream_kernel_f32"),
+            "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic("conv_wgrad_stream_kernel_f32", args.batch_per_gpu),
             "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)", "algorithmic_bytes_per_launch": nbytes,
             "avg_launch_us": sec * 1e6}
 
@@ -224,7 +228,7 @@ def s2dgrad_probe(args, reps=20):
     return {"kernel": "conv_pipe_kernel<bf16, TO=32, 4 classes> (dgv2_conv_taps_ex: D block-0 conv2 data gradient, "
                       "2B x 32x256x64 -> 64x512x32, 3x3 stride 2 ring, one launch)",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-            "traffic": _pmc_traffic("conv_pipe_kernel_s2dgrad"), "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
+            "traffic": _pmc_traffic("conv_pipe_kernel_s2dgrad", args.batch_per_gpu), "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12}
 
 
@@ -250,7 +254,7 @@ def roofline_probe(args, reps=20):
     kname = "conv3x3_strip_kernel" if strip else "conv_pipe_kernel"
     return {"kernel": kname + " (dgv2_conv_taps: D block-0 conv1 fwd, 2B x 64x512, 32->32, 3x3 ring, bias+lrelu)",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-            "traffic": _pmc_traffic(kname), "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
+            "traffic": _pmc_traffic(kname, args.batch_per_gpu), "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12}
 
 
@@ -306,7 +310,7 @@ def modconv_probe(args, reps=20):
     return {"kernel": "modconv_up_kernel (dgv2_modconv_up_fwd: G level-4 conv1, B x 32768 px, PE K=512, O=32, "
                       "up2 of the low-res xa part as 4 more K-steps)",
             "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": _pmc_traffic("modconv_up_kernel"),
+            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": _pmc_traffic("modconv_up_kernel", args.batch_per_gpu),
             "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)",
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6,
             "algorithmic_hbm_GBps": nbytes / sec / 1e9,
@@ -386,7 +390,8 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             torch.cuda.set_device(local)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            from gans import parallel   # RCCL's kernels on a high-priority stream (see parallel.init_process_group)
+            parallel.init_process_group("nccl", device=torch.device("cuda", local))
     from gans.utils import init_random_seed
 
     init_random_seed(0, rank)

@@ -36,52 +36,14 @@
 
 #include "gemm_core.h"
 
+#ifndef DGV2_S2D_ASM
+#define DGV2_S2D_ASM 0
+#endif
+
 namespace {
 
 constexpr int DTH = 4;
 constexpr int DTW = 32;
-
-// MFMA accumulating IN PLACE, as inline asm.  The unrolled-tap kernels issue MFMAs under wave-uniform branches (dead
-// taps); with the builtin the compiler gives every conditional MFMA a fresh destination and copies whole accumulator
-// sets around the branches (a second 64-register set, then spills).  The asm's "+v" keeps one set.  The compiler does
-// not see inside: fragments arrive through ordinary ds_reads (it places their lgkmcnt waits in front of the asm),
-// dependent MFMAs on the same accumulator are interlocked by the hardware, and the one software hazard -- an MFMA
-// result read by a VALU instruction -- is covered by mfma_drain() in front of the epilogue.
-#ifndef DGV2_S2D_ASM
-#define DGV2_S2D_ASM 0
-#endif
-template <typename T> struct MfmaAsm;
-template <> struct MfmaAsm<bf16_t> {
-  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
-    union { uint4 u; bf16x8 v; } ua, ub;
-    ua.u = a;
-    ub.u = b;
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ua.v), "v"(ub.v));
-  }
-};
-template <> struct MfmaAsm<fp8_t> {   // see Mfma16<fp8_t>
-  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
-    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-    const u32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
-    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a0), "v"(b0));
-    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a1), "v"(b1));
-  }
-};
-template <> struct MfmaAsm<float> {
-  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.x), "v"(b.x));
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.y), "v"(b.y));
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.z), "v"(b.z));
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.w), "v"(b.w));
-  }
-};
-// every MFMA issued so far has written its accumulator when this returns (the longest of the shapes used here takes
-// 8 passes = 32 cycles; the fences keep the scheduler from moving accumulator reads in front of the wait)
-__device__ __forceinline__ void mfma_drain() {
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
 
 struct DConv {
   int B, Hin, Win, Cin;
@@ -798,6 +760,12 @@ int dgv2_conv_strip_try(void* y, const void* x, const void* w, int B, int H, int
                         const int* taps4, int nextra, const int* extras5, int hzero, const float* bias,
                         const void* resid, int act, float alpha, float scale, hipStream_t st);
 
+// conv8.hip: eight-wave form of the unrolled 3x3 forward conv (two groups of four waves sharing the halo tile or the
+// weight slab); -2 = not covered
+int dgv2_conv8_try(void* y, int ldy, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg, int Wg, int O,
+                   int in_stride, int wtaps, int widx0, int wstep, const float* bias, const float* acc_scale,
+                   const void* resid, int act, float alpha, float scale, int dtype, hipStream_t st, int wimg);
+
 namespace {
 
 template <typename T, int TO, typename TY = T>
@@ -987,6 +955,18 @@ static int conv_taps_impl(void* y, int ldy, const void* x, const void* w, int B,
       seen |= 1u << ((top ? 0 : 3) + (j & 3));
     }
     p.border_ok = (ok && seen == 63u) ? 1 : 0;
+  }
+  if ((dtype == DGV2_BF16 || dtype == DGV2_FP8) && f33 && ncls == 1 && nextra == 0 && !accumulate && !hzero && ring &&
+      out_stride == 1 && ioff_h == 0 && ioff_w == 0 && cls_host[0] == 0 && cls_host[1] == 0 && dymin == -1 && dxmin == -1 &&
+      Hy == Hg && Wy == Wg) {
+    // forward 3x3 convs from 64 channels up: the eight-wave engine (conv8.hip) where it covers the geometry
+    rc = dgv2_conv8_try(y, ldy, x, w, B, Hin, Win, Cin, Hg, Wg, O, in_stride, wtaps, p.widx[0], p.widx[1] - p.widx[0], bias,
+                        acc_scale, resid, act, alpha, scale, dtype, st, 0);
+    if (rc != -2) {
+      if (rc) return rc;
+      DGV2_RETURN_LAST();
+    }
+    rc = 0;
   }
   if (dtype == DGV2_FP8) {
     // e4m3 operands, bf16 result / residual: the forward convs behind the FIRs (>= 64 output channels, one class)

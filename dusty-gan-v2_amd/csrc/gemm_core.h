@@ -49,6 +49,45 @@ template <> struct Mfma16<float> {
   }
 };
 
+// MFMA accumulating IN PLACE, as inline asm.  The unrolled-tap kernels issue MFMAs under wave-uniform branches (dead
+// taps); with the builtin the compiler gives every conditional MFMA a fresh destination and copies whole accumulator
+// sets around the branches (a second 64-register set, then spills).  The asm's "+v" keeps one set.  The compiler does
+// not see inside: fragments arrive through ordinary ds_reads (it places their lgkmcnt waits in front of the asm),
+// dependent MFMAs on the same accumulator are interlocked by the hardware, and the one software hazard -- an MFMA
+// result read by a VALU instruction -- is covered by mfma_drain() in front of the epilogue.
+template <typename T> struct MfmaAsm;
+template <> struct MfmaAsm<bf16_t> {
+  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; bf16x8 v; } ua, ub;
+    ua.u = a;
+    ub.u = b;
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ua.v), "v"(ub.v));
+  }
+};
+template <> struct MfmaAsm<fp8_t> {   // see Mfma16<fp8_t>
+  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a0), "v"(b0));
+    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a1), "v"(b1));
+  }
+};
+template <> struct MfmaAsm<float> {
+  __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.x), "v"(b.x));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.y), "v"(b.y));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.z), "v"(b.z));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.w), "v"(b.w));
+  }
+};
+// every MFMA issued so far has written its accumulator when this returns (the longest of the shapes used here takes
+// 8 passes = 32 cycles; the fences keep the scheduler from moving accumulator reads in front of the wait)
+__device__ __forceinline__ void mfma_drain() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // ----------------------------------------------------------------------------------------------
 // Loaders (NN engine): chunk (row, kchunk) of a [rows, K] K-contiguous operand.
 // ----------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ struct BankArgs {
   const float* src[WB_MAX];
   void* wf[WB_MAX];
   void* wt[WB_MAX];
+  void* w8[WB_MAX];   // optional (3x3, O % 64 == 0, Cpad % 32 == 0, 2-byte T): conv8.hip's staging image, else nullptr
   int O[WB_MAX], C[WB_MAX], Cpad[WB_MAX], kk[WB_MAX];
   float scale[WB_MAX];
 };
@@ -90,6 +91,21 @@ __global__ __launch_bounds__(256) void weight_bank_tiled_kernel(BankArgs a) {
     const int t = r % kk, o = r / kk;
     if (o0 + o < O && c0 + c < Cp) wf[((size_t)(o0 + o) * kk + t) * Cp + c0 + c] = from_f32<T>(tile[o][c * kk + t]);
   }
+  if (KK == 9 && sizeof(T) == 2 && a.w8[l]) {
+    // conv8.hip's image: [slab = o / 64][chunk = c / 32][unit id] of 16 bytes (8 channels), id = the kernel's staging
+    // slot order for (row = tap * 64 + o % 64, plane = (c % 32) / 8): (row >> 3) * 32 + plane * 8 + (row & 7)
+    T* w8 = reinterpret_cast<T*>(a.w8[l]);
+    const int nchunks = Cp / WB_TC;
+    for (int f = threadIdx.x; f < WB_TO * run; f += 256) {
+      const int c = f % WB_TC, r = f / WB_TC;
+      const int t = r % kk, o = r / kk;
+      if (o0 + o < O) {
+        const int og = o0 + o, row = t * 64 + (og & 63), plane = c >> 3;
+        const size_t unit = ((size_t)(og >> 6) * nchunks + c0 / WB_TC) * (576 * 4) + (row >> 3) * 32 + plane * 8 + (row & 7);
+        w8[unit * 8 + (c & 7)] = from_f32<T>(tile[o][c * kk + t]);
+      }
+    }
+  }
   for (int g = threadIdx.x; g < WB_TO * run; g += 256) {   // transposed layout: runs of 64 output channels
     const int o = g % WB_TO, r = g / WB_TO;
     const int t = r % kk, c = r / kk;
@@ -100,11 +116,28 @@ __global__ __launch_bounds__(256) void weight_bank_tiled_kernel(BankArgs a) {
 }  // namespace
 
 // src / wf / wt: HOST arrays of L <= 32 device pointers; O, C, Cpad, kk (= kh*kw), scale: HOST arrays.
+extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, const float* const* src,
+                                        const int* O, const int* C, const int* Cpad, const int* kk, const float* scale, int L,
+                                        int dtype, void* stream);
+
 extern "C" int dgv2_conv_weight_bank(void* const* wf, void* const* wt, const float* const* src, const int* O,
                                      const int* C, const int* Cpad, const int* kk, const float* scale, int L,
                                      int dtype, void* stream) {
+  return dgv2_conv_weight_bank_ex(wf, wt, nullptr, src, O, C, Cpad, kk, scale, L, dtype, stream);
+}
+
+// ... with a third, optional output per layer: w8[l] != nullptr asks for the staging image of the eight-wave forward
+// conv (conv8.hip, dgv2_conv3x3_fwd8): [O / 64][Cpad / 32][2304 units of 16 bytes in the kernel's slot order], the same
+// values as wf.  Needs kk == 9, O % 64 == 0, Cpad % 32 == 0, bf16 (DGV2_EINVAL otherwise); w8 itself may be nullptr.
+extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, const float* const* src,
+                                        const int* O, const int* C, const int* Cpad, const int* kk, const float* scale, int L,
+                                        int dtype, void* stream) {
   if (!wf || !wt || !src || !O || !C || !Cpad || !kk || !scale || L < 1 || L > WB_MAX) return DGV2_EINVAL;
   BankArgs a;
+  for (int l = 0; l < L; ++l) {
+    a.w8[l] = w8 ? w8[l] : nullptr;
+    if (a.w8[l] && (kk[l] != 9 || O[l] % 64 || Cpad[l] % 32 || dtype != DGV2_BF16)) return DGV2_EINVAL;
+  }
   int nmax = 0, tmax = 0, kmax = 0;
   for (int l = 0; l < L; ++l) {
     if (!wf[l] || !wt[l] || !src[l] || O[l] < 1 || C[l] < 1 || Cpad[l] < C[l] || kk[l] < 1) return DGV2_EINVAL;
@@ -127,6 +160,9 @@ extern "C" int dgv2_conv_weight_bank(void* const* wf, void* const* wt, const flo
       else if (kk[l] == 9) has9 = true;
       else other = true;
     }
+    if (other)
+      for (int l = 0; l < L; ++l)
+        if (a.w8[l]) return DGV2_ENOTSUP;   // the image comes from the 9-tap instance only
     DGV2_DISPATCH_DTYPE(dtype, {
       if (other) {
         weight_bank_tiled_kernel<T, 0><<<tgrid, 256, 0, st>>>(a);
@@ -137,6 +173,8 @@ extern "C" int dgv2_conv_weight_bank(void* const* wf, void* const* wt, const flo
     });
     DGV2_RETURN_LAST();
   }
+  for (int l = 0; l < L; ++l)
+    if (a.w8[l]) return DGV2_ENOTSUP;   // the image is written by the tiled kernel only
   dim3 grid(grid_for(nmax, 256, 256), L);
   DGV2_DISPATCH_DTYPE(dtype, { weight_bank_kernel<T><<<grid, 256, 0, st>>>(a); });
   DGV2_RETURN_LAST();

@@ -128,9 +128,17 @@ class AdaptiveAugment(torch.nn.Module):
         self.n_pred_cum += len(y_real)
 
     @torch.no_grad()
-    def update_p(self):
-        """reference: adaptive_augment.py:372-384; one packed all-reduce, in-place buffer updates."""
-        stats = reduce_sum(torch.cat([self.sign_cum, self.n_pred_cum]))
+    def stats(self):
+        """This rank's (sign_cum, n_pred_cum), for a caller that sums them over ranks inside a collective of its own
+        (parallel.tail_exchange) and hands the sum to update_p."""
+        return torch.cat([self.sign_cum.reshape(1), self.n_pred_cum.reshape(1)])
+
+    @torch.no_grad()
+    def update_p(self, stats=None):
+        """reference: adaptive_augment.py:372-384; one packed all-reduce (or `stats`, already summed over ranks),
+        in-place buffer updates."""
+        if stats is None:
+            stats = reduce_sum(torch.cat([self.sign_cum, self.n_pred_cum]))
         rt = stats[0] / stats[1]
         if self.p_target is not None:
             adjust = torch.sign(rt - self.p_target) * stats[1] / self.kimg

@@ -733,11 +733,12 @@ class Discriminator(nn.Module):
             items.append(epi)
         if len(items) > 32:
             return None
-        prepared = native.conv_weight_bank([e for _, e in items], dt)
-        bank = {m: (e[1], e[2], wf, wt) for (m, e), (wf, wt) in zip(items, prepared)}
+        # the 3x3 convs also get the staging image of the eight-wave forward engine (conv8.hip) where it applies
+        prepared = native.conv_weight_bank([e for _, e in items], dt, image8=[True] * len(items))
+        bank = {m: (e[1], e[2], wf, wt, w8) for (m, e), (wf, wt, w8) in zip(items, prepared)}
         if edt != dt:   # fp32 epilogue behind a reduced-precision trunk: its weight is prepared by a launch of its own
             (wf, wt), = native.conv_weight_bank([epi[1]], edt)
-            bank[conv] = (epi[1][1], epi[1][2], wf, wt)
+            bank[conv] = (epi[1][1], epi[1][2], wf, wt, None)
         return bank
 
     def _fp8_bank(self):

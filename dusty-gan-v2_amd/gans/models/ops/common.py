@@ -182,6 +182,7 @@ class Conv2d(nn.Sequential):
                 else:
                     w = native.scaled_handle(p_raw, s_used, cpad_used)
                 w._dgv2_wf, w._dgv2_wt = ent[2], ent[3]
+                w._dgv2_w8 = ent[4] if len(ent) > 4 else None   # conv8.hip's staging image of the same values
                 b, gain = self._params_bias()
             else:
                 ent = None

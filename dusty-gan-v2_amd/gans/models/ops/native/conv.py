@@ -76,12 +76,22 @@ def _direct_ok(g, cin):
     return bool(g.ring) and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2) and cin
 
 
-def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None):
+_CONV8_IMG = os.environ.get("DGV2_NO_CONV8_IMG") is None   # A/B switch for benchmarking
+
+
+def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None, w8=None):
+    """w8: the weight bank's staging image of the same weights (conv_weight_bank(image8=...)): 3x3 ring convs the
+    eight-wave engine covers then run dgv2_conv3x3_fwd8 on it."""
     B, H, W, C = x.shape
     O = w.shape[0]
     Ho, Wo = g.out_hw(H, W)
     N.check(x, w, bias)
     y = torch.empty((B, Ho, Wo, O), device=x.device, dtype=x.dtype)
+    if (w8 is not None and _CONV8_IMG and x.dtype == torch.bfloat16 and g.ring and (g.kh, g.kw, g.pad) == (3, 3, 1)
+            and g.stride in (1, 2) and N.try_call("dgv2_conv3x3_fwd8", N.ptr(y), N.ptr(x), N.ptr(w8), B, H, W, C, O,
+                                                   g.stride, N.ptr(bias), N.ptr(resid), act, alpha, scale, _dt(x),
+                                                   N.stream())):
+        return y
     if _direct_ok(g, C % _kstep(x) == 0):
         taps = [(ky - g.pad, kx - g.pad, ky * g.kw + kx) for ky in range(g.kh) for kx in range(g.kw)]
         _conv_taps(y, x, w.reshape(O, g.kh * g.kw, C), Ho, Wo, g.stride, (0, 0), 1, (0, 0), taps, False,
@@ -259,6 +269,12 @@ def _bank(w, x):
     return None, None
 
 
+def _bank8(w, x):
+    """The bank's staging image for the eight-wave forward conv (same values as the forward layout), or None."""
+    w8 = getattr(w, "_dgv2_w8", None)
+    return w8 if (w8 is not None and w8.dtype == x.dtype and getattr(w, "_dgv2_wf", None) is not None) else None
+
+
 class _ConvFwd(Function):
     @staticmethod
     def forward(ctx, x, w, g):
@@ -270,7 +286,7 @@ class _ConvFwd(Function):
             wc = _values(w, x.dtype)
         ctx.save_for_backward(x, w)
         ctx.g = g
-        return _conv_fwd_raw(x, wc.reshape(w.shape), g)
+        return _conv_fwd_raw(x, wc.reshape(w.shape), g, w8=_bank8(w, x))
 
     @staticmethod
     def backward(ctx, gy):
@@ -352,7 +368,7 @@ class _ConvAct(Function):
         ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
-        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale, w8=_bank8(w, x))
         ctx.save_for_backward(x, w, out)
         ctx.cfg = (g, alpha, scale, bias.numel())
         return out
@@ -627,9 +643,20 @@ def scaled_handle(param, scale, cpad=0):
     return h
 
 
-def conv_weight_bank(entries, dtype):
+def conv8_image_ok(p, cpad, dtype):
+    """Whether conv_weight_bank can also write conv8.hip's staging image for this layer (3x3, whole 64-channel slabs,
+    whole 32-channel K-chunks, at least two of them, bf16)."""
+    return (dtype == torch.bfloat16 and tuple(p.shape[2:]) == (3, 3) and p.shape[0] % 64 == 0 and cpad % 32 == 0
+            and cpad >= 64)
+
+
+def conv_weight_bank(entries, dtype, image8=None):
     """entries: list of (param fp32 [O,C,kh,kw], scale, Cpad).  One launch; returns [(wf [O,kh*kw,Cpad], wt
-    [Cpad,kh*kw,O])] in `dtype` (views of two flat buffers)."""
+    [Cpad,kh*kw,O])] in `dtype` (views of two flat buffers).  image8: list of bools -- also write the staging image of
+    the eight-wave forward conv for those layers (dgv2_conv_weight_bank_ex); the result tuples then carry it (or None)
+    as a third element."""
+    if image8 is not None:
+        return _conv_weight_bank8(entries, dtype, image8)
     L = len(entries)
     dev = entries[0][0].device
     dims = [(p.shape[0], p.shape[1], int(cp), p.shape[2] * p.shape[3]) for p, _, cp in entries]
@@ -649,6 +676,31 @@ def conv_weight_bank(entries, dtype):
     return list(zip(wfs, wts))
 
 
+def _conv_weight_bank8(entries, dtype, image8):
+    L = len(entries)
+    dev = entries[0][0].device
+    dims = [(p.shape[0], p.shape[1], int(cp), p.shape[2] * p.shape[3]) for p, _, cp in entries]
+    sizes = [o * kk * cp for o, _, cp, kk in dims]
+    flat_f = torch.empty(sum(sizes), device=dev, dtype=dtype)
+    flat_t = torch.empty(sum(sizes), device=dev, dtype=dtype)
+    want = [bool(f) and conv8_image_ok(p, cp, dtype) for f, (p, _, cp) in zip(image8, entries)]
+    flat_8 = torch.empty(sum(n for n, f in zip(sizes, want) if f), device=dev, dtype=dtype) if any(want) else None
+    wfs, wts, w8s, off, off8 = [], [], [], 0, 0
+    for (o, c, cp, kk), n, f in zip(dims, sizes, want):
+        wfs.append(flat_f[off:off + n].view(o, kk, cp))
+        wts.append(flat_t[off:off + n].view(cp, kk, o))
+        w8s.append(flat_8[off8:off8 + n] if f else None)
+        off += n
+        off8 += n if f else 0
+    srcs = [p.detach() for p, _, _ in entries]
+    N.check(*srcs)
+    N.call("dgv2_conv_weight_bank_ex", _ptr_array(wfs), _ptr_array(wts), _ptr_array(w8s), _ptr_array(srcs),
+           _int_array([d[0] for d in dims]), _int_array([d[1] for d in dims]), _int_array([d[2] for d in dims]),
+           _int_array([d[3] for d in dims]), (_ct.c_float * L)(*[float(s) for _, s, _ in entries]), L,
+           N.dtype_code(flat_f), N.stream())
+    return list(zip(wfs, wts, w8s))
+
+
 class _ConvActFork(Function):
     """(lrelu(conv(x, w) + b) * scale, x): the second output hands the SAME input on to a sibling branch (the skip
     path of ResidualBlock), so that in backward both gradients of x arrive here together and the sibling's is added
@@ -662,7 +714,7 @@ class _ConvActFork(Function):
         ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
-        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale, w8=_bank8(w, x))
         ctx.save_for_backward(x, w, out)
         ctx.cfg = (g, alpha, scale, bias.numel())
         return out, x.view_as(x)
@@ -740,7 +792,7 @@ class _ConvActDown(Function):
         ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
-        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale)
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale, w8=_bank8(w, x))
         in_hw = (out.shape[1], out.shape[2])
         ctx.save_for_backward(x, w, out)
         ctx.cfg = (g, alpha, scale, bias.numel(), spec, in_hw)
@@ -793,7 +845,7 @@ class _ConvResid(Function):
             wc = _values(w, x.dtype)
         ctx.save_for_backward(x, w)
         ctx.g = g
-        return _conv_fwd_raw(x, wc.reshape(w.shape), g, resid=resid)
+        return _conv_fwd_raw(x, wc.reshape(w.shape), g, resid=resid, w8=_bank8(w, x))
 
     @staticmethod
     def backward(ctx, gy):

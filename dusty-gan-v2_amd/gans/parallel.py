@@ -8,10 +8,19 @@ Here the exchanges are explicit and sized for xGMI:
 
   FlatGradSync      every parameter's .grad is a VIEW into one flat fp32 buffer per model, so the
                     gradient exchange is a single large all-reduce (17.5 MB for G, 154 MB for D)
-                    with no bucket copies; averaging is folded into one in-place scale.
+                    with no bucket copies; averaging is folded into one in-place scale.  The buffer
+                    can CARRY rank 0's mutable module buffers behind the gradients (carry_buffers):
+                    the broadcast DDP issues before the next forward rides in the same collective.
   sync_buffers      rank 0's mutable G buffers (w_avg + the 19 ema_var scalars) packed into one
-                    531-float broadcast instead of DDP's per-buffer broadcasts.
-  reduce_scalars    all logged scalars packed into one vector all-reduce; no host sync.
+                    531-float broadcast instead of DDP's per-buffer broadcasts (the stand-alone form).
+  tail_exchange     ONE small all-reduce at the end of an iteration: every logged scalar, ADA's
+                    statistic pair when its update is due, and rank 0's mutable G buffers for the
+                    next iteration's first forward.
+  init_process_group  "nccl" (= RCCL) with its kernels on a HIGH-PRIORITY stream.
+
+Collectives per iteration (world > 1): G gradients + buffers (asynchronous, under the real-batch
+preparation), D head gradients (asynchronous, under the trunk's backward), D remaining gradients
+(asynchronous, under the EMA update), the tail; + R1's gradients every lazy.gp-th iteration.
 """
 from contextlib import contextmanager
 
@@ -38,7 +47,7 @@ def world_size():
 class FlatGradSync:
     """Owns the gradients of `module`: p.grad are views of self.flat (fp32)."""
 
-    def __init__(self, module, payload_dtype=None, first=None):
+    def __init__(self, module, payload_dtype=None, first=None, carry_buffers=False):
         """payload_dtype: torch.bfloat16 sends the gradients as bf16 (half the xGMI bytes; one cast pass each way, the
         sum itself is then rounded to bf16 -- NOT what the reference's fp32 DDP buckets do, hence opt-in:
         training.grad_payload: bf16).  None / torch.float32: the flat fp32 buffer itself is reduced in place.
@@ -55,7 +64,17 @@ class FlatGradSync:
         self.n_first = sum(p.numel() for p in first)
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        # gradients, then (carry_buffers) room for the module's mutable buffers: ONE allocation, so that a reduction of
+        # "everything" can take both in one collective; self.flat is the gradient part (what Adam's views live in)
+        self._carry = mutable_buffers(module) if carry_buffers and self.payload_dtype is None else []
+        k = sum(b.numel() for b in self._carry)
+        self._store = torch.zeros(n + k, device=dev, dtype=torch.float32)
+        self.flat = self._store[:n]
+        self._tail = self._store[n:]
+        self._tail_views, toff = [], 0
+        for b in self._carry:
+            self._tail_views.append(self._tail[toff:toff + b.numel()].view_as(b))
+            toff += b.numel()
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -140,17 +159,30 @@ class FlatGradSync:
         finally:
             self._sync = old
 
-    def all_reduce(self, async_op=False, part=None):
+    def carries_buffers(self):
+        return bool(self._carry)
+
+    def all_reduce(self, async_op=False, part=None, carry=False):
         """Average the flat gradient (or one segment of it) over ranks (no-op for one process or inside no_sync).
         async_op: start the reduction on the communication stream and return a handle for wait(); work issued in
-        between overlaps it."""
+        between overlaps it.  carry (with part None or "rest", a sync built with carry_buffers): rank 0's current
+        values of the module's mutable buffers travel behind the gradients and are written into every rank's buffers
+        when the reduction completes."""
         if not (self._sync and is_dist()):
             return None
         avg = _avg_supported(self.flat.device)
         _, (lo, hi) = self._part(part)
+        carry = bool(carry and self._carry and hi == self.flat.numel())
+        if carry:
+            if dist.get_rank() == 0:
+                torch._foreach_copy_(self._tail_views, self._carry)
+                self._tail.mul_(float(dist.get_world_size()))
+            else:
+                self._tail.zero_()
+            hi = self._store.numel()
         if hi <= lo:
             return None
-        buf = self.flat[lo:hi]
+        buf = self._store[lo:hi]
         if self.payload_dtype is not None:
             if self._payload is None:
                 self._payload = torch.empty_like(self.flat, dtype=self.payload_dtype)
@@ -159,23 +191,25 @@ class FlatGradSync:
         # RCCL averages inside the reduction: no extra pass over the 154 MB buffer
         work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
         if async_op:
-            return (work, avg, lo, hi)
-        self._finish(avg, lo, hi)
+            return (work, avg, lo, hi, carry)
+        self._finish(avg, lo, hi, carry)
         return None
 
-    def _finish(self, avg, lo, hi):
+    def _finish(self, avg, lo, hi, carry=False):
         if self.payload_dtype is not None:
             self.flat[lo:hi].copy_(self._payload[lo:hi])
         if not avg:
-            self.flat[lo:hi].mul_(1.0 / dist.get_world_size())
+            self._store[lo:hi].mul_(1.0 / dist.get_world_size())
+        if carry:
+            torch._foreach_copy_(self._carry, self._tail_views)
 
     def wait(self, handle):
         """Complete an all_reduce(async_op=True): the current stream waits for the reduction."""
         if handle is None:
             return
-        work, avg, lo, hi = handle
+        work, avg, lo, hi, carry = handle
         work.wait()
-        self._finish(avg, lo, hi)
+        self._finish(avg, lo, hi, carry)
 
 
 _AVG_OK = None
@@ -235,6 +269,59 @@ def broadcast_module(module, src=0):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)
+
+
+@torch.no_grad()
+def tail_exchange(named, ada_stats=None, module=None):
+    """The iteration's last collective: ONE all-reduce(SUM) of [logged scalars | ADA's (sign_cum, n_pred_cum) when its
+    update is due | rank 0's mutable buffers of `module` (zeros from the other ranks)] instead of reduce_scalars + ADA's
+    own all-reduce (adaptive_augment.py:372-384) + the buffer broadcast before the next iteration's first forward
+    (DDP broadcast_buffers=True, reference trainer.py:77; nothing touches the buffers in between).
+    Returns (scalars averaged over ranks, summed ADA statistics or None).  No host synchronisation."""
+    keys = list(named.keys())
+    parts = [torch.stack([named[k].detach().float().reshape(()) for k in keys])] if keys else []
+    n_sc = len(keys)
+    n_ada = 0
+    if ada_stats is not None:
+        parts.append(ada_stats.detach().float().reshape(-1))
+        n_ada = parts[-1].numel()
+    bufs = mutable_buffers(module) if (module is not None and is_dist()) else []
+    if bufs:
+        flat = torch.cat([b.detach().float().reshape(-1) for b in bufs])
+        parts.append(flat if dist.get_rank() == 0 else torch.zeros_like(flat))
+    if not parts:
+        return {}, None
+    vec = torch.cat(parts)
+    if is_dist():
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    world = float(world_size())
+    sc = vec[:n_sc] / world
+    ada = vec[n_sc:n_sc + n_ada] if n_ada else None
+    if bufs:
+        off = n_sc + n_ada
+        views = []
+        for b in bufs:
+            views.append(vec[off:off + b.numel()].view_as(b))
+            off += b.numel()
+        torch._foreach_copy_(bufs, views)
+    return {k: sc[i] for i, k in enumerate(keys)}, ada
+
+
+def init_process_group(backend="nccl", device=None, **kw):
+    """torch.distributed.init_process_group with the RCCL kernels on a HIGH-PRIORITY stream: the trunk-backward
+    kernels of the step are full-chip grids (`__launch_bounds__(512, 1)` / two blocks per CU), so a reduction that
+    starts under them would otherwise queue behind every workgroup already dispatched; with a high-priority queue the
+    command processor hands the reduction's (few, small) workgroups the next CUs that free up.  Chosen over capping the
+    compute kernels' grids, which would slow the one-GPU path this build is measured on."""
+    if backend == "nccl":
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            kw.setdefault("pg_options", opts)
+        except Exception:   # noqa: BLE001  (an older torch without the option: default-priority stream)
+            pass
+        if device is not None:
+            kw.setdefault("device_id", device)
+    return dist.init_process_group(backend=backend, **kw)
 
 
 @torch.no_grad()

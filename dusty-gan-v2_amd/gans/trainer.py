@@ -89,7 +89,10 @@ class Trainer:
         for m in (self.G, self.G_ema, self.D, self.A, self.coord):
             m.requires_grad_(False)
         payload = {"fp32": None, "bf16": torch.bfloat16}[str(cfg.training.get("grad_payload", "fp32"))]
-        self.g_sync = parallel.FlatGradSync(self.G, payload)
+        # G's flat gradient buffer also carries rank 0's mutable buffers (ema_var, w_avg): the broadcast that DDP issues
+        # before the D step's G forward rides in the gradient all-reduce (parallel.FlatGradSync.carry_buffers)
+        self.g_sync = parallel.FlatGradSync(self.G, payload, carry_buffers=True)
+        self._g_bufs_synced = False   # True while every rank's G buffers are known to equal rank 0's
         # D's backward in two pieces (training.overlap_d_reduce; default: whenever there is someone to exchange with):
         # the head's gradients -- the 65536 -> 512 Linear, 134 of 154 MB -- are complete after the first few kernels of
         # the backward pass and travel while the trunk's backward runs (what DDP's reverse-order buckets do for the
@@ -502,12 +505,15 @@ class Trainer:
                 # under graph replay the body's scalar tensors are static buffers: keep a copy per chunk
                 per_chunk[k].append(v.clone() if nacc > 1 else v)
 
-        # a rank's share of the global batch, chunk by chunk (reference: trainer.py:253-257)
-        if nacc == 1:
-            self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
-            reals = [self.x_real]
-        else:
+        # a rank's share of the global batch, chunk by chunk (reference: trainer.py:253-257).  With one chunk and an
+        # objective whose G step does not look at reals, the batch is prepared AFTER the G step's backward: it is the one
+        # piece of work on this rank that does not depend on G's reduced gradient, so G's all-reduce runs under it.
+        late_reals = nacc == 1 and not self.use_real_in_g
+        reals = None
+        if nacc > 1:
             reals = [self.fetch_reals(next(self.iter_train_loader))["image"] for _ in range(nacc)]
+        elif not late_reals:
+            self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
 
         def real(j):
             if nacc > 1:
@@ -520,29 +526,38 @@ class Trainer:
         # of an iteration are preceded by a broadcast -- between the two this rank's forward has moved ema_var / w_avg,
         # the second one is not redundant -- while the later chunks of an accumulation loop (their predecessors ran
         # under no_sync) are not.  Exactly that is kept.
+        # Where the broadcast travels: the one before the G step rode in the previous iteration's tail exchange
+        # (_g_bufs_synced), the one before the D step rides behind G's gradients; the stand-alone sync_buffers remains
+        # for the first iteration and around the path-length step.
         for j in range(nacc):
-            if j == 0:
+            if j == 0 and not self._g_bufs_synced:
                 parallel.sync_buffers(self.G)
             if self.use_real_in_g:
                 log(self._run(self._acc_name("g_fb", j), self.g_fb_rel, real(j), j))
             else:
                 log(self._run(self._acc_name("g_fb", j), self.g_fb, j))
-        # nothing on this rank is independent of G's reduced gradient (the D step starts with a forward of the updated
-        # G), so this 17.5 MB reduction is synchronous
-        self.g_sync.all_reduce()
+        # G's 17.5 MB (+ rank 0's buffers) leave on the communication stream; the real batch of this iteration is
+        # fetched / generated and converted meanwhile (the D step itself starts with a forward of the UPDATED G)
+        h = self.g_sync.all_reduce(async_op=True, carry=True)
+        if late_reals:
+            self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
+        self.g_sync.wait(h)
+        self._g_bufs_synced = h is not None and self.g_sync.carries_buffers()
         self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
 
         if self.pl_weight > 0.0 and iteration % self.lazy_pl == 0:
             for j in range(nacc):
-                if j == 0:
+                if j == 0 and not self._g_bufs_synced:
                     parallel.sync_buffers(self.G)
                 log(self._run(self._acc_name("pl_fb", j), self.pl_fb, j))
-            self.g_sync.all_reduce()
+            h = self.g_sync.all_reduce(async_op=True, carry=True)
+            self.g_sync.wait(h)
+            self._g_bufs_synced = h is not None and self.g_sync.carries_buffers()
             self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
 
         pending = []
         for j in range(nacc):
-            if j == 0:
+            if j == 0 and not self._g_bufs_synced:
                 parallel.sync_buffers(self.G)
             if self.split_d:
                 head, tail = self._acc_name("d_fb_head", j), self._acc_name("d_fb_tail", j)
@@ -563,20 +578,31 @@ class Trainer:
             self.d_sync.wait(h)
         self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
 
+        self._g_bufs_synced = False   # the D step's G forward moved this rank's ema_var / w_avg again
+        r1_pending = None
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
             for j in range(nacc):
                 log(self._run(self._acc_name("r1_fb", j), self.r1_fb, real(j), j))
-            self.d_sync.all_reduce()
-            self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
-        set_requires_grad(self.D, False)
+            # R1's 154 MB leave asynchronously as well: the packing launches of the tail exchange run under them (the
+            # exchange itself queues behind the reduction on the communication stream).  The optimizer step cannot move
+            # past the next iteration's G step, whose D forward must see the regularised weights (trainer.py:419-451).
+            r1_pending = self.d_sync.all_reduce(async_op=True)
 
         scalars = {k: (v[0] if len(v) == 1 else torch.stack([t.reshape(()) for t in v]).mean())
                    for k, v in per_chunk.items()}          # mean over the chunks (reference: trainer.py:471-476)
-        if iteration % self.lazy_ada == 0:
-            scalars["stats/ada_rt"] = self.A.update_p().reshape(())
-            scalars["stats/ada_p"] = self.A.p.detach().clone()
+        # ONE small collective closes the iteration: the logged scalars, ADA's statistic pair when its update is due
+        # (adaptive_augment.py:372-384) and rank 0's G buffers for the next iteration's first forward
+        ada_due = iteration % self.lazy_ada == 0
+        out, ada_stats = parallel.tail_exchange(scalars, self.A.stats() if ada_due else None, self.G)
+        self._g_bufs_synced = parallel.is_dist()
+        if ada_due:
+            out["stats/ada_rt"] = self.A.update_p(stats=ada_stats).reshape(())
+            out["stats/ada_p"] = self.A.p.detach().clone()
+        if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
+            self.d_sync.wait(r1_pending)
+            self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
+        set_requires_grad(self.D, False)
 
-        out = parallel.reduce_scalars(scalars)
         if self.sync_scalars:
             out = {k: v.cpu().item() for k, v in out.items()}
         out["stats/ema_decay"] = decay

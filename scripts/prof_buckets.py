@@ -1,15 +1,26 @@
-"""Aggregate a rocprofv3 kernel_stats.csv into per-engine buckets (ms per step).
-usage: python scripts/prof_buckets.py <kernel_stats.csv> <steps>"""
+"""Aggregate a rocprofv3 kernel_stats.csv into per-engine buckets (ms per training iteration).
+The number of iterations the profiled process ran is COUNTED from the file: every iteration launches the fused Adam
+kernel exactly twice (G and D) plus once more on a lazy-R1 iteration (every 16th), so iterations = Adam launches /
+(2 + 1/16).  A second argument overrides the count.
+usage: python scripts/prof_buckets.py <kernel_stats.csv> [iterations]"""
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = float(sys.argv[2])
+adam = sum(int(r["Calls"]) for r in rows if "adam_step_kernel" in r["Name"])
+if len(sys.argv) > 2:
+    steps = float(sys.argv[2])
+elif adam:
+    steps = adam / (2.0 + 1.0 / 16.0)
+else:
+    raise SystemExit("no adam_step_kernel launches in the file: pass the iteration count")
+print(f"# {adam} Adam launches -> {steps:.1f} training iterations in the profiled process (warm-up, capture, timed and "
+      f"extra-measurement iterations alike; probe launches outside iterations are included in the totals)")
 B = collections.OrderedDict([
-    ("conv_pipe", r"conv_pipe_kernel"), ("conv_direct_fallback", r"conv_direct_kernel"),
+    ("conv_pipe", r"conv_pipe_kernel"), ("conv8", r"conv8_kernel"), ("conv_strip", r"conv3x3_strip"), ("conv_direct_fallback", r"conv_direct_kernel"),
     ("conv_wgrad_stream", r"wgrad_stream|wgrad_reduce"), ("conv_wgrad_direct", r"wgrad_direct"), ("gemm_tn(im2col wgrad)", r"gemm_tn_kernel.*Im2col"),
     ("gemm_tn", r"gemm_tn_kernel"), ("gemm_nn(conv)", r"gemm_nn_kernel.*Im2col"), ("gemm_nn", r"gemm_nn_kernel"),
-    ("resample", r"resample"), ("upfirdn/ada", r"upfirdn|ada_"), ("mod_prep", r"mod_prep"),
+    ("fir_mfma", r"fir_same_mfma"), ("resample", r"resample"), ("upfirdn/ada", r"upfirdn|ada_"), ("mod_prep", r"mod_prep"),
     ("bias_act", r"bias_act|bias_grad"), ("sumsq", r"sum_squares"), ("tail/fourier/coords", r"gen_tail|fourier|coords|downsample_angle"),
-    ("modconv_pe", r"modconv_pe"), ("stem", r"stem_"), ("adam/lerp", r"adam_|lerp_list"), ("ema/pack/bank", r"ema_scalar|pack2d|weight_bank"),
+    ("modconv_pe", r"modconv_pe"), ("modconv_up", r"modconv_up|up2_lag"), ("pe_wgrad", r"pe_wgrad"), ("gemm_x3", r"gemm_x3"), ("stem", r"stem_"), ("adam/lerp", r"adam_|lerp_list"), ("ema/pack/bank", r"ema_scalar|pack2d|weight_bank"),
     ("zero", r"dgv2_zero"), ("blas", r"Cijk|rocblas|hipblas"), ("torch_other", r".*")])
 agg = collections.defaultdict(lambda: [0.0, 0])
 for r in rows:

@@ -53,7 +53,8 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     elif os.environ.get("DGV2_DIST_WORLD1"):   # one rank, RCCL itself: every collective of the N > 1 path runs (see parallel.py)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, LOCAL_RANK="0")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from gans import parallel
+        parallel.init_process_group("nccl", device=torch.device("cuda", 0), rank=0, world_size=1)
     import recipe
     from gans.trainer import Trainer
     from helpers import build_models

@@ -844,6 +844,14 @@ CONVS = [  # B, H, W, C, O, k, stride, pad, ring
     # the stride-2 data gradient's unrolled four-class path with two K-chunks of gy (both weight slabs resident in LDS)
     (2, 16, 72, 32, 64, 3, 2, 1, True),
     (3, 8, 64, 64, 64, 3, 2, 1, True),
+    # eight-wave engine (conv8.hip), stride 2 (two channel slabs on one halo tile, column-parity LDS image): 4-row tiles,
+    # 8-row tiles with ragged H and W and two slab pairs (XCD-aware order), a block walking two super-tiles (>= 512 tiles)
+    (4, 8, 64, 64, 128, 3, 2, 1, True),
+    (2, 40, 144, 64, 256, 3, 2, 1, True),
+    (128, 16, 256, 64, 128, 3, 2, 1, True),
+    # ... stride 1 (two pixel tiles on one weight slab): odd number of tiles (half-dead super-tile), ragged H, two slabs
+    (2, 8, 96, 64, 64, 3, 1, 1, True),
+    (2, 20, 128, 64, 128, 3, 1, 1, True),
 ]
 
 
@@ -899,6 +907,38 @@ def test_conv_bf16_exact_on_integers(nat, cfg):
     assert torch.equal(gwd.permute(0, 3, 1, 2).cpu(), gw)
 
 
+@pytest.mark.parametrize("B,H,W,C,O,stride", [(2, 40, 144, 96, 256, 2), (3, 8, 64, 128, 128, 2), (2, 24, 96, 96, 64, 1),
+                                               (2, 8, 128, 128, 192, 1)])
+def test_conv8_three_chunks_and_fused_epilogue_exact_on_integers(nat, B, H, W, C, O, stride):
+    """The eight-wave engine (conv8.hip) with what the conv triple above does not pass it: three / four K-chunks, bias +
+    leaky ReLU + gain + residual in the epilogue (the ResidualBlock call sites, dusty_v2.py:331-345).  Operands in
+    {-1, 0, 1}, alpha = 0.25, gain 2, integer bias / residual: every intermediate is exact in bf16."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-1, 2, (B, C, H, W), generator=g).float()
+    w = torch.randint(-1, 2, (O, C, 3, 3), generator=g).float()
+    bias = torch.randint(-3, 4, (O,), generator=g).float()
+    t = _conv_oracle(x, w, stride, 1, True) + bias[None, :, None, None]
+    resid = torch.randint(-3, 4, t.shape, generator=g).float()
+    want = torch.where(t > 0, t, 0.25 * t) * 2.0 + resid
+    assert float(want.abs().max()) < 256
+    geom = nat.ConvGeom(3, 3, stride, 1, True)
+    got = nat._conv_fwd_raw(cl(x).bfloat16(), w.permute(0, 2, 3, 1).contiguous().to(DEV).bfloat16(), geom, bias.to(DEV), 3,
+                            0.25, 2.0, cl(resid).bfloat16())
+    assert torch.equal(nchw(got), want)
+    # ... and on the weight bank's staging image (dgv2_conv3x3_fwd8)
+    (wf, wt, w8), = nat.conv_weight_bank([(w.to(DEV), 1.0, C)], torch.bfloat16, image8=[True])
+    assert w8 is not None
+    got8 = nat._conv_fwd_raw(cl(x).bfloat16(), wf.reshape(O, 3, 3, C), geom, bias.to(DEV), 3, 0.25, 2.0, cl(resid).bfloat16(),
+                             w8=w8)
+    assert torch.equal(nchw(got8), want)
+    # the direct call refuses nothing silently: a geometry the engine does not cover reports ENOTSUP (-> False here)
+    import dgv2_native as N
+    y = torch.empty(1, 2, 16, 64, device=DEV, dtype=torch.bfloat16)
+    xs = torch.zeros(1, 2, 16, 64, device=DEV, dtype=torch.bfloat16)
+    assert N.try_call("dgv2_conv3x3_fwd8", N.ptr(y), N.ptr(xs), N.ptr(w8), 1, 2, 16, 64, 64, 1, None, None, 0, 0.2, 1.0,
+                      N.BF16, N.stream()) is False
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_weight_bank_both_layouts(nat, dtype):
     """wf = scale * w as [O, kh*kw, Cpad] and wt = the same as [Cpad, kh*kw, O], zero padded channels -- exact
@@ -918,6 +958,19 @@ def test_conv_weight_bank_both_layouts(nat, dtype):
     for (wf, wt), ref in zip(out, refs):
         assert torch.equal(wf.cpu(), ref)
         assert torch.equal(wt.cpu(), ref.permute(2, 1, 0))
+    # the optional third output: conv8.hip's staging image, [O/64][Cpad/32][unit id][8 channels] with the unit of
+    # (row = tap * 64 + o % 64, plane = (c % 32) / 8) at (row >> 3) * 32 + plane * 8 + (row & 7) -- same values as wf
+    out8 = nat.conv_weight_bank(entries, dtype, image8=[True] * len(entries))
+    have = [w8 is not None for _, _, w8 in out8]
+    assert have == [dtype == torch.bfloat16 and k == 3 and O % 64 == 0 and cp % 32 == 0 and cp >= 64 for O, C, k, cp in shapes]
+    for (wf, wt, w8), ref, (O, C, k, cp) in zip(out8, refs, shapes):
+        assert torch.equal(wf.cpu(), ref) and torch.equal(wt.cpu(), ref.permute(2, 1, 0))
+        if w8 is not None:
+            img = w8.cpu().view(O // 64, cp // 32, 576 * 4, 8)
+            row, plane = torch.meshgrid(torch.arange(576), torch.arange(4), indexing="ij")
+            unit = (row >> 3) * 32 + plane * 8 + (row & 7)
+            want = ref.view(O // 64, 64, 9, cp // 32, 4, 8).permute(0, 3, 2, 1, 4, 5).reshape(O // 64, cp // 32, 576, 4, 8)
+            assert torch.equal(img[:, :, unit.reshape(-1)].view(O // 64, cp // 32, 576, 4, 8), want)
 
 
 # ---------------------------------------------------------------------------------------

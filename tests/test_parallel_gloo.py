@@ -66,8 +66,33 @@ def _worker(rank, world, tmp, q):
     A.cumulate(torch.ones(4, 1))
     A.update_p()  # rt = 1 on both -> p += 8 / 1000
 
+    # round 4: rank 0's buffers ride behind the gradients (carry_buffers) ...
+    sync2 = parallel.FlatGradSync(G, carry_buffers=True)
+    assert sync2.carries_buffers() and sync2.flat.numel() == sync.flat.numel()
+    sync2.begin()
+    for p in params:
+        p.grad = torch.full_like(p, float(rank + 1))
+    sync2.collect()
+    with torch.no_grad():
+        for i, b in enumerate(parallel.mutable_buffers(G)):
+            b.fill_(3.25 * (i + 1) + 100 * rank)
+    h = sync2.all_reduce(async_op=True, carry=True)
+    sync2.wait(h)
+    carried = (float(sync2.flat[0]), float(sync2.flat[-1]),
+               [float(b.flatten()[0]) for b in parallel.mutable_buffers(G)][:3])
+    # ... and in the iteration's tail exchange, with the scalars and ADA's statistics
+    with torch.no_grad():
+        for i, b in enumerate(parallel.mutable_buffers(G)):
+            b.fill_(7.5 * (i + 1) - 50 * rank)
+    A2 = AdaptiveAugment(p_init=0.0, p_target=0.6, kimg=1)
+    A2.cumulate(torch.ones(6, 1) if rank == 0 else -torch.ones(6, 1))
+    sc2, ada = parallel.tail_exchange({"a": torch.tensor(float(rank)), "b": torch.tensor(4.0)}, A2.stats(), G)
+    rt2 = float(A2.update_p(stats=ada))
+    tail = ({k: float(v) for k, v in sc2.items()}, [float(v) for v in ada], rt2,
+            [float(b.flatten()[0]) for b in parallel.mutable_buffers(G)][:3])
+
     q.put((rank, w0.sum().item(), local_only, averaged, bufs, {k: float(v) for k, v in sc.items()}, rt, float(A.p),
-           packed))
+           packed, carried, tail))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,6 +117,8 @@ def test_two_rank_data_parallel_plumbing():
     assert r0[5] == r1[5] == {"a": 0.5, "b": 2.0}
     assert r0[6] == r1[6] == 0.0 and r0[7] == r1[7] == pytest.approx(8 / 1000)
     assert r0[8] == r1[8] == (15.0, 0.0, 15.0)              # begin/collect: mean of (10, 20); untouched slice zeroed
+    assert r0[9] == r1[9] == (1.5, 1.5, [3.25, 6.5, 9.75])  # gradients averaged, rank 0's buffers (exactly) everywhere
+    assert r0[10] == r1[10] == ({"a": 0.5, "b": 4.0}, [0.0, 12.0], 0.0, [7.5, 15.0, 22.5])
 
 
 def _worker_segments(rank, world, tmp, q):
