@@ -56,12 +56,13 @@ __device__ __forceinline__ int pack_pair_bf16(const float (&va)[4], const float 
     pa.e[r] = (bf16_t)va[r];
     pb.e[r] = (bf16_t)vb[r];
   }
+  // v_permlane16_swap(a, b): the odd 16-lane rows of a trade places with the even rows of b -- exactly this exchange
+  // (row = lc), with no LDS round trip (the __shfl_xor form was two ds_bpermute + selects per pair, serialised on the
+  // LDS latency: a quarter of the epilogue of the 16-fragment data-gradient tiles)
+  const auto lo = __builtin_amdgcn_permlane16_swap(pa.u.x, pb.u.x, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(pa.u.y, pb.u.y, false, false);
+  out = make_uint4(lo[0], hi[0], lo[1], hi[1]);
   const bool odd = lc & 1;
-  const uint2 send = odd ? pa.u : pb.u;
-  uint2 recv;
-  recv.x = __shfl_xor((int)send.x, 16, 64);
-  recv.y = __shfl_xor((int)send.y, 16, 64);
-  out = odd ? make_uint4(recv.x, recv.y, pb.u.x, pb.u.y) : make_uint4(pa.u.x, pa.u.y, recv.x, recv.y);
   return odd ? 16 + 4 * (lc - 1) : 4 * lc;
 }
 

@@ -64,10 +64,19 @@ struct C8Cfg {
   static constexpr size_t LDS = sizeof(uint4) * 4 * ((size_t)GN * PIN + (size_t)GM * PW);
 };
 
-template <typename T, typename TY, int S, int GM, int GN, int RW>
+// HZ: the stride-1 DATA GRADIENT of the same conv (x = gy, w = the transposed weights in the launch's tap order): rows
+// outside the image are ZERO, not clamped -- they are staged as whatever the clamped address holds, because every tap that
+// would read them is a dead tap of that output row and is skipped (wave-uniform branch around in-place MFMAs) -- and
+// the replicate-padding term of a border row (output row 0 sees its own gy row once more through the weights of the
+// tap mirrored in dy, likewise the last row) is issued next to that mirrored tap's MFMAs: weights already in
+// registers, one more pixel-fragment read (conv_pipe_kernel's F33 = 2 form).
+// WIMG: w is the staging image (C8::wimg); a template parameter because the two addressing forms together cost the
+// 256-register instances five spilled dwords
+template <typename T, typename TY, int S, int GM, int GN, int RW, int HZ, bool WIMG>
 __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict__ y, const T* __restrict__ x,
                                                                  const T* __restrict__ w, C8 p) {
   using Cf = C8Cfg<T, TY, S, GM, GN, RW>;
+  static_assert(HZ == 0 || S == 1, "data gradient: stride 1");
   constexpr int UI = Cf::UI, UW = Cf::UW, CE = Cf::CE, TH = Cf::TH, MF = Cf::MF, NF = Cf::NF;
   constexpr int ICOLS = Cf::ICOLS, NPIX = Cf::NPIX, PITCH = Cf::PITCH, LIVE = Cf::LIVE;
   constexpr int NI = Cf::NI, PIN = Cf::PIN, PW = Cf::PW, TS = Cf::TS, NW = Cf::NW;
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
   };
   // weight slot j = tap t0 + TS * j of output row o0 + (w_row0 & 63): a uniform tap pointer + this lane offset
   const int t0 = w_row0 >> 6;
-  const unsigned wlane = (unsigned)(((o0 + (w_row0 & 63)) * p.wtaps + t0 * p.wstep) * p.Cin + w_plane * CE);
+  [[maybe_unused]] const unsigned wlane = (unsigned)(((o0 + (w_row0 & 63)) * p.wtaps + t0 * p.wstep) * p.Cin + w_plane * CE);
 
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   u32x4 rin[NI], rwt[NW];
@@ -150,18 +159,18 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
   };
   auto issue_w = [&](int c0) {
     if (C8_ABL & 8) return;
-    if (p.wimg) {
+    if constexpr (WIMG) {
       const u32x4* img = reinterpret_cast<const u32x4*>(w) + ((size_t)(o0 >> 6) * nchunks + c0 / kchunk) * (PW * 4) + uw;
 #pragma unroll
       for (int j = 0; j < NW; ++j)
         if (TS * (NW - 1) + (TS - 1) < 9 || t0 + TS * j < 9) rwt[j] = img[UW * j];
-      return;
-    }
+    } else {
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int t = t0 + TS * j;
-      const T* wu = w + (p.widx0 + TS * j * p.wstep) * p.Cin + c0;
-      if (TS * (NW - 1) + (TS - 1) < 9 || t < 9) rwt[j] = *reinterpret_cast<const u32x4*>(wu + wlane);
+      for (int j = 0; j < NW; ++j) {
+        const int t = t0 + TS * j;
+        const T* wu = w + (p.widx0 + TS * j * p.wstep) * p.Cin + c0;
+        if (TS * (NW - 1) + (TS - 1) < 9 || t < 9) rwt[j] = *reinterpret_cast<const u32x4*>(wu + wlane);
+      }
     }
   };
   uint4* const st_in = lds_in + in_plane * PIN;
@@ -182,6 +191,21 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
   if (t256 < 64) s_bias[gm * 64 + t256] = p.bias ? p.bias[o0 + t256] : 0.f;   // (GN = 2: both groups write the same values)
   const uint4* const a_base = lds_w + lc * PW + lr;
   const uint4* const b_base = lds_in + lc * PIN;
+
+  // HZ: taps that read only the zero rows above / below the image for this wave's output rows (tap t = (dy + 1) * 3 + dx + 1)
+  unsigned dead[RW];
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+    dead[rr] = 0u;
+    if constexpr (HZ != 0) {
+      const int orow = h0 + wave4 * RW + rr;
+      unsigned m = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if ((unsigned)(orow + t / 3 - 1) >= (unsigned)p.Hin) m |= 1u << t;
+      dead[rr] = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    }
+  }
 
   tile_offsets(st0);
   issue_in(0);
@@ -213,6 +237,16 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
       // tap t+1 as soon as its MFMAs of tap t are issued, the weight fragments alternate between two sets
       constexpr int APG = MF / NF;
       uint4 a[2][MF], bb[NF];
+      unsigned dd[RW];
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        dd[rr] = 0u;
+        if constexpr (HZ != 0) {
+          dd[rr] = dead[rr];
+          // the bit tests stay in the loop: hoisted, their results live in SGPR pairs that spill (conv_direct.hip)
+          asm volatile("" : "+s"(dd[rr]));
+        }
+      }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) a[0][mf] = a_base[mf * 16];
 #pragma unroll
@@ -222,8 +256,28 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
           __builtin_amdgcn_sched_barrier(0);
+          if (!(HZ && ((dd[nf >> 1] >> t) & 1u))) {
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[mf][nf], a[t & 1][mf], bb[nf]);
+            for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[mf][nf], a[t & 1][mf], bb[nf]);
+          }
+          if constexpr (HZ != 0) {
+            // replicate-row border term: this group's row has its MIRRORED tap dead (t - 6 at the first row, t + 6 at
+            // the last): that tap's operand would be the clamped copy of the border row, i.e. the pixel fragment of tap
+            // (dy = 0, dx), through the weights in registers right now
+            if (t < 3 || t >= 6) {
+              const int tm = t < 3 ? t + 6 : t - 6;
+              if ((dd[nf >> 1] >> tm) & 1u) {
+                const uint4 bx = b_base[bpix[nf] + ICOLS + t % 3];
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[mf][nf], a[t & 1][mf], bx);
+              }
+            }
+            // The branches of this variant put compiler-generated VALU instructions (v_cndmask of the next group's
+            // condition) right behind a group's last MFMA -- into a register that MFMA is still reading as its B operand
+            // (found by scripts/audit_asm_mfma.py; the hazard recogniser does not see inside the asm).  Five wait states
+            // cover a 4-pass MFMA's source reads.
+            asm volatile("s_nop 4");
+          }
           __builtin_amdgcn_sched_barrier(0);
           if (t + 1 < 9) {
             const int ky = (t + 1) / 3, kx = (t + 1) % 3;
@@ -289,8 +343,8 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
   }
 }
 
-template <typename T, typename TY, int S, int GM, int GN, int RW>
-int launch8(void* y, const void* x, const void* w, C8 p, hipStream_t st) {
+template <typename T, typename TY, int S, int GM, int GN, int RW, int HZ, bool WIMG>
+int launch8w(void* y, const void* x, const void* w, C8 p, hipStream_t st) {
   using Cf = C8Cfg<T, TY, S, GM, GN, RW>;
   constexpr int TH = Cf::TH;
   static_assert(Cf::LDS <= 160 * 1024 - 1024, "LDS image");
@@ -298,7 +352,7 @@ int launch8(void* y, const void* x, const void* w, C8 p, hipStream_t st) {
   const int nsup = (tiles_w + GN - 1) / GN;
   // ring wrap of the kernel: -1 <= gw < 3 * Win
   if ((nsup * GN * 32 - 1) * S + 2 >= 3 * p.Win) return -2;
-  auto kern = conv8_kernel<T, TY, S, GM, GN, RW>;
+  auto kern = conv8_kernel<T, TY, S, GM, GN, RW, HZ, WIMG>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::LDS);
@@ -326,6 +380,16 @@ int launch8(void* y, const void* x, const void* w, C8 p, hipStream_t st) {
   return 0;
 }
 
+template <typename T, typename TY, int S, int GM, int GN, int RW, int HZ = 0>
+int launch8(void* y, const void* x, const void* w, C8 p, hipStream_t st) {
+  if (p.wimg) {
+    if constexpr (sizeof(T) == 2) return launch8w<T, TY, S, GM, GN, RW, HZ, true>(y, x, w, p, st);
+    else return -2;   // no e4m3 image yet
+  }
+  if constexpr (HZ != 0) return -2;   // the data gradient is reached through dgv2_conv3x3_dgrad8 (image) only
+  else return launch8w<T, TY, S, GM, GN, RW, HZ, false>(y, x, w, p, st);
+}
+
 }  // namespace
 
 // Called by conv_direct.hip's dispatcher for single-class launches whose taps are the full 3x3 grid in order (f33),
@@ -333,9 +397,9 @@ int launch8(void* y, const void* x, const void* w, C8 p, hipStream_t st) {
 // cover the geometry (the caller goes on to conv_pipe_kernel).  dtype: DGV2_BF16 or DGV2_FP8 (y bf16 either way).
 int dgv2_conv8_try(void* y, int ldy, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg, int Wg, int O,
                    int in_stride, int wtaps, int widx0, int wstep, const float* bias, const float* acc_scale,
-                   const void* resid, int act, float alpha, float scale, int dtype, hipStream_t st, int wimg) {
+                   const void* resid, int act, float alpha, float scale, int dtype, hipStream_t st, int wimg, int hzero) {
   static const bool off = getenv("DGV2_NO_CONV8") != nullptr;                 // A/B switch for benchmarking
-  static const char* s1env = getenv("DGV2_CONV8_S1");                        // "gn" (default), "gm", "off"
+  static const char* s1env = getenv("DGV2_CONV8_S1");                        // experiments: "gn", "gm", "off"
   if (off || O % 64 || Wg < 32 || Hg < 4) return -2;
   const int kstep = dtype == DGV2_FP8 ? 64 : 32;
   if (Cin % kstep || Cin < 2 * kstep) return -2;                             // the prologue amortises over >= 2 K-chunks
@@ -351,13 +415,21 @@ int dgv2_conv8_try(void* y, int ldy, const void* x, const void* w, int B, int Hi
   int rc = -2;
 #define C8_GO(TT, S_, GM_, GN_, RW_) rc = launch8<TT, bf16_t, S_, GM_, GN_, RW_>(y, x, w, p, st)
   if (in_stride == 2) {
-    if (Hin != 2 * Hg || Win != 2 * Wg || O % 128) return -2;
+    if (Hin != 2 * Hg || Win != 2 * Wg || O % 128 || hzero) return -2;
     if (dtype == DGV2_BF16) { if (Hg >= 8) C8_GO(bf16_t, 2, 2, 1, 2); else C8_GO(bf16_t, 2, 2, 1, 1); }
     else { if (Hg >= 8) C8_GO(fp8_t, 2, 2, 1, 2); else C8_GO(fp8_t, 2, 2, 1, 1); }
+  } else if (in_stride == 1 && hzero) {
+    // the stride-1 data gradient (the caller has checked the canonical form: taps (dy, dx) in order, weight slots affine,
+    // the six replicate-row extras): a border row may not be its own mirror (H >= 2 holds: Hg >= 8)
+    if (Hin != Hg || Win != Wg || Hg < 8 || dtype != DGV2_BF16) return -2;
+    if (O % 128 == 0) rc = launch8<bf16_t, bf16_t, 1, 2, 1, 2, 1>(y, x, w, p, st);
+    else if (Wg >= 64) rc = launch8<bf16_t, bf16_t, 1, 1, 2, 2, 1>(y, x, w, p, st);
   } else if (in_stride == 1) {
     if (Hin != Hg || Win != Wg || Hg < 8 || dtype != DGV2_BF16) return -2;
-    const bool want_gm = s1env && !strcmp(s1env, "gm");
+    // two channel slabs per halo tile where the layer has them (measured: 16x128 128->128 85.9 vs 88.8 us, 8x64 256->256
+    // 76.0 vs 80.9, profiles/round4_mb_conv8.txt), two pixel tiles per weight slab otherwise (O = 64)
     if (s1env && !strcmp(s1env, "off")) return -2;
+    const bool want_gm = s1env ? !strcmp(s1env, "gm") : (O % 128 == 0);
     if (want_gm) { if (O % 128) return -2; C8_GO(bf16_t, 1, 2, 1, 2); }
     else { if (Wg < 64) return -2; C8_GO(bf16_t, 1, 1, 2, 2); }
   }
@@ -377,7 +449,23 @@ extern "C" int dgv2_conv3x3_fwd8(void* y, const void* x, const void* w8, int B, 
   if (dtype != DGV2_BF16) return DGV2_ENOTSUP;
   if (Hin % stride || Win % stride) return DGV2_ENOTSUP;
   const int rc = dgv2_conv8_try(y, O, x, w8, B, Hin, Win, Cin, Hin / stride, Win / stride, O, stride, 9, 0, 1, bias, nullptr,
-                                resid, act, alpha, scale, dtype, (hipStream_t)stream, 1);
+                                resid, act, alpha, scale, dtype, (hipStream_t)stream, 1, 0);
+  if (rc == -2) return DGV2_ENOTSUP;
+  if (rc) return rc;
+  DGV2_RETURN_LAST();
+}
+
+// The stride-1 data gradient of the same 3x3 ring conv on the TRANSPOSED staging image (w8t of dgv2_conv_weight_bank_ex):
+//   gx [B, H, W, C] (bf16) = sum_{ky,kx,o} gy[B, Hz(h + 1 - ky), wrap(w + 1 - kx), o] * w[o, ky, kx, c]
+//                            + the replicate-row terms of rows 0 and H - 1  (+ resid: the gradient of a sibling branch).
+// DGV2_ENOTSUP where the engine does not cover the geometry (callers then run dgv2_conv_taps_ex on wt).
+extern "C" int dgv2_conv3x3_dgrad8(void* gx, const void* gy, const void* w8t, int B, int H, int W, int C, int O,
+                                   const void* resid, int dtype, void* stream) {
+  if (!gx || !gy || !w8t || B < 1 || H < 1 || W < 1 || C < 1 || O < 1) return DGV2_EINVAL;
+  if (dtype != DGV2_BF16) return DGV2_ENOTSUP;
+  // the launch contracts over the conv's OUTPUT channels (its K) and produces the conv's INPUT channels
+  const int rc = dgv2_conv8_try(gx, C, gy, w8t, B, H, W, O, H, W, C, 1, 9, 0, 1, nullptr, nullptr, resid, 0, 0.2f, 1.f, dtype,
+                                (hipStream_t)stream, 1, 1);
   if (rc == -2) return DGV2_ENOTSUP;
   if (rc) return rc;
   DGV2_RETURN_LAST();

@@ -496,6 +496,9 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
       // fast path (block-uniform): full channel tile, plain overwrite -- straight-line bias / lrelu / convert and,
       // for bf16, fragment pairs leaving as 16-byte stores; everything else takes the general store_frag
       const bool fast = !p.accumulate && o0 + TO <= p.O && (p.O & 7) == 0;
+      // data gradients have no bias, no activation and no accumulator scale: their (output-heavy: K is one or two chunks
+      // per tile) epilogue then is convert + exchange + store, without the LDS bias reads and four fma / max per value
+      const bool plain = !p.bias && !p.acc_scale && p.act != 3;
       const TY* rbase = reinterpret_cast<const TY*>(p.resid);   // optional residual, same layout as y
       // pixel fragment outermost: its 64-bit row address is formed once, the classes add (ooh * Wy + oow) * ldy
 #pragma unroll
@@ -512,6 +515,11 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
             float f[MF][4];
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
+              if (plain) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[mf][r] = acc[c][mf][nf][r];
+                continue;
+              }
               const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[mf * 16 + lc * 4]);
               const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -764,7 +772,7 @@ int dgv2_conv_strip_try(void* y, const void* x, const void* w, int B, int H, int
 // weight slab); -2 = not covered
 int dgv2_conv8_try(void* y, int ldy, const void* x, const void* w, int B, int Hin, int Win, int Cin, int Hg, int Wg, int O,
                    int in_stride, int wtaps, int widx0, int wstep, const float* bias, const float* acc_scale,
-                   const void* resid, int act, float alpha, float scale, int dtype, hipStream_t st, int wimg);
+                   const void* resid, int act, float alpha, float scale, int dtype, hipStream_t st, int wimg, int hzero);
 
 namespace {
 
@@ -961,7 +969,7 @@ static int conv_taps_impl(void* y, int ldy, const void* x, const void* w, int B,
       Hy == Hg && Wy == Wg) {
     // forward 3x3 convs from 64 channels up: the eight-wave engine (conv8.hip) where it covers the geometry
     rc = dgv2_conv8_try(y, ldy, x, w, B, Hin, Win, Cin, Hg, Wg, O, in_stride, wtaps, p.widx[0], p.widx[1] - p.widx[0], bias,
-                        acc_scale, resid, act, alpha, scale, dtype, st, 0);
+                        acc_scale, resid, act, alpha, scale, dtype, st, 0, 0);
     if (rc != -2) {
       if (rc) return rc;
       DGV2_RETURN_LAST();

@@ -18,6 +18,7 @@ struct BankArgs {
   void* wf[WB_MAX];
   void* wt[WB_MAX];
   void* w8[WB_MAX];   // optional (3x3, O % 64 == 0, Cpad % 32 == 0, 2-byte T): conv8.hip's staging image, else nullptr
+  void* w8t[WB_MAX];  // optional (3x3, Cpad % 64 == 0, O % 32 == 0): the image of the data gradient's operand, else nullptr
   int O[WB_MAX], C[WB_MAX], Cpad[WB_MAX], kk[WB_MAX];
   float scale[WB_MAX];
 };
@@ -106,6 +107,21 @@ __global__ __launch_bounds__(256) void weight_bank_tiled_kernel(BankArgs a) {
       }
     }
   }
+  if (KK == 9 && sizeof(T) == 2 && a.w8t[l]) {
+    // the data gradient contracts over o and produces c: slab = c / 64, chunk = o / 32, row = t' * 64 + c % 64 with the
+    // kernel's tap order t' = (dy + 1) * 3 + dx + 1, dy = 1 - ky: t' = 8 - (ky * 3 + kx); plane = (o % 32) / 8
+    T* w8t = reinterpret_cast<T*>(a.w8t[l]);
+    const int nchunks = O / 32;
+    for (int g = threadIdx.x; g < WB_TO * run; g += 256) {
+      const int o = g % WB_TO, r = g / WB_TO;
+      const int t = r % kk, c = r / kk;
+      if (o0 + o < O && c0 + c < Cp) {
+        const int og = o0 + o, cg = c0 + c, row = (8 - t) * 64 + (cg & 63), plane = (og & 31) >> 3;
+        const size_t unit = ((size_t)(cg >> 6) * nchunks + (og >> 5)) * (576 * 4) + (row >> 3) * 32 + plane * 8 + (row & 7);
+        w8t[unit * 8 + (og & 7)] = from_f32<T>(tile[o][c * kk + t]);
+      }
+    }
+  }
   for (int g = threadIdx.x; g < WB_TO * run; g += 256) {   // transposed layout: runs of 64 output channels
     const int o = g % WB_TO, r = g / WB_TO;
     const int t = r % kk, c = r / kk;
@@ -116,27 +132,31 @@ __global__ __launch_bounds__(256) void weight_bank_tiled_kernel(BankArgs a) {
 }  // namespace
 
 // src / wf / wt: HOST arrays of L <= 32 device pointers; O, C, Cpad, kk (= kh*kw), scale: HOST arrays.
-extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, const float* const* src,
-                                        const int* O, const int* C, const int* Cpad, const int* kk, const float* scale, int L,
-                                        int dtype, void* stream);
+extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, void* const* w8t,
+                                        const float* const* src, const int* O, const int* C, const int* Cpad, const int* kk,
+                                        const float* scale, int L, int dtype, void* stream);
 
 extern "C" int dgv2_conv_weight_bank(void* const* wf, void* const* wt, const float* const* src, const int* O,
                                      const int* C, const int* Cpad, const int* kk, const float* scale, int L,
                                      int dtype, void* stream) {
-  return dgv2_conv_weight_bank_ex(wf, wt, nullptr, src, O, C, Cpad, kk, scale, L, dtype, stream);
+  return dgv2_conv_weight_bank_ex(wf, wt, nullptr, nullptr, src, O, C, Cpad, kk, scale, L, dtype, stream);
 }
 
-// ... with a third, optional output per layer: w8[l] != nullptr asks for the staging image of the eight-wave forward
+// ... with two more, optional outputs per layer: w8[l] != nullptr asks for the staging image of the eight-wave forward
 // conv (conv8.hip, dgv2_conv3x3_fwd8): [O / 64][Cpad / 32][2304 units of 16 bytes in the kernel's slot order], the same
-// values as wf.  Needs kk == 9, O % 64 == 0, Cpad % 32 == 0, bf16 (DGV2_EINVAL otherwise); w8 itself may be nullptr.
-extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, const float* const* src,
-                                        const int* O, const int* C, const int* Cpad, const int* kk, const float* scale, int L,
-                                        int dtype, void* stream) {
+// values as wf (needs kk == 9, O % 64 == 0, Cpad % 32 == 0, bf16); w8t[l] != nullptr for the image of its stride-1 data
+// gradient (dgv2_conv3x3_dgrad8): [Cpad / 64][O / 32][2304 units], taps in the gradient's order (needs kk == 9,
+// Cpad % 64 == 0, O % 32 == 0, bf16).  DGV2_EINVAL otherwise; the arrays themselves may be nullptr.
+extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, void* const* w8t,
+                                        const float* const* src, const int* O, const int* C, const int* Cpad, const int* kk,
+                                        const float* scale, int L, int dtype, void* stream) {
   if (!wf || !wt || !src || !O || !C || !Cpad || !kk || !scale || L < 1 || L > WB_MAX) return DGV2_EINVAL;
   BankArgs a;
   for (int l = 0; l < L; ++l) {
     a.w8[l] = w8 ? w8[l] : nullptr;
+    a.w8t[l] = w8t ? w8t[l] : nullptr;
     if (a.w8[l] && (kk[l] != 9 || O[l] % 64 || Cpad[l] % 32 || dtype != DGV2_BF16)) return DGV2_EINVAL;
+    if (a.w8t[l] && (kk[l] != 9 || Cpad[l] % 64 || O[l] % 32 || dtype != DGV2_BF16)) return DGV2_EINVAL;
   }
   int nmax = 0, tmax = 0, kmax = 0;
   for (int l = 0; l < L; ++l) {
@@ -162,7 +182,7 @@ extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* 
     }
     if (other)
       for (int l = 0; l < L; ++l)
-        if (a.w8[l]) return DGV2_ENOTSUP;   // the image comes from the 9-tap instance only
+        if (a.w8[l] || a.w8t[l]) return DGV2_ENOTSUP;   // the images come from the 9-tap instance only
     DGV2_DISPATCH_DTYPE(dtype, {
       if (other) {
         weight_bank_tiled_kernel<T, 0><<<tgrid, 256, 0, st>>>(a);
@@ -174,7 +194,7 @@ extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* 
     DGV2_RETURN_LAST();
   }
   for (int l = 0; l < L; ++l)
-    if (a.w8[l]) return DGV2_ENOTSUP;   // the image is written by the tiled kernel only
+    if (a.w8[l] || a.w8t[l]) return DGV2_ENOTSUP;   // the images are written by the tiled kernel only
   dim3 grid(grid_for(nmax, 256, 256), L);
   DGV2_DISPATCH_DTYPE(dtype, { weight_bank_kernel<T><<<grid, 256, 0, st>>>(a); });
   DGV2_RETURN_LAST();

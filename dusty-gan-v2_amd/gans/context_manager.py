@@ -1,6 +1,7 @@
 """Gradient-accumulation helper (reference: gans/context_manager.py:21-35): every micro-step but the
 last runs with gradient exchange suppressed.  Works with torch DDP (`no_sync`) and with this
-repo's FlatGradSync (gans/parallel.py) which exposes the same `no_sync` context."""
+repo's FlatGradSync (gans/parallel.py) which exposes the same `no_sync` context; Trainer.step drives its
+chunk loops through it."""
 from contextlib import ExitStack, contextmanager
 
 

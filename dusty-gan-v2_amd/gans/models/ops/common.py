@@ -182,7 +182,8 @@ class Conv2d(nn.Sequential):
                 else:
                     w = native.scaled_handle(p_raw, s_used, cpad_used)
                 w._dgv2_wf, w._dgv2_wt = ent[2], ent[3]
-                w._dgv2_w8 = ent[4] if len(ent) > 4 else None   # conv8.hip's staging image of the same values
+                w._dgv2_w8 = ent[4] if len(ent) > 4 else None   # conv8.hip's staging images of the same values
+                w._dgv2_w8t = ent[5] if len(ent) > 5 else None
                 b, gain = self._params_bias()
             else:
                 ent = None

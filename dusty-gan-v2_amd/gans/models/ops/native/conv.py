@@ -110,6 +110,16 @@ def _axis_taps_s2(parity):
     return [(0, 1)] if parity == 0 else [(1, 0), (0, 2)]
 
 
+def _conv_dgrad8(gy, w8t, xshape, resid):
+    """The stride-1 3x3 ring data gradient on the bank's transposed staging image (dgv2_conv3x3_dgrad8); None where the
+    eight-wave engine does not cover the shape."""
+    B, H, W, C = xshape
+    gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
+    ok = N.try_call("dgv2_conv3x3_dgrad8", N.ptr(gx), N.ptr(gy), N.ptr(w8t), B, H, W, C, gy.shape[3], N.ptr(resid), _dt(gy),
+                    N.stream())
+    return gx if ok else None
+
+
 def _conv_dgrad_direct(gy, wt3, g, xshape, resid=None):
     """Data gradient on the direct engine: gy [B,Ho,Wo,O], wt3 [C,kh*kw,O] -> gx [B,H,W,C] (+ resid, the gradient
     of a sibling branch of the same input, added in the epilogue of the one-launch stride-1 path).
@@ -171,10 +181,17 @@ def _conv_dgrad_direct(gy, wt3, g, xshape, resid=None):
     return gx
 
 
-def _conv_dgrad_raw(gy, w, g, xshape, wt=None, resid=None):
-    """w [O,kh,kw,C] in gy's dtype, or wt = the prepared transposed weights [C, kh*kw, O] (weight bank)."""
+def _conv_dgrad_raw(gy, w, g, xshape, wt=None, resid=None, w8t=None):
+    """w [O,kh,kw,C] in gy's dtype, or wt = the prepared transposed weights [C, kh*kw, O] (weight bank); w8t: the
+    bank's staging image of the same transposed weights for the eight-wave engine."""
     B, H, W, C = xshape
     O = gy.shape[3]
+    if (w8t is not None and _CONV8_IMG and gy.dtype == torch.bfloat16 and g.ring and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1)
+            and w8t.dtype == gy.dtype):
+        N.check(gy, w8t, resid)
+        gx = _conv_dgrad8(gy, w8t, xshape, resid)
+        if gx is not None:
+            return gx
     if wt is None:   # cached on the values tensor (see modgemm._values): first and second pass of R1 share it
         c = getattr(w, "_dgv2_wt", None)
         if c is not None and c[0] == w._version:
@@ -281,6 +298,7 @@ class _ConvFwd(Function):
         ctx.set_materialize_grads(False)   # an absent cotangent stays absent (see _ConvAct)
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
+        ctx.w8t = getattr(w, "_dgv2_w8t", None) if ctx.wt is not None else None
         ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
@@ -293,13 +311,13 @@ class _ConvFwd(Function):
         if gy is None:
             return None, None, None
         x, w = ctx.saved_tensors
-        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if want_param_grad(ctx, 1) else None
         return gx, gw, None
 
 
-def _dgrad(gy, w, g, xshape, wt=None, resid=None, gscale=None):
-    return _ConvDgrad.apply(gy, w, g, xshape, wt, resid, gscale)
+def _dgrad(gy, w, g, xshape, wt=None, resid=None, gscale=None, w8t=None):
+    return _ConvDgrad.apply(gy, w, g, xshape, wt, resid, gscale, w8t)
 
 
 class _ConvDgrad(Function):
@@ -307,7 +325,7 @@ class _ConvDgrad(Function):
     the kernel's epilogue instead of by a separate elementwise add over the activation."""
 
     @staticmethod
-    def forward(ctx, gy, w, g, xshape, wt, resid, gscale=None):
+    def forward(ctx, gy, w, g, xshape, wt, resid, gscale=None, w8t=None):
         """gscale: `w` is a plain view of the parameter whose VALUE the kernels take from the weight bank as
         gscale * parameter; gradients that flow to `w` carry that factor explicitly."""
         gy = gy.contiguous()
@@ -316,7 +334,7 @@ class _ConvDgrad(Function):
         if resid is not None:
             resid = resid.contiguous().to(gy.dtype)
         if wt is not None and wt.dtype == gy.dtype:
-            return _conv_dgrad_raw(gy, None, g, xshape, wt=wt, resid=resid)
+            return _conv_dgrad_raw(gy, None, g, xshape, wt=wt, resid=resid, w8t=w8t)
         wc = _values(w, gy.dtype)
         return _conv_dgrad_raw(gy, wc, g, xshape, resid=resid)
 
@@ -325,7 +343,7 @@ class _ConvDgrad(Function):
         gy, w = ctx.saved_tensors
         g_gy = _ConvFwd.apply(ggx, w, ctx.g) if ctx.needs_input_grad[0] else None
         g_w = _ConvWgrad.apply(gy, ggx, ctx.g, ctx.gscale) if ctx.needs_input_grad[1] else None
-        return g_gy, g_w, None, None, None, (ggx if ctx.needs_input_grad[5] else None), None
+        return g_gy, g_w, None, None, None, (ggx if ctx.needs_input_grad[5] else None), None, None
 
 
 class _ConvWgrad(Function):
@@ -365,6 +383,7 @@ class _ConvAct(Function):
         ctx.set_materialize_grads(False)
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
+        ctx.w8t = getattr(w, "_dgv2_w8t", None) if ctx.wt is not None else None
         ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
@@ -380,7 +399,7 @@ class _ConvAct(Function):
         x, w, out = ctx.saved_tensors
         g, alpha, scale, size_b = ctx.cfg
         gpre, gb = _BiasActBackward.apply(gy, out, want_param_grad(ctx, 2), alpha, scale, 1, size_b)
-        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if want_param_grad(ctx, 1) else None
         return gx, gw, gb, None, None, None
 
@@ -643,6 +662,12 @@ def scaled_handle(param, scale, cpad=0):
     return h
 
 
+def conv8t_image_ok(p, cpad, dtype):
+    """... and the image of its stride-1 data gradient (dgv2_conv3x3_dgrad8)."""
+    return (dtype == torch.bfloat16 and tuple(p.shape[2:]) == (3, 3) and cpad % 64 == 0 and p.shape[0] % 32 == 0
+            and p.shape[0] >= 64)
+
+
 def conv8_image_ok(p, cpad, dtype):
     """Whether conv_weight_bank can also write conv8.hip's staging image for this layer (3x3, whole 64-channel slabs,
     whole 32-channel K-chunks, at least two of them, bf16)."""
@@ -653,8 +678,8 @@ def conv8_image_ok(p, cpad, dtype):
 def conv_weight_bank(entries, dtype, image8=None):
     """entries: list of (param fp32 [O,C,kh,kw], scale, Cpad).  One launch; returns [(wf [O,kh*kw,Cpad], wt
     [Cpad,kh*kw,O])] in `dtype` (views of two flat buffers).  image8: list of bools -- also write the staging image of
-    the eight-wave forward conv for those layers (dgv2_conv_weight_bank_ex); the result tuples then carry it (or None)
-    as a third element."""
+    the eight-wave forward conv (and of its stride-1 data gradient) for those layers (dgv2_conv_weight_bank_ex); the
+    result tuples then are (wf, wt, w8 or None, w8t or None)."""
     if image8 is not None:
         return _conv_weight_bank8(entries, dtype, image8)
     L = len(entries)
@@ -683,22 +708,28 @@ def _conv_weight_bank8(entries, dtype, image8):
     sizes = [o * kk * cp for o, _, cp, kk in dims]
     flat_f = torch.empty(sum(sizes), device=dev, dtype=dtype)
     flat_t = torch.empty(sum(sizes), device=dev, dtype=dtype)
+    # image8 entries: True = both images where the shape allows, "fwd" = only the forward one (stride-2 convs have no
+    # stride-1 data gradient)
     want = [bool(f) and conv8_image_ok(p, cp, dtype) for f, (p, _, cp) in zip(image8, entries)]
+    want_t = [f is True and conv8t_image_ok(p, cp, dtype) for f, (p, _, cp) in zip(image8, entries)]
     flat_8 = torch.empty(sum(n for n, f in zip(sizes, want) if f), device=dev, dtype=dtype) if any(want) else None
-    wfs, wts, w8s, off, off8 = [], [], [], 0, 0
-    for (o, c, cp, kk), n, f in zip(dims, sizes, want):
+    flat_8t = torch.empty(sum(n for n, f in zip(sizes, want_t) if f), device=dev, dtype=dtype) if any(want_t) else None
+    wfs, wts, w8s, w8ts, off, off8, off8t = [], [], [], [], 0, 0, 0
+    for (o, c, cp, kk), n, f, ft in zip(dims, sizes, want, want_t):
         wfs.append(flat_f[off:off + n].view(o, kk, cp))
         wts.append(flat_t[off:off + n].view(cp, kk, o))
         w8s.append(flat_8[off8:off8 + n] if f else None)
+        w8ts.append(flat_8t[off8t:off8t + n] if ft else None)
         off += n
         off8 += n if f else 0
+        off8t += n if ft else 0
     srcs = [p.detach() for p, _, _ in entries]
     N.check(*srcs)
-    N.call("dgv2_conv_weight_bank_ex", _ptr_array(wfs), _ptr_array(wts), _ptr_array(w8s), _ptr_array(srcs),
+    N.call("dgv2_conv_weight_bank_ex", _ptr_array(wfs), _ptr_array(wts), _ptr_array(w8s), _ptr_array(w8ts), _ptr_array(srcs),
            _int_array([d[0] for d in dims]), _int_array([d[1] for d in dims]), _int_array([d[2] for d in dims]),
            _int_array([d[3] for d in dims]), (_ct.c_float * L)(*[float(s) for _, s, _ in entries]), L,
            N.dtype_code(flat_f), N.stream())
-    return list(zip(wfs, wts, w8s))
+    return list(zip(wfs, wts, w8s, w8ts))
 
 
 class _ConvActFork(Function):
@@ -711,6 +742,7 @@ class _ConvActFork(Function):
         ctx.set_materialize_grads(False)
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
+        ctx.w8t = getattr(w, "_dgv2_w8t", None) if ctx.wt is not None else None
         ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
@@ -726,7 +758,7 @@ class _ConvActFork(Function):
         if gy is None:   # only the sibling branch carries a gradient
             return gx_sibling, None, None, None, None, None
         gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
-        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None
 
@@ -789,6 +821,7 @@ class _ConvActDown(Function):
         ctx.set_materialize_grads(False)
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
+        ctx.w8t = getattr(w, "_dgv2_w8t", None) if ctx.wt is not None else None
         ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
@@ -821,7 +854,7 @@ class _ConvActDown(Function):
         else:   # composed (also the differentiable form for create_graph=True)
             gh = _Resample.apply(gy, spec, True, in_hw)
             gpre, gb = _BiasActBackward.apply(gh, out, True, alpha, scale, 1, size_b)
-        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale) if ctx.needs_input_grad[0] else gx_sibling
+        gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else gx_sibling
         gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None, None, None, None
 
@@ -840,6 +873,7 @@ class _ConvResid(Function):
         x = x.contiguous()
         resid = resid.contiguous()
         wc, ctx.wt = _bank(w, x)
+        ctx.w8t = getattr(w, "_dgv2_w8t", None) if ctx.wt is not None else None
         ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
@@ -852,7 +886,7 @@ class _ConvResid(Function):
         if gy is None:
             return None, None, None, None
         x, w = ctx.saved_tensors
-        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if want_param_grad(ctx, 1) else None
         return gx, gw, (gy if ctx.needs_input_grad[2] else None), None
 

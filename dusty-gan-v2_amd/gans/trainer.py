@@ -23,6 +23,7 @@ import torch.optim as optim
 
 from gans import parallel
 from gans.augment.adaptive_augment import AdaptiveAugment
+from gans.context_manager import gradient_accumulation
 from gans.coords import CoordBridge, synthetic_angle_grid
 from gans.datasets.synthetic import SyntheticRangeImages
 from gans.models.builder import build_discriminator, build_generator
@@ -505,7 +506,9 @@ class Trainer:
                 # under graph replay the body's scalar tensors are static buffers: keep a copy per chunk
                 per_chunk[k].append(v.clone() if nacc > 1 else v)
 
-        # a rank's share of the global batch, chunk by chunk (reference: trainer.py:253-257).  With one chunk and an
+        # a rank's share of the global batch, chunk by chunk (reference: trainer.py:253-257; the loops below run under
+        # gans.context_manager.gradient_accumulation like the reference's: every chunk but the last inside the
+        # gradient exchangers' no_sync, so that an exchange issued from inside a body would be suppressed there).  With one chunk and an
         # objective whose G step does not look at reals, the batch is prepared AFTER the G step's backward: it is the one
         # piece of work on this rank that does not depend on G's reduced gradient, so G's all-reduce runs under it.
         late_reals = nacc == 1 and not self.use_real_in_g
@@ -529,7 +532,7 @@ class Trainer:
         # Where the broadcast travels: the one before the G step rode in the previous iteration's tail exchange
         # (_g_bufs_synced), the one before the D step rides behind G's gradients; the stand-alone sync_buffers remains
         # for the first iteration and around the path-length step.
-        for j in range(nacc):
+        for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
             if j == 0 and not self._g_bufs_synced:
                 parallel.sync_buffers(self.G)
             if self.use_real_in_g:
@@ -546,7 +549,7 @@ class Trainer:
         self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
 
         if self.pl_weight > 0.0 and iteration % self.lazy_pl == 0:
-            for j in range(nacc):
+            for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
                 if j == 0 and not self._g_bufs_synced:
                     parallel.sync_buffers(self.G)
                 log(self._run(self._acc_name("pl_fb", j), self.pl_fb, j))
@@ -556,7 +559,7 @@ class Trainer:
             self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
 
         pending = []
-        for j in range(nacc):
+        for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
             if j == 0 and not self._g_bufs_synced:
                 parallel.sync_buffers(self.G)
             if self.split_d:
@@ -581,7 +584,7 @@ class Trainer:
         self._g_bufs_synced = False   # the D step's G forward moved this rank's ema_var / w_avg again
         r1_pending = None
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
-            for j in range(nacc):
+            for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
                 log(self._run(self._acc_name("r1_fb", j), self.r1_fb, real(j), j))
             # R1's 154 MB leave asynchronously as well: the packing launches of the tail exchange run under them (the
             # exchange itself queues behind the reduction on the communication stream).  The optimizer step cannot move

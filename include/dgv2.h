@@ -477,14 +477,16 @@ int dgv2_bmm_tn_stream_x(float* gw, float* scratch, int64_t scratch_elems, const
 int dgv2_conv_weight_bank(void* const* wf, void* const* wt, const float* const* src, const int* O,
                           const int* C, const int* Cpad, const int* kk, const float* scale, int L,
                           int dtype, void* stream);
-/* ... with a third, optional output per layer (w8 == NULL or w8[l] == NULL: none): the STAGING IMAGE of the eight-wave
- * forward conv dgv2_conv3x3_fwd8 -- [O / 64][Cpad / 32][2304 units of 16 bytes], unit (row = tap * 64 + o % 64,
+/* ... with two more, optional outputs per layer (array or entry NULL: none).  w8t[l]: the staging image of the stride-1
+ * data gradient dgv2_conv3x3_dgrad8 -- [Cpad / 64][O / 32][2304 units], row = t' * 64 + c % 64 with the gradient's tap
+ * order t' = 8 - (ky * 3 + kx), plane = (o % 32) / 8 (needs Cpad % 64 == 0, O % 32 == 0).  w8[l]: the STAGING IMAGE of
+ * the eight-wave forward conv dgv2_conv3x3_fwd8 -- [O / 64][Cpad / 32][2304 units of 16 bytes], unit (row = tap * 64 + o % 64,
  * plane = (c % 32) / 8) at (row >> 3) * 32 + plane * 8 + (row & 7), the order the kernel's staging slots read it: a
  * slab's K-chunk is one contiguous 36 KB run instead of 576 pieces of 64 bytes.  Same values as wf.  Needs kh*kw == 9,
  * O % 64 == 0, Cpad % 32 == 0, DGV2_BF16.  replaces: the same EqualLR weights (common.py:158-210). */
-int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, const float* const* src, const int* O,
-                             const int* C, const int* Cpad, const int* kk, const float* scale, int L, int dtype,
-                             void* stream);
+int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, void* const* w8t,
+                             const float* const* src, const int* O, const int* C, const int* Cpad, const int* kk,
+                             const float* scale, int L, int dtype, void* stream);
 /* Forward 3x3 ring conv, stride 1 or 2, pad 1, on that image (conv8.hip: eight waves per block = two groups of four that
  * share the halo tile (stride 2: two 64-channel slabs per 8 x 32 pixel tile) or the weight slab (stride 1: two pixel
  * tiles per slab)):  y [B, Hin/stride, Win/stride, O] (bf16) = act( conv(x [B,Hin,Win,Cin], w) + resid + bias ) * scale,
@@ -495,6 +497,13 @@ int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, 
  * dgv2_conv_taps on wf. */
 int dgv2_conv3x3_fwd8(void* y, const void* x, const void* w8, int B, int Hin, int Win, int Cin, int O, int stride,
                       const float* bias, const void* resid, int act, float alpha, float scale, int dtype, void* stream);
+/* The stride-1 data gradient of the same conv on the transposed image w8t: gx [B,H,W,C] (bf16) from gy [B,H,W,O], the
+ * replicate-row terms of rows 0 and H - 1 included, + resid (the gradient of a sibling branch of the same input, like gx,
+ * or NULL).  replaces: the cuDNN data gradient autograd calls for ops.Conv2d (common.py:187-210) at ResidualBlock.conv1
+ * (dusty_v2.py:329).  DGV2_ENOTSUP where the engine does not cover the geometry (C % 64, O % 32, O >= 64, H >= 8,
+ * W >= 32 / 64): callers then run dgv2_conv_taps_ex on wt. */
+int dgv2_conv3x3_dgrad8(void* gx, const void* gy, const void* w8t, int B, int H, int W, int C, int O, const void* resid,
+                        int dtype, void* stream);
 
 /* Streaming weight gradient -- the hot-path engine for every discriminator conv (same reference lines as
  * dgv2_conv_wgrad).  A block keeps one (o, c) tile of gw for all k*k taps in registers and streams its

@@ -24,12 +24,18 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             g = nat.ConvGeom(3, 3, stride, 1, True)
             x = torch.randn(B, H, W, C, device="cuda", dtype=torch.bfloat16)
             pw = torch.randn(O, C, 3, 3, device="cuda") / 24
-            (wf, wt, w8), = nat.conv_weight_bank([(pw, 1.0, C)], torch.bfloat16, image8=[True])
+            (wf, wt, w8, w8t), = nat.conv_weight_bank([(pw, 1.0, C)], torch.bfloat16, image8=[True])
             w = wf.reshape(O, 3, 3, C)
             bias = torch.randn(O, device="cuda")
             us = t(lambda: nat._conv_fwd_raw(x, w, g, bias, 3, 0.2, 1.4142, w8=w8))
             fl = 2.0 * B * (H // stride) * (W // stride) * O * 9 * C
-            out.append(f"{us:6.1f} ({fl / us / 1e6:4.0f})")
+            cell = f"{us:6.1f} ({fl / us / 1e6:4.0f})"
+            if stride == 1:   # + the data gradient with the sibling gradient added (conv1's backward)
+                gy = torch.randn(B, H, W, O, device="cuda", dtype=torch.bfloat16)
+                rs = torch.randn(B, H, W, C, device="cuda", dtype=torch.bfloat16)
+                ud = t(lambda: nat._conv_dgrad_raw(gy, None, g, (B, H, W, C), wt=wt, resid=rs, w8t=w8t))
+                cell += f" d{ud:6.1f}"
+            out.append(cell)
     print(f"{sys.argv[2]:>28}: " + "  ".join(out), flush=True)
 else:
     print("us (TF/s) fwd at B=128:  s2: " + ", ".join(f"{h}x{w} {c}->{o}" for h, w, c, o in S2) + " | s1: " +

@@ -926,7 +926,7 @@ def test_conv8_three_chunks_and_fused_epilogue_exact_on_integers(nat, B, H, W, C
                             0.25, 2.0, cl(resid).bfloat16())
     assert torch.equal(nchw(got), want)
     # ... and on the weight bank's staging image (dgv2_conv3x3_fwd8)
-    (wf, wt, w8), = nat.conv_weight_bank([(w.to(DEV), 1.0, C)], torch.bfloat16, image8=[True])
+    (wf, wt, w8, _), = nat.conv_weight_bank([(w.to(DEV), 1.0, C)], torch.bfloat16, image8=[True])
     assert w8 is not None
     got8 = nat._conv_fwd_raw(cl(x).bfloat16(), wf.reshape(O, 3, 3, C), geom, bias.to(DEV), 3, 0.25, 2.0, cl(resid).bfloat16(),
                              w8=w8)
@@ -937,6 +937,31 @@ def test_conv8_three_chunks_and_fused_epilogue_exact_on_integers(nat, B, H, W, C
     xs = torch.zeros(1, 2, 16, 64, device=DEV, dtype=torch.bfloat16)
     assert N.try_call("dgv2_conv3x3_fwd8", N.ptr(y), N.ptr(xs), N.ptr(w8), 1, 2, 16, 64, 64, 1, None, None, 0, 0.2, 1.0,
                       N.BF16, N.stream()) is False
+
+
+@pytest.mark.parametrize("B,H,W,C,O", [(2, 24, 96, 64, 96), (2, 8, 128, 128, 192), (1, 16, 64, 128, 64), (3, 9, 70, 64, 64)])
+def test_conv8_data_gradient_exact_on_integers(nat, B, H, W, C, O):
+    """dgv2_conv3x3_dgrad8: the stride-1 3x3 ring data gradient on the bank's transposed staging image -- dead taps of
+    the border rows skipped, their replicate-row terms re-weighted, the sibling branch's gradient added (the call of
+    ResidualBlock.conv1's backward, dusty_v2.py:329); both group layouts (two slabs per halo tile / two tiles per
+    slab), ragged H and W, borders inside one wave pair.  Integers: exact."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.zeros(B, C, H, W, requires_grad=True)
+    w = torch.randint(-1, 2, (O, C, 3, 3), generator=g).float()
+    y = _conv_oracle(x, w, 1, 1, True)
+    gy = torch.randint(-1, 2, y.shape, generator=g).float()
+    (gx,) = torch.autograd.grad(y, [x], gy)
+    resid = torch.randint(-3, 4, gx.shape, generator=g).float()
+    want = gx + resid
+    assert float(want.abs().max()) < 256
+    (wf, wt, w8, w8t), = nat.conv_weight_bank([(w.to(DEV), 1.0, C)], torch.bfloat16, image8=[True])
+    assert w8t is not None
+    geom = nat.ConvGeom(3, 3, 1, 1, True)
+    got = nat._conv_dgrad_raw(cl(gy).bfloat16(), None, geom, (B, H, W, C), wt=wt, resid=cl(resid).bfloat16(), w8t=w8t)
+    assert torch.equal(nchw(got), want)
+    # same call without the image: the four-wave engine on wt
+    ref = nat._conv_dgrad_raw(cl(gy).bfloat16(), None, geom, (B, H, W, C), wt=wt, resid=cl(resid).bfloat16())
+    assert torch.equal(nchw(ref), want)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -961,9 +986,9 @@ def test_conv_weight_bank_both_layouts(nat, dtype):
     # the optional third output: conv8.hip's staging image, [O/64][Cpad/32][unit id][8 channels] with the unit of
     # (row = tap * 64 + o % 64, plane = (c % 32) / 8) at (row >> 3) * 32 + plane * 8 + (row & 7) -- same values as wf
     out8 = nat.conv_weight_bank(entries, dtype, image8=[True] * len(entries))
-    have = [w8 is not None for _, _, w8 in out8]
+    have = [w8 is not None for _, _, w8, _ in out8]
     assert have == [dtype == torch.bfloat16 and k == 3 and O % 64 == 0 and cp % 32 == 0 and cp >= 64 for O, C, k, cp in shapes]
-    for (wf, wt, w8), ref, (O, C, k, cp) in zip(out8, refs, shapes):
+    for (wf, wt, w8, w8t), ref, (O, C, k, cp) in zip(out8, refs, shapes):
         assert torch.equal(wf.cpu(), ref) and torch.equal(wt.cpu(), ref.permute(2, 1, 0))
         if w8 is not None:
             img = w8.cpu().view(O // 64, cp // 32, 576 * 4, 8)
@@ -971,6 +996,14 @@ def test_conv_weight_bank_both_layouts(nat, dtype):
             unit = (row >> 3) * 32 + plane * 8 + (row & 7)
             want = ref.view(O // 64, 64, 9, cp // 32, 4, 8).permute(0, 3, 2, 1, 4, 5).reshape(O // 64, cp // 32, 576, 4, 8)
             assert torch.equal(img[:, :, unit.reshape(-1)].view(O // 64, cp // 32, 576, 4, 8), want)
+        assert (w8t is not None) == (dtype == torch.bfloat16 and k == 3 and cp % 64 == 0 and O % 32 == 0 and O >= 64)
+        if w8t is not None:   # [cp/64][O/32][unit][8 o]: row = (8 - tap) * 64 + c % 64, plane = (o % 32) / 8
+            img = w8t.cpu().view(cp // 64, O // 32, 576 * 4, 8)
+            row, plane = torch.meshgrid(torch.arange(576), torch.arange(4), indexing="ij")
+            unit = (row >> 3) * 32 + plane * 8 + (row & 7)
+            flipped = ref.flip(1)                                         # tap t' = 8 - tap
+            want = flipped.view(O // 32, 4, 8, 9, cp // 64, 64).permute(4, 0, 3, 5, 1, 2).reshape(cp // 64, O // 32, 576, 4, 8)
+            assert torch.equal(img[:, :, unit.reshape(-1)].view(cp // 64, O // 32, 576, 4, 8), want)
 
 
 # ---------------------------------------------------------------------------------------
