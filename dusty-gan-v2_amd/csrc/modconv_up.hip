@@ -33,7 +33,8 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 struct MUGeom {
-  int B, P, Wout, Hin, Win;   // output pixels P = Hout * Wout; T is [B, 32, Hin * Win]
+  int B, P, Wout, Hin, Win;   // output pixels P = Hout * Wout; T is [B, O, Hin * Win] in 8-pixel units
+  int O;                      // output channels of the layer: blockIdx.z owns the 32-channel slab [32 z, 32 z + 32)
   int Ks;                     // w is the per-sample MFMA image [B][Ks/32][2 mt][4 kq][16 o][8 k] (dgv2_modconv_up_t)
   int samples_per_block;
   const int* idx_h;           // [Hout][2] low-res rows of the two taps, coef_h [Hout][2]
@@ -63,7 +64,6 @@ template <int KS32, bool LRELU>   // Ks / 32; leaky ReLU or no activation
 __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ tcm,
                                                             const bf16_t* __restrict__ xs, const bf16_t* __restrict__ w,
                                                             MUGeom g) {
-  constexpr int O = 32;
   constexpr int KT = KS32 + UP32;                   // K-steps per sample
   constexpr int WBUF = KS32 * 128;                  // 16-byte slots of one sample's weights: [KS32][2 mt][4 kq][16 o]
   constexpr int TBUF = UP32 * 128;                  // ... of one wave's T window: [UP32][2 mt][4 kq][16 o]
@@ -76,6 +76,10 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it is wave-uniform
   const int n16 = lane & 15, kq = lane >> 4;
+  // Levels with more than 32 output channels (round 4: O = 64 / 128 at levels 3 / 2) run as 32-channel SLABS, one per
+  // blockIdx.z: T is [B][Hin][O / 16 tiles][Win / 8][16 o][8 px], the weight image [B][O / 32][Ks / 32][2][4][16][8] -- a
+  // slab's per-sample weights and its window of T are the same contiguous 1 KB pieces as at O = 32.
+  const int zs = blockIdx.z, MT = g.O >> 4, nslab = g.O >> 5;
   const int p0 = blockIdx.x * 256 + wave * 32;      // P % 32 == 0: a wave is all live or all dead
   const int b0 = blockIdx.y * g.samples_per_block;
   const int b1 = min(b0 + g.samples_per_block, g.B);
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
   for (int q = 0; q < NTP; ++q) {
     int c = winbase + 8 * kq;
     c = c >= g.Win ? c - g.Win : c;
-    toff[q] = (((iy[q >> 1] * 2 + (q & 1)) * (g.Win >> 3) + (c >> 3)) * 16 + n16) * 8;
+    toff[q] = (((iy[q >> 1] * MT + 2 * zs + (q & 1)) * (g.Win >> 3) + (c >> 3)) * 16 + n16) * 8;
   }
 
   // LDS slot L = ((s * 2 + mt) * 4 + kq) * 16 + o16  <-  image slot L of sample b: every piece is one contiguous 1 KB
@@ -107,10 +111,10 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
     if ((g.ablate & 1) || (q >= NW && (g.ablate & 16))) return;
 #endif
     if (q < NW)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(w + ((int64_t)b * WBUF + tid + q * 512) * 8),
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(w + (((int64_t)b * nslab + zs) * WBUF + tid + q * 512) * 8),
                                        (lds_void_t*)(lds_w + buf * WBUF + q * 512 + wave * 64), 16, 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(tcm + (int64_t)b * O * g.Hin * g.Win + toff[q - NW]),
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(tcm + (int64_t)b * g.O * g.Hin * g.Win + toff[q - NW]),
                                        (lds_void_t*)(lds_w + TOFF + (buf * 8 + wave) * TBUF + (q - NW) * 64), 16, 0, 0);
   };
   constexpr int NQ = NW + NTP;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias_c[mt][r] = g.bias ? g.bias[16 * mt + 4 * kq + r] * gain : 0.f;
+    for (int r = 0; r < 4; ++r) bias_c[mt][r] = g.bias ? g.bias[32 * zs + 16 * mt + 4 * kq + r] * gain : 0.f;
 
   float ss = 0.f;
   const float lr_k = (1.f - g.alpha) / (1.f + g.alpha);
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
     }
     // even kq: qa = own block-A quad, qb = the block-A quad of kq + 1;  odd kq: qa = block-B quad of kq - 1, qb = own
     if (live)
-      *reinterpret_cast<uint4*>(y + ((int64_t)bprev * g.P + px + 16 * nt) * O + co) = make_uint4(qa.u[0], qa.u[1], qb.u[0], qb.u[1]);
+      *reinterpret_cast<uint4*>(y + ((int64_t)bprev * g.P + px + 16 * nt) * g.O + 32 * zs + co) = make_uint4(qa.u[0], qa.u[1], qb.u[0], qb.u[1]);
   };
 
   auto step = [&](auto has_prev, f32x4 (&acc)[2][2], f32x4 (&prev)[2][2], int buf, int b) {
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void modconv_up_kernel(bf16_t* __restrict__
   if (g.sumsq) {
     __shared__ float red[16];
     const float s = block_sum(live ? ss : 0.f, red);
-    if (tid == 0) g.sumsq[blockIdx.y * gridDim.x + blockIdx.x] = s;
+    if (tid == 0) g.sumsq[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
   }
 }
 
@@ -327,11 +331,13 @@ template <int KA16>   // Ka / 16
 __global__ __launch_bounds__(512) void modconv_up_t_kernel(bf16_t* __restrict__ tcm, bf16_t* __restrict__ wimg,
                                                            const bf16_t* __restrict__ h, const bf16_t* __restrict__ w,
                                                            const float* __restrict__ row_scale, float gain, int Plow,
-                                                           int Wlow, int I, int koff, int Ks) {
-  constexpr int O = 32, Ka = KA16 * 16;
+                                                           int Wlow, int I, int koff, int Ks, int Otot) {
+  constexpr int O = 32, Ka = KA16 * 16;               // O: the slab this block computes, [32 z, 32 z + 32) of Otot
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = lane & 31, kg = lane >> 5;
-  const int b = blockIdx.y;
+  const int b = blockIdx.y, zs = blockIdx.z, MT = Otot >> 4, nslab = Otot >> 5;
+  w += (int64_t)zs * O * I;                             // this slab's rows of every sample's weights (sample stride Otot * I)
+  if (row_scale) row_scale += zs * O;
   if (blockIdx.x == 0 && wimg) {
     // image slot L = ((s * 2 + mt) * 4 + kq) * 16 + o16  <-  w[b][16 mt + o16][koff + 32 s + 8 kq .. + 8]: the A fragments of
     // v_mfma_f32_16x16x32_bf16, one contiguous 1 KB per (K-step, M tile)
@@ -339,19 +345,19 @@ __global__ __launch_bounds__(512) void modconv_up_t_kernel(bf16_t* __restrict__ 
     for (int L = tid; L < slots; L += 512) {
       const int o = ((L >> 6) & 1) * 16 + (L & 15), kq4 = (L >> 4) & 3, s32 = L >> 7;
       vec16<bf16_t> v;
-      v.raw = *reinterpret_cast<const uint4*>(w + ((int64_t)b * O + o) * I + koff + s32 * 32 + kq4 * 8);
+      v.raw = *reinterpret_cast<const uint4*>(w + ((int64_t)b * Otot + o) * I + koff + s32 * 32 + kq4 * 8);
       const float c = (row_scale ? row_scale[o] : 1.f) * gain;
       if (c != 1.f) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v.set(e, v.get(e) * c);
       }
-      *reinterpret_cast<uint4*>(wimg + ((int64_t)b * slots + L) * 8) = v.raw;
+      *reinterpret_cast<uint4*>(wimg + (((int64_t)b * nslab + zs) * slots + L) * 8) = v.raw;
     }
   }
   const int p0 = blockIdx.x * 256 + wave * 32;
   if (p0 >= Plow) return;
   const bf16_t* hp = h + ((int64_t)b * Plow + p0 + n) * Ka + kg * 8;
-  const bf16_t* wp = w + ((int64_t)b * O + n) * I + kg * 8;
+  const bf16_t* wp = w + ((int64_t)b * Otot + n) * I + kg * 8;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -369,9 +375,10 @@ __global__ __launch_bounds__(512) void modconv_up_t_kernel(bf16_t* __restrict__ 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
   }
   // lane (o = n, kg) holds pixels 8j + 4kg .. +3 (j = 0..3) -> two runs of 8 consecutive pixels (= two units);
-  // layout [B][Hlow][2 mt][Wlow/8][16 o][8 px] (Wlow % 32 == 0: the wave's 32 pixels lie in one row)
+  // layout [B][Hlow][Otot / 16 tiles][Wlow/8][16 o][8 px] (Wlow % 32 == 0: the wave's 32 pixels lie in one row)
   const int trow = p0 / Wlow, tcol = p0 - trow * Wlow;
-  bf16_t* dst = tcm + (int64_t)b * Plow * O + ((((int64_t)trow * 2 + (n >> 4)) * (Wlow >> 3) + (tcol >> 3)) * 16 + (n & 15)) * 8;
+  bf16_t* dst = tcm + (int64_t)b * Plow * Otot +
+                ((((int64_t)trow * MT + 2 * zs + (n >> 4)) * (Wlow >> 3) + (tcol >> 3)) * 16 + (n & 15)) * 8;
   const float c = (row_scale ? row_scale[n] : 1.f) * gain;
 #pragma unroll
   for (int j = 0; j < 4; j += 2) {
@@ -398,23 +405,26 @@ __global__ __launch_bounds__(512) void modconv_up_tl_kernel(bf16_t* __restrict__
                                                             float gain, const float* __restrict__ ghd,
                                                             const float* __restrict__ gho, const float* __restrict__ gwd,
                                                             const float* __restrict__ gwo, int Hlow, int Wlow, int I,
-                                                            int koff, int Ks, int RS, float* __restrict__ partial) {
+                                                            int koff, int Ks, int RS, float* __restrict__ partial,
+                                                            int Otot, int z0) {
   constexpr int O = 32, Ka = KA16 * 16;
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = lane & 31, kg = lane >> 5;
-  const int b = blockIdx.y;
+  // slab z0 + blockIdx.z of the Otot output channels (the statistic instance runs slab 0 only: grid.z = 1)
+  const int b = blockIdx.y, zs = z0 + blockIdx.z, MT = Otot >> 4, nslab = Otot >> 5;
+  w += (int64_t)zs * O * I;
   if (blockIdx.x == 0 && wimg) {   // the PE columns of the sample's weights as the MFMA image (see modconv_up_t_kernel)
     const int slots = (Ks >> 5) * 128;
     for (int L = tid; L < slots; L += 512) {
       const int o = ((L >> 6) & 1) * 16 + (L & 15), kq4 = (L >> 4) & 3, s32 = L >> 7;
       vec16<bf16_t> v;
-      v.raw = *reinterpret_cast<const uint4*>(w + ((int64_t)b * O + o) * I + koff + s32 * 32 + kq4 * 8);
+      v.raw = *reinterpret_cast<const uint4*>(w + ((int64_t)b * Otot + o) * I + koff + s32 * 32 + kq4 * 8);
       if (gain != 1.f) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v.set(e, v.get(e) * gain);
       }
-      *reinterpret_cast<uint4*>(wimg + ((int64_t)b * slots + L) * 8) = v.raw;
+      *reinterpret_cast<uint4*>(wimg + (((int64_t)b * nslab + zs) * slots + L) * 8) = v.raw;
     }
   }
   const int segs = Wlow >> 5;
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(512) void modconv_up_tl_kernel(bf16_t* __restrict__
     const int iend = min(i0 + RS, Hlow);
     const int col = seg * 32 + n, col1 = col + 1 == Wlow ? 0 : col + 1;
     const bf16_t* hb = h + (int64_t)b * Hlow * Wlow * Ka + kg * 8;
-    const bf16_t* wp = w + ((int64_t)b * O + n) * I + kg * 8;
+    const bf16_t* wp = w + ((int64_t)b * Otot + n) * I + kg * 8;
     uint4 fb[KA16], a[KA16], bq[KA16], c[KA16], d[KA16];
 #pragma unroll
     for (int s = 0; s < KA16; ++s) {
@@ -436,7 +446,8 @@ __global__ __launch_bounds__(512) void modconv_up_tl_kernel(bf16_t* __restrict__
 #pragma unroll
     for (int s = 0; s < KA16; ++s) fb[s] = *reinterpret_cast<const uint4*>(wp + s * 16);
     const float wd = STAT ? gwd[col] : 0.f, wo = STAT ? gwo[col] : 0.f;
-    bf16_t* dst0 = tcm + (int64_t)b * Hlow * Wlow * O + ((int64_t)((n >> 4) * (Wlow >> 3) + (seg * 4)) * 16 + (n & 15)) * 8;
+    bf16_t* dst0 = tcm + (int64_t)b * Hlow * Wlow * Otot +
+                   ((int64_t)((2 * zs + (n >> 4)) * (Wlow >> 3) + (seg * 4)) * 16 + (n & 15)) * 8;
     for (int i = i0; i < iend; ++i) {
       const int i1 = min(i + 1, Hlow - 1);
       if (STAT || i + 1 < iend) {
@@ -456,8 +467,8 @@ __global__ __launch_bounds__(512) void modconv_up_tl_kernel(bf16_t* __restrict__
         ub.u = fb[s];
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
       }
-      // [B][Hlow][2 mt][Wlow/8][16 o][8 px]: row i, units 4 seg + (j + kg)
-      bf16_t* dst = dst0 + (int64_t)i * 2 * (Wlow >> 3) * 128;
+      // [B][Hlow][Otot / 16 tiles][Wlow/8][16 o][8 px]: row i, units 4 seg + (j + kg)
+      bf16_t* dst = dst0 + (int64_t)i * MT * (Wlow >> 3) * 128;
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {
         vec16<bf16_t> o;
@@ -563,11 +574,12 @@ __global__ __launch_bounds__(256) void up2_lag_sumsq_kernel(const bf16_t* __rest
 
 }  // namespace
 
-// y[b,p,:32] = act( up2(T)[b,p,:] + sum_{k<Ks} xs[p,k] W_s[b,:,k] + bias )   (bf16 in / out), T and W_s carrying the
+// y[b,p,:O] = act( up2(T)[b,p,:] + sum_{k<Ks} xs[p,k] W_s[b,:,k] + bias )   (bf16 in / out; O in {32, 64, 128}: generator
+//   levels 4 / 3 / 2, as 32-channel slabs of the same kernel), T and W_s carrying the
 //   layer's input-magnitude factor row_scale[o] times gain = scale (1 + alpha) / 2 for act 3, 1 for act 0 (this entry
 //   puts the same gain on the bias; the leaky ReLU is then one fma, see the kernel):
-//   t [B,Hin,2,Win/8,16,8] = row_scale * gain * W_a . h at the previous level's resolution in 8-pixel units and
-//   wimg [B,Ks/32,2,4,16,8] = the PE columns row_scale * gain * W_s of the prepared per-sample weights as the MFMA image,
+//   t [B,Hin,O/16,Win/8,16,8] = row_scale * gain * W_a . h at the previous level's resolution in 8-pixel units and
+//   wimg [B,O/32,Ks/32,2,4,16,8] = the PE columns row_scale * gain * W_s of the prepared per-sample weights as the MFMA image,
 //   both from dgv2_modconv_up_t; up2 by the
 //   two-tap tables idx/coef [Hout][2], [Wout][2] (native.ResampleSpec.tables of the block's up-2 Resample, zero-padded to
 //   two taps); xs: the batch-shared PE [Hout*Wout, Ks] as the fragment image [Hout*Wout/16][Ks/32][4][16][8]
@@ -583,28 +595,28 @@ extern "C" int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const
                                    int* sumsq_used, void* stream) {
   if (sumsq_used) *sumsq_used = 0;
   if (!y || !t || !xs || !wimg || !idx_h || !coef_h || !idx_w || !coef_w || B <= 0 || Hout <= 0 || Wout <= 0) return DGV2_EINVAL;
-  if (dtype != DGV2_BF16 || (act != 0 && act != 3) || O != 32 || Ks != 512 || (Wout & 31) || (Win & 7) || Win < 32 ||
-      Hin <= 0 || (act == 3 && !(scale > 0.f)))
+  if (dtype != DGV2_BF16 || (act != 0 && act != 3) || (O != 32 && O != 64 && O != 128) || Ks != 512 || (Wout & 31) ||
+      (Win & 7) || Win < 32 || Hin <= 0 || (act == 3 && !(scale > 0.f)))
     return DGV2_ENOTSUP;
   if (!aligned16(y) || !aligned16(t) || !aligned16(xs) || !aligned16(wimg)) return DGV2_EINVAL;
   const int P = Hout * Wout;
-  MUGeom g{B, P, Wout, Hin, Win, Ks, 1, idx_h, coef_h, idx_w, coef_w, bias, in_scale, act, alpha, scale, sumsq};
+  MUGeom g{B, P, Wout, Hin, Win, O, Ks, 1, idx_h, coef_h, idx_w, coef_w, bias, in_scale, act, alpha, scale, sumsq};
 #ifdef DGV2_ABLATE
   g.ablate = getenv("DGV2_MU_ABLATE") ? atoi(getenv("DGV2_MU_ABLATE")) : 0;
 #endif
-  const int tiles = (P + 255) / 256;
-  int nsplit = (256 + tiles - 1) / tiles;          // one resident block per CU (the B fragments fill the registers)
+  const int tiles = (P + 255) / 256, nslab = O / 32;
+  int nsplit = (256 + tiles * nslab - 1) / (tiles * nslab);   // one resident block per CU (the B fragments fill the registers)
   nsplit = nsplit < 1 ? 1 : (nsplit > B ? B : nsplit);
   g.samples_per_block = (B + nsplit - 1) / nsplit;
   nsplit = (B + g.samples_per_block - 1) / g.samples_per_block;
-  if (g.sumsq && sumsq_used && tiles * nsplit <= sumsq_cap) *sumsq_used = tiles * nsplit;
+  if (g.sumsq && sumsq_used && tiles * nsplit * nslab <= sumsq_cap) *sumsq_used = tiles * nsplit * nslab;
   else g.sumsq = nullptr;
   constexpr int KS32 = 16;
   const size_t lds = sizeof(uint4) * (2 * KS32 * 128 + 2 * 8 * UP32 * 128);
   auto kern = act == 3 ? modconv_up_kernel<KS32, true> : modconv_up_kernel<KS32, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  dim3 grid(tiles, nsplit);
+  dim3 grid(tiles, nsplit, nslab);
   kern<<<grid, 512, lds, (hipStream_t)stream>>>((bf16_t*)y, (const bf16_t*)t, (const bf16_t*)xs, (const bf16_t*)wimg, g);
   DGV2_RETURN_LAST();
 }
@@ -614,24 +626,26 @@ extern "C" int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const
 //                         units of channels 0..15 then those of channels 16..31 (the four units a T piece of
 //                         dgv2_modconv_up_fwd reads are then one contiguous 1 KB), f[o] = row_scale[o] (1 if NULL) * gain
 //   wimg [B,Ks/32,2,4,16,8] (or NULL): f[o] w[b][16 mt + o16][koff + 32 s + 8 kq + j] at [b][s][mt][kq][o16][j]
-// h [B,Hlow*Wlow,Ka], w [B,O,I] prepared per-sample weights (bf16); O = 32, Ka in {64, 128}, Wlow % 32 == 0, Ks % 32 == 0.
+// h [B,Hlow*Wlow,Ka], w [B,O,I] prepared per-sample weights (bf16); O in {32, 64, 128} (32-channel slabs: tcm then is
+// [B,Hlow,O/16,Wlow/8,16,8], wimg [B,O/32,Ks/32,2,4,16,8]), Ka in {64, 128, 256}, Wlow % 32 == 0, Ks % 32 == 0.
 // replaces: the xa columns of the ModConv2d contraction, gans/models/ops/style.py:105-118.
 extern "C" int dgv2_modconv_up_t(void* tcm, void* wimg, const void* h, const void* w, const float* row_scale, float gain,
                                  int B, int Hlow, int Wlow, int Ka, int Ks, int O, int I, int koff, int dtype,
                                  void* stream) {
   const int Plow = Hlow * Wlow;
   if (!tcm || !h || !w || B <= 0 || Hlow <= 0 || Wlow <= 0) return DGV2_EINVAL;
-  if (dtype != DGV2_BF16 || O != 32 || (Ka != 64 && Ka != 128) || (Wlow & 31) || (I & 7) || I < Ka ||
-      (wimg && ((Ks & 31) || (koff & 7) || koff + Ks > I)))
+  if (dtype != DGV2_BF16 || (O != 32 && O != 64 && O != 128) || (Ka != 64 && Ka != 128 && Ka != 256) || (Wlow & 31) ||
+      (I & 7) || I < Ka || (wimg && ((Ks & 31) || (koff & 7) || koff + Ks > I)))
     return DGV2_ENOTSUP;
   if (!aligned16(tcm) || !aligned16(h) || !aligned16(w) || (wimg && !aligned16(wimg))) return DGV2_EINVAL;
-  dim3 grid((Plow + 255) / 256, B);
-  if (Ka == 64)
-    modconv_up_t_kernel<4><<<grid, 512, 0, (hipStream_t)stream>>>((bf16_t*)tcm, (bf16_t*)wimg, (const bf16_t*)h,
-                                                                 (const bf16_t*)w, row_scale, gain, Plow, Wlow, I, koff, Ks);
-  else
-    modconv_up_t_kernel<8><<<grid, 512, 0, (hipStream_t)stream>>>((bf16_t*)tcm, (bf16_t*)wimg, (const bf16_t*)h,
-                                                                 (const bf16_t*)w, row_scale, gain, Plow, Wlow, I, koff, Ks);
+  dim3 grid((Plow + 255) / 256, B, O / 32);
+#define DGV2_T(KA16)                                                                                                  \
+  modconv_up_t_kernel<KA16><<<grid, 512, 0, (hipStream_t)stream>>>((bf16_t*)tcm, (bf16_t*)wimg, (const bf16_t*)h,    \
+                                                                   (const bf16_t*)w, row_scale, gain, Plow, Wlow, I, koff, Ks, O)
+  if (Ka == 64) DGV2_T(4);
+  else if (Ka == 128) DGV2_T(8);
+  else DGV2_T(16);
+#undef DGV2_T
   DGV2_RETURN_LAST();
 }
 
@@ -648,10 +662,12 @@ extern "C" int dgv2_modconv_up_t_lag(void* tcm, void* wimg, const void* h, const
   if (!tcm || !h || !w || B <= 0 || Hlow <= 0 || Wlow <= 0) return DGV2_EINVAL;
   const bool stat = ghd != nullptr;
   if (stat && (!gho || !gwd || !gwo || !sumsq || !sumsq_used)) return DGV2_EINVAL;
-  if (dtype != DGV2_BF16 || O != 32 || (Ka != 64 && Ka != 128) || (Wlow & 31) || (I & 7) || I < Ka ||
-      (wimg && ((Ks & 31) || (koff & 7) || koff + Ks > I)))
-    return DGV2_ENOTSUP;
+  if (dtype != DGV2_BF16 || (O != 32 && O != 64 && O != 128) || (Ka != 64 && Ka != 128) || (Wlow & 31) || (I & 7) ||
+      I < Ka || (wimg && ((Ks & 31) || (koff & 7) || koff + Ks > I)))
+    return DGV2_ENOTSUP;   // (Ka = 256, level 2: five fragment sets of 16 do not fit the registers -> dgv2_modconv_up_t +
+                           //  dgv2_up2_lag_sumsq as two launches)
   if (!aligned16(tcm) || !aligned16(h) || !aligned16(w) || (wimg && !aligned16(wimg))) return DGV2_EINVAL;
+  const int nslab = O / 32;
   const char* rs_env = getenv("DGV2_TL_ROWS");   // rows a wave walks (A/B benchmarking)
   // 8 rows per wave where that still leaves a block per CU (B = 64 at 32 x 256: 1 / 2 / 4 / 8 / 16 rows measured
   // 51 / 35 / 28 / 23 / 37 us; the two separate passes 29 + 16)
@@ -665,14 +681,17 @@ extern "C" int dgv2_modconv_up_t_lag(void* tcm, void* wimg, const void* h, const
     if ((int64_t)grid.x * grid.y > sumsq_cap) return DGV2_ENOTSUP;
     *sumsq_used = (int)(grid.x * grid.y);
   }
-#define DGV2_TL(KA16, ST)                                                                                              \
-  modconv_up_tl_kernel<KA16, ST><<<grid, 512, 0, (hipStream_t)stream>>>((bf16_t*)tcm, (bf16_t*)wimg, (const bf16_t*)h,  \
-                                                                        (const bf16_t*)w, gain, ghd, gho, gwd, gwo, Hlow, \
-                                                                        Wlow, I, koff, Ks, RS, sumsq)
+  // the statistic is a property of h alone: slab 0's launch takes it, the other slabs run the plain instance
+#define DGV2_TL(KA16, ST, GZ, Z0)                                                                                       \
+  modconv_up_tl_kernel<KA16, ST><<<dim3(grid.x, grid.y, GZ), 512, 0, (hipStream_t)stream>>>(                            \
+      (bf16_t*)tcm, (bf16_t*)wimg, (const bf16_t*)h, (const bf16_t*)w, gain, ghd, gho, gwd, gwo, Hlow, Wlow, I, koff, Ks, \
+      RS, sumsq, O, Z0)
   if (Ka == 64) {
-    if (stat) DGV2_TL(4, true); else DGV2_TL(4, false);
+    if (stat) { DGV2_TL(4, true, 1, 0); if (nslab > 1) DGV2_TL(4, false, nslab - 1, 1); }
+    else DGV2_TL(4, false, nslab, 0);
   } else {
-    if (stat) DGV2_TL(8, true); else DGV2_TL(8, false);
+    if (stat) { DGV2_TL(8, true, 1, 0); if (nslab > 1) DGV2_TL(8, false, nslab - 1, 1); }
+    else DGV2_TL(8, false, nslab, 0);
   }
 #undef DGV2_TL
   DGV2_RETURN_LAST();

@@ -180,11 +180,16 @@ def pe_frag16(xs):
     return img
 
 
+# output widths the commuted form runs at: 32 (level 4), 64 / 128 (levels 3 / 2, round 4: 32-channel slabs of the same
+# kernels); DGV2_UP_COMMUTE_O=32 restores round 3's choice for A/B runs
+_UP_O = tuple(int(v) for v in os.environ.get("DGV2_UP_COMMUTE_O", "32,64,128").split(","))
+
+
 def mod_up_ok(h, xs, wb, spec):
     return bool(_UP_COMMUTE and h is not None and xs is not None and h.is_cuda and h.dtype == torch.bfloat16
-                and wb.shape[1] == 32 and xs.shape[3] == 512 and h.shape[3] % 8 == 0
+                and wb.shape[1] in _UP_O and xs.shape[3] == 512 and h.shape[3] % 8 == 0
                 and tuple(a[1] for a in spec.axes) == (2, 2) and tuple(a[2] for a in spec.axes) == (1, 1)
-                and h.shape[3] in (64, 128) and h.shape[2] % 32 == 0
+                and h.shape[3] in (64, 128, 256) and h.shape[2] % 32 == 0
                 and spec.out_size(h.shape[1], h.shape[2]) == tuple(xs.shape[1:3])
                 and _up_tables(spec, h.shape[1], h.shape[2], h.device) is not None)
 
@@ -220,8 +225,8 @@ def mod_up_prepare(h, xs, wb, spec, act=True, alpha=0.2, scale=math.sqrt(2.0), w
     if want_stat and gram is None:
         return None
     h = h.contiguous()
-    t = torch.empty((B, hl, 2, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
-    wimg = torch.empty((B, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)      # W_s as the MFMA operand image
+    t = torch.empty((B, hl, Otot // 16, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
+    wimg = torch.empty((B, Otot // 32, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)   # W_s as the MFMA operand image
     gain = float(scale) * 0.5 * (1.0 + float(alpha)) if act else 1.0
     sq = _sq_args(dev) if want_stat else None
     N.check(h, wb)
@@ -252,8 +257,8 @@ class _ModUpPrepared(Function):
         if t is not None:
             in_scale = cvec          # T / the image from mod_up_prepare carry the gain only: c rides on the B operands
         else:
-            t = torch.empty((B, hl, 2, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
-            wimg = torch.empty((B, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)   # W_s as the MFMA operand image
+            t = torch.empty((B, hl, Otot // 16, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
+            wimg = torch.empty((B, Otot // 32, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)   # W_s as the MFMA operand image
             N.check(h, wb, cvec)
             # T and the image carry c[o] * gain, the kernel puts gain on the bias and runs the leaky ReLU as f' + k |f'|
             gain = cfg["scale"] * 0.5 * (1.0 + cfg["alpha"]) if cfg["act"] else 1.0

@@ -72,6 +72,8 @@ class ModConv2d(nn.Module):
     def update_ema(self, sumsq, count, sumsq_add, cvec):
         """Input-magnitude EMA update (style.py:98-103) for the batched-preparation path: one scalar launch that
         also writes this layer's output factor 1/(sqrt(ema_var)+1e-8) into `cvec` (its rows of the GEMM's scale)."""
+        if getattr(self, "_cvec_ready", False):
+            return   # inference: written up front for the whole pass (SynthesisNetwork._batched_weights)
         upd = self.ema and self.training and (sumsq is not None or sumsq_add != 0.0)
         with torch.no_grad():
             native.ema_update(self.ema_var, sumsq, sumsq_add, count if upd else 1, 1 - self.ema_decay, upd, cvec=cvec)

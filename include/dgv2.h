@@ -224,8 +224,9 @@ int dgv2_bmm_nn_cat(void* y, const void* xa, const void* xs, const void* w, int 
  * f' + |f'| (1 - alpha) / (1 + alpha)) already inside T and the weight image, the bias (fp32, times gain) as the C input
  * of each chain's first MFMA, and up2 as two more K-steps (of 32) of the same v_mfma_f32_16x16x32_bf16 chain (A = the wave's window of T, B = the constant interpolation
  * matrix of its 32 pixels, built in registers from the tables).
- * t [B,Hin,2,Win/8,16,8]: row_scale * gain * T in 8-pixel units (row, channel half, unit u, channel: pixels 8u..8u+7) and
- * wimg [B,Ks/32,2,4,16,8]: row_scale * gain * the PE columns of the prepared per-sample weights as the MFMA operand image
+ * O in {32, 64, 128} (generator levels 4 / 3 / 2): the launch runs O / 32 slabs of 32 channels of the same kernel.
+ * t [B,Hin,O/16,Win/8,16,8]: row_scale * gain * T in 8-pixel units (row, 16-channel tile, unit u, channel: pixels 8u..8u+7) and
+ * wimg [B,O/32,Ks/32,2,4,16,8]: row_scale * gain * the PE columns of the prepared per-sample weights as the MFMA operand image
  * -- both written by dgv2_modconv_up_t (the caller passes it that gain), so that
  * every LDS-DMA piece of the sample walk is one contiguous 1 KB; up2 given as two-tap tables idx/coef [Hout][2],
  * [Wout][2] (low-resolution index, weight: the sparse rows of Resample(up=2), gans/models/ops/common.py:105-135, with
@@ -245,12 +246,13 @@ int dgv2_modconv_up_fwd(void* y, const void* t, const void* xs, const void* wimg
                         const float* coef_w, const float* bias, const float* in_scale, int act, float alpha, float scale,
                         int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream);
 /* The low-resolution xa part of the commuted level-input conv and the operand images of dgv2_modconv_up_fwd:
- *   tcm [B,Hlow,2,Wlow/8,16,8]: T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units (per row: the units
- *   of channels 0..15, then those of channels 16..31), f[o] = row_scale[o] * gain
+ *   tcm [B,Hlow,O/16,Wlow/8,16,8]: T[b][o][p] = f[o] sum_{c<Ka} w[b][o][c] h[b][p][c] in 8-pixel units (per row: the units
+ *   of channels 0..15, then those of channels 16..31, ...), f[o] = row_scale[o] * gain
  *   (row_scale fp32 [O] or NULL = 1: the input-magnitude factor of ModConv2d, style.py:98-103);
- *   wimg [B,Ks/32,2,4,16,8] (or NULL): f[o] w[b][16 mt + o16][koff + 32 s + 8 kq + j] at [b][s][mt][kq][o16][j] (the A
- *   fragments of v_mfma_f32_16x16x32_bf16: one contiguous 1 KB per (K-step, M tile)).
- * h [B,Hlow*Wlow,Ka], w [B,O,I] (bf16); O = 32, Ka in {64, 128}, Wlow % 32 == 0, Ks % 32 == 0.
+ *   wimg [B,O/32,Ks/32,2,4,16,8] (or NULL): f[o] w[b][32 z + 16 mt + o16][koff + 32 s + 8 kq + j] at [b][z][s][mt][kq][o16][j]
+ *   (the A fragments of v_mfma_f32_16x16x32_bf16: one contiguous 1 KB per (K-step, M tile)).
+ * h [B,Hlow*Wlow,Ka], w [B,O,I] (bf16); O in {32, 64, 128}, Ka in {64, 128, 256} (the fused dgv2_modconv_up_t_lag: Ka <= 128),
+ * Wlow % 32 == 0, Ks % 32 == 0.
  * replaces: the xa columns of the ModConv2d contraction, gans/models/ops/style.py:105-118. */
 int dgv2_modconv_up_t(void* tcm, void* wimg, const void* h, const void* w, const float* row_scale, float gain, int B,
                       int Hlow, int Wlow, int Ka, int Ks, int O, int I, int koff, int dtype, void* stream);

@@ -1248,14 +1248,15 @@ def test_conv_strip_kernel_under_load_matches_the_generic_engine(nat):
     assert torch.equal(got_gxr.float(), want_gx + res)
 
 
-def test_modconv_up_commuted_upsampling_matches_cat_path(nat):
+@pytest.mark.parametrize("Ka,O", [(64, 32), (128, 64), (256, 128)])
+def test_modconv_up_commuted_upsampling_matches_cat_path(nat, Ka, O):
     """dgv2_modconv_up_fwd (conv1 of a generator level with the up-sampling commuted past the 1x1 contraction,
     csrc/modconv_up.hip) + its backward against (a) the float64 statement of the reference, act(c * ([up2(h) | PE] . W) +
     bias) (dusty_v2.py:153-162, style.py:105-118, Resample common.py:105-135), and (b) the existing path that
     materialises up2(h) (resample + dgv2_modconv_pe_fwd), outputs and every gradient; plus the statistic-only pass."""
     from gans.models.ops.common import Resample
     g = torch.Generator().manual_seed(77)
-    B, hl, wl, Ka, F, O = 3, 8, 32, 64, 256, 32
+    B, hl, wl, F = 3, 8, 32, 256
     H, W = 2 * hl, 2 * wl
     up = Resample(up=2, window=[1, 3, 3, 1], ring=True)
     spec = up.spec
@@ -1310,8 +1311,9 @@ def test_modconv_up_commuted_upsampling_matches_cat_path(nat):
         assert_rel(a, b, 1.5e-2, name)
 
 
-@pytest.mark.parametrize("B,hl,wl,Ka", [(2, 32, 256, 64), (3, 8, 32, 64), (1, 4, 64, 128), (2, 16, 96, 64)])
-def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
+@pytest.mark.parametrize("B,hl,wl,Ka,O", [(2, 32, 256, 64, 32), (3, 8, 32, 64, 32), (1, 4, 64, 128, 32), (2, 16, 96, 64, 32),
+                                          (2, 16, 128, 128, 64), (3, 8, 64, 256, 128), (2, 4, 32, 128, 64)])
+def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka, O):
     """The three launches of the commuted level-input conv through the C ABI, each against a float64 statement:
     dgv2_modconv_up_t (T = W_a . h, channel-major), dgv2_up2_lag_sumsq (sum up2(h)^2 from h's 2 x 2 neighbourhood
     products) and dgv2_modconv_up_fwd (up2 of T as four K-steps of the MFMA chain) -- the latter also BIT-EXACT on
@@ -1322,9 +1324,12 @@ def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
     from gans.models.ops.common import Resample
     g = torch.Generator().manual_seed(5 + hl)
     spec = Resample(up=2, window=[1, 3, 3, 1], ring=True).spec
-    Ks, O = 512, 32
+    Ks = 512          # O = 64 / 128 (generator levels 3 / 2, round 4): 32-channel slabs of the same kernels
     H, W = 2 * hl, 2 * wl
     bf = torch.bfloat16
+    MT, NS = O // 16, O // 32
+    t_flat = lambda t8: t8.permute(0, 2, 4, 1, 3, 5).reshape(B, O, hl * wl)              # [b, row, tile, unit, o16, px] -> [B, O, pixels]
+    w_flat = lambda wi: wi.permute(0, 1, 3, 5, 2, 4, 6).reshape(B, O, Ks)                # [b, slab, s, mt, kq, o16, j] -> [B, O, Ks]
     tabs = nat._up_tables(spec, hl, wl, torch.device(DEV))
     assert tabs is not None
     ih, ch, iw, cw = tabs
@@ -1342,15 +1347,15 @@ def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
         h, w, pe = h.to(DEV, bf), w.to(DEV, bf), pe.to(DEV, bf)
         bias = torch.randn(O, generator=g).to(DEV) if not exact else torch.zeros(O, device=DEV)
         cvec = (torch.rand(O, generator=g) + 0.5).to(DEV) if not exact else torch.ones(O, device=DEV)
-        t8 = torch.empty(B, hl, 2, wl // 8, 16, 8, device=DEV, dtype=bf)
-        wimg = torch.empty(B, Ks // 32, 2, 4, 16, 8, device=DEV, dtype=bf)
+        t8 = torch.empty(B, hl, MT, wl // 8, 16, 8, device=DEV, dtype=bf)
+        wimg = torch.empty(B, NS, Ks // 32, 2, 4, 16, 8, device=DEV, dtype=bf)
         act, scale = (0, 1.0) if exact else (3, math.sqrt(2.0))
         gain = scale * 0.5 * (1 + 0.2) if act else 1.0             # the contract of dgv2_modconv_up_fwd
         N.call("dgv2_modconv_up_t", N.ptr(t8), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), gain, B, hl, wl, Ka, Ks, O,
                Ka + Ks, Ka, N.BF16, N.stream())
-        t = t8.permute(0, 2, 4, 1, 3, 5).reshape(B, O, hl * wl)     # [b, row, mt, unit, o16, px] -> [B, O, pixels]
+        t = t_flat(t8)
         f = (cvec * gain)[None, :, None]                            # the layer's c[o] * gain rides in T and the image
-        assert torch.equal(wimg.permute(0, 2, 4, 1, 3, 5).reshape(B, O, Ks), (w[:, :, Ka:].float() * f).to(bf))   # [b,s,mt,kq,o16,j]
+        assert torch.equal(w_flat(wimg), (w[:, :, Ka:].float() * f).to(bf))
         want_t = torch.einsum("bpc,boc->bop", h.double().reshape(B, hl * wl, Ka), w.double()[:, :, :Ka]) * f.double()
         if exact:
             assert torch.equal(t.double(), want_t)
@@ -1363,7 +1368,7 @@ def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
                nat._SQ_CAP, ctypes.addressof(sq[1]), N.stream())
         # float64: up2 of the bf16 T the kernel read, plus the PE contraction with the image the kernel read
         tup = o.resample(t.double().cpu().reshape(B, O, hl, wl), (1, 3, 3, 1), up=2, ring=True).permute(0, 2, 3, 1)
-        ws = wimg.permute(0, 2, 4, 1, 3, 5).reshape(B, O, Ks).double().cpu()
+        ws = w_flat(wimg).double().cpu()
         pre = (tup + torch.einsum("hwk,bok->bhwo", pe.double().cpu()[0], ws) + bias.double().cpu() * gain) / gain * scale
         want = pre if exact else torch.where(pre > 0, pre, pre * 0.2)
         if exact:
@@ -1380,12 +1385,15 @@ def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
         assert_rel(lag.double().sum().cpu(), hup.square().sum(), 1e-5, "sum up2(h)^2")
         # T and the statistic from ONE read of h (dgv2_modconv_up_t_lag), the factor c as the kernel's in_scale
         pre2 = nat.mod_up_prepare(h, pe, w, spec, act=bool(act), alpha=0.2, scale=scale, want_stat=True)
+        if Ka > 128:      # level 2: the fused pass does not exist (five fragment sets of 16): two launches instead
+            assert pre2 is None
+            continue
         assert pre2 is not None
         t2, wimg2, part = pre2
         assert_rel(part.double().sum().cpu(), hup.square().sum(), 1e-5, "sum up2(h)^2 (fused pass)")
-        t2f = t2.permute(0, 2, 4, 1, 3, 5).reshape(B, O, hl * wl)
+        t2f = t_flat(t2)
         want_t2 = torch.einsum("bpc,boc->bop", h.double().reshape(B, hl * wl, Ka), w.double()[:, :, :Ka]) * gain
-        assert torch.equal(wimg2.permute(0, 2, 4, 1, 3, 5).reshape(B, O, Ks), (w[:, :, Ka:].float() * gain).to(bf))
+        assert torch.equal(w_flat(wimg2), (w[:, :, Ka:].float() * gain).to(bf))
         if exact:
             assert torch.equal(t2f.double(), want_t2)
         else:
@@ -1399,7 +1407,7 @@ def test_modconv_up_kernels_against_float64(nat, B, hl, wl, Ka):
                N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), N.ptr(cdev), act, 0.2, scale, N.BF16, None, 0,
                None, N.stream())
         tup2 = o.resample(t2f.double().cpu().reshape(B, O, hl, wl), (1, 3, 3, 1), up=2, ring=True).permute(0, 2, 3, 1)
-        ws2 = wimg2.permute(0, 2, 4, 1, 3, 5).reshape(B, O, Ks).double().cpu()
+        ws2 = w_flat(wimg2).double().cpu()
         pre = (cin * (tup2 + torch.einsum("hwk,bok->bhwo", pe.double().cpu()[0], ws2)) + bias.double().cpu() * gain) / gain * scale
         want2 = pre if exact else torch.where(pre > 0, pre, pre * 0.2)
         if exact:

@@ -306,12 +306,18 @@ def test_full_size_bf16_graph_replay_equals_eager():
     dev = max(worst(a, b) for a, b in zip(e2, gr))
     where = max(((abs(a[k] - b[k]) / (abs(a[k]) + 1e-3), i + 1, k, a[k], b[k]) for i, (a, b) in enumerate(zip(e2, gr)) for k in a))
     where_n = max(((abs(a[k] - b[k]) / (abs(a[k]) + 1e-3), i + 1, k, a[k], b[k]) for i, (a, b) in enumerate(zip(e1, e2)) for k in a))
-    assert dev <= 3 * noise + 1e-4, (dev, noise, "graph vs eager:", where, "eager vs eager:", where_n)
+    # A capture bug (a stale static buffer, a wrong pool, a memset node) moves the scalars by O(1).  The yardstick `noise`
+    # is ONE eager-vs-eager sample of a chaotic quantity: the bodies are reproducible to ~1e-6 per gradient tensor (float
+    # atomics only: scripts/repro_trainer_bodies.py, 60 replays of every body, graph and eager alike), and Adam with
+    # beta1 = 0 turns that into sign flips of near-zero gradient entries, so by iteration 4 the R1 penalty of two runs
+    # differs by 0.2 - 2.1 % (18 runs over three boxes in round 4: three of them beyond 3 x their own eager sample, graph
+    # AND eager pairs alike).  Hence the floor of 4 %.
+    assert dev <= max(3 * noise + 1e-4, 4e-2), (dev, noise, "graph vs eager:", where, "eager vs eager:", where_n)
     mods = (("G", eager.G, graph.G), ("D", eager.D, graph.D), ("Gema", eager.G_ema, graph.G_ema))
     for name, me, mg in mods:
         n_frac = _state_mismatch(state_first[name], me.state_dict())
         g_frac = _state_mismatch(me.state_dict(), mg.state_dict())
-        assert g_frac <= 3 * n_frac + 1e-4, (name, g_frac, n_frac)
+        assert g_frac <= max(3 * n_frac + 1e-4, 2e-2), (name, g_frac, n_frac)
 
 
 # ---------------------------------------------------------------------------- gradient accumulation
