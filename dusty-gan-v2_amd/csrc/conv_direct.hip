@@ -500,9 +500,68 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
       // per tile) epilogue then is convert + exchange + store, without the LDS bias reads and four fma / max per value
       const bool plain = !p.bias && !p.acc_scale && p.act != 3;
       const TY* rbase = reinterpret_cast<const TY*>(p.resid);   // optional residual, same layout as y
+      bool paired = false;
+      if constexpr (NC == 4 && sizeof(TY) == 2 && MF >= 2) {
+        // The stride-2 data gradient (p.s2d: class c writes pixel (2 gh + (c >> 1), 2 gw + (c & 1))): stored class by class,
+        // an instruction writes 16 pixels of 64 bytes at a 128-byte pitch -- HALF of 16 cache lines, the other half one
+        // instruction later (PMC: 330 MB written for a 268 MB tensor).  The column parities of a row are classes c, c + 1
+        // of the SAME lane: lanes lr and lr ^ 1 trade one of their two packed quads (DPP quad_perm, no LDS), after which
+        // instruction 1 carries the pixel pairs (2 j, 2 j + 1) of the even j and instruction 2 those of the odd j --
+        // whole 128-byte lines each.
+        paired = fast && plain && p.s2d && !rbase;
+        if (paired) {
+          const bool even = (lr & 1) == 0;
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            const int gh = h0 + wave * RW + (nf >> 1);
+            const int gwl = w0 + (nf & 1) * 16 + lr;
+            const int col1 = 2 * gwl + (even ? 0 : -1), col2 = col1 + 2;
+            const bool rowlive = gh < p.Hg && !((CP_ABL & 1) && acc[0][0][nf][0] != 12345.678f);
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+              TY* const rowp = y + (((int64_t)b * p.Hy + 2 * gh + ph) * p.Wy) * p.ldy + o0;
+#pragma unroll
+              for (int mf = 0; mf < MF; mf += 2) {
+                float fa[2][2][4];
+#pragma unroll
+                for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                  for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fa[pw][m][r] = acc[2 * ph + pw][mf + m][nf][r];
+                uint4 pk0, pk1;
+                const int co = pack_pair_bf16(fa[0][0], fa[0][1], lc, pk0);
+                pack_pair_bf16(fa[1][0], fa[1][1], lc, pk1);
+                const uint4 send = even ? pk1 : pk0;
+                uint4 recv;   // the neighbour's (lr ^ 1) quad: quad_perm [1, 0, 3, 2]
+                recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, true);
+                recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, true);
+                recv.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.z, 0xB1, 0xF, 0xF, true);
+                recv.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.w, 0xB1, 0xF, 0xF, true);
+                const uint4 s1 = even ? pk0 : recv, s2 = even ? recv : pk1;
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                TY* const q1 = rowp + (int64_t)col1 * p.ldy + mf * 16 + co;
+                TY* const q2 = rowp + (int64_t)col2 * p.ldy + mf * 16 + co;
+                if (rowlive && col1 < p.Wy) {
+                  if (p.nt) __builtin_nontemporal_store((u32x4){s1.x, s1.y, s1.z, s1.w}, reinterpret_cast<u32x4*>(q1));
+                  else *reinterpret_cast<uint4*>(q1) = s1;
+                }
+                if (rowlive && col2 < p.Wy) {
+                  if (p.nt) __builtin_nontemporal_store((u32x4){s2.x, s2.y, s2.z, s2.w}, reinterpret_cast<u32x4*>(q2));
+                  else *reinterpret_cast<uint4*>(q2) = s2;
+                }
+              }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+              for (int mf = 0; mf < MF; ++mf) acc[c][mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
       // pixel fragment outermost: its 64-bit row address is formed once, the classes add (ooh * Wy + oow) * ldy
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
+      for (int nf = 0; nf < (paired ? 0 : NF); ++nf) {
         const int gh = h0 + wave * RW + (nf >> 1);
         const int gw = w0 + (nf & 1) * 16 + lr;
         const bool live0 = gh < p.Hg && gw < p.Wg;

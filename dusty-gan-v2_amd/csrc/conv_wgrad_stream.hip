@@ -206,21 +206,25 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_stream_kernel(float* __rest
 //    so (ky, kx) are constants of the unrolled MFMA loop: every read is `per-lane offset + immediate`, the
 //    per-lane offsets (3 column shifts x 2 halves + the A offsets) are computed once per block.
 // ---------------------------------------------------------------------------------------------
-template <int S, int MFN, int NFN, bool K3>
+// GO = 2 (round 4): EIGHT waves = two groups of four on two neighbouring 64-channel o-slabs and the SAME c-slab: the
+// input halo tile -- at stride 2 a 5 x 65 pixel tile, 42 of the 50 KB a block stages per pixel tile -- is staged once
+// for 128 output channels (the kernel is bound by its staging, not by the MFMAs: profiles/round4_s2_ablation_start.txt).
+template <int S, int MFN, int NFN, bool K3, int GO = 1>
 struct WZCfg {
+  static constexpr int NTHR = 256 * GO;
   static constexpr int TO = 16 * MFN, TC = 16 * NFN;
   static constexpr int WR = S == 1 ? 4 : 2;
   static constexpr int KK = K3 ? 3 : 1;
   static constexpr int IN_ROWS = (WR - 1) * S + KK, IN_COLS = 31 * S + KK;
   static constexpr int PL = S;                        // column planes per halo row
   static constexpr int PC = (IN_COLS + S - 1) / S;    // columns per plane
-  static constexpr int GV = TO / 8, XV = TC / 8;      // 16-byte slots per pixel
-  static constexpr int NG = (WR * 32 * GV + 255) / 256, NX = (IN_ROWS * IN_COLS * XV + 255) / 256;
+  static constexpr int GV = TO / 8, XV = TC / 8;      // 16-byte slots per pixel (gy: per o-group)
+  static constexpr int NG = (WR * 32 * GV * GO + NTHR - 1) / NTHR, NX = (IN_ROWS * IN_COLS * XV + NTHR - 1) / NTHR;
   static constexpr int MW = NFN == 4 ? MFN : MFN / 2; // o-fragments per wave
   static constexpr int NT = KK * KK;
   static constexpr int NCS = K3 ? (S == 1 ? 3 : 2) : 1;   // distinct column shifts of the taps
-  static constexpr int GY_BYTES = WR * 32 * TO * 2;
-  static constexpr size_t LDS = (size_t)GY_BYTES + (size_t)IN_ROWS * PL * PC * TC * 2;
+  static constexpr int GY_BYTES = WR * 32 * TO * 2;       // one o-group's gy image
+  static constexpr size_t LDS = (size_t)GO * GY_BYTES + (size_t)IN_ROWS * PL * PC * TC * 2;
 };
 
 template <int ROWB>
@@ -237,24 +241,25 @@ __device__ __forceinline__ uint4 wz_tr_read(const char* p0, const char* p1) {
   return r.u;
 }
 
-template <int S, int MFN, int NFN, bool K3>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_stream_bf16_kernel(float* __restrict__ part,
-                                                                        const bf16_t* __restrict__ gy,
-                                                                        const bf16_t* __restrict__ x, WSGeom g) {
-  using Cf = WZCfg<S, MFN, NFN, K3>;
+template <int S, int MFN, int NFN, bool K3, int GO>
+__global__ __launch_bounds__(256 * GO, 2) void conv_wgrad_stream_bf16_kernel(float* __restrict__ part,
+                                                                             const bf16_t* __restrict__ gy,
+                                                                             const bf16_t* __restrict__ x, WSGeom g) {
+  using Cf = WZCfg<S, MFN, NFN, K3, GO>;
   constexpr int TO = Cf::TO, TC = Cf::TC, WR = Cf::WR, KK = Cf::KK, IN_COLS = Cf::IN_COLS, PL = Cf::PL, PC = Cf::PC;
   constexpr int GV = Cf::GV, XV = Cf::XV, NG = Cf::NG, NX = Cf::NX, MW = Cf::MW, NT = Cf::NT, NCS = Cf::NCS;
+  constexpr int NTHR = Cf::NTHR, GVT = GV * GO;
   constexpr int n_x = Cf::IN_ROWS * IN_COLS * XV;
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   uint4* lds_gy = smem;
-  uint4* lds_x = smem + Cf::GY_BYTES / 16;
+  uint4* lds_x = smem + GO * Cf::GY_BYTES / 16;
   const char* lbase = reinterpret_cast<const char*>(smem);
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = (tid >> 6) & 3, grp = tid >> 8, lane = tid & 63;   // grp: the o-group (64-channel slab) of this wave
   const int split = blockIdx.x;
   const int c0 = (blockIdx.y % g.ctiles) * TC;
-  const int o0 = (blockIdx.y / g.ctiles) * TO;
+  const int o0 = (blockIdx.y / g.ctiles) * TO * GO;
   const int off = g.pad;
   const int nf = NFN == 4 ? wave : (wave & 1);
   const int m0w = NFN == 4 ? 0 : (wave >> 1) * MW;
@@ -263,15 +268,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_bf16_kernel(float* _
   int gpix[NG], gw_[NG];
 #pragma unroll
   for (int j = 0; j < NG; ++j) {
-    const int id = tid + j * 256;
-    const int pix = id / GV, c16 = id % GV;
-    gpix[j] = (id < WR * 32 * GV && o0 + c16 * 8 < g.O) ? (((pix >> 5) << 8) | (pix & 31)) : -1;
-    gw_[j] = pix * GV + ((((c16 >> 1) ^ wz_swz<TO * 2>(pix & 31)) << 1) | (c16 & 1));
+    const int id = tid + j * NTHR;
+    const int pix = id / GVT, c16t = id % GVT;        // a pixel's GO * TO channels are contiguous in gy
+    const int c16 = c16t % GV;
+    gpix[j] = (id < WR * 32 * GVT && o0 + c16t * 8 < g.O) ? (((pix >> 5) << 8) | (pix & 31)) : -1;
+    gw_[j] = (c16t / GV) * (Cf::GY_BYTES / 16) + pix * GV + ((((c16 >> 1) ^ wz_swz<TO * 2>(pix & 31)) << 1) | (c16 & 1));
   }
   int xpos[NX], xw_[NX];
 #pragma unroll
   for (int j = 0; j < NX; ++j) {
-    const int id = tid + j * 256;
+    const int id = tid + j * NTHR;
     const int pix = id / XV, c16 = id % XV;
     const int iy = pix / IN_COLS, ix = pix - iy * IN_COLS;
     xpos[j] = (id < n_x && c0 + c16 * 8 < g.C) ? ((iy << 16) | ix) : -1;
@@ -291,15 +297,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_bf16_kernel(float* _
     }
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
-      const int id = tid + j * 256;
+      const int id = tid + j * NTHR;
       const int ho = h0 + (gpix[j] >> 8), wo = w0 + (gpix[j] & 255);
       rg[j] = make_uint4(0, 0, 0, 0);
       if (gpix[j] >= 0 && ho < g.Ho && wo < g.Wo)
-        rg[j] = *reinterpret_cast<const uint4*>(gyb + (ho * g.Wo + wo) * g.O + (id % GV) * 8);
+        rg[j] = *reinterpret_cast<const uint4*>(gyb + (ho * g.Wo + wo) * g.O + (id % GVT) * 8);
     }
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
-      const int id = tid + j * 256;
+      const int id = tid + j * NTHR;
       int hi = h0 * S - off + (xpos[j] >> 16), wi = w0 * S - off + (xpos[j] & 0xffff);
       hi = hi < 0 ? 0 : (hi >= g.H ? g.H - 1 : hi);
       if (g.ring == 2) wi = wi < 0 ? wi + g.W : (wi >= g.W ? wi - g.W : wi);   // host-checked: one wrap suffices
@@ -324,10 +330,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_bf16_kernel(float* _
     const int L = 8 * fg + fq + 4 * h;          // k index (pixel column inside the tile row) of this lane's 4 values
 #pragma unroll
     for (int mw = 0; mw < MW; ++mw)
-      voffA[mw][h] = L * TO * 2 + (((m0w + mw) ^ wz_swz<TO * 2>(L)) * 32) + 8 * fp;
+      voffA[mw][h] = grp * Cf::GY_BYTES + L * TO * 2 + (((m0w + mw) ^ wz_swz<TO * 2>(L)) * 32) + 8 * fp;
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs)
-      voffB[cs][h] = Cf::GY_BYTES + (cs + L) * TC * 2 + ((nf ^ wz_swz<TC * 2>(cs + L)) * 32) + 8 * fp;
+      voffB[cs][h] = GO * Cf::GY_BYTES + (cs + L) * TC * 2 + ((nf ^ wz_swz<TC * 2>(cs + L)) * 32) + 8 * fp;
   }
 
   const int t_begin = split * g.tiles_per_split;
@@ -340,10 +346,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_bf16_kernel(float* _
     __syncthreads();             // every wave has finished reading tile t-1
 #pragma unroll
     for (int j = 0; j < NG; ++j)
-      if (tid + j * 256 < WR * 32 * GV) lds_gy[gw_[j]] = rg[j];
+      if (tid + j * NTHR < WR * 32 * GVT) lds_gy[gw_[j]] = rg[j];
 #pragma unroll
     for (int j = 0; j < NX; ++j)
-      if (tid + j * 256 < n_x) lds_x[xw_[j]] = rx[j];
+      if (tid + j * NTHR < n_x) lds_x[xw_[j]] = rx[j];
     if (t + 1 < t_end) issue();
     __syncthreads();
     if (WS_ABL & 2) continue;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_bf16_kernel(float* _
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int o = o0 + (m0w + mw) * 16 + lc * 4 + r;
+          const int o = o0 + grp * TO + (m0w + mw) * 16 + lc * 4 + r;
           if (o < g.O) pb[((int64_t)o * NT + tap) * g.C + c] = acc[tap][mw][r];
         }
   }
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ g
 struct WSPlan {
   WSGeom g;
   int nsplit, otiles, mfn, nfn;
+  int go;   // o-groups per block (bf16 64 x 64 tiles at stride 2: 2 = eight waves sharing the halo tile)
 };
 
 bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, int pad, int ring, int dtype,
@@ -475,7 +482,9 @@ bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, in
   g.tiles_w = (g.Wo + 31) / 32;
   g.ntiles = B * g.tiles_h * g.tiles_w;
   g.ctiles = (C + 16 * p.nfn - 1) / (16 * p.nfn);
-  p.otiles = (O + 16 * p.mfn - 1) / (16 * p.mfn);
+  static const bool no_go2 = getenv("DGV2_WS_NO_GO2") != nullptr;   // A/B switch for benchmarking
+  p.go = (!no_go2 && dtype == DGV2_BF16 && p.mfn == 4 && p.nfn == 4 && k == 3 && stride == 2 && O % 128 == 0 && !per_image) ? 2 : 1;
+  p.otiles = (O + 16 * p.mfn * p.go - 1) / (16 * p.mfn * p.go);
   const int pairs = g.ctiles * p.otiles;
 #ifdef DGV2_ABLATE
   static const int abl = getenv("DGV2_WS_ABLATE") ? atoi(getenv("DGV2_WS_ABLATE")) : 0;
@@ -486,7 +495,8 @@ bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, in
   // measured against 256: 8x64 256->256 115 -> 85 us, 16x128 128->128 117 -> 90 us, 4x32 544->512 156 -> 103 us
   static const int blocks_big = getenv("DGV2_WS_BLOCKS_BIG") ? atoi(getenv("DGV2_WS_BLOCKS_BIG")) : 512;
   static const int blocks_small = getenv("DGV2_WS_BLOCKS_SMALL") ? atoi(getenv("DGV2_WS_BLOCKS_SMALL")) : 512;
-  int nsplit = (wide32 ? 512 : (p.mfn == 4 && p.nfn == 4) ? blocks_big : blocks_small) / pairs;
+  // (eight-wave blocks: one per CU)
+  int nsplit = (p.go == 2 ? 256 : wide32 ? 512 : (p.mfn == 4 && p.nfn == 4) ? blocks_big : blocks_small) / pairs;
   nsplit = nsplit < 1 ? 1 : (nsplit > g.ntiles ? g.ntiles : nsplit);
   g.tiles_per_split = (g.ntiles + nsplit - 1) / nsplit;
   p.nsplit = (g.ntiles + g.tiles_per_split - 1) / g.tiles_per_split;
@@ -507,8 +517,20 @@ template <typename T, int S, int MFN, int NFN, bool K3>
 int ws_launch(float* part, const void* gy, const void* x, const WSPlan& p, hipStream_t st) {
   dim3 grid(p.nsplit, p.g.ctiles * p.otiles);
   if constexpr (sizeof(T) == 2) {
+    if constexpr (S == 2 && MFN == 4 && NFN == 4 && K3) {
+      if (p.go == 2) {
+        using Cf2 = WZCfg<S, MFN, NFN, K3, 2>;
+        auto kern2 = conv_wgrad_stream_bf16_kernel<S, MFN, NFN, K3, 2>;
+        if (Cf2::LDS > 64 * 1024) {
+          hipError_t e = hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf2::LDS);
+          if (e != hipSuccess) return (int)e;
+        }
+        kern2<<<grid, 512, Cf2::LDS, st>>>(part, (const bf16_t*)gy, (const bf16_t*)x, p.g);
+        return 0;
+      }
+    }
     using Cf = WZCfg<S, MFN, NFN, K3>;
-    auto kern = conv_wgrad_stream_bf16_kernel<S, MFN, NFN, K3>;
+    auto kern = conv_wgrad_stream_bf16_kernel<S, MFN, NFN, K3, 1>;
     if (Cf::LDS > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::LDS);
       if (e != hipSuccess) return (int)e;

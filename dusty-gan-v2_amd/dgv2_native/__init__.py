@@ -119,6 +119,9 @@ SIGNATURES = {
     "dgv2_bmm_tn_stream_x": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 7 + [_c_ptr],
     "dgv2_conv_weight_bank": [_c_ptr] * 8 + [_c_int, _c_int, _c_ptr],
     "dgv2_conv_weight_bank_ex": [_c_ptr] * 10 + [_c_int, _c_int, _c_ptr],
+    "dgv2_glin_fwd": [_c_ptr] * 6 + [_c_int] * 3 + [_c_f32, _c_f32, _c_int, _c_f32, _c_int, _c_ptr, _c_ptr],
+    "dgv2_glin_dinput": [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
+    "dgv2_glin_dweight": [_c_ptr] * 7 + [_c_int] * 3 + [_c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr],
     "dgv2_conv3x3_dgrad8": [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr, _c_int, _c_ptr],
     "dgv2_conv3x3_fwd8": [_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_conv_wgrad_stream_scratch": [_c_ptr] + [_c_int] * 9,

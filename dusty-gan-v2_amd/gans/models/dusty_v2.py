@@ -48,6 +48,28 @@ class MappingNetwork(nn.Sequential):
             ch = out_ch
         super().__init__(*layers)
 
+    def forward(self, z):
+        """PixelNorm -> (EqualLR Linear -> LeakyReLU) x depth.  On the GPU every layer is ONE launch (native.grouped_linear,
+        csrc/glin.hip: the pixel norm rides in the first layer's operand read, bias / gain / leaky ReLU in the epilogue;
+        exact fp32 MFMA) instead of five element-wise ops + addmm + activation per layer in the passes that record no
+        autograd graph (native.glin_wanted: the D step's generator forward, sampling, inference); anything else takes the
+        module-by-module path."""
+        blocks = list(self)[1:]
+        if (z.is_cuda and z.dtype == torch.float32 and z.dim() == 2 and not (z.requires_grad and torch.is_grad_enabled())
+                and native.glin_wanted(*self.parameters())
+                and all(isinstance(b[0], ops.EqualLR) and isinstance(b[0].module, nn.Linear) and b[0].module.bias is not None
+                        for b in blocks)):
+            x = z
+            for i, b in enumerate(blocks):
+                lin = b[0]
+                out = native.grouped_linear(x, [lin.module.weight], [lin.module.bias], lin.scale * lin.gain_, lin.gain_,
+                                            act=True, slope=b[1].negative_slope, prenorm=(i == 0))
+                if out is None:
+                    return super().forward(z)
+                x = out[0]
+            return x
+        return super().forward(z)
+
 
 _BATCHED_PREP = os.environ.get("DGV2_NO_BATCHED_PREP") is None
 

@@ -70,9 +70,127 @@ class _Unpack2d(Function):
 _KIDX_CACHE = {}
 
 
+
+_GLIN = os.environ.get("DGV2_NO_GLIN") is None   # A/B switch for benchmarking
+# Passes that record a graph for autograd keep the library calls unless DGV2_GLIN_GRAD=1: measured on one box the grouped
+# forward + its two backward launches against addmm / baddbmm and their autograd is a wash for the training iteration
+# (4 132 / 4 136 vs 4 150 img/s: the 12 MB weight-gradient launch gives back what the forward saves), while the
+# gradient-free passes -- the D step's generator forward, sampling, BASELINE configs[1] -- gain 12 % (56.2 k vs 50.0 k img/s)
+_GLIN_GRAD = os.environ.get("DGV2_GLIN_GRAD") is not None
+_GLIN_MAX = 24
+
+
+def glin_wanted(*tensors):
+    """Whether a call with these inputs should take the grouped-Linear launches (see _GLIN_GRAD)."""
+    return _GLIN and (_GLIN_GRAD or not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)))
+
+
+def _ptrs(ptrs):
+    return (_ct.c_void_p * len(ptrs))(*[None if v is None else int(v) for v in ptrs])
+
+
+class _GroupedLinear(Function):
+    """y_l = act(alpha * PN(x_l) W_l^T + beta * b_l) for L small Linear layers in ONE launch (csrc/glin.hip: fp32 on
+    v_mfma_f32_16x16x4_f32), backward in two (all weight / bias gradients; the input gradient of the layers that share
+    an input).  x: ONE tensor -- [B, K] read by every layer (the style vector w of a pass whose styles are all the same),
+    or [B, S, K] with layer l reading x[:, kidx[l]].  First order only (the twice-differentiable generator pass keeps the
+    torch ops)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *wb):
+        L = len(wb) // 2
+        ws_, bs_ = wb[:L], wb[L:]
+        alpha, beta, act, slope, prenorm, kidx = cfg
+        x = x.contiguous() if x.dim() == 2 else x
+        B, K = x.shape[0], x.shape[-1]
+        if x.dim() == 3:
+            sB, sS = x.stride(0), x.stride(1)
+            xptr = [x.data_ptr() + 4 * kidx[l] * sS for l in range(L)]
+            lda = [sB] * L
+        else:
+            xptr, lda = [x.data_ptr()] * L, [x.stride(0)] * L
+        Ns = [w.shape[0] for w in ws_]
+        ys = [torch.empty((B, n), device=x.device, dtype=torch.float32) for n in Ns]
+        rn = torch.empty(B, device=x.device, dtype=torch.float32) if prenorm else None
+        N.check(*ws_, *[b for b in bs_ if b is not None])
+        N.call("dgv2_glin_fwd", _ptr_array(ys), _ptrs(xptr), _ptr_array(ws_), _ptr_array(bs_), _int_array(Ns),
+               _int_array(lda), L, B, K, float(alpha), float(beta), int(act), float(slope), int(prenorm), N.ptr(rn),
+               N.stream())
+        ctx.cfg = (cfg, L, Ns, xptr, lda)
+        ctx.save_for_backward(x, rn, *ws_, *(ys if act else ()))
+        ctx.has_bias = [b is not None for b in bs_]
+        return tuple(ys)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        (alpha, beta, act, slope, prenorm, kidx), L, Ns, xptr, lda = ctx.cfg
+        saved = ctx.saved_tensors
+        x, rn, ws_ = saved[0], saved[1], saved[2:2 + L]
+        ys = saved[2 + L:] if act else [None] * L
+        B, K = x.shape[0], x.shape[-1]
+        dev = x.device
+        live = [l for l in range(L) if gs[l] is not None]
+
+        def al16(t):   # gradients may arrive as views at any float offset of a flat buffer (mod_prep_all's backward)
+            t = t.contiguous().float()
+            return t if t.data_ptr() % 16 == 0 else t.clone()
+        gs = [None if g is None else al16(g) for g in gs]
+        gws = [None] * L
+        gbs = [None] * L
+        # inputs of apply(): cfg, x, weights[0..L), biases[0..L)
+        if live and any(ctx.needs_input_grad[2 + l] or ctx.needs_input_grad[2 + L + l] for l in live):
+            for l in live:
+                gws[l] = torch.empty((Ns[l], K), device=dev, dtype=torch.float32)
+                gbs[l] = torch.empty(Ns[l], device=dev, dtype=torch.float32) if ctx.has_bias[l] else None
+            N.call("dgv2_glin_dweight", _ptr_array([gws[l] for l in live]), _ptr_array([gbs[l] for l in live]),
+                   _ptr_array([gs[l] for l in live]), _ptr_array([ys[l] for l in live]), _ptrs([xptr[l] for l in live]),
+                   _int_array([Ns[l] for l in live]), _int_array([lda[l] for l in live]), len(live), B, K, float(alpha),
+                   float(beta), float(slope), N.ptr(rn), N.stream())
+        gx = None
+        if ctx.needs_input_grad[1] and live:
+            if prenorm:
+                raise RuntimeError("dgv2: gradient w.r.t. the input of a pixel-normalised grouped Linear is not built")
+            if x.dim() == 2:
+                gx = torch.empty((B, K), device=dev, dtype=torch.float32)
+                N.call("dgv2_glin_dinput", N.ptr(gx), K, _ptr_array([gs[l] for l in live]), _ptr_array([ys[l] for l in live]),
+                       _ptr_array([ws_[l] for l in live]), _int_array([Ns[l] for l in live]), len(live), B, K, float(alpha),
+                       float(slope), 0, N.stream())
+            else:
+                S = x.shape[1]
+                gx = torch.zeros((B, S, K), device=dev, dtype=torch.float32)
+                for sidx in sorted({kidx[l] for l in live}):
+                    sel = [l for l in live if kidx[l] == sidx]
+                    N.call("dgv2_glin_dinput", gx.data_ptr() + 4 * sidx * K, S * K, _ptr_array([gs[l] for l in sel]),
+                           _ptr_array([ys[l] for l in sel]), _ptr_array([ws_[l] for l in sel]),
+                           _int_array([Ns[l] for l in sel]), len(sel), B, K, float(alpha), float(slope), 0, N.stream())
+        return (None, gx) + tuple(gws) + tuple(gbs)
+
+
+def grouped_linear(x, weights, biases, alpha, beta=1.0, act=False, slope=0.2, prenorm=False, kidx=None):
+    """See _GroupedLinear; weights[l] [N_l, K] fp32 parameters, biases[l] [N_l] or None.  None when the shapes are not
+    covered (callers keep their torch path)."""
+    L = len(weights)
+    K = x.shape[-1]
+    ok = (_GLIN and x.is_cuda and x.dtype == torch.float32 and 1 <= L <= _GLIN_MAX and K % 64 == 0 and x.stride(-1) == 1
+          and all(w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] == K and w.shape[0] % 32 == 0 for w in weights)
+          and (x.dim() == 2 or (x.dim() == 3 and kidx is not None and x.stride(0) % 4 == 0 and x.stride(1) % 4 == 0)))
+    if not ok:
+        return None
+    cfg = (float(alpha), float(beta), bool(act), float(slope), bool(prenorm), None if kidx is None else tuple(kidx))
+    return _GroupedLinear.apply(cfg, x, *weights, *biases)
+
+
 def style_affines(ws, weights, biases, kidx, scale):
     """styles[l] = (ws[:, kidx[l]] @ weights[l].T) * scale + biases[l] for all l at once.
     ws [B,S,K] fp32; weights[l] [I_l,K]; biases[l] [I_l] -> list of contiguous [B, I_l]."""
+    if ws.dtype == torch.float32 and len(weights) <= _GLIN_MAX and glin_wanted(ws, *weights, *biases):
+        # one launch (csrc/glin.hip); a pass whose styles are all the same vector (ws = w[:, None].expand(...): training,
+        # plain sampling) hands over that vector, so that its gradient is ONE launch over the 19 layers as well
+        x = ws[:, 0] if (ws.stride(1) == 0 or ws.shape[1] == 1) else ws
+        out = grouped_linear(x, weights, biases, scale, 1.0, kidx=None if x.dim() == 2 else kidx)
+        if out is not None:
+            return list(out)
     B, S, K = ws.shape
     L = len(weights)
     Is = [w.shape[0] for w in weights]

@@ -761,6 +761,27 @@ int dgv2_conv_taps_fp8(void* y, const void* x8, const void* w8, const float* acc
                        const int* taps_host, int ring, const float* bias, const void* resid, int act, float alpha,
                        float scale, void* stream);
 
+/* Grouped small Linear layers in fp32 on the matrix cores (glin.hip): L <= 24 layers that share the batch B and the
+ * input width K in ONE launch, the layers' parameter addresses as HOST arrays (they travel by value in the kernel
+ * arguments).  y_l [B,N_l] = act( alpha * PN(x_l) W_l^T + beta * bias_l ): x_l rows of K floats at row stride lda[l]
+ * (a style vector inside ws [B,S,K]: lda = S*K), W_l [N_l,K], bias_l [N_l] or NULL; act 0 | 1 = leaky ReLU(slope);
+ * prenorm: rows normalised by rsqrt(mean_k x^2 + 1e-8) first, the factors stored in rnorm [B] when given.
+ * Exact fp32 (v_mfma_f32_16x16x4_f32 = fmaf chains).  K % 64 == 0.
+ * replaces: PixelNorm + EqualLR(nn.Linear) + LeakyReLU of MappingNetwork (gans/models/dusty_v2.py:13-29,
+ * ops/common.py:158-184,213-223) and the style affine ModConv2d.mod of every modulated conv (ops/style.py:30,75). */
+int dgv2_glin_fwd(float* const* y, const float* const* x, const float* const* w, const float* const* bias, const int* N,
+                  const int* lda, int L, int B, int K, float alpha, float beta, int act, float slope, int prenorm,
+                  float* rnorm, void* stream);
+/* Its input gradient: dx [B,K] at row stride ldx (=|+= when accumulate) alpha * sum_l (g_l . act'(y_l)) W_l over the L
+ * layers that read this input; g_l, y_l [B,N_l] contiguous (yact entries NULL: no activation), N_l % 32 == 0. */
+int dgv2_glin_dinput(float* dx, int ldx, const float* const* g, const float* const* yact, const float* const* w,
+                     const int* N, int L, int B, int K, float alpha, float slope, int accumulate, void* stream);
+/* ... and the parameter gradients of all L layers in one launch: dW_l [N_l,K] = alpha * (g_l . act'(y_l))^T (x_l * rnorm),
+ * dbias_l [N_l] = beta * column sums (dbias or entries NULL: skipped); x_l rows at stride ldx[l], rnorm [B] or NULL. */
+int dgv2_glin_dweight(float* const* dw, float* const* dbias, const float* const* g, const float* const* yact,
+                      const float* const* x, const int* N, const int* ldx, int L, int B, int K, float alpha, float beta,
+                      float slope, const float* rnorm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -748,6 +748,69 @@ def test_style_affines_match_per_layer_linear(nat):
         assert_rel(a.cpu(), b, 5e-6)
 
 
+@pytest.mark.parametrize("B,shared", [(5, True), (32, True), (7, False)])
+def test_grouped_linear_style_affines_and_mapping_network(nat, B, shared, monkeypatch):
+    """csrc/glin.hip (dgv2_glin_fwd / _dinput / _dweight) at the generator's own shapes: the 19 style affines of a pass
+    as ONE launch (styles expanded from one vector -- the training case -- or a [B, S, K] tensor with per-layer style
+    indices) and the mapping network (PixelNorm + two EqualLR Linear + LeakyReLU, dusty_v2.py:13-29), values and every
+    gradient against float64 torch ops (reference: style.py:30,75, common.py:158-184,213-223)."""
+    monkeypatch.setattr(nat.modgemm, "_GLIN_GRAD", True)     # (default: gradient-recording passes keep the library calls)
+    g = torch.Generator().manual_seed(3 + B)
+    K, S = 512, 10
+    Is = [512, 512, 512, 1024, 256, 256, 256, 768, 128, 128, 128, 640, 64, 64, 64, 576, 32, 32, 32]
+    kidx = [0, 1, 1, 1, 2, 3, 3, 3, 4, 5, 5, 5, 6, 7, 7, 7, 8, 9, 9]
+    scale = 1.0 / math.sqrt(K)
+    w_lat = torch.randn(B, K, generator=g)
+    ws = w_lat[:, None, :].expand(B, S, K) if shared else torch.randn(B, S, K, generator=g)
+    Ws = [torch.randn(i, K, generator=g) for i in Is]
+    bs = [torch.randn(i, generator=g) for i in Is]
+    gys = [torch.randn(B, i, generator=g) for i in Is]
+    src = (w_lat if shared else ws).double().requires_grad_(True)
+    rws = src[:, None, :].expand(B, S, K) if shared else src
+    ref_p = [t.double().requires_grad_(True) for t in Ws + bs]
+    want = [(rws[:, k] @ ref_p[l].t()) * scale + ref_p[len(Is) + l] for l, k in enumerate(kidx)]
+    gwant = torch.autograd.grad(want, [src] + ref_p, [t.double() for t in gys])
+    dsrc = (w_lat if shared else ws).to(DEV).requires_grad_(True)
+    dws = dsrc[:, None, :].expand(B, S, K) if shared else dsrc
+    dev_p = [t.to(DEV).requires_grad_(True) for t in Ws + bs]
+    got = nat.style_affines(dws, dev_p[:len(Is)], dev_p[len(Is):], kidx, scale)
+    ggot = torch.autograd.grad(got, [dsrc] + dev_p, [t.to(DEV) for t in gys])
+    for a, b in zip(got, want):
+        assert a.is_contiguous()
+        assert_rel(a.cpu(), b.detach(), 3e-6)
+    for a, b in zip(ggot, gwant):
+        assert_rel(a.cpu(), b, 5e-6)
+    # the mapping network as the module runs it
+    from gans.models.dusty_v2 import MappingNetwork
+    net = MappingNetwork(512, 512, 2).to(DEV)
+    with torch.no_grad():
+        for b_ in (net[1][0].module.bias, net[2][0].module.bias):
+            b_.copy_(torch.randn(b_.shape, generator=g))
+    z = torch.randn(B, 512, generator=g).to(DEV)
+    gy = torch.randn(B, 512, generator=g).to(DEV)
+    y = net(z)
+    params = [p for p in net.parameters()]
+    gp = torch.autograd.grad(y, params, gy)
+    zd = z.double().cpu()
+    pd = [p.detach().double().cpu().requires_grad_(True) for p in params]
+    x = zd / zd.pow(2).mean(dim=1, keepdim=True).add(1e-8).sqrt()
+    for i in range(2):
+        lin = net[1 + i][0]
+        x = torch.nn.functional.leaky_relu((x @ pd[2 * i].t()) * (lin.scale * lin.gain_) + pd[2 * i + 1] * lin.gain_, 0.2)
+    gref = torch.autograd.grad(x, pd, gy.double().cpu())
+    assert_rel(y.cpu(), x.detach(), 3e-6, "mapping network")
+    for a, b, n in zip(gp, gref, ("W1", "b1", "W2", "b2")):
+        assert_rel(a.cpu(), b, 1e-5, n)
+    with torch.no_grad():      # the gradient-free pass (always on the grouped launches): same values
+        assert torch.equal(net(z), y.detach())
+        got0 = nat.style_affines(dws.detach(), [t.detach() for t in dev_p[:len(Is)]], [t.detach() for t in dev_p[len(Is):]], kidx, scale)
+        assert all(torch.equal(a, b.detach()) for a, b in zip(got0, got))
+    # a z that requires grad takes the module-by-module path and still differentiates
+    z2 = z.clone().requires_grad_(True)
+    (gz,) = torch.autograd.grad(net(z2).sum(), z2)
+    assert gz.shape == z.shape and torch.isfinite(gz).all()
+
+
 @pytest.mark.parametrize("B,H,W,I,O", [(3, 32, 64, 64, 32), (2, 20, 96, 128, 64), (2, 8, 40, 32, 32)])
 def test_bmm_tn_stream_per_sample_weight_gradient(nat, B, H, W, I, O):
     """dgv2_bmm_tn_stream (streaming split-K engine, every split inside one image) = the per-sample weight

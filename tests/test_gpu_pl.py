@@ -97,7 +97,7 @@ def test_second_order_pass_equals_the_fused_pass_and_the_oracle_double_backward(
     (gw,) = torch.autograd.grad((out["image"] * yy).sum(), w, create_graph=True)
     lengths = gw.pow(2).sum(-1).sqrt()
     assert rel(lengths, len_o) < 1e-3
-    ema = 0.01 * lengths.mean().detach()
+    ema = 0.01 * lengths.mean()       # lerp(0, mean, 0.01), NOT detached: the reference's form (trainer.py:349-353)
     pen = (lengths - ema).pow(2).mean()
     assert abs(float(pen) - float(pen_o)) < 1e-3 * abs(float(pen_o)) and abs(float(ema) - float(ema_o)) < 1e-4 * abs(float(ema_o))
     params = dict(G.named_parameters())
