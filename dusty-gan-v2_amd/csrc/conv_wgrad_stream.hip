@@ -483,7 +483,9 @@ bool ws_plan(WSPlan& p, int B, int H, int W, int C, int O, int k, int stride, in
   g.ntiles = B * g.tiles_h * g.tiles_w;
   g.ctiles = (C + 16 * p.nfn - 1) / (16 * p.nfn);
   static const bool no_go2 = getenv("DGV2_WS_NO_GO2") != nullptr;   // A/B switch for benchmarking
-  p.go = (!no_go2 && dtype == DGV2_BF16 && p.mfn == 4 && p.nfn == 4 && k == 3 && stride == 2 && O % 128 == 0 && !per_image) ? 2 : 1;
+  static const bool go2_s1 = getenv("DGV2_WS_GO2_S1") != nullptr;   // experiment: the stride-1 layers as well
+  p.go = (!no_go2 && dtype == DGV2_BF16 && p.mfn == 4 && p.nfn == 4 && k == 3 && (stride == 2 || go2_s1) && O % 128 == 0 &&
+          !per_image) ? 2 : 1;
   p.otiles = (O + 16 * p.mfn * p.go - 1) / (16 * p.mfn * p.go);
   const int pairs = g.ctiles * p.otiles;
 #ifdef DGV2_ABLATE
@@ -517,7 +519,7 @@ template <typename T, int S, int MFN, int NFN, bool K3>
 int ws_launch(float* part, const void* gy, const void* x, const WSPlan& p, hipStream_t st) {
   dim3 grid(p.nsplit, p.g.ctiles * p.otiles);
   if constexpr (sizeof(T) == 2) {
-    if constexpr (S == 2 && MFN == 4 && NFN == 4 && K3) {
+    if constexpr (MFN == 4 && NFN == 4 && K3) {
       if (p.go == 2) {
         using Cf2 = WZCfg<S, MFN, NFN, K3, 2>;
         auto kern2 = conv_wgrad_stream_bf16_kernel<S, MFN, NFN, K3, 2>;

@@ -48,7 +48,7 @@ def test_fp32_g_and_d_step_match_the_oracle_at_128x1024():
     sdD = recipe.fill_state_dict({k: v.clone() for k, v in D.state_dict().items()}, 4321)
     G.load_state_dict(sdG)
     D.load_state_dict(sdD)
-    B = 1
+    B = 4                # one full minibatch-stddev group (common.py:239-241); round 3 ran B = 1
     g = torch.Generator().manual_seed(3)
     z = torch.randn(B, 512, generator=g)
     shifts = torch.rand(B, generator=g) * 6.2831853
@@ -66,6 +66,15 @@ def test_fp32_g_and_d_step_match_the_oracle_at_128x1024():
         loss_d, grads_d, _, exd = step.d_step(sG, sD, f64(z), f64(ang).repeat_interleave(B, 0), f64(shifts), f64(u), f64(x_real))
     finally:
         torch.set_default_dtype(old)
+    # The yardstick (as at 64 x 512, DESIGN 2 "Rounding yardstick"): the SAME restatement evaluated in float32 -- the
+    # reference's own arithmetic on the reference's own precision -- deviates from its float64 value by the rounding of
+    # sums over 131 k pixels per image.  A gradient tensor is held to 1e-3 of its maximum PLUS that deviation of the
+    # float32 evaluation for the same tensor: "within 1e-3 of the reference's fp32 run" where that run itself is only
+    # defined up to its rounding.
+    _, grads_g32, _, _ = step.g_step(sdG, sdD, z, ang.repeat_interleave(B, 0), shifts, u)
+    _, grads_d32, _, _ = step.d_step(sdG, sdD, z, ang.repeat_interleave(B, 0), shifts, u, x_real)
+    floor_g = {k: err(v, grads_g[k]) for k, v in grads_g32.items() if v is not None}
+    floor_d = {k: err(v, grads_d[k]) for k, v in grads_d32.items()}
 
     G, D = G.to(DEV).train().requires_grad_(True), D.to(DEV).train().requires_grad_(False)
     o = G(z.to(DEV), angle=ang.to(DEV), noise={"shifts": shifts.to(DEV), "gumbel_u": u.to(DEV)})
@@ -80,8 +89,9 @@ def test_fp32_g_and_d_step_match_the_oracle_at_128x1024():
     got = {k: v for k, v in zip(params, torch.autograd.grad(loss, list(params.values()), allow_unused=True)) if v is not None}
     want = {k: v for k, v in grads_g.items() if v is not None}
     assert set(got) == set(want)
-    worst = max((err(got[k], want[k]), k) for k in want)
-    assert worst[0] < 2e-3, worst       # whole tensors; 131 k pixels per image: the fp32 sums are twice as long as at 64 x 512
+    bad = [(k, err(got[k], want[k]), floor_g[k]) for k in want if err(got[k], want[k]) > 1e-3 + floor_g[k]]
+    assert not bad, bad                  # whole tensors
+    assert max(err(got[k], want[k]) for k in want) < 4e-3
 
     D.requires_grad_(True)
     with torch.no_grad():
@@ -92,8 +102,60 @@ def test_fp32_g_and_d_step_match_the_oracle_at_128x1024():
     assert err(lossd, loss_d) < 1e-4
     dparams = dict(D.named_parameters())
     gd = dict(zip(dparams, torch.autograd.grad(lossd, list(dparams.values()))))
-    worst = max((err(gd[k], grads_d[k]), k) for k in grads_d)
-    assert worst[0] < 2e-3, worst
+    bad = [(k, err(gd[k], grads_d[k]), floor_d[k]) for k in grads_d if err(gd[k], grads_d[k]) > 1e-3 + floor_d[k]]
+    assert not bad, bad
+    assert max(err(gd[k], grads_d[k]) for k in grads_d) < 4e-3
+
+
+def test_e4m3_branches_against_the_float64_oracle_at_128x1024():
+    """The e4m3 discriminator (conv2 / skip operands of the four blocks from 64 channels up as OCP e4m3, csrc/fp8.hip)
+    against the ORACLE in float64 on the same weights and inputs -- not against the bf16 HIP path (round 3's test).
+    Tolerances from the rounding model (tests/test_gpu_fp8.py): one e4m3 rounding is <= 2^-4 relative, 1.8 % rms; a
+    contraction whose two operands were rounded independently carries ~2.5-3 % of its output rms whatever K is; two such
+    branches per block join a bf16 residual stream -> trunk features within 3 % x sqrt(2 x 4 blocks) rel-L2 (plus the
+    bf16 trunk's own ~1 %), logits within 0.05 absolute (a freshly initialised discriminator's logits are a
+    near-cancelling sum, |y| ~ 0.05-0.5), parameter gradients pointing the same way (cosine >= 0.98 over all parameters).
+    B = 4 (one minibatch-stddev group): the float64 oracle pass on the host (~6 s per image on 8 cores) is what bounds
+    the batch here; the B = 32 run of the config is test_e4m3_branches_at_128x1024_batch_32."""
+    import recipe
+    from oracle import model, ops as o_ops
+    torch.manual_seed(0)
+    B = 4
+    _, D = build_models(cfg_at(True), "cpu")
+    sdD = recipe.fill_state_dict({k: v.clone() for k, v in D.state_dict().items()}, 4321)
+    D.load_state_dict(sdD)
+    x = (torch.rand(B, 1, *RES, generator=torch.Generator().manual_seed(9)) * 2 - 1)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        sd = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sdD.items()}
+        h = o_ops.blur_vh(x.double(), True)
+        h = o_ops.equal_lr_conv2d(h, sd["layers.1.0.module.weight"], 1, 0, True)
+        h = o_ops.fused_leaky_relu(h, sd["layers.2.bias"])
+        i = 3
+        while f"layers.{i}.conv1.1.module.weight" in sd:
+            h = model.residual_block(sd, f"layers.{i}.", h)
+            i += 1
+        feats_o = h.detach()
+        y_o = model.discriminator(sd, x.double())
+        keys = [k for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad]
+        g_o = dict(zip(keys, torch.autograd.grad(F.softplus(-y_o).mean(), [sd[k] for k in keys], allow_unused=True)))
+    finally:
+        torch.set_default_dtype(old)
+    D = D.to(DEV).requires_grad_(True)
+    D.fp8_branches = True
+    assert D._fp8_bank() is not None and len(D._fp8_bank()) == 8
+    xd = x.to(DEV)
+    feats = D(xd, features_only=True).float().permute(0, 3, 1, 2).cpu().double()     # channels-last -> NCHW
+    rel = float((feats - feats_o).norm() / feats_o.norm())
+    assert rel < 0.03 * math.sqrt(2 * 4) + 0.01, rel
+    y = D(xd)
+    assert float((y.detach().double().cpu() - y_o.detach()).abs().max()) < 0.05
+    gs = dict(zip([k for k, _ in D.named_parameters()], torch.autograd.grad(F.softplus(-y).mean(), list(D.parameters()))))
+    a = torch.cat([gs[k].double().cpu().reshape(-1) for k in keys if g_o[k] is not None and k in gs])
+    b = torch.cat([g_o[k].reshape(-1) for k in keys if g_o[k] is not None and k in gs])
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > 0.98 and bool(torch.isfinite(a).all()), cos
 
 
 def test_bf16_training_iterations_replay_as_graphs_at_128x1024():
