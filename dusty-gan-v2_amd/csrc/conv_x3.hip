@@ -1,0 +1,474 @@
+// fp32 3x3 ring convolutions on the bf16 matrix cores: the discriminator's fp32 epilogue conv
+//   reference: ops.Conv2d(ch(4) + 1, ch(4), 3, 1, 1, ring) of Discriminator.epilogue (gans/models/dusty_v2.py:376-378) under
+//   the fp32 island of Discriminator.forward (:394-395: h.to(torch.float32) in front of the epilogue).
+//
+// The island ran on v_mfma_f32_16x16x4_f32 (conv_pipe_kernel<float>, exact fp32 fma chains) at 0.73-0.78 of that
+// instruction's 157 TFLOP/s -- and was 17 % of the train step's GPU time (five launches of 77 / 39 GFLOP per iteration).
+// gfx950 runs bf16 MFMA at 16x the fp32 MFMA rate, so here every fp32 operand value is split into three bf16 planes
+//     x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)      (|x - h - m - l| <= 2^-26 |x|)
+// and a product a * b is taken as the six bf16 products
+//     a_h b_l + a_h b_m + a_h b_h + a_m b_m + a_m b_h + a_l b_h
+// on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- gemm_x3.hip's scheme (the dropped terms are below 2^-25 of the
+// product, less than the rounding of an fp32 multiply-add chain itself; tests hold the result to the fp32 kernel's own
+// distance from float64).  Six bf16 products cost 3/8 of one fp32 product.
+//
+// Structure: conv8.hip's (eight waves = two groups of four, operands in four 16-byte K planes, nine taps straight-line
+// with immediate LDS offsets, in-place asm MFMAs), with the planes changing what is worth sharing:
+//   * the WEIGHTS arrive pre-split from the weight bank (dgv2_conv_weight_bank_ex with dtype fp32: three staging images,
+//     one per plane, each a contiguous 36 KB run per (64-channel slab, 32-channel chunk));
+//   * the ACTIVATIONS are split while their halo tile is staged (two 16-byte loads -> three 16-byte LDS units);
+//   * a block is two 4 x 32 pixel tiles on ONE 64-channel slab; per 32-channel chunk it runs three stages, one per
+//     weight plane: stage 0 contracts w_h with x_l, x_m, x_h, stage 1 w_m with x_m, x_h, stage 2 w_l with x_h -- a
+//     fragment read serves up to three MFMA groups, 2 MFMAs per ds_read_b128 against conv8's 1.3;
+//   * the weight plane of stage s + 1 is written into the other of two LDS buffers at the start of stage s (its global
+//     loads were issued one stage earlier and land under a whole stage of MFMAs): one barrier per stage.
+// LDS: 2 tiles x 3 planes x 13 KB + 2 x 36 KB = 150 KB, one block per CU.
+// The data gradient is the same kernel on the transposed images with zero rows and the replicate-row border terms
+// (conv8.hip's HZ form); its input channels past the last whole 64-channel slab (the one minibatch-stddev channel of
+// 512 + 1) come from a small exact-fp32 kernel.
+#include <stdlib.h>
+
+#include "gemm_core.h"
+
+namespace {
+
+struct CX3 {
+  int B, H, W, Cx;        // x [B, H, W, Cx] fp32 (Cx % 8 == 0)
+  int nchunks;            // 32-channel chunks of the weight images (= ceil(Cx / 32); channels >= Cx are staged as zeros)
+  int O, ldy;             // output channels written (a multiple of 64) and the row pitch of y
+  int tiles_h, tiles_w, ntiles, npairs, nslab, per_xcd, total;
+  const float* bias;
+  const float* resid;
+  int act;
+  float alpha, scale;
+};
+
+constexpr int X_ICOLS = 34, X_NPIX = 6 * X_ICOLS, X_PIN = 208, X_PW = 9 * 64, X_NI = 4, X_NW = 5;
+constexpr int X_TILE = 3 * 4 * X_PIN;   // 16-byte units of one pixel tile: three split planes x four K planes
+constexpr int X_WBUF = 4 * X_PW;
+constexpr size_t X_LDS = sizeof(uint4) * (2 * X_TILE + 2 * X_WBUF);
+static_assert(X_LDS <= 160 * 1024 - 1024, "LDS image");
+
+// eight fp32 values -> their three bf16 planes (round to nearest even each time; the residuals are exact in fp32)
+__device__ __forceinline__ void split3x8(const float4& lo, const float4& hi, uint4& h, uint4& m, uint4& l) {
+  const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  union { uint4 u; bf16_t e[8]; } ph, pm, pl;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bf16_t hh = (bf16_t)f[i];
+    const float r1 = f[i] - (float)hh;
+    const bf16_t mm = (bf16_t)r1;
+    const float r2 = r1 - (float)mm;
+    ph.e[i] = hh;
+    pm.e[i] = mm;
+    pl.e[i] = (bf16_t)r2;
+  }
+  h = ph.u;
+  m = pm.u;
+  l = pl.u;
+}
+
+// One stage: the nine taps of one weight plane (LDS buffer a_base, this lane's K plane and row) against the NX first
+// split planes of the wave's pixel row (xb: split 0 of this lane's K plane; split q is q * 4 * X_PIN further), smallest
+// plane first.  HZ: conv8.hip's data-gradient form -- `dead` = taps that read only zero rows for this wave's output row.
+template <int NX, int HZ>
+__device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __restrict__ a_base, const uint4* __restrict__ xb,
+                                         const int (&bpix)[2], unsigned dead) {
+  constexpr int SLOTS = 2 * NX;
+  uint4 a[2][4], bb[2][NX];
+  unsigned dd = 0u;
+  if constexpr (HZ != 0) {
+    dd = dead;
+    asm volatile("" : "+s"(dd));   // the bit tests stay in the loop (hoisted, their results live in SGPR pairs that spill)
+  }
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) a[0][mf] = a_base[mf * 16];
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+    for (int q = 0; q < NX; ++q) bb[nf][q] = xb[q * 4 * X_PIN + bpix[nf]];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+      for (int qi = 0; qi < NX; ++qi) {
+        const int q = NX - 1 - qi;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(HZ && ((dd >> t) & 1u))) {
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) MfmaAsm<bf16_t>::run(acc[mf][nf], a[t & 1][mf], bb[nf][q]);
+        }
+        if constexpr (HZ != 0) {
+          // replicate-row border term (conv8.hip): the tap mirrored in dy is dead for this row -> the border row once
+          // more (the pixel fragment of tap (dy = 0, dx)) through the weights in registers right now
+          if (t < 3 || t >= 6) {
+            const int tm = t < 3 ? t + 6 : t - 6;
+            if ((dd >> tm) & 1u) {
+              const uint4 bx = xb[q * 4 * X_PIN + bpix[nf] + X_ICOLS + t % 3];
+#pragma unroll
+              for (int mf = 0; mf < 4; ++mf) MfmaAsm<bf16_t>::run(acc[mf][nf], a[t & 1][mf], bx);
+            }
+          }
+          // compiler-generated VALU instructions of the next group's condition may not write a register the last MFMA
+          // still reads as an operand (scripts/audit_asm_mfma.py): five wait states cover a 4-pass MFMA's source reads
+          asm volatile("s_nop 4");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < 9) {
+          const int ky = (t + 1) / 3, kx = (t + 1) % 3;
+          bb[nf][q] = xb[q * 4 * X_PIN + bpix[nf] + ky * X_ICOLS + kx];
+          const int slot = nf * NX + qi;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k >= slot * 4 / SLOTS && k < (slot + 1) * 4 / SLOTS) a[(t + 1) & 1][k] = a_base[(t + 1) * 64 + k * 16];
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int HZ>
+__global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                         const bf16_t* __restrict__ wimg, CX3 p) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  __shared__ __attribute__((aligned(16))) float s_bias[64];
+  // blocks of one XCD (ids 8 apart) walk a contiguous range of (slab, tile pair) in slab-major order: the three weight
+  // planes of a slab (1.9 MB at 544 channels) stay in that XCD's L2
+  const int n = blockIdx.x, kk = n >> 3;
+  const int item = (n & 7) * p.per_xcd + kk;
+  if (kk >= p.per_xcd || item >= p.total) return;
+  const int slab = item / p.npairs, pair = item - slab * p.npairs;
+
+  const int tid = threadIdx.x;
+  const int t256 = tid & 255, gn = tid >> 8;
+  const int wave4 = (tid >> 6) & 3, lane = tid & 63;
+  const int lr = lane & 15, lc = lane >> 4;
+  uint4* const xs = smem + gn * X_TILE;
+  uint4* const wb = smem + 2 * X_TILE;
+
+  const int q_ = pair * 2 + gn;
+  const bool tile_live = q_ < p.ntiles;
+  const int qc = tile_live ? q_ : p.ntiles - 1;
+  const int per_img = p.tiles_h * p.tiles_w;
+  const int b = qc / per_img, rem = qc - b * per_img;
+  const int h0 = (rem / p.tiles_w) * 4, w0 = (rem % p.tiles_w) * 32;
+  const int o0 = slab * 64;
+  const float* xb_g = x + (int64_t)b * p.H * p.W * p.Cx;
+
+  // ---- staging slots ----
+  const int in_plane = (t256 >> 3) & 3;
+  int goff[X_NI], lrow[X_NI];
+#pragma unroll
+  for (int j = 0; j < X_NI; ++j) {
+    const int u = t256 + 256 * j;
+    const int pix = ((u >> 5) << 3) | (u & 7);
+    const int pl = pix < X_NPIX ? pix : X_NPIX - 1;
+    const int iy = pl / X_ICOLS, ix = pl - iy * X_ICOLS;
+    int gh = h0 - 1 + iy;
+    gh = gh < 0 ? 0 : (gh >= p.H ? p.H - 1 : gh);       // rows clamp (HZ: those rows are only read by dead taps)
+    int gw = w0 - 1 + ix;
+    gw = gw < 0 ? gw + p.W : (gw >= p.W ? gw - p.W : gw);
+    goff[j] = (gh * p.W + gw) * p.Cx + in_plane * 8;
+    lrow[j] = pix < X_NPIX ? pix : -1;
+  }
+  float4 rin[X_NI][2];
+  bool rin_ok = true;
+  auto issue_in = [&](int c0) {
+    // whole 8-channel units (Cx % 8 == 0); a unit past Cx loads channel 0.. of its pixel instead and is staged as zeros
+    // (a conditional load with a zero alternative crashes this compiler's machine copy propagation)
+    rin_ok = c0 + in_plane * 8 < p.Cx;
+    const int cc = rin_ok ? c0 : -in_plane * 8;
+#pragma unroll
+    for (int j = 0; j < X_NI; ++j) {
+      const float4* src = reinterpret_cast<const float4*>(xb_g + cc + goff[j]);
+      rin[j][0] = src[0];
+      rin[j][1] = src[1];
+    }
+  };
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 rwt[X_NW];
+  const size_t plane_units = (size_t)p.nslab * p.nchunks * (X_PW * 4);
+  auto issue_w = [&](int st) {                               // stage st = chunk * 3 + plane
+    const int c = st / 3, pl = st - c * 3;
+    const u32x4* img = reinterpret_cast<const u32x4*>(wimg) + pl * plane_units + ((size_t)slab * p.nchunks + c) * (X_PW * 4) + tid;
+#pragma unroll
+    for (int j = 0; j < X_NW; ++j)
+      if (j < X_NW - 1 || tid + 512 * j < X_PW * 4) rwt[j] = img[512 * j];
+  };
+  const int w_plane = (tid >> 3) & 3, w_row0 = ((tid >> 5) << 3) | (tid & 7);
+  auto write_w = [&](int buf) {
+    uint4* dst = wb + buf * X_WBUF + w_plane * X_PW + w_row0;
+#pragma unroll
+    for (int j = 0; j < X_NW; ++j)
+      if (j < X_NW - 1 || tid + 512 * j < X_PW * 4) *reinterpret_cast<u32x4*>(dst + 128 * j) = rwt[j];
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int bpix[2];
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) bpix[nf] = wave4 * X_ICOLS + nf * 16 + lr;
+  if (tid < 64) s_bias[tid] = p.bias ? p.bias[o0 + tid] : 0.f;
+
+  unsigned dead = 0u;
+  if constexpr (HZ != 0) {
+    const int orow = h0 + wave4;
+    unsigned m = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      if ((unsigned)(orow + t / 3 - 1) >= (unsigned)p.H) m |= 1u << t;
+    dead = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+  }
+
+  const int nst = p.nchunks * 3;
+  issue_w(0);
+  issue_in(0);
+  write_w(0);
+  if (nst > 1) issue_w(1);
+  const uint4* const xlane = xs + lc * X_PIN;
+  for (int c = 0; c < p.nchunks; ++c) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int st = c * 3 + s;
+      if (s == 0) {
+        // every wave has passed the barrier behind the last stage of chunk c - 1: the pixel planes are free
+#pragma unroll
+        for (int j = 0; j < X_NI; ++j) {
+          uint4 h, m, l;
+          split3x8(rin[j][0], rin[j][1], h, m, l);
+          if (!rin_ok) h = m = l = make_uint4(0u, 0u, 0u, 0u);
+          if (lrow[j] >= 0) {
+            uint4* d = xs + in_plane * X_PIN + lrow[j];
+            d[0] = h;
+            d[4 * X_PIN] = m;
+            d[8 * X_PIN] = l;
+          }
+        }
+      }
+      if (st + 1 < nst) write_w((st + 1) & 1);               // the plane of the next stage (loads issued a stage ago)
+      if (s == 0 && c + 1 < p.nchunks) issue_in((c + 1) * 32);
+      if (st + 2 < nst) issue_w(st + 2);
+      if (s == 0) __syncthreads();                           // the pixel planes of chunk c are visible
+      const uint4* a_base = wb + (st & 1) * X_WBUF + lc * X_PW + lr;
+      if (s == 0) x3_stage<3, HZ>(acc, a_base, xlane, bpix, dead);
+      else if (s == 1) x3_stage<2, HZ>(acc, a_base, xlane, bpix, dead);
+      else x3_stage<1, HZ>(acc, a_base, xlane, bpix, dead);
+      __syncthreads();                                       // stage st read; the next stage's weight plane is visible
+    }
+  }
+
+  mfma_drain();
+  const int gh = h0 + wave4;
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) {
+    const int gw = w0 + nf * 16 + lr;
+    const bool live = tile_live && gh < p.H && gw < p.W;
+    const int64_t row = (((int64_t)b * p.H + gh) * p.W + gw) * p.ldy;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+      const int o = o0 + mf * 16 + lc * 4;
+      const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[mf * 16 + lc * 4]);
+      const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+      float f[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = acc[mf][nf][r] + bq[r];
+        if (p.act == 3) t = fmaxf(t, t * p.alpha) * p.scale;   // leaky ReLU, 0 <= alpha <= 1
+        f[r] = t;
+      }
+      if (live && o < p.O) {
+        if (p.resid) {
+          const float4 r4 = *reinterpret_cast<const float4*>(p.resid + row + o);
+          f[0] += r4.x; f[1] += r4.y; f[2] += r4.z; f[3] += r4.w;
+        }
+        *reinterpret_cast<float4*>(y + row + o) = make_float4(f[0], f[1], f[2], f[3]);
+      }
+    }
+  }
+}
+
+// The data gradient's channels past the last whole slab, exact fp32: gx[b, h, w, c] for c0 <= c < c0 + nc:
+//   sum_{ky, kx, o} gy[b, Hz(h + 1 - ky), wrap(w + 1 - kx), o] * wt[c][ky * 3 + kx][o] + the replicate-row terms,
+// and resid / zeros in c0 + nc <= c < cend.  A block is one image row, a wave a quarter of its pixels; per pixel the lanes
+// split the O x 9 contraction (weights and the three gy rows come from L1 / L2: 18 KB + 3 rows per block).
+__global__ __launch_bounds__(256) void x3_dgrad_tail_kernel(float* __restrict__ gx, const float* __restrict__ gy,
+                                                            const float* __restrict__ wt, const float* __restrict__ resid,
+                                                            int B, int H, int W, int ldx, int O, int c0, int nc, int cend) {
+  const int row = blockIdx.x;                  // b * H + h
+  const int b = row / H, h = row - b * H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (W + 3) / 4;
+  const float* gimg = gy + (int64_t)b * H * W * O;
+  for (int ci = 0; ci < nc; ++ci) {
+    const float* wc = wt + (size_t)(c0 + ci) * 9 * O;
+    for (int w = wave * per; w < min(W, (wave + 1) * per); ++w) {
+      float s = 0.f;
+      for (int ob = lane * 4; ob < O; ob += 256) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {          // gy row h + d - 1 through ky = 2 - d; rows outside the image are zero
+          const int gh = h + d - 1;
+          if (gh < 0 || gh >= H) continue;
+          const float* grow = gimg + (int64_t)gh * W * O + ob;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            int j = w + 1 - kx;                // output pixel w sees gy pixel w + 1 - kx through tap kx
+            j = j < 0 ? j + W : (j >= W ? j - W : j);
+            const float4 g = *reinterpret_cast<const float4*>(grow + (int64_t)j * O);
+            float4 k4 = *reinterpret_cast<const float4*>(wc + ((2 - d) * 3 + kx) * O + ob);
+            // replicate padding of the forward: its output row 0 read x row 0 through ky = 0 as well (and row H - 1
+            // through ky = 2): the border gy row (d = 1) once more through that kernel row
+            if (d == 1 && (h == 0 || h == H - 1)) {
+              const float4 e = *reinterpret_cast<const float4*>(wc + ((h == 0 ? 0 : 2) * 3 + kx) * O + ob);
+              k4.x += e.x; k4.y += e.y; k4.z += e.z; k4.w += e.w;
+            }
+            s = fmaf(g.x, k4.x, fmaf(g.y, k4.y, fmaf(g.z, k4.z, fmaf(g.w, k4.w, s))));
+          }
+        }
+      }
+      s = wave_sum(s);
+      if (lane == 0) {
+        const int64_t at = ((int64_t)row * W + w) * ldx + c0 + ci;
+        gx[at] = s + (resid ? resid[at] : 0.f);
+      }
+    }
+  }
+  const int nz = cend - c0 - nc;
+  for (int i = threadIdx.x; i < W * nz; i += 256) {
+    const int64_t at = ((int64_t)row * W + i / nz) * ldx + c0 + nc + i % nz;
+    gx[at] = resid ? resid[at] : 0.f;
+  }
+}
+
+// The plane images from weight VALUES w [O][9][Cp] fp32 (the layout of the conv's own operand) -- for the passes that
+// do not run on the weight bank (R1's double backward): one thread per 16-byte image unit.
+__global__ __launch_bounds__(256) void x3_image_fwd_kernel(bf16_t* __restrict__ w3, const float* __restrict__ w, int O, int Cp,
+                                                           int nch) {
+  const int n = O * 9 * nch * 4;
+  const size_t plane = (size_t)(O >> 6) * nch * (X_PW * 4);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int c8 = i % (nch * 4), r = i / (nch * 4);
+    const int t = r % 9, o = r / 9;
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    if (c8 * 8 < Cp) {   // Cp % 8 == 0
+      const float4* src = reinterpret_cast<const float4*>(w + ((size_t)o * 9 + t) * Cp + c8 * 8);
+      lo = src[0];
+      hi = src[1];
+    }
+    uint4 h, m, l;
+    split3x8(lo, hi, h, m, l);
+    const int row = t * 64 + (o & 63);
+    const size_t unit = ((size_t)(o >> 6) * nch + (c8 >> 2)) * (X_PW * 4) + (row >> 3) * 32 + (c8 & 3) * 8 + (row & 7);
+    uint4* img = reinterpret_cast<uint4*>(w3);
+    img[unit] = h;
+    img[plane + unit] = m;
+    img[2 * plane + unit] = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void x3_image_bwd_kernel(bf16_t* __restrict__ w3t, const float* __restrict__ w, int O, int Cp,
+                                                           int nslab) {
+  const int CS = nslab * 64, nch = O / 32;
+  const int n = CS * 9 * (O / 8);
+  const size_t plane = (size_t)nslab * nch * (X_PW * 4);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int c = i % CS, r = i / CS;
+    const int t = r % 9, o8 = r / 9;
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = w[((size_t)(o8 * 8 + k) * 9 + t) * Cp + c];
+    uint4 h, m, l;
+    split3x8(make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7]), h, m, l);
+    const int row = (8 - t) * 64 + (c & 63);      // the gradient's tap order
+    const size_t unit = ((size_t)(c >> 6) * nch + (o8 >> 2)) * (X_PW * 4) + (row >> 3) * 32 + (o8 & 3) * 8 + (row & 7);
+    uint4* img = reinterpret_cast<uint4*>(w3t);
+    img[unit] = h;
+    img[plane + unit] = m;
+    img[2 * plane + unit] = l;
+  }
+}
+
+template <int HZ>
+int launch_x3(float* y, const float* x, const bf16_t* wimg, CX3 p, hipStream_t st) {
+  auto kern = conv_x3_kernel<HZ>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  p.tiles_h = (p.H + 3) / 4;
+  p.tiles_w = p.W / 32;
+  p.ntiles = p.B * p.tiles_h * p.tiles_w;
+  p.npairs = (p.ntiles + 1) / 2;
+  p.total = p.npairs * p.nslab;
+  p.per_xcd = (p.total + 7) / 8;
+  kern<<<p.per_xcd * 8, 512, X_LDS, st>>>(y, x, wimg, p);
+  return 0;
+}
+
+}  // namespace
+
+// y [B, H, W, O] (fp32) = act( conv3x3_ring(x [B, H, W, Cx] fp32, w) + bias ) * scale + resid, the weights as the three
+// plane images dgv2_conv_weight_bank_ex writes for dtype fp32 (w8: [3][O / 64][ceil(Cx / 32)][2304 units of 8 bf16]).
+// fp32-equivalent (six bf16 products per multiply, fp32 accumulation).  Stride 1, pad 1, rows replicate, columns wrap.
+// DGV2_ENOTSUP where the kernel does not cover the geometry (callers then run dgv2_conv_taps in fp32).
+extern "C" int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B, int H, int W, int Cx, int O,
+                                   const float* bias, const void* resid, int act, float alpha, float scale, void* stream) {
+  if (!y || !x || !w3 || B < 1 || H < 1 || W < 1 || Cx < 1 || O < 1) return DGV2_EINVAL;
+  if (act != 0 && act != 3) return DGV2_EINVAL;
+  static const bool off = getenv("DGV2_NO_CONV_X3") != nullptr;   // A/B switch for benchmarking
+  if (off || W % 32 || Cx % 8 || O % 64 || Cx < 64) return DGV2_ENOTSUP;
+  if (!aligned16(y) || !aligned16(x) || !aligned16(w3) || (resid && !aligned16(resid))) return DGV2_ENOTSUP;
+  if ((int64_t)B * H * W * (Cx > O ? Cx : O) >= (1ll << 31)) return DGV2_ENOTSUP;
+  CX3 p;
+  p.B = B; p.H = H; p.W = W; p.Cx = Cx; p.nchunks = (Cx + 31) / 32; p.O = O; p.ldy = O; p.nslab = O / 64;
+  p.bias = bias; p.resid = (const float*)resid; p.act = act; p.alpha = alpha; p.scale = scale;
+  const int rc = launch_x3<0>((float*)y, (const float*)x, (const bf16_t*)w3, p, (hipStream_t)stream);
+  if (rc) return rc;
+  DGV2_RETURN_LAST();
+}
+
+// The data gradient of the same conv: gx [B, H, W, ldx] (fp32), channels [0, C) = the gradient (+ resid), [C, ldx) = resid
+// or zero.  w3t: the transposed plane images ([3][ldx / 64][O / 32][2304 units], taps in the gradient's order) cover the
+// channels of whole 64-channel slabs below C; wt [ldx, 9, O] fp32 (the bank's transposed layout) serves the up to four
+// channels behind them in exact fp32 (up to 16, a launch pass each).  H >= 2 (a border row may not be its own mirror).
+extern "C" int dgv2_conv3x3_x3_dgrad(void* gx, const void* gy, const void* w3t, const void* wt, int B, int H, int W, int C,
+                                     int ldx, int O, const void* resid, void* stream) {
+  if (!gx || !gy || !w3t || !wt || B < 1 || H < 1 || W < 1 || C < 1 || ldx < C || O < 1) return DGV2_EINVAL;
+  static const bool off = getenv("DGV2_NO_CONV_X3") != nullptr;
+  const int nslab = C / 64, ntail = C - nslab * 64;
+  if (off || H < 2 || W % 32 || O % 32 || O < 64 || nslab < 1 || ntail > 16 || ldx % 4 || nslab != ldx / 64)
+    return DGV2_ENOTSUP;
+  if (!aligned16(gx) || !aligned16(gy) || !aligned16(w3t) || !aligned16(wt) || (resid && !aligned16(resid))) return DGV2_ENOTSUP;
+  if ((int64_t)B * H * W * (ldx > O ? ldx : O) >= (1ll << 31)) return DGV2_ENOTSUP;
+  CX3 p;
+  p.B = B; p.H = H; p.W = W; p.Cx = O; p.nchunks = O / 32; p.O = nslab * 64; p.ldy = ldx; p.nslab = nslab;
+  p.bias = nullptr; p.resid = (const float*)resid; p.act = 0; p.alpha = 0.2f; p.scale = 1.f;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = launch_x3<1>((float*)gx, (const float*)gy, (const bf16_t*)w3t, p, st);
+  if (rc) return rc;
+  if (ldx > nslab * 64)
+    x3_dgrad_tail_kernel<<<B * H, 256, 0, st>>>((float*)gx, (const float*)gy, (const float*)wt, (const float*)resid, B, H, W,
+                                               ldx, O, nslab * 64, ntail, ldx);
+  DGV2_RETURN_LAST();
+}
+
+// The plane images of both entries above from weight VALUES w [O, 9, Cp] fp32 (what dgv2_conv_taps takes) -- for passes
+// that do not run on the weight bank.  w3 [3][O / 64][ceil(Cp / 32)][2304 units], w3t [3][Cp / 64][O / 32][2304 units] or
+// NULL.  O % 64 == 0, Cp % 8 == 0, Cp >= 64.
+extern "C" int dgv2_conv_x3_images(void* w3, void* w3t, const void* w, int O, int Cp, void* stream) {
+  if (!w3 || !w || O < 64 || O % 64 || Cp < 64 || Cp % 8) return DGV2_EINVAL;
+  if (!aligned16(w3) || !aligned16(w) || (w3t && !aligned16(w3t))) return DGV2_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (Cp + 31) / 32;
+  x3_image_fwd_kernel<<<grid_for((int64_t)O * 9 * nch * 4, 256), 256, 0, st>>>((bf16_t*)w3, (const float*)w, O, Cp, nch);
+  if (w3t)
+    x3_image_bwd_kernel<<<grid_for((int64_t)(Cp / 64) * 64 * 9 * (O / 8), 256), 256, 0, st>>>((bf16_t*)w3t, (const float*)w, O,
+                                                                                                 Cp, Cp / 64);
+  DGV2_RETURN_LAST();
+}

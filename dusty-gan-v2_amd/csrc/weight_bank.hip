@@ -122,6 +122,53 @@ __global__ __launch_bounds__(256) void weight_bank_tiled_kernel(BankArgs a) {
       }
     }
   }
+  if constexpr (KK == 9 && sizeof(T) == 4) {
+    // fp32 layers: the images are conv_x3.hip's -- the value split into three bf16 planes (h = bf16(v), m = bf16(v - h),
+    // l = bf16(v - h - m)), one image per plane in the layout above ([3][slab][chunk][2304 units of 8 bf16]); the forward
+    // image has ceil(Cpad / 32) whole chunks (zeros past C), the transposed one the floor(Cpad / 64) whole slabs
+    auto split = [](float v, bf16_t& h, bf16_t& m, bf16_t& l) {
+      h = (bf16_t)v;
+      const float r1 = v - (float)h;
+      m = (bf16_t)r1;
+      l = (bf16_t)(r1 - (float)m);
+    };
+    if (a.w8[l]) {
+      bf16_t* w8 = reinterpret_cast<bf16_t*>(a.w8[l]);
+      const int nchunks = tc;
+      const size_t plane = (size_t)(O >> 6) * nchunks * (576 * 4) * 8;
+      for (int f = threadIdx.x; f < WB_TO * run; f += 256) {
+        const int c = f % WB_TC, r = f / WB_TC;
+        const int t = r % kk, o = r / kk;
+        if (o0 + o < O) {
+          const int og = o0 + o, row = t * 64 + (og & 63), pl = c >> 3;
+          const size_t unit = ((size_t)(og >> 6) * nchunks + c0 / WB_TC) * (576 * 4) + (row >> 3) * 32 + pl * 8 + (row & 7);
+          bf16_t h, m, lo;
+          split(tile[o][c * kk + t], h, m, lo);
+          w8[unit * 8 + (c & 7)] = h;
+          w8[plane + unit * 8 + (c & 7)] = m;
+          w8[2 * plane + unit * 8 + (c & 7)] = lo;
+        }
+      }
+    }
+    if (a.w8t[l]) {
+      bf16_t* w8t = reinterpret_cast<bf16_t*>(a.w8t[l]);
+      const int nchunks = O / 32, nslab = Cp >> 6;
+      const size_t plane = (size_t)nslab * nchunks * (576 * 4) * 8;
+      for (int g = threadIdx.x; g < WB_TO * run; g += 256) {
+        const int o = g % WB_TO, r = g / WB_TO;
+        const int t = r % kk, c = r / kk;
+        if (o0 + o < O && c0 + c < nslab * 64) {
+          const int og = o0 + o, cg = c0 + c, row = (8 - t) * 64 + (cg & 63), pl = (og & 31) >> 3;
+          const size_t unit = ((size_t)(cg >> 6) * nchunks + (og >> 5)) * (576 * 4) + (row >> 3) * 32 + pl * 8 + (row & 7);
+          bf16_t h, m, lo;
+          split(tile[o][c * kk + t], h, m, lo);
+          w8t[unit * 8 + (og & 7)] = h;
+          w8t[plane + unit * 8 + (og & 7)] = m;
+          w8t[2 * plane + unit * 8 + (og & 7)] = lo;
+        }
+      }
+    }
+  }
   for (int g = threadIdx.x; g < WB_TO * run; g += 256) {   // transposed layout: runs of 64 output channels
     const int o = g % WB_TO, r = g / WB_TO;
     const int t = r % kk, c = r / kk;
@@ -146,7 +193,10 @@ extern "C" int dgv2_conv_weight_bank(void* const* wf, void* const* wt, const flo
 // conv (conv8.hip, dgv2_conv3x3_fwd8): [O / 64][Cpad / 32][2304 units of 16 bytes in the kernel's slot order], the same
 // values as wf (needs kk == 9, O % 64 == 0, Cpad % 32 == 0, bf16); w8t[l] != nullptr for the image of its stride-1 data
 // gradient (dgv2_conv3x3_dgrad8): [Cpad / 64][O / 32][2304 units], taps in the gradient's order (needs kk == 9,
-// Cpad % 64 == 0, O % 32 == 0, bf16).  DGV2_EINVAL otherwise; the arrays themselves may be nullptr.
+// Cpad % 64 == 0, O % 32 == 0, bf16).  dtype fp32: the images are conv_x3.hip's -- each value split into three bf16 planes
+// (h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)), one image per plane: w8 [3][O / 64][ceil(Cpad / 32)][2304 units of
+// 8 bf16] (kk == 9, O % 64 == 0, Cpad % 8 == 0), w8t [3][floor(Cpad / 64)][O / 32][2304 units] (the channels of whole
+// 64-channel slabs; kk == 9, Cpad >= 64, O % 32 == 0).  DGV2_EINVAL otherwise; the arrays themselves may be nullptr.
 extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, void* const* w8t,
                                         const float* const* src, const int* O, const int* C, const int* Cpad, const int* kk,
                                         const float* scale, int L, int dtype, void* stream) {
@@ -155,6 +205,11 @@ extern "C" int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* 
   for (int l = 0; l < L; ++l) {
     a.w8[l] = w8 ? w8[l] : nullptr;
     a.w8t[l] = w8t ? w8t[l] : nullptr;
+    if (dtype == DGV2_F32) {   // conv_x3.hip's three-plane images
+      if (a.w8[l] && (kk[l] != 9 || O[l] % 64 || Cpad[l] % 8)) return DGV2_EINVAL;
+      if (a.w8t[l] && (kk[l] != 9 || Cpad[l] < 64 || O[l] % 32)) return DGV2_EINVAL;
+      continue;
+    }
     if (a.w8[l] && (kk[l] != 9 || O[l] % 64 || Cpad[l] % 32 || dtype != DGV2_BF16)) return DGV2_EINVAL;
     if (a.w8t[l] && (kk[l] != 9 || Cpad[l] % 64 || O[l] % 32 || dtype != DGV2_BF16)) return DGV2_EINVAL;
   }

@@ -771,12 +771,14 @@ class Discriminator(nn.Module):
         if len(items) > 32:
             return None
         # the 3x3 convs also get the staging image of the eight-wave forward engine (conv8.hip) where it applies
+        # (the fp32 parity mode keeps its convs on the exact fp32 MFMA: no images)
         prepared = native.conv_weight_bank([e for _, e in items], dt,
-                                           image8=[True if m.geom.stride == 1 else "fwd" for m, _ in items])
+                                           image8=[dt == LOW and (True if m.geom.stride == 1 else "fwd") for m, _ in items])
         bank = {m: (e[1], e[2], wf, wt, w8, w8t) for (m, e), (wf, wt, w8, w8t) in zip(items, prepared)}
         if edt != dt:   # fp32 epilogue behind a reduced-precision trunk: its weight is prepared by a launch of its own
-            (wf, wt), = native.conv_weight_bank([epi[1]], edt)
-            bank[conv] = (epi[1][1], epi[1][2], wf, wt, None, None)
+            # ... with the three-plane bf16 images of conv_x3.hip (fp32 on the bf16 matrix cores) where the shape allows
+            (wf, wt, w8, w8t), = native.conv_weight_bank([epi[1]], edt, image8=[True])
+            bank[conv] = (epi[1][1], epi[1][2], wf, wt, w8, w8t)
         return bank
 
     def _fp8_bank(self):

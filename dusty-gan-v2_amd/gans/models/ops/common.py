@@ -184,6 +184,8 @@ class Conv2d(nn.Sequential):
                 w._dgv2_wf, w._dgv2_wt = ent[2], ent[3]
                 w._dgv2_w8 = ent[4] if len(ent) > 4 else None   # conv8.hip's staging images of the same values
                 w._dgv2_w8t = ent[5] if len(ent) > 5 else None
+                if w._dgv2_w8t is not None:
+                    w._dgv2_w8t._dgv2_clive = int(p_raw.shape[1])   # input channels before padding (conv_x3's data gradient)
                 b, gain = self._params_bias()
             else:
                 ent = None

@@ -79,6 +79,9 @@ def _direct_ok(g, cin):
 _CONV8_IMG = os.environ.get("DGV2_NO_CONV8_IMG") is None   # A/B switch for benchmarking
 
 
+_CONV_X3 = os.environ.get("DGV2_NO_CONV_X3") is None       # A/B switch: fp32 convs as six bf16 products (conv_x3.hip)
+
+
 def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None, w8=None):
     """w8: the weight bank's staging image of the same weights (conv_weight_bank(image8=...)): 3x3 ring convs the
     eight-wave engine covers then run dgv2_conv3x3_fwd8 on it."""
@@ -92,6 +95,11 @@ def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None, w
                                                    g.stride, N.ptr(bias), N.ptr(resid), act, alpha, scale, _dt(x),
                                                    N.stream())):
         return y
+    if (w8 is not None and _CONV_X3 and x.dtype == torch.float32 and w8.dtype == torch.bfloat16 and g.ring
+            and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1)
+            and N.try_call("dgv2_conv3x3_x3_fwd", N.ptr(y), N.ptr(x), N.ptr(w8), B, H, W, C, O, N.ptr(bias), N.ptr(resid),
+                           act, alpha, scale, N.stream())):
+        return y     # fp32 on the bf16 matrix cores (three-plane split, six products per multiply: conv_x3.hip)
     if _direct_ok(g, C % _kstep(x) == 0):
         taps = [(ky - g.pad, kx - g.pad, ky * g.kw + kx) for ky in range(g.kh) for kx in range(g.kw)]
         _conv_taps(y, x, w.reshape(O, g.kh * g.kw, C), Ho, Wo, g.stride, (0, 0), 1, (0, 0), taps, False,
@@ -183,7 +191,8 @@ def _conv_dgrad_direct(gy, wt3, g, xshape, resid=None):
 
 def _conv_dgrad_raw(gy, w, g, xshape, wt=None, resid=None, w8t=None):
     """w [O,kh,kw,C] in gy's dtype, or wt = the prepared transposed weights [C, kh*kw, O] (weight bank); w8t: the
-    bank's staging image of the same transposed weights for the eight-wave engine."""
+    bank's staging image of the same transposed weights for the eight-wave engine (fp32: conv_x3.hip's plane images;
+    the conv's channel count before padding rides on the image as _dgv2_clive)."""
     B, H, W, C = xshape
     O = gy.shape[3]
     if (w8t is not None and _CONV8_IMG and gy.dtype == torch.bfloat16 and g.ring and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1)
@@ -191,6 +200,14 @@ def _conv_dgrad_raw(gy, w, g, xshape, wt=None, resid=None, w8t=None):
         N.check(gy, w8t, resid)
         gx = _conv_dgrad8(gy, w8t, xshape, resid)
         if gx is not None:
+            return gx
+    if (w8t is not None and _CONV_X3 and gy.dtype == torch.float32 and w8t.dtype == torch.bfloat16 and wt is not None
+            and g.ring and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1) and getattr(w8t, "_dgv2_clive", None)):
+        clive = w8t._dgv2_clive
+        N.check(gy, w8t, wt, resid)
+        gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
+        if N.try_call("dgv2_conv3x3_x3_dgrad", N.ptr(gx), N.ptr(gy), N.ptr(w8t), N.ptr(wt), B, H, W, int(clive), C, O,
+                      N.ptr(resid), N.stream()):
             return gx
     if wt is None:   # cached on the values tensor (see modgemm._values): first and second pass of R1 share it
         c = getattr(w, "_dgv2_wt", None)
@@ -289,7 +306,8 @@ def _bank(w, x):
 def _bank8(w, x):
     """The bank's staging image for the eight-wave forward conv (same values as the forward layout), or None."""
     w8 = getattr(w, "_dgv2_w8", None)
-    return w8 if (w8 is not None and w8.dtype == x.dtype and getattr(w, "_dgv2_wf", None) is not None) else None
+    ok = w8 is not None and (w8.dtype == x.dtype or (x.dtype == torch.float32 and w8.dtype == torch.bfloat16))   # fp32: conv_x3's planes
+    return w8 if (ok and getattr(w, "_dgv2_wf", None) is not None) else None
 
 
 class _ConvFwd(Function):
@@ -675,6 +693,18 @@ def conv8_image_ok(p, cpad, dtype):
             and cpad >= 64)
 
 
+def convx3_image_ok(p, cpad, dtype):
+    """fp32 layers: conv_x3.hip's three bf16 plane images of the forward conv (3x3, whole 64-channel slabs) ..."""
+    return (dtype == torch.float32 and _CONV_X3 and tuple(p.shape[2:]) == (3, 3) and p.shape[0] % 64 == 0 and cpad % 8 == 0
+            and cpad >= 64)
+
+
+def convx3t_image_ok(p, cpad, dtype):
+    """... and of its data gradient: whole 64-channel slabs of the input channels, at most four channels behind them."""
+    return (dtype == torch.float32 and _CONV_X3 and tuple(p.shape[2:]) == (3, 3) and p.shape[0] % 32 == 0 and p.shape[0] >= 64
+            and cpad >= 64 and p.shape[1] % 64 <= 4 and p.shape[1] // 64 == cpad // 64)
+
+
 def conv_weight_bank(entries, dtype, image8=None):
     """entries: list of (param fp32 [O,C,kh,kw], scale, Cpad).  One launch; returns [(wf [O,kh*kw,Cpad], wt
     [Cpad,kh*kw,O])] in `dtype` (views of two flat buffers).  image8: list of bools -- also write the staging image of
@@ -709,20 +739,27 @@ def _conv_weight_bank8(entries, dtype, image8):
     flat_f = torch.empty(sum(sizes), device=dev, dtype=dtype)
     flat_t = torch.empty(sum(sizes), device=dev, dtype=dtype)
     # image8 entries: True = both images where the shape allows, "fwd" = only the forward one (stride-2 convs have no
-    # stride-1 data gradient)
-    want = [bool(f) and conv8_image_ok(p, cp, dtype) for f, (p, _, cp) in zip(image8, entries)]
-    want_t = [f is True and conv8t_image_ok(p, cp, dtype) for f, (p, _, cp) in zip(image8, entries)]
-    flat_8 = torch.empty(sum(n for n, f in zip(sizes, want) if f), device=dev, dtype=dtype) if any(want) else None
-    flat_8t = torch.empty(sum(n for n, f in zip(sizes, want_t) if f), device=dev, dtype=dtype) if any(want_t) else None
+    # stride-1 data gradient).  fp32 layers get conv_x3.hip's three-plane bf16 images instead.
+    x3 = dtype == torch.float32
+    want = [bool(f) and (convx3_image_ok if x3 else conv8_image_ok)(p, cp, dtype) for f, (p, _, cp) in zip(image8, entries)]
+    want_t = [f is True and (convx3t_image_ok if x3 else conv8t_image_ok)(p, cp, dtype) for f, (p, _, cp) in zip(image8, entries)]
+    if x3:
+        n8 = [3 * (o // 64) * ((cp + 31) // 32) * 2304 * 8 for o, _, cp, _ in dims]
+        n8t = [3 * (cp // 64) * (o // 32) * 2304 * 8 for o, _, cp, _ in dims]
+    else:
+        n8 = n8t = sizes
+    idt = torch.bfloat16 if x3 else dtype
+    flat_8 = torch.empty(sum(n for n, f in zip(n8, want) if f), device=dev, dtype=idt) if any(want) else None
+    flat_8t = torch.empty(sum(n for n, f in zip(n8t, want_t) if f), device=dev, dtype=idt) if any(want_t) else None
     wfs, wts, w8s, w8ts, off, off8, off8t = [], [], [], [], 0, 0, 0
-    for (o, c, cp, kk), n, f, ft in zip(dims, sizes, want, want_t):
+    for (o, c, cp, kk), n, m8, m8t, f, ft in zip(dims, sizes, n8, n8t, want, want_t):
         wfs.append(flat_f[off:off + n].view(o, kk, cp))
         wts.append(flat_t[off:off + n].view(cp, kk, o))
-        w8s.append(flat_8[off8:off8 + n] if f else None)
-        w8ts.append(flat_8t[off8t:off8t + n] if ft else None)
+        w8s.append(flat_8[off8:off8 + m8] if f else None)
+        w8ts.append(flat_8t[off8t:off8t + m8t] if ft else None)
         off += n
-        off8 += n if f else 0
-        off8t += n if ft else 0
+        off8 += m8 if f else 0
+        off8t += m8t if ft else 0
     srcs = [p.detach() for p, _, _ in entries]
     N.check(*srcs)
     N.call("dgv2_conv_weight_bank_ex", _ptr_array(wfs), _ptr_array(wts), _ptr_array(w8s), _ptr_array(w8ts), _ptr_array(srcs),

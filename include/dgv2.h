@@ -485,7 +485,11 @@ int dgv2_conv_weight_bank(void* const* wf, void* const* wt, const float* const* 
  * the eight-wave forward conv dgv2_conv3x3_fwd8 -- [O / 64][Cpad / 32][2304 units of 16 bytes], unit (row = tap * 64 + o % 64,
  * plane = (c % 32) / 8) at (row >> 3) * 32 + plane * 8 + (row & 7), the order the kernel's staging slots read it: a
  * slab's K-chunk is one contiguous 36 KB run instead of 576 pieces of 64 bytes.  Same values as wf.  Needs kh*kw == 9,
- * O % 64 == 0, Cpad % 32 == 0, DGV2_BF16.  replaces: the same EqualLR weights (common.py:158-210). */
+ * O % 64 == 0, Cpad % 32 == 0, DGV2_BF16.  dtype DGV2_F32: the images are the three-plane images of
+ * dgv2_conv3x3_x3_fwd / _dgrad instead -- every value split as h = bf16(v), m = bf16(v - h), l = bf16(v - h - m), one image
+ * per plane in the layout above: w8 [3][O / 64][ceil(Cpad / 32)][2304] (O % 64 == 0, Cpad % 8 == 0; zeros past C),
+ * w8t [3][floor(Cpad / 64)][O / 32][2304] (O % 32 == 0, Cpad >= 64).
+ * replaces: the same EqualLR weights (common.py:158-210). */
 int dgv2_conv_weight_bank_ex(void* const* wf, void* const* wt, void* const* w8, void* const* w8t,
                              const float* const* src, const int* O, const int* C, const int* Cpad, const int* kk,
                              const float* scale, int L, int dtype, void* stream);
@@ -506,6 +510,30 @@ int dgv2_conv3x3_fwd8(void* y, const void* x, const void* w8, int B, int Hin, in
  * W >= 32 / 64): callers then run dgv2_conv_taps_ex on wt. */
 int dgv2_conv3x3_dgrad8(void* gx, const void* gy, const void* w8t, int B, int H, int W, int C, int O, const void* resid,
                         int dtype, void* stream);
+
+/* fp32 3x3 ring conv (stride 1, pad 1) on the bf16 matrix cores (conv_x3.hip): the fp32 operands as three bf16 planes
+ * each (x = h + m + l), six bf16 products per multiply, fp32 accumulation -- fp32-equivalent (dropped terms < 2^-25 of a
+ * product), at 3/8 of the cost of v_mfma_f32_16x16x4_f32.  w3 = the three plane images dgv2_conv_weight_bank_ex writes
+ * for dtype DGV2_F32 (w8: [3][O / 64][ceil(Cx / 32)][2304 units of 8 bf16]); the activations are split while staged.
+ *   y [B,H,W,O] (fp32) = act( conv(x [B,H,W,Cx] fp32, w) + bias ) * scale + resid,  act 0 | 3, bias [O] or NULL,
+ *   resid like y or NULL.
+ * replaces: ops.Conv2d(ch(4) + 1, ch(4), 3, 1, 1, ring) + FusedLeakyReLU of Discriminator.epilogue
+ * (gans/models/dusty_v2.py:376-379) in the fp32 island of Discriminator.forward (:394-395).  DGV2_ENOTSUP where the
+ * kernel does not cover the geometry (W % 32, Cx % 8, Cx >= 64, O % 64): callers then run dgv2_conv_taps in fp32. */
+int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B, int H, int W, int Cx, int O, const float* bias,
+                        const void* resid, int act, float alpha, float scale, void* stream);
+/* Its data gradient: gx [B,H,W,ldx] (fp32) from gy [B,H,W,O] fp32 -- channels [0, C) the gradient (+ resid), [C, ldx)
+ * resid or zero.  w3t = the transposed plane images (w8t of dgv2_conv_weight_bank_ex, dtype DGV2_F32:
+ * [3][ldx / 64][O / 32][2304 units]) serve the channels of whole 64-channel slabs; wt [ldx, 9, O] fp32 (the bank's
+ * data-gradient layout) the channels behind them in exact fp32, one pass per channel (the minibatch-stddev channel of
+ * 512 + 1; at most 16).  replaces: the cuDNN data gradient autograd calls for that conv.  DGV2_ENOTSUP: H < 2, W % 32,
+ * O % 32, O < 64, C < 64, C % 64 > 16, ldx / 64 != C / 64. */
+int dgv2_conv3x3_x3_dgrad(void* gx, const void* gy, const void* w3t, const void* wt, int B, int H, int W, int C, int ldx,
+                          int O, const void* resid, void* stream);
+/* Both image sets from weight VALUES w [O, 9, Cp] fp32 (the operand layout of dgv2_conv_taps), for passes that do not
+ * run on the weight bank (R1's double backward): w3 [3][O / 64][ceil(Cp / 32)][2304 units of 8 bf16], w3t
+ * [3][Cp / 64][O / 32][2304 units] or NULL.  O % 64 == 0, Cp % 8 == 0, Cp >= 64. */
+int dgv2_conv_x3_images(void* w3, void* w3t, const void* w, int O, int Cp, void* stream);
 
 /* Streaming weight gradient -- the hot-path engine for every discriminator conv (same reference lines as
  * dgv2_conv_wgrad).  A block keeps one (o, c) tile of gw for all k*k taps in registers and streams its

@@ -1027,13 +1027,86 @@ def test_conv8_data_gradient_exact_on_integers(nat, B, H, W, C, O):
     assert torch.equal(nchw(ref), want)
 
 
+X3_CASES = [(4, 4, 32, 513, 512), (1, 4, 32, 72, 64), (3, 8, 64, 64, 128), (2, 6, 32, 130, 64), (5, 2, 96, 200, 192)]
+
+
+@pytest.mark.parametrize("B,H,W,C,O", X3_CASES)
+def test_conv_x3_is_fp32_equivalent(nat, B, H, W, C, O):
+    """conv_x3.hip (dgv2_conv3x3_x3_fwd / _dgrad: the fp32 3x3 ring conv of the discriminator's fp32 epilogue,
+    dusty_v2.py:376-379 under :394-395, on the bf16 matrix cores -- operands as three bf16 planes, six products per multiply)
+    against float64 on data with a wide dynamic range, the error per element relative to sum |x||w|: not above what
+    the exact-fp32 MFMA kernel (dgv2_conv_taps, v_mfma_f32_16x16x4_f32) leaves on the same operands, and bit-exact on
+    small integers.  The epilogue's own shape (513 -> 512 on 4 x 32: a 17th chunk with one live channel, the gradient of
+    that channel from the exact-fp32 tail kernel), an odd tile count, two rows of tiles, ragged H, three tile columns;
+    bias + leaky ReLU + gain in the forward's epilogue, the sibling gradient in the data gradient's."""
+    cpad = (C + 7) // 8 * 8
+    geom = nat.ConvGeom(3, 3, 1, 1, True)
+    for exact in (True, False):
+        g = torch.Generator().manual_seed(B + H + W + C + O + int(exact))
+        if exact:
+            x = torch.randint(-3, 4, (B, C, H, W), generator=g).float()
+            w = torch.randint(-3, 4, (O, C, 3, 3), generator=g).float()
+            bias = torch.randint(-3, 4, (O,), generator=g).float()
+        else:
+            wide = lambda *sh: torch.randn(*sh, generator=g) * torch.exp(2.0 * torch.randn(*sh, generator=g))
+            x, w, bias = wide(B, C, H, W), wide(O, C, 3, 3) / 64, torch.randn(O, generator=g)
+        xr = x.double().requires_grad_(True)
+        t = _conv_oracle(xr, w.double(), 1, 1, True)
+        want = torch.where(t + bias[None, :, None, None] > 0, t + bias[None, :, None, None], 0.25 * (t + bias[None, :, None, None])) * 2.0
+        gy = (torch.randint(-3, 4, t.shape, generator=g).float() if exact else wide(*t.shape))
+        (gx_want,) = torch.autograd.grad(t, [xr], gy.double())
+        resid = torch.randint(-3, 4, (B, C, H, W), generator=g).float() if exact else torch.randn(B, C, H, W, generator=g)
+        gx_want = gx_want + resid.double()
+        bound = _conv_oracle(x.double().abs(), w.double().abs(), 1, 1, True)
+        (wf, wt, w3, w3t), = nat.conv_weight_bank([(w.to(DEV), 1.0, cpad)], torch.float32, image8=[True])
+        assert w3 is not None and w3.dtype == torch.bfloat16
+        xp = torch.zeros(B, H, W, cpad, device=DEV)
+        xp[..., :C] = cl(x)
+        wr = wf.reshape(O, 3, 3, cpad)
+        got = nat._conv_fwd_raw(xp, wr, geom, bias.to(DEV), 3, 0.25, 2.0, w8=w3)
+        ref = nat._conv_fwd_raw(xp, wr, geom, bias.to(DEV), 3, 0.25, 2.0)              # exact fp32 MFMA
+        # the data gradient
+        has_t = C % 64 <= 4 and C // 64 == cpad // 64
+        assert (w3t is not None) == has_t
+        rp = torch.zeros(B, H, W, cpad, device=DEV)
+        rp[..., :C] = cl(resid)
+        gref = nat._conv_dgrad_raw(cl(gy), None, geom, (B, H, W, cpad), wt=wt, resid=rp)
+        if has_t:
+            w3t._dgv2_clive = C
+            ggot = nat._conv_dgrad_raw(cl(gy), None, geom, (B, H, W, cpad), wt=wt, resid=rp, w8t=w3t)
+            assert torch.equal(ggot[..., C:], rp[..., C:])
+        if exact:
+            assert torch.equal(nchw(got).double(), want.detach()) and torch.equal(nchw(ref).double(), want.detach())
+            if has_t:
+                assert torch.equal(nchw(ggot[..., :C]).double(), gx_want)
+        else:
+            err = float(((nchw(got).double() - want.detach()).abs() / (2.0 * bound + 1e-30)).max())
+            err_ref = float(((nchw(ref).double() - want.detach()).abs() / (2.0 * bound + 1e-30)).max())
+            print(f"conv_x3 fwd {B}x{H}x{W} {C}->{O}: err / sum|x||w| = {err:.2e} (fp32 MFMA: {err_ref:.2e})")
+            assert err < 1.5 * err_ref + 4 * 2.0 ** -24, (err, err_ref)
+            if has_t:
+                xa = x.double().abs().requires_grad_(True)
+                (gbound,) = torch.autograd.grad(_conv_oracle(xa, w.double().abs(), 1, 1, True), [xa], gy.double().abs())
+                gbound = gbound + resid.double().abs() + 1e-30
+                e = float(((nchw(ggot[..., :C]).double() - gx_want).abs() / gbound).max())
+                e_ref = float(((nchw(gref[..., :C]).double() - gx_want).abs() / gbound).max())
+                print(f"conv_x3 dgrad: err / sum|gy||w| = {e:.2e} (fp32 MFMA: {e_ref:.2e})")
+                assert e < 1.5 * e_ref + 4 * 2.0 ** -24, (e, e_ref)
+    # a geometry the kernel does not cover reports ENOTSUP (-> False here), it is not mis-computed
+    import dgv2_native as N
+    y = torch.empty(1, 4, 48, 64, device=DEV)
+    assert N.try_call("dgv2_conv3x3_x3_fwd", N.ptr(y), N.ptr(y), N.ptr(w3), 1, 4, 48, 64, 64, None, None, 0, 0.2, 1.0,
+                      N.stream()) is False
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_weight_bank_both_layouts(nat, dtype):
     """wf = scale * w as [O, kh*kw, Cpad] and wt = the same as [Cpad, kh*kw, O], zero padded channels -- exact
     (one rounding of the fp32 product); ragged O / C exercise the tile edges (reference: EqualLR runtime scaling
     + ops.Conv2d weight use, gans/models/ops/common.py:158-210)."""
     g = torch.Generator().manual_seed(21)
-    shapes = [(64, 64, 3, 64), (128, 64, 3, 64), (128, 64, 1, 64), (72, 40, 3, 48), (8, 33, 1, 64), (130, 65, 3, 96)]
+    shapes = [(64, 64, 3, 64), (128, 64, 3, 64), (128, 64, 1, 64), (72, 40, 3, 48), (8, 33, 1, 64), (130, 65, 3, 96),
+              (64, 66, 3, 72)]
     entries, refs = [], []
     for i, (O, C, k, cp) in enumerate(shapes):
         w = torch.randn(O, C, k, k, generator=g)
@@ -1050,6 +1123,35 @@ def test_conv_weight_bank_both_layouts(nat, dtype):
     # (row = tap * 64 + o % 64, plane = (c % 32) / 8) at (row >> 3) * 32 + plane * 8 + (row & 7) -- same values as wf
     out8 = nat.conv_weight_bank(entries, dtype, image8=[True] * len(entries))
     have = [w8 is not None for _, _, w8, _ in out8]
+    if dtype == torch.float32:   # conv_x3.hip's three bf16 plane images (checked below)
+        assert have == [k == 3 and O % 64 == 0 and cp % 8 == 0 and cp >= 64 for O, C, k, cp in shapes]
+        for (wf, wt, w3, w3t), ref, (O, C, k, cp) in zip(out8, refs, shapes):
+            assert torch.equal(wf.cpu(), ref) and torch.equal(wt.cpu(), ref.permute(2, 1, 0))
+            if w3 is None:
+                continue
+            nch = (cp + 31) // 32
+            full = torch.zeros(O, 9, nch * 32)
+            full[:, :, :cp] = ref
+            h = full.bfloat16()
+            m = (full - h.float()).bfloat16()
+            lo = (full - h.float() - m.float()).bfloat16()
+            assert float((h.double() + m.double() + lo.double() - full.double()).abs().max()) <= 2.0 ** -24 * float(full.abs().max())
+            img = w3.cpu().view(3, O // 64, nch, 576 * 4, 8)
+            row, plane = torch.meshgrid(torch.arange(576), torch.arange(4), indexing="ij")
+            unit = (row >> 3) * 32 + plane * 8 + (row & 7)
+            for pl, val in enumerate((h, m, lo)):
+                want = val.view(O // 64, 64, 9, nch, 4, 8).permute(0, 3, 2, 1, 4, 5).reshape(O // 64, nch, 576, 4, 8)
+                assert torch.equal(img[pl][:, :, unit.reshape(-1)].view(O // 64, nch, 576, 4, 8), want)
+            ok_t = O % 32 == 0 and O >= 64 and C % 64 <= 4 and C // 64 == cp // 64
+            assert (w3t is not None) == ok_t
+            if w3t is not None:
+                ns = cp // 64
+                imgt = w3t.cpu().view(3, ns, O // 32, 576 * 4, 8)
+                for pl, val in enumerate((h, m, lo)):
+                    flipped = val[:, :, :ns * 64].flip(1).contiguous()                  # tap t' = 8 - tap
+                    want = flipped.view(O // 32, 4, 8, 9, ns, 64).permute(4, 0, 3, 5, 1, 2).reshape(ns, O // 32, 576, 4, 8)
+                    assert torch.equal(imgt[pl][:, :, unit.reshape(-1)].view(ns, O // 32, 576, 4, 8), want)
+        return
     assert have == [dtype == torch.bfloat16 and k == 3 and O % 64 == 0 and cp % 32 == 0 and cp >= 64 for O, C, k, cp in shapes]
     for (wf, wt, w8, w8t), ref, (O, C, k, cp) in zip(out8, refs, shapes):
         assert torch.equal(wf.cpu(), ref) and torch.equal(wt.cpu(), ref.permute(2, 1, 0))
