@@ -138,7 +138,7 @@ def _time_launches(fn, reps):
     return s.elapsed_time(e) * 1e-3 / reps
 
 
-PMC_FILE = os.path.join("profiles", "round3_pmc.json")
+PMC_FILE = os.path.join("profiles", "round4_pmc.json")
 
 
 PMC_BATCH_PER_GPU = 64   # scripts/pmc_probe.py launches the probes at this --batch-per-gpu
@@ -158,7 +158,7 @@ def _pmc_traffic(kernel_key, batch_per_gpu=PMC_BATCH_PER_GPU):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_*_f32, /opt/skills/guides/MI355X_MICROARCH.md
-STATS_FILE = "profiles/round3_bench_graph_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this command (committed)
+STATS_FILE = "profiles/round4_bench_graph_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this command (committed)
 
 
 def dominant_instance():
@@ -167,7 +167,7 @@ def dominant_instance():
     (the three largest instances are within half a point of each other and trade places between runs)."""
     import csv
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), STATS_FILE)
-    probes = (("wgrad_f32", lambda n: "conv_wgrad_stream_kernel<float, 1, 4, 4, true>" in n),
+    probes = (("conv_x3", lambda n: "conv_x3_kernelILi1E" in n or "conv_x3_kernel<1>" in n),
               # rocprofv3 demangles the bf16 four-class instance badly: <bool _Accum, bLi32ELi1ELi4ELi ...>
               ("s2dgrad", lambda n: "conv_pipe_kernel" in n and "Li32ELi1ELi4ELi" in n),
               ("strip", lambda n: "conv3x3_strip_kernel" in n))
@@ -176,34 +176,46 @@ def dominant_instance():
             for key, pred in probes:
                 if pred(r["Name"]):
                     return key, r["Name"][:96], float(r["Percentage"])
-    return "wgrad_f32", None, None
+    return "conv_x3", None, None
 
 
-def dominant_probe(args, reps=10):
-    """`roofline`: the kernel INSTANCE with the largest share of GPU time in the committed graph kernel statistics
-    (profiles/round3_bench_graph_kernel_stats.csv: conv_wgrad_stream_kernel<float, 1, 4, 4, true>, 5.74 %): the weight
-    gradient of the discriminator's fp32 epilogue conv (reference: autograd of ops.Conv2d(513, 512, 3, 1, 1, ring) at
-    gans/models/dusty_v2.py:377, run in fp32 as the reference does, :394-395) in the D step: x [2B, 4, 32, 528] (513
-    channels padded to whole K-chunks), gy [2B, 4, 32, 512] -> gw [512, 3, 3, 528], exact fp32 on v_mfma_f32_16x16x4_f32.
-    MFMA-bound: 308 FLOP per byte of its operands.  `achieved` counts the algorithmic 513 input channels."""
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def x3_probe(args, reps=10):
+    """`roofline_conv_x3`: conv_x3_kernel<1> (csrc/conv_x3.hip), the largest kernel instance of the round-4 statistics -- the
+    data gradient of the discriminator's fp32 epilogue conv (reference: the cuDNN dgrad autograd calls for
+    ops.Conv2d(513, 512, 3, 1, 1, ring), gans/models/dusty_v2.py:377, in fp32 as the reference runs it, :394-395) in the D
+    step: gy [2B, 4, 32, 512] fp32 -> gx [2B, 4, 32, 528].  fp32 on the bf16 matrix cores: every operand value as three
+    bf16 planes, SIX v_mfma_f32_16x16x32_bf16 products per fp32 multiply (fp32-equivalent: tests/test_gpu_ops.py
+    test_conv_x3_is_fp32_equivalent).  MFMA-bound.  `achieved` = the bf16 MFMA FLOP the kernel issues for the algorithmic
+    fp32 conv (6 x 2 x pixels x 9 x 512 x 512) / time, against the dense bf16 peak; `fp32_equiv_tflops` = the algorithmic
+    fp32 FLOP / time, which `fp32_mfma_peak_frac` prices against the 157.3 TFLOP/s of v_mfma_f32_16x16x4_f32 (what the
+    same conv was bound by in round 3: conv_pipe_kernel<float>, timed beside it here)."""
     from gans.models.ops import native
     if args.dtype == "fp32":
         return None
     B, H, W, C, Cp, O = 2 * args.batch_per_gpu, 4, 32, 513, 528, 512
     g = native.ConvGeom(3, 3, 1, 1, True)
-    x = torch.randn(B, H, W, Cp, device="cuda")
-    x[..., C:] = 0
+    w = torch.randn(O, C, 3, 3, device="cuda") / 64
+    (wf, wt, w3, w3t), = native.conv_weight_bank([(w, 1.0, Cp)], torch.float32, image8=[True])
+    if w3t is None:
+        return None
+    w3t._dgv2_clive = C
     gy = torch.randn(B, H, W, O, device="cuda")
-    sec = _time_launches(lambda: native._conv_wgrad_raw(gy, x, g, 0.01), reps)
-    flops = 2.0 * B * H * W * 9 * C * O
-    nbytes = (B * H * W * (Cp + O) + O * 9 * Cp) * 4
-    ach = flops / sec / 1e12
-    return {"kernel": "conv_wgrad_stream_kernel<float, 1, 4, 4, true> + wgrad_reduce_kernel (dgv2_conv_wgrad_stream_pl: "
-                      "D epilogue conv weight gradient, 2B x 4x32, 513(528)->512, 3x3 ring, fp32)",
-            "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": _pmc_traffic("conv_wgrad_stream_kernel_f32", args.batch_per_gpu),
+    sec = _time_launches(lambda: native._conv_dgrad_raw(gy, None, g, (B, H, W, Cp), wt=wt, w8t=w3t), reps)
+    sec32 = _time_launches(lambda: native._conv_dgrad_raw(gy, None, g, (B, H, W, Cp), wt=wt), reps)
+    flops = 2.0 * B * H * W * 9 * 512 * O            # the 512 channels on the matrix cores (the 513th: exact-fp32 tail kernel)
+    nbytes = (B * H * W * (Cp + O)) * 4 + 3 * 512 * 9 * O * 2
+    ach = 6.0 * flops / sec / 1e12
+    return {"kernel": "conv_x3_kernel<1> + x3_dgrad_tail_kernel (dgv2_conv3x3_x3_dgrad: D epilogue conv data gradient, "
+                      "2B x 4x32, 512 -> 513(528), 3x3 ring, fp32 as 3 bf16 planes x 6 products)",
+            "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": _pmc_traffic("conv_x3_kernel_dgrad", args.batch_per_gpu),
             "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)", "algorithmic_bytes_per_launch": nbytes,
-            "avg_launch_us": sec * 1e6}
+            "avg_launch_us": sec * 1e6, "fp32_equiv_tflops": flops / sec / 1e12,
+            "fp32_mfma_peak_frac": flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "exact_fp32_kernel_us": sec32 * 1e6}
 
 
 def s2dgrad_probe(args, reps=20):
@@ -487,7 +499,7 @@ def main():
         if world == 1:
             raise AssertionError(msg)
         print("bench.py: WARNING: " + msg, file=sys.stderr)   # N > 1: report it in extra.graphs_live, keep the line
-    roof = dominant_probe(args) if rank == 0 else None
+    roof = x3_probe(args) if rank == 0 else None
     roof_s2 = s2dgrad_probe(args) if rank == 0 else None
     roof_strip = roofline_probe(args) if rank == 0 else None
     roof_mod = modconv_probe(args) if rank == 0 else None
@@ -523,14 +535,14 @@ def main():
                        "pe_table_precomputed": os.environ.get("DGV2_NO_CONST_CACHE") is None},
             "model_tflops_per_gpu": value / world * GFLOP_PER_IMG_ITER / 1e3 if args.res == "64x512" else None,
             "extra": extra,
-            "roofline_wgrad_f32": roof,
+            "roofline_conv_x3": roof,
             "roofline_conv_s2dgrad": roof_s2,
             "roofline_strip": roof_strip,
             "roofline_modconv": roof_mod,
         }
         # `roofline` = the probe of the instance the committed statistics rank highest
         key, name, pct = dominant_instance()
-        chosen = {"wgrad_f32": roof, "s2dgrad": roof_s2, "strip": roof_strip}.get(key) or roof
+        chosen = {"conv_x3": roof, "s2dgrad": roof_s2, "strip": roof_strip}.get(key) or roof
         out["roofline"] = None if chosen is None else dict(
             chosen, selected_by=f"largest Percentage among the probed kernel instances in {STATS_FILE}: {pct} % ({key})")
         if world == 1 and not args.no_cpu_baseline:

@@ -410,6 +410,283 @@ __global__ __launch_bounds__(256 * GO, 2) void conv_wgrad_stream_bf16_kernel(flo
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 on the bf16 matrix cores (conv_x3.hip's scheme: every fp32 operand value as three bf16 planes h + m + l, a product as
+// six bf16 products on v_mfma_f32_16x16x32_bf16, fp32 accumulation -- fp32-equivalent at 3/8 of the fp32 MFMA's cost):
+// the weight gradient of the discriminator's fp32 epilogue conv (3x3, stride 1, ring; reference: the autograd of
+// ops.Conv2d(ch(4) + 1, ch(4), 3, 1, 1) at gans/models/dusty_v2.py:377 under the fp32 island of :394-395).
+// The bf16 kernel above with both operands split while they are staged (two 16-byte loads -> one 16-byte unit in each of
+// three LDS images of the same swizzled layout): a wave owns one 16-channel c-fragment x 64 output channels x 9 taps
+// (144 accumulator registers, in place); per 32-pixel tile row it reads 12 gy fragments and 27 halo fragments for 216
+// MFMAs -- 5.5 MFMAs per fragment read against the bf16 kernel's 2.8.  Input channels past the last whole 64-channel
+// c-tile (the minibatch-stddev channel, 512 + 1) are left to conv_wgrad_x3_tail_kernel.
+// ---------------------------------------------------------------------------------------------
+struct WXCfg {
+  static constexpr int WR = 4, IN_ROWS = 6, IN_COLS = 34;
+  static constexpr int NG = 4, NX = (IN_ROWS * IN_COLS * 8 + 255) / 256;
+  static constexpr int GYB = WR * 32 * 64 * 2, XB = IN_ROWS * IN_COLS * 64 * 2;   // one plane's image, bytes
+  static constexpr size_t LDS = 3 * (size_t)GYB + 3 * (size_t)XB;
+};
+
+__device__ __forceinline__ void wx_split8(const float4& lo, const float4& hi, uint4& h, uint4& m, uint4& l) {
+  const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  union { uint4 u; bf16_t e[8]; } ph, pm, pl;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bf16_t hh = (bf16_t)f[i];
+    const float r1 = f[i] - (float)hh;
+    const bf16_t mm = (bf16_t)r1;
+    ph.e[i] = hh;
+    pm.e[i] = mm;
+    pl.e[i] = (bf16_t)(r1 - (float)mm);
+  }
+  h = ph.u;
+  m = pm.u;
+  l = pl.u;
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(float* __restrict__ part, const float* __restrict__ gy,
+                                                               const float* __restrict__ x, WSGeom g) {
+  using Cf = WXCfg;
+  constexpr int WR = Cf::WR, IN_COLS = Cf::IN_COLS, NG = Cf::NG, NX = Cf::NX, GYB = Cf::GYB, XB = Cf::XB;
+  constexpr int n_x = Cf::IN_ROWS * IN_COLS * 8;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  uint4* lds_gy = smem;
+  uint4* lds_x = smem + 3 * GYB / 16;
+  const char* lbase = reinterpret_cast<const char*>(smem);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int split = blockIdx.x;
+  const int c0 = (blockIdx.y % g.ctiles) * 64;
+  const int o0 = (blockIdx.y / g.ctiles) * 64;
+
+  int gpix[NG], gw_[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int id = tid + j * 256;
+    const int pix = id >> 3, c16 = id & 7;
+    gpix[j] = ((pix >> 5) << 8) | (pix & 31);
+    gw_[j] = pix * 8 + ((((c16 >> 1) ^ wz_swz<128>(pix & 31)) << 1) | (c16 & 1));
+  }
+  int xpos[NX], xw_[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const int id = tid + j * 256;
+    const int pix = id >> 3, c16 = id & 7;
+    const int iy = pix / IN_COLS, ix = pix - iy * IN_COLS;
+    xpos[j] = id < n_x ? ((iy << 16) | ix) : -1;
+    xw_[j] = (iy * IN_COLS + ix) * 8 + ((((c16 >> 1) ^ wz_swz<128>(ix)) << 1) | (c16 & 1));
+  }
+
+  float4 rg[NG][2], rx[NX][2];
+  int tw_n, th_n, b_n;
+  auto issue = [&]() {
+    const int h0 = th_n * WR, w0 = tw_n * 32;
+    const float* gyb = gy + (int64_t)b_n * g.Ho * g.Wo * g.O + o0;
+    const float* xb = x + (int64_t)b_n * g.H * g.W * g.C + c0;
+    if (++tw_n == g.tiles_w) {
+      tw_n = 0;
+      if (++th_n == g.tiles_h) { th_n = 0; ++b_n; }
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int id = tid + j * 256;
+      int ho = h0 + (gpix[j] >> 8), wo = w0 + (gpix[j] & 255);
+      const bool ok = ho < g.Ho && wo < g.Wo;
+      ho = ok ? ho : 0;                       // (a conditional load with a zero alternative: see conv_x3.hip)
+      wo = ok ? wo : 0;
+      const float4* src = reinterpret_cast<const float4*>(gyb + (ho * g.Wo + wo) * g.O + (id & 7) * 8);
+      rg[j][0] = src[0];
+      rg[j][1] = src[1];
+      if (!ok) rg[j][0] = rg[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int id = tid + j * 256;
+      const int xp = xpos[j] < 0 ? 0 : xpos[j];
+      int hi = h0 - 1 + (xp >> 16), wi = w0 - 1 + (xp & 0xffff);
+      hi = hi < 0 ? 0 : (hi >= g.H ? g.H - 1 : hi);
+      wi = wi < 0 ? wi + g.W : (wi >= g.W ? wi - g.W : wi);        // host-checked: W % 32 == 0, one wrap suffices
+      const float4* src = reinterpret_cast<const float4*>(xb + (hi * g.W + wi) * g.C + (id & 7) * 8);
+      rx[j][0] = src[0];
+      rx[j][1] = src[1];
+    }
+  };
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mw = 0; mw < 4; ++mw) acc[t][mw] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fg = lane >> 4, fi = lane & 15;
+  const int fq = fi >> 2, fp = fi & 3;
+  int voffA[4][2], voffB[3][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int L = 8 * fg + fq + 4 * h;
+#pragma unroll
+    for (int mw = 0; mw < 4; ++mw) voffA[mw][h] = L * 128 + ((mw ^ wz_swz<128>(L)) * 32) + 8 * fp;
+#pragma unroll
+    for (int cs = 0; cs < 3; ++cs) voffB[cs][h] = 3 * GYB + (cs + L) * 128 + ((wave ^ wz_swz<128>(cs + L)) * 32) + 8 * fp;
+  }
+
+  const int t_begin = split * g.tiles_per_split;
+  const int t_end = min(t_begin + g.tiles_per_split, g.ntiles);
+  tw_n = t_begin % g.tiles_w;
+  th_n = (t_begin / g.tiles_w) % g.tiles_h;
+  b_n = t_begin / (g.tiles_w * g.tiles_h);
+  if (t_begin < t_end) issue();
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();             // every wave has finished reading tile t-1
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      uint4 h, m, l;
+      wx_split8(rg[j][0], rg[j][1], h, m, l);
+      lds_gy[gw_[j]] = h;
+      lds_gy[GYB / 16 + gw_[j]] = m;
+      lds_gy[2 * (GYB / 16) + gw_[j]] = l;
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      uint4 h, m, l;
+      wx_split8(rx[j][0], rx[j][1], h, m, l);
+      if (xpos[j] >= 0) {
+        lds_x[xw_[j]] = h;
+        lds_x[XB / 16 + xw_[j]] = m;
+        lds_x[2 * (XB / 16) + xw_[j]] = l;
+      }
+    }
+    if (t + 1 < t_end) issue();
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < WR; ++r) {
+      uint4 a[3][4];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int mw = 0; mw < 4; ++mw)
+          a[q][mw] = wz_tr_read(lbase + voffA[mw][0] + q * GYB + r * 32 * 128, lbase + voffA[mw][1] + q * GYB + r * 32 * 128);
+      auto bread = [&](int tap, int q) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int imm = q * XB + (r + ky) * IN_COLS * 128;
+        return wz_tr_read(lbase + voffB[kx][0] + imm, lbase + voffB[kx][1] + imm);
+      };
+      uint4 bn[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) bn[q] = bread(0, q);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        uint4 bb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bb[q] = bn[q];
+        if (tap + 1 < 9) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bn[q] = bread(tap + 1, q);
+        }
+        // smallest terms first: gy_h x_l, gy_h x_m, gy_m x_m, gy_l x_h, gy_m x_h, gy_h x_h
+        constexpr int QA[6] = {0, 0, 1, 2, 1, 0}, QB[6] = {2, 1, 1, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+          for (int mw = 0; mw < 4; ++mw) {
+            union { uint4 u; bf16x8 v; } ua, ub;
+            ua.u = a[QA[k]][mw];
+            ub.u = bb[QB[k]];
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[tap][mw]) : "v"(ua.v), "v"(ub.v));
+          }
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int lr = lane & 15, lc = lane >> 4;
+  float* pb = part + (int64_t)split * g.O * 9 * g.C;
+  const int c = c0 + wave * 16 + lr;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int mw = 0; mw < 4; ++mw)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o0 + mw * 16 + lc * 4 + r;
+        pb[((int64_t)o * 9 + tap) * g.C + c] = acc[tap][mw][r];
+      }
+}
+
+// ... and the input channels behind the last whole c-tile, exact fp32 (NC of them at a time, c0 <= c < clive).  The sums
+// run over every output pixel of the batch while the result is 9 x NC numbers per output channel: a block takes a slice
+// of the pixel tiles (its own split axis, TS slices) and 128 output channels, 8 pixel lanes per channel, and leaves
+// tpart[ts][o][tap][k]; conv_wgrad_x3_tail_reduce_kernel folds the slices into part[0] (zeros in the other splits and in
+// clive <= c < C), which the common reduce then treats like the matrix-core columns.
+template <int NC>
+__global__ __launch_bounds__(1024) void conv_wgrad_x3_tail_kernel(float* __restrict__ tpart, const float* __restrict__ gy,
+                                                                  const float* __restrict__ x, WSGeom g, int c0, int tiles_per_ts) {
+  __shared__ float red[8][128];
+  const int ts = blockIdx.x, o0 = blockIdx.y * 128;
+  const int ol = threadIdx.x & 127, pl = threadIdx.x >> 7;
+  const int t_begin = ts * tiles_per_ts, t_end = min(t_begin + tiles_per_ts, g.ntiles);
+  float acc[9][NC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[t][k] = 0.f;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tw = tile % g.tiles_w, th = (tile / g.tiles_w) % g.tiles_h, b = tile / (g.tiles_w * g.tiles_h);
+    const float* gyb = gy + (int64_t)b * g.Ho * g.Wo * g.O + o0 + ol;
+    const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
+#pragma unroll 4
+    for (int p = pl; p < 128; p += 8) {
+      const int ho = th * 4 + (p >> 5), wo = tw * 32 + (p & 31);
+      if (ho >= g.Ho) continue;                 // (W % 32 == 0: no ragged columns)
+      const float gv = gyb[(ho * g.Wo + wo) * g.O];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        int hi = ho + t / 3 - 1, wi = wo + t % 3 - 1;
+        hi = hi < 0 ? 0 : (hi >= g.H ? g.H - 1 : hi);
+        wi = wi < 0 ? wi + g.W : (wi >= g.W ? wi - g.W : wi);
+        const float* xp = xb + (hi * g.W + wi) * g.C;     // wave-uniform
+#pragma unroll
+        for (int k = 0; k < NC; ++k) acc[t][k] = fmaf(gv, xp[k], acc[t][k]);
+      }
+    }
+  }
+  float* out = tpart + ((int64_t)ts * g.O + o0 + ol) * 9 * NC;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      red[pl][ol] = acc[t][k];
+      __syncthreads();
+      if (pl == 0) {
+        float v = red[0][ol];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) v += red[l][ol];
+        out[t * NC + k] = v;
+      }
+      __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_x3_tail_reduce_kernel(float* __restrict__ part, const float* __restrict__ tpart,
+                                                                        int O, int C, int c0, int clive, int NC, int TS, int nsplit) {
+  const int nz = C - c0;
+  const int64_t n = (int64_t)nsplit * O * 9 * nz;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % nz);
+    const int64_t r = i / nz;
+    const int t = (int)(r % 9);
+    const int o = (int)((r / 9) % O), split = (int)(r / 9 / O);
+    float v = 0.f;
+    if (split == 0 && k < NC && c0 + k < clive)
+      for (int s = 0; s < TS; ++s) v += tpart[(((int64_t)s * O + o) * 9 + t) * NC + k];
+    part[(((int64_t)split * O + o) * 9 + t) * C + c0 + k] = v;
+  }
+}
+
 // gw[i] = sum_k part[k][i].  256 threads = 16 float4 columns x 16 split lanes: every lane sums its share
 // of the splits with independent loads, LDS folds the 16 lanes.  n is a multiple of 4.
 // scale: factor on the result; kkC > 0: write the PARAMETER's layout [O, C, kh*kw] instead of [O, kh*kw, C]
@@ -649,4 +926,83 @@ extern "C" int dgv2_conv_wgrad_stream_pl(float* gw, float* scratch, int64_t scra
   wgrad_reduce_kernel<<<(int)((n / 4 + 15) / 16), 256, 0, st>>>(gw, scratch, n, p.nsplit, scale,
                                                                  param_layout ? k * k * C : 0, C);
   DGV2_RETURN_LAST();
+}
+
+// The same weight gradient for the fp32 3x3 stride-1 ring conv on the bf16 matrix cores (conv_wgrad_x3_kernel: both operands
+// as three bf16 planes, six products per multiply; fp32-equivalent):  gw fp32 [O, 9, C] (or the parameter's layout) from
+// gy [B, H, W, O] and x [B, H, W, C] fp32.  Input channels [0, 64 * floor(C / 64)) on the matrix cores, [.., clive) in
+// exact fp32 (at most 16), [clive, C) = 0 (padding channels of x).  scratch: dgv2_conv3x3_x3_wgrad_scratch.
+// DGV2_ENOTSUP where the kernel does not cover the geometry (O % 128, C < 64, C % 8, clive - 64 * floor(C / 64) > 16,
+// W % 32): callers then run dgv2_conv_wgrad_stream_pl.
+extern "C" int dgv2_conv3x3_x3_wgrad(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x, int B,
+                                     int H, int W, int C, int clive, int O, float scale, int param_layout, void* stream) {
+  if (!gw || !scratch || !gy || !x || !aligned16(gy) || !aligned16(x) || !aligned16(scratch) || !aligned16(gw))
+    return DGV2_EINVAL;
+  if (B < 1 || H < 1 || W < 1 || C < 1 || O < 1 || clive < 1 || clive > C) return DGV2_EINVAL;
+  static const bool off = getenv("DGV2_NO_CONV_X3") != nullptr || getenv("DGV2_NO_WGRAD_X3") != nullptr;
+  const int ctiles = C / 64, ntail = clive - ctiles * 64;
+  if (off || O % 64 || ctiles < 1 || C % 8 || ntail > 16 || W % 32) return DGV2_ENOTSUP;
+  if ((int64_t)B * H * W * (C > O ? C : O) >= (1ll << 31)) return DGV2_ENOTSUP;
+  WSPlan p;
+  WSGeom& g = p.g;
+  g = WSGeom{B, H, W, C, O, H, W, 3, 1, 1, 2};
+  g.tiles_h = (H + 3) / 4;
+  g.tiles_w = W / 32;
+  g.ntiles = B * g.tiles_h * g.tiles_w;
+  g.ctiles = ctiles;
+  g.x_shared = 0;
+#ifdef DGV2_ABLATE
+  g.ablate = 0;
+#endif
+  const int pairs = ctiles * (O / 64);
+  int nsplit = 256 / pairs;                 // one block per CU (127 KB of LDS each)
+  nsplit = nsplit < 1 ? 1 : (nsplit > g.ntiles ? g.ntiles : nsplit);
+  g.tiles_per_split = (g.ntiles + nsplit - 1) / nsplit;
+  nsplit = (g.ntiles + g.tiles_per_split - 1) / g.tiles_per_split;
+  const int64_t n = (int64_t)O * 9 * C;
+  const bool tail = C > ctiles * 64;
+  const int NC = ntail <= 1 ? 1 : (ntail <= 4 ? 4 : 16);
+  const int TS = g.ntiles < 64 ? g.ntiles : 64, tiles_per_ts = (g.ntiles + TS - 1) / TS;
+  const int64_t tneed = tail ? (int64_t)TS * O * 9 * NC : 0;
+  if (scratch_elems < (int64_t)nsplit * n + tneed || O % 128) return DGV2_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)WXCfg::LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  conv_wgrad_x3_kernel<<<dim3(nsplit, pairs), 256, WXCfg::LDS, st>>>(scratch, (const float*)gy, (const float*)x, g);
+  if (tail) {
+    float* tpart = scratch + (int64_t)nsplit * n;
+    const dim3 tg(TS, O / 128);
+    const int c0 = ctiles * 64;
+    if (NC == 1) conv_wgrad_x3_tail_kernel<1><<<tg, 1024, 0, st>>>(tpart, (const float*)gy, (const float*)x, g, c0, tiles_per_ts);
+    else if (NC == 4) conv_wgrad_x3_tail_kernel<4><<<tg, 1024, 0, st>>>(tpart, (const float*)gy, (const float*)x, g, c0, tiles_per_ts);
+    else conv_wgrad_x3_tail_kernel<16><<<tg, 1024, 0, st>>>(tpart, (const float*)gy, (const float*)x, g, c0, tiles_per_ts);
+    conv_wgrad_x3_tail_reduce_kernel<<<grid_for((int64_t)nsplit * O * 9 * (C - c0), 256), 256, 0, st>>>(scratch, tpart, O, C, c0,
+                                                                                                      clive, NC, TS, nsplit);
+  }
+  wgrad_reduce_kernel<<<(int)((n / 4 + 15) / 16), 256, 0, st>>>(gw, scratch, n, nsplit, scale, param_layout ? 9 * C : 0, C);
+  DGV2_RETURN_LAST();
+}
+
+// fp32 elements of scratch dgv2_conv3x3_x3_wgrad needs (split-K partials + the tail kernel's slices); 0 and DGV2_ENOTSUP
+// where the geometry is not covered.
+extern "C" int dgv2_conv3x3_x3_wgrad_scratch(int64_t* elems, int B, int H, int W, int C, int clive, int O) {
+  if (!elems) return DGV2_EINVAL;
+  *elems = 0;
+  if (B < 1 || H < 1 || W < 1 || C < 64 || O < 1 || clive < 1 || clive > C) return DGV2_EINVAL;
+  const int ctiles = C / 64, ntail = clive - ctiles * 64;
+  if (O % 128 || C % 8 || ntail > 16 || W % 32) return DGV2_ENOTSUP;
+  const int ntiles = B * ((H + 3) / 4) * (W / 32);
+  int nsplit = 256 / (ctiles * (O / 64));
+  nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
+  const int tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  const int NC = ntail <= 1 ? 1 : (ntail <= 4 ? 4 : 16);
+  const int TS = ntiles < 64 ? ntiles : 64;
+  *elems = (int64_t)nsplit * O * 9 * C + (C > ctiles * 64 ? (int64_t)TS * O * 9 * NC : 0);
+  return 0;
 }

@@ -41,6 +41,12 @@ struct CX3 {
   const float* resid;
   int act;
   float alpha, scale;
+#ifdef DGV2_ABLATE   // benchmarking builds only (make ABLATE=1): wrong results by design, never in the shipped library
+  int ablate;        // DGV2_X3_ABLATE: 2 no MFMA loop, 4 no input loads / split, 8 no weight loads / writes, 16 no barriers' extra (x) sync
+#define X3_ABL (p.ablate)
+#else
+#define X3_ABL 0
+#endif
 };
 
 constexpr int X_ICOLS = 34, X_NPIX = 6 * X_ICOLS, X_PIN = 208, X_PW = 9 * 64, X_NI = 4, X_NW = 5;
@@ -71,9 +77,10 @@ __device__ __forceinline__ void split3x8(const float4& lo, const float4& hi, uin
 // One stage: the nine taps of one weight plane (LDS buffer a_base, this lane's K plane and row) against the NX first
 // split planes of the wave's pixel row (xb: split 0 of this lane's K plane; split q is q * 4 * X_PIN further), smallest
 // plane first.  HZ: conv8.hip's data-gradient form -- `dead` = taps that read only zero rows for this wave's output row.
-template <int NX, int HZ>
+// `side(t)` runs once behind the MFMA groups of tap t: the staging work of the coming stages, issued under this stage's MFMAs.
+template <int NX, int HZ, typename Side>
 __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __restrict__ a_base, const uint4* __restrict__ xb,
-                                         const int (&bpix)[2], unsigned dead) {
+                                         const int (&bpix)[2], unsigned dead, Side&& side) {
   constexpr int SLOTS = 2 * NX;
   uint4 a[2][4], bb[2][NX];
   unsigned dd = 0u;
@@ -125,6 +132,11 @@ __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __rest
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // five wait states: the side work's VALU results (conditions, the split) may be allocated to registers the last MFMA
+    // is still reading as operands; the hazard recogniser does not see inside the asm (scripts/audit_asm_mfma.py)
+    asm volatile("s_nop 4");
+    side(t);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -226,39 +238,84 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
   }
 
   const int nst = p.nchunks * 3;
+  // slot j of the weight plane: store it into the OTHER buffer (stage st + 1's plane, in registers since the stage before)
+  // and reload the register with stage st + 2's
+  auto w_slot = [&](int st, int j) {
+    if (X3_ABL & 8) return;
+    const bool in = j < X_NW - 1 || tid + 512 * j < X_PW * 4;
+    if (st + 1 < nst && in) {
+      uint4* dst = wb + ((st + 1) & 1) * X_WBUF + w_plane * X_PW + w_row0;
+      *reinterpret_cast<u32x4*>(dst + 128 * j) = rwt[j];
+    }
+    if (st + 2 < nst && in) {
+      const int c = (st + 2) / 3, pl = (st + 2) - c * 3;
+      const u32x4* img = reinterpret_cast<const u32x4*>(wimg) + pl * plane_units + ((size_t)slab * p.nchunks + c) * (X_PW * 4) + tid;
+      rwt[j] = img[512 * j];
+    }
+  };
+  uint4 xh[X_NI];                            // plane h of the coming chunk's pixels between their split and the boundary
+  // split slot j of the pixels in registers; planes m and l go to LDS at once, h waits in xh
+  auto split_store = [&](int j, bool all) {
+    uint4 m, l;
+    split3x8(rin[j][0], rin[j][1], xh[j], m, l);
+    if (!rin_ok) xh[j] = m = l = make_uint4(0u, 0u, 0u, 0u);
+    if (lrow[j] >= 0) {
+      uint4* d = xs + in_plane * X_PIN + lrow[j];
+      if (all) d[0] = xh[j];
+      d[4 * X_PIN] = m;
+      d[8 * X_PIN] = l;
+    }
+  };
+
   issue_w(0);
   issue_in(0);
   write_w(0);
   if (nst > 1) issue_w(1);
+#pragma unroll
+  for (int j = 0; j < X_NI; ++j) split_store(j, true);
+  if (p.nchunks > 1) issue_in(32);
+  __syncthreads();
   const uint4* const xlane = xs + lc * X_PIN;
   for (int c = 0; c < p.nchunks; ++c) {
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int st = c * 3 + s;
-      if (s == 0) {
-        // every wave has passed the barrier behind the last stage of chunk c - 1: the pixel planes are free
-#pragma unroll
-        for (int j = 0; j < X_NI; ++j) {
-          uint4 h, m, l;
-          split3x8(rin[j][0], rin[j][1], h, m, l);
-          if (!rin_ok) h = m = l = make_uint4(0u, 0u, 0u, 0u);
-          if (lrow[j] >= 0) {
-            uint4* d = xs + in_plane * X_PIN + lrow[j];
-            d[0] = h;
-            d[4 * X_PIN] = m;
-            d[8 * X_PIN] = l;
-          }
+    const bool more = c + 1 < p.nchunks && !(X3_ABL & 4);
+    const int st = c * 3;
+    // stage 0: w_h x (x_l, x_m, x_h); under it the weight slots of the coming stages
+    if (!(X3_ABL & 2))
+      x3_stage<3, HZ>(acc, wb + (st & 1) * X_WBUF + lc * X_PW + lr, xlane, bpix, dead, [&](int t) {
+        if (t < X_NW) w_slot(st, t);
+      });
+    else
+      for (int t = 0; t < X_NW; ++t) w_slot(st, t);
+    __syncthreads();
+    // stage 1: w_m x (x_m, x_h)
+    if (!(X3_ABL & 2))
+      x3_stage<2, HZ>(acc, wb + ((st + 1) & 1) * X_WBUF + lc * X_PW + lr, xlane, bpix, dead, [&](int t) {
+        if (t < X_NW) w_slot(st + 1, t);
+      });
+    else
+      for (int t = 0; t < X_NW; ++t) w_slot(st + 1, t);
+    __syncthreads();
+    // stage 2: w_l x x_h -- planes m and l of the pixel tiles are no longer read: the coming chunk's pixels (loaded two
+    // stages ago) are split under it, m and l stored at once
+    if (!(X3_ABL & 2))
+      x3_stage<1, HZ>(acc, wb + (st & 1) * X_WBUF + lc * X_PW + lr, xlane, bpix, dead, [&](int t) {
+        if (t < X_NW) w_slot(st + 2, t);
+        if (more && t >= 9 - 2 * X_NI && ((t - (9 - 2 * X_NI)) & 1) == 0) {
+          split_store((t - (9 - 2 * X_NI)) >> 1, false);
         }
-      }
-      if (st + 1 < nst) write_w((st + 1) & 1);               // the plane of the next stage (loads issued a stage ago)
-      if (s == 0 && c + 1 < p.nchunks) issue_in((c + 1) * 32);
-      if (st + 2 < nst) issue_w(st + 2);
-      if (s == 0) __syncthreads();                           // the pixel planes of chunk c are visible
-      const uint4* a_base = wb + (st & 1) * X_WBUF + lc * X_PW + lr;
-      if (s == 0) x3_stage<3, HZ>(acc, a_base, xlane, bpix, dead);
-      else if (s == 1) x3_stage<2, HZ>(acc, a_base, xlane, bpix, dead);
-      else x3_stage<1, HZ>(acc, a_base, xlane, bpix, dead);
-      __syncthreads();                                       // stage st read; the next stage's weight plane is visible
+      });
+    else {
+      for (int t = 0; t < X_NW; ++t) w_slot(st + 2, t);
+      if (more)
+        for (int j = 0; j < X_NI; ++j) split_store(j, false);
+    }
+    __syncthreads();                                         // chunk c read
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < X_NI; ++j)
+        if (lrow[j] >= 0) xs[in_plane * X_PIN + lrow[j]] = xh[j];
+      if (c + 2 < p.nchunks) issue_in((c + 2) * 32);
+      __syncthreads();                                       // plane h of chunk c + 1 visible
     }
   }
 
@@ -304,10 +361,14 @@ __global__ __launch_bounds__(256) void x3_dgrad_tail_kernel(float* __restrict__ 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = (W + 3) / 4;
   const float* gimg = gy + (int64_t)b * H * W * O;
+  const bool border = h == 0 || h == H - 1;
   for (int ci = 0; ci < nc; ++ci) {
     const float* wc = wt + (size_t)(c0 + ci) * 9 * O;
-    for (int w = wave * per; w < min(W, (wave + 1) * per); ++w) {
-      float s = 0.f;
+    // eight pixels at a time: their loads are independent (one pixel after the other was a chain of L2 latencies)
+    for (int w0 = wave * per; w0 < min(W, (wave + 1) * per); w0 += 8) {
+      float s[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] = 0.f;
       for (int ob = lane * 4; ob < O; ob += 256) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {          // gy row h + d - 1 through ky = 2 - d; rows outside the image are zero
@@ -316,24 +377,32 @@ __global__ __launch_bounds__(256) void x3_dgrad_tail_kernel(float* __restrict__ 
           const float* grow = gimg + (int64_t)gh * W * O + ob;
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
-            int j = w + 1 - kx;                // output pixel w sees gy pixel w + 1 - kx through tap kx
-            j = j < 0 ? j + W : (j >= W ? j - W : j);
-            const float4 g = *reinterpret_cast<const float4*>(grow + (int64_t)j * O);
             float4 k4 = *reinterpret_cast<const float4*>(wc + ((2 - d) * 3 + kx) * O + ob);
             // replicate padding of the forward: its output row 0 read x row 0 through ky = 0 as well (and row H - 1
             // through ky = 2): the border gy row (d = 1) once more through that kernel row
-            if (d == 1 && (h == 0 || h == H - 1)) {
+            if (d == 1 && border) {
               const float4 e = *reinterpret_cast<const float4*>(wc + ((h == 0 ? 0 : 2) * 3 + kx) * O + ob);
               k4.x += e.x; k4.y += e.y; k4.z += e.z; k4.w += e.w;
             }
-            s = fmaf(g.x, k4.x, fmaf(g.y, k4.y, fmaf(g.z, k4.z, fmaf(g.w, k4.w, s))));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              int j = w0 + k + 1 - kx;         // output pixel w sees gy pixel w + 1 - kx through tap kx
+              j = j < 0 ? j + W : (j >= W ? j - W : j);
+              j = j >= W ? 0 : j;              // (pixels past the wave's share: computed, not stored)
+              const float4 g = *reinterpret_cast<const float4*>(grow + (int64_t)j * O);
+              s[k] = fmaf(g.x, k4.x, fmaf(g.y, k4.y, fmaf(g.z, k4.z, fmaf(g.w, k4.w, s[k]))));
+            }
           }
         }
       }
-      s = wave_sum(s);
-      if (lane == 0) {
-        const int64_t at = ((int64_t)row * W + w) * ldx + c0 + ci;
-        gx[at] = s + (resid ? resid[at] : 0.f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = wave_sum(s[k]);
+        const int w = w0 + k;
+        if (lane == 0 && w < min(W, (wave + 1) * per)) {
+          const int64_t at = ((int64_t)row * W + w) * ldx + c0 + ci;
+          gx[at] = v + (resid ? resid[at] : 0.f);
+        }
       }
     }
   }
@@ -407,6 +476,9 @@ int launch_x3(float* y, const float* x, const bf16_t* wimg, CX3 p, hipStream_t s
   p.npairs = (p.ntiles + 1) / 2;
   p.total = p.npairs * p.nslab;
   p.per_xcd = (p.total + 7) / 8;
+#ifdef DGV2_ABLATE
+  p.ablate = getenv("DGV2_X3_ABLATE") ? atoi(getenv("DGV2_X3_ABLATE")) : 0;
+#endif
   kern<<<p.per_xcd * 8, 512, X_LDS, st>>>(y, x, wimg, p);
   return 0;
 }
@@ -459,14 +531,15 @@ extern "C" int dgv2_conv3x3_x3_dgrad(void* gx, const void* gy, const void* w3t, 
 }
 
 // The plane images of both entries above from weight VALUES w [O, 9, Cp] fp32 (what dgv2_conv_taps takes) -- for passes
-// that do not run on the weight bank.  w3 [3][O / 64][ceil(Cp / 32)][2304 units], w3t [3][Cp / 64][O / 32][2304 units] or
-// NULL.  O % 64 == 0, Cp % 8 == 0, Cp >= 64.
+// that do not run on the weight bank.  w3 [3][O / 64][ceil(Cp / 32)][2304 units], w3t [3][Cp / 64][O / 32][2304 units]; either
+// may be NULL.  O % 64 == 0, Cp % 8 == 0, Cp >= 64.
 extern "C" int dgv2_conv_x3_images(void* w3, void* w3t, const void* w, int O, int Cp, void* stream) {
-  if (!w3 || !w || O < 64 || O % 64 || Cp < 64 || Cp % 8) return DGV2_EINVAL;
-  if (!aligned16(w3) || !aligned16(w) || (w3t && !aligned16(w3t))) return DGV2_EINVAL;
+  if ((!w3 && !w3t) || !w || O < 64 || O % 64 || Cp < 64 || Cp % 8) return DGV2_EINVAL;
+  if ((w3 && !aligned16(w3)) || !aligned16(w) || (w3t && !aligned16(w3t))) return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nch = (Cp + 31) / 32;
-  x3_image_fwd_kernel<<<grid_for((int64_t)O * 9 * nch * 4, 256), 256, 0, st>>>((bf16_t*)w3, (const float*)w, O, Cp, nch);
+  if (w3)
+    x3_image_fwd_kernel<<<grid_for((int64_t)O * 9 * nch * 4, 256), 256, 0, st>>>((bf16_t*)w3, (const float*)w, O, Cp, nch);
   if (w3t)
     x3_image_bwd_kernel<<<grid_for((int64_t)(Cp / 64) * 64 * 9 * (O / 8), 256), 256, 0, st>>>((bf16_t*)w3t, (const float*)w, O,
                                                                                                  Cp, Cp / 64);

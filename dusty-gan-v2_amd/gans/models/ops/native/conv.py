@@ -4,6 +4,7 @@ Part of gans.models.ops.native (autograd-aware wrappers around the libdgv2 C ABI
 parts import each other in order, every name stays reachable as native.<name>.
 """
 import math
+import contextlib
 import os
 
 import torch
@@ -82,6 +83,38 @@ _CONV8_IMG = os.environ.get("DGV2_NO_CONV8_IMG") is None   # A/B switch for benc
 _CONV_X3 = os.environ.get("DGV2_NO_CONV_X3") is None       # A/B switch: fp32 convs as six bf16 products (conv_x3.hip)
 
 
+_X3_AUTO = [False, {}]
+
+
+@contextlib.contextmanager
+def x3_auto(on=True, live=None):
+    """Inside: fp32 3x3 ring convs that arrive WITHOUT the weight bank's images (R1's double backward through the
+    discriminator's fp32 epilogue) build conv_x3.hip's plane images from their weight values per call (two small launches)
+    and run on the bf16 matrix cores (fp32-equivalent: six bf16 products per multiply).  The fp32 parity mode stays
+    outside: its convs run the exact fp32 MFMA.  live: {padded input channel count: channels before padding} of the convs
+    inside (the padding channels of their inputs are zeros: no gradient is computed for them)."""
+    old = tuple(_X3_AUTO)
+    _X3_AUTO[0] = bool(on) and _CONV_X3
+    _X3_AUTO[1] = dict(live or {})
+    try:
+        yield
+    finally:
+        _X3_AUTO[0], _X3_AUTO[1] = old
+
+
+def _x3_auto_images(wv, fwd):
+    """conv_x3.hip's plane images (forward or transposed) of weight values wv [O,3,3,Cp] fp32, or None."""
+    O, kh, kw, Cp = wv.shape
+    if (not _X3_AUTO[0] or wv.dtype != torch.float32 or not wv.is_cuda or (kh, kw) != (3, 3) or O % 64 or Cp % 8 or Cp < 64
+            or not wv.is_contiguous()):
+        return None
+    n = 3 * (O // 64) * ((Cp + 31) // 32) if fwd else 3 * (Cp // 64) * (O // 32)
+    img = torch.empty(n * 2304 * 8, device=wv.device, dtype=torch.bfloat16)
+    N.check(wv)
+    N.call("dgv2_conv_x3_images", N.ptr(img) if fwd else None, None if fwd else N.ptr(img), N.ptr(wv), O, Cp, N.stream())
+    return img
+
+
 def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None, w8=None):
     """w8: the weight bank's staging image of the same weights (conv_weight_bank(image8=...)): 3x3 ring convs the
     eight-wave engine covers then run dgv2_conv3x3_fwd8 on it."""
@@ -95,6 +128,9 @@ def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None, w
                                                    g.stride, N.ptr(bias), N.ptr(resid), act, alpha, scale, _dt(x),
                                                    N.stream())):
         return y
+    if (w8 is None and _X3_AUTO[0] and x.dtype == torch.float32 and g.ring and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1)
+            and W % 32 == 0):
+        w8 = _x3_auto_images(w, True)
     if (w8 is not None and _CONV_X3 and x.dtype == torch.float32 and w8.dtype == torch.bfloat16 and g.ring
             and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1)
             and N.try_call("dgv2_conv3x3_x3_fwd", N.ptr(y), N.ptr(x), N.ptr(w8), B, H, W, C, O, N.ptr(bias), N.ptr(resid),
@@ -217,6 +253,14 @@ def _conv_dgrad_raw(gy, w, g, xshape, wt=None, resid=None, w8t=None):
             wt = w.permute(3, 1, 2, 0).contiguous()
             w._dgv2_wt = (w._version, wt)
     N.check(gy, wt, resid)
+    if (w is not None and _X3_AUTO[0] and gy.dtype == torch.float32 and g.ring and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1)
+            and W % 32 == 0 and H >= 2 and C % 64 <= 16):
+        w3t = _x3_auto_images(w, False)      # (padding channels, if any, are weights of zero: their gradient comes out as 0)
+        if w3t is not None:
+            gx = torch.empty(xshape, device=gy.device, dtype=gy.dtype)
+            if N.try_call("dgv2_conv3x3_x3_dgrad", N.ptr(gx), N.ptr(gy), N.ptr(w3t), N.ptr(wt), B, H, W,
+                          int(_X3_AUTO[1].get(C, C)), C, O, N.ptr(resid), N.stream()):
+                return gx
     even = g.stride == 1 or (H % 2 == 0 and W % 2 == 0)
     if _direct_ok(g, O % _kstep(gy) == 0) and even and not (g.kh == 1 and g.stride == 2):
         return _conv_dgrad_direct(gy, wt.reshape(C, g.kh * g.kw, O), g, xshape, resid)
@@ -249,12 +293,27 @@ _TN_SCRATCH = {}
 _LIB_WGRAD = os.environ.get("DGV2_NO_LIB_WGRAD") is None         # A/B switch for benchmarking
 
 
-def _conv_wgrad_raw(gy, x, g, gscale=None):
+def _conv_wgrad_raw(gy, x, g, gscale=None, x3=None):
     """gw fp32 [O,kh,kw,C].  gscale: return scale * gw as a PERMUTED VIEW of a contiguous [O,C,kh,kw] buffer (the
-    parameter's layout): the permute-backward of a weight handle then hands the optimizer a contiguous gradient."""
+    parameter's layout): the permute-backward of a weight handle then hands the optimizer a contiguous gradient.
+    x3: fp32 operands on the bf16 matrix cores (dgv2_conv3x3_x3_wgrad; = the input channel count before padding)."""
     B, H, W, C = x.shape
     O = gy.shape[3]
     N.check(gy, x)
+    if x3 is None and _X3_AUTO[0]:
+        x3 = int(_X3_AUTO[1].get(C, C))
+    if (x3 and _CONV_X3 and x.dtype == torch.float32 and g.ring and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1)
+            and O % 128 == 0 and C >= 64 and C % 8 == 0 and W % 32 == 0 and 0 <= x3 - C // 64 * 64 <= 16):
+        key = ("x3", B, H, W, C, int(x3), O)
+        if key not in _WGRAD_SCRATCH:
+            n = _ct.c_int64(0)
+            N.call("dgv2_conv3x3_x3_wgrad_scratch", _ct.addressof(n), B, H, W, C, int(x3), O)
+            _WGRAD_SCRATCH[key] = n.value
+        scratch = torch.empty(_WGRAD_SCRATCH[key], device=x.device, dtype=torch.float32)
+        gw3 = torch.empty((O, C, 3, 3) if gscale is not None else (O, 3, 3, C), device=x.device, dtype=torch.float32)
+        if N.try_call("dgv2_conv3x3_x3_wgrad", N.ptr(gw3), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(x), B, H, W, C,
+                      int(x3), O, 1.0 if gscale is None else float(gscale), int(gscale is not None), N.stream()):
+            return gw3 if gscale is None else gw3.permute(0, 2, 3, 1)
     stream_ok = (_WGRAD_STREAM and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2)
                  and C % (16 // x.element_size()) == 0 and O % (16 // x.element_size()) == 0)
     if gscale is not None:
@@ -330,7 +389,7 @@ class _ConvFwd(Function):
             return None, None, None
         x, w = ctx.saved_tensors
         gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if want_param_grad(ctx, 1) else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale, _x3_hint(ctx, gy)) if want_param_grad(ctx, 1) else None
         return gx, gw, None
 
 
@@ -364,14 +423,23 @@ class _ConvDgrad(Function):
         return g_gy, g_w, None, None, None, (ggx if ctx.needs_input_grad[5] else None), None, None
 
 
+def _x3_hint(ctx, gy):
+    """The conv ran on conv_x3.hip's plane images (fp32 behind the weight bank): its weight gradient does too; -> the
+    conv's input channel count before padding, or None."""
+    w8t = getattr(ctx, "w8t", None)
+    if gy.dtype == torch.float32 and w8t is not None and w8t.dtype == torch.bfloat16:
+        return getattr(w8t, "_dgv2_clive", None)
+    return None
+
+
 class _ConvWgrad(Function):
     @staticmethod
-    def forward(ctx, gy, x, g, gscale=None):
+    def forward(ctx, gy, x, g, gscale=None, x3=None):
         gy = gy.contiguous()
         x = x.contiguous()
         ctx.save_for_backward(gy, x)
         ctx.g, ctx.gscale = g, gscale
-        return _conv_wgrad_raw(gy.to(x.dtype), x, g, gscale)
+        return _conv_wgrad_raw(gy.to(x.dtype), x, g, gscale, x3)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -380,7 +448,7 @@ class _ConvWgrad(Function):
         gy, x = ctx.saved_tensors
         g_gy = _ConvFwd.apply(x, ggw, ctx.g) if ctx.needs_input_grad[0] else None
         g_x = _dgrad(gy, ggw, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[1] else None
-        return g_gy, g_x, None, None
+        return g_gy, g_x, None, None, None
 
 
 def conv_ring(x, w, geom):
@@ -418,7 +486,7 @@ class _ConvAct(Function):
         g, alpha, scale, size_b = ctx.cfg
         gpre, gb = _BiasActBackward.apply(gy, out, want_param_grad(ctx, 2), alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if want_param_grad(ctx, 1) else None
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre)) if want_param_grad(ctx, 1) else None
         return gx, gw, gb, None, None, None
 
 
@@ -796,7 +864,7 @@ class _ConvActFork(Function):
             return gx_sibling, None, None, None, None, None
         gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre)) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None
 
 
@@ -892,7 +960,7 @@ class _ConvActDown(Function):
             gh = _Resample.apply(gy, spec, True, in_hw)
             gpre, gb = _BiasActBackward.apply(gh, out, True, alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else gx_sibling
-        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale) if ctx.needs_input_grad[1] else None
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre)) if ctx.needs_input_grad[1] else None
         return gx, gw, gb, None, None, None, None, None, None
 
 
@@ -924,7 +992,7 @@ class _ConvResid(Function):
             return None, None, None, None
         x, w = ctx.saved_tensors
         gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale) if want_param_grad(ctx, 1) else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale, _x3_hint(ctx, gy)) if want_param_grad(ctx, 1) else None
         return gx, gw, (gy if ctx.needs_input_grad[2] else None), None
 
 

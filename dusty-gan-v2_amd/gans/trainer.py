@@ -29,7 +29,7 @@ from gans.datasets.synthetic import SyntheticRangeImages
 from gans.models.builder import build_discriminator, build_generator
 from gans.models.loss import GANLoss
 from gans.models.ops.common import filter2d
-from gans.models.ops.native import input_grads_only
+from gans.models.ops.native import input_grads_only, x3_auto
 from gans.utils import set_requires_grad, tanh_to_sigmoid
 
 
@@ -353,6 +353,14 @@ class Trainer:
         set_requires_grad(self.D, True)
         self.d_sync.begin(direct=False)
         x = x_real.detach().requires_grad_(True)
+        # behind a bf16 trunk the fp32 epilogue conv of this pass (forward, data gradient and the forward conv of the
+        # double backward; no weight bank here) runs on the bf16 matrix cores too (conv_x3.hip, fp32-equivalent)
+        conv = self.D.epilogue[1] if hasattr(self.D, "epilogue") else None
+        live = {(conv.in_ch + 15) // 16 * 16: conv.in_ch} if conv is not None and hasattr(conv, "in_ch") else None
+        with x3_auto(getattr(self.D, "num_fp16_layers", 0) == -1, live):
+            return self._r1_body(x, j, scalars)
+
+    def _r1_body(self, x, j, scalars):
         y_real = self.D(self.A(self.warmup(x, self._draw("r1.keep")), draws=self._ada("r1.ada")), double_backward=True)
         # (only the gradient w.r.t. the input is taken here: the Functions skip their weight / bias gradients, which
         # ctx.needs_input_grad alone would make them compute and discard)

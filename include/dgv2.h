@@ -530,9 +530,18 @@ int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B, int H, in
  * O % 32, O < 64, C < 64, C % 64 > 16, ldx / 64 != C / 64. */
 int dgv2_conv3x3_x3_dgrad(void* gx, const void* gy, const void* w3t, const void* wt, int B, int H, int W, int C, int ldx,
                           int O, const void* resid, void* stream);
+/* Its weight gradient (conv_wgrad_stream.hip: conv_wgrad_x3_kernel, both operands split while staged):
+ * gw fp32 [O, 9, C] (param_layout != 0: [O, C, 3, 3]) = scale * sum_{b,h,w} gy[b,h,w,o] xpad[b,h+ky-1,w+kx-1,c] from
+ * gy [B,H,W,O], x [B,H,W,C] fp32.  Input channels [0, 64 floor(C/64)) on the matrix cores, [.., clive) in exact fp32
+ * (at most 16), [clive, C) = 0 (x's padding channels).  scratch: fp32 [>= dgv2_conv3x3_x3_wgrad_scratch(...)].
+ * replaces: the cuDNN weight gradient autograd calls for that conv.  DGV2_ENOTSUP: O % 128, C < 64, C % 8, W % 32,
+ * more than 16 such channels. */
+int dgv2_conv3x3_x3_wgrad(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x, int B, int H,
+                          int W, int C, int clive, int O, float scale, int param_layout, void* stream);
+int dgv2_conv3x3_x3_wgrad_scratch(int64_t* elems, int B, int H, int W, int C, int clive, int O);
 /* Both image sets from weight VALUES w [O, 9, Cp] fp32 (the operand layout of dgv2_conv_taps), for passes that do not
  * run on the weight bank (R1's double backward): w3 [3][O / 64][ceil(Cp / 32)][2304 units of 8 bf16], w3t
- * [3][Cp / 64][O / 32][2304 units] or NULL.  O % 64 == 0, Cp % 8 == 0, Cp >= 64. */
+ * [3][Cp / 64][O / 32][2304 units]; either may be NULL.  O % 64 == 0, Cp % 8 == 0, Cp >= 64. */
 int dgv2_conv_x3_images(void* w3, void* w3t, const void* w, int O, int Cp, void* stream);
 
 /* Streaming weight gradient -- the hot-path engine for every discriminator conv (same reference lines as

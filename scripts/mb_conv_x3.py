@@ -32,5 +32,6 @@ for B in (64, 128):
     c = t(lambda: nat._conv_dgrad_raw(gy, None, g, (B, H, W, cp), wt=wt, w8t=w3t))
     d = t(lambda: nat._conv_dgrad_raw(gy, None, g, (B, H, W, cp), wt=wt))
     e = t(lambda: nat._conv_wgrad_raw(gy, x, g, 0.01))
+    f = t(lambda: nat._conv_wgrad_raw(gy, x, g, 0.01, x3=C))
     print(f"B={B} {H}x{W} {C}->{O}: fwd x3 {a:7.1f} us ({fl / a / 1e6:5.0f} TF/s fp32-equiv, {6 * fl / a / 1e6:5.0f} bf16-MFMA)  fp32 {b:7.1f} us ({fl / b / 1e6:5.0f})"
-          f" | dgrad x3 {c:7.1f} us  fp32 {d:7.1f} us | wgrad fp32 {e:7.1f} us ({fl / e / 1e6:5.0f})")
+          f" | dgrad x3 {c:7.1f} us  fp32 {d:7.1f} us | wgrad x3 {f:7.1f} us ({fl / f / 1e6:5.0f}) fp32 {e:7.1f} us ({fl / e / 1e6:5.0f})")

@@ -16,10 +16,16 @@ fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 res = {}
 # "alias=substring": record under `alias` the kernel whose name contains `substring`
-for key in (sys.argv[3:] or ("conv_wgrad_stream_kernel_f32=conv_wgrad_stream_kernel", "conv_pipe_kernel_s2dgrad=conv_pipe_kernel", "conv3x3_strip_kernel", "modconv_pe_fwd_kernel",
+for key in (sys.argv[3:] or ("conv_x3_kernel_dgrad=conv_x3_kernel", "conv_pipe_kernel_s2dgrad=conv_pipe_kernel!float", "conv3x3_strip_kernel", "modconv_pe_fwd_kernel",
                              "modconv_up_kernel", "modconv_up_tl_kernel", "modconv_up_t_kernel", "up2_lag_sumsq_kernel")):
     key, _, sub = key.partition("=")
     sub = sub or key
+    sub, _, excl = sub.partition("!")          # "substring!exclude": names containing `exclude` do not count
+    if excl:
+        fetch_v = {k: v for k, v in fetch.items() if excl not in k}
+        write_v = {k: v for k, v in write.items() if excl not in k}
+    else:
+        fetch_v, write_v = fetch, write
     if sub.endswith("*"):   # every instance whose name contains the substring, each under its own name
         for k in sorted(k for k in fetch if sub[:-1] in k and k in write):
             fv, wv = fetch[k], write[k]
@@ -28,8 +34,8 @@ for key in (sys.argv[3:] or ("conv_wgrad_stream_kernel_f32=conv_wgrad_stream_ker
                             "fetch_bytes_corrected": 2 * f_raw * 1024, "write_bytes": w_raw * 1024,
                             "traffic_bytes_per_launch": 2 * f_raw * 1024 + w_raw * 1024}
         continue
-    fk = [k for k in fetch if sub in k and (sub != "modconv_up_kernel" or "modconv_up_t" not in k)]
-    wk = [k for k in write if sub in k and (sub != "modconv_up_kernel" or "modconv_up_t" not in k)]
+    fk = [k for k in fetch_v if sub in k and (sub != "modconv_up_kernel" or "modconv_up_t" not in k)]
+    wk = [k for k in write_v if sub in k and (sub != "modconv_up_kernel" or "modconv_up_t" not in k)]
     if not fk or not wk:
         continue
     fv, wv = fetch[fk[0]], write[wk[0]]

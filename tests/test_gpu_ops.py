@@ -1027,7 +1027,8 @@ def test_conv8_data_gradient_exact_on_integers(nat, B, H, W, C, O):
     assert torch.equal(nchw(ref), want)
 
 
-X3_CASES = [(4, 4, 32, 513, 512), (1, 4, 32, 72, 64), (3, 8, 64, 64, 128), (2, 6, 32, 130, 64), (5, 2, 96, 200, 192)]
+X3_CASES = [(4, 4, 32, 513, 512), (1, 4, 32, 72, 64), (3, 8, 64, 64, 128), (2, 6, 32, 130, 64), (5, 2, 96, 200, 192),
+            (2, 4, 32, 140, 128), (3, 4, 32, 67, 256)]
 
 
 @pytest.mark.parametrize("B,H,W,C,O", X3_CASES)
@@ -1075,10 +1076,24 @@ def test_conv_x3_is_fp32_equivalent(nat, B, H, W, C, O):
             w3t._dgv2_clive = C
             ggot = nat._conv_dgrad_raw(cl(gy), None, geom, (B, H, W, cpad), wt=wt, resid=rp, w8t=w3t)
             assert torch.equal(ggot[..., C:], rp[..., C:])
+        # the weight gradient (dgv2_conv3x3_x3_wgrad): channels of whole 64-channel tiles on the matrix cores, the ones behind
+        # them (up to C) from the exact-fp32 tail kernel, zeros in the padding
+        wd = w.double().requires_grad_(True)
+        (gw_want,) = torch.autograd.grad(_conv_oracle(x.double(), wd, 1, 1, True), [wd], gy.double())
+        gw_want = gw_want.permute(0, 2, 3, 1)                                            # [O, 3, 3, C]
+        gw_ref = nat._conv_wgrad_raw(cl(gy), xp, geom)
+        has_w = C - C // 64 * 64 <= 16 and O % 128 == 0
+        gw_got = nat._conv_wgrad_raw(cl(gy), xp, geom, x3=C) if has_w else None
+        if has_w:
+            assert float(gw_got[..., C:].abs().max()) == 0.0 if cpad > C else True
+            gp = nat._conv_wgrad_raw(cl(gy), xp, geom, 0.5, x3=C)                        # the parameter's layout, scaled
+            assert gp.permute(0, 3, 1, 2).is_contiguous() and torch.equal(gp, gw_got * 0.5)
         if exact:
             assert torch.equal(nchw(got).double(), want.detach()) and torch.equal(nchw(ref).double(), want.detach())
             if has_t:
                 assert torch.equal(nchw(ggot[..., :C]).double(), gx_want)
+            if has_w:
+                assert torch.equal(gw_got[..., :C].cpu().double(), gw_want)
         else:
             err = float(((nchw(got).double() - want.detach()).abs() / (2.0 * bound + 1e-30)).max())
             err_ref = float(((nchw(ref).double() - want.detach()).abs() / (2.0 * bound + 1e-30)).max())
@@ -1092,6 +1107,29 @@ def test_conv_x3_is_fp32_equivalent(nat, B, H, W, C, O):
                 e_ref = float(((nchw(gref[..., :C]).double() - gx_want).abs() / gbound).max())
                 print(f"conv_x3 dgrad: err / sum|gy||w| = {e:.2e} (fp32 MFMA: {e_ref:.2e})")
                 assert e < 1.5 * e_ref + 4 * 2.0 ** -24, (e, e_ref)
+            if has_w:
+                wa = w.double().abs().requires_grad_(True)
+                (wbound,) = torch.autograd.grad(_conv_oracle(x.double().abs(), wa, 1, 1, True), [wa], gy.double().abs())
+                wbound = wbound.permute(0, 2, 3, 1) + 1e-30
+                e = float(((gw_got[..., :C].cpu().double() - gw_want).abs() / wbound).max())
+                e_ref = float(((gw_ref[..., :C].cpu().double() - gw_want).abs() / wbound).max())
+                print(f"conv_x3 wgrad: err / sum|gy||x| = {e:.2e} (fp32 MFMA: {e_ref:.2e})")
+                assert e < 1.5 * e_ref + 4 * 2.0 ** -24, (e, e_ref)
+    # without the bank (R1's double backward): inside x3_auto() the images are built from the weight values per call
+    # (dgv2_conv_x3_images) -- same results as on the bank's images, bit for bit
+    wv = wr.contiguous()
+    plain = nat._conv_fwd_raw(xp, wv, geom, bias.to(DEV), 3, 0.25, 2.0)
+    with nat.x3_auto():
+        auto = nat._conv_fwd_raw(xp, wv, geom, bias.to(DEV), 3, 0.25, 2.0)
+        gauto = nat._conv_dgrad_raw(cl(gy), wv, geom, (B, H, W, cpad), resid=rp)
+        wauto = nat._conv_wgrad_raw(cl(gy), xp, geom)
+    assert torch.equal(auto, got) and torch.equal(plain, ref)
+    if cpad - cpad // 64 * 64 <= 16 and O % 128 == 0:
+        assert float((wauto - (gw_got if has_w else gw_ref)).abs().max()) <= 1e-5 * float(gw_ref.abs().max())
+    if has_t:
+        assert torch.equal(gauto, ggot)
+    elif cpad % 64 <= 16:
+        assert float((gauto - gref).abs().max()) <= 1e-5 * float(gref.abs().max())
     # a geometry the kernel does not cover reports ENOTSUP (-> False here), it is not mis-computed
     import dgv2_native as N
     y = torch.empty(1, 4, 48, 64, device=DEV)
