@@ -15,7 +15,7 @@ else:
 print(f"# {adam} Adam launches -> {steps:.1f} training iterations in the profiled process (warm-up, capture, timed and "
       f"extra-measurement iterations alike; probe launches outside iterations are included in the totals)")
 B = collections.OrderedDict([
-    ("conv_pipe", r"conv_pipe_kernel"), ("conv8", r"conv8_kernel"), ("conv_strip", r"conv3x3_strip"), ("conv_direct_fallback", r"conv_direct_kernel"),
+    ("conv_x3 (fp32 epilogue conv)", r"conv_x3_|x3_dgrad_tail|conv_wgrad_x3|x3_image"), ("conv_pipe", r"conv_pipe_kernel"), ("conv8", r"conv8_kernel"), ("conv_strip", r"conv3x3_strip"), ("conv_direct_fallback", r"conv_direct_kernel"),
     ("conv_wgrad_stream", r"wgrad_stream|wgrad_reduce"), ("conv_wgrad_direct", r"wgrad_direct"), ("gemm_tn(im2col wgrad)", r"gemm_tn_kernel.*Im2col"),
     ("gemm_tn", r"gemm_tn_kernel"), ("gemm_nn(conv)", r"gemm_nn_kernel.*Im2col"), ("gemm_nn", r"gemm_nn_kernel"),
     ("fir_mfma", r"fir_same_mfma"), ("resample", r"resample"), ("upfirdn/ada", r"upfirdn|ada_"), ("mod_prep", r"mod_prep"),
