@@ -366,225 +366,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Wave-specialised form: the eight compute waves above plus FOUR LOADER WAVES per block (768 threads, three waves per
-// SIMD).  In conv_x3_kernel every wave stages and computes; its staging instructions sit between its own MFMA groups, and a
-// wave's instruction stream is serial: what does not fit into the 16-cycle shadow of a group's last MFMA stalls the next
-// group (measured: 118 us of staging on top of a 290 us MFMA loop at B = 128, profiles/round4_mb_x3_ablate.txt).  Here the
-// loaders run the whole staging schedule -- the global loads, the three-plane split, the LDS stores -- as instruction
-// streams of their own, issued in the cycles the compute waves spend blocked on the matrix pipe; the compute waves
-// execute nothing but fragment reads and MFMAs.  Same LDS images, same stage order, same barriers (every wave takes part
-// in every barrier):
-//   stage 0  compute w_h x (x_l, x_m, x_h) | loaders: store the weight plane of stage 1, load the one of stage 2
-//   stage 1  compute w_m x (x_m, x_h)      | loaders: weight planes as above; load the coming chunk's pixels
-//   stage 2  compute w_l x x_h             | loaders: weight planes; split those pixels, store their m and l planes
-//   boundary                                | loaders: store plane h; barrier
-template <int HZ>
-__global__ __launch_bounds__(768, 3) void conv_x3_ws_kernel(float* __restrict__ y, const float* __restrict__ x,
-                                                            const bf16_t* __restrict__ wimg, CX3 p) {
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-  __shared__ __attribute__((aligned(16))) float s_bias[64];
-  const int n = blockIdx.x, kk = n >> 3;
-  const int item = (n & 7) * p.per_xcd + kk;
-  if (kk >= p.per_xcd || item >= p.total) return;
-  const int slab = item / p.npairs, pair = item - slab * p.npairs;
-  const int tid = threadIdx.x;
-  const bool loader = tid >= 512;
-  uint4* const wb = smem + 2 * X_TILE;
-  const int per_img = p.tiles_h * p.tiles_w;
-  const int nst = p.nchunks * 3;
-  const int o0 = slab * 64;
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-  if (loader) {
-    // ------------------------------------------------ loaders ------------------------------------------------
-    const int lt = tid - 512;                               // 0 .. 255
-    constexpr int LW = 9;                                   // weight units per thread and plane (2304 / 256)
-    constexpr int LX = 8;                                   // pixel units per thread and chunk (2 tiles x 1024 slots / 256)
-    const int w_plane = (lt >> 3) & 3, w_row0 = ((lt >> 5) << 3) | (lt & 7);      // unit lt + 256 j: row + 64 j
-    const size_t plane_units = (size_t)p.nslab * p.nchunks * (X_PW * 4);
-    u32x4 rw[LW];
-    auto load_w = [&](int st) {
-      const int c = st / 3, pl = st - c * 3;
-      const u32x4* img = reinterpret_cast<const u32x4*>(wimg) + pl * plane_units + ((size_t)slab * p.nchunks + c) * (X_PW * 4) + lt;
-#pragma unroll
-      for (int j = 0; j < LW; ++j) rw[j] = img[256 * j];
-    };
-    auto store_w = [&](int buf) {
-      uint4* dst = wb + buf * X_WBUF + w_plane * X_PW + w_row0;
-#pragma unroll
-      for (int j = 0; j < LW; ++j) *reinterpret_cast<u32x4*>(dst + 64 * j) = rw[j];
-    };
-    // pixel slots: slot v = lt + 256 k: tile v >> 10, unit u = v & 1023 -> (K plane, pixel) as in conv_x3_kernel
-    const int in_plane = (lt >> 3) & 3;
-    int goff[LX], lrow[LX];
-#pragma unroll
-    for (int k = 0; k < LX; ++k) {
-      const int v = lt + 256 * k, tile = v >> 10, u = v & 1023;
-      const int q_ = pair * 2 + tile;
-      const int qc = q_ < p.ntiles ? q_ : p.ntiles - 1;
-      const int b = qc / per_img, rem = qc - b * per_img;
-      const int h0 = (rem / p.tiles_w) * 4, w0 = (rem % p.tiles_w) * 32;
-      const int pix = ((u >> 5) << 3) | (u & 7);
-      const int pl = pix < X_NPIX ? pix : X_NPIX - 1;
-      const int iy = pl / X_ICOLS, ix = pl - iy * X_ICOLS;
-      int gh = h0 - 1 + iy;
-      gh = gh < 0 ? 0 : (gh >= p.H ? p.H - 1 : gh);
-      int gw = w0 - 1 + ix;
-      gw = gw < 0 ? gw + p.W : (gw >= p.W ? gw - p.W : gw);
-      goff[k] = ((b * p.H + gh) * p.W + gw) * p.Cx + in_plane * 8;       // host-checked: B H W Cx < 2^31
-      lrow[k] = pix < X_NPIX ? tile * X_TILE + in_plane * X_PIN + pix : -1;
-    }
-    // The coming chunk's pixels pass through registers in two halves of four slots (the whole set, its plane h and a
-    // weight plane together do not fit the 168 registers three waves per SIMD leave).  Plane l of a pixel tile is read in
-    // stage 0 only, plane m in stages 0-1, plane h throughout:
-    //   stage 0: load half A | stage 1: split A, store l_A; load half B | stage 2: store m_A; split B, store l_B, m_B
-    //   boundary: store h_A, h_B
-    constexpr int LH = LX / 2;
-    float4 rx[LH][2];
-    uint4 xh[LX], xmA[LH];
-    bool okA = true, okB = true;
-    auto load_half = [&](int c0, int half, bool& ok) {
-      ok = c0 + in_plane * 8 < p.Cx;
-      const int cc = ok ? c0 : -in_plane * 8;             // (see conv_x3_kernel: no conditional load)
-#pragma unroll
-      for (int k = 0; k < LH; ++k) {
-        const float4* src = reinterpret_cast<const float4*>(x + cc + (half ? goff[LH + k] : goff[k]));
-        rx[k][0] = src[0];
-        rx[k][1] = src[1];
-      }
-    };
-    // split the half in registers: plane l (and m / h when asked) to LDS, h (and m) kept
-    auto split_half = [&](int half, bool ok, bool store_m, bool store_h) {
-#pragma unroll
-      for (int k = 0; k < LH; ++k) {
-        const int kk2 = half * LH + k;
-        uint4 m, l;
-        split3x8(rx[k][0], rx[k][1], xh[kk2], m, l);
-        if (!ok) xh[kk2] = m = l = make_uint4(0u, 0u, 0u, 0u);
-        if (!half) xmA[k] = m;
-        if (lrow[kk2] >= 0) {
-          uint4* d = smem + lrow[kk2];
-          if (store_h) d[0] = xh[kk2];
-          if (store_m) d[4 * X_PIN] = m;
-          d[8 * X_PIN] = l;
-        }
-      }
-    };
-    load_w(0);
-    load_half(0, 0, okA);
-    store_w(0);
-    if (nst > 1) load_w(1);
-    split_half(0, okA, true, true);
-    load_half(0, 1, okB);
-    split_half(1, okB, true, true);
-    __syncthreads();
-    for (int c = 0; c < p.nchunks; ++c) {
-      const bool more = c + 1 < p.nchunks;
-      const int st = c * 3;
-      if (st + 1 < nst) store_w((st + 1) & 1);
-      if (st + 2 < nst) load_w(st + 2);
-      if (more) load_half((c + 1) * 32, 0, okA);
-      __syncthreads();
-      if (st + 2 < nst) store_w((st + 2) & 1);
-      if (st + 3 < nst) load_w(st + 3);
-      if (more) {
-        split_half(0, okA, false, false);
-        load_half((c + 1) * 32, 1, okB);
-      }
-      __syncthreads();
-      if (st + 3 < nst) store_w((st + 3) & 1);
-      if (st + 4 < nst) load_w(st + 4);
-      if (more) {
-#pragma unroll
-        for (int k = 0; k < LH; ++k)
-          if (lrow[k] >= 0) smem[lrow[k] + 4 * X_PIN] = xmA[k];
-        split_half(1, okB, true, false);
-      }
-      __syncthreads();
-      if (more) {
-#pragma unroll
-        for (int k = 0; k < LX; ++k)
-          if (lrow[k] >= 0) smem[lrow[k]] = xh[k];
-        __syncthreads();
-      }
-    }
-    return;
-  }
-
-  // ---------------------------------------------------- compute waves ----------------------------------------------------
-  const int gn = tid >> 8;
-  const int wave4 = (tid >> 6) & 3, lane = tid & 63;
-  const int lr = lane & 15, lc = lane >> 4;
-  uint4* const xs = smem + gn * X_TILE;
-  const int q_ = pair * 2 + gn;
-  const bool tile_live = q_ < p.ntiles;
-  const int qc = tile_live ? q_ : p.ntiles - 1;
-  const int b = qc / per_img, rem = qc - b * per_img;
-  const int h0 = (rem / p.tiles_w) * 4, w0 = (rem % p.tiles_w) * 32;
-
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int mf = 0; mf < 4; ++mf)
-#pragma unroll
-    for (int nf = 0; nf < 2; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int bpix[2];
-#pragma unroll
-  for (int nf = 0; nf < 2; ++nf) bpix[nf] = wave4 * X_ICOLS + nf * 16 + lr;
-  if (tid < 64) s_bias[tid] = p.bias ? p.bias[o0 + tid] : 0.f;
-  unsigned dead = 0u;
-  if constexpr (HZ != 0) {
-    const int orow = h0 + wave4;
-    unsigned m = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-      if ((unsigned)(orow + t / 3 - 1) >= (unsigned)p.H) m |= 1u << t;
-    dead = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
-  }
-  const uint4* const xlane = xs + lc * X_PIN;
-  auto nothing = [](int) {};
-  __syncthreads();
-  for (int c = 0; c < p.nchunks; ++c) {
-    const int st = c * 3;
-    x3_stage<3, HZ>(acc, wb + (st & 1) * X_WBUF + lc * X_PW + lr, xlane, bpix, dead, nothing);
-    __syncthreads();
-    x3_stage<2, HZ>(acc, wb + ((st + 1) & 1) * X_WBUF + lc * X_PW + lr, xlane, bpix, dead, nothing);
-    __syncthreads();
-    x3_stage<1, HZ>(acc, wb + (st & 1) * X_WBUF + lc * X_PW + lr, xlane, bpix, dead, nothing);
-    __syncthreads();
-    if (c + 1 < p.nchunks) __syncthreads();
-  }
-
-  mfma_drain();
-  const int gh = h0 + wave4;
-#pragma unroll
-  for (int nf = 0; nf < 2; ++nf) {
-    const int gw = w0 + nf * 16 + lr;
-    const bool live = tile_live && gh < p.H && gw < p.W;
-    const int64_t row = (((int64_t)b * p.H + gh) * p.W + gw) * p.ldy;
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-      const int o = o0 + mf * 16 + lc * 4;
-      const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[mf * 16 + lc * 4]);
-      const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
-      float f[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = acc[mf][nf][r] + bq[r];
-        if (p.act == 3) t = fmaxf(t, t * p.alpha) * p.scale;   // leaky ReLU, 0 <= alpha <= 1
-        f[r] = t;
-      }
-      if (live && o < p.O) {
-        if (p.resid) {
-          const float4 r4 = *reinterpret_cast<const float4*>(p.resid + row + o);
-          f[0] += r4.x; f[1] += r4.y; f[2] += r4.z; f[3] += r4.w;
-        }
-        *reinterpret_cast<float4*>(y + row + o) = make_float4(f[0], f[1], f[2], f[3]);
-      }
-    }
-  }
-}
-
 // The data gradient's channels past the last whole slab, exact fp32: gx[b, h, w, c] for c0 <= c < c0 + nc:
 //   sum_{ky, kx, o} gy[b, Hz(h + 1 - ky), wrap(w + 1 - kx), o] * wt[c][ky * 3 + kx][o] + the replicate-row terms,
 // and resid / zeros in c0 + nc <= c < cend.  A block is one image row, a wave a quarter of its pixels; per pixel the lanes
@@ -699,8 +480,7 @@ __global__ __launch_bounds__(256) void x3_image_bwd_kernel(bf16_t* __restrict__ 
 
 template <int HZ>
 int launch_x3(float* y, const float* x, const bf16_t* wimg, CX3 p, hipStream_t st) {
-  static const bool no_ws = getenv("DGV2_X3_NO_WS") != nullptr;   // A/B switch: every wave stages and computes
-  auto kern = no_ws ? conv_x3_kernel<HZ> : conv_x3_ws_kernel<HZ>;
+  auto kern = conv_x3_kernel<HZ>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS);
@@ -716,7 +496,7 @@ int launch_x3(float* y, const float* x, const bf16_t* wimg, CX3 p, hipStream_t s
 #ifdef DGV2_ABLATE
   p.ablate = getenv("DGV2_X3_ABLATE") ? atoi(getenv("DGV2_X3_ABLATE")) : 0;
 #endif
-  kern<<<p.per_xcd * 8, no_ws ? 512 : 768, X_LDS, st>>>(y, x, wimg, p);
+  kern<<<p.per_xcd * 8, 512, X_LDS, st>>>(y, x, wimg, p);
   return 0;
 }
 
