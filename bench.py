@@ -161,6 +161,28 @@ MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_*_f32, /opt/skills/guides/MI355X_MI
 STATS_FILE = "profiles/round4_bench_graph_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this command (committed)
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the HIP sources the library is built from: stamps the committed statistics
+    (STATS_FILE's .meta.json sidecar, written by scripts/stats_meta.py when the file is refreshed) so that a bench line
+    says whether the ranking it selects `roofline` by was measured on THIS tree's kernels."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dusty-gan-v2_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "dusty-gan-v2_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def stats_current():
+    """True / False: the committed statistics carry this tree's kernel_source_hash(); None: no sidecar."""
+    meta = os.path.join(ROOT, STATS_FILE[:-4] + ".meta.json")
+    if not os.path.exists(meta):
+        return None
+    return json.load(open(meta)).get("src_sha16") == kernel_source_hash()
+
+
 def dominant_instance():
     """Which probed kernel instance the committed graph statistics rank highest: (probe key, kernel name, Percentage).
     The file is sorted by total duration; the first row that one of the probes covers decides what `roofline` reports
@@ -544,7 +566,8 @@ def main():
         key, name, pct = dominant_instance()
         chosen = {"conv_x3": roof, "s2dgrad": roof_s2, "strip": roof_strip}.get(key) or roof
         out["roofline"] = None if chosen is None else dict(
-            chosen, selected_by=f"largest Percentage among the probed kernel instances in {STATS_FILE}: {pct} % ({key})")
+            chosen, selected_by=f"largest Percentage among the probed kernel instances in {STATS_FILE}: {pct} % ({key})",
+            stats_measured_on_this_tree=stats_current())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         _emit(json.dumps(out), out_fd)
