@@ -27,6 +27,7 @@ struct WSGeom {
 #define WS_ABL 0
 #endif
   int x_shared; // x is ONE image [H, W, C] shared by all samples (the batch-shared positional encoding)
+  int x_exact;  // conv_wgrad_x3_kernel: channels [0, x_exact) of x are bf16-representable (dgv2.h: dgv2_conv3x3_x3_fwd)
 };
 
 template <typename T, int S, int MFN, int NFN, bool K3>
@@ -445,6 +446,63 @@ __device__ __forceinline__ void wx_split8(const float4& lo, const float4& hi, ui
   l = pl.u;
 }
 
+__device__ int wx3_inexact_flag;   // a value outside the x_exact promise was staged (dgv2_conv_x3_status)
+
+// XE: the c-tile's input channels are bf16-exact (WSGeom::x_exact): x = x_h, the planes m and l of x are neither staged nor
+// multiplied -- three products per multiply (gy_l x_h, gy_m x_h, gy_h x_h), the same sum
+template <bool XE>
+__device__ __forceinline__ void wx3_tile(f32x4 (&acc)[9][4], const char* lbase, const int (&voffA)[4][2], const int (&voffB)[3][2]) {
+  using Cf = WXCfg;
+  constexpr int WR = Cf::WR, IN_COLS = Cf::IN_COLS, GYB = Cf::GYB, XB = Cf::XB;
+  constexpr int NQ = XE ? 1 : 3;
+#pragma unroll
+  for (int r = 0; r < WR; ++r) {
+    uint4 a[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int mw = 0; mw < 4; ++mw)
+        a[q][mw] = wz_tr_read(lbase + voffA[mw][0] + q * GYB + r * 32 * 128, lbase + voffA[mw][1] + q * GYB + r * 32 * 128);
+    auto bread = [&](int tap, int q) {
+      const int ky = tap / 3, kx = tap % 3;
+      const int imm = q * XB + (r + ky) * IN_COLS * 128;
+      return wz_tr_read(lbase + voffB[kx][0] + imm, lbase + voffB[kx][1] + imm);
+    };
+    uint4 bn[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bn[q] = bread(0, q);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      uint4 bb[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) bb[q] = bn[q];
+      if (tap + 1 < 9) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) bn[q] = bread(tap + 1, q);
+      }
+      // smallest terms first: gy_h x_l, gy_h x_m, gy_m x_m, gy_l x_h, gy_m x_h, gy_h x_h  (XE: the last three)
+      constexpr int QA[6] = {0, 0, 1, 2, 1, 0}, QB[6] = {2, 1, 1, 0, 0, 0};
+#pragma unroll
+      for (int k = XE ? 3 : 0; k < 6; ++k) {
+        // the four MFMAs of a (plane pair, tap) as one asm statement with eight wait states behind the last (conv_x3.hip,
+        // mfma4_bf16: nothing the compiler generates can write an operand register a group's MFMA is still reading)
+        union U { uint4 u; bf16x8 v; };
+        U a0, a1, a2, a3, ub;
+        a0.u = a[QA[k]][0]; a1.u = a[QA[k]][1]; a2.u = a[QA[k]][2]; a3.u = a[QA[k]][3]; ub.u = bb[QB[k]];
+        asm volatile(
+            "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"
+            "v_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t"
+            "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\t"
+            "v_mfma_f32_16x16x32_bf16 %3, %7, %8, %3\n\t"
+            "s_nop 7"
+            : "+v"(acc[tap][0]), "+v"(acc[tap][1]), "+v"(acc[tap][2]), "+v"(acc[tap][3])
+            : "v"(a0.v), "v"(a1.v), "v"(a2.v), "v"(a3.v), "v"(ub.v));
+      }
+    }
+  }
+}
+
+template <bool XE>   // every c-tile of the launch lies below WSGeom::x_exact (host-checked)
 __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(float* __restrict__ part, const float* __restrict__ gy,
                                                                const float* __restrict__ x, WSGeom g) {
   using Cf = WXCfg;
@@ -460,6 +518,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(float* __restrict
   const int split = blockIdx.x;
   const int c0 = (blockIdx.y % g.ctiles) * 64;
   const int o0 = (blockIdx.y / g.ctiles) * 64;
+  constexpr bool xe = XE;
 
   int gpix[NG], gw_[NG];
 #pragma unroll
@@ -554,50 +613,17 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(float* __restrict
       wx_split8(rx[j][0], rx[j][1], h, m, l);
       if (xpos[j] >= 0) {
         lds_x[xw_[j]] = h;
-        lds_x[XB / 16 + xw_[j]] = m;
-        lds_x[2 * (XB / 16) + xw_[j]] = l;
+        if (!xe) {
+          lds_x[XB / 16 + xw_[j]] = m;
+          lds_x[2 * (XB / 16) + xw_[j]] = l;
+        } else if ((m.x | m.y | m.z | m.w) != 0u) {
+          atomicOr(&wx3_inexact_flag, 1);                  // (m = bf16(x - h) is zero exactly when x is bf16-representable)
+        }
       }
     }
     if (t + 1 < t_end) issue();
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < WR; ++r) {
-      uint4 a[3][4];
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int mw = 0; mw < 4; ++mw)
-          a[q][mw] = wz_tr_read(lbase + voffA[mw][0] + q * GYB + r * 32 * 128, lbase + voffA[mw][1] + q * GYB + r * 32 * 128);
-      auto bread = [&](int tap, int q) {
-        const int ky = tap / 3, kx = tap % 3;
-        const int imm = q * XB + (r + ky) * IN_COLS * 128;
-        return wz_tr_read(lbase + voffB[kx][0] + imm, lbase + voffB[kx][1] + imm);
-      };
-      uint4 bn[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) bn[q] = bread(0, q);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        uint4 bb[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) bb[q] = bn[q];
-        if (tap + 1 < 9) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q) bn[q] = bread(tap + 1, q);
-        }
-        // smallest terms first: gy_h x_l, gy_h x_m, gy_m x_m, gy_l x_h, gy_m x_h, gy_h x_h
-        constexpr int QA[6] = {0, 0, 1, 2, 1, 0}, QB[6] = {2, 1, 1, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-          for (int mw = 0; mw < 4; ++mw) {
-            union { uint4 u; bf16x8 v; } ua, ub;
-            ua.u = a[QA[k]][mw];
-            ub.u = bb[QB[k]];
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[tap][mw]) : "v"(ua.v), "v"(ub.v));
-          }
-      }
-    }
+    wx3_tile<XE>(acc, lbase, voffA, voffB);
   }
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -934,11 +960,22 @@ extern "C" int dgv2_conv_wgrad_stream_pl(float* gw, float* scratch, int64_t scra
 // exact fp32 (at most 16), [clive, C) = 0 (padding channels of x).  scratch: dgv2_conv3x3_x3_wgrad_scratch.
 // DGV2_ENOTSUP where the kernel does not cover the geometry (O % 128, C < 64, C % 8, clive - 64 * floor(C / 64) > 16,
 // W % 32): callers then run dgv2_conv_wgrad_stream_pl.
+int wx3_status_read_clear() {   // for dgv2_conv_x3_status (conv_x3.hip)
+  int h = 0;
+  if (hipMemcpyFromSymbol(&h, HIP_SYMBOL(wx3_inexact_flag), sizeof(int)) != hipSuccess) return -1;
+  if (h) {
+    const int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(wx3_inexact_flag), &z, sizeof(int)) != hipSuccess) return -1;
+  }
+  return h;
+}
+
 extern "C" int dgv2_conv3x3_x3_wgrad(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x, int B,
-                                     int H, int W, int C, int clive, int O, float scale, int param_layout, void* stream) {
+                                     int H, int W, int C, int clive, int x_exact, int O, float scale, int param_layout,
+                                     void* stream) {
   if (!gw || !scratch || !gy || !x || !aligned16(gy) || !aligned16(x) || !aligned16(scratch) || !aligned16(gw))
     return DGV2_EINVAL;
-  if (B < 1 || H < 1 || W < 1 || C < 1 || O < 1 || clive < 1 || clive > C) return DGV2_EINVAL;
+  if (B < 1 || H < 1 || W < 1 || C < 1 || O < 1 || clive < 1 || clive > C || x_exact < 0 || x_exact > C) return DGV2_EINVAL;
   static const bool off = getenv("DGV2_NO_CONV_X3") != nullptr || getenv("DGV2_NO_WGRAD_X3") != nullptr;
   const int ctiles = C / 64, ntail = clive - ctiles * 64;
   if (off || O % 64 || ctiles < 1 || C % 8 || ntail > 16 || W % 32) return DGV2_ENOTSUP;
@@ -951,6 +988,7 @@ extern "C" int dgv2_conv3x3_x3_wgrad(float* gw, float* scratch, int64_t scratch_
   g.ntiles = B * g.tiles_h * g.tiles_w;
   g.ctiles = ctiles;
   g.x_shared = 0;
+  g.x_exact = x_exact;
 #ifdef DGV2_ABLATE
   g.ablate = 0;
 #endif
@@ -966,14 +1004,15 @@ extern "C" int dgv2_conv3x3_x3_wgrad(float* gw, float* scratch, int64_t scratch_
   const int64_t tneed = tail ? (int64_t)TS * O * 9 * NC : 0;
   if (scratch_elems < (int64_t)nsplit * n + tneed || O % 128) return DGV2_ENOTSUP;
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)WXCfg::LDS);
+  const bool xe = x_exact >= ctiles * 64;
+  auto kern = xe ? conv_wgrad_x3_kernel<true> : conv_wgrad_x3_kernel<false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[xe]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WXCfg::LDS);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set[xe] = true;
   }
-  conv_wgrad_x3_kernel<<<dim3(nsplit, pairs), 256, WXCfg::LDS, st>>>(scratch, (const float*)gy, (const float*)x, g);
+  kern<<<dim3(nsplit, pairs), 256, WXCfg::LDS, st>>>(scratch, (const float*)gy, (const float*)x, g);
   if (tail) {
     float* tpart = scratch + (int64_t)nsplit * n;
     const dim3 tg(TS, O / 128);

@@ -36,6 +36,8 @@ struct CX3 {
   int B, H, W, Cx;        // x [B, H, W, Cx] fp32 (Cx % 8 == 0)
   int nchunks;            // 32-channel chunks of the weight images (= ceil(Cx / 32); channels >= Cx are staged as zeros)
   int O, ldy;             // output channels written (a multiple of 64) and the row pitch of y
+  int xexact;             // the caller's promise: channels [0, xexact) of x hold bf16-representable values (activations of a
+                          // bf16 trunk widened to fp32) -- their m and l planes are zero: not staged, their products not issued
   int tiles_h, tiles_w, ntiles, npairs, nslab, per_xcd, total;
   const float* bias;
   const float* resid;
@@ -74,16 +76,48 @@ __device__ __forceinline__ void split3x8(const float4& lo, const float4& hi, uin
   l = pl.u;
 }
 
+// the promise CX3::xexact is checked where it is used: a value with a residual raises this flag (dgv2_conv_x3_status)
+__device__ int x3_inexact_flag;
+
+// eight fp32 values that are promised to be bf16-representable -> plane h; true if one of them is not
+__device__ __forceinline__ bool exact1x8(const float4& lo, const float4& hi, uint4& h) {
+  const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  union { uint4 u; bf16_t e[8]; } ph;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    ph.e[i] = (bf16_t)f[i];
+    bad |= (f[i] - (float)ph.e[i]) != 0.f;
+  }
+  h = ph.u;
+  return bad;
+}
+
 // One stage: the nine taps of one weight plane (LDS buffer a_base, this lane's K plane and row) against the NX first
 // split planes of the wave's pixel row (xb: split 0 of this lane's K plane; split q is q * 4 * X_PIN further), smallest
 // plane first.  HZ: conv8.hip's data-gradient form -- `dead` = taps that read only zero rows for this wave's output row.
 // `side(t)` runs once behind the MFMA groups of tap t: the staging work of the coming stages, issued under this stage's MFMAs.
-// in-place bf16 MFMA with five wait states attached: nothing the compiler generates can land between the MFMA and the nop
-__device__ __forceinline__ void mfma_bf16_nop(f32x4& acc, const uint4& a, const uint4& b) {
-  union { uint4 u; bf16x8 v; } ua, ub;
-  ua.u = a;
-  ub.u = b;
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 4" : "+v"(acc) : "v"(ua.v), "v"(ub.v));
+// A group of four in-place bf16 MFMAs (one B fragment against four A fragments) as ONE asm statement with eight wait states
+// behind the last (five cover its operand reads, eight its result: at high register pressure the allocator splits an
+// accumulator's live range around the dead-tap branches and copies it with v_mov_b64 right behind the group -- with five
+// wait states the copy read the upper half of the last fragment before the MFMA had written it: wrong values in one
+// output row of the data gradient, found by tests/test_gpu_ops.py and then by the extended audit): the compiler can place nothing between them, and nothing it generates behind the group (register
+// shuffles at high pressure, branch conditions materialised through VGPRs) can write an operand register an MFMA of the
+// group is still reading -- the hazard recogniser does not look inside asm (scripts/audit_asm_mfma.py).
+// Inside the group the next MFMA's issue covers the previous one's operand reads.
+__device__ __forceinline__ void mfma4_bf16(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, const uint4& a0, const uint4& a1,
+                                           const uint4& a2, const uint4& a3, const uint4& b) {
+  union U { uint4 u; bf16x8 v; };
+  U ua0, ua1, ua2, ua3, ub;
+  ua0.u = a0; ua1.u = a1; ua2.u = a2; ua3.u = a3; ub.u = b;
+  asm volatile(
+      "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"
+      "v_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t"
+      "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\t"
+      "v_mfma_f32_16x16x32_bf16 %3, %7, %8, %3\n\t"
+      "s_nop 7"
+      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+      : "v"(ua0.v), "v"(ua1.v), "v"(ua2.v), "v"(ua3.v), "v"(ub.v));
 }
 
 template <int NX, int HZ, typename Side>
@@ -110,15 +144,8 @@ __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __rest
       for (int qi = 0; qi < NX; ++qi) {
         const int q = NX - 1 - qi;
         __builtin_amdgcn_sched_barrier(0);
-        if (!(HZ && ((dd >> t) & 1u))) {
-#pragma unroll
-          for (int mf = 0; mf < 4; ++mf) {
-            // HZ: the branch conditions behind a group are materialised through VGPRs, and the compiler picks operand
-            // registers of the group for them (scripts/audit_asm_mfma.py): the group's last MFMA carries its wait states
-            if (HZ != 0 && mf == 3) mfma_bf16_nop(acc[mf][nf], a[t & 1][mf], bb[nf][q]);
-            else MfmaAsm<bf16_t>::run(acc[mf][nf], a[t & 1][mf], bb[nf][q]);
-          }
-        }
+        if (!(HZ && ((dd >> t) & 1u)))
+          mfma4_bf16(acc[0][nf], acc[1][nf], acc[2][nf], acc[3][nf], a[t & 1][0], a[t & 1][1], a[t & 1][2], a[t & 1][3], bb[nf][q]);
         if constexpr (HZ != 0) {
           // replicate-row border term (conv8.hip): the tap mirrored in dy is dead for this row -> the border row once
           // more (the pixel fragment of tap (dy = 0, dx)) through the weights in registers right now
@@ -126,16 +153,9 @@ __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __rest
             const int tm = t < 3 ? t + 6 : t - 6;
             if ((dd >> tm) & 1u) {
               const uint4 bx = xb[q * 4 * X_PIN + bpix[nf] + X_ICOLS + t % 3];
-#pragma unroll
-              for (int mf = 0; mf < 4; ++mf) {
-                if (mf == 3) mfma_bf16_nop(acc[mf][nf], a[t & 1][mf], bx);
-                else MfmaAsm<bf16_t>::run(acc[mf][nf], a[t & 1][mf], bx);
-              }
+              mfma4_bf16(acc[0][nf], acc[1][nf], acc[2][nf], acc[3][nf], a[t & 1][0], a[t & 1][1], a[t & 1][2], a[t & 1][3], bx);
             }
           }
-          // compiler-generated VALU instructions of the next group's condition may not write a register the last MFMA
-          // still reads as an operand (scripts/audit_asm_mfma.py): five wait states cover a 4-pass MFMA's source reads
-          asm volatile("s_nop 4");
         }
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < 9) {
@@ -149,16 +169,14 @@ __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __rest
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // five wait states: the side work's VALU results (conditions, the split) may be allocated to registers the last MFMA
-    // is still reading as operands; the hazard recogniser does not see inside the asm (scripts/audit_asm_mfma.py)
-    asm volatile("s_nop 4");
     side(t);
   }
-  asm volatile("s_nop 4");   // ... and the code behind the stage (loop conditions) likewise
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int HZ>
+// XE: the launch carries an x_exact promise (the exact-chunk code is compiled in); the data gradient and promise-free
+// forwards run the instances without it -- 40 registers lighter
+template <int HZ, bool XE>
 __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                          const bf16_t* __restrict__ wimg, CX3 p) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -272,7 +290,14 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
   };
   uint4 xh[X_NI];                            // plane h of the coming chunk's pixels between their split and the boundary
   // split slot j of the pixels in registers; planes m and l go to LDS at once, h waits in xh
-  auto split_store = [&](int j, bool all) {
+  auto split_store = [&](int j, bool all, bool ex) {
+    if (ex) {   // promised bf16-exact channels: plane h is the value, planes m and l are zero and never read for this chunk
+      const bool bad = exact1x8(rin[j][0], rin[j][1], xh[j]);
+      if (bad && rin_ok && lrow[j] >= 0) atomicOr(&x3_inexact_flag, 1);
+      if (!rin_ok) xh[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (all && lrow[j] >= 0) xs[in_plane * X_PIN + lrow[j]] = xh[j];
+      return;
+    }
     uint4 m, l;
     split3x8(rin[j][0], rin[j][1], xh[j], m, l);
     if (!rin_ok) xh[j] = m = l = make_uint4(0u, 0u, 0u, 0u);
@@ -289,42 +314,43 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
   write_w(0);
   if (nst > 1) issue_w(1);
 #pragma unroll
-  for (int j = 0; j < X_NI; ++j) split_store(j, true);
+  for (int j = 0; j < X_NI; ++j) split_store(j, true, XE && 32 <= p.xexact);
   if (p.nchunks > 1) issue_in(32);
   __syncthreads();
   const uint4* const xlane = xs + lc * X_PIN;
   for (int c = 0; c < p.nchunks; ++c) {
     const bool more = c + 1 < p.nchunks && !(X3_ABL & 4);
     const int st = c * 3;
+    // chunks of bf16-exact input channels (CX3::xexact): x = x_h, so each stage is its weight plane against x_h alone --
+    // three products per multiply instead of six, the same sum (the other three are products with zero)
+    const bool ex = XE && (c + 1) * 32 <= p.xexact, ex_next = XE && (c + 2) * 32 <= p.xexact;
+    const uint4* const a0 = wb + (st & 1) * X_WBUF + lc * X_PW + lr;
+    const uint4* const a1 = wb + ((st + 1) & 1) * X_WBUF + lc * X_PW + lr;
     // stage 0: w_h x (x_l, x_m, x_h); under it the weight slots of the coming stages
-    if (!(X3_ABL & 2))
-      x3_stage<3, HZ>(acc, wb + (st & 1) * X_WBUF + lc * X_PW + lr, xlane, bpix, dead, [&](int t) {
-        if (t < X_NW) w_slot(st, t);
-      });
-    else
-      for (int t = 0; t < X_NW; ++t) w_slot(st, t);
+    auto side0 = [&](int t) { if (t < X_NW) w_slot(st, t); };
+    if (X3_ABL & 2) { for (int t = 0; t < X_NW; ++t) w_slot(st, t); }
+    else if (ex) x3_stage<1, HZ>(acc, a0, xlane, bpix, dead, side0);
+    else x3_stage<3, HZ>(acc, a0, xlane, bpix, dead, side0);
     __syncthreads();
     // stage 1: w_m x (x_m, x_h)
-    if (!(X3_ABL & 2))
-      x3_stage<2, HZ>(acc, wb + ((st + 1) & 1) * X_WBUF + lc * X_PW + lr, xlane, bpix, dead, [&](int t) {
-        if (t < X_NW) w_slot(st + 1, t);
-      });
-    else
-      for (int t = 0; t < X_NW; ++t) w_slot(st + 1, t);
+    auto side1 = [&](int t) { if (t < X_NW) w_slot(st + 1, t); };
+    if (X3_ABL & 2) { for (int t = 0; t < X_NW; ++t) w_slot(st + 1, t); }
+    else if (ex) x3_stage<1, HZ>(acc, a1, xlane, bpix, dead, side1);
+    else x3_stage<2, HZ>(acc, a1, xlane, bpix, dead, side1);
     __syncthreads();
     // stage 2: w_l x x_h -- planes m and l of the pixel tiles are no longer read: the coming chunk's pixels (loaded two
     // stages ago) are split under it, m and l stored at once
     if (!(X3_ABL & 2))
-      x3_stage<1, HZ>(acc, wb + (st & 1) * X_WBUF + lc * X_PW + lr, xlane, bpix, dead, [&](int t) {
+      x3_stage<1, HZ>(acc, a0, xlane, bpix, dead, [&](int t) {
         if (t < X_NW) w_slot(st + 2, t);
         if (more && t >= 9 - 2 * X_NI && ((t - (9 - 2 * X_NI)) & 1) == 0) {
-          split_store((t - (9 - 2 * X_NI)) >> 1, false);
+          split_store((t - (9 - 2 * X_NI)) >> 1, false, ex_next);
         }
       });
     else {
       for (int t = 0; t < X_NW; ++t) w_slot(st + 2, t);
       if (more)
-        for (int j = 0; j < X_NI; ++j) split_store(j, false);
+        for (int j = 0; j < X_NI; ++j) split_store(j, false, ex_next);
     }
     __syncthreads();                                         // chunk c read
     if (more) {
@@ -478,9 +504,9 @@ __global__ __launch_bounds__(256) void x3_image_bwd_kernel(bf16_t* __restrict__ 
   }
 }
 
-template <int HZ>
+template <int HZ, bool XE>
 int launch_x3(float* y, const float* x, const bf16_t* wimg, CX3 p, hipStream_t st) {
-  auto kern = conv_x3_kernel<HZ>;
+  auto kern = conv_x3_kernel<HZ, XE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS);
@@ -505,10 +531,14 @@ int launch_x3(float* y, const float* x, const bf16_t* wimg, CX3 p, hipStream_t s
 // y [B, H, W, O] (fp32) = act( conv3x3_ring(x [B, H, W, Cx] fp32, w) + bias ) * scale + resid, the weights as the three
 // plane images dgv2_conv_weight_bank_ex writes for dtype fp32 (w8: [3][O / 64][ceil(Cx / 32)][2304 units of 8 bf16]).
 // fp32-equivalent (six bf16 products per multiply, fp32 accumulation).  Stride 1, pad 1, rows replicate, columns wrap.
+// x_exact: the caller's promise that channels [0, x_exact) of x hold bf16-representable values (the activations of a bf16
+// trunk widened to fp32: the discriminator's features in front of its fp32 epilogue) -- their m and l planes are zero, so
+// their three products are not issued: the same sum at half the MFMAs.  A value that breaks the promise raises
+// dgv2_conv_x3_status().  0: no promise.
 // DGV2_ENOTSUP where the kernel does not cover the geometry (callers then run dgv2_conv_taps in fp32).
-extern "C" int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B, int H, int W, int Cx, int O,
+extern "C" int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B, int H, int W, int Cx, int x_exact, int O,
                                    const float* bias, const void* resid, int act, float alpha, float scale, void* stream) {
-  if (!y || !x || !w3 || B < 1 || H < 1 || W < 1 || Cx < 1 || O < 1) return DGV2_EINVAL;
+  if (!y || !x || !w3 || B < 1 || H < 1 || W < 1 || Cx < 1 || O < 1 || x_exact < 0 || x_exact > Cx) return DGV2_EINVAL;
   if (act != 0 && act != 3) return DGV2_EINVAL;
   static const bool off = getenv("DGV2_NO_CONV_X3") != nullptr;   // A/B switch for benchmarking
   if (off || W % 32 || Cx % 8 || O % 64 || Cx < 64) return DGV2_ENOTSUP;
@@ -516,8 +546,10 @@ extern "C" int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B
   if ((int64_t)B * H * W * (Cx > O ? Cx : O) >= (1ll << 31)) return DGV2_ENOTSUP;
   CX3 p;
   p.B = B; p.H = H; p.W = W; p.Cx = Cx; p.nchunks = (Cx + 31) / 32; p.O = O; p.ldy = O; p.nslab = O / 64;
+  p.xexact = x_exact;
   p.bias = bias; p.resid = (const float*)resid; p.act = act; p.alpha = alpha; p.scale = scale;
-  const int rc = launch_x3<0>((float*)y, (const float*)x, (const bf16_t*)w3, p, (hipStream_t)stream);
+  const int rc = x_exact >= 32 ? launch_x3<0, true>((float*)y, (const float*)x, (const bf16_t*)w3, p, (hipStream_t)stream)
+                               : launch_x3<0, false>((float*)y, (const float*)x, (const bf16_t*)w3, p, (hipStream_t)stream);
   if (rc) return rc;
   DGV2_RETURN_LAST();
 }
@@ -537,9 +569,10 @@ extern "C" int dgv2_conv3x3_x3_dgrad(void* gx, const void* gy, const void* w3t, 
   if ((int64_t)B * H * W * (ldx > O ? ldx : O) >= (1ll << 31)) return DGV2_ENOTSUP;
   CX3 p;
   p.B = B; p.H = H; p.W = W; p.Cx = O; p.nchunks = O / 32; p.O = nslab * 64; p.ldy = ldx; p.nslab = nslab;
+  p.xexact = 0;
   p.bias = nullptr; p.resid = (const float*)resid; p.act = 0; p.alpha = 0.2f; p.scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = launch_x3<1>((float*)gx, (const float*)gy, (const bf16_t*)w3t, p, st);
+  const int rc = launch_x3<1, false>((float*)gx, (const float*)gy, (const bf16_t*)w3t, p, st);
   if (rc) return rc;
   if (ldx > nslab * 64)
     x3_dgrad_tail_kernel<<<B * H, 256, 0, st>>>((float*)gx, (const float*)gy, (const float*)wt, (const float*)resid, B, H, W,
@@ -561,4 +594,20 @@ extern "C" int dgv2_conv_x3_images(void* w3, void* w3t, const void* w, int O, in
     x3_image_bwd_kernel<<<grid_for((int64_t)(Cp / 64) * 64 * 9 * (O / 8), 256), 256, 0, st>>>((bf16_t*)w3t, (const float*)w, O,
                                                                                                  Cp, Cp / 64);
   DGV2_RETURN_LAST();
+}
+
+// 1 if a launch since the last call met a value outside its x_exact promise (the result of that launch is then the conv of
+// the bf16-ROUNDED input), 0 otherwise, < 0 on a runtime error.  Synchronises the device: tests and debugging.
+int wx3_status_read_clear();   // conv_wgrad_stream.hip: the weight gradient's flag
+
+extern "C" int dgv2_conv_x3_status(void) {
+  int h = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&h, HIP_SYMBOL(x3_inexact_flag), sizeof(int)) != hipSuccess) return -1;
+  if (h) {
+    const int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(x3_inexact_flag), &z, sizeof(int)) != hipSuccess) return -1;
+  }
+  const int hw = wx3_status_read_clear();
+  return hw < 0 ? hw : (h | hw);
 }

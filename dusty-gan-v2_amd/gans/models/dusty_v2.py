@@ -863,6 +863,7 @@ class Discriminator(nn.Module):
         mb, conv, act1, _, lin1, act2, lin2 = self.epilogue
         # fp32 island of the reference (dusty_v2.py:394-395) unless epilogue_dtype == "bf16" was asked for
         edt = self._epilogue_dtype()
+        trunk_low, n_trunk = x.dtype == LOW, int(x.shape[3])
         cin = x.shape[3] + mb.features
         vec = 32 if edt == LOW else 16
         cpad = (cin + vec - 1) // vec * vec  # whole 64-byte K-steps for the direct conv engine
@@ -873,6 +874,10 @@ class Discriminator(nn.Module):
             x = native.mbstd_cat(x, mb.group, splits, cpad, out_dtype=edt)
         else:
             x = mb.forward_cl(x.to(edt).float(), pad_to=cpad, splits=splits).to(edt)
+        if edt == torch.float32 and trunk_low and x.dtype == torch.float32:
+            # the trunk's features are bf16 values widened to fp32 (the statistic channel behind them is not): the fp32 conv on
+            # the bf16 matrix cores skips their zero planes (conv_x3.hip: three of six products; same sum, checked in-kernel)
+            x._dgv2_exact = n_trunk
         x = conv.forward_cl(x, pad_in_to=cpad, act=act1, bank=bank)
         # NCHW flatten order of the reference's nn.Flatten
         x = native.flatten_nchw(x) if (x.is_cuda and not double_backward) else ops.from_cl(x).flatten(1)

@@ -115,9 +115,10 @@ def _x3_auto_images(wv, fwd):
     return img
 
 
-def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None, w8=None):
+def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None, w8=None, xexact=0):
     """w8: the weight bank's staging image of the same weights (conv_weight_bank(image8=...)): 3x3 ring convs the
-    eight-wave engine covers then run dgv2_conv3x3_fwd8 on it."""
+    eight-wave engine covers then run dgv2_conv3x3_fwd8 on it.  xexact (fp32 on conv_x3.hip): channels [0, xexact) of x
+    hold bf16-representable values (dgv2.h: their zero planes are skipped)."""
     B, H, W, C = x.shape
     O = w.shape[0]
     Ho, Wo = g.out_hw(H, W)
@@ -133,8 +134,8 @@ def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None, w
         w8 = _x3_auto_images(w, True)
     if (w8 is not None and _CONV_X3 and x.dtype == torch.float32 and w8.dtype == torch.bfloat16 and g.ring
             and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1)
-            and N.try_call("dgv2_conv3x3_x3_fwd", N.ptr(y), N.ptr(x), N.ptr(w8), B, H, W, C, O, N.ptr(bias), N.ptr(resid),
-                           act, alpha, scale, N.stream())):
+            and N.try_call("dgv2_conv3x3_x3_fwd", N.ptr(y), N.ptr(x), N.ptr(w8), B, H, W, C, min(int(xexact), C), O, N.ptr(bias),
+                           N.ptr(resid), act, alpha, scale, N.stream())):
         return y     # fp32 on the bf16 matrix cores (three-plane split, six products per multiply: conv_x3.hip)
     if _direct_ok(g, C % _kstep(x) == 0):
         taps = [(ky - g.pad, kx - g.pad, ky * g.kw + kx) for ky in range(g.kh) for kx in range(g.kw)]
@@ -293,7 +294,7 @@ _TN_SCRATCH = {}
 _LIB_WGRAD = os.environ.get("DGV2_NO_LIB_WGRAD") is None         # A/B switch for benchmarking
 
 
-def _conv_wgrad_raw(gy, x, g, gscale=None, x3=None):
+def _conv_wgrad_raw(gy, x, g, gscale=None, x3=None, xexact=0):
     """gw fp32 [O,kh,kw,C].  gscale: return scale * gw as a PERMUTED VIEW of a contiguous [O,C,kh,kw] buffer (the
     parameter's layout): the permute-backward of a weight handle then hands the optimizer a contiguous gradient.
     x3: fp32 operands on the bf16 matrix cores (dgv2_conv3x3_x3_wgrad; = the input channel count before padding)."""
@@ -312,7 +313,8 @@ def _conv_wgrad_raw(gy, x, g, gscale=None, x3=None):
         scratch = torch.empty(_WGRAD_SCRATCH[key], device=x.device, dtype=torch.float32)
         gw3 = torch.empty((O, C, 3, 3) if gscale is not None else (O, 3, 3, C), device=x.device, dtype=torch.float32)
         if N.try_call("dgv2_conv3x3_x3_wgrad", N.ptr(gw3), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(x), B, H, W, C,
-                      int(x3), O, 1.0 if gscale is None else float(gscale), int(gscale is not None), N.stream()):
+                      int(x3), min(int(xexact), C), O, 1.0 if gscale is None else float(gscale), int(gscale is not None),
+                      N.stream()):
             return gw3 if gscale is None else gw3.permute(0, 2, 3, 1)
     stream_ok = (_WGRAD_STREAM and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2)
                  and C % (16 // x.element_size()) == 0 and O % (16 // x.element_size()) == 0)
@@ -434,12 +436,12 @@ def _x3_hint(ctx, gy):
 
 class _ConvWgrad(Function):
     @staticmethod
-    def forward(ctx, gy, x, g, gscale=None, x3=None):
+    def forward(ctx, gy, x, g, gscale=None, x3=None, xexact=0):
         gy = gy.contiguous()
         x = x.contiguous()
         ctx.save_for_backward(gy, x)
         ctx.g, ctx.gscale = g, gscale
-        return _conv_wgrad_raw(gy.to(x.dtype), x, g, gscale, x3)
+        return _conv_wgrad_raw(gy.to(x.dtype), x, g, gscale, x3, xexact)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -448,7 +450,7 @@ class _ConvWgrad(Function):
         gy, x = ctx.saved_tensors
         g_gy = _ConvFwd.apply(x, ggw, ctx.g) if ctx.needs_input_grad[0] else None
         g_x = _dgrad(gy, ggw, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[1] else None
-        return g_gy, g_x, None, None, None
+        return g_gy, g_x, None, None, None, None
 
 
 def conv_ring(x, w, geom):
@@ -467,13 +469,17 @@ class _ConvAct(Function):
         # whole backward below on a zero tensor -- for the fp32 epilogue conv a data and a weight gradient of zeros,
         # 0.9 ms per R1 iteration.
         ctx.set_materialize_grads(False)
+        # the caller's promise (Discriminator.forward: the features of a bf16 trunk widened to fp32 for the epilogue):
+        # channels [0, n) of x are bf16-representable -- conv_x3.hip skips their zero planes (forward, weight gradient)
+        ctx.x_exact = int(getattr(x, "_dgv2_exact", 0))
         x = x.contiguous()
         wc, ctx.wt = _bank(w, x)
         ctx.w8t = getattr(w, "_dgv2_w8t", None) if ctx.wt is not None else None
         ctx.gscale = getattr(w, "_dgv2_gscale", None)
         if wc is None:
             wc = _values(w, x.dtype)
-        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale, w8=_bank8(w, x))
+        out = _conv_fwd_raw(x, wc.reshape(w.shape), g, bias.detach().float().contiguous(), 3, alpha, scale, w8=_bank8(w, x),
+                            xexact=ctx.x_exact)
         ctx.save_for_backward(x, w, out)
         ctx.cfg = (g, alpha, scale, bias.numel())
         return out
@@ -486,7 +492,7 @@ class _ConvAct(Function):
         g, alpha, scale, size_b = ctx.cfg
         gpre, gb = _BiasActBackward.apply(gy, out, want_param_grad(ctx, 2), alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre)) if want_param_grad(ctx, 1) else None
+        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre), ctx.x_exact) if want_param_grad(ctx, 1) else None
         return gx, gw, gb, None, None, None
 
 

@@ -520,8 +520,15 @@ int dgv2_conv3x3_dgrad8(void* gx, const void* gy, const void* w8t, int B, int H,
  * replaces: ops.Conv2d(ch(4) + 1, ch(4), 3, 1, 1, ring) + FusedLeakyReLU of Discriminator.epilogue
  * (gans/models/dusty_v2.py:376-379) in the fp32 island of Discriminator.forward (:394-395).  DGV2_ENOTSUP where the
  * kernel does not cover the geometry (W % 32, Cx % 8, Cx >= 64, O % 64): callers then run dgv2_conv_taps in fp32. */
-int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B, int H, int W, int Cx, int O, const float* bias,
-                        const void* resid, int act, float alpha, float scale, void* stream);
+int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B, int H, int W, int Cx, int x_exact, int O,
+                        const float* bias, const void* resid, int act, float alpha, float scale, void* stream);
+/* x_exact (forward and weight gradient): the caller's promise that channels [0, x_exact) of x hold bf16-representable
+ * values -- the activations of a bf16 trunk widened to fp32, which is what the discriminator's epilogue receives
+ * (dusty_v2.py:394: h.to(torch.float32)).  Their planes m and l are zero, so three of the six products of a multiply are
+ * products with zero: they are not issued (same sum, half the MFMAs).  0 = no promise.  The kernels check the promise on
+ * the values they stage; dgv2_conv_x3_status() returns 1 if a launch since the last call met a value that broke it (that
+ * launch then computed with the bf16-rounded input), 0 otherwise; it synchronises the device (tests, debugging). */
+int dgv2_conv_x3_status(void);
 /* Its data gradient: gx [B,H,W,ldx] (fp32) from gy [B,H,W,O] fp32 -- channels [0, C) the gradient (+ resid), [C, ldx)
  * resid or zero.  w3t = the transposed plane images (w8t of dgv2_conv_weight_bank_ex, dtype DGV2_F32:
  * [3][ldx / 64][O / 32][2304 units]) serve the channels of whole 64-channel slabs; wt [ldx, 9, O] fp32 (the bank's
@@ -537,7 +544,7 @@ int dgv2_conv3x3_x3_dgrad(void* gx, const void* gy, const void* w3t, const void*
  * replaces: the cuDNN weight gradient autograd calls for that conv.  DGV2_ENOTSUP: O % 128, C < 64, C % 8, W % 32,
  * more than 16 such channels. */
 int dgv2_conv3x3_x3_wgrad(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x, int B, int H,
-                          int W, int C, int clive, int O, float scale, int param_layout, void* stream);
+                          int W, int C, int clive, int x_exact, int O, float scale, int param_layout, void* stream);
 int dgv2_conv3x3_x3_wgrad_scratch(int64_t* elems, int B, int H, int W, int C, int clive, int O);
 /* Both image sets from weight VALUES w [O, 9, Cp] fp32 (the operand layout of dgv2_conv_taps), for passes that do not
  * run on the weight bank (R1's double backward): w3 [3][O / 64][ceil(Cp / 32)][2304 units of 8 bf16], w3t

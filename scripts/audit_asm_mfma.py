@@ -39,7 +39,7 @@ def scan(lines, stash_in, collect):
     """One linear pass.  Control flow: the MFMAs still pending at a branch are carried to its target label (`stash`),
     nothing is pending behind an unconditional s_branch; run twice so that backward branches are covered too."""
     kernel, in_asm = None, False
-    pending, stash = [], {}
+    pending, stash, pend_dst = [], {}, []
     flagged, n_asm = {}, {}
     for no, raw in enumerate(lines, 1):
         s = raw.strip()
@@ -48,7 +48,7 @@ def scan(lines, stash_in, collect):
             if name.startswith(".L"):
                 pending = pending + stash_in.get((kernel, name), [])
             else:
-                kernel, pending = name, []
+                kernel, pending, pend_dst = name, [], []
             continue
         if s.startswith(";;#ASMSTART"):
             in_asm = True
@@ -69,10 +69,15 @@ def scan(lines, stash_in, collect):
             ops = [t.strip() for t in s[len(op):].split(",")]
             k = 4 * passes(op)
             pending = [(a, b, c, d - k) for a, b, c, d in pending if d - k > 0]
+            pend_dst = [(a, b, c, d - k) for a, b, c, d in pend_dst if d - k > 0]
             if in_asm and len(ops) >= 4:
                 src = regs(ops[1]) | regs(ops[2]) | (regs(ops[3]) - regs(ops[0]))
                 n_asm[kernel] = n_asm.get(kernel, 0) + 1
                 pending.append((no, s, src, {4: 5, 8: 11, 16: 19}[passes(op)]))
+                # the RESULT: a VALU / LDS / memory instruction that reads or overwrites the destination before the MFMA has
+                # written it (passes + 3 wait states; the compiler pads builtin MFMAs, not asm ones) -- the accumulator
+                # copies the register allocator makes around branches at high pressure
+                pend_dst.append((no, s, regs(ops[0]), passes(op) + 4))
             continue
         if op.startswith("v_") and not in_asm:
             ops = [t.strip() for t in s[len(op):].split(",")]
@@ -80,11 +85,17 @@ def scan(lines, stash_in, collect):
             for mno, mtxt, src, _ in pending:
                 if dst & src and (mno, no) not in flagged.setdefault(kernel, {}):
                     flagged[kernel][(mno, no)] = (mtxt, s)
+        if not in_asm and op.startswith(("v_", "ds_write", "ds_store", "global_store", "buffer_store", "scratch_store", "flat_store")):
+            touched = regs(s[len(op):])
+            for mno, mtxt, dreg, _ in pend_dst:
+                if touched & dreg and (mno, no) not in flagged.setdefault(kernel, {}):
+                    flagged[kernel][(mno, no)] = (mtxt, s + "      ; touches a result in flight")
         k = 1
         if op == "s_nop":
             m = re.search(r"s_nop\s+(\d+)", s)
             k = int(m.group(1)) + 1 if m else 1
         pending = [(a, b, c, d - k) for a, b, c, d in pending if d - k > 0]
+        pend_dst = [(a, b, c, d - k) for a, b, c, d in pend_dst if d - k > 0]
     return stash, flagged, n_asm
 
 
@@ -94,7 +105,7 @@ def main(path):
     _, flagged, n_asm = scan(lines, stash, True)
     for k in sorted(n_asm):
         f = flagged.get(k, {})
-        print(f"{k[:100]}: {n_asm[k]} asm MFMAs, {len(f)} VALU writes into live MFMA sources")
+        print(f"{k[:100]}: {n_asm[k]} asm MFMAs, {len(f)} VALU writes into live MFMA sources / accesses to results in flight")
         for (mno, no), (mtxt, s) in list(sorted(f.items()))[:6]:
             print(f"    line {mno}: {mtxt}\n      <- line {no}: {s}")
     return sum(len(v) for v in flagged.values())

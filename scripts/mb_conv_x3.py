@@ -33,5 +33,9 @@ for B in (64, 128):
     d = t(lambda: nat._conv_dgrad_raw(gy, None, g, (B, H, W, cp), wt=wt))
     e = t(lambda: nat._conv_wgrad_raw(gy, x, g, 0.01))
     f = t(lambda: nat._conv_wgrad_raw(gy, x, g, 0.01, x3=C))
+    xe = x.clone(); xe[..., :512] = xe[..., :512].bfloat16().float()
+    a2 = t(lambda: nat._conv_fwd_raw(xe, wr, g, bias, 3, 0.2, 1.4, w8=w3, xexact=512))
+    f2 = t(lambda: nat._conv_wgrad_raw(gy, xe, g, 0.01, x3=C, xexact=512))
     print(f"B={B} {H}x{W} {C}->{O}: fwd x3 {a:7.1f} us ({fl / a / 1e6:5.0f} TF/s fp32-equiv, {6 * fl / a / 1e6:5.0f} bf16-MFMA)  fp32 {b:7.1f} us ({fl / b / 1e6:5.0f})"
+          f" [x_exact 512: fwd {a2:7.1f} us, wgrad {f2:7.1f} us]"
           f" | dgrad x3 {c:7.1f} us  fp32 {d:7.1f} us | wgrad x3 {f:7.1f} us ({fl / f / 1e6:5.0f}) fp32 {e:7.1f} us ({fl / e / 1e6:5.0f})")

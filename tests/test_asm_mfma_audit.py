@@ -48,6 +48,18 @@ kern_behind_an_mfma:
 	v_mfma_f32_16x16x32_bf16 v[82:85], v[218:221], v[46:49], v[82:85]
 	;;#ASMEND
 	v_mov_b64_e32 v[42:43], v[110:111]
+kern_result_copied_too_early:
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[76:79], v[140:143], v[124:127], v[76:79]
+	s_nop 4
+	;;#ASMEND
+	v_mov_b64_e32 v[138:139], v[78:79]
+kern_result_copied_in_time:
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[76:79], v[140:143], v[124:127], v[76:79]
+	s_nop 7
+	;;#ASMEND
+	v_mov_b64_e32 v[138:139], v[78:79]
 """
 
 
@@ -55,10 +67,14 @@ def test_auditor_on_the_pattern_that_broke_the_stride2_data_gradient(tmp_path, c
     import audit_asm_mfma as au
     p = tmp_path / "x.s"
     p.write_text(BROKEN)
-    assert au.main(str(p)) == 2           # kern_bad (B overwritten behind its MFMA) and kern_branch's target (A overwritten)
+    # kern_bad (B overwritten behind its MFMA), kern_branch's target (A overwritten), and -- round 4, conv_x3's data gradient
+    # at 256 registers -- the allocator's copy of an accumulator five wait states behind the MFMA that writes it (the
+    # upper half of the fragment arrived stale; eight wait states are enough)
+    assert au.main(str(p)) == 3
     out = capsys.readouterr().out
     assert "kern_bad: 2 asm MFMAs, 1 VALU" in out and "kern_padded: 1 asm MFMAs, 0 VALU" in out
     assert "kern_branch: 1 asm MFMAs, 1 VALU" in out and "kern_behind_an_mfma: 2 asm MFMAs, 0 VALU" in out
+    assert "kern_result_copied_too_early: 1 asm MFMAs, 1 VALU" in out and "kern_result_copied_in_time: 1 asm MFMAs, 0 VALU" in out
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
@@ -67,9 +83,9 @@ def test_shipped_kernels_with_asm_mfmas_have_no_unpadded_source_overwrite():
     csrc = os.path.join(ROOT, "dusty-gan-v2_amd", "csrc")
     def issues_asm_mfmas(f):
         txt = open(os.path.join(csrc, f)).read()
-        return 'asm volatile("v_mfma' in txt or "MfmaAsm<" in txt    # (MfmaAsm: the in-place forms of gemm_core.h)
+        return ("asm volatile(" in txt and "v_mfma_" in txt) or "MfmaAsm<" in txt    # (MfmaAsm: the in-place forms of gemm_core.h)
     files = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip") and issues_asm_mfmas(f)]
-    assert {"conv_direct.hip", "conv8.hip", "conv_wgrad_stream.hip"} <= set(files)
+    assert {"conv_direct.hip", "conv8.hip", "conv_wgrad_stream.hip", "conv_x3.hip"} <= set(files)
     assert files, "no source issues MFMAs as inline asm any more: drop this test"
     with tempfile.TemporaryDirectory() as d:
         def isa(f):

@@ -1130,10 +1130,29 @@ def test_conv_x3_is_fp32_equivalent(nat, B, H, W, C, O):
         assert torch.equal(gauto, ggot)
     elif cpad % 64 <= 16:
         assert float((gauto - gref).abs().max()) <= 1e-5 * float(gref.abs().max())
-    # a geometry the kernel does not cover reports ENOTSUP (-> False here), it is not mis-computed
+    # x_exact: input channels that hold bf16-representable values (the features of a bf16 trunk in front of the fp32
+    # epilogue) have zero m / l planes -- the kernels skip those planes' products: the SAME bits as with them, and a value
+    # that breaks the promise raises dgv2_conv_x3_status()
     import dgv2_native as N
+    ne = min(C // 32 * 32, 64 * (C // 64)) if C >= 64 else 0
+    if ne:
+        xe = xp.clone()
+        xe[..., :ne] = xe[..., :ne].bfloat16().float()
+        assert N.lib.dgv2_conv_x3_status() == 0
+        full = nat._conv_fwd_raw(xe, wr, geom, bias.to(DEV), 3, 0.25, 2.0, w8=w3)
+        skip = nat._conv_fwd_raw(xe, wr, geom, bias.to(DEV), 3, 0.25, 2.0, w8=w3, xexact=ne)
+        assert torch.equal(full, skip)
+        if has_w:
+            assert torch.equal(nat._conv_wgrad_raw(cl(gy), xe, geom, x3=C), nat._conv_wgrad_raw(cl(gy), xe, geom, x3=C, xexact=ne))
+        assert N.lib.dgv2_conv_x3_status() == 0
+        nat._conv_fwd_raw(xp, wr, geom, bias.to(DEV), 3, 0.25, 2.0, w8=w3, xexact=ne)       # xp is not bf16-exact
+        assert N.lib.dgv2_conv_x3_status() == 1 and N.lib.dgv2_conv_x3_status() == 0
+        if has_w:
+            nat._conv_wgrad_raw(cl(gy), xp, geom, x3=C, xexact=ne)
+            assert N.lib.dgv2_conv_x3_status() == 1
+    # a geometry the kernel does not cover reports ENOTSUP (-> False here), it is not mis-computed
     y = torch.empty(1, 4, 48, 64, device=DEV)
-    assert N.try_call("dgv2_conv3x3_x3_fwd", N.ptr(y), N.ptr(y), N.ptr(w3), 1, 4, 48, 64, 64, None, None, 0, 0.2, 1.0,
+    assert N.try_call("dgv2_conv3x3_x3_fwd", N.ptr(y), N.ptr(y), N.ptr(w3), 1, 4, 48, 64, 0, 64, None, None, 0, 0.2, 1.0,
                       N.stream()) is False
 
 
