@@ -58,49 +58,85 @@ __device__ __forceinline__ int find_group(const GLArgs& p, int tile) {
 }
 
 // forward: y_l[b, n] = act( alpha * rn[b] * sum_k x[b, k] W_l[n, k] + beta * bias_l[n] )
+// A block is a 16 x 64 tile; its four waves SPLIT K (wave w contracts k in [w K/4, (w+1) K/4) for all four 16-column
+// groups) and fold through LDS.  The first form gave every wave its own 16 columns and the whole of K: a chain of K / 64
+// round trips to L2 with eight loads each and 128 dependent MFMAs -- 16 us for microseconds of work (three such launches
+// were 8 % of the generator-only forward).  Here a wave's loads of 128 k are all in flight at once and its four
+// accumulators are independent chains.
 __global__ __launch_bounds__(256) void glin_fwd_kernel(GLArgs p) {
+  __shared__ f32x4 red[3][4][64];
+  __shared__ float red_ss[4][16];
   const int l = find_group(p, blockIdx.x);
   const GLGroup& g = p.g[l];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, kq = lane >> 4;
   const int b0 = blockIdx.y * 16;
-  const int n0 = (blockIdx.x - g.tile0) * 64 + wave * 16;
-  const int brow = min(b0 + r, p.B - 1), nrow = min(n0 + r, g.N - 1);
-  const float4* xa = reinterpret_cast<const float4*>(g.a + (int64_t)brow * g.lda) + kq;
-  const float4* wb = reinterpret_cast<const float4*>(g.b + (int64_t)nrow * p.K) + kq;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  float ss = 0.f;
-  const int steps = p.K >> 4;                     // 16 k per step: element j of lane group kq is k = 16 s + 4 kq + j
-  for (int s = 0; s < steps; s += 4) {            // K % 64 == 0 (host-checked): eight loads in flight per trip
-    float4 a[4], b[4];
+  const int n0 = (blockIdx.x - g.tile0) * 64;
+  const int kw = p.K >> 2;                        // this wave's share of K (K % 64 == 0: a multiple of 16)
+  const int brow = min(b0 + r, p.B - 1);
+  const float4* xa = reinterpret_cast<const float4*>(g.a + (int64_t)brow * g.lda + wave * kw) + kq;
+  const float4* wb[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u] = xa[4 * (s + u)];
-      b[u] = wb[4 * (s + u)];
+  for (int c = 0; c < 4; ++c)
+    wb[c] = reinterpret_cast<const float4*>(g.b + (int64_t)min(n0 + 16 * c + r, g.N - 1) * p.K + wave * kw) + kq;
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ss = 0.f;
+  const int steps = kw >> 4;                      // 16 k per step: element j of lane group kq is k = 16 s + 4 kq + j
+  for (int s0 = 0; s0 < steps; s0 += 8) {         // up to 128 k per trip: 40 loads in flight
+    float4 a[8], b[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = min(s0 + u, steps - 1);       // (a short last trip re-loads its last step; not accumulated)
+      a[u] = xa[4 * s];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[u][c] = wb[c][4 * s];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (p.prenorm) ss = fmaf(a[u].x, a[u].x, fmaf(a[u].y, a[u].y, fmaf(a[u].z, a[u].z, fmaf(a[u].w, a[u].w, ss))));
-      acc = mfma4(a[u], b[u], acc);
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u < steps) {
+        if (p.prenorm) ss = fmaf(a[u].x, a[u].x, fmaf(a[u].y, a[u].y, fmaf(a[u].z, a[u].z, fmaf(a[u].w, a[u].w, ss))));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = mfma4(a[u], b[u][c], acc[c]);
+      }
     }
   }
-  float rn = 1.f;
-  if (p.prenorm) {   // row r's sum of squares lives in the four lanes (r, kq = 0..3)
+  if (p.prenorm) {   // row r's partial sum of squares lives in the four lanes (r, kq = 0..3) of every wave
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
-    rn = rsqrtf(ss / (float)p.K + 1e-8f);
-    if (p.rnorm && blockIdx.x == 0 && wave == 0 && kq == 0 && b0 + r < p.B) p.rnorm[b0 + r] = rn;
+    if (kq == 0) red_ss[wave][r] = ss;
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave - 1][c][lane] = acc[c];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  float rn = 1.f;
+  if (p.prenorm) {
+    rn = rsqrtf((red_ss[0][r] + red_ss[1][r] + red_ss[2][r] + red_ss[3][r]) / (float)p.K + 1e-8f);
+    if (p.rnorm && blockIdx.x == 0 && kq == 0 && b0 + r < p.B) p.rnorm[b0 + r] = rn;
   }
   // C layout: column (n) = lane & 15, rows (batch) 4 kq + j
-  const int n = n0 + r;
-  const float bv = (g.bias && n < g.N) ? g.bias[n] * p.beta : 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int bb = b0 + 4 * kq + j;
-    const float rj = p.prenorm ? __shfl(rn, 4 * kq + j, 64) : 1.f;   // the factor of row 4 kq + j sits in lane r = 4 kq + j
-    float v = fmaf(acc[j] * rj, p.alpha, bv);
-    if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-    if (bb < p.B && n < g.N) g.out[(int64_t)bb * g.ldo + n] = v;
+  for (int c = 0; c < 4; ++c) {
+    f32x4 t = acc[c];
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const f32x4 o = red[w][c][lane];
+      t[0] += o[0]; t[1] += o[1]; t[2] += o[2]; t[3] += o[3];
+    }
+    const int n = n0 + 16 * c + r;
+    const float bv = (g.bias && n < g.N) ? g.bias[n] * p.beta : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int bb = b0 + 4 * kq + j;
+      const float rj = p.prenorm ? __shfl(rn, 4 * kq + j, 64) : 1.f;   // the factor of row 4 kq + j sits in lane r = 4 kq + j
+      float v = fmaf(t[j] * rj, p.alpha, bv);
+      if (p.act == 1) v = v > 0.f ? v : v * p.slope;
+      if (bb < p.B && n < g.N) g.out[(int64_t)bb * g.ldo + n] = v;
+    }
   }
 }
 
