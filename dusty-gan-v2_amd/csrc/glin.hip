@@ -141,51 +141,61 @@ __global__ __launch_bounds__(256) void glin_fwd_kernel(GLArgs p) {
 }
 
 // d-input: dx[b, k] (+)= alpha * sum_l sum_n gm_l[b, n] W_l[n, k],  gm = g * (mask > 0 ? 1 : slope).  The groups of one
-// launch all ADD into the output of group 0's `out` layout (ldo): the host launches one call per distinct input (style
-// index), whose groups are the layers that read it; first = overwrite.
-__global__ __launch_bounds__(256) void glin_din_kernel(GLArgs p) {
+// launch all ADD into ONE output (the layers that read one input): the contraction runs over every output feature of every
+// layer (6 k for the 19 style affines), so it is cut into CHUNKS of up to 256 features (blockIdx.z; GLGroup::tile0 = the
+// group's first chunk): a block contracts one chunk for a 16 x 64 tile of dx with all its loads in flight and leaves a
+// partial, glin_din_reduce_kernel folds the chunks (fixed order: reproducible).  The first form walked all layers in one
+// wave: a serial chain of ~190 round trips to L2.
+constexpr int GL_CHUNK = 256;
+
+__global__ __launch_bounds__(256) void glin_din_kernel(GLArgs p, float* __restrict__ part) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, kq = lane >> 4;
   const int b0 = blockIdx.y * 16;
   const int k0 = blockIdx.x * 64 + wave * 16;
   const int brow = min(b0 + r, p.B - 1);
+  const int l = find_group(p, blockIdx.z);
+  const GLGroup& g = p.g[l];
+  const int nbeg = (blockIdx.z - g.tile0) * GL_CHUNK, nend = min(nbeg + GL_CHUNK, g.N);
+  const float* ga = g.a + (int64_t)brow * g.lda;
+  const float* ma = g.mask ? g.mask + (int64_t)brow * g.lda : nullptr;
+  const float* wcol = g.b + min(k0 + r, p.K - 1);             // W[n][k0 + r]: contiguous over the 16 lanes of a group
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int l = 0; l < p.L; ++l) {
-    const GLGroup& g = p.g[l];
-    const float* ga = g.a + (int64_t)brow * g.lda;
-    const float* ma = g.mask ? g.mask + (int64_t)brow * g.lda : nullptr;
-    const float* wcol = g.b + k0 + r;                       // W[n][k0 + r]: contiguous over the 16 lanes of a group
-    const int steps = g.N >> 4;                             // N % 32 == 0 (host-checked): two steps per trip
-    for (int s = 0; s < steps; s += 2) {
-      float4 a[2], b[2];
+  const int steps = (nend - nbeg) >> 4;                         // N % 32 == 0 (host-checked): whole steps of 16
+  for (int s0 = 0; s0 < steps; s0 += 8) {
+    float4 a[8], b[8];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int nb = 16 * (s + u) + 4 * kq;
-        a[u] = *reinterpret_cast<const float4*>(ga + nb);
-        if (ma) {
-          const float4 m = *reinterpret_cast<const float4*>(ma + nb);
-          a[u].x *= m.x > 0.f ? 1.f : p.slope; a[u].y *= m.y > 0.f ? 1.f : p.slope;
-          a[u].z *= m.z > 0.f ? 1.f : p.slope; a[u].w *= m.w > 0.f ? 1.f : p.slope;
-        }
-        b[u].x = wcol[(int64_t)(nb + 0) * p.K]; b[u].y = wcol[(int64_t)(nb + 1) * p.K];
-        b[u].z = wcol[(int64_t)(nb + 2) * p.K]; b[u].w = wcol[(int64_t)(nb + 3) * p.K];
+    for (int u = 0; u < 8; ++u) {
+      const int nb = nbeg + 16 * min(s0 + u, steps - 1) + 4 * kq;
+      a[u] = *reinterpret_cast<const float4*>(ga + nb);
+      if (ma) {
+        const float4 m = *reinterpret_cast<const float4*>(ma + nb);
+        a[u].x *= m.x > 0.f ? 1.f : p.slope; a[u].y *= m.y > 0.f ? 1.f : p.slope;
+        a[u].z *= m.z > 0.f ? 1.f : p.slope; a[u].w *= m.w > 0.f ? 1.f : p.slope;
       }
-      acc = mfma4(a[0], b[0], acc);
-      acc = mfma4(a[1], b[1], acc);
+      b[u].x = wcol[(int64_t)(nb + 0) * p.K]; b[u].y = wcol[(int64_t)(nb + 1) * p.K];
+      b[u].z = wcol[(int64_t)(nb + 2) * p.K]; b[u].w = wcol[(int64_t)(nb + 3) * p.K];
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < steps) acc = mfma4(a[u], b[u], acc);
   }
-  const GLGroup& g0 = p.g[0];
   const int k = k0 + r;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int bb = b0 + 4 * kq + j;
-    if (bb < p.B && k < p.K) {
-      float* q = g0.out + (int64_t)bb * g0.ldo + k;
-      const float v = acc[j] * p.alpha;
-      *q = p.act ? *q + v : v;                              // act != 0: accumulate into what an earlier launch wrote
-    }
+    if (bb < p.B && k < p.K) part[((int64_t)blockIdx.z * p.B + bb) * p.K + k] = acc[j];
   }
+}
+
+__global__ __launch_bounds__(256) void glin_din_reduce_kernel(float* __restrict__ dx, int ldx, const float* __restrict__ part,
+                                                              int nchunks, int B, int K, float alpha, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * K) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * B * K + i];
+  float* q = dx + (int64_t)(i / K) * ldx + i % K;
+  *q = accumulate ? *q + s * alpha : s * alpha;
 }
 
 // d-weight: dW_l[n, k] = alpha * sum_b gm_l[b, n] x[b, k] (* rn[b] when the forward normalised x),  dbias_l[n] = beta * sum_b gm_l[b, n]
@@ -270,9 +280,11 @@ extern "C" int dgv2_glin_fwd(float* const* y, const float* const* x, const float
 
 // dx [B, K] at row stride ldx (=|+=) alpha * sum_l (g_l . act'(y_l)) W_l over the L layers that read this input
 // (accumulate != 0: added to what dx holds).  g_l, y_l [B, N_l] contiguous (y_l NULL: no activation), N_l % 32 == 0.
-extern "C" int dgv2_glin_dinput(float* dx, int ldx, const float* const* g, const float* const* yact, const float* const* w,
-                                const int* N, int L, int B, int K, float alpha, float slope, int accumulate, void* stream) {
-  if (!dx || !g || !w || !N || L < 1 || L > GL_MAX || B < 1 || K < 16 || (K & 15)) return DGV2_EINVAL;
+// scratch: fp32 [>= B * K * sum_l ceil(N_l / 256)] (the chunk partials of the contraction over the layers' features).
+extern "C" int dgv2_glin_dinput(float* dx, int ldx, float* scratch, int64_t scratch_elems, const float* const* g,
+                                const float* const* yact, const float* const* w, const int* N, int L, int B, int K, float alpha,
+                                float slope, int accumulate, void* stream) {
+  if (!dx || !scratch || !g || !w || !N || L < 1 || L > GL_MAX || B < 1 || K < 16 || (K & 15)) return DGV2_EINVAL;
   GLArgs p;
   float* outs[GL_MAX];
   int lda[GL_MAX], ldo[GL_MAX];
@@ -280,9 +292,12 @@ extern "C" int dgv2_glin_dinput(float* dx, int ldx, const float* const* g, const
     if (N[l] & 31) return DGV2_ENOTSUP;
     outs[l] = dx; lda[l] = N[l]; ldo[l] = ldx;
   }
-  if (fill(p, L, g, w, nullptr, yact, outs, nullptr, N, lda, nullptr, ldo, 64) < 0) return DGV2_EINVAL;
+  const int nchunks = fill(p, L, g, w, nullptr, yact, outs, nullptr, N, lda, nullptr, ldo, GL_CHUNK);
+  if (nchunks < 0 || scratch_elems < (int64_t)nchunks * B * K || !aligned16(scratch)) return DGV2_EINVAL;
   p.L = L; p.B = B; p.K = K; p.alpha = alpha; p.beta = 0.f; p.slope = slope; p.act = accumulate; p.prenorm = 0; p.rnorm = nullptr;
-  glin_din_kernel<<<dim3((K + 63) / 64, (B + 15) / 16), 256, 0, (hipStream_t)stream>>>(p);
+  hipStream_t st = (hipStream_t)stream;
+  glin_din_kernel<<<dim3((K + 63) / 64, (B + 15) / 16, nchunks), 256, 0, st>>>(p, scratch);
+  glin_din_reduce_kernel<<<(B * K + 255) / 256, 256, 0, st>>>(dx, ldx, scratch, nchunks, B, K, alpha, accumulate);
   DGV2_RETURN_LAST();
 }
 

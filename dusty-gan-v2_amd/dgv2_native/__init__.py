@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGV2_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -120,7 +120,8 @@ SIGNATURES = {
     "dgv2_conv_weight_bank": [_c_ptr] * 8 + [_c_int, _c_int, _c_ptr],
     "dgv2_conv_weight_bank_ex": [_c_ptr] * 10 + [_c_int, _c_int, _c_ptr],
     "dgv2_glin_fwd": [_c_ptr] * 6 + [_c_int] * 3 + [_c_f32, _c_f32, _c_int, _c_f32, _c_int, _c_ptr, _c_ptr],
-    "dgv2_glin_dinput": [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
+    "dgv2_glin_dinput": [_c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_f32, _c_f32,
+                         _c_int, _c_ptr],
     "dgv2_glin_dweight": [_c_ptr] * 7 + [_c_int] * 3 + [_c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr],
     "dgv2_conv3x3_dgrad8": [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr, _c_int, _c_ptr],
     "dgv2_conv3x3_x3_wgrad_scratch": [_c_ptr] + [_c_int] * 6,

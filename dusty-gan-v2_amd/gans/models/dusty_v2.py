@@ -598,15 +598,19 @@ class Generator(base.Generator):
         mm = self.measurement_model
         if len(mm.gumbel_sigmoid._forward_hooks) > 0:
             return super().forward(z, angle, style_mixing, truncation_psi, input_w)
-        w = z if input_w else self.forward_mapping(z, style_mixing)
-        assert w.ndim == 3
-        if self.training:
-            self.moving_average_w(w)
-        else:
-            w = self.truncation_trick(w, truncation_psi)
-        angle = self.angle if angle is None else angle
-        noise = noise or {}
-        skip, shift = self.synthesis_network.synthesize(w, angle, noise.get("shifts", "auto"), composable=second_order)
+        # bf16 trunks, first order: the mapping network and the style affines take the grouped fp32 launches (csrc/glin.hip)
+        # in gradient-recording passes too (native.glin_grad: what it gains and why the fp32 parity mode stays out)
+        low = all(getattr(m, "use_fp16", False) for m in self.synthesis_network.layers)
+        with native.glin_grad(low and not second_order):
+            w = z if input_w else self.forward_mapping(z, style_mixing)
+            assert w.ndim == 3
+            if self.training:
+                self.moving_average_w(w)
+            else:
+                w = self.truncation_trick(w, truncation_psi)
+            angle = self.angle if angle is None else angle
+            noise = noise or {}
+            skip, shift = self.synthesis_network.synthesize(w, angle, noise.get("shifts", "auto"), composable=second_order)
         B, H, W, _ = skip.shape
         u = noise.get("gumbel_u")
         u = native.gumbel_uniform((B, 1, H, W), skip.device) if u is None else u.float().contiguous()

@@ -4,6 +4,7 @@ Part of gans.models.ops.native (autograd-aware wrappers around the libdgv2 C ABI
 parts import each other in order, every name stays reachable as native.<name>.
 """
 import math
+import contextlib
 import os
 
 import torch
@@ -72,17 +73,33 @@ _KIDX_CACHE = {}
 
 
 _GLIN = os.environ.get("DGV2_NO_GLIN") is None   # A/B switch for benchmarking
-# Passes that record a graph for autograd keep the library calls unless DGV2_GLIN_GRAD=1: measured on one box the grouped
-# forward + its two backward launches against addmm / baddbmm and their autograd is a wash for the training iteration
-# (4 132 / 4 136 vs 4 150 img/s: the 12 MB weight-gradient launch gives back what the forward saves), while the
-# gradient-free passes -- the D step's generator forward, sampling, BASELINE configs[1] -- gain 12 % (56.2 k vs 50.0 k img/s)
+# Passes that record a graph for autograd keep the library calls unless DGV2_GLIN_GRAD=1 or inside glin_grad() (the
+# generator's bf16 passes); the gradient-free passes -- the D step's generator forward, sampling, BASELINE configs[1] --
+# always take the grouped launches (+12 %: 56.2 k vs 50.0 k img/s)
 _GLIN_GRAD = os.environ.get("DGV2_GLIN_GRAD") is not None
+_GLIN_GRAD_CTX = [False]
 _GLIN_MAX = 24
 
 
+@contextlib.contextmanager
+def glin_grad(on=True):
+    """Inside: gradient-recording passes take the grouped-Linear launches too (first order only).  Round 4: with the input
+    gradient contracted in 256-feature chunks (it was one serial chain over all 19 layers) the training iteration gains
+    1.7 % (4 704 vs 4 616 / 4 634 img/s on one box).  The generator switches it on for its bf16 passes; the fp32 parity mode
+    keeps the library GEMMs: same fp32 arithmetic, another summation order -- enough to flip a pixel of the hard ray-drop
+    threshold against the float64 oracle and move a few gradient tensors from 0.9e-3 to 1.1-1.7e-3 of their maximum."""
+    old = _GLIN_GRAD_CTX[0]
+    _GLIN_GRAD_CTX[0] = bool(on) and os.environ.get("DGV2_NO_GLIN_GRAD") is None
+    try:
+        yield
+    finally:
+        _GLIN_GRAD_CTX[0] = old
+
+
 def glin_wanted(*tensors):
-    """Whether a call with these inputs should take the grouped-Linear launches (see _GLIN_GRAD)."""
-    return _GLIN and (_GLIN_GRAD or not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)))
+    """Whether a call with these inputs should take the grouped-Linear launches (see _GLIN_GRAD, glin_grad)."""
+    return _GLIN and (_GLIN_GRAD or _GLIN_GRAD_CTX[0]
+                      or not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)))
 
 
 def _ptrs(ptrs):
@@ -151,18 +168,21 @@ class _GroupedLinear(Function):
         if ctx.needs_input_grad[1] and live:
             if prenorm:
                 raise RuntimeError("dgv2: gradient w.r.t. the input of a pixel-normalised grouped Linear is not built")
+            chunks = lambda sel: sum((Ns[l] + 255) // 256 for l in sel)
             if x.dim() == 2:
                 gx = torch.empty((B, K), device=dev, dtype=torch.float32)
-                N.call("dgv2_glin_dinput", N.ptr(gx), K, _ptr_array([gs[l] for l in live]), _ptr_array([ys[l] for l in live]),
-                       _ptr_array([ws_[l] for l in live]), _int_array([Ns[l] for l in live]), len(live), B, K, float(alpha),
-                       float(slope), 0, N.stream())
+                scratch = torch.empty(chunks(live) * B * K, device=dev, dtype=torch.float32)
+                N.call("dgv2_glin_dinput", N.ptr(gx), K, N.ptr(scratch), scratch.numel(), _ptr_array([gs[l] for l in live]),
+                       _ptr_array([ys[l] for l in live]), _ptr_array([ws_[l] for l in live]), _int_array([Ns[l] for l in live]),
+                       len(live), B, K, float(alpha), float(slope), 0, N.stream())
             else:
                 S = x.shape[1]
                 gx = torch.zeros((B, S, K), device=dev, dtype=torch.float32)
                 for sidx in sorted({kidx[l] for l in live}):
                     sel = [l for l in live if kidx[l] == sidx]
-                    N.call("dgv2_glin_dinput", gx.data_ptr() + 4 * sidx * K, S * K, _ptr_array([gs[l] for l in sel]),
-                           _ptr_array([ys[l] for l in sel]), _ptr_array([ws_[l] for l in sel]),
+                    scratch = torch.empty(chunks(sel) * B * K, device=dev, dtype=torch.float32)
+                    N.call("dgv2_glin_dinput", gx.data_ptr() + 4 * sidx * K, S * K, N.ptr(scratch), scratch.numel(),
+                           _ptr_array([gs[l] for l in sel]), _ptr_array([ys[l] for l in sel]), _ptr_array([ws_[l] for l in sel]),
                            _int_array([Ns[l] for l in sel]), len(sel), B, K, float(alpha), float(slope), 0, N.stream())
         return (None, gx) + tuple(gws) + tuple(gbs)
 

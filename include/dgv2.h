@@ -817,9 +817,12 @@ int dgv2_glin_fwd(float* const* y, const float* const* x, const float* const* w,
                   const int* lda, int L, int B, int K, float alpha, float beta, int act, float slope, int prenorm,
                   float* rnorm, void* stream);
 /* Its input gradient: dx [B,K] at row stride ldx (=|+= when accumulate) alpha * sum_l (g_l . act'(y_l)) W_l over the L
- * layers that read this input; g_l, y_l [B,N_l] contiguous (yact entries NULL: no activation), N_l % 32 == 0. */
-int dgv2_glin_dinput(float* dx, int ldx, const float* const* g, const float* const* yact, const float* const* w,
-                     const int* N, int L, int B, int K, float alpha, float slope, int accumulate, void* stream);
+ * layers that read this input; g_l, y_l [B,N_l] contiguous (yact entries NULL: no activation), N_l % 32 == 0.  The
+ * contraction over all layers' features runs in chunks of 256 (one block each) whose partials a second kernel folds in
+ * fixed order: scratch fp32 [>= B * K * sum_l ceil(N_l / 256)]. */
+int dgv2_glin_dinput(float* dx, int ldx, float* scratch, int64_t scratch_elems, const float* const* g,
+                     const float* const* yact, const float* const* w, const int* N, int L, int B, int K, float alpha,
+                     float slope, int accumulate, void* stream);
 /* ... and the parameter gradients of all L layers in one launch: dW_l [N_l,K] = alpha * (g_l . act'(y_l))^T (x_l * rnorm),
  * dbias_l [N_l] = beta * column sums (dbias or entries NULL: skipped); x_l rows at stride ldx[l], rnorm [B] or NULL. */
 int dgv2_glin_dweight(float* const* dw, float* const* dbias, const float* const* g, const float* const* yact,
