@@ -1,7 +1,7 @@
 #!/bin/bash
-O=gpurun_out/r4x; mkdir -p $O
+O=gpurun_out/r5c; mkdir -p $O
 timeout 300 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "conv_x3" > $O/test_x3.txt 2>&1; echo "rc=$?"; tail -2 $O/test_x3.txt
-bash scripts/refresh_profiles.sh r4x > $O/refresh.log 2>&1
+bash scripts/refresh_profiles.sh r5c > $O/refresh.log 2>&1
 for f in bench_default bench_gfwd bench_128x1024_bf16 bench_128x1024_fp8 bench_one_rank_rccl; do python -c "
 import json,sys
 try:
