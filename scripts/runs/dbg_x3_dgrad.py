@@ -1,5 +1,5 @@
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "dusty-gan-v2_amd"))
 from gans.models.ops import native as nat
 torch.manual_seed(0)
