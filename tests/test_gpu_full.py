@@ -351,3 +351,51 @@ def test_forward_of_the_discriminator_is_reproducible():
         assert torch.isfinite(y0).all()
         bad = sum(int(not torch.equal(D(xin, splits=2), y0)) for _ in range(100))
     assert bad == 0, f"{bad} of 100 forwards differ from the first"
+
+
+@pytest.mark.parametrize("low", [False, True])
+def test_r1_pass_with_the_epilogue_conv_on_the_matrix_cores_matches_the_exact_fp32_conv(low):
+    """R1 (reference: trainer.py:419-451) through the discriminator, once with its fp32 epilogue conv on the bf16 matrix
+    cores (native.x3_auto: plane images built per call -- the pass has no weight bank --, the 15 padding channels told apart
+    by the `live` map; bf16 trunk: the zero planes of its features skipped) and once on the exact fp32 MFMA kernels;
+    everything else in the two passes is the same launch.  fp32 trunk: the penalty agrees to 1e-5, every weight gradient
+    to the fp32 accumulation noise both kernels carry (< 5e-4 of the tensor's norm; see below).  bf16 trunk: the 1e-6 differences of the
+    epilogue's results flip bf16 roundings of the trunk's first- and second-order gradients behind it, every tensor --
+    the epilogue's own second-order terms included -- then agrees to a few 1e-3.  In-situ check of what
+    tests/test_gpu_ops.py::test_conv_x3_is_fp32_equivalent holds per call."""
+    import dgv2_native as N
+    from gans.models.ops import native as nat
+    torch.manual_seed(3)
+    _, D = build_models(full_cfg(low), DEV)
+    D.requires_grad_(True)
+    xr = (torch.rand(8, 1, 64, 512, device=DEV) * 2 - 1)
+    conv = D.epilogue[1]
+    live = {(conv.in_ch + 15) // 16 * 16: conv.in_ch}
+
+    def run(on):
+        for p in D.parameters():
+            p.grad = None
+        x = xr.clone().requires_grad_(True)
+        with nat.x3_auto(on, live):
+            y = D(x, double_backward=True)
+            (g,) = torch.autograd.grad(y.sum(), [x], create_graph=True)
+            r1 = (g.float() ** 2).sum(dim=[1, 2, 3]).mean()
+            r1.backward()
+        return float(r1.detach()), {k: p.grad.detach().float().clone() for k, p in D.named_parameters() if p.grad is not None}
+
+    r_off, g_off = run(False)
+    r_on, g_on = run(True)
+    assert N.lib.dgv2_conv_x3_status() == 0
+    assert set(g_on) == set(g_off) and len(g_on) >= 20
+    assert abs(r_on - r_off) <= 1e-4 * abs(r_off), (r_on, r_off)
+    rel = sorted(((float((g_on[k] - g_off[k]).norm() / (g_off[k].norm() + 1e-30)), k) for k in g_off), reverse=True)
+    print(f"low={low}: r1 {r_on:.6e} vs {r_off:.6e};", ", ".join(f"{k} {v:.1e}" for v, k in rel))
+    if low:
+        assert rel[0][0] < 2e-2, rel[:4]
+    else:
+        # both convs carry fp32 accumulation noise of ~3e-6 of sum |g||w| over 4 608 terms of random sign, i.e. ~2e-4 of the
+        # RESULT, in different realisations: every weight gradient behind them differs by about that (measured 1.3-1.9e-4,
+        # uniformly over the layers); the bias gradients of R1 are small sums through the minibatch-stddev path only (a
+        # piecewise-linear network has no other second-order dependence on its biases) and amplify it ten-fold
+        assert all(v < 5e-4 for v, k in rel if k.endswith("weight")), [r for r in rel if r[1].endswith("weight")][:4]
+        assert rel[0][0] < 5e-3, rel[:4]
