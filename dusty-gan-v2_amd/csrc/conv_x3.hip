@@ -54,7 +54,7 @@ struct CX3 {
 constexpr int X_ICOLS = 34, X_NPIX = 6 * X_ICOLS, X_PIN = 208, X_PW = 9 * 64, X_NI = 4, X_NW = 5;
 constexpr int X_TILE = 3 * 4 * X_PIN;   // 16-byte units of one pixel tile: three split planes x four K planes
 constexpr int X_WBUF = 4 * X_PW;
-constexpr size_t X_LDS = sizeof(uint4) * (2 * X_TILE + 2 * X_WBUF);
+constexpr size_t X_LDS = sizeof(uint4) * (2 * X_TILE + 2 * X_WBUF + 512);   // + one dummy row per thread (w_store)
 static_assert(X_LDS <= 160 * 1024 - 1024, "LDS image");
 
 // eight fp32 values -> their three bf16 planes (round to nearest even each time; the residuals are exact in fp32)
@@ -93,32 +93,47 @@ __device__ __forceinline__ bool exact1x8(const float4& lo, const float4& hi, uin
   return bad;
 }
 
-// One stage: the nine taps of one weight plane (LDS buffer a_base, this lane's K plane and row) against the NX first
-// split planes of the wave's pixel row (xb: split 0 of this lane's K plane; split q is q * 4 * X_PIN further), smallest
-// plane first.  HZ: conv8.hip's data-gradient form -- `dead` = taps that read only zero rows for this wave's output row.
-// `side(t)` runs once behind the MFMA groups of tap t: the staging work of the coming stages, issued under this stage's MFMAs.
-// A group of four in-place bf16 MFMAs (one B fragment against four A fragments) as ONE asm statement with eight wait states
-// behind the last (five cover its operand reads, eight its result: at high register pressure the allocator splits an
-// accumulator's live range around the dead-tap branches and copies it with v_mov_b64 right behind the group -- with five
-// wait states the copy read the upper half of the last fragment before the MFMA had written it: wrong values in one
-// output row of the data gradient, found by tests/test_gpu_ops.py and then by the extended audit): the compiler can place nothing between them, and nothing it generates behind the group (register
-// shuffles at high pressure, branch conditions materialised through VGPRs) can write an operand register an MFMA of the
-// group is still reading -- the hazard recogniser does not look inside asm (scripts/audit_asm_mfma.py).
-// Inside the group the next MFMA's issue covers the previous one's operand reads.
+// A group of four in-place bf16 MFMAs (one B fragment against four A fragments) as ONE asm statement: the compiler can place
+// nothing between them, and inside the group the next MFMA's issue covers the previous one's operand reads.  NOP: eight
+// wait states behind the last MFMA, so that nothing the compiler generates behind the group (branch conditions
+// materialised through VGPRs, register shuffles at high pressure, the staging work) can write an operand register the
+// MFMA is still reading (five wait states) or touch its result before it is written (eight) -- the hazard recogniser does
+// not look inside asm (scripts/audit_asm_mfma.py).  At 256 registers the allocator split an
+// accumulator's live range around the dead-tap branches and copied it with v_mov_b64 right behind a group that carried five
+// wait states only: the copy took the upper half of the last fragment before the MFMA had written it (wrong values in one
+// output row of the data gradient; found by tests/test_gpu_ops.py, then by the extended audit).
+// NOP = false exists for experiments only (8 cycles per group = 5 % of the forward; unsafe, see x3_stage).
+template <bool NOP>
 __device__ __forceinline__ void mfma4_bf16(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, const uint4& a0, const uint4& a1,
                                            const uint4& a2, const uint4& a3, const uint4& b) {
   union U { uint4 u; bf16x8 v; };
   U ua0, ua1, ua2, ua3, ub;
   ua0.u = a0; ua1.u = a1; ua2.u = a2; ua3.u = a3; ub.u = b;
-  asm volatile(
-      "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"
-      "v_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t"
-      "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\t"
-      "v_mfma_f32_16x16x32_bf16 %3, %7, %8, %3\n\t"
-      "s_nop 7"
-      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
-      : "v"(ua0.v), "v"(ua1.v), "v"(ua2.v), "v"(ua3.v), "v"(ub.v));
+  if constexpr (NOP) {
+    asm volatile(
+        "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\t"
+        "v_mfma_f32_16x16x32_bf16 %3, %7, %8, %3\n\t"
+        "s_nop 7"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(ua0.v), "v"(ua1.v), "v"(ua2.v), "v"(ua3.v), "v"(ub.v));
+  } else {
+    asm volatile(
+        "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\t"
+        "v_mfma_f32_16x16x32_bf16 %3, %7, %8, %3"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(ua0.v), "v"(ua1.v), "v"(ua2.v), "v"(ua3.v), "v"(ub.v));
+  }
 }
+
+// One stage: the nine taps of one weight plane (LDS buffer a_base, this lane's K plane and row) against the NX first
+// split planes of the wave's pixel row (xb: split 0 of this lane's K plane; split q is q * 4 * X_PIN further), smallest
+// plane first.  HZ: conv8.hip's data-gradient form -- `dead` = taps that read only zero rows for this wave's output row.
+// `side(t)` runs once behind the MFMA groups of tap t: the staging work of the coming stages, issued under this stage's MFMAs.
+#define X3_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <int NX, int HZ, typename Side>
 __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __restrict__ a_base, const uint4* __restrict__ xb,
@@ -143,9 +158,14 @@ __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __rest
 #pragma unroll
       for (int qi = 0; qi < NX; ++qi) {
         const int q = NX - 1 - qi;
-        __builtin_amdgcn_sched_barrier(0);
+        X3_SB();
         if (!(HZ && ((dd >> t) & 1u)))
-          mfma4_bf16(acc[0][nf], acc[1][nf], acc[2][nf], acc[3][nf], a[t & 1][0], a[t & 1][1], a[t & 1][2], a[t & 1][3], bb[nf][q]);
+        {
+          // Wait states behind EVERY group.  Dropping them where only fragment reads and the next group follow measured 5 % on
+          // the forward -- and the audit then found a v_mov_b64 of the allocator into a live B operand in the x_exact
+          // instance: what the compiler puts between two groups is not under this file's control.
+          mfma4_bf16<true>(acc[0][nf], acc[1][nf], acc[2][nf], acc[3][nf], a[t & 1][0], a[t & 1][1], a[t & 1][2], a[t & 1][3], bb[nf][q]);
+        }
         if constexpr (HZ != 0) {
           // replicate-row border term (conv8.hip): the tap mirrored in dy is dead for this row -> the border row once
           // more (the pixel fragment of tap (dy = 0, dx)) through the weights in registers right now
@@ -153,11 +173,11 @@ __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __rest
             const int tm = t < 3 ? t + 6 : t - 6;
             if ((dd >> tm) & 1u) {
               const uint4 bx = xb[q * 4 * X_PIN + bpix[nf] + X_ICOLS + t % 3];
-              mfma4_bf16(acc[0][nf], acc[1][nf], acc[2][nf], acc[3][nf], a[t & 1][0], a[t & 1][1], a[t & 1][2], a[t & 1][3], bx);
+              mfma4_bf16<true>(acc[0][nf], acc[1][nf], acc[2][nf], acc[3][nf], a[t & 1][0], a[t & 1][1], a[t & 1][2], a[t & 1][3], bx);
             }
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        X3_SB();
         if (t + 1 < 9) {
           const int ky = (t + 1) / 3, kx = (t + 1) % 3;
           bb[nf][q] = xb[q * 4 * X_PIN + bpix[nf] + ky * X_ICOLS + kx];
@@ -168,10 +188,10 @@ __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __rest
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    X3_SB();
     side(t);
   }
-  __builtin_amdgcn_sched_barrier(0);
+  X3_SB();
 }
 
 // XE: the launch carries an x_exact promise (the exact-chunk code is compiled in); the data gradient and promise-free
@@ -273,20 +293,37 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
   }
 
   const int nst = p.nchunks * 3;
-  // slot j of the weight plane: store it into the OTHER buffer (stage st + 1's plane, in registers since the stage before)
-  // and reload the register with stage st + 2's
-  auto w_slot = [&](int st, int j) {
+  // The weight plane of stage st + 1 (in registers since the stage before) goes into the OTHER buffer in the FIRST taps of
+  // stage st, the registers are reloaded with stage st + 2's plane in its LAST taps.  Never a load in front of a store of
+  // the same stage: the compiler waits with vmcnt(0) in front of every such store (it cannot count across the predicated
+  // slots), i.e. for every load issued so far -- with store j, load j, store j + 1 interleaved each store waited out the
+  // global load issued one tap before it, a round trip to L2 per slot (that, not the instruction count, was the 118 us of
+  // "staging" of profiles/round4_mb_x3_ablate.txt).
+  // ... and never a BRANCH around either: behind a conditional load the compiler's wait-count merge no longer knows how many
+  // loads are younger than the one a store needs and falls back to vmcnt(0).  So: the slot of the plane that does not exist
+  // (last slot, upper half of the block; the stages behind the last) is stored into a dummy LDS row and loaded from a valid
+  // address; every thread issues every slot.
+  uint4* const w_dummy = smem + 2 * X_TILE + 2 * X_WBUF + tid;
+  auto w_store = [&](int st, int j) {
     if (X3_ABL & 8) return;
     const bool in = j < X_NW - 1 || tid + 512 * j < X_PW * 4;
-    if (st + 1 < nst && in) {
-      uint4* dst = wb + ((st + 1) & 1) * X_WBUF + w_plane * X_PW + w_row0;
-      *reinterpret_cast<u32x4*>(dst + 128 * j) = rwt[j];
-    }
-    if (st + 2 < nst && in) {
-      const int c = (st + 2) / 3, pl = (st + 2) - c * 3;
-      const u32x4* img = reinterpret_cast<const u32x4*>(wimg) + pl * plane_units + ((size_t)slab * p.nchunks + c) * (X_PW * 4) + tid;
-      rwt[j] = img[512 * j];
-    }
+    uint4* dst = wb + ((st + 1) & 1) * X_WBUF + w_plane * X_PW + w_row0 + 128 * j;
+    dst = in ? dst : w_dummy;
+    *reinterpret_cast<u32x4*>(dst) = rwt[j];
+  };
+  auto w_load = [&](int st, int j) {
+    if (X3_ABL & 8) return;
+    const bool in = j < X_NW - 1 || tid + 512 * j < X_PW * 4;
+    const int s2 = min(st + 2, nst - 1);
+    const int c = s2 / 3, pl = s2 - c * 3;
+    const u32x4* img = reinterpret_cast<const u32x4*>(wimg) + pl * plane_units + ((size_t)slab * p.nchunks + c) * (X_PW * 4) + tid;
+    rwt[j] = img[in ? 512 * j : 0];
+  };
+  // taps 0..4: stores; taps 5..8: the five loads (two in tap 5)
+  auto w_side = [&](int st, int t) {
+    if (t < X_NW) w_store(st, t);
+    if (t == 5) { w_load(st, 0); w_load(st, 1); }
+    if (t > 5) w_load(st, t - 4);
   };
   uint4 xh[X_NI];                            // plane h of the coming chunk's pixels between their split and the boundary
   // split slot j of the pixels in registers; planes m and l go to LDS at once, h waits in xh
@@ -315,7 +352,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
   if (nst > 1) issue_w(1);
 #pragma unroll
   for (int j = 0; j < X_NI; ++j) split_store(j, true, XE && 32 <= p.xexact);
-  if (p.nchunks > 1) issue_in(32);
   __syncthreads();
   const uint4* const xlane = xs + lc * X_PIN;
   for (int c = 0; c < p.nchunks; ++c) {
@@ -323,41 +359,38 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
     const int st = c * 3;
     // chunks of bf16-exact input channels (CX3::xexact): x = x_h, so each stage is its weight plane against x_h alone --
     // three products per multiply instead of six, the same sum (the other three are products with zero)
-    const bool ex = XE && (c + 1) * 32 <= p.xexact, ex_next = XE && (c + 2) * 32 <= p.xexact;
+    const bool ex = XE && (c + 1) * 32 <= p.xexact, ex_next = XE && (min(c + 1, p.nchunks - 1) + 1) * 32 <= p.xexact;
     const uint4* const a0 = wb + (st & 1) * X_WBUF + lc * X_PW + lr;
     const uint4* const a1 = wb + ((st + 1) & 1) * X_WBUF + lc * X_PW + lr;
-    // stage 0: w_h x (x_l, x_m, x_h); under it the weight slots of the coming stages
-    auto side0 = [&](int t) { if (t < X_NW) w_slot(st, t); };
-    if (X3_ABL & 2) { for (int t = 0; t < X_NW; ++t) w_slot(st, t); }
+    // stage 0: w_h x (x_l, x_m, x_h); under it the weight stores / loads, and (behind the stores) the loads of the coming
+    // chunk's pixels, which stage 2 splits
+    auto side0 = [&](int t) {
+      w_side(st, t);
+      if (t == 5 && !(X3_ABL & 4)) issue_in(min(c + 1, p.nchunks - 1) * 32);   // (last chunk: its own pixels once more, unused)
+    };
+    if (X3_ABL & 2) { for (int t = 0; t < 9; ++t) side0(t); }
     else if (ex) x3_stage<1, HZ>(acc, a0, xlane, bpix, dead, side0);
     else x3_stage<3, HZ>(acc, a0, xlane, bpix, dead, side0);
     __syncthreads();
     // stage 1: w_m x (x_m, x_h)
-    auto side1 = [&](int t) { if (t < X_NW) w_slot(st + 1, t); };
-    if (X3_ABL & 2) { for (int t = 0; t < X_NW; ++t) w_slot(st + 1, t); }
+    auto side1 = [&](int t) { w_side(st + 1, t); };
+    if (X3_ABL & 2) { for (int t = 0; t < 9; ++t) side1(t); }
     else if (ex) x3_stage<1, HZ>(acc, a1, xlane, bpix, dead, side1);
     else x3_stage<2, HZ>(acc, a1, xlane, bpix, dead, side1);
     __syncthreads();
-    // stage 2: w_l x x_h -- planes m and l of the pixel tiles are no longer read: the coming chunk's pixels (loaded two
-    // stages ago) are split under it, m and l stored at once
-    if (!(X3_ABL & 2))
-      x3_stage<1, HZ>(acc, a0, xlane, bpix, dead, [&](int t) {
-        if (t < X_NW) w_slot(st + 2, t);
-        if (more && t >= 9 - 2 * X_NI && ((t - (9 - 2 * X_NI)) & 1) == 0) {
-          split_store((t - (9 - 2 * X_NI)) >> 1, false, ex_next);
-        }
-      });
-    else {
-      for (int t = 0; t < X_NW; ++t) w_slot(st + 2, t);
-      if (more)
-        for (int j = 0; j < X_NI; ++j) split_store(j, false, ex_next);
-    }
+    // stage 2: w_l x x_h -- planes m and l of the pixel tiles are no longer read: the coming chunk's pixels (loaded in
+    // stage 0) are split under its first taps, m and l stored at once
+    auto side2 = [&](int t) {
+      if (t < X_NI && !(X3_ABL & 4)) split_store(t, false, ex_next);
+      w_side(st + 2, t);
+    };
+    if (X3_ABL & 2) { for (int t = 0; t < 9; ++t) side2(t); }
+    else x3_stage<1, HZ>(acc, a0, xlane, bpix, dead, side2);
     __syncthreads();                                         // chunk c read
     if (more) {
 #pragma unroll
       for (int j = 0; j < X_NI; ++j)
         if (lrow[j] >= 0) xs[in_plane * X_PIN + lrow[j]] = xh[j];
-      if (c + 2 < p.nchunks) issue_in((c + 2) * 32);
       __syncthreads();                                       // plane h of chunk c + 1 visible
     }
   }
