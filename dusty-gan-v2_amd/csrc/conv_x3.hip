@@ -44,7 +44,7 @@ struct CX3 {
   int act;
   float alpha, scale;
 #ifdef DGV2_ABLATE   // benchmarking builds only (make ABLATE=1): wrong results by design, never in the shipped library
-  int ablate;        // DGV2_X3_ABLATE: 2 no MFMA loop, 4 no input loads / split, 8 no weight loads / writes, 16 no barriers' extra (x) sync
+  int ablate;        // DGV2_X3_ABLATE: 2 no MFMA loop, 4 no input loads / split, 8 no weight loads / writes, 64 no barriers inside the chunk loop
 #define X3_ABL (p.ablate)
 #else
 #define X3_ABL 0
@@ -134,11 +134,18 @@ __device__ __forceinline__ void mfma4_bf16(f32x4& c0, f32x4& c1, f32x4& c2, f32x
 // plane first.  HZ: conv8.hip's data-gradient form -- `dead` = taps that read only zero rows for this wave's output row.
 // `side(t)` runs once behind the MFMA groups of tap t: the staging work of the coming stages, issued under this stage's MFMAs.
 #define X3_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef DGV2_ABLATE
+__device__ int x3_abl_noreads;   // ablation builds: 1 = the in-loop fragment re-reads are skipped (timing of the pure MFMA issue)
+#define X3_NOREADS (x3_abl_noreads != 0)
+#else
+#define X3_NOREADS false
+#endif
 
 template <int NX, int HZ, typename Side>
 __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __restrict__ a_base, const uint4* __restrict__ xb,
                                          const int (&bpix)[2], unsigned dead, Side&& side) {
   constexpr int SLOTS = 2 * NX;
+  const bool noreads = X3_NOREADS;
   uint4 a[2][4], bb[2][NX];
   unsigned dd = 0u;
   if constexpr (HZ != 0) {
@@ -178,7 +185,7 @@ __device__ __forceinline__ void x3_stage(f32x4 (&acc)[4][2], const uint4* __rest
           }
         }
         X3_SB();
-        if (t + 1 < 9) {
+        if (t + 1 < 9 && !noreads) {
           const int ky = (t + 1) / 3, kx = (t + 1) % 3;
           bb[nf][q] = xb[q * 4 * X_PIN + bpix[nf] + ky * X_ICOLS + kx];
           const int slot = nf * NX + qi;
@@ -371,13 +378,13 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
     if (X3_ABL & 2) { for (int t = 0; t < 9; ++t) side0(t); }
     else if (ex) x3_stage<1, HZ>(acc, a0, xlane, bpix, dead, side0);
     else x3_stage<3, HZ>(acc, a0, xlane, bpix, dead, side0);
-    __syncthreads();
+    if (!(X3_ABL & 64)) __syncthreads();
     // stage 1: w_m x (x_m, x_h)
     auto side1 = [&](int t) { w_side(st + 1, t); };
     if (X3_ABL & 2) { for (int t = 0; t < 9; ++t) side1(t); }
     else if (ex) x3_stage<1, HZ>(acc, a1, xlane, bpix, dead, side1);
     else x3_stage<2, HZ>(acc, a1, xlane, bpix, dead, side1);
-    __syncthreads();
+    if (!(X3_ABL & 64)) __syncthreads();
     // stage 2: w_l x x_h -- planes m and l of the pixel tiles are no longer read: the coming chunk's pixels (loaded in
     // stage 0) are split under its first taps, m and l stored at once
     auto side2 = [&](int t) {
@@ -386,12 +393,12 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
     };
     if (X3_ABL & 2) { for (int t = 0; t < 9; ++t) side2(t); }
     else x3_stage<1, HZ>(acc, a0, xlane, bpix, dead, side2);
-    __syncthreads();                                         // chunk c read
+    if (!(X3_ABL & 64)) __syncthreads();                                         // chunk c read
     if (more) {
 #pragma unroll
       for (int j = 0; j < X_NI; ++j)
         if (lrow[j] >= 0) xs[in_plane * X_PIN + lrow[j]] = xh[j];
-      __syncthreads();                                       // plane h of chunk c + 1 visible
+      if (!(X3_ABL & 64)) __syncthreads();                                       // plane h of chunk c + 1 visible
     }
   }
 
@@ -554,6 +561,10 @@ int launch_x3(float* y, const float* x, const bf16_t* wimg, CX3 p, hipStream_t s
   p.per_xcd = (p.total + 7) / 8;
 #ifdef DGV2_ABLATE
   p.ablate = getenv("DGV2_X3_ABLATE") ? atoi(getenv("DGV2_X3_ABLATE")) : 0;
+  {
+    const int nr = (p.ablate & 128) ? 1 : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(x3_abl_noreads), &nr, sizeof(int));
+  }
 #endif
   kern<<<p.per_xcd * 8, 512, X_LDS, st>>>(y, x, wimg, p);
   return 0;

@@ -1,6 +1,6 @@
 """Ablation timing of conv_x3_kernel (forward, B = 128, 4x32, 513 -> 512) on the ablation build (make ABLATE=1,
 DGV2_LIB_PATH=.../libdgv2_abl.so): DGV2_X3_ABLATE bits 2 no MFMA loop, 4 no input loads / split / writes, 8 no weight
-loads / writes.  Wrong results by design."""
+loads / writes, 64 no barriers inside the chunk loop.  Wrong results by design."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -25,7 +25,7 @@ print("%%7.1f us" %% (s.elapsed_time(e) * 1e3 / 20))
 ''' % ROOT
 lib = os.path.join(ROOT, "dusty-gan-v2_amd", "lib", "libdgv2_abl.so")
 for abl, what in ((0, "full"), (2, "no MFMA loop"), (4, "no input staging"), (8, "no weight staging"), (12, "no staging at all"),
-                  (14, "barriers + epilogue only")):
+                  (14, "barriers + epilogue only"), (64, "no barriers in the chunk loop"), (76, "no staging, no barriers"), (204, "... and no fragment re-reads")):
     env = dict(os.environ, DGV2_LIB_PATH=lib, DGV2_X3_ABLATE=str(abl))
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     print(f"ablate {abl:2d} ({what:24s}): {out.stdout.strip()} {out.stderr.strip()[-200:] if out.returncode else ''}")
