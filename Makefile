@@ -14,9 +14,19 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-functi
 
 all: $(LIB)
 
-$(BUILD)/%.o: $(PKG)/csrc/%.hip $(wildcard $(PKG)/csrc/*.h) include/dgv2.h
+# Every object is assembled from the ISA the audit below has read (-save-temps=obj keeps that .s next to the object):
+# hipcc's hazard recogniser does not look inside `asm`, so a compiler-generated VALU write into a register an asm-issued
+# MFMA is still reading -- or a read of its result in flight -- goes unpadded.
+# scripts/audit_asm_mfma.py scans the ISA for exactly that and FAILS THE BUILD on a finding, whatever the flags
+# (EXTRA=, ABLATE=1, another ARCH, a compiler upgrade); sources without asm MFMAs pass trivially.
+PYTHON ?= python3
+$(BUILD)/%.o: $(PKG)/csrc/%.hip $(wildcard $(PKG)/csrc/*.h) include/dgv2.h scripts/audit_asm_mfma.py
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -save-temps=obj -c $< -o $@
+	@$(PYTHON) scripts/audit_asm_mfma.py $(BUILD)/$*-hip-amdgcn-amd-amdhsa-$(ARCH).s > $(BUILD)/$*.audit \
+	  || { cat $(BUILD)/$*.audit; echo "asm-MFMA hazard audit FAILED for $<"; rm -f $@; exit 1; }
+	@rm -f $(BUILD)/$*-hip-*.bc $(BUILD)/$*-hip-*.hipi $(BUILD)/$*-hip-*.out $(BUILD)/$*-hip-*.out.resolution.txt \
+	  $(BUILD)/$*-host-*.bc $(BUILD)/$*-host-*.hipi $(BUILD)/$*-host-*.s $(BUILD)/$*.hip-hip-*.hipfb $(BUILD)/$*-hip-*.o
 
 $(LIB): $(OBJ)
 	@mkdir -p $(dir $(LIB))

@@ -28,6 +28,7 @@ struct WSGeom {
 #endif
   int x_shared; // x is ONE image [H, W, C] shared by all samples (the batch-shared positional encoding)
   int x_exact;  // conv_wgrad_x3_kernel: channels [0, x_exact) of x are bf16-representable (dgv2.h: dgv2_conv3x3_x3_fwd)
+  int* status;  // ... and the caller's device status word a breach of that promise is reported to (dgv2.h: status words)
 };
 
 template <typename T, int S, int MFN, int NFN, bool K3>
@@ -446,7 +447,6 @@ __device__ __forceinline__ void wx_split8(const float4& lo, const float4& hi, ui
   l = pl.u;
 }
 
-__device__ int wx3_inexact_flag;   // a value outside the x_exact promise was staged (dgv2_conv_x3_status)
 
 // XE: the c-tile's input channels are bf16-exact (WSGeom::x_exact): x = x_h, the planes m and l of x are neither staged nor
 // multiplied -- three products per multiply (gy_l x_h, gy_m x_h, gy_h x_h), the same sum
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_x3_kernel(float* __restrict
           lds_x[XB / 16 + xw_[j]] = m;
           lds_x[2 * (XB / 16) + xw_[j]] = l;
         } else if ((m.x | m.y | m.z | m.w) != 0u) {
-          atomicOr(&wx3_inexact_flag, 1);                  // (m = bf16(x - h) is zero exactly when x is bf16-representable)
+          atomicOr(g.status, DGV2_STATUS_X_INEXACT);             // (m = bf16(x - h) is zero exactly when x is bf16-representable)
         }
       }
     }
@@ -960,22 +960,13 @@ extern "C" int dgv2_conv_wgrad_stream_pl(float* gw, float* scratch, int64_t scra
 // exact fp32 (at most 16), [clive, C) = 0 (padding channels of x).  scratch: dgv2_conv3x3_x3_wgrad_scratch.
 // DGV2_ENOTSUP where the kernel does not cover the geometry (O % 128, C < 64, C % 8, clive - 64 * floor(C / 64) > 16,
 // W % 32): callers then run dgv2_conv_wgrad_stream_pl.
-int wx3_status_read_clear() {   // for dgv2_conv_x3_status (conv_x3.hip)
-  int h = 0;
-  if (hipMemcpyFromSymbol(&h, HIP_SYMBOL(wx3_inexact_flag), sizeof(int)) != hipSuccess) return -1;
-  if (h) {
-    const int z = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(wx3_inexact_flag), &z, sizeof(int)) != hipSuccess) return -1;
-  }
-  return h;
-}
-
 extern "C" int dgv2_conv3x3_x3_wgrad(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x, int B,
                                      int H, int W, int C, int clive, int x_exact, int O, float scale, int param_layout,
-                                     void* stream) {
+                                     int* status, void* stream) {
   if (!gw || !scratch || !gy || !x || !aligned16(gy) || !aligned16(x) || !aligned16(scratch) || !aligned16(gw))
     return DGV2_EINVAL;
   if (B < 1 || H < 1 || W < 1 || C < 1 || O < 1 || clive < 1 || clive > C || x_exact < 0 || x_exact > C) return DGV2_EINVAL;
+  if (x_exact > 0 && !status) return DGV2_EINVAL;
   static const bool off = getenv("DGV2_NO_CONV_X3") != nullptr || getenv("DGV2_NO_WGRAD_X3") != nullptr;
   const int ctiles = C / 64, ntail = clive - ctiles * 64;
   if (off || O % 64 || ctiles < 1 || C % 8 || ntail > 16 || W % 32) return DGV2_ENOTSUP;
@@ -989,6 +980,7 @@ extern "C" int dgv2_conv3x3_x3_wgrad(float* gw, float* scratch, int64_t scratch_
   g.ctiles = ctiles;
   g.x_shared = 0;
   g.x_exact = x_exact;
+  g.status = status;
 #ifdef DGV2_ABLATE
   g.ablate = 0;
 #endif

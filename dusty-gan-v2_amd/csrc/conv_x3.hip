@@ -39,6 +39,7 @@ struct CX3 {
   int xexact;             // the caller's promise: channels [0, xexact) of x hold bf16-representable values (activations of a
                           // bf16 trunk widened to fp32) -- their m and l planes are zero: not staged, their products not issued
   int tiles_h, tiles_w, ntiles, npairs, nslab, per_xcd, total;
+  int* status;            // the caller's device status word (non-NULL whenever xexact > 0)
   const float* bias;
   const float* resid;
   int act;
@@ -76,8 +77,8 @@ __device__ __forceinline__ void split3x8(const float4& lo, const float4& hi, uin
   l = pl.u;
 }
 
-// the promise CX3::xexact is checked where it is used: a value with a residual raises this flag (dgv2_conv_x3_status)
-__device__ int x3_inexact_flag;
+// the promise CX3::xexact is checked where it is used: a value with a residual raises bit 0 of the caller's status word
+// (CX3::status, dgv2.h "status words"); the library keeps no flag of its own
 
 // eight fp32 values that are promised to be bf16-representable -> plane h; true if one of them is not
 __device__ __forceinline__ bool exact1x8(const float4& lo, const float4& hi, uint4& h) {
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(float* __restrict__ y, 
   auto split_store = [&](int j, bool all, bool ex) {
     if (ex) {   // promised bf16-exact channels: plane h is the value, planes m and l are zero and never read for this chunk
       const bool bad = exact1x8(rin[j][0], rin[j][1], xh[j]);
-      if (bad && rin_ok && lrow[j] >= 0) atomicOr(&x3_inexact_flag, 1);
+      if (bad && rin_ok && lrow[j] >= 0) atomicOr(p.status, DGV2_STATUS_X_INEXACT);
       if (!rin_ok) xh[j] = make_uint4(0u, 0u, 0u, 0u);
       if (all && lrow[j] >= 0) xs[in_plane * X_PIN + lrow[j]] = xh[j];
       return;
@@ -578,11 +579,13 @@ int launch_x3(float* y, const float* x, const bf16_t* wimg, CX3 p, hipStream_t s
 // x_exact: the caller's promise that channels [0, x_exact) of x hold bf16-representable values (the activations of a bf16
 // trunk widened to fp32: the discriminator's features in front of its fp32 epilogue) -- their m and l planes are zero, so
 // their three products are not issued: the same sum at half the MFMAs.  A value that breaks the promise raises
-// dgv2_conv_x3_status().  0: no promise.
+// bit DGV2_STATUS_X_INEXACT of *status (the caller's device word; required when x_exact > 0).  0: no promise.
 // DGV2_ENOTSUP where the kernel does not cover the geometry (callers then run dgv2_conv_taps in fp32).
 extern "C" int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B, int H, int W, int Cx, int x_exact, int O,
-                                   const float* bias, const void* resid, int act, float alpha, float scale, void* stream) {
+                                   const float* bias, const void* resid, int act, float alpha, float scale, int* status,
+                                   void* stream) {
   if (!y || !x || !w3 || B < 1 || H < 1 || W < 1 || Cx < 1 || O < 1 || x_exact < 0 || x_exact > Cx) return DGV2_EINVAL;
+  if (x_exact > 0 && !status) return DGV2_EINVAL;   // a promise without a word to report its breach to
   if (act != 0 && act != 3) return DGV2_EINVAL;
   static const bool off = getenv("DGV2_NO_CONV_X3") != nullptr;   // A/B switch for benchmarking
   if (off || W % 32 || Cx % 8 || O % 64 || Cx < 64) return DGV2_ENOTSUP;
@@ -591,6 +594,7 @@ extern "C" int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B
   CX3 p;
   p.B = B; p.H = H; p.W = W; p.Cx = Cx; p.nchunks = (Cx + 31) / 32; p.O = O; p.ldy = O; p.nslab = O / 64;
   p.xexact = x_exact;
+  p.status = status;
   p.bias = bias; p.resid = (const float*)resid; p.act = act; p.alpha = alpha; p.scale = scale;
   const int rc = x_exact >= 32 ? launch_x3<0, true>((float*)y, (const float*)x, (const bf16_t*)w3, p, (hipStream_t)stream)
                                : launch_x3<0, false>((float*)y, (const float*)x, (const bf16_t*)w3, p, (hipStream_t)stream);
@@ -614,6 +618,7 @@ extern "C" int dgv2_conv3x3_x3_dgrad(void* gx, const void* gy, const void* w3t, 
   CX3 p;
   p.B = B; p.H = H; p.W = W; p.Cx = O; p.nchunks = O / 32; p.O = nslab * 64; p.ldy = ldx; p.nslab = nslab;
   p.xexact = 0;
+  p.status = nullptr;
   p.bias = nullptr; p.resid = (const float*)resid; p.act = 0; p.alpha = 0.2f; p.scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
   const int rc = launch_x3<1, false>((float*)gx, (const float*)gy, (const bf16_t*)w3t, p, st);
@@ -640,18 +645,3 @@ extern "C" int dgv2_conv_x3_images(void* w3, void* w3t, const void* w, int O, in
   DGV2_RETURN_LAST();
 }
 
-// 1 if a launch since the last call met a value outside its x_exact promise (the result of that launch is then the conv of
-// the bf16-ROUNDED input), 0 otherwise, < 0 on a runtime error.  Synchronises the device: tests and debugging.
-int wx3_status_read_clear();   // conv_wgrad_stream.hip: the weight gradient's flag
-
-extern "C" int dgv2_conv_x3_status(void) {
-  int h = 0;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(&h, HIP_SYMBOL(x3_inexact_flag), sizeof(int)) != hipSuccess) return -1;
-  if (h) {
-    const int z = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(x3_inexact_flag), &z, sizeof(int)) != hipSuccess) return -1;
-  }
-  const int hw = wx3_status_read_clear();
-  return hw < 0 ? hw : (h | hw);
-}

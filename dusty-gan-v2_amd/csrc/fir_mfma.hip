@@ -60,7 +60,7 @@ struct FMTabs {
   int H, W, Eh, Ew;
   const int* idx_h; const float* coef_h; const int* cnt_h;
   const int* idx_w; const float* coef_w; const int* cnt_w;
-  int* err;               // set to 1 when a table entry falls outside its window (contract violation)
+  int* err;               // the caller's status word: bit DGV2_STATUS_FIR_TABLE when a table entry breaks the contract
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned fm_u32x4;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void fir_bands_kernel(uint4* __restrict__ bands
     if ((float)(bf16_t)v[j] != v[j]) bad = true;   // coefficients (and their sums) must be exact in bf16
   bands[(int64_t)blockIdx.x * 64 + lane] =
       make_uint4(fm_pack2(v[0], v[1]), fm_pack2(v[2], v[3]), fm_pack2(v[4], v[5]), fm_pack2(v[6], v[7]));
-  if (bad) *t.err = 1;
+  if (bad) atomicOr(t.err, DGV2_STATUS_FIR_TABLE);
 }
 
 template <bool ACT>
@@ -338,15 +338,6 @@ __global__ __launch_bounds__(256) void fm_bias_reduce_kernel(float* __restrict__
   if (threadIdx.x == 0) gb[c] = s;
 }
 
-int* fm_err_flag() {
-  static int* flag = nullptr;
-  if (!flag) {
-    if (hipMalloc(&flag, sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemset(flag, 0, sizeof(int)) != hipSuccess) return nullptr;   // the plain (synchronous) runtime call: once, outside any capture
-  }
-  return flag;
-}
-
 bool fm_covers(int B, int C, int H, int W) {
   return B > 0 && C % FM_CB == 0 && H % FM_RS == 0 && H >= FM_RS && W % FM_CT == 0 && W >= FM_CT && B < 65536 &&
          C / FM_CB < 65536;
@@ -360,21 +351,20 @@ int64_t fm_band_bytes(int H, int W) { return 1024 * ((int64_t)H / FM_RS + 1 + W 
 
 // Band operands of dgv2_fir_same_mfma for one SAME-SIZE table set (sparse rows exactly as for dgv2_resample_tab): built
 // once, kept by the caller next to the tables.  bands: device buffer of >= *bytes_needed bytes (a call with bands == NULL
-// only reports *bytes_needed).  Contract on the tables (a violation raises the flag dgv2_fir_same_mfma_status reports):
+// only reports *bytes_needed).  Contract on the tables (a violation raises bit DGV2_STATUS_FIR_TABLE of the caller's device word *status):
 //   |idx_h[ho][a] - ho| <= 4,   (idx_w[wo][e] - wo + 8) mod W < 24,   every coefficient -- and every sum of the
 //   coefficients of one row that name the same input -- exact in bf16.
 // DGV2_ENOTSUP unless H % 8 == 0 and W % 32 == 0.
 extern "C" int dgv2_fir_same_mfma_prep(void* bands, int64_t bands_bytes, int64_t* bytes_needed, const int* idx_h,
                                        const float* coef_h, const int* cnt_h, int Eh, const int* idx_w, const float* coef_w,
-                                       const int* cnt_w, int Ew, int H, int W, void* stream) {
+                                       const int* cnt_w, int Ew, int H, int W, int* status, void* stream) {
   if (H < FM_RS || H % FM_RS || W < FM_CT || W % FM_CT || Eh < 1 || Ew < 1) return DGV2_ENOTSUP;
   const int64_t need = fm_band_bytes(H, W);
   if (bytes_needed) *bytes_needed = need;
   if (!bands) return bytes_needed ? 0 : DGV2_EINVAL;
   if (bands_bytes < need || !aligned16(bands) || !idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w) return DGV2_EINVAL;
-  int* err = fm_err_flag();
-  if (!err) return DGV2_EINVAL;
-  FMTabs t{H, W, Eh, Ew, idx_h, coef_h, cnt_h, idx_w, coef_w, cnt_w, err};
+  if (!status) return DGV2_EINVAL;
+  FMTabs t{H, W, Eh, Ew, idx_h, coef_h, cnt_h, idx_w, coef_w, cnt_w, status};
   fir_bands_kernel<<<(int)(need / 1024), 64, 0, (hipStream_t)stream>>>((uint4*)bands, t);
   DGV2_RETURN_LAST();
 }
@@ -435,17 +425,3 @@ extern "C" int dgv2_fir_same_mfma_actbwd(void* y, float* gb, float* scratch, int
   DGV2_RETURN_LAST();
 }
 
-// 1 when dgv2_fir_same_mfma_prep met a table entry outside its window or an inexact coefficient since the last call (synchronises the
-// device: tests and debugging only), 0 otherwise, < 0 on a runtime error.
-extern "C" int dgv2_fir_same_mfma_status(void) {
-  int* err = fm_err_flag();
-  if (!err) return -1;
-  int h = 0;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpy(&h, err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (h) {
-    int z = 0;
-    if (hipMemcpy(err, &z, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
-  }
-  return h;
-}

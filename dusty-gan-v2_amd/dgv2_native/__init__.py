@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGV2_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 44
+ABI_VERSION = 45
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -69,7 +69,8 @@ SIGNATURES = {
     "dgv2_emd_approxmatch": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_emd_matchcost": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_emd_matchcost_grad": [_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr],
-    "dgv2_nsgan_loss": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr],
+    "dgv2_nsgan_loss": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_f32, _c_ptr, _c_ptr, _c_ptr],
+    "dgv2_rng_fill": [_c_ptr] * 5 + [_c_int, _c_ptr, _c_ptr],
     "dgv2_modconv_up_fwd": [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr] * 6 + [_c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                             _c_ptr],
     "dgv2_modconv_up_t_lag": [_c_ptr] * 4 + [_c_f32] + [_c_ptr] * 4 + [_c_int] * 9 + [_c_ptr, _c_int, _c_ptr, _c_ptr],
@@ -82,11 +83,10 @@ SIGNATURES = {
     "dgv2_up2_lag_sumsq": [_c_ptr] * 5 + [_c_int] * 5 + [_c_ptr, _c_int, _c_ptr, _c_ptr],
     "dgv2_resample_tab_actbwd": [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr] + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3
                                 + [_c_int] * 7 + [_c_f32, _c_f32, _c_int, _c_ptr],
-    "dgv2_fir_same_mfma_prep": [_c_ptr, _c_i64, _c_ptr] + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 3 + [_c_ptr],
+    "dgv2_fir_same_mfma_prep": [_c_ptr, _c_i64, _c_ptr] + [_c_ptr] * 3 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 3 + [_c_ptr, _c_ptr],
     "dgv2_fir_same_mfma": [_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr],
     "dgv2_fir_same_mfma_actbwd": [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_int] * 4
                                  + [_c_f32, _c_f32, _c_ptr],
-    "dgv2_fir_same_mfma_status": [],
     "dgv2_resample_tab_sq": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr, _c_int, _c_ptr, _c_ptr],
     "dgv2_bmm_tn_cat": [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr],
     "dgv2_lerp_list": [_c_ptr] * 3 + [_c_int, _c_f32, _c_ptr],
@@ -125,11 +125,10 @@ SIGNATURES = {
     "dgv2_glin_dweight": [_c_ptr] * 7 + [_c_int] * 3 + [_c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr],
     "dgv2_conv3x3_dgrad8": [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr, _c_int, _c_ptr],
     "dgv2_conv3x3_x3_wgrad_scratch": [_c_ptr] + [_c_int] * 6,
-    "dgv2_conv3x3_x3_wgrad": [_c_ptr, _c_ptr, _c_i64] + [_c_ptr] * 2 + [_c_int] * 7 + [_c_f32, _c_int, _c_ptr],
+    "dgv2_conv3x3_x3_wgrad": [_c_ptr, _c_ptr, _c_i64] + [_c_ptr] * 2 + [_c_int] * 7 + [_c_f32, _c_int, _c_ptr, _c_ptr],
     "dgv2_conv_x3_images": [_c_ptr] * 3 + [_c_int] * 2 + [_c_ptr],
     "dgv2_conv3x3_x3_dgrad": [_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr, _c_ptr],
-    "dgv2_conv3x3_x3_fwd": [_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_ptr],
-    "dgv2_conv_x3_status": [],
+    "dgv2_conv3x3_x3_fwd": [_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_ptr, _c_ptr],
     "dgv2_conv3x3_fwd8": [_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_conv_wgrad_stream_scratch": [_c_ptr] + [_c_int] * 9,
     "dgv2_conv_wgrad_stream": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 10 + [_c_ptr],
@@ -212,3 +211,48 @@ def try_call(name, *args):
     if rc != 0:
         raise RuntimeError(f"{name} failed with code {rc}")
     return True
+
+
+# ---------------------------------------------------------------------------------------
+# status words (include/dgv2.h "Status words"): the library keeps no flag of its own; entries that check a promise of
+# the caller on the values they stage OR a bit into a device int32 the caller owns.  One word per device, owned here.
+# ---------------------------------------------------------------------------------------
+STATUS_X_INEXACT, STATUS_FIR_TABLE = 1, 2
+_STATUS_TEXT = {
+    STATUS_X_INEXACT: "a launch with an x_exact promise (fp32 conv on conv_x3.hip / its weight gradient: 'these input "
+                      "channels hold bf16-representable values') staged a value that is not: that launch computed on the "
+                      "bf16 rounding of its input",
+    STATUS_FIR_TABLE: "dgv2_fir_same_mfma_prep met a table entry outside its contract: the band operands are unusable",
+}
+_status_words = {}
+
+
+def status_word(device=None):
+    """The int32 device word of `device` (current device by default) that status-reporting entries OR their bits into."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    w = _status_words.get(idx)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("dgv2: the status word must exist before a hipGraph capture (call dgv2_native.status_word() "
+                               "once outside the capture; gans.trainer.Trainer does)")
+        w = _status_words[idx] = torch.zeros(1, device=torch.device("cuda", idx), dtype=torch.int32)
+    return w
+
+
+def status_read(clear=True):
+    """OR of the status words of every device that has one (synchronises those devices); clears them."""
+    bits = 0
+    for w in _status_words.values():
+        v = int(w.item())
+        bits |= v
+        if v and clear:
+            w.zero_()
+    return bits
+
+
+def status_check():
+    """Raise if a status bit is set (and clear it).  Called wherever the host synchronises anyway."""
+    bits = status_read()
+    if bits:
+        raise RuntimeError("dgv2: " + "; ".join(t for b, t in _STATUS_TEXT.items() if bits & b))

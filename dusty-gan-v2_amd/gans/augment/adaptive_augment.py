@@ -302,16 +302,18 @@ class AdaptiveAugment(torch.nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, img, draws=None):
         """img [B,1,H,W] -> augmented [B,1,H,W] (fp32).  `draws` optionally injects
-        {"G": [B,3,3], "C": [B,4,4]} (parity tests); otherwise they are sampled on the device."""
+        {"G": [B,3,3], "C": [B,4,4]} (parity tests) or the RAW draws {"u": [B,16] uniform, "n": [B,8] normal} of the
+        fused sampler (the step bodies make every draw of a body in one launch); otherwise they are sampled on the device."""
         B, ch, H, W = img.shape
         if ch != 1:
             raise NotImplementedError("ADA on this path handles 1-channel range images")
         dev = img.device
         with torch.no_grad():
             M1y, _, M1x, _, taps = self._chain_consts(H, W, dev)
-            if draws is None:
+            if draws is None or "u" in draws:
                 # sampling + colour collapse in one kernel, operators in two (dgv2_ada_sample / _build)
-                gaff, a, c = native.ada_sample(B, H, W, self.p.reshape(1), self.policy_vector(), dev)
+                raw = {} if draws is None else dict(u=draws["u"], n=draws["n"])
+                gaff, a, c = native.ada_sample(B, H, W, self.p.reshape(1), self.policy_vector(), dev, **raw)
             else:
                 G = draws["G"].to(dev).float()
                 gaff = torch.stack([G[:, 0, 0], G[:, 0, 2], G[:, 1, 1], G[:, 1, 2]], dim=1).contiguous()

@@ -23,6 +23,12 @@ class GANLoss(nn.Module):
         from .ops import native
         return native.nsgan_loss(y, n_real)
 
+    def fused_nsgan_step(self, y, n_real, weight=1.0, cum=None):
+        """The same objective for a step body that needs no scalar-loss graph: (stats, gy) with gy = weight * d loss / d y
+        shaped like y, to be handed to y.backward(gy) (native.nsgan_step)."""
+        from .ops import native
+        return native.nsgan_step(y, n_real, weight, cum)
+
     def can_fuse(self, y):
         return self.metric == "nsgan" and y.is_cuda and y.dtype == torch.float32
 

@@ -238,7 +238,8 @@ class ResampleSpec:
             if H >= _FIR_MFMA_MIN_H and H % 8 == 0 and W % 32 == 0 and self.mfma_ok(H, W, adjoint, device):
                 (ih, chh, nh, Eh), (iw, cw, nw, Ew) = self.tables(H, W, adjoint, device)
                 need = _ct.c_int64(0)
-                tabs = (N.ptr(ih), N.ptr(chh), N.ptr(nh), Eh, N.ptr(iw), N.ptr(cw), N.ptr(nw), Ew, H, W)
+                tabs = (N.ptr(ih), N.ptr(chh), N.ptr(nh), Eh, N.ptr(iw), N.ptr(cw), N.ptr(nw), Ew, H, W,
+                        N.ptr(N.status_word(device)))
                 if N.try_call("dgv2_fir_same_mfma_prep", None, 0, _ct.addressof(need), *tabs, N.stream()):
                     buf = torch.empty(need.value, device=device, dtype=torch.uint8)
                     N.call("dgv2_fir_same_mfma_prep", N.ptr(buf), buf.numel(), None, *tabs, N.stream())

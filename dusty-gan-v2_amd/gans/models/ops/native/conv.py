@@ -135,7 +135,7 @@ def _conv_fwd_raw(x, w, g, bias=None, act=0, alpha=0.2, scale=1.0, resid=None, w
     if (w8 is not None and _CONV_X3 and x.dtype == torch.float32 and w8.dtype == torch.bfloat16 and g.ring
             and (g.kh, g.kw, g.pad, g.stride) == (3, 3, 1, 1)
             and N.try_call("dgv2_conv3x3_x3_fwd", N.ptr(y), N.ptr(x), N.ptr(w8), B, H, W, C, min(int(xexact), C), O, N.ptr(bias),
-                           N.ptr(resid), act, alpha, scale, N.stream())):
+                           N.ptr(resid), act, alpha, scale, N.ptr(N.status_word(x.device)), N.stream())):
         return y     # fp32 on the bf16 matrix cores (three-plane split, six products per multiply: conv_x3.hip)
     if _direct_ok(g, C % _kstep(x) == 0):
         taps = [(ky - g.pad, kx - g.pad, ky * g.kw + kx) for ky in range(g.kh) for kx in range(g.kw)]
@@ -314,7 +314,7 @@ def _conv_wgrad_raw(gy, x, g, gscale=None, x3=None, xexact=0):
         gw3 = torch.empty((O, C, 3, 3) if gscale is not None else (O, 3, 3, C), device=x.device, dtype=torch.float32)
         if N.try_call("dgv2_conv3x3_x3_wgrad", N.ptr(gw3), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(x), B, H, W, C,
                       int(x3), min(int(xexact), C), O, 1.0 if gscale is None else float(gscale), int(gscale is not None),
-                      N.stream()):
+                      N.ptr(N.status_word(x.device)), N.stream()):
             return gw3 if gscale is None else gw3.permute(0, 2, 3, 1)
     stream_ok = (_WGRAD_STREAM and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2)
                  and C % (16 // x.element_size()) == 0 and O % (16 // x.element_size()) == 0)

@@ -57,7 +57,7 @@ class _NsganLoss(Function):
         stats = torch.empty(4, device=y.device, dtype=torch.float32)
         gy = torch.empty(n, device=y.device, dtype=torch.float32)
         N.check(yf)
-        N.call("dgv2_nsgan_loss", N.ptr(stats), N.ptr(gy), N.ptr(yf), int(n_real), n - int(n_real), N.stream())
+        N.call("dgv2_nsgan_loss", N.ptr(stats), N.ptr(gy), N.ptr(yf), int(n_real), n - int(n_real), 1.0, None, None, N.stream())
         ctx.save_for_backward(gy)
         ctx.shape, ctx.dtype = y.shape, y.dtype
         ctx.mark_non_differentiable(stats)
@@ -72,6 +72,74 @@ class _NsganLoss(Function):
 def nsgan_loss(y, n_real):
     """(loss, stats[4]) for logits y [n,1] with the first n_real rows judged as real (see _NsganLoss)."""
     return _NsganLoss.apply(y, n_real)
+
+
+def nsgan_step(y, n_real, weight=1.0, cum=None):
+    """The objective of a step body WITHOUT a scalar-loss graph: (stats[4], gy) with gy = weight * d loss / d y shaped like
+    y -- the cotangent the body hands to y.backward(gy).  One launch; `(weight * loss).backward()` costs a clone, a scalar
+    multiply, the ones_like seed, the multiply's backward and the broadcast product with the saved gradient on top.
+    cum = (sign_cum, n_pred_cum): AdaptiveAugment's fp32 [1] buffers, updated in the same launch (its `cumulate`)."""
+    yf = y.detach().float().contiguous().reshape(-1)
+    n = yf.numel()
+    stats = torch.empty(4, device=y.device, dtype=torch.float32)
+    gy = torch.empty(n, device=y.device, dtype=torch.float32)
+    N.check(yf)
+    sc, nc = (None, None) if cum is None else cum
+    if cum is not None and not all(t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in cum):
+        raise ValueError("nsgan_step: cum = (sign_cum, n_pred_cum), fp32 [1] device tensors")
+    N.call("dgv2_nsgan_loss", N.ptr(stats), N.ptr(gy), N.ptr(yf), int(n_real), n - int(n_real), float(weight), N.ptr(sc),
+           N.ptr(nc), N.stream())
+    return stats, gy.reshape(y.shape).to(y.dtype)
+
+
+# ---------------------------------------------------------------------------------------
+# every random number of a step body from one launch (dgv2_rng_fill, csrc/rng.hip)
+# ---------------------------------------------------------------------------------------
+_RNG_STATE = {}
+RNG_UNIFORM, RNG_NORMAL, RNG_CLAMPED = 0, 1, 2
+
+
+def rng_state(device=None, seed=None):
+    """The Philox stream of `device` (int64[4] device tensor: seed, offset, ticket, unused), created on first use from
+    torch's seed of that moment (torch.initial_seed(): init_random_seed / manual_seed decide it, per rank).  `seed`
+    re-seeds the stream and rewinds it.  Must exist before a hipGraph capture that draws from it."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    st = _RNG_STATE.get(idx)
+    if st is None or seed is not None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("dgv2: the RNG stream must exist before a hipGraph capture (native.rng_state())")
+        sd = torch.initial_seed() if seed is None else int(seed)
+        vals = torch.tensor([sd & 0x7FFFFFFFFFFFFFFF, 0, 0, 0], dtype=torch.int64)
+        if st is None:
+            st = _RNG_STATE[idx] = vals.to(torch.device("cuda", idx))
+        else:
+            st.copy_(vals)
+    return st
+
+
+def rng_fill(specs, device):
+    """specs: list of (shape, kind, a, b) -> list of fp32 tensors (views of one allocation), ONE launch.
+    kind RNG_UNIFORM: uniform in [a, b); RNG_NORMAL: mean a, std b; RNG_CLAMPED: u in [0, 1) clamped to [a, b]."""
+    if not 1 <= len(specs) <= 16:
+        raise ValueError("rng_fill takes 1..16 segments")
+    counts = [int(math.prod(sh)) for sh, _, _, _ in specs]
+    offs, tot = [], 0
+    for c in counts:
+        offs.append(tot)
+        tot += (c + 3) // 4 * 4            # 16-byte aligned segments: whole float4 stores
+    st = rng_state(device)
+    buf = torch.empty(tot, device=device, dtype=torch.float32)
+    outs = [buf[o:o + c].view(sh) for o, c, (sh, _, _, _) in zip(offs, counts, specs)]
+    import ctypes as _c
+    n = len(specs)
+    ptrs = (_c.c_void_p * n)(*[t.data_ptr() for t in outs])
+    cnt = (_c.c_int64 * n)(*counts)
+    kinds = (_c.c_int * n)(*[int(k) for _, k, _, _ in specs])
+    a = (_c.c_float * n)(*[float(v) for _, _, v, _ in specs])
+    b = (_c.c_float * n)(*[float(v) for _, _, _, v in specs])
+    N.call("dgv2_rng_fill", ptrs, cnt, kinds, a, b, n, N.ptr(st), N.stream())
+    return outs
 
 
 # ---------------------------------------------------------------------------------------

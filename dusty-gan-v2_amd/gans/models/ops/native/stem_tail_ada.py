@@ -144,11 +144,16 @@ def ada_apply(x, Ay, kx, off, sgn, a, c):
     return _AdaApply.apply(x, Ay, kx, off, sgn, a, c, False)
 
 
-def ada_sample(B, H, W, p, policy, device):
+def ada_sample(B, H, W, p, policy, device, u=None, n=None):
     """Draw the per-sample affine (sx, tx, sy, ty) and collapsed colour (a, c) of ADA in one kernel.
-    policy: 11 python floats (see dgv2_ada_sample).  Returns gaff [B,4], a [B], c [B]."""
-    u = torch.rand(B, 16, device=device)
-    n = torch.randn(B, 8, device=device)
+    policy: 11 python floats (see dgv2_ada_sample).  Returns gaff [B,4], a [B], c [B].
+    u [B,16] uniform in [0,1) / n [B,8] standard normal: the raw draws, when the caller made them already (the step
+    bodies draw everything they need in one launch, native.rng_fill)."""
+    u = torch.rand(B, 16, device=device) if u is None else u.float().contiguous()
+    n = torch.randn(B, 8, device=device) if n is None else n.float().contiguous()
+    if tuple(u.shape) != (B, 16) or tuple(n.shape) != (B, 8):
+        raise ValueError(f"ada_sample: u {tuple(u.shape)} / n {tuple(n.shape)} for B = {B}")
+    N.check(u, n)
     gaff = torch.empty((B, 4), device=device, dtype=torch.float32)
     a = torch.empty(B, device=device, dtype=torch.float32)
     c = torch.empty(B, device=device, dtype=torch.float32)

@@ -162,6 +162,22 @@ class FlatGradSync:
     def carries_buffers(self):
         return bool(self._carry)
 
+    def _carry_valid(self):
+        """The carried buffer list was captured at construction; module.to(...), load_state_dict(assign=True) or a
+        re-registered buffer replace the tensors.  Re-derive the list (as sync_buffers does) and re-point the views when
+        the set still fits the tail; otherwise this reduction does not carry (the caller's sync_buffers fallback runs)."""
+        bufs = mutable_buffers(self.module)
+        if len(bufs) == len(self._carry) and all(a is b or a.data_ptr() == b.data_ptr() for a, b in zip(bufs, self._carry)):
+            return True
+        if sum(b.numel() for b in bufs) != self._tail.numel() or any(b.dtype != torch.float32 for b in bufs):
+            return False
+        self._carry = bufs
+        self._tail_views, toff = [], 0
+        for b in bufs:
+            self._tail_views.append(self._tail[toff:toff + b.numel()].view_as(b))
+            toff += b.numel()
+        return True
+
     def all_reduce(self, async_op=False, part=None, carry=False):
         """Average the flat gradient (or one segment of it) over ranks (no-op for one process or inside no_sync).
         async_op: start the reduction on the communication stream and return a handle for wait(); work issued in
@@ -172,11 +188,19 @@ class FlatGradSync:
             return None
         avg = _avg_supported(self.flat.device)
         _, (lo, hi) = self._part(part)
-        carry = bool(carry and self._carry and hi == self.flat.numel())
+        carry = bool(carry and self._carry and hi == self.flat.numel() and self._carry_valid())
         if carry:
+            # rank 0's values + zeros from everybody else: x + 0 + ... + 0 = x exactly, so the carried part must see a
+            # plain SUM.  Where the reduction AVERAGES (RCCL), rank 0 pre-multiplies by W -- exact only for a power-of-two
+            # world (x * W / W returns x; for W = 3, 5, 6, 7 it does not, and DDP's broadcast is exact) -- so any other
+            # world size reduces this buffer with SUM and scales the GRADIENT part afterwards (17.5 MB for G).
+            W = dist.get_world_size()
+            if avg and W & (W - 1):
+                avg = False
             if dist.get_rank() == 0:
                 torch._foreach_copy_(self._tail_views, self._carry)
-                self._tail.mul_(float(dist.get_world_size()))
+                if avg:
+                    self._tail.mul_(float(W))
             else:
                 self._tail.zero_()
             hi = self._store.numel()
@@ -199,7 +223,8 @@ class FlatGradSync:
         if self.payload_dtype is not None:
             self.flat[lo:hi].copy_(self._payload[lo:hi])
         if not avg:
-            self._store[lo:hi].mul_(1.0 / dist.get_world_size())
+            # (never the carried tail: it holds rank 0's values as they are)
+            self._store[lo:min(hi, self.flat.numel())].mul_(1.0 / dist.get_world_size())
         if carry:
             torch._foreach_copy_(self._carry, self._tail_views)
 

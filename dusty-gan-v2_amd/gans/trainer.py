@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+import dgv2_native
 from gans import parallel
 from gans.augment.adaptive_augment import AdaptiveAugment
 from gans.context_manager import gradient_accumulation
@@ -162,6 +163,20 @@ class Trainer:
         self.optim_D = optim.Adam(self.D.parameters(), lr=ld.alpha * ratio_D, capturable=self.use_graphs, fused=self.device.type == "cuda",
                                   betas=(float(ld.beta1) ** ratio_D, float(ld.beta2) ** ratio_D))
         self.x_real = torch.empty(self.B, 1, *self.resolution, device=self.device)  # static input of the graphs
+        # the device word the kernels report broken promises to (include/dgv2.h "Status words": the x_exact promise of D's
+        # fp32 epilogue conv); it must exist before the first capture and is read wherever this class synchronises
+        dgv2_native.status_word(self.device)
+        # every random number of a step body from ONE launch (native.rng_fill, csrc/rng.hip: a Philox stream whose state
+        # lives on the device, so captured bodies draw fresh numbers on every replay) instead of ~8 generator launches with
+        # their scale / clamp companions per body and two philox-state fills per hipGraph replay.  training.native_rng:
+        # false keeps torch's generator (same distributions, another stream).
+        from gans.models import dusty_v2 as _v2
+        from gans.models.ops import native as _native
+        self.native_rng = (bool(cfg.training.get("native_rng", True)) and self.device.type == "cuda"
+                           and isinstance(self.G, _v2.Generator))
+        if self.native_rng:
+            _native.rng_state(self.device)
+        self._body = None
 
         # resume
         self.start_iteration = 0
@@ -258,22 +273,70 @@ class Trainer:
             else:
                 self._injected[k].copy_(v)
 
+    def _begin_body(self, body):
+        """Draw every random number the body `body` (g / d / r1) will consume with one launch (self.native_rng); the
+        helpers below hand them out by call site.  Injected draws (set_draws) take precedence."""
+        self._body = None
+        if self._injected is not None or not self.native_rng:
+            return
+        from gans.models.ops import native
+        B, (H, W) = self.B, self.resolution
+        syn = self.G.synthesis_network
+        eps = float(torch.finfo(torch.float32).eps)
+        specs, keys = [], []
+
+        def add(key, shape, kind, a, b):
+            keys.append(key)
+            specs.append((shape, kind, a, b))
+
+        if body in ("g", "d"):
+            add(body + ".z", (B, int(self.cfg.model.generator.mapping_kwargs.in_ch)), native.RNG_NORMAL, 0.0, 1.0)
+            if self.G.training and syn.aug_coords and not syn.aug_coords_blitting:
+                add(body + ".shifts", (B,), native.RNG_UNIFORM, 0.0, 2 * np.pi)   # dusty_v2.py:267-274
+            add(body + ".u", (B, 1, H, W), native.RNG_CLAMPED, eps, 1.0 - eps)     # gumbel.py:23-29 (clamp_probs)
+        sites = {"g": ["g.ada"] + (["g.ada_real"] if self.use_real_in_g else []),
+                 "d": ["d.ada_real", "d.ada_fake"], "r1": ["r1.ada"]}[body]
+        for site in sites:
+            add(site + ".u", (B, 16), native.RNG_UNIFORM, 0.0, 1.0)                # adaptive_augment.py:386-470
+            add(site + ".n", (B, 8), native.RNG_NORMAL, 0.0, 1.0)
+        if self._warm() and float(self.cfg.training.warmup.dropout_init_ratio) > 0.0:
+            ksites = {"g": ["g.keep"] + (["g.keep_real"] if self.use_real_in_g else []),
+                      "d": ["d.keep_real", "d.keep_fake"], "r1": ["r1.keep"]}[body]
+            for site in ksites:
+                add(site + ".uniform", (B, 1, H, W), native.RNG_UNIFORM, 0.0, 1.0)  # trainer.py:241-245
+        self._body = dict(zip(keys, native.rng_fill(specs, self.device)))
+
     def _draw(self, key):
-        return None if self._injected is None else self._injected.get(key)
+        if self._injected is not None:
+            return self._injected.get(key)
+        if self._body is not None and key + ".uniform" in self._body:   # a keep mask from this body's uniforms
+            return (self._body[key + ".uniform"] < (1 - self._wu_ratio)).float()
+        return None
 
     def _z(self, site):
         z = self._draw(site + ".z")
+        if z is None and self._body is not None:
+            z = self._body.get(site + ".z")
         return self.sample_z(self.B) if z is None else z
 
     def _g_noise(self, site):
-        if self._injected is None:
-            return None
-        return {"shifts": self._injected[site + ".shifts"], "gumbel_u": self._injected[site + ".u"]}
+        if self._injected is not None:
+            return {"shifts": self._injected[site + ".shifts"], "gumbel_u": self._injected[site + ".u"]}
+        if self._body is not None:
+            noise = {"gumbel_u": self._body[site + ".u"]}
+            if site + ".shifts" in self._body:
+                noise["shifts"] = self._body[site + ".shifts"]
+            return noise
+        return None
 
     def _ada(self, site):
-        if self._injected is None or site + ".G" not in self._injected:
-            return None
-        return {"G": self._injected[site + ".G"], "C": self._injected[site + ".C"]}
+        if self._injected is not None:
+            if site + ".G" not in self._injected:
+                return None
+            return {"G": self._injected[site + ".G"], "C": self._injected[site + ".C"]}
+        if self._body is not None and site + ".u" in self._body:
+            return {"u": self._body[site + ".u"], "n": self._body[site + ".n"]}
+        return None
 
     # ------------------------------------------------------------------ sub-steps
     # Each sub-step is split into a forward/backward body (`*_fb`), the gradient all-reduce (eager,
@@ -282,6 +345,7 @@ class Trainer:
     def g_fb(self, j, scalars, x_real=None):
         set_requires_grad(self.G, True)
         self.g_sync.begin(direct=j == 0)
+        self._begin_body("g")
         z = self._z("g")
         x_fake = self.G(z, noise=self._g_noise("g"), **self.auxin)["image"]
         y_fake = self.D(self.A(self.warmup(x_fake, self._draw("g.keep")), draws=self._ada("g.ada")))
@@ -291,10 +355,14 @@ class Trainer:
                 x_real_aug = self.A(self.warmup(x_real, self._draw("g.keep_real")), draws=self._ada("g.ada_real"))
             y_real = self.D(x_real_aug)
         if self.adversarial_loss.can_fuse(y_fake):
-            loss_gan, _ = self.adversarial_loss.fused_nsgan(y_fake, len(y_fake))   # softplus(-y_fake).mean(), one launch
+            # softplus(-y_fake).mean() and the cotangent loss.gan * d loss / d y from one launch; y.backward(gy) replaces
+            # (loss.gan * loss).backward() and its five scalar-graph launches
+            stats, gy = self.adversarial_loss.fused_nsgan_step(y_fake, len(y_fake), float(self.cfg.training.loss.gan))
+            loss_gan = stats[0]
+            y_fake.backward(gy)
         else:
             loss_gan = self.adversarial_loss(y_real, y_fake, "G")
-        (self.cfg.training.loss.gan * loss_gan).backward()
+            (self.cfg.training.loss.gan * loss_gan).backward()
         self.g_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
         set_requires_grad(self.G, False)
         scalars["loss/G/adversarial"] = loss_gan.detach()
@@ -306,6 +374,7 @@ class Trainer:
     def d_fb(self, x_real, j, scalars, cut=False):
         set_requires_grad(self.D, True)
         self.d_sync.begin(direct=j == 0)
+        self._begin_body("d")
         z = self._z("d")
         with torch.no_grad():
             x_fake = self.G(z, noise=self._g_noise("d"), **self.auxin)["image"]
@@ -316,15 +385,17 @@ class Trainer:
         y = self.D(torch.cat([x_real_aug, x_fake_aug], dim=0), splits=2, **({"cut": True} if cut else {}))
         y_real, y_fake = y[:self.B], y[self.B:]
         if self.adversarial_loss.can_fuse(y):
-            # objective, its gradient, both output means and ADA's sign statistic from one launch
-            loss_gan, stats = self.adversarial_loss.fused_nsgan(y, self.B)
-            self.A.cumulate(y_real, sign_sum=stats[3])
-            out_real, out_fake = stats[1], stats[2]
+            # objective, its weighted gradient, both output means and ADA's sign statistic from one launch
+            # (ADA's cumulate, adaptive_augment.py:368-370, rides in the same launch)
+            stats, gy = self.adversarial_loss.fused_nsgan_step(y, self.B, float(self.cfg.training.loss.gan),
+                                                               cum=(self.A.sign_cum, self.A.n_pred_cum))
+            loss_gan, out_real, out_fake = stats[0], stats[1], stats[2]
+            y.backward(gy)
         else:
             self.A.cumulate(y_real)
             loss_gan = self.adversarial_loss(y_real, y_fake, "D")
             out_real, out_fake = y_real.mean().detach(), y_fake.mean().detach()
-        (self.cfg.training.loss.gan * loss_gan).backward()
+            (self.cfg.training.loss.gan * loss_gan).backward()
         if cut:
             # the head's gradients are final; the trunk's backward is d_fb_tail
             self._d_cut = self.D.take_cut()
@@ -352,6 +423,7 @@ class Trainer:
         """lazy R1 (reference: trainer.py:419-451): double backward through D and ADA."""
         set_requires_grad(self.D, True)
         self.d_sync.begin(direct=False)
+        self._begin_body("r1")
         x = x_real.detach().requires_grad_(True)
         # behind a bf16 trunk the fp32 epilogue conv of this pass (forward, data gradient and the forward conv of the
         # double backward; no weight bank here) runs on the bf16 matrix cores too (conv_x3.hip, fp32-equivalent)
@@ -616,10 +688,18 @@ class Trainer:
 
         if self.sync_scalars:
             out = {k: v.cpu().item() for k, v in out.items()}
+            self.check_status()
         out["stats/ema_decay"] = decay
         out["stats/warmup_blur_sigma"] = self.blur_sigma
         out["stats/warmup_dropout_ratio"] = self.dropout_ratio
         return out
+
+    def check_status(self):
+        """Read the kernels' status word (synchronises) and raise if a launch met a broken promise -- e.g. a value that is
+        not bf16-representable in the channels Discriminator.forward promised to be (x_exact): the fp32 epilogue conv
+        would then have computed on bf16-rounded features without any other sign.  Called where the host waits for the
+        device anyway: the scalar read-back of step(), validation(), save_checkpoint()."""
+        dgv2_native.status_check()
 
     def graphs_live(self):
         """name -> True (captured, replaying) / False (capture failed: that body runs eagerly).  bench.py asserts that
@@ -678,6 +758,7 @@ class Trainer:
             fake.append(self.pointnet_features(out["image"], net).cpu())
         fake = torch.cat(fake, dim=0)
 
+        self.check_status()
         tag = f"{N // 1000}k"
         f1, f2 = fake.double().numpy(), self.val_real_feats.double().numpy()
         return {
@@ -686,7 +767,8 @@ class Trainer:
         }
 
     def save_checkpoint(self, save_path, step):
-        """Same keys as the reference (trainer.py:551-567); `cfg` is stored as plain containers (see `plain`)."""
+        """Same keys as the reference (trainer.py:551-567); `cfg` is stored as the reference stores it (an OmegaConf node)
+        where omegaconf is importable, as plain containers otherwise (see `plain`)."""
         def optim_state(opt):
             # the fused Adam kernel keeps ONE device step counter that every per-parameter `step` entry views; a
             # checkpoint carries independent copies so that stock torch.optim.Adam can resume from it
@@ -709,12 +791,21 @@ class Trainer:
                 return [plain(v) for v in o]
             return o
 
+        cfg_out = plain(self.cfg)
+        try:   # the reference pickles its OmegaConf node (trainer.py:551-567) and its tools read it by attribute
+            # (quick_demo.py:25, test_gan.py:48): where omegaconf is importable the file is written in that form and is
+            # directly consumable upstream; gans.pretrained.load_checkpoint accepts both forms
+            from omegaconf import OmegaConf
+            cfg_out = OmegaConf.create(cfg_out)
+        except ImportError:
+            pass
         ckpt = {
-            "cfg": plain(self.cfg), "step": step, "angle": self.coord.angle.detach().cpu(),
+            "cfg": cfg_out, "step": step, "angle": self.coord.angle.detach().cpu(),
             "G": self.G.state_dict(), "D": self.D.state_dict(), "G_ema": self.G_ema.state_dict(),
             "A": self.A.state_dict(), "optim_G": optim_state(self.optim_G), "optim_D": optim_state(self.optim_D),
         }
         if self.pl_weight > 0.0:
             ckpt["pl_ema"] = self.pl_ema.detach().cpu()
+        self.check_status()   # (state_dict -> file synchronises anyway) never write weights trained on a broken promise
         save_path.parent.mkdir(parents=True, exist_ok=True)
         torch.save(ckpt, save_path)

@@ -32,6 +32,14 @@ extern "C" {
 #define DGV2_EINVAL (-1)
 #define DGV2_ENOTSUP (-3) /* valid request that this build's kernels do not cover: use the documented fallback */
 
+/* Status words.  A few entries check a promise of the caller on the values they stage (dgv2_conv3x3_x3_fwd /
+ * dgv2_conv3x3_x3_wgrad: `x_exact`; dgv2_fir_same_mfma_prep: the table contract).  A breach cannot be a return code
+ * (the launch is asynchronous), and the library keeps no flag of its own: such entries take `int* status`, a device
+ * int32 the CALLER owns (zero-initialised once), and OR one of the bits below into it.  The caller reads the word
+ * whenever it synchronises anyway (gans.trainer.Trainer: scalar sync, validation, checkpoint; native.status_check). */
+#define DGV2_STATUS_X_INEXACT 1 /* a value outside an x_exact promise was staged: that launch computed on its bf16 rounding */
+#define DGV2_STATUS_FIR_TABLE 2 /* dgv2_fir_same_mfma_prep met a table entry outside its contract: the bands are unusable */
+
 /* Library/ABI version; bumped when a signature changes. */
 int dgv2_abi_version(void);
 
@@ -148,24 +156,21 @@ int dgv2_resample_tab_actbwd(void* y, float* gb, float* scratch, int64_t scratch
  * filter band as a constant operand (fir_mfma.hip).
  * dgv2_fir_same_mfma_prep builds the band operands ONCE from sparse-row tables exactly as dgv2_resample_tab takes them
  *   (bands: device buffer of >= *bytes_needed bytes, 16-byte aligned; bands == NULL only reports *bytes_needed).
- *   Contract on the tables (a violation raises the flag dgv2_fir_same_mfma_status reports and the bands are unusable):
+ *   Contract on the tables (a violation raises DGV2_STATUS_FIR_TABLE in *status and the bands are unusable):
  *   |idx_h[ho][a] - ho| <= 4,  (idx_w[wo][e] - wo + 8) mod W < 24,  every coefficient -- and every sum of the
  *   coefficients of one row that name the same input -- exactly representable in bf16.  DGV2_ENOTSUP unless
  *   H % 8 == 0 and W % 32 == 0.
  * dgv2_fir_same_mfma / _actbwd: DGV2_ENOTSUP unless C % 32 == 0, H % 8 == 0, W % 32 == 0 (then: dgv2_resample_tab /
  *   dgv2_resample_tab_actbwd, whose contracts they share: same scratch protocol for the bias gradient).
- * dgv2_fir_same_mfma_status: 1 if a prep call met a contract violation since the last call (synchronises the device:
- *   tests / debugging), 0 if not, < 0 on a runtime error.
  * replaces: Blur / Resample(up = down = 1) (gans/models/ops/common.py:105-135) at gans/models/dusty_v2.py:325-345, its
  *   adjoint, and FusedLeakyReLUFunctionBackward (gans/models/ops/fused_act/fused_act.py:22-45) behind it. */
 int dgv2_fir_same_mfma_prep(void* bands, int64_t bands_bytes, int64_t* bytes_needed, const int* idx_h, const float* coef_h,
                             const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew,
-                            int H, int W, void* stream);
+                            int H, int W, int* status, void* stream);
 int dgv2_fir_same_mfma(void* y, const void* x, const void* bands, int B, int C, int H, int W, void* stream);
 int dgv2_fir_same_mfma_actbwd(void* y, float* gb, float* scratch, int64_t scratch_elems, int64_t* blocks_needed,
                               const void* x, const void* ref, const void* bands, int B, int C, int H, int W, float alpha,
                               float scale, void* stream);
-int dgv2_fir_same_mfma_status(void);
 
 /* ---------------------------------------------------------------------------
  * Fourier features (positional encoding of the laser angles)
@@ -521,14 +526,14 @@ int dgv2_conv3x3_dgrad8(void* gx, const void* gy, const void* w8t, int B, int H,
  * (gans/models/dusty_v2.py:376-379) in the fp32 island of Discriminator.forward (:394-395).  DGV2_ENOTSUP where the
  * kernel does not cover the geometry (W % 32, Cx % 8, Cx >= 64, O % 64): callers then run dgv2_conv_taps in fp32. */
 int dgv2_conv3x3_x3_fwd(void* y, const void* x, const void* w3, int B, int H, int W, int Cx, int x_exact, int O,
-                        const float* bias, const void* resid, int act, float alpha, float scale, void* stream);
+                        const float* bias, const void* resid, int act, float alpha, float scale, int* status,
+                        void* stream);
 /* x_exact (forward and weight gradient): the caller's promise that channels [0, x_exact) of x hold bf16-representable
  * values -- the activations of a bf16 trunk widened to fp32, which is what the discriminator's epilogue receives
  * (dusty_v2.py:394: h.to(torch.float32)).  Their planes m and l are zero, so three of the six products of a multiply are
  * products with zero: they are not issued (same sum, half the MFMAs).  0 = no promise.  The kernels check the promise on
- * the values they stage; dgv2_conv_x3_status() returns 1 if a launch since the last call met a value that broke it (that
- * launch then computed with the bf16-rounded input), 0 otherwise; it synchronises the device (tests, debugging). */
-int dgv2_conv_x3_status(void);
+ * the values they stage: a value that breaks it raises DGV2_STATUS_X_INEXACT in *status (the caller's device word, see
+ * "Status words" above; required when x_exact > 0) -- that launch then computed with the bf16-rounded input. */
 /* Its data gradient: gx [B,H,W,ldx] (fp32) from gy [B,H,W,O] fp32 -- channels [0, C) the gradient (+ resid), [C, ldx)
  * resid or zero.  w3t = the transposed plane images (w8t of dgv2_conv_weight_bank_ex, dtype DGV2_F32:
  * [3][ldx / 64][O / 32][2304 units]) serve the channels of whole 64-channel slabs; wt [ldx, 9, O] fp32 (the bank's
@@ -544,7 +549,8 @@ int dgv2_conv3x3_x3_dgrad(void* gx, const void* gy, const void* w3t, const void*
  * replaces: the cuDNN weight gradient autograd calls for that conv.  DGV2_ENOTSUP: O % 128, C < 64, C % 8, W % 32,
  * more than 16 such channels. */
 int dgv2_conv3x3_x3_wgrad(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x, int B, int H,
-                          int W, int C, int clive, int x_exact, int O, float scale, int param_layout, void* stream);
+                          int W, int C, int clive, int x_exact, int O, float scale, int param_layout, int* status,
+                          void* stream);
 int dgv2_conv3x3_x3_wgrad_scratch(int64_t* elems, int B, int H, int W, int C, int clive, int O);
 /* Both image sets from weight VALUES w [O, 9, Cp] fp32 (the operand layout of dgv2_conv_taps), for passes that do not
  * run on the weight bank (R1's double backward): w3 [3][O / 64][ceil(Cp / 32)][2304 units of 8 bf16], w3t
@@ -700,9 +706,28 @@ int dgv2_surface_normal(float* out, const float* points, int B, int H, int W, in
  *   gans/trainer.py:400-406 and AdaptiveAugment.cumulate's sign sum (adaptive_augment.py:368-370)
  * y fp32 [n_real + n_fake] logits, reals first (either count may be 0: loss_G = mean softplus(-y_fake) is the
  * "real" formula applied to the fakes); stats fp32 [4] = loss, mean y_real, mean y_fake, sum sign(y_real);
- * gy fp32 [n_real + n_fake] = d loss / d y.
+ * gy fp32 [n_real + n_fake] = gy_scale * d loss / d y  (gy_scale: the objective's weight cfg.training.loss.gan, so that
+ * gy is the cotangent the step body hands to y.backward() directly -- no scalar-loss graph, gans/trainer.py:293-297).
+ * sign_cum / n_cum (both or neither, fp32 [1]): AdaptiveAugment's running statistic, updated in the same launch
+ * (+= sum sign(y_real), += n_real: AdaptiveAugment.cumulate, adaptive_augment.py:368-370).
  * ------------------------------------------------------------------------- */
-int dgv2_nsgan_loss(float* stats, float* gy, const float* y, int n_real, int n_fake, void* stream);
+int dgv2_nsgan_loss(float* stats, float* gy, const float* y, int n_real, int n_fake, float gy_scale, float* sign_cum,
+                    float* n_cum, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * every random number of one step body from ONE launch
+ * replaces: the torch.randn / torch.rand calls of an iteration -- Trainer.sample_z (gans/trainer.py:206-208), the azimuth
+ *   shift (gans/models/dusty_v2.py:267-274), the uniforms of GumbelSigmoid (gans/models/ops/gumbel.py:23-29), the draws of
+ *   AdaptiveAugment.sample_affine / sample_color (gans/augment/adaptive_augment.py:386-470), the warm-up keep mask
+ *   (gans/trainer.py:241-245).
+ * Philox4x32-10 (the generator torch.cuda uses); the stream state is DEVICE memory the caller owns: state uint64[4] =
+ * {seed, offset, 0, 0}.  The launch advances `offset` itself (its last block to finish), so a launch captured into a
+ * hipGraph draws fresh numbers on every replay.  nseg <= 16 segments: out[s] fp32 [count[s]],
+ *   kind 0: uniform in [a, b);  kind 1: normal, mean a, standard deviation b;  kind 2: u in [0, 1) clamped to [a, b].
+ * out / count / kind / a / b are HOST arrays (read during the call).  Launches on one state must be stream-ordered.
+ * ------------------------------------------------------------------------- */
+int dgv2_rng_fill(float* const* out, const int64_t* count, const int* kind, const float* a, const float* b, int nseg,
+                  uint64_t* state, void* stream);
 
 /* ---------------------------------------------------------------------------
  * KITTI scan -> range image (the front end of the real-data path)

@@ -19,4 +19,4 @@ for it in range(1, N + 1):
         ev = [float(b) for n, b in tr.G.named_buffers() if n.endswith("ema_var")][:4]
         print(it, {k: round(v, 4) for k, v in vals.items() if "loss" in k or "ada" in k}, "finite", finite, "ema_var", [round(e, 3) for e in ev])
 import dgv2_native as _N
-print("dgv2_conv_x3_status after the run (a value outside the x_exact promise of the fp32 epilogue conv would have raised it):", _N.lib.dgv2_conv_x3_status())
+print("status word after the run (a value outside the x_exact promise of the fp32 epilogue conv would have raised bit 1):", _N.status_read())

@@ -385,7 +385,7 @@ def test_r1_pass_with_the_epilogue_conv_on_the_matrix_cores_matches_the_exact_fp
 
     r_off, g_off = run(False)
     r_on, g_on = run(True)
-    assert N.lib.dgv2_conv_x3_status() == 0
+    assert N.status_read() == 0
     assert set(g_on) == set(g_off) and len(g_on) >= 20
     assert abs(r_on - r_off) <= 1e-4 * abs(r_off), (r_on, r_off)
     rel = sorted(((float((g_on[k] - g_off[k]).norm() / (g_off[k].norm() + 1e-30)), k) for k in g_off), reverse=True)

@@ -1132,28 +1132,33 @@ def test_conv_x3_is_fp32_equivalent(nat, B, H, W, C, O):
         assert float((gauto - gref).abs().max()) <= 1e-5 * float(gref.abs().max())
     # x_exact: input channels that hold bf16-representable values (the features of a bf16 trunk in front of the fp32
     # epilogue) have zero m / l planes -- the kernels skip those planes' products: the SAME bits as with them, and a value
-    # that breaks the promise raises dgv2_conv_x3_status()
+    # that breaks the promise raises DGV2_STATUS_X_INEXACT in the caller's status word
     import dgv2_native as N
     ne = min(C // 32 * 32, 64 * (C // 64)) if C >= 64 else 0
     if ne:
         xe = xp.clone()
         xe[..., :ne] = xe[..., :ne].bfloat16().float()
-        assert N.lib.dgv2_conv_x3_status() == 0
+        assert N.status_read() == 0
         full = nat._conv_fwd_raw(xe, wr, geom, bias.to(DEV), 3, 0.25, 2.0, w8=w3)
         skip = nat._conv_fwd_raw(xe, wr, geom, bias.to(DEV), 3, 0.25, 2.0, w8=w3, xexact=ne)
         assert torch.equal(full, skip)
         if has_w:
             assert torch.equal(nat._conv_wgrad_raw(cl(gy), xe, geom, x3=C), nat._conv_wgrad_raw(cl(gy), xe, geom, x3=C, xexact=ne))
-        assert N.lib.dgv2_conv_x3_status() == 0
+        assert N.status_read() == 0
         nat._conv_fwd_raw(xp, wr, geom, bias.to(DEV), 3, 0.25, 2.0, w8=w3, xexact=ne)       # xp is not bf16-exact
-        assert N.lib.dgv2_conv_x3_status() == 1 and N.lib.dgv2_conv_x3_status() == 0
+        assert N.status_read() == N.STATUS_X_INEXACT and N.status_read() == 0
         if has_w:
             nat._conv_wgrad_raw(cl(gy), xp, geom, x3=C, xexact=ne)
-            assert N.lib.dgv2_conv_x3_status() == 1
+            assert N.status_read() == N.STATUS_X_INEXACT
     # a geometry the kernel does not cover reports ENOTSUP (-> False here), it is not mis-computed
     y = torch.empty(1, 4, 48, 64, device=DEV)
     assert N.try_call("dgv2_conv3x3_x3_fwd", N.ptr(y), N.ptr(y), N.ptr(w3), 1, 4, 48, 64, 0, 64, None, None, 0, 0.2, 1.0,
-                      N.stream()) is False
+                      None, N.stream()) is False
+    # a promise without a status word to report its breach to is an invalid call
+    y2 = torch.empty(1, 4, 64, 64, device=DEV)
+    with pytest.raises(RuntimeError):
+        N.call("dgv2_conv3x3_x3_fwd", N.ptr(y2), N.ptr(y2), N.ptr(w3), 1, 4, 64, 64, 64, 64, None, None, 0, 0.2, 1.0,
+               None, N.stream())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -1710,7 +1715,7 @@ def test_fir_same_size_on_mfma(nat, B, H, W, C, adjoint):
     xd = x.to(DEV)
     assert ar._FIR_MFMA
     got = ar._resample_raw(xd, spec, adjoint, (H, W))
-    assert N.lib.dgv2_fir_same_mfma_status() == 0
+    assert N.status_read() == 0
     ar._FIR_MFMA = False
     try:
         old = ar._resample_raw(xd, spec, adjoint, (H, W))
@@ -1734,7 +1739,7 @@ def test_fir_same_size_with_activation_backward_on_mfma(nat):
     gy = torch.randn(B, H, W, C, generator=g).bfloat16().to(DEV)
     out = torch.randn(B, H, W, C, generator=g).bfloat16().to(DEV)
     gpre, gb = cv._resample_actbwd(gy, out, spec, (H, W), 0.2, 2.0 ** 0.5)
-    assert N.lib.dgv2_fir_same_mfma_status() == 0
+    assert N.status_read() == 0
     gx = ar._resample_raw(gy, spec, True, (H, W)).float()
     want = (torch.where(out.float() > 0, gx, gx * 0.2) * 2.0 ** 0.5).bfloat16()
     assert torch.equal(gpre, want)
@@ -1757,14 +1762,14 @@ def test_fir_mfma_flags_tables_outside_its_windows(nat):
     def prep(spec, Hin, Win, H, W):
         (ih, chh, nh, Eh), (iw, cw, nw, Ew) = spec.tables(Hin, Win, False, DEV)
         need = ctypes.c_int64(0)
-        tabs = (N.ptr(ih), N.ptr(chh), N.ptr(nh), Eh, N.ptr(iw), N.ptr(cw), N.ptr(nw), Ew, H, W)
+        tabs = (N.ptr(ih), N.ptr(chh), N.ptr(nh), Eh, N.ptr(iw), N.ptr(cw), N.ptr(nw), Ew, H, W, N.ptr(N.status_word()))
         N.call("dgv2_fir_same_mfma_prep", None, 0, ctypes.addressof(need), *tabs, N.stream())
         assert need.value in (1024 * (H // 8 + 1 + W // 16), 1024 * (H // 4 + 1 + W // 16))
         buf = torch.empty(need.value, device=DEV, dtype=torch.uint8)
         N.call("dgv2_fir_same_mfma_prep", N.ptr(buf), buf.numel(), None, *tabs, N.stream())
-        return N.lib.dgv2_fir_same_mfma_status()
+        return N.status_read()
 
     assert prep(nat.ResampleSpec([1, 3, 3, 1]), 32, 64, 32, 64) == 0
     # 32 x 64 outputs of a 64 x 128 decimation presented as a same-size problem: row ho reads inputs 2 ho - 1 ...
-    assert prep(nat.ResampleSpec([1, 3, 3, 1], down=(2, 2)), 64, 128, 32, 64) == 1
-    assert N.lib.dgv2_fir_same_mfma_status() == 0
+    assert prep(nat.ResampleSpec([1, 3, 3, 1], down=(2, 2)), 64, 128, 32, 64) == N.STATUS_FIR_TABLE
+    assert N.status_read() == 0

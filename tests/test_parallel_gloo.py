@@ -121,6 +121,66 @@ def test_two_rank_data_parallel_plumbing():
     assert r0[10] == r1[10] == ({"a": 0.5, "b": 4.0}, [0.0, 12.0], 0.0, [7.5, 15.0, 22.5])
 
 
+def _worker_carry3(rank, world, tmp, q):
+    """Three ranks (not a power of two): the carried buffers must arrive bit-exact (x * 3 / 3 != x in fp32 for a good
+    share of values), also where the backend would average inside the reduction, and also after the module's buffer
+    tensors were replaced behind the exchanger's back."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{tmp}/init", world_size=world, rank=rank)
+    from gans import parallel
+    from gans.models.builder import build_generator
+    from helpers import small_cfg
+
+    torch.manual_seed(0)
+    G = build_generator(small_cfg().model.generator)
+    # pretend the backend averages (RCCL's ReduceOp.AVG): for a non-power-of-two world the exchanger must fall back to
+    # SUM by itself (gloo would raise on AVG, so reaching the end of this worker proves it did)
+    parallel._AVG_OK = True
+    sync = parallel.FlatGradSync(G, carry_buffers=True)
+    g0 = torch.Generator().manual_seed(123)
+    want = [torch.randn(b.shape, generator=g0) * 3.7 for b in parallel.mutable_buffers(G)]   # rank 0's values
+    out = []
+    for round_ in range(2):
+        if round_ == 1:
+            # replace the buffer tensors (what module.to() / load_state_dict(assign=True) do)
+            for name, b in list(G.named_buffers()):
+                if name.endswith("ema_var") or name == "w_avg":
+                    mod = G.get_submodule(name.rsplit(".", 1)[0]) if "." in name else G
+                    mod.register_buffer(name.rsplit(".", 1)[-1], b.detach().clone())
+        sync.begin()
+        for p in G.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))
+        sync.collect()
+        with torch.no_grad():
+            for b, w in zip(parallel.mutable_buffers(G), want):
+                b.copy_(w if rank == 0 else torch.full_like(w, -1.0 - rank))
+        h = sync.all_reduce(async_op=True, carry=True)
+        sync.wait(h)
+        exact = all(torch.equal(b, w) for b, w in zip(parallel.mutable_buffers(G), want))
+        out.append((exact, float(sync.flat[0]), float(sync.flat[-1])))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_carried_buffers_are_exact():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = [ctx.Process(target=_worker_carry3, args=(r, world, tmp, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    for rank, out in res:
+        for exact, g_first, g_last in out:
+            assert exact, f"rank {rank}: carried buffers differ from rank 0's"
+            assert g_first == g_last == 2.0               # mean of (1, 2, 3)
+
+
 def _worker_segments(rank, world, tmp, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{tmp}/init", world_size=world, rank=rank)
