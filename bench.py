@@ -138,7 +138,7 @@ def _time_launches(fn, reps):
     return s.elapsed_time(e) * 1e-3 / reps
 
 
-PMC_FILE = os.path.join("profiles", "round4_pmc.json")
+PMC_FILE = os.path.join("profiles", "round5_pmc.json")
 
 
 PMC_BATCH_PER_GPU = 64   # scripts/pmc_probe.py launches the probes at this --batch-per-gpu
@@ -158,7 +158,9 @@ def _pmc_traffic(kernel_key, batch_per_gpu=PMC_BATCH_PER_GPU):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_*_f32, /opt/skills/guides/MI355X_MICROARCH.md
-STATS_FILE = "profiles/round4_bench_graph_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of this command (committed)
+# per-body launch listing of this command's kernel trace (scripts/step_listing.py --json; committed): every (kernel, grid)
+# instance with its time per TRAINING iteration = G body + D body + R1 body / 16
+STATS_FILE = "profiles/round5_step_instances.json"
 
 
 def kernel_source_hash():
@@ -176,28 +178,29 @@ def kernel_source_hash():
 
 
 def stats_current():
-    """True / False: the committed statistics carry this tree's kernel_source_hash(); None: no sidecar."""
-    meta = os.path.join(ROOT, STATS_FILE[:-4] + ".meta.json")
-    if not os.path.exists(meta):
+    """True / False: the committed listing carries this tree's kernel_source_hash(); None: no file / no stamp."""
+    path = os.path.join(ROOT, STATS_FILE)
+    if not os.path.exists(path):
         return None
-    return json.load(open(meta)).get("src_sha16") == kernel_source_hash()
+    sha = json.load(open(path)).get("src_sha16")
+    return None if sha is None else sha == kernel_source_hash()
 
 
 def dominant_instance():
-    """Which probed kernel instance the committed graph statistics rank highest: (probe key, kernel name, Percentage).
-    The file is sorted by total duration; the first row that one of the probes covers decides what `roofline` reports
-    (the three largest instances are within half a point of each other and trade places between runs)."""
-    import csv
+    """Which probed kernel instance the committed per-body listing ranks highest: (probe key, kernel name, share of the
+    training iteration in %).  An instance = (kernel, grid) with its time per training iteration (G body + D body + R1
+    body / 16: the step's own ranking, whatever the warm-up of the profiled process ran); the first instance, largest
+    first, that one of the probes covers decides what `roofline` reports."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), STATS_FILE)
-    probes = (("conv_x3", lambda n: "conv_x3_kernelILi1E" in n or "conv_x3_kernel<1>" in n),
+    probes = (("conv_x3", lambda n, g: ("conv_x3_kernelILi1E" in n or "conv_x3_kernel<1" in n)),
               # rocprofv3 demangles the bf16 four-class instance badly: <bool _Accum, bLi32ELi1ELi4ELi ...>
-              ("s2dgrad", lambda n: "conv_pipe_kernel" in n and "Li32ELi1ELi4ELi" in n),
-              ("strip", lambda n: "conv3x3_strip_kernel" in n))
+              ("s2dgrad", lambda n, g: "conv_pipe_kernel" in n and "Li32ELi1ELi4ELi" in n),
+              ("strip", lambda n, g: "conv3x3_strip_kernel" in n))
     if os.path.exists(path):
-        for r in csv.DictReader(open(path)):
+        for r in json.load(open(path))["instances"]:
             for key, pred in probes:
-                if pred(r["Name"]):
-                    return key, r["Name"][:96], float(r["Percentage"])
+                if pred(r["name"], r["grid"]):
+                    return key, r["name"][:96], round(r["pct"], 2)
     return "conv_x3", None, None
 
 
@@ -235,6 +238,8 @@ def x3_probe(args, reps=10):
             "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": _pmc_traffic("conv_x3_kernel_dgrad", args.batch_per_gpu),
             "traffic_source": PMC_FILE + " (rocprofv3 --pmc, committed)", "algorithmic_bytes_per_launch": nbytes,
+            "achieved_counts": "ISSUED bf16 MFMA FLOPs: six v_mfma_f32_16x16x32_bf16 products per fp32 multiply (MFMA "
+                               "utilisation); the algorithmic figure is fp32_equiv_tflops = achieved / 6",
             "avg_launch_us": sec * 1e6, "fp32_equiv_tflops": flops / sec / 1e12,
             "fp32_mfma_peak_frac": flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
             "exact_fp32_kernel_us": sec32 * 1e6}
@@ -292,7 +297,20 @@ def roofline_probe(args, reps=20):
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12}
 
 
-def modconv_probe(args, reps=20):
+def modconv_levels(args):
+    """`roofline_modconv` at the three pyramid levels that run the commuted kernel in the training step: level 4 (the
+    headline instance, full detail), level 3 and level 2 (own algorithmic FLOPs 2 B P Ks O over the kernel's launch time)."""
+    if args.dtype == "fp32":
+        return None
+    out = modconv_probe(args)
+    out["levels"] = {"4": {k: out[k] for k in ("achieved", "frac", "avg_launch_us", "layer_tflops")}}
+    for lvl, (hl, wl, Ka, O) in (("3", (16, 128, 128, 64)), ("2", (8, 64, 256, 128))):
+        r = modconv_probe(args, shape=(hl, wl, Ka, O), brief=True)
+        out["levels"][lvl] = r
+    return out
+
+
+def modconv_probe(args, reps=20, shape=(32, 256, 64, 32), brief=False):
     """The MFMA kernel north_star names: the modulated 1x1 conv at its heaviest site, generator level-4 conv1
     (B x 32768 pixels, K = 64 + 512 shared-PE channels, O = 32, bias + lrelu) as the training step runs it:
       dgv2_modconv_up_t_lag  T = W_a . h at 32x256 (the xa columns, commuted past the up-sampling: a quarter of the
@@ -307,7 +325,8 @@ def modconv_probe(args, reps=20):
     import dgv2_native as N
     from gans.models.ops import native
     from gans.models.ops.common import Resample
-    B, hl, wl, Ka, Ks, O = args.batch_per_gpu, 32, 256, 64, 512, 32
+    B, Ks = args.batch_per_gpu, 512
+    hl, wl, Ka, O = shape
     H, W = 2 * hl, 2 * wl
     P = H * W
     bf = torch.bfloat16
@@ -329,9 +348,14 @@ def modconv_probe(args, reps=20):
     sec = _time_launches(lambda: N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(t), N.ptr(xsf), N.ptr(wimg), B, H, W, hl, wl, Ks,
                                         O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), N.ptr(cvec), 3, 0.2, 2.0 ** 0.5,
                                         N.BF16, None, 0, None, N.stream()), reps)
+    sec_tl = _time_launches(lambda: native.mod_up_prepare(h, xs, w, spec, True, 0.2, 2.0 ** 0.5, want_stat=True), reps)
+    if brief:
+        fl = 2.0 * B * P * Ks * O
+        return {"shape": f"B x {P} px, Ka={Ka} (low res {hl}x{wl}), PE K={Ks}, O={O}", "achieved": fl / sec / 1e12,
+                "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_us": sec * 1e6,
+                "layer_tflops": 2.0 * B * P * (Ka + Ks) * O / (sec + sec_tl) / 1e12}
     sec_lo = _time_launches(lowres, reps)
     sec_sq = _time_launches(lambda: native.up2_lag_sumsq(h, spec), reps)
-    sec_tl = _time_launches(lambda: native.mod_up_prepare(h, xs, w, spec, True, 0.2, 2.0 ** 0.5, want_stat=True), reps)
     # the same layer on the un-commuted kernel (dgv2_modconv_pe_fwd on a materialised up2(h): the full K = Ka + Ks
     # contraction in one launch; levels 3 and 2 run this kernel in the training step)
     hup = native._resample_raw(h, spec, False, (hl, wl))
@@ -376,10 +400,13 @@ def timed_steps(trainer, first_it, n, barrier):
 
 
 def warm(trainer, cfg, n):
-    # the first calls use iteration 16 so that the lazy-R1 and ADA-update paths are warm as well
-    # (with hipGraphs every body needs 2 eager runs + 1 capture before it replays)
-    for _ in range(max(n, 1) + (3 if cfg.training.hip_graph else 0)):
+    # three calls at iteration 16 capture every body, the lazy-R1 one included (with hipGraphs a body needs 2 eager runs
+    # + 1 capture before it replays); the requested warm-up iterations then are PLAIN ones, so that a profile of this
+    # command carries the regulariser at the share the timed region gives it, not at the warm-up's
+    for _ in range(3 if cfg.training.hip_graph else 1):
         trainer.step(16)
+    for k in range(max(n, 1)):
+        trainer.step(1 + k % 15)
 
 
 def gfwd_probe_roofline(args, sec_per_batch):
@@ -521,10 +548,14 @@ def main():
         if world == 1:
             raise AssertionError(msg)
         print("bench.py: WARNING: " + msg, file=sys.stderr)   # N > 1: report it in extra.graphs_live, keep the line
+    import dgv2_native
+    extra["status_word"] = dgv2_native.status_read()   # 0: no kernel met a broken promise (x_exact) during the run
+    if extra["status_word"]:
+        raise AssertionError(f"a kernel reported a broken promise: status word {extra['status_word']} (include/dgv2.h)")
     roof = x3_probe(args) if rank == 0 else None
     roof_s2 = s2dgrad_probe(args) if rank == 0 else None
     roof_strip = roofline_probe(args) if rank == 0 else None
-    roof_mod = modconv_probe(args) if rank == 0 else None
+    roof_mod = modconv_levels(args) if rank == 0 else None
     if not args.no_extra and world == 1 and args.dtype == "bf16" and args.res == "64x512":
         # the same step with the discriminator epilogue in bf16 (opt-in; NOT what `value` is quoted on)
         other = "bf16" if args.d_epilogue == "fp32" else "fp32"
@@ -566,7 +597,8 @@ def main():
         key, name, pct = dominant_instance()
         chosen = {"conv_x3": roof, "s2dgrad": roof_s2, "strip": roof_strip}.get(key) or roof
         out["roofline"] = None if chosen is None else dict(
-            chosen, selected_by=f"largest Percentage among the probed kernel instances in {STATS_FILE}: {pct} % ({key})",
+            chosen, selected_by=f"largest share of the training iteration among the probed (kernel, grid) instances in {STATS_FILE}: "
+                                 f"{pct} % ({key})",
             stats_measured_on_this_tree=stats_current())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)

@@ -717,14 +717,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_tail_reduce_kernel(float* _
 // of the splits with independent loads, LDS folds the 16 lanes.  n is a multiple of 4.
 // scale: factor on the result; kkC > 0: write the PARAMETER's layout [O, C, kh*kw] instead of [O, kh*kw, C]
 // (kkC = kh*kw*C, C = Cc), so that the gradient needs no permute / scale pass before the optimizer sees it.
+// ldo > 0 (with kkC == 0): row r = i / Cc of an image goes to gw[r * ldo + i % Cc], images ldo * (n / Cc) apart -- the
+// caller's gradient of a wider weight, written in place (dgv2_bmm_tn_stream_ld).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ gw, const float* __restrict__ part,
                                                            int64_t n, int nsplit, float scale = 1.f, int kkC = 0,
-                                                           int Cc = 0) {
+                                                           int Cc = 0, int64_t ldo = 0) {
   __shared__ float4 red[16][16];
   const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int64_t i = ((int64_t)blockIdx.x * 16 + col) * 4;
   part += (int64_t)blockIdx.y * nsplit * n;   // per-image mode: image blockIdx.y owns its own nsplit partials
-  gw += (int64_t)blockIdx.y * n;
+  gw += (int64_t)blockIdx.y * (ldo > 0 ? (n / Cc) * ldo : n);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n) {
 #pragma unroll 4
@@ -742,7 +744,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ g
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
-    if (kkC == 0) {
+    if (kkC == 0 && ldo > 0) {
+      const int64_t r = i / Cc;
+      *reinterpret_cast<float4*>(gw + r * ldo + (i - r * Cc)) = s;
+    } else if (kkC == 0) {
       *reinterpret_cast<float4*>(gw + i) = s;
     } else {
       const float v4[4] = {s.x, s.y, s.z, s.w};
@@ -907,8 +912,16 @@ extern "C" int dgv2_bmm_tn_stream(float* gw, float* scratch, int64_t scratch_ele
 // gw[b, o, c] = sum_p gy[b, p, o] * pe[p, c]).
 extern "C" int dgv2_bmm_tn_stream_x(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
                                     int x_shared, int B, int H, int W, int C, int O, int dtype, void* stream) {
+  return dgv2_bmm_tn_stream_ld(gw, 0, scratch, scratch_elems, gy, x, x_shared, B, H, W, C, O, dtype, stream);
+}
+
+// ldo > 0: gw is [B, O, ldo] with ldo >= C (and a multiple of 4): the columns [0, C) of the caller's wider per-sample weight
+// gradient, written in place (offset the pointer for another first column); 0: contiguous [B, O, C].
+extern "C" int dgv2_bmm_tn_stream_ld(float* gw, int64_t ldo, float* scratch, int64_t scratch_elems, const void* gy,
+                                     const void* x, int x_shared, int B, int H, int W, int C, int O, int dtype, void* stream) {
   if (!gw || !scratch || !gy || !x || !aligned16(gy) || !aligned16(x) || !aligned16(scratch) || !aligned16(gw))
     return DGV2_EINVAL;
+  if (ldo < 0 || (ldo > 0 && (ldo < C || (ldo & 3)))) return DGV2_EINVAL;
   if (dtype != DGV2_BF16 && dtype != DGV2_F32) return DGV2_EINVAL;
   WSPlan p;
   if (!ws_plan(p, B, H, W, C, O, 1, 1, 0, 0, dtype, true)) return DGV2_EINVAL;
@@ -920,7 +933,7 @@ extern "C" int dgv2_bmm_tn_stream_x(float* gw, float* scratch, int64_t scratch_e
                                     : ws_dispatch_geom<float>(scratch, gy, x, p, st);
   if (rc) return rc;
   dim3 grid((unsigned)((n / 4 + 15) / 16), B);
-  wgrad_reduce_kernel<<<grid, 256, 0, st>>>(gw, scratch, n, p.nsplit / B);
+  wgrad_reduce_kernel<<<grid, 256, 0, st>>>(gw, scratch, n, p.nsplit / B, 1.f, 0, C, ldo);
   DGV2_RETURN_LAST();
 }
 

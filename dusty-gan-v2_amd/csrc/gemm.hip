@@ -369,6 +369,182 @@ __global__ __launch_bounds__(256) void small_bias_reduce_kernel(float* __restric
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// The WHOLE backward of a level's output heads in one streaming pass (round 5).  The heads' input x [B, P, K] (the
+// trunk's activation) is read once and serves as the operand of the head weight gradient AND as the `ref` of the
+// upstream layer's activation backward; the skip gradient gy [B, P, O] fp32 (O <= 4 head channels) is read once:
+//   g[p, o]   = T(gy[p, o] * cvec[o])                                  (the heads' accumulator gradient, rounded to T)
+//   y[p, k]   = ((sum_o g[p, o] w[b, k, o]) + resid[p, k]) * (x > 0 ? 1 : alpha) * ascale * row_scale[k]
+//   gb_up[k]  = sum_{b, p} of the unscaled, rounded y                  (upstream bias gradient)
+//   gw[b,o,k] = sum_p g[p, o] x[p, k]                                  (head weight gradient, per sample)
+//   gbh[o]    = sum_{b, p} gy[p, o]                                    (head bias gradient, unscaled fp32)
+// replaces five launches per level (column sum, scale + cast, dgv2_bmm_nn_small_act, dgv2_bmm_tn_small and their zero
+// fills / reducers) that read x twice and gy three times.  Partials per block, folded by ONE reduce launch.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T, int O>
+__global__ __launch_bounds__(256) void head_bwd_kernel(T* __restrict__ y, const float* __restrict__ gyf,
+                                                       const float* __restrict__ cvec, const T* __restrict__ w,
+                                                       const T* __restrict__ resid, const T* __restrict__ ref, int P, int K,
+                                                       int ppb, const float* __restrict__ row_scale, float alpha,
+                                                       float ascale, float* __restrict__ p_gb, float* __restrict__ p_gw,
+                                                       float* __restrict__ p_gbh) {
+  constexpr int VN = vec16<T>::N;
+  __shared__ float red[256 * VN];
+  const int b = blockIdx.y;
+  const int kvecs = K / VN, lanes = 256 / kvecs;
+  const int kv = threadIdx.x % kvecs, pl = threadIdx.x / kvecs;
+  float wr[VN][O], cv[O];
+#pragma unroll
+  for (int j = 0; j < VN; ++j)
+#pragma unroll
+    for (int o = 0; o < O; ++o) wr[j][o] = to_f32(w[((int64_t)b * K + kv * VN + j) * O + o]);
+#pragma unroll
+  for (int o = 0; o < O; ++o) cv[o] = cvec[o];
+  const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, P);
+  const float* gb_ = gyf + (int64_t)b * P * O;
+  float rs[VN], bsum[VN], hw[O][VN], hb[O];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) {
+    rs[j] = row_scale ? row_scale[kv * VN + j] : 1.f;
+    bsum[j] = 0.f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) hw[o][j] = 0.f;
+  }
+#pragma unroll
+  for (int o = 0; o < O; ++o) hb[o] = 0.f;
+  for (int p = p0 + pl; p < p1; p += lanes) {
+    float g[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const float raw = gb_[(int64_t)p * O + o];
+      if (kv == 0) hb[o] += raw;                      // one thread per pixel sums the unscaled gradient
+      g[o] = to_f32(from_f32<T>(raw * cv[o]));
+    }
+    const int64_t off = ((int64_t)b * P + p) * K + kv * VN;
+    vec16<T> r, f, out;
+    if (resid) r.load(resid + off);
+    f.load(ref + off);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      const float xv = f.get(j);
+      float s = resid ? r.get(j) : 0.f;
+#pragma unroll
+      for (int o = 0; o < O; ++o) {
+        s = fmaf(g[o], wr[j][o], s);
+        hw[o][j] = fmaf(g[o], xv, hw[o][j]);
+      }
+      const float v = (xv > 0.f ? s : s * alpha) * ascale;
+      out.set(j, v);
+      bsum[j] += out.get(j);          // the bias gradient sums the rounded, unscaled gradient
+      out.set(j, v * rs[j]);
+    }
+    out.store(y + off);
+  }
+  // per-block partials: the `lanes` pixel lanes of a channel vector fold through LDS, one quantity at a time
+  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int q = 0; q <= O; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VN; ++j) red[threadIdx.x * VN + j] = q == 0 ? bsum[j] : hw[q > 0 ? q - 1 : 0][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += 256) {
+      const int v = c / VN, j = c - v * VN;
+      float s2 = 0.f;
+      for (int t = 0; t < lanes; ++t) s2 += red[(t * kvecs + v) * VN + j];
+      if (q == 0) p_gb[blk * K + c] = s2;
+      else p_gw[(blk * O + (q - 1)) * K + c] = s2;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int o = 0; o < O; ++o) red[threadIdx.x * O + o] = kv == 0 ? hb[o] : 0.f;
+  __syncthreads();
+  if (threadIdx.x < O) {
+    float s2 = 0.f;
+    for (int t = 0; t < 256; ++t) s2 += red[t * O + threadIdx.x];
+    p_gbh[blk * O + threadIdx.x] = s2;
+  }
+}
+
+// blocks [0, K): gb_up[c];  [K, K + B*O): gw[b, o, :] over the sample's nsplit blocks;  [K + B*O, K + B*O + O): gbh[o]
+__global__ __launch_bounds__(256) void head_bwd_reduce_kernel(float* __restrict__ gb, float* __restrict__ gw,
+                                                              float* __restrict__ gbh, const float* __restrict__ p_gb,
+                                                              const float* __restrict__ p_gw, const float* __restrict__ p_gbh,
+                                                              int nsplit, int B, int O, int K) {
+  __shared__ float red[16];
+  const int nblk = nsplit * B;
+  int id = blockIdx.x;
+  if (id < K) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = threadIdx.x; k < nblk; k += 256) s += p_gb[(int64_t)k * K + id];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) gb[id] = s;
+    return;
+  }
+  id -= K;
+  if (id < B * O) {
+    const int b = id / O, o = id - b * O;
+    for (int c = threadIdx.x; c < K; c += 256) {
+      float s = 0.f;
+      for (int k = 0; k < nsplit; ++k) s += p_gw[(((int64_t)b * nsplit + k) * O + o) * K + c];
+      gw[((int64_t)b * O + o) * K + c] = s;
+    }
+    return;
+  }
+  id -= B * O;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < nblk; k += 256) s += p_gbh[(int64_t)k * O + id];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) gbh[id] = s;
+}
+
+}  // namespace
+
+// See the section comment above.  gyf fp32 [B, P, O], cvec fp32 [O], w [B, K, O] / resid / ref / y [B, P, K] in `dtype`;
+// gb_up fp32 [K], gw fp32 [B, O, K], gbh fp32 [O] (all overwritten).  scratch: fp32 [>= *blocks_needed * (K + O K + O)];
+// y == NULL with blocks_needed: query only.  DGV2_ENOTSUP: O > 4, K not a multiple of the 16-byte vector or K / vector not
+// dividing 256 (callers then run the separate launches).
+extern "C" int dgv2_head_bwd(void* y, float* gw, float* gbh, float* gb_up, float* scratch, int64_t scratch_elems,
+                             int64_t* blocks_needed, const float* gyf, const float* cvec, const void* w, const void* resid,
+                             const void* ref, const float* row_scale, float alpha, float ascale, int B, int P, int O, int K,
+                             int dtype, void* stream) {
+  if (B <= 0 || P <= 0 || O <= 0 || K <= 0) return DGV2_EINVAL;
+  const int vn = dtype == DGV2_BF16 ? 8 : (dtype == DGV2_F32 ? 4 : 0);
+  if (!vn) return DGV2_EINVAL;
+  if (O > 4 || K % vn || 256 % (K / vn)) return DGV2_ENOTSUP;
+  const int lanes = 256 / (K / vn);
+  int nsplit = (2048 + B - 1) / B;
+  const int minpix = lanes * 8;
+  if ((int64_t)nsplit * minpix > P) nsplit = (P + minpix - 1) / minpix;
+  nsplit = nsplit < 1 ? 1 : nsplit;
+  const int ppb = (P + nsplit - 1) / nsplit;
+  dim3 grid((P + ppb - 1) / ppb, B);
+  const int64_t nblk = (int64_t)grid.x * grid.y;
+  if (blocks_needed) *blocks_needed = nblk;
+  if (blocks_needed && !y) return 0;   // query only
+  if (!y || !gw || !gbh || !gb_up || !scratch || !gyf || !cvec || !w || !ref) return DGV2_EINVAL;
+  if (scratch_elems < nblk * ((int64_t)K + (int64_t)O * K + O)) return DGV2_EINVAL;
+  if (!aligned16(y) || !aligned16(ref) || (resid && !aligned16(resid))) return DGV2_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  float* p_gb = scratch;
+  float* p_gw = p_gb + nblk * K;
+  float* p_gbh = p_gw + nblk * O * K;
+  DGV2_DISPATCH_DTYPE(dtype, {
+    switch (O) {
+      case 1: head_bwd_kernel<T, 1><<<grid, 256, 0, st>>>((T*)y, gyf, cvec, (const T*)w, (const T*)resid, (const T*)ref, P, K, ppb, row_scale, alpha, ascale, p_gb, p_gw, p_gbh); break;
+      case 2: head_bwd_kernel<T, 2><<<grid, 256, 0, st>>>((T*)y, gyf, cvec, (const T*)w, (const T*)resid, (const T*)ref, P, K, ppb, row_scale, alpha, ascale, p_gb, p_gw, p_gbh); break;
+      case 3: head_bwd_kernel<T, 3><<<grid, 256, 0, st>>>((T*)y, gyf, cvec, (const T*)w, (const T*)resid, (const T*)ref, P, K, ppb, row_scale, alpha, ascale, p_gb, p_gw, p_gbh); break;
+      default: head_bwd_kernel<T, 4><<<grid, 256, 0, st>>>((T*)y, gyf, cvec, (const T*)w, (const T*)resid, (const T*)ref, P, K, ppb, row_scale, alpha, ascale, p_gb, p_gw, p_gbh); break;
+    }
+  });
+  head_bwd_reduce_kernel<<<K + B * O + O, 256, 0, st>>>(gb_up, gw, gbh, p_gb, p_gw, p_gbh, (int)grid.x, B, O, K);
+  DGV2_RETURN_LAST();
+}
+
 // y [B, P, K] = x [B, P, O] . w [B, K, O]^T (+ resid [B, P, K]), all in `dtype`; 1 <= O <= 4, K a multiple of the
 // 16-byte vector with K / vector dividing 256.  DGV2_ENOTSUP otherwise (use dgv2_bmm_nn).
 extern "C" int dgv2_bmm_nn_small(void* y, const void* x, const void* w, const void* resid, int B, int P, int O, int K,

@@ -500,6 +500,374 @@ __global__ __launch_bounds__(256) void mod_prep_all_w_fix_kernel(PrepAll a_by_va
              rsqrtf((float)I), local, a.aux[l], red);
 }
 
+// ------------------------------------------------------------------------------------------------
+// V4 forms of the batched kernels (round 5).  The wave-per-row kernels above walk a row with column i = lane + 64 j,
+// j < 16 -- sixteen 4-byte loads per operand and sixteen 2-byte stores per lane whatever I is (clamped addresses), and
+// the backward combines its OG x BG register tiles with fp32 atomics (0.5 per element: what bound it).  Here a lane owns
+// 16-byte CHUNKS: chunk q = lane + 64 jj covers columns [4q, 4q + 4), jj < JJ = ceil(I / 256) (a template parameter),
+// so a row is JJ float4 loads per operand and JJ 8-byte stores, and the rotation partner of a sin column (i + 256) is
+// chunk q + 64 = the SAME lane's next chunk.  The backward keeps the sums over its samples in registers and leaves
+// PARTIAL results per (row group, sample chunk) in scratch with plain stores; the two fix-up kernels, which read every
+// gW / gs element anyway, fold the partials: no atomics, no zero fill, run-to-run identical bits.
+// Conditions (host-checked, else the kernels above run): I % 4 == 0, rotating layers cin % 4 == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int V4_BC = 8;   // samples per unit (forward: consecutive rows share the W row; backward: register sums)
+constexpr int V4_OG = 4;   // rows per backward unit
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator*(const float4& a, const float4& b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator+(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(const float4& a, const float4& b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(const float4& a, float b) { return make_float4(a.x * b, a.y * b, a.z * b, a.w * b); }
+__device__ __forceinline__ float hsum(const float4& a) { return (a.x + a.y) + (a.z + a.w); }
+
+template <typename TO> __device__ __forceinline__ void st4(TO* p, const float4& v);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float4& v) {
+  union { uint2 u; bf16_t e[4]; } q;
+  q.e[0] = (bf16_t)v.x; q.e[1] = (bf16_t)v.y; q.e[2] = (bf16_t)v.z; q.e[3] = (bf16_t)v.w;
+  *reinterpret_cast<uint2*>(p) = q.u;
+}
+
+// (sin, cos) of the four frequencies of sin chunk q of a rotating layer (table [B, 256] of float2, mod_stats_all_kernel)
+__device__ __forceinline__ void rot4(const float* __restrict__ rot_lb, int f0, float4& sd, float4& cd) {
+  const float4 a = ld4(rot_lb + 2 * f0), b = ld4(rot_lb + 2 * f0 + 4);
+  sd = make_float4(a.x, a.z, b.x, b.z);
+  cd = make_float4(a.y, a.w, b.y, b.w);
+}
+
+template <int JJ, typename TO>
+__device__ __forceinline__ void prep_fwd_v4(const PrepAll& a, int l, int o, int b0, int nb) {
+  const int lane = threadIdx.x & 63;
+  const int I = a.I[l], O = a.O[l], Otot = a.Otot[l], row_off = a.row_off[l];
+  const bool demod = a.flags[l] & 1, rotate = (a.flags[l] & 2) && a.shift;
+  const int cin4 = a.cin[l] >> 2;
+  const float* stats = a.stats + (size_t)l * (2 + 2 * a.B);
+  const float inv_wmax = demod ? 1.f / stats[0] : rsqrtf((float)I);
+  const float* Wr = a.W[l] + (int64_t)o * I;
+  float4 wp[JJ];
+  bool in[JJ];
+#pragma unroll
+  for (int jj = 0; jj < JJ; ++jj) {
+    const int q = lane + 64 * jj;
+    in[jj] = 4 * q < I;
+    wp[jj] = in[jj] ? ld4(Wr + 4 * q) * inv_wmax : f4(0.f);
+  }
+  TO* wb = (TO*)a.wb[l];
+  for (int bi = 0; bi < nb; ++bi) {
+    const int b = b0 + bi;
+    const float inv_smax = demod ? 1.f / stats[2 + 2 * b] : 1.f;
+    const float* sr = a.s[l] + (int64_t)b * I;
+    float4 m[JJ];
+    float ss = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) {
+      const int q = lane + 64 * jj;
+      const float4 t = in[jj] ? ld4(sr + 4 * q) * inv_smax + f4(1.f) : f4(0.f);
+      m[jj] = wp[jj] * t;
+      ss += hsum(m[jj] * m[jj]);
+    }
+    float d = 1.f;
+    if (demod) d = rsqrtf(wave_sum(ss) + 1e-8f);
+    if (lane == 0) a.dsave[l][(int64_t)b * O + o] = d;
+    if (rotate) {
+      const float* rot_lb = a.rot + ((size_t)l * a.B + b) * PB * 2;
+#pragma unroll
+      for (int jj = 0; jj + 1 < JJ; ++jj) {
+        const int q = lane + 64 * jj;
+        const bool sc = q >= cin4 && q < cin4 + 64;
+        float4 sd, cd;
+        rot4(rot_lb, 4 * min(max(q - cin4, 0), 63), sd, cd);
+        const float4 ws = m[jj], wc = m[jj + 1];
+        if (sc) {
+          m[jj] = ws * cd - wc * sd;
+          m[jj + 1] = ws * sd + wc * cd;
+        }
+      }
+    }
+    TO* out = wb + ((int64_t)b * Otot + row_off + o) * I;
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj)
+      if (in[jj]) st4<TO>(out + 4 * (lane + 64 * jj), m[jj] * d);
+  }
+}
+
+// blocks of layer l: ceil(O / 4) row groups x ceil(B / V4_BC) sample chunks; wave w of a block owns row 4 og + w
+__global__ __launch_bounds__(PB) void mod_prep_all_fwd_v4_kernel(PrepAll a_by_value) {
+  const PrepAll& a = kernarg_view(a_by_value);
+  int local;
+  const int l = find_layer(a, blockIdx.x, local);
+  const int O = a.O[l], nog = (O + 3) / 4;
+  const int o = (local % nog) * 4 + (threadIdx.x >> 6), b0 = (local / nog) * V4_BC;
+  if (o >= O) return;
+  const int nb = min(V4_BC, a.B - b0);
+  const int JJ = (a.I[l] + 255) >> 8;
+  if (a.flags[l] & 4) {
+    switch (JJ) {
+      case 1: prep_fwd_v4<1, bf16_t>(a, l, o, b0, nb); break;
+      case 2: prep_fwd_v4<2, bf16_t>(a, l, o, b0, nb); break;
+      case 3: prep_fwd_v4<3, bf16_t>(a, l, o, b0, nb); break;
+      default: prep_fwd_v4<4, bf16_t>(a, l, o, b0, nb); break;
+    }
+  } else {
+    switch (JJ) {
+      case 1: prep_fwd_v4<1, float>(a, l, o, b0, nb); break;
+      case 2: prep_fwd_v4<2, float>(a, l, o, b0, nb); break;
+      case 3: prep_fwd_v4<3, float>(a, l, o, b0, nb); break;
+      default: prep_fwd_v4<4, float>(a, l, o, b0, nb); break;
+    }
+  }
+}
+
+// ---- backward ----
+struct PrepAllB {
+  const float* W[MPA_MAX];
+  const float* s[MPA_MAX];
+  const float* G[MPA_MAX];       // dL/d(prepared weights) fp32 [B, Otot, I]
+  const float* dsave[MPA_MAX];
+  float* out[MPA_MAX];           // [gW (O I) | gs (B I) | ...]
+  float* gtp[MPA_MAX];           // scratch: gt partials [nog][B][I]
+  float* gwp[MPA_MAX];           // scratch: gW partials [nbc][O][I]
+  float* corr[MPA_MAX];          // scratch: one slot per unit
+  int O[MPA_MAX], I[MPA_MAX], Otot[MPA_MAX], row_off[MPA_MAX], cin[MPA_MAX], flags[MPA_MAX];
+  int blk_end[MPA_MAX];
+  const float* stats;
+  const float* rot;
+  const float* shift;
+  int B, L;
+};
+__device__ __forceinline__ const PrepAllB& kernarg_view(const PrepAllB&) {
+  return *(const PrepAllB*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+__device__ __forceinline__ int find_layer(const PrepAllB& a, int bid, int& local) {
+  int l = 0;
+#pragma unroll
+  for (int k = 0; k < MPA_MAX; ++k) l += bid >= a.blk_end[k] ? 1 : 0;
+  l = min(l, a.L - 1);
+  local = bid - (l ? a.blk_end[l - 1] : 0);
+  return l;
+}
+
+// one unit: rows 4 og .. 4 og + 3 against samples b0 .. b0 + nb - 1 (see the header of this section)
+template <int JJ>
+__device__ __forceinline__ void prep_bwd_v4(const PrepAllB& a, int l, int og, int bc, int unit) {
+  const int lane = threadIdx.x & 63;
+  const int I = a.I[l], O = a.O[l], Otot = a.Otot[l], row_off = a.row_off[l];
+  const bool demod = a.flags[l] & 1, rotate = (a.flags[l] & 2) && a.shift;
+  const int cin4 = a.cin[l] >> 2;
+  const float* stats = a.stats + (size_t)l * (2 + 2 * a.B);
+  const float inv_wmax = demod ? 1.f / stats[0] : rsqrtf((float)I);
+  const int o0 = og * V4_OG, b0 = bc * V4_BC, nb = min(V4_BC, a.B - b0);
+  const int no = min(V4_OG, O - o0);
+  float4 wp[V4_OG][JJ], gw[V4_OG][JJ];
+  bool in[JJ];
+#pragma unroll
+  for (int jj = 0; jj < JJ; ++jj) in[jj] = 4 * (lane + 64 * jj) < I;
+#pragma unroll
+  for (int ol = 0; ol < V4_OG; ++ol)
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) {
+      const int oc = min(o0 + ol, O - 1);
+      wp[ol][jj] = (in[jj] && ol < no) ? ld4(a.W[l] + (int64_t)oc * I + 4 * (lane + 64 * jj)) * inv_wmax : f4(0.f);
+      gw[ol][jj] = f4(0.f);
+    }
+  float part = 0.f;
+  const int nog = (O + V4_OG - 1) / V4_OG;
+  for (int bi = 0; bi < nb; ++bi) {
+    const int b = b0 + bi;
+    const float inv_smax = demod ? 1.f / stats[2 + 2 * b] : 1.f;
+    const float* sr = a.s[l] + (int64_t)b * I;
+    float4 t[JJ], gt[JJ];
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) {
+      t[jj] = in[jj] ? ld4(sr + 4 * (lane + 64 * jj)) * inv_smax + f4(1.f) : f4(0.f);
+      gt[jj] = f4(0.f);
+    }
+    // this lane's rotation factors (one sin chunk per lane at most)
+    float4 sd = f4(0.f), cd = f4(1.f);
+    int jsin = -1;
+    if (rotate) {
+#pragma unroll
+      for (int jj = 0; jj + 1 < JJ; ++jj) {
+        const int q = lane + 64 * jj;
+        if (q >= cin4 && q < cin4 + 64) jsin = jj;
+      }
+      const int qs = lane + 64 * max(jsin, 0);
+      rot4(a.rot + ((size_t)l * a.B + b) * PB * 2, 4 * min(max(qs - cin4, 0), 63), sd, cd);
+    }
+    // the four rows' gradients are requested together (rows past O: a clamped re-read against zero weights), so that
+    // one memory latency covers them; their reductions are independent
+    float4 gp[V4_OG][JJ];
+#pragma unroll
+    for (int ol = 0; ol < V4_OG; ++ol) {
+      const float* Gr = a.G[l] + ((int64_t)b * Otot + row_off + min(o0 + ol, O - 1)) * I;
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) gp[ol][jj] = in[jj] ? ld4(Gr + 4 * (lane + 64 * jj)) : f4(0.f);
+    }
+    float dv[V4_OG];
+#pragma unroll
+    for (int ol = 0; ol < V4_OG; ++ol) dv[ol] = demod ? a.dsave[l][(int64_t)b * O + min(o0 + ol, O - 1)] : 1.f;
+    if (rotate) {   // transpose of the rotation
+#pragma unroll
+      for (int ol = 0; ol < V4_OG; ++ol)
+#pragma unroll
+        for (int jj = 0; jj + 1 < JJ; ++jj) {
+          const float4 gs = gp[ol][jj], gc = gp[ol][jj + 1];
+          if (jj == jsin) {
+            gp[ol][jj] = gs * cd + gc * sd;
+            gp[ol][jj + 1] = gc * cd - gs * sd;
+          }
+        }
+    }
+    float r[V4_OG];
+#pragma unroll
+    for (int ol = 0; ol < V4_OG; ++ol) {
+      r[ol] = 0.f;
+      if (demod) {
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) r[ol] += hsum(gp[ol][jj] * (wp[ol][jj] * t[jj]));
+      }
+    }
+    if (demod) {   // four interleaved butterflies
+#pragma unroll
+      for (int sft = 32; sft > 0; sft >>= 1)
+#pragma unroll
+        for (int ol = 0; ol < V4_OG; ++ol) r[ol] += __shfl_xor(r[ol], sft, 64);
+    }
+#pragma unroll
+    for (int ol = 0; ol < V4_OG; ++ol) {
+      const float live = ol < no ? 1.f : 0.f;   // rows past O contribute nothing (their wp is zero; gm must be too)
+      const float d = dv[ol], d2r = d * d * r[ol];
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) {
+        const float4 gm = demod ? (gp[ol][jj] - (wp[ol][jj] * t[jj]) * d2r) * (d * live) : gp[ol][jj] * live;
+        const float4 gwv = gm * t[jj];
+        gw[ol][jj] = gw[ol][jj] + gwv;
+        gt[jj] = gt[jj] + gm * wp[ol][jj];
+        part += hsum(gwv * wp[ol][jj]);
+      }
+    }
+    float* gtr = a.gtp[l] + ((int64_t)og * a.B + b) * I;
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj)
+      if (in[jj]) st4<float>(gtr + 4 * (lane + 64 * jj), gt[jj]);
+  }
+  (void)nog;
+#pragma unroll
+  for (int ol = 0; ol < V4_OG; ++ol) {
+    if (ol >= no) break;
+    float* gwr = a.gwp[l] + ((int64_t)bc * O + o0 + ol) * I;
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj)
+      if (in[jj]) st4<float>(gwr + 4 * (lane + 64 * jj), gw[ol][jj]);
+  }
+  part = wave_sum(part);
+  if (lane == 0) a.corr[l][unit] = part;
+}
+
+// units of layer l: ceil(O / 4) row groups x ceil(B / V4_BC) sample chunks, one WAVE each (four per block)
+__global__ __launch_bounds__(PB) void mod_prep_all_bwd_v4_kernel(PrepAllB a_by_value) {
+  const PrepAllB& a = kernarg_view(a_by_value);
+  int local;
+  const int l = find_layer(a, blockIdx.x, local);
+  const int nog = (a.O[l] + V4_OG - 1) / V4_OG, nbc = (a.B + V4_BC - 1) / V4_BC;
+  const int unit = local * 4 + (threadIdx.x >> 6);
+  if (unit >= nog * nbc) return;
+  const int og = unit % nog, bc = unit / nog;
+  switch ((a.I[l] + 255) >> 8) {
+    case 1: prep_bwd_v4<1>(a, l, og, bc, unit); break;
+    case 2: prep_bwd_v4<2>(a, l, og, bc, unit); break;
+    case 3: prep_bwd_v4<3>(a, l, og, bc, unit); break;
+    default: prep_bwd_v4<4>(a, l, og, bc, unit); break;
+  }
+}
+
+// gs[b, :] = sum over the row groups' partials (+ the max-norm term of s' = s / smax on demodulating layers): one block
+// per (layer, sample); I <= 1024: one float4 chunk per thread
+__global__ __launch_bounds__(PB) void mod_prep_all_s_fix_v4_kernel(PrepAllB a_by_value) {
+  const PrepAllB& a = kernarg_view(a_by_value);
+  __shared__ float red[4];
+  int b;
+  const int l = find_layer(a, blockIdx.x, b);
+  const int I = a.I[l], O = a.O[l], nog = (O + V4_OG - 1) / V4_OG;
+  const bool demod = a.flags[l] & 1;
+  const int i = threadIdx.x * 4;
+  const bool in = i < I;
+  float4 acc = f4(0.f);
+  if (in) {
+    const float* p = a.gtp[l] + (int64_t)b * I + i;
+    const int64_t step = (int64_t)a.B * I;
+    float4 a0 = f4(0.f), a1 = f4(0.f), a2 = f4(0.f), a3 = f4(0.f);
+    int g = 0;
+    for (; g + 3 < nog; g += 4) {
+      a0 = a0 + ld4(p + (g + 0) * step);
+      a1 = a1 + ld4(p + (g + 1) * step);
+      a2 = a2 + ld4(p + (g + 2) * step);
+      a3 = a3 + ld4(p + (g + 3) * step);
+    }
+    for (; g < nog; ++g) a0 = a0 + ld4(p + g * step);
+    acc = (a0 + a1) + (a2 + a3);
+  }
+  float* gs = a.out[l] + (size_t)O * I + (int64_t)b * I;
+  if (!demod) {
+    if (in) st4<float>(gs + i, acc);
+    return;
+  }
+  const float smax = a.stats[(size_t)l * (2 + 2 * a.B) + 2 + 2 * b];
+  const float4 sv = in ? ld4(a.s[l] + (int64_t)b * I + i) : f4(0.f);
+  float dot = hsum(acc * sv);
+  dot = block_sum(dot, red);
+  if (in) {
+    const float k = dot / (smax * smax);
+    float4 v = make_float4(acc.x / smax, acc.y / smax, acc.z / smax, acc.w / smax);
+    if (fabsf(sv.x) == smax) v.x -= (sv.x > 0.f ? 1.f : -1.f) * k;
+    if (fabsf(sv.y) == smax) v.y -= (sv.y > 0.f ? 1.f : -1.f) * k;
+    if (fabsf(sv.z) == smax) v.z -= (sv.z > 0.f ? 1.f : -1.f) * k;
+    if (fabsf(sv.w) == smax) v.w -= (sv.w > 0.f ? 1.f : -1.f) * k;
+    st4<float>(gs + i, v);
+  }
+}
+
+// gW = (sum over the sample chunks' partials) * k, minus the max-norm term of W' = W / wmax on demodulating layers
+__global__ __launch_bounds__(256) void mod_prep_all_w_fix_v4_kernel(PrepAllB a_by_value, int blocks_per_layer_cap) {
+  const PrepAllB& a = kernarg_view(a_by_value);
+  __shared__ float red[4];
+  int local;
+  const int l = find_layer(a, blockIdx.x, local);
+  const int O = a.O[l], I = a.I[l], OI = O * I;
+  const bool demod = a.flags[l] & 1;
+  const int nbc = (a.B + V4_BC - 1) / V4_BC, nog = (O + V4_OG - 1) / V4_OG;
+  const int nblk = (l ? a.blk_end[l] - a.blk_end[l - 1] : a.blk_end[0]);
+  const float* stats = a.stats + (size_t)l * (2 + 2 * a.B);
+  const float wmax = demod ? stats[0] : 1.f;
+  const float k = demod ? 1.f / wmax : rsqrtf((float)I);
+  float csum = 0.f;
+  if (demod) {
+    const int nc = nog * nbc;
+    for (int t = threadIdx.x; t < nc; t += 256) csum += a.corr[l][t];
+    csum = block_sum(csum, red);
+  }
+  float* gW = a.out[l];
+  const float* W = a.W[l];
+  const float* p = a.gwp[l];
+  for (int i = (local * 256 + threadIdx.x) * 4; i < OI; i += nblk * 1024) {
+    float4 v = ld4(p + i);
+    for (int c = 1; c < nbc; ++c) v = v + ld4(p + (int64_t)c * OI + i);
+    v = v * k;
+    if (demod) {
+      const float4 w = ld4(W + i);
+      const float f = csum / wmax;
+      if (fabsf(w.x) == wmax) v.x -= (w.x > 0.f ? 1.f : -1.f) * f;
+      if (fabsf(w.y) == wmax) v.y -= (w.y > 0.f ? 1.f : -1.f) * f;
+      if (fabsf(w.z) == wmax) v.z -= (w.z > 0.f ? 1.f : -1.f) * f;
+      if (fabsf(w.w) == wmax) v.w -= (w.w > 0.f ? 1.f : -1.f) * f;
+    }
+    st4<float>(gW + i, v);
+  }
+  (void)blocks_per_layer_cap;
+}
+
 bool geom_ok(int B, int O, int I, int Otot, int row_off, int cin, int F) {
   return B > 0 && O > 0 && I > 0 && I <= PB * MAXJ && Otot >= row_off + O && row_off >= 0 &&
          (F == 0 || (F == PB && cin >= 0 && cin + 2 * F <= I));
@@ -670,6 +1038,35 @@ extern "C" int dgv2_mod_prep_bwd(float* gW, float* gs, float* corr, const float*
 // with flags[l] & 2 (rotation of the PE columns [cin, cin + 512) by shift[b], shift NULL = no rotation).
 // The prepared weights do NOT contain 1/(sqrt(ema_var)+1e-8): pass that factor as row_scale to the GEMM.
 // ------------------------------------------------------------------------------------------------
+// the V4 kernels' conditions: whole float4 chunks per row, rotation pairs chunk-aligned; DGV2_NO_PREP_V4: A/B switch
+static bool v4_ok(const int* I, const int* cin, const int* flags, int L, bool rotating) {
+  static const bool off = getenv("DGV2_NO_PREP_V4") != nullptr;
+  if (off) return false;
+  for (int l = 0; l < L; ++l)
+    if ((I[l] & 3) || (rotating && (flags[l] & 2) && (cin[l] & 3))) return false;
+  return true;
+}
+
+// fp32 scratch of the V4 backward per layer: gt partials [ceil(O/4)][B][I], gW partials [ceil(B/8)][O][I], one slot per unit
+static int64_t v4_bwd_scratch(int O, int I, int B, int64_t* gtp = nullptr, int64_t* gwp = nullptr) {
+  const int64_t nog = (O + V4_OG - 1) / V4_OG, nbc = (B + V4_BC - 1) / V4_BC;
+  const int64_t n_gt = nog * B * I, n_gw = nbc * O * I, n_c = (nog * nbc + 3) / 4 * 4;
+  if (gtp) *gtp = 0;
+  if (gwp) *gwp = n_gt;
+  return n_gt + n_gw + n_c;
+}
+
+extern "C" int dgv2_mod_prep_all_bwd_scratch(int64_t* elems, const int* O, const int* I, int B, int L) {
+  if (!elems || !O || !I || B < 1 || L < 1 || L > MPA_MAX) return DGV2_EINVAL;
+  int64_t n = 0;
+  for (int l = 0; l < L; ++l) {
+    if (O[l] < 1 || I[l] < 1) return DGV2_EINVAL;
+    n += v4_bwd_scratch(O[l], I[l], B);
+  }
+  *elems = n;
+  return 0;
+}
+
 static int fill_common(PrepAll& a, const float* const* W, const float* const* s, const float* const* fw, const int* O,
                        const int* I, const int* Otot, const int* row_off, const int* cin, const int* flags, int B, int L) {
   if (!W || !s || !fw || !O || !I || !Otot || !row_off || !cin || !flags || B < 1 || L < 1 || L > MPA_MAX) return DGV2_EINVAL;
@@ -713,6 +1110,16 @@ extern "C" int dgv2_mod_prep_all_fwd(void* const* wb, float* const* dsave, float
     mod_stats_all_kernel<<<nstat, PB, 0, st>>>(a);
   }
   int nblk = 0;
+  bool al = true;
+  for (int l = 0; l < L && al; ++l) al = aligned16(wb[l]) && aligned16(W[l]) && aligned16(s[l]);
+  if (al && aligned16(rot) && v4_ok(I, cin, flags, L, shift != nullptr)) {
+    for (int l = 0; l < L; ++l) {
+      nblk += ((O[l] + 3) / 4) * ((B + V4_BC - 1) / V4_BC);   // four rows (waves) x V4_BC samples per block
+      a.blk_end[l] = nblk;
+    }
+    mod_prep_all_fwd_v4_kernel<<<nblk, PB, 0, st>>>(a);
+    DGV2_RETURN_LAST();
+  }
   for (int l = 0; l < L; ++l) {
     nblk += (O[l] * B + 3) / 4;   // one wave per row
     a.blk_end[l] = nblk;
@@ -729,12 +1136,52 @@ extern "C" int dgv2_mod_prep_all_bwd(float* flat, int64_t flat_elems, float* con
                                      const float* stats, const float* rot, float* const* dsave,
                                      const float* const* fw, const int* O, const int* I, const int* Otot,
                                      const int* row_off, const int* cin, const int* flags, const float* shift, int B,
-                                     int L, void* stream) {
+                                     int L, float* scratch, int64_t scratch_elems, void* stream) {
   PrepAll a;
   if (!flat || flat_elems < 1 || !out || !ncorr || !G || !stats || !dsave || !rot) return DGV2_EINVAL;
   int rc = fill_common(a, W, s, fw, O, I, Otot, row_off, cin, flags, B, L);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  int64_t need = 0;
+  for (int l = 0; l < L; ++l) need += v4_bwd_scratch(O[l], I[l], B);
+  bool al = true;
+  for (int l = 0; l < L && al; ++l)
+    al = out[l] && G[l] && aligned16(out[l]) && aligned16(G[l]) && aligned16(W[l]) && aligned16(s[l]);
+  if (al && scratch && scratch_elems >= need && aligned16(scratch) && v4_ok(I, cin, flags, L, shift != nullptr)) {
+    // V4: partial sums in scratch, folded by the fix-up kernels -- no atomics, nothing to clear
+    PrepAllB q;
+    int64_t off = 0;
+    int n1 = 0;
+    for (int l = 0; l < L; ++l) {
+      if (!out[l] || !G[l] || !dsave[l]) return DGV2_EINVAL;
+      if (out[l] < flat || out[l] + (size_t)O[l] * I[l] + (size_t)B * I[l] > flat + flat_elems) return DGV2_EINVAL;
+      int64_t o_gt, o_gw;
+      const int64_t n = v4_bwd_scratch(O[l], I[l], B, &o_gt, &o_gw);
+      const int64_t nog = (O[l] + V4_OG - 1) / V4_OG, nbc = (B + V4_BC - 1) / V4_BC;
+      q.W[l] = W[l]; q.s[l] = s[l]; q.G[l] = G[l]; q.dsave[l] = dsave[l]; q.out[l] = out[l];
+      q.gtp[l] = scratch + off + o_gt; q.gwp[l] = scratch + off + o_gw; q.corr[l] = scratch + off + n - (nog * nbc + 3) / 4 * 4;
+      q.O[l] = O[l]; q.I[l] = I[l]; q.Otot[l] = Otot[l]; q.row_off[l] = row_off[l]; q.cin[l] = cin[l]; q.flags[l] = flags[l];
+      off += n;
+      n1 += (int)((nog * nbc + 3) / 4);
+      q.blk_end[l] = n1;
+    }
+    for (int l = L; l < MPA_MAX; ++l) q.blk_end[l] = 0x7fffffff;
+    q.stats = stats; q.rot = rot; q.shift = shift; q.B = B; q.L = L;
+    mod_prep_all_bwd_v4_kernel<<<n1, PB, 0, st>>>(q);
+    int n2 = 0;
+    for (int l = 0; l < L; ++l) {
+      n2 += B;
+      q.blk_end[l] = n2;
+    }
+    mod_prep_all_s_fix_v4_kernel<<<n2, PB, 0, st>>>(q);
+    int n3 = 0;
+    for (int l = 0; l < L; ++l) {
+      n3 += grid_for(((int64_t)O[l] * I[l] + 1023) / 1024, 1, 64);
+      q.blk_end[l] = n3;
+    }
+    mod_prep_all_w_fix_v4_kernel<<<n3, 256, 0, st>>>(q, 64);
+    DGV2_RETURN_LAST();
+  }
   a.stats = const_cast<float*>(stats); a.shift = shift; a.rot = const_cast<float*>(rot);
   int cls[MPA_MAX], nb[MPA_MAX];
   for (int l = 0; l < L; ++l) {

@@ -100,9 +100,11 @@ SIGNATURES = {
     "dgv2_bmm_nn_small_act": [_c_ptr] * 4 + [_c_int] * 4 + [_c_ptr, _c_ptr, _c_f32, _c_f32, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_int,
                               _c_ptr],
     "dgv2_bmm_tn_small": [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr],
+    "dgv2_head_bwd": [_c_ptr] * 5 + [_c_i64] + [_c_ptr] * 7 + [_c_f32, _c_f32] + [_c_int] * 5 + [_c_ptr],
     "dgv2_transpose_list": [_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr],
     "dgv2_mod_prep_all_fwd": [_c_ptr] * 13 + [_c_ptr, _c_int, _c_int, _c_ptr],
-    "dgv2_mod_prep_all_bwd": [_c_ptr, _c_i64] + [_c_ptr] * 15 + [_c_ptr, _c_int, _c_int, _c_ptr],
+    "dgv2_mod_prep_all_bwd": [_c_ptr, _c_i64] + [_c_ptr] * 15 + [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr],
+    "dgv2_mod_prep_all_bwd_scratch": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int],
     "dgv2_mod_prep_fwd": [_c_ptr] * 8 + [_c_int] * 9 + [_c_ptr],
     "dgv2_mod_prep_bwd": [_c_ptr] * 11 + [_c_int] * 9 + [_c_ptr],
     "dgv2_sum_squares": [_c_ptr, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_ptr],
@@ -117,6 +119,7 @@ SIGNATURES = {
     "dgv2_bmm_tn_stream_scratch": [_c_ptr] + [_c_int] * 6,
     "dgv2_bmm_tn_stream": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 6 + [_c_ptr],
     "dgv2_bmm_tn_stream_x": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 7 + [_c_ptr],
+    "dgv2_bmm_tn_stream_ld": [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr] + [_c_int] * 7 + [_c_ptr],
     "dgv2_conv_weight_bank": [_c_ptr] * 8 + [_c_int, _c_int, _c_ptr],
     "dgv2_conv_weight_bank_ex": [_c_ptr] * 10 + [_c_int, _c_int, _c_ptr],
     "dgv2_glin_fwd": [_c_ptr] * 6 + [_c_int] * 3 + [_c_f32, _c_f32, _c_int, _c_f32, _c_int, _c_ptr, _c_ptr],

@@ -300,10 +300,11 @@ class AdaptiveAugment(torch.nn.Module):
         return Cm[:, :3].sum(dim=1).contiguous(), Cm[:, 3].contiguous()
 
     # ------------------------------------------------------------------ forward
-    def forward(self, img, draws=None):
+    def forward(self, img, draws=None, out=None):
         """img [B,1,H,W] -> augmented [B,1,H,W] (fp32).  `draws` optionally injects
         {"G": [B,3,3], "C": [B,4,4]} (parity tests) or the RAW draws {"u": [B,16] uniform, "n": [B,8] normal} of the
-        fused sampler (the step bodies make every draw of a body in one launch); otherwise they are sampled on the device."""
+        fused sampler (the step bodies make every draw of a body in one launch); otherwise they are sampled on the device.
+        `out` (no-grad callers): the fp32 tensor to write into (one half of a stacked batch)."""
         B, ch, H, W = img.shape
         if ch != 1:
             raise NotImplementedError("ADA on this path handles 1-channel range images")
@@ -319,7 +320,7 @@ class AdaptiveAugment(torch.nn.Module):
                 gaff = torch.stack([G[:, 0, 0], G[:, 0, 2], G[:, 1, 1], G[:, 1, 2]], dim=1).contiguous()
                 a, c = self.collapse_color(draws["C"].to(dev).float())
             Ay, kx, off, sgn = native.ada_build(gaff, M1y, M1x, taps, H, W, KTAPS)
-        return native.ada_apply(img.float(), Ay, kx, off, sgn, a, c)
+        return native.ada_apply(img.float(), Ay, kx, off, sgn, a, c, out=out)
 
     def policy_vector(self):
         m = self.mul

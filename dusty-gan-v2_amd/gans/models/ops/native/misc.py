@@ -395,9 +395,19 @@ class _ModUpPrepared(Function):
                 if wt is None:
                     wt = wb[:, :, :Ka].transpose(1, 2).contiguous()
                 gh = _bmm_nn_raw(gt3, wt, h.dtype).reshape(h.shape)
-            if need_w:
+            Ks = xs.shape[3]
+            stream_a = _TN_STREAM and Ka % 8 == 0 and Otot % 8 == 0 and hl * wl >= 2048
+            if need_w and stream_a and (Ka + Ks) % 4 == 0 and Ka % 4 == 0:
+                # both column ranges of the [B, Otot, Ka + Ks] gradient written in place by their engines (the PE columns
+                # at full resolution, the activation columns at the low one): no concatenation pass
+                gwb = torch.empty((B, Otot, Ka + Ks), device=dev, dtype=torch.float32)
+                if pe_wgrad(g3, xs.reshape(H * W_, -1), out=gwb, col0=Ka) is not None:
+                    _bmm_tn_stream(gt3, h, B, hl, wl, Ka, Otot, out=gwb)
+                else:
+                    gwb = None
+            if need_w and gwb is None:
                 h3 = h.reshape(B, hl * wl, Ka)
-                if _TN_STREAM and Ka % 8 == 0 and Otot % 8 == 0 and hl * wl >= 2048:
+                if stream_a:
                     gwa = _bmm_tn_stream(gt3, h, B, hl, wl, Ka, Otot)
                 else:
                     gwa = torch.empty((B, Otot, Ka), device=dev, dtype=torch.float32)

@@ -22,17 +22,19 @@ from .stem_tail_ada import *  # noqa: F401,F403
 # act-grad, data gradient, weight gradient, preparation backward (dgv2_mod_prep_bwd).
 # reference: ModConv2d.forward + FusedLeakyReLU, gans/models/ops/style.py:68-126, dusty_v2.py:161-170
 # ---------------------------------------------------------------------------------------
-def _bmm_tn_stream(g3, xa, B, H, W_, I, O, shared=False):
+def _bmm_tn_stream(g3, xa, B, H, W_, I, O, shared=False, out=None):
     """gw fp32 [B,O,I] = per-sample sum over pixels of gy [B,H*W,O] x xa [B,H,W,I] (dgv2_bmm_tn_stream); shared: xa is
-    one image [1,H,W,I] contracted against every sample (the positional encoding)."""
+    one image [1,H,W,I] contracted against every sample (the positional encoding).  out: a [B,O,ld] fp32 tensor
+    (ld >= I) whose first I columns receive the result in place (dgv2_bmm_tn_stream_ld)."""
     key = (B, H, W_, I, O)
     if key not in _TN_SCRATCH:
         n = _ct.c_int64(0)
         N.call("dgv2_bmm_tn_stream_scratch", _ct.addressof(n), B, H, W_, I, O, _dt(xa))
         _TN_SCRATCH[key] = n.value
-    gw = torch.empty((B, O, I), device=xa.device, dtype=torch.float32)
+    gw = torch.empty((B, O, I), device=xa.device, dtype=torch.float32) if out is None else out
+    ld = 0 if out is None else int(out.shape[2])
     scratch = torch.empty(_TN_SCRATCH[key], device=xa.device, dtype=torch.float32)
-    N.call("dgv2_bmm_tn_stream_x", N.ptr(gw), N.ptr(scratch), scratch.numel(), N.ptr(g3), N.ptr(xa), int(shared), B, H,
+    N.call("dgv2_bmm_tn_stream_ld", N.ptr(gw), ld, N.ptr(scratch), scratch.numel(), N.ptr(g3), N.ptr(xa), int(shared), B, H,
            W_, I, O, _dt(xa), N.stream())
     return gw
 
@@ -267,7 +269,7 @@ class _ModPrepAll(Function):
         for m in lay:
             nc = min(m["O"] * B, 8192)
             ncorr.append(nc)
-            sizes.append(m["O"] * m["I"] + B * m["I"] + nc)
+            sizes.append((m["O"] * m["I"] + B * m["I"] + nc + 3) // 4 * 4)   # 16-byte aligned slices (float4 kernels)
         flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
         outs, off = [], 0
         for n in sizes:
@@ -277,10 +279,18 @@ class _ModPrepAll(Function):
         for m in lay:
             dsaves.append(dflat[off:off + B * m["O"]])
             off += B * m["O"]
+        # scratch of the atomic-free form (dgv2.h): per-unit partial sums, folded by the fix-up kernels
+        key = ("prep_all_bwd", tuple((m["O"], m["I"]) for m in lay), B)
+        if key not in _TN_SCRATCH:
+            n = _ct.c_int64(0)
+            N.call("dgv2_mod_prep_all_bwd_scratch", _ct.addressof(n), ints["O"], ints["I"], B, L)
+            _TN_SCRATCH[key] = n.value
+        scratch = torch.empty(_TN_SCRATCH[key], device=dev, dtype=torch.float32)
         N.call("dgv2_mod_prep_all_bwd", N.ptr(flat), flat.numel(), _ptr_array(outs), _int_array(ncorr),
                _ptr_array([Gs[m["group"]] for m in lay]), _ptr_array(list(Ws)), _ptr_array(list(Ss)), N.ptr(stats),
                N.ptr(rot_tab), _ptr_array(dsaves), _ptr_array([m["fw"] for m in lay]), ints["O"], ints["I"], ints["Otot"],
-               ints["row_off"], ints["cin"], ints["flags"], N.ptr(shift) if ctx.rot else None, B, L, N.stream())
+               ints["row_off"], ints["cin"], ints["flags"], N.ptr(shift) if ctx.rot else None, B, L, N.ptr(scratch),
+               scratch.numel(), N.stream())
         res = []
         for m, o in zip(lay, outs):
             OI, BI = m["O"] * m["I"], B * m["I"]
@@ -358,6 +368,14 @@ class _ModGemmPrepared(Function):
         B, Otot, I = wb.shape
         dt = wb.dtype
         gy = gy.contiguous()
+        if (not cfg["act"] and cfg["fork"] and cfg.get("upstream") is not None and xs is None and xa is not None
+                and wt is not None and not torch.is_grad_enabled() and ctx.needs_input_grad[1] and ctx.needs_input_grad[4]):
+            # the output heads of a level: data gradient + the upstream layer's activation backward, the heads' weight and
+            # bias gradients in ONE pass over the heads' input (dgv2_head_bwd)
+            fused = _head_bwd_fused(gy, cvec, wt, g_sib, xa, cfg["upstream"])
+            if fused is not None:
+                gxa, gwb, gbh = fused
+                return None, gxa, None, (gbh if cfg["has_bias"] else None), gwb, None, None, None
         H, W_ = gy.shape[1:3]
         P = H * W_
         dev = gy.device
@@ -428,9 +446,10 @@ _PE_WGRAD = os.environ.get("DGV2_NO_PE_WGRAD") is None   # A/B switch for benchm
 _PE_WGRAD_MINP = int(os.environ.get("DGV2_PE_WGRAD_MINP", "2048"))
 
 
-def pe_wgrad(g3, xs):
+def pe_wgrad(g3, xs, out=None, col0=0):
     """gw fp32 [B, O, Ks] = g3^T pe per sample on dgv2_pe_wgrad (several samples share a staged PE tile); None where the
-    shape is outside the kernel's range."""
+    shape is outside the kernel's range.  out [B, O, ld] fp32, col0: write the columns [col0, col0 + Ks) of the caller's
+    wider gradient in place."""
     B, P, O = g3.shape
     Ks = xs.shape[-1]
     # measured (B = 64, Ks = 512; scripts/mb_pewgrad2.py): P = 32768, O = 32: 113 us against the library's 243;
@@ -442,10 +461,14 @@ def pe_wgrad(g3, xs):
         return None
     g3 = g3.contiguous()
     xs = xs.contiguous()
-    out = torch.empty((B, O, Ks), device=g3.device, dtype=torch.float32)
+    ld = Ks if out is None else int(out.shape[2])
+    if ld % 4 or col0 % 4 or ld < col0 + Ks:
+        return None
+    if out is None:
+        out = torch.empty((B, O, Ks), device=g3.device, dtype=torch.float32)
     scratch = torch.empty(n.value, device=g3.device, dtype=torch.float32)
     N.check(g3, xs)
-    N.call("dgv2_pe_wgrad", N.ptr(out), N.ptr(scratch), n.value, N.ptr(g3), N.ptr(xs), B, P, O, Ks, Ks, 0, N.stream())
+    N.call("dgv2_pe_wgrad", N.ptr(out), N.ptr(scratch), n.value, N.ptr(g3), N.ptr(xs), B, P, O, Ks, ld, int(col0), N.stream())
     return out
 
 
@@ -453,6 +476,13 @@ def _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt):
     """gwb fp32 [B,Otot,I] = per-sample g3^T [xa | xs] (the engine choice of _ModLayer.backward)."""
     P = H * W_
     Ka = 0 if xa is None else xa.shape[3]
+    if (xs is not None and xa is not None and _LIB_WGRAD and dt == torch.bfloat16 and P >= 2048 and _TN_STREAM and Ka % 8 == 0
+            and Otot % 8 == 0 and I % 4 == 0 and Ka % 4 == 0):
+        # both column ranges of the [B, Otot, Ka + Ks] gradient written in place by their engines: no concatenation
+        gwb = torch.empty((B, Otot, I), device=g3.device, dtype=torch.float32)
+        if pe_wgrad(g3, xs.reshape(P, -1), out=gwb, col0=Ka) is not None:
+            _bmm_tn_stream(g3, xa, B, H, W_, Ka, Otot, out=gwb)
+            return gwb
     if xs is not None and _LIB_WGRAD and dt == torch.bfloat16 and P >= 2048:
         gT = g3.transpose(1, 2)
         parts = []
@@ -517,5 +547,42 @@ def _head_dgrad_actbwd(g3, wt, resid, xa, up):
     up["link"]["done"] = True
     up["link"]["gb"] = gb
     return y
+
+_HEAD_BWD = os.environ.get("DGV2_NO_HEAD_BWD") is None   # A/B switch for benchmarking
+
+
+def _head_bwd_fused(gy, cvec, wt, resid, xa, up):
+    """dgv2_head_bwd (see include/dgv2.h): gy fp32 [B,H,W,O] -> (gxa like xa, gwb fp32 [B,O,K], gbh fp32 [O]); marks the
+    upstream link like _head_dgrad_actbwd.  None where the kernel does not apply."""
+    B, Ka, Otot = wt.shape
+    P = gy.numel() // (B * Otot)
+    if (not (_HEAD_BWD and _HEAD_ACTBWD) or Otot > 4 or gy.dtype != torch.float32 or wt.dtype != xa.dtype
+            or xa.dtype not in (torch.float32, torch.bfloat16)):
+        return None
+    key = ("head_bwd", B, P, Otot, Ka, _dt(xa))
+    if key not in _HEAD_ACT_BLOCKS:
+        nb = _ct.c_int64(0)
+        ok = N.try_call("dgv2_head_bwd", None, None, None, None, None, 0, _ct.addressof(nb), None, None, None, None, None,
+                        None, 1.0, 1.0, B, P, Otot, Ka, _dt(xa), N.stream())
+        _HEAD_ACT_BLOCKS[key] = nb.value if ok else 0
+    nblk = _HEAD_ACT_BLOCKS[key]
+    if nblk == 0:
+        return None
+    r = None if resid is None else resid.contiguous().to(xa.dtype)
+    xr = xa.contiguous()
+    y = torch.empty_like(xr)
+    gwb = torch.empty((B, Otot, Ka), device=xa.device, dtype=torch.float32)
+    gbh = torch.empty(Otot, device=xa.device, dtype=torch.float32)
+    gb_up = torch.empty(Ka, device=xa.device, dtype=torch.float32)
+    scratch = torch.empty(nblk * (Ka + Otot * Ka + Otot), device=xa.device, dtype=torch.float32)
+    N.check(gy, cvec, wt, r, xr, up["cvec"])
+    if not N.try_call("dgv2_head_bwd", N.ptr(y), N.ptr(gwb), N.ptr(gbh), N.ptr(gb_up), N.ptr(scratch), scratch.numel(), None,
+                      N.ptr(gy), N.ptr(cvec), N.ptr(wt), N.ptr(r), N.ptr(xr), N.ptr(up["cvec"]), up["alpha"], up["scale"],
+                      B, P, Otot, Ka, _dt(xa), N.stream()):
+        return None
+    up["link"]["done"] = True
+    up["link"]["gb"] = gb_up
+    return y, gwb, gbh
+
 
 __all__ = [n_ for n_ in dir() if not n_.startswith("__")]

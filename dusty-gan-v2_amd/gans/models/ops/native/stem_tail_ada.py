@@ -121,11 +121,13 @@ def gumbel_uniform(shape, device):
 # ---------------------------------------------------------------------------------------
 class _AdaApply(Function):
     @staticmethod
-    def forward(ctx, x, Ay, kx, off, sgn, a, c, transpose):
+    def forward(ctx, x, Ay, kx, off, sgn, a, c, transpose, out=None):
         x = x.contiguous().float()
         B, _, H, W = x.shape
-        N.check(x, Ay, kx, off, sgn, a, c)
-        y = torch.empty_like(x)
+        N.check(x, Ay, kx, off, sgn, a, c, out)
+        if out is not None and (out.shape != x.shape or out.dtype != torch.float32):
+            raise ValueError("ada_apply: `out` must be a contiguous fp32 tensor shaped like the input")
+        y = torch.empty_like(x) if out is None else out
         N.call("dgv2_ada_apply", N.ptr(y), N.ptr(x), N.ptr(Ay), N.ptr(kx), N.ptr(off), N.ptr(sgn), N.ptr(a),
                N.ptr(c), B, H, W, kx.shape[1], int(transpose), N.stream())
         ctx.save_for_backward(Ay, kx, off, sgn, a, c)
@@ -137,11 +139,15 @@ class _AdaApply(Function):
         Ay, kx, off, sgn, a, _ = ctx.saved_tensors
         # derivative of an affine map: the offset c never appears in (double) backward
         gx = _AdaApply.apply(g, Ay, kx, off, sgn, a, None, not ctx.transpose)
-        return gx, None, None, None, None, None, None, None
+        return gx, None, None, None, None, None, None, None, None
 
 
-def ada_apply(x, Ay, kx, off, sgn, a, c):
-    return _AdaApply.apply(x, Ay, kx, off, sgn, a, c, False)
+def ada_apply(x, Ay, kx, off, sgn, a, c, out=None):
+    """out: write the result into this (contiguous, fp32) tensor -- e.g. one half of the stacked real / fake batch the
+    discriminator step feeds to D in one pass; gradient-free callers only."""
+    if out is not None and torch.is_grad_enabled() and x.requires_grad:
+        raise RuntimeError("ada_apply(out=...) is for passes that record no graph")
+    return _AdaApply.apply(x, Ay, kx, off, sgn, a, c, False, out)
 
 
 def ada_sample(B, H, W, p, policy, device, u=None, n=None):

@@ -378,11 +378,13 @@ class Trainer:
         z = self._z("d")
         with torch.no_grad():
             x_fake = self.G(z, noise=self._g_noise("d"), **self.auxin)["image"]
-            x_real_aug = self.A(self.warmup(x_real, self._draw("d.keep_real")), draws=self._ada("d.ada_real"))
-            x_fake_aug = self.A(self.warmup(x_fake, self._draw("d.keep_fake")), draws=self._ada("d.ada_fake"))
+            # both augmented halves are written straight into the stacked batch (no concatenation pass)
+            x_both = torch.empty((2 * self.B,) + tuple(x_real.shape[1:]), device=self.device, dtype=torch.float32)
+            self.A(self.warmup(x_real, self._draw("d.keep_real")), draws=self._ada("d.ada_real"), out=x_both[:self.B])
+            self.A(self.warmup(x_fake, self._draw("d.keep_fake")), draws=self._ada("d.ada_fake"), out=x_both[self.B:])
         # D(real) and D(fake) in ONE pass over the discriminator (minibatch-stddev per half), instead of
         # the reference's two calls (trainer.py:391-392): same result, half the launches / weight reads
-        y = self.D(torch.cat([x_real_aug, x_fake_aug], dim=0), splits=2, **({"cut": True} if cut else {}))
+        y = self.D(x_both, splits=2, **({"cut": True} if cut else {}))
         y_real, y_fake = y[:self.B], y[self.B:]
         if self.adversarial_loss.can_fuse(y):
             # objective, its weighted gradient, both output means and ADA's sign statistic from one launch

@@ -305,6 +305,19 @@ int dgv2_bmm_nn_small(void* y, const void* x, const void* w, const void* resid, 
 int dgv2_bmm_nn_small_act(void* y, const void* x, const void* w, const void* resid, int B, int P, int O, int K,
                           const void* ref, const float* row_scale, float alpha, float ascale, float* gb,
                           float* scratch, int64_t scratch_elems, int64_t* blocks_needed, int dtype, void* stream);
+/* The whole backward of a level's output heads in ONE streaming pass + one reduce launch (round 5): the heads' input
+ * x = ref [B,P,K] is read once (operand of the head weight gradient AND reference of the upstream layer's activation
+ * backward), the skip gradient gyf fp32 [B,P,O] once:
+ *   g = T(gyf * cvec[o]);  y = ((g . w[b]^T) + resid) * (ref > 0 ? 1 : alpha) * ascale * row_scale[k]  (as _small_act);
+ *   gb_up[k] = column sums of the unscaled rounded y;  gw[b,o,k] = sum_p g[p,o] ref[p,k];  gbh[o] = sum gyf[.,o].
+ * replaces: the autograd of the two ModConv2d heads of a SynthesisBlock (gans/models/dusty_v2.py:30-57,171-178 on
+ *   gans/models/ops/style.py:105-118) and of the FusedLeakyReLU in front of them (fused_act.py:22-45) -- five launches per
+ *   level here before (column sum, scale + cast, dgv2_bmm_nn_small_act, dgv2_bmm_tn_small, reducers / zero fills).
+ * scratch: fp32 [>= *blocks_needed * (K + O*K + O)]; y == NULL with blocks_needed: query.  DGV2_ENOTSUP as _small_act. */
+int dgv2_head_bwd(void* y, float* gw, float* gbh, float* gb_up, float* scratch, int64_t scratch_elems,
+                  int64_t* blocks_needed, const float* gyf, const float* cvec, const void* w, const void* resid,
+                  const void* ref, const float* row_scale, float alpha, float ascale, int B, int P, int O, int K, int dtype,
+                  void* stream);
 
 /* The same contraction as dgv2_bmm_nn_cat, organised for the two top pyramid levels where it dominates
  * the generator ((Ka, Ks, O) = (64, 512, 32) and, as two 32-channel slabs, (128, 512, 64); bf16): a block owns a tile of pixels and walks the
@@ -383,7 +396,13 @@ int dgv2_mod_prep_all_bwd(float* flat, int64_t flat_elems, float* const* out, co
                           const float* stats, const float* rot, float* const* dsave,
                           const float* const* fw, const int* O, const int* I, const int* Otot,
                           const int* row_off, const int* cin, const int* flags, const float* shift, int B,
-                          int L, void* stream);
+                          int L, float* scratch, int64_t scratch_elems, void* stream);
+/* scratch (fp32, 16-byte aligned, >= dgv2_mod_prep_all_bwd_scratch elements): the backward then keeps its sums over a
+ * unit's samples in registers and leaves per-unit partials there, which its two fix-up kernels fold -- no atomics,
+ * nothing cleared, bit-identical from run to run (needs I % 4 == 0 and cin % 4 == 0 on rotating layers; NULL or any
+ * other shape: the atomic form on `flat`, which this entry clears).  The forward takes the matching float4 form under
+ * the same shape conditions by itself. */
+int dgv2_mod_prep_all_bwd_scratch(int64_t* elems, const int* O, const int* I, int B, int L);
 
 /* Batched transposes in one launch: dst[l][b, c, r] = src[l][b, r, c] (r < rows[l], c < cols[l], source leading
  * dimension ld[l]); HOST arrays of L <= 32 device pointers, elem_size 2 or 4 bytes.  Produces the operands of all
@@ -477,6 +496,10 @@ int dgv2_bmm_tn_stream(float* gw, float* scratch, int64_t scratch_elems, const v
  * batch-shared positional-encoding columns, gw[b,o,c] = sum_p gy[b,p,o] * pe[p,c]. */
 int dgv2_bmm_tn_stream_x(float* gw, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
                          int x_shared, int B, int H, int W, int C, int O, int dtype, void* stream);
+/* ... with a row pitch: gw is [B, O, ldo] (ldo >= C, ldo % 4 == 0; 0 = contiguous), the columns [0, C) of the layer's
+ * whole [B, O, Ka + Ks] weight gradient written in place next to the PE columns of dgv2_pe_wgrad -- no concatenation. */
+int dgv2_bmm_tn_stream_ld(float* gw, int64_t ldo, float* scratch, int64_t scratch_elems, const void* gy, const void* x,
+                          int x_shared, int B, int H, int W, int C, int O, int dtype, void* stream);
 
 /* Compute-dtype copies of all conv weights of the discriminator in ONE launch (L <= 32): from each fp32
  * master [O,C,kh,kw] (EqualLR runtime scale folded in: common.py:158-184) the forward layout

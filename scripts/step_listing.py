@@ -3,10 +3,12 @@ of bench.py or scripts/prof_plain.py): which kernels one G body / D body / R1 bo
 duration averaged over the replays of that body.  The bodies are cut at the fused Adam launches (the G optimizer's is
 the short one, D's the long one; a D body that directly follows a D body is the lazy-R1 pass) and only the bodies with
 the modal launch count of their kind are averaged (the graph replays; eager warm-up bodies differ).
-usage: python scripts/step_listing.py <kernel_trace.csv> [--full] [--kernel REGEX]
+usage: python scripts/step_listing.py <kernel_trace.csv> [--full] [--kernel REGEX] [--json OUT]
   default: per-body totals, bucket table per plain iteration (G + D body) and launch counts
   --full:  every launch of the three bodies (index, avg us, grid, workgroup, name)
-  --kernel REGEX: per-launch durations (every replay) of the launches whose name matches, grouped by grid"""
+  --kernel REGEX: per-launch durations (every replay) of the launches whose name matches, grouped by grid
+  --json OUT: the (kernel, grid) instances of a TRAINING iteration (G body + D body + R1 body / 16) with their time, share
+              and launch count, largest first, stamped with the hash of the HIP sources (bench.py ranks `roofline` by it)"""
 import collections
 import csv
 import re
@@ -123,6 +125,31 @@ def main():
             print(f"\n## body {kind}")
             for j, (l, a) in enumerate(zip(bs[0], avg)):
                 print(f"{j:4d} {a:9.1f} us  grid {str(l[3]):22s} wg {l[4][0]:4d}  {bucket(l[2]):14s} {l[2][:120]}")
+    if "--json" in sys.argv:
+        import hashlib
+        import glob
+        import json
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        h = hashlib.sha256()
+        for f in sorted(glob.glob(os.path.join(root, "dusty-gan-v2_amd", "csrc", "*.hip")) +
+                        glob.glob(os.path.join(root, "dusty-gan-v2_amd", "csrc", "*.h"))):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+        inst = collections.defaultdict(lambda: [0.0, 0.0])
+        weight = {"g": 1.0, "d": 1.0, "r1": 1.0 / 16.0}
+        for kind, (bs, avg, _) in summary.items():
+            for l, a in zip(bs[0], avg):
+                inst[(l[2], l[3])][0] += a * weight[kind]
+                inst[(l[2], l[3])][1] += weight[kind]
+        tot = sum(v[0] for v in inst.values())
+        out = {"src_sha16": h.hexdigest()[:16], "source": os.path.basename(path),
+               "us_per_training_iteration": tot, "launches_per_training_iteration": sum(v[1] for v in inst.values()),
+               "bodies": {k: {"launches": len(v[1]), "kernel_us": sum(v[1]), "span_us": v[2], "replays": len(v[0])}
+                          for k, v in summary.items()},
+               "instances": [{"name": n, "grid": list(g), "us": v[0], "launches": v[1], "pct": 100 * v[0] / tot}
+                             for (n, g), v in sorted(inst.items(), key=lambda kv: -kv[1][0])]}
+        json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=0)
     if pat:
         print(f"\n## launches matching /{pat}/ in the averaged bodies (every replay)")
         groups = collections.defaultdict(list)

@@ -1773,3 +1773,98 @@ def test_fir_mfma_flags_tables_outside_its_windows(nat):
     # 32 x 64 outputs of a 64 x 128 decimation presented as a same-size problem: row ho reads inputs 2 ho - 1 ...
     assert prep(nat.ResampleSpec([1, 3, 3, 1], down=(2, 2)), 64, 128, 32, 64) == N.STATUS_FIR_TABLE
     assert N.status_read() == 0
+
+
+# ---------------------------------------------------------------------------------------
+# round 5: one-launch RNG of a step body (rng.hip) and the objective's cotangent without a scalar-loss graph
+def test_rng_fill_distributions_stream_and_graph_replay(nat):
+    """dgv2_rng_fill: the three kinds have the moments / ranges they claim, segments are independent, the stream state
+    advances on the device (same seed -> same numbers, next launch -> different numbers), and a captured launch draws
+    fresh numbers on every replay."""
+    eps = float(torch.finfo(torch.float32).eps)
+    nat.rng_state(DEV, seed=1234)
+    specs = [((64, 512), nat.RNG_NORMAL, 0.0, 1.0), ((64,), nat.RNG_UNIFORM, 0.0, 2 * np.pi),
+             ((8, 1, 64, 512), nat.RNG_CLAMPED, eps, 1 - eps), ((64, 16), nat.RNG_UNIFORM, 0.0, 1.0),
+             ((64, 8), nat.RNG_NORMAL, 0.0, 1.0), ((7,), nat.RNG_NORMAL, 3.0, 0.5)]
+    a = [t.clone() for t in nat.rng_fill(specs, DEV)]
+    st = nat.rng_state(DEV).cpu()
+    groups = sum((int(np.prod(s[0])) + 3) // 4 for s in specs)
+    assert int(st[1]) == groups and int(st[2]) == 0            # offset advanced by the launch itself, ticket back at 0
+    z, sh, u, au, an, odd = a
+    assert [tuple(t.shape) for t in a] == [s[0] for s in specs]
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1) < 0.02
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.15                                   # kurtosis of a normal
+    assert float(sh.min()) >= 0 and float(sh.max()) < 2 * np.pi
+    assert float(u.min()) >= eps and float(u.max()) <= 1 - eps
+    assert abs(float(u.mean()) - 0.5) < 2e-3 and abs(float(u.var()) - 1 / 12) < 1e-3
+    assert float(au.min()) >= 0 and float(au.max()) < 1
+    assert abs(float(odd.mean()) - 3.0) < 1.0
+    # no correlation between neighbouring values / segments
+    zf = z.flatten()
+    assert abs(float((zf[:-1] * zf[1:]).mean())) < 0.02
+    assert abs(float((z.flatten()[:512] * an.flatten()).mean())) < 0.2
+    b = nat.rng_fill(specs, DEV)
+    assert not torch.equal(a[0], b[0]) and not torch.equal(a[2], b[2])                # the stream moved on
+    nat.rng_state(DEV, seed=1234)
+    c = nat.rng_fill(specs, DEV)
+    assert all(torch.equal(x, y) for x, y in zip(a, c))                               # same seed, same offset: same numbers
+    nat.rng_state(DEV, seed=1235)
+    d = nat.rng_fill(specs, DEV)
+    assert not torch.equal(a[0], d[0])
+    # captured: fresh numbers on every replay
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = nat.rng_fill(specs[:2], DEV)
+    g.replay()
+    first = out[0].clone()
+    g.replay()
+    assert not torch.equal(first, out[0])
+    assert abs(float(out[0].std()) - 1) < 0.02
+
+
+def test_nsgan_step_cotangent_and_ada_cumulate(nat):
+    """native.nsgan_step: gy = weight * d loss / d y (what (weight * loss).backward() would push into y) and ADA's running
+    statistic updated in the same launch."""
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(11)
+    for n_real, n_fake in ((64, 64), (5, 3), (8, 0)):
+        y = (torch.randn(n_real + n_fake, 1, generator=g) * 3).to(DEV)
+        sc, nc = torch.full((1,), 2.0, device=DEV), torch.full((1,), 5.0, device=DEV)
+        stats, gy = nat.nsgan_step(y, n_real, 0.7, cum=(sc, nc))
+        yr = y.cpu().double().requires_grad_(True)
+        want = F.softplus(-yr[:n_real]).mean() + (F.softplus(yr[n_real:]).mean() if n_fake else 0.0)
+        (gw,) = torch.autograd.grad(want * 0.7, yr)
+        assert gy.shape == y.shape
+        assert abs(float(stats[0]) - float(want)) < 1e-5 * abs(float(want)) + 1e-7
+        assert_rel(gy.cpu(), gw, 1e-5, "weight * d loss / d y")
+        assert float(sc) == 2.0 + float(yr[:n_real].sign().sum()) and float(nc) == 5.0 + n_real
+
+
+@pytest.mark.parametrize("dtype,B,P,K,O,res", [(torch.bfloat16, 3, 2048, 32, 2, True), (torch.bfloat16, 2, 640, 256, 2, False),
+                                               (torch.float32, 2, 512, 64, 2, True), (torch.bfloat16, 2, 300, 64, 1, True)])
+def test_head_backward_in_one_pass(nat, dtype, B, P, K, O, res):
+    """dgv2_head_bwd: data gradient of the output heads + the upstream layer's activation backward + the heads' weight and
+    bias gradients from one pass over the heads' input, against the same quantities in float64."""
+    from gans.models.ops.native import modlayer as ml
+    g = torch.Generator().manual_seed(P + K)
+    gy = torch.randn(B, 1, P, O, generator=g).to(DEV)
+    cvec = (torch.rand(O, generator=g) + 0.5).to(DEV)
+    wt = (torch.randn(B, K, O, generator=g) / 4).to(dtype).to(DEV)
+    xa = torch.randn(B, 1, P, K, generator=g).to(dtype).to(DEV)
+    resid = torch.randn(B, P, K, generator=g).to(dtype).to(DEV) if res else None
+    up_c = (torch.rand(K, generator=g) + 0.5).to(DEV)
+    link = {}
+    up = dict(link=link, alpha=0.2, scale=2.0 ** 0.5, cvec=up_c)
+    out = ml._head_bwd_fused(gy, cvec, wt, resid, xa, up)
+    assert out is not None and link.get("done") is True
+    y, gw, gbh = out
+    gq = (gy.reshape(B, P, O) * cvec).to(dtype).double()
+    s = torch.einsum("bpo,bko->bpk", gq, wt.double()) + (resid.double() if res else 0.0)
+    x64 = xa.reshape(B, P, K).double()
+    v = torch.where(x64 > 0, s, s * 0.2) * 2.0 ** 0.5
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
+    assert_rel(y.reshape(B, P, K).double().cpu(), (v * up_c.double()).cpu(), tol, "y")
+    assert_rel(link["gb"].double().cpu(), v.to(dtype).double().sum((0, 1)).cpu(), 5e-3 if dtype == torch.bfloat16 else 1e-4, "gb_up")
+    assert_rel(gw.double().cpu(), torch.einsum("bpo,bpk->bok", gq, x64).cpu(), 1e-4, "head weight gradient")
+    assert_rel(gbh.double().cpu(), gy.double().sum((0, 1, 2)).cpu(), 1e-4, "head bias gradient")
