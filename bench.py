@@ -337,8 +337,8 @@ def modconv_probe(args, reps=20, shape=(32, 256, 64, 32), brief=False):
     bias = torch.randn(O, device="cuda")
     cvec = torch.ones(O, device="cuda")
     y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
-    t = torch.empty(B, hl, 2, wl // 8, 16, 8, device="cuda", dtype=bf)
-    wimg = torch.empty(B, Ks // 32, 2, 4, 16, 8, device="cuda", dtype=bf)
+    t = torch.empty(B, hl, O // 16, wl // 8, 16, 8, device="cuda", dtype=bf)            # (native.mod_up_prepare's layouts)
+    wimg = torch.empty(B, O // 32, Ks // 32, 2, 4, 16, 8, device="cuda", dtype=bf)
 
     def lowres():
         N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), 2.0 ** 0.5 * 0.6, B, hl, wl, Ka, Ks, O, Ka + Ks, Ka, N.BF16, N.stream())
@@ -543,6 +543,9 @@ def main():
     graphs_live = trainer.graphs_live()
     extra["graphs_live"] = graphs_live
     extra["overlap_d_reduce"] = bool(getattr(trainer, "split_d", False))   # D's backward in two graphs, head reduced under the tail
+    if dist_on:   # the gradient reductions replayed as hipGraphs on a side stream (parallel.FlatGradSync.all_reduce_captured)
+        extra["captured_collectives"] = {"G": {str(k): v for k, v in trainer.g_sync.captured().items()},
+                                         "D": {str(k): v for k, v in trainer.d_sync.captured().items()}}
     if cfg.training.hip_graph and not (graphs_live and all(graphs_live.values())):
         msg = f"a step body is not replaying as a hipGraph: {graphs_live}"
         if world == 1:

@@ -39,6 +39,11 @@ struct MPGeom {
   float alpha, scale;
   float* sumsq;   // optional: one partial sum of squares of the stored outputs per block
   const float* row_scale;   // optional fp32 [O]: y = act(acc * row_scale[o] + bias[o])
+  // HEAD instances: the two 1-channel output heads of the level read this layer's output -- their contraction
+  //   hd[b, p, j] = sum_o y[b, p, o] hw[b, j, o]   (j < 2, on the stored bf16 values, fp32 sum)
+  // leaves from this epilogue instead of a pass of its own over y (reference: Head.forward, dusty_v2.py:30-57,171-178)
+  const bf16_t* hw;   // [B, 2, O] the heads' prepared per-sample weights
+  float* hd;          // [B, P, 2]
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned mp_u32x4;
@@ -60,8 +65,32 @@ __device__ __forceinline__ void mp_issue_xa(mp_u32x4 (&dst)[NFW][KA > 0 ? KA : 1
   }
 }
 
+// head weights of one sample: per lane the 8 channels it will hold of each fragment pair after pack_pair_bf16, both heads
+template <int MF>
+__device__ __forceinline__ void mp_issue_hw(mp_u32x4 (&dst)[MF / 2][2], const bf16_t* __restrict__ hw, int b, int O, int lc) {
+  const int co = (lc & 1) ? 16 + 4 * (lc - 1) : 4 * lc;
+#pragma unroll
+  for (int pr = 0; pr < MF / 2; ++pr)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16_t* src = hw + ((int64_t)b * 2 + j) * O + pr * 32 + co;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[pr][j]) : "v"(src) : "memory");
+    }
+}
+
+__device__ __forceinline__ float dot8_bf16(const uint4& a, const mp_u32x4& b) {
+  const unsigned aw[4] = {a.x, a.y, a.z, a.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s = fmaf(__uint_as_float(aw[i] << 16), __uint_as_float(b[i] << 16), s);
+    s = fmaf(__uint_as_float(aw[i] & 0xffff0000u), __uint_as_float(b[i] & 0xffff0000u), s);
+  }
+  return s;
+}
+
 // MF = O / 16, NFW = 16-pixel fragments per wave, KA = Ka / 32, KS = Ks / 32 (compile-time: register arrays)
-template <int MF, int NFW, int KA, int KS>
+template <int MF, int NFW, int KA, int KS, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ xa,
                                                                 const bf16_t* __restrict__ xs,
                                                                 const bf16_t* __restrict__ w, MPGeom g) {
@@ -121,9 +150,11 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
       __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
     }
   };
+  u32x4 hwr[2][HEAD ? MF / 2 : 1][2];   // HEAD: head weights of samples b, b+1 (this lane's channels)
   auto issue_x = [&](auto slot, int b) {
     if constexpr (KA > 0)
       mp_issue_xa<NFW, KA>(xr[decltype(slot)::value], xa, min(b, b1 - 1), g.P, g.Ka, p0, lr, lc);   // tail: re-reads the last sample
+    if constexpr (HEAD) mp_issue_hw<MF>(hwr[decltype(slot)::value], g.hw, min(b, b1 - 1), O, lc);
   };
   const int aswz = lc ^ ((lr >> 2) & 3);
 
@@ -149,11 +180,17 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     // everything but the stores of the previous sample (the youngest operations) has retired: the weights and the xa
     // fragments of THIS sample have landed (first sample / partial tile: full drain)
     if (b == b0 || !full_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFW * (MF / 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFW * (MF / 2) + (HEAD ? NFW : 0)) : "memory");   // (+ the hd stores)
 #pragma unroll
     for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
       for (int kc = 0; kc < KA; ++kc) asm volatile("" : "+v"(xr[S][nf][kc]));
+    if constexpr (HEAD) {
+#pragma unroll
+      for (int pr = 0; pr < MF / 2; ++pr)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(hwr[S][pr][j]));
+    }
     __builtin_amdgcn_s_barrier();   // all pieces landed; every wave is done with the other buffer
     asm volatile("" ::: "memory");
     if (!(MP_ABL & 4)) dma_w(min(b + 1, b1 - 1), S ^ 1);
@@ -206,6 +243,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
       const int px = p0 + nf * 16 + lr;
       const bool live = px < g.P && !((MP_ABL & 1) && acc[0][0][0] != 12345.678f);
       bf16_t* row = y + ((int64_t)b * g.P + px) * g.O + o_base;
+      float hd0 = 0.f, hd1 = 0.f;
 #pragma unroll
       for (int mf = 0; mf < MF; mf += 2) {
         float va[4], vb[4];
@@ -227,6 +265,18 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
           *reinterpret_cast<uint4*>(row + mf * 16 + co) = pk;
           if (g.sumsq) ss += sumsq_bf16x8(pk);
         }
+        if constexpr (HEAD) {
+          hd0 += dot8_bf16(pk, hwr[S][mf / 2][0]);
+          hd1 += dot8_bf16(pk, hwr[S][mf / 2][1]);
+        }
+      }
+      if constexpr (HEAD) {
+        // the four lc lanes of a pixel hold disjoint channel sets: fold them (all lanes take part), lane lc == 0 stores
+        hd0 += __shfl_xor(hd0, 16, 64);
+        hd1 += __shfl_xor(hd1, 16, 64);
+        hd0 += __shfl_xor(hd0, 32, 64);
+        hd1 += __shfl_xor(hd1, 32, 64);
+        if (live && lc == 0) *reinterpret_cast<float2*>(g.hd + ((int64_t)b * g.P + px) * 2) = make_float2(hd0, hd1);
       }
     }
   };
@@ -252,6 +302,14 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
       for (int kc = 0; kc < KAR; ++kc) asm volatile("" : "+v"(xr[s2][nf][kc]));
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int pr = 0; pr < MF / 2; ++pr)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(hwr[s2][pr][j]));
+  }
   if (g.sumsq) {
     __shared__ float red[16];
     const float s = block_sum(ss, red);
@@ -259,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   }
 }
 
-template <int MF, int NFW, int KA, int KS>
+template <int MF, int NFW, int KA, int KS, bool HEAD = false>
 int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, hipStream_t st, int sumsq_cap,
               int* sumsq_used) {
   constexpr int TP = 8 * 16 * NFW;
@@ -283,7 +341,7 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
   if (g.sumsq && sumsq_used && tiles * nsplit * slabs <= sumsq_cap) *sumsq_used = tiles * nsplit * slabs;
   else g.sumsq = nullptr;
   constexpr size_t lds = sizeof(uint4) * 2 * (size_t)(((MF * 16) * (KA + KS) * 4 + 511) / 512 * 512);
-  auto kern = modconv_pe_fwd_kernel<MF, NFW, KA, KS>;
+  auto kern = modconv_pe_fwd_kernel<MF, NFW, KA, KS, HEAD>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -297,29 +355,42 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
 
 // Same contract as dgv2_bmm_nn_cat (bf16 in / bf16 out) for the shapes of the two top generator levels:
 // (Ka, Ks, O) = (64, 512, 32) (level-4 conv1) and, with Ks = 0 (xs unused), the PE-free shapes
-// (64,0,32), (32,0,64), (128,0,64), (64,0,128), (32,0,32), (64,0,64) = conv0 / conv2 of levels 4/3 and the data gradients.  Returns DGV2_EINVAL for anything else: callers fall back to
+// (64,0,32), (32,0,64), (128,0,64), (64,0,128), (32,0,32), (64,0,64), (128,0,128), (256,0,256), (256,0,128), (128,0,256) = conv0 /
+// conv2 of levels 4 ... 1 and the data gradients.  Returns DGV2_EINVAL for anything else: callers fall back to
 // dgv2_bmm_nn_cat.
 extern "C" int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
                                    int Ks, int O, const float* bias, int act, float alpha, float scale, int dtype,
                                    void* stream) {
-  return dgv2_modconv_pe_fwd_sq(y, xa, xs, w, B, P, Ka, Ks, O, nullptr, bias, act, alpha, scale, dtype, nullptr, 0, nullptr,
-                                stream);
+  return dgv2_modconv_pe_fwd_head(y, xa, xs, w, B, P, Ka, Ks, O, nullptr, bias, act, alpha, scale, dtype, nullptr, 0, nullptr,
+                                  nullptr, nullptr, stream);
 }
 
 extern "C" int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
                                       int Ks, int O, const float* row_scale, const float* bias, int act, float alpha,
-                                      float scale, int dtype, float* sumsq, int sumsq_cap, int* sumsq_used,
-                                      void* stream) {
+                                      float scale, int dtype, float* sumsq, int sumsq_cap, int* sumsq_used, void* stream) {
+  return dgv2_modconv_pe_fwd_head(y, xa, xs, w, B, P, Ka, Ks, O, row_scale, bias, act, alpha, scale, dtype, sumsq, sumsq_cap,
+                                  sumsq_used, nullptr, nullptr, stream);
+}
+
+extern "C" int dgv2_modconv_pe_fwd_head(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka,
+                                        int Ks, int O, const float* row_scale, const float* bias, int act, float alpha,
+                                        float scale, int dtype, float* sumsq, int sumsq_cap, int* sumsq_used,
+                                        const void* head_w, float* head_out, void* stream) {
   if (sumsq_used) *sumsq_used = 0;
+  if ((!head_w) != (!head_out)) return DGV2_EINVAL;
+  // head_w [B, 2, O] / head_out fp32 [B, P, 2]: the contraction of the level's two output heads on this layer's output,
+  // from this epilogue (PE-free one-slab shapes (32, 32) and (64, 64): conv2 of levels 4 / 3; DGV2_ENOTSUP otherwise)
+  if (head_w && !(Ks == 0 && ((Ka == 32 && O == 32) || (Ka == 64 && O == 64)) && aligned16(head_w) && aligned16(head_out)))
+    return DGV2_ENOTSUP;
   if (!y || !w || (Ks > 0 && !xs) || (Ka > 0 && !xa) || B <= 0 || P <= 0) return DGV2_EINVAL;
   if (dtype != DGV2_BF16 || (act != 0 && act != 3)) return DGV2_EINVAL;
   if (!aligned16(y) || !aligned16(xa) || !aligned16(xs) || !aligned16(w)) return DGV2_EINVAL;
   if (Ks == 0) xs = xa;   // never dereferenced (KS = 0), keeps the pointer arithmetic defined
 #ifdef DGV2_ABLATE
   static const int abl = getenv("DGV2_MP_ABLATE") ? atoi(getenv("DGV2_MP_ABLATE")) : 0;
-  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, abl, bias, act, alpha, scale, sumsq, row_scale};
+  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, abl, bias, act, alpha, scale, sumsq, row_scale, (const bf16_t*)head_w, head_out};
 #else
-  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, bias, act, alpha, scale, sumsq, row_scale};
+  MPGeom g{B, P, Ka, Ks, O, Ka + Ks, 1, bias, act, alpha, scale, sumsq, row_scale, (const bf16_t*)head_w, head_out};
 #endif
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -332,6 +403,14 @@ extern "C" int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, c
   else if (Ks == 0 && Ka == 32 && O == 64) rc = mp_launch<4, 2, 1, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   else if (Ks == 0 && Ka == 128 && O == 64) rc = mp_launch<4, 2, 4, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   else if (Ks == 0 && Ka == 64 && O == 128) rc = mp_launch<8, 2, 2, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  // conv2 of level 2 (and its data gradient): one 128-pixel tile per block keeps acc + two xa slots within 128 VGPRs
+  else if (Ks == 0 && Ka == 128 && O == 128) rc = mp_launch<8, 1, 4, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  // conv2 of level 1: two slabs of 128 output channels (a slab's weights: 64 KB per buffer)
+  else if (Ks == 0 && Ka == 256 && O == 256) rc = mp_launch<8, 1, 8, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ks == 0 && Ka == 256 && O == 128) rc = mp_launch<8, 1, 8, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ks == 0 && Ka == 128 && O == 256) rc = mp_launch<8, 1, 4, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ks == 0 && Ka == 32 && O == 32 && head_w) rc = mp_launch<2, 2, 1, 0, true>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
+  else if (Ks == 0 && Ka == 64 && O == 64 && head_w) rc = mp_launch<4, 2, 2, 0, true>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   else if (Ks == 0 && Ka == 32 && O == 32) rc = mp_launch<2, 2, 1, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   else if (Ks == 0 && Ka == 64 && O == 64) rc = mp_launch<4, 2, 2, 0>(y, xa, xs, w, g, st, sumsq_cap, sumsq_used);
   else return DGV2_EINVAL;

@@ -673,50 +673,58 @@ __device__ __forceinline__ void prep_bwd_v4(const PrepAllB& a, int l, int og, in
       gw[ol][jj] = f4(0.f);
     }
   float part = 0.f;
-  const int nog = (O + V4_OG - 1) / V4_OG;
-  for (int bi = 0; bi < nb; ++bi) {
-    const int b = b0 + bi;
+  // this lane's sin chunk (one at most) of a rotating layer
+  int jsin = -1;
+  if (rotate) {
+#pragma unroll
+    for (int jj = 0; jj + 1 < JJ; ++jj) {
+      const int q = lane + 64 * jj;
+      if (q >= cin4 && q < cin4 + 64) jsin = jj;
+    }
+  }
+  const int f0 = 4 * min(max(lane + 64 * max(jsin, 0) - cin4, 0), 63);
+  // One step = one sample: t, the four rows' gradients (rows past O: a clamped re-read against zero weights), their
+  // demodulation factors and the rotation factors.  The NEXT step's operands are requested before this step's
+  // arithmetic (one wave per SIMD at this register count: nothing else would hide the memory latency), and the four
+  // rows' reductions run as interleaved butterflies.
+  struct Step {
+    float4 t[JJ], gp[V4_OG][JJ], sd, cd;
+    float dv[V4_OG];
+  };
+  auto load_step = [&](Step& st, int b) {
     const float inv_smax = demod ? 1.f / stats[2 + 2 * b] : 1.f;
     const float* sr = a.s[l] + (int64_t)b * I;
-    float4 t[JJ], gt[JJ];
 #pragma unroll
-    for (int jj = 0; jj < JJ; ++jj) {
-      t[jj] = in[jj] ? ld4(sr + 4 * (lane + 64 * jj)) * inv_smax + f4(1.f) : f4(0.f);
-      gt[jj] = f4(0.f);
-    }
-    // this lane's rotation factors (one sin chunk per lane at most)
-    float4 sd = f4(0.f), cd = f4(1.f);
-    int jsin = -1;
-    if (rotate) {
-#pragma unroll
-      for (int jj = 0; jj + 1 < JJ; ++jj) {
-        const int q = lane + 64 * jj;
-        if (q >= cin4 && q < cin4 + 64) jsin = jj;
-      }
-      const int qs = lane + 64 * max(jsin, 0);
-      rot4(a.rot + ((size_t)l * a.B + b) * PB * 2, 4 * min(max(qs - cin4, 0), 63), sd, cd);
-    }
-    // the four rows' gradients are requested together (rows past O: a clamped re-read against zero weights), so that
-    // one memory latency covers them; their reductions are independent
-    float4 gp[V4_OG][JJ];
+    for (int jj = 0; jj < JJ; ++jj) st.t[jj] = in[jj] ? ld4(sr + 4 * (lane + 64 * jj)) * inv_smax + f4(1.f) : f4(0.f);
 #pragma unroll
     for (int ol = 0; ol < V4_OG; ++ol) {
-      const float* Gr = a.G[l] + ((int64_t)b * Otot + row_off + min(o0 + ol, O - 1)) * I;
+      const int oc = min(o0 + ol, O - 1);
+      const float* Gr = a.G[l] + ((int64_t)b * Otot + row_off + oc) * I;
 #pragma unroll
-      for (int jj = 0; jj < JJ; ++jj) gp[ol][jj] = in[jj] ? ld4(Gr + 4 * (lane + 64 * jj)) : f4(0.f);
+      for (int jj = 0; jj < JJ; ++jj) st.gp[ol][jj] = in[jj] ? ld4(Gr + 4 * (lane + 64 * jj)) : f4(0.f);
+      st.dv[ol] = demod ? a.dsave[l][(int64_t)b * O + oc] : 1.f;
     }
-    float dv[V4_OG];
+    st.sd = f4(0.f);
+    st.cd = f4(1.f);
+    if (rotate) rot4(a.rot + ((size_t)l * a.B + b) * PB * 2, f0, st.sd, st.cd);
+  };
+  Step cur, nxt;
+  load_step(cur, b0);
+  for (int bi = 0; bi < nb; ++bi) {
+    const int b = b0 + bi;
+    load_step(nxt, min(b + 1, b0 + nb - 1));   // (the last step re-reads itself: no branch around the loads)
+    float4 gt[JJ];
 #pragma unroll
-    for (int ol = 0; ol < V4_OG; ++ol) dv[ol] = demod ? a.dsave[l][(int64_t)b * O + min(o0 + ol, O - 1)] : 1.f;
+    for (int jj = 0; jj < JJ; ++jj) gt[jj] = f4(0.f);
     if (rotate) {   // transpose of the rotation
 #pragma unroll
       for (int ol = 0; ol < V4_OG; ++ol)
 #pragma unroll
         for (int jj = 0; jj + 1 < JJ; ++jj) {
-          const float4 gs = gp[ol][jj], gc = gp[ol][jj + 1];
+          const float4 gs = cur.gp[ol][jj], gc = cur.gp[ol][jj + 1];
           if (jj == jsin) {
-            gp[ol][jj] = gs * cd + gc * sd;
-            gp[ol][jj + 1] = gc * cd - gs * sd;
+            cur.gp[ol][jj] = gs * cur.cd + gc * cur.sd;
+            cur.gp[ol][jj + 1] = gc * cur.cd - gs * cur.sd;
           }
         }
     }
@@ -726,7 +734,7 @@ __device__ __forceinline__ void prep_bwd_v4(const PrepAllB& a, int l, int og, in
       r[ol] = 0.f;
       if (demod) {
 #pragma unroll
-        for (int jj = 0; jj < JJ; ++jj) r[ol] += hsum(gp[ol][jj] * (wp[ol][jj] * t[jj]));
+        for (int jj = 0; jj < JJ; ++jj) r[ol] += hsum(cur.gp[ol][jj] * (wp[ol][jj] * cur.t[jj]));
       }
     }
     if (demod) {   // four interleaved butterflies
@@ -738,11 +746,11 @@ __device__ __forceinline__ void prep_bwd_v4(const PrepAllB& a, int l, int og, in
 #pragma unroll
     for (int ol = 0; ol < V4_OG; ++ol) {
       const float live = ol < no ? 1.f : 0.f;   // rows past O contribute nothing (their wp is zero; gm must be too)
-      const float d = dv[ol], d2r = d * d * r[ol];
+      const float d = cur.dv[ol], d2r = d * d * r[ol];
 #pragma unroll
       for (int jj = 0; jj < JJ; ++jj) {
-        const float4 gm = demod ? (gp[ol][jj] - (wp[ol][jj] * t[jj]) * d2r) * (d * live) : gp[ol][jj] * live;
-        const float4 gwv = gm * t[jj];
+        const float4 gm = demod ? (cur.gp[ol][jj] - (wp[ol][jj] * cur.t[jj]) * d2r) * (d * live) : cur.gp[ol][jj] * live;
+        const float4 gwv = gm * cur.t[jj];
         gw[ol][jj] = gw[ol][jj] + gwv;
         gt[jj] = gt[jj] + gm * wp[ol][jj];
         part += hsum(gwv * wp[ol][jj]);
@@ -752,8 +760,8 @@ __device__ __forceinline__ void prep_bwd_v4(const PrepAllB& a, int l, int og, in
 #pragma unroll
     for (int jj = 0; jj < JJ; ++jj)
       if (in[jj]) st4<float>(gtr + 4 * (lane + 64 * jj), gt[jj]);
+    cur = nxt;
   }
-  (void)nog;
 #pragma unroll
   for (int ol = 0; ol < V4_OG; ++ol) {
     if (ol >= no) break;

@@ -187,8 +187,15 @@ __global__ __launch_bounds__(256) void resample_tab_smallc_kernel(
     T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ idx_h, const float* __restrict__ coef_h,
     const int* __restrict__ cnt_h, int Eh, const int* __restrict__ idx_w, const float* __restrict__ coef_w,
     const int* __restrict__ cnt_w, int Ew, int B, int in_h, int in_w, int out_h, int out_w,
-    const T* __restrict__ resid = nullptr) {
+    const T* __restrict__ resid = nullptr, const float* __restrict__ rscale = nullptr,
+    const float* __restrict__ rbias = nullptr) {
   struct alignas(sizeof(T) * CC) Px { T e[CC]; };
+  float rs[CC], rb[CC];   // dgv2_resample_tab_add_affine: resid enters as rscale[c] * resid + rbias[c]
+#pragma unroll
+  for (int j = 0; j < CC; ++j) {
+    rs[j] = rscale ? rscale[j] : 1.f;
+    rb[j] = rbias ? rbias[j] : 0.f;
+  }
   const int64_t total = (int64_t)B * out_h * out_w;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int wo = (int)(t % out_w);
@@ -214,7 +221,10 @@ __global__ __launch_bounds__(256) void resample_tab_smallc_kernel(
     if (resid) {   // y = resid + resample(x): the running image of the generator's skip pyramid (dusty_v2.py:179-180)
       const Px rv = reinterpret_cast<const Px*>(resid)[t];
 #pragma unroll
-      for (int j = 0; j < CC; ++j) o.e[j] = from_f32<T>(to_f32(rv.e[j]) + to_f32(from_f32<T>(acc[j])));
+      for (int j = 0; j < CC; ++j) {
+        const float rj = rscale ? to_f32(from_f32<T>(fmaf(to_f32(rv.e[j]), rs[j], rb[j]))) : to_f32(rv.e[j]);
+        o.e[j] = from_f32<T>(rj + to_f32(from_f32<T>(acc[j])));
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < CC; ++j) o.e[j] = from_f32<T>(acc[j]);
@@ -553,6 +563,18 @@ extern "C" int dgv2_resample_tab_add(void* y, const void* x, const void* resid, 
                                      const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w,
                                      int Ew, int B, int C, int in_h, int in_w, int out_h, int out_w, int dtype,
                                      void* stream) {
+  return dgv2_resample_tab_add_affine(y, x, resid, nullptr, nullptr, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, C,
+                                      in_h, in_w, out_h, out_w, dtype, stream);
+}
+
+// ... with resid entering as rscale[c] * resid + rbias[c] (fp32 [C] each, both or neither): the level's head output
+// c * (heads' contraction) + bias formed in the same store that adds the up-sampled running image, when the contraction
+// itself came out of conv2's epilogue (dgv2_modconv_pe_fwd_head).
+extern "C" int dgv2_resample_tab_add_affine(void* y, const void* x, const void* resid, const float* rscale,
+                                            const float* rbias, const int* idx_h, const float* coef_h, const int* cnt_h,
+                                            int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew, int B,
+                                            int C, int in_h, int in_w, int out_h, int out_w, int dtype, void* stream) {
+  if ((!rscale) != (!rbias)) return DGV2_EINVAL;
   if (!y || !x || !resid || !idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w) return DGV2_EINVAL;
   if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || Eh <= 0 || Ew <= 0) return DGV2_EINVAL;
   if (!(C == 1 || C == 2 || C == 4)) return DGV2_ENOTSUP;
@@ -562,9 +584,9 @@ extern "C" int dgv2_resample_tab_add(void* y, const void* x, const void* resid, 
     if (reinterpret_cast<uintptr_t>(x) % al || reinterpret_cast<uintptr_t>(y) % al || reinterpret_cast<uintptr_t>(resid) % al)
       return DGV2_ENOTSUP;
     const int g2 = grid_for((int64_t)B * out_h * out_w, 256, 256 * 64);
-    if (C == 1) resample_tab_smallc_kernel<T, 1><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w, (const T*)resid);
-    else if (C == 2) resample_tab_smallc_kernel<T, 2><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w, (const T*)resid);
-    else resample_tab_smallc_kernel<T, 4><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w, (const T*)resid);
+    if (C == 1) resample_tab_smallc_kernel<T, 1><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w, (const T*)resid, rscale, rbias);
+    else if (C == 2) resample_tab_smallc_kernel<T, 2><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w, (const T*)resid, rscale, rbias);
+    else resample_tab_smallc_kernel<T, 4><<<g2, 256, 0, st>>>((T*)y, (const T*)x, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, B, in_h, in_w, out_h, out_w, (const T*)resid, rscale, rbias);
   });
   DGV2_RETURN_LAST();
 }

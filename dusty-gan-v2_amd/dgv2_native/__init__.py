@@ -45,6 +45,7 @@ SIGNATURES = {
     "dgv2_resample": [_c_ptr] * 4 + [_c_int] * 19 + [_c_ptr],
     "dgv2_resample_tab": [_c_ptr] * 5 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 10 + [_c_ptr],
     "dgv2_resample_tab_add": [_c_ptr] * 6 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 8 + [_c_ptr],
+    "dgv2_resample_tab_add_affine": [_c_ptr] * 8 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 8 + [_c_ptr],
     "dgv2_fourier_feature": [_c_ptr] * 5 + [_c_int] * 8 + [_c_ptr],
     "dgv2_downsample_angle": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr],
     "dgv2_bmm_nn": [_c_ptr] * 3 + [_c_int] * 6 + [_c_i64, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_int, _c_ptr],
@@ -57,6 +58,8 @@ SIGNATURES = {
     "dgv2_modconv_pe_fwd": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_modconv_pe_fwd_sq": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                                _c_ptr],
+    "dgv2_modconv_pe_fwd_head": [_c_ptr] * 4 + [_c_int] * 5 + [_c_ptr, _c_ptr, _c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
+                                 _c_ptr, _c_ptr, _c_ptr],
     "dgv2_kitti_rows": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr],
     "dgv2_kitti_project": [_c_ptr] * 4 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_fps_scratch": [_c_ptr, _c_int, _c_int],

@@ -88,9 +88,20 @@ class Head(nn.Module):
             self.heads[o["name"]] = ops.ModConv2d(out_ch=o["ch"], in_ch=in_ch, mod_ch=mod_ch, ksize=1, stride=1,
                                                   padding=0, demod=False, ema=True)
 
-    def forward_cl(self, x, style, sumsq=None, fork=False, upstream=None):
+    def fused_weights(self):
+        """The heads' prepared per-sample weights [B, 2, C] (bf16) when the producer of their input can take their
+        contraction in its own epilogue (two 1-channel heads on the batched-preparation path), else None."""
+        heads = list(self.heads.values())
+        if len(heads) != 2 or any(h.out_ch != 1 for h in heads) or heads[0]._prep is None:
+            return None
+        wb = heads[0]._prep[1]
+        return wb if (wb.dtype == LOW and wb.shape[1] == 2) else None
+
+    def forward_cl(self, x, style, sumsq=None, fork=False, upstream=None, pre_d=None, affine_out=None):
         """x [B,H,W,C] -> fp32 [B,H,W,sum(ch)] (heads concatenated in dict order); sumsq = partial sums of
-        squares of x when its producer already took them."""
+        squares of x when its producer already took them; pre_d: the heads' contraction, when the producer of x took it.
+        affine_out (a dict, with pre_d): leave `cvec * pre_d + bias` to the caller's next store (native.resample_add with
+        rscale / rbias): the dict receives "scale" and "bias", the returned tensor is the bare contraction."""
         if sumsq is None and self.training:
             sumsq = native.sum_squares(x)
         heads = list(self.heads.values())
@@ -115,8 +126,11 @@ class Head(nn.Module):
                     off += head.out_ch
             # fork: also return x for the NEXT consumer (the following block), so that both gradients of x meet in
             # this layer's data-gradient GEMM
+            later = affine_out is not None and pre_d is not None and pre_d.numel() > 0
+            if later:
+                affine_out["scale"], affine_out["bias"] = cvec, bias
             return native.mod_gemm_layer(x, None, handle, wb, cvec, bias=bias, act=False, out_dtype=torch.float32, wt=wt,
-                                         fork=fork, upstream=upstream)
+                                         fork=fork, upstream=upstream, pre_d=pre_d, defer_affine=later)
         mods = [head.prep_args(style, sumsq, x.numel()) for head in heads]
         return native.mod_layer(x, None, mods, bias=bias, act=False, out_dtype=torch.float32)
 
@@ -278,6 +292,7 @@ class SynthesisBlock(nn.Module):
             h = self.conv1.forward_cl(x1, ws[0], act=self.bias_act1)
         nxt = 1
         sq_h = None
+        pre_d = None
         if isinstance(h, tuple):   # (activation, partial sums of squares) from the producing kernel
             h, sq_h = h
         if not self.is_first:
@@ -286,8 +301,12 @@ class SynthesisBlock(nn.Module):
             if self.conv2._prep is not None:
                 handle, wb, cvec, wt = self.conv2._prep
                 self.conv2.update_ema(sumsq, h.numel(), 0.0, cvec)
+                hw = self.head.fused_weights()
                 h = native.mod_gemm_layer(h, None, handle, wb, cvec, bias=a2.bias, act=True, alpha=a2.negative_slope,
-                                          scale=a2.scale, want_sq=self.head.training, wt=wt, defer=link)
+                                          scale=a2.scale, want_sq=self.head.training, wt=wt, defer=link, head_w=hw)
+                if hw is not None:   # the heads' contraction left conv2's epilogue (levels 4 / 3; empty where it did not)
+                    pre_d = h[-1]
+                    h = h[0] if len(h) == 2 else h[:-1]
                 up = dict(link=link, alpha=float(a2.negative_slope), scale=float(a2.scale), cvec=cvec)
             else:
                 h = native.mod_layer(h, None, [self.conv2.prep_args(ws[1], sumsq, h.numel())], bias=a2.bias,
@@ -296,11 +315,12 @@ class SynthesisBlock(nn.Module):
             if isinstance(h, tuple):
                 h, sq_h = h
             nxt = 2
-        o = self.head.forward_cl(h, ws[nxt], sumsq=sq_h, fork=True, upstream=up)
+        aff = {} if (skip is not None and pre_d is not None) else None   # the heads' affine rides in the skip store below
+        o = self.head.forward_cl(h, ws[nxt], sumsq=sq_h, fork=True, upstream=up, pre_d=pre_d, affine_out=aff)
         if isinstance(o, tuple):
             o, h = o
         if skip is not None:   # o + up(skip) in the resampler's store (dusty_v2.py:179-180)
-            o = native.resample_add(skip, o, self.resample.spec)
+            o = native.resample_add(skip, o, self.resample.spec, **({"rscale": aff["scale"], "rbias": aff["bias"]} if aff else {}))
         return h, o
 
     def forward_composable(self, h, skip, ws, angle, shift, B):

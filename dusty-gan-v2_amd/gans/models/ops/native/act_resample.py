@@ -342,18 +342,22 @@ def resample(x, spec):
 
 
 class _ResampleAdd(Function):
-    """resid + resample(x) for packed few-channel images in the resampler's store (dgv2_resample_tab_add)."""
+    """resid + resample(x) for packed few-channel images in the resampler's store (dgv2_resample_tab_add).
+    rscale / rbias (fp32 [C], no gradient): resid enters as rscale * resid + rbias -- an affine map that BELONGS to the
+    producer of resid (the output heads, whose backward applies it), merely evaluated here: the gradient handed back for
+    resid is the gradient of the affine's OUTPUT."""
 
     @staticmethod
-    def forward(ctx, x, resid, spec):
+    def forward(ctx, x, resid, spec, rscale=None, rbias=None):
         x, resid = x.contiguous(), resid.contiguous()
-        N.check(x, resid)
+        N.check(x, resid, rscale, rbias)
         B, H, W, C = x.shape
         Ho, Wo = spec.out_size(H, W)
         (ih_idx, ih_coef, ih_cnt, Eh), (iw_idx, iw_coef, iw_cnt, Ew) = spec.tables(H, W, False, x.device)
         out = torch.empty((B, Ho, Wo, C), device=x.device, dtype=x.dtype)
-        N.call("dgv2_resample_tab_add", N.ptr(out), N.ptr(x), N.ptr(resid), N.ptr(ih_idx), N.ptr(ih_coef), N.ptr(ih_cnt),
-               Eh, N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew, B, C, H, W, Ho, Wo, _dt(x), N.stream())
+        N.call("dgv2_resample_tab_add_affine", N.ptr(out), N.ptr(x), N.ptr(resid), N.ptr(rscale), N.ptr(rbias), N.ptr(ih_idx),
+               N.ptr(ih_coef), N.ptr(ih_cnt), Eh, N.ptr(iw_idx), N.ptr(iw_coef), N.ptr(iw_cnt), Ew, B, C, H, W, Ho, Wo, _dt(x),
+               N.stream())
         ctx.cfg = (spec, (H, W))
         return out
 
@@ -361,16 +365,20 @@ class _ResampleAdd(Function):
     def backward(ctx, g):
         spec, in_hw = ctx.cfg
         gx = _Resample.apply(g, spec, True, in_hw) if ctx.needs_input_grad[0] else None
-        return gx, (g if ctx.needs_input_grad[1] else None), None
+        return gx, (g if ctx.needs_input_grad[1] else None), None, None, None
 
 
-def resample_add(x, resid, spec):
+def resample_add(x, resid, spec, rscale=None, rbias=None):
     """resid + resample(x), x [B,H,W,C] channels-last; one launch for the generator's packed 1 / 2 / 4-channel images
-    (same bits as the two-launch form), the composed form otherwise."""
+    (same bits as the two-launch form), the composed form otherwise.  rscale / rbias: see _ResampleAdd."""
     Ho, Wo = spec.out_size(x.shape[1], x.shape[2])
     if (x.shape[3] in (1, 2, 4) and x.dtype == resid.dtype and tuple(resid.shape) == (x.shape[0], Ho, Wo, x.shape[3])
             and x.dtype in (torch.float32, torch.bfloat16)):
-        return _ResampleAdd.apply(x, resid, spec)
+        if rscale is not None:
+            rscale, rbias = rscale.detach().float().contiguous(), rbias.detach().float().contiguous()
+        return _ResampleAdd.apply(x, resid, spec, rscale, rbias)
+    if rscale is not None:
+        raise RuntimeError("resample_add: the deferred head affine needs the packed few-channel kernel")
     return resid + resample(x, spec)
 
 

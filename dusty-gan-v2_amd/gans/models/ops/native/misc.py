@@ -430,17 +430,24 @@ def mod_up_layer(h, xs, spec, handle, wb, cvec, bias=None, act=True, alpha=0.2, 
 
 
 def mod_gemm_layer(xa, xs, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=None,
-                   want_sq=False, wt=None, fork=False, defer=None, upstream=None):
+                   want_sq=False, wt=None, fork=False, defer=None, upstream=None, head_w=None, pre_d=None,
+                   defer_affine=False):
     """defer: a dict shared with the ONE consumer of this layer's output (a head in fork form); when that consumer
     ran this layer's activation backward inside its own data-gradient kernel it marks the dict and this layer's
     backward skips its own pass.  upstream: the consumer's side of the same link (see _head_dgrad_actbwd).
     The contraction of a modulated layer whose weights came from mod_prep_all (handle, wb) and whose
-    input-magnitude factor is cvec fp32 [Otot] (native.ema_update(..., cvec=...))."""
+    input-magnitude factor is cvec fp32 [Otot] (native.ema_update(..., cvec=...)).
+    head_w: also return (behind the output and its statistic) the contraction of the level's two output heads on this
+    layer's output where the kernel takes it in its epilogue (an empty tensor where it does not);
+    pre_d: this layer is the heads and that contraction exists already (see _ModGemmPrepared.forward)."""
     ref = xa if xa is not None else xs
     cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0,
                out_dtype=ref.dtype if out_dtype is None else out_dtype, want_sq=bool(want_sq),
-               fork=bool(fork and xa is not None and xa.requires_grad), defer=defer, upstream=upstream)
-    return _ModGemmPrepared.apply(cfg, xa, xs, bias, handle, wb, cvec, wt)
+               fork=bool(fork and xa is not None and xa.requires_grad), defer=defer, upstream=upstream,
+               defer_affine=bool(defer_affine))
+    if pre_d is not None and pre_d.numel() == 0:
+        pre_d = None
+    return _ModGemmPrepared.apply(cfg, xa, xs, bias, handle, wb, cvec, wt, head_w, pre_d)
 
 
 

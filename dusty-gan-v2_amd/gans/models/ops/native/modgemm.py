@@ -337,9 +337,22 @@ def up_cat_pe(h, spec, angle, shift, freqs2, phase, dtype, B):
 # batched channel GEMM = contraction of the modulated 1x1 conv
 # (reference: grouped F.conv2d in ModConv2d.forward, gans/models/ops/style.py:105-118)
 # ---------------------------------------------------------------------------------------
-def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=None, row_scale=None, resid=None):
+_HEAD_FWD = os.environ.get("DGV2_NO_HEAD_FWD") is None   # A/B switch for benchmarking
+# (I, O) -> smallest pixel count from which the sample-walking kernel (dgv2_modconv_pe_fwd, PE-free form) takes a
+# per-sample-weight contraction.  Measured at B = 64 (scripts/mb_midgemm.py, profiles/round5_mb_midgemm.txt): it runs these
+# shapes 3.4-3.9x faster than the generic NN engine (whose 128 x 128 tiles re-stage 32-128 KB of per-sample weights per
+# block for four K-steps of work); round 5 added the 128- and 256-channel shapes of levels 2 / 1.
+_PE_FREE_MINP = {(64, 32): 4096, (32, 64): 4096, (32, 32): 4096, (64, 64): 4096, (128, 64): 2048, (64, 128): 2048,
+                 (128, 128): 1024, (256, 256): 512, (256, 128): 512, (128, 256): 512}
+if os.environ.get("DGV2_NO_PE_MID"):   # A/B switch: the round-4 routing
+    _PE_FREE_MINP = {k: 4096 for k in ((64, 32), (32, 64), (128, 64), (64, 128), (32, 32), (64, 64))}
+
+
+def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=None, row_scale=None, resid=None, head=None):
     """x3 [B,P,I]; w3 [Bw,O,I] (Bw = B or 1) same dtype -> [B,P,O]; optional fused
-    bias (fp32 [O]) + leaky-ReLU epilogue.  sq = _sq_args(): sum-of-squares partials where the kernel has them."""
+    bias (fp32 [O]) + leaky-ReLU epilogue.  sq = _sq_args(): sum-of-squares partials where the kernel has them.
+    head = [hw [B,2,O] bf16, None]: where the kernel can, the contraction of the level's two output heads on THIS output
+    leaves from the same launch (dgv2_modconv_pe_fwd_head): head[1] then holds it, fp32 [B,P,2]; else it stays None."""
     B, P, I = x3.shape
     Bw, O, _ = w3.shape
     N.check(x3, w3, bias)
@@ -349,9 +362,17 @@ def _bmm_nn_raw(x3, w3, out_dtype, bias=None, act=0, alpha=0.2, scale=1.0, sq=No
         r = None if resid is None else resid.contiguous().to(out_dtype)
         if N.try_call("dgv2_bmm_nn_small", N.ptr(y), N.ptr(x3), N.ptr(w3), N.ptr(r), B, P, I, O, _dt(x3), N.stream()):
             return y
-    if (resid is None and _PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and P >= 4096
-            and (I, O) in ((64, 32), (32, 64), (128, 64), (64, 128), (32, 32), (64, 64))):
+    if (resid is None and _PE_FWD and Bw == B and x3.dtype == torch.bfloat16 and out_dtype == torch.bfloat16
+            and P >= _PE_FREE_MINP.get((I, O), 1 << 30)):
         # streaming shapes of the two top levels: sample-walking kernel without a PE part
+        if (head is not None and _HEAD_FWD and head[0].dtype == torch.bfloat16 and tuple(head[0].shape) == (B, 2, O)
+                and head[0].is_contiguous()):
+            hd = torch.empty((B, P, 2), device=x3.device, dtype=torch.float32)
+            if N.try_call("dgv2_modconv_pe_fwd_head", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(row_scale),
+                          N.ptr(bias), act, alpha, scale, _dt(x3), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0,
+                          _ct.addressof(sq[1]) if sq else None, N.ptr(head[0]), N.ptr(hd), N.stream()):
+                head[1] = hd
+                return y
         if sq is not None or row_scale is not None:
             N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(x3), None, N.ptr(w3), B, P, I, 0, O, N.ptr(row_scale),
                    N.ptr(bias), act, alpha, scale, _dt(x3), N.ptr(sq[0]) if sq else None, _SQ_CAP if sq else 0,

@@ -318,7 +318,11 @@ class _ModGemmPrepared(Function):
     the gradient dL/dwb back to the batched preparation, c (fp32 [Otot], no gradient) is the layers' output factor."""
 
     @staticmethod
-    def forward(ctx, cfg, xa, xs, bias, handle, wb, cvec, wt=None):
+    def forward(ctx, cfg, xa, xs, bias, handle, wb, cvec, wt=None, head_w=None, pre_d=None):
+        """head_w [B,2,Otot] bf16: the prepared weights of the level's two output heads, whose contraction on this
+        layer's output is wanted (an extra output, fp32 [B,H,W,2] or an EMPTY tensor where the kernel could not take it);
+        pre_d fp32 [B,H,W,Otot]: this layer IS the heads and its contraction was taken by the producer of xa already --
+        what remains is out = cvec * pre_d + bias."""
         ctx.set_materialize_grads(False)
         ref = xa if xa is not None else xs
         dt = ref.dtype
@@ -343,10 +347,20 @@ class _ModGemmPrepared(Function):
             else:
                 N.call("dgv2_bmm_nn_cat_sq", N.ptr(out), N.ptr(xa), N.ptr(xs), N.ptr(wb), B, P, Ka, xs.shape[3], Otot,
                        N.ptr(cvec), N.ptr(bias32), act, cfg["alpha"], cfg["scale"], _dt(xs), _dt(xs), *tail)
+        elif pre_d is not None and not cfg["act"] and not cfg["want_sq"]:
+            xa = xa.contiguous()
+            if cfg.get("defer_affine"):
+                # out = cvec * pre_d + bias is evaluated by the consumer (native.resample_add(..., rscale, rbias)): this
+                # node hands the contraction on as it is and its backward receives the gradient of the affine's OUTPUT
+                out = pre_d.reshape(B, H, W_, Otot).view(B, H, W_, Otot)
+            else:
+                b0 = bias32 if bias32 is not None else torch.zeros(Otot, device=dev)
+                out = torch.addcmul(b0, pre_d.reshape(B, H, W_, Otot), cvec).to(odt)
         else:
             xa = xa.contiguous()
+            head = [head_w, None] if head_w is not None else None
             out = _bmm_nn_raw(xa.reshape(B, P, I), wb, odt, bias32, act, cfg["alpha"], cfg["scale"], sq=sq,
-                              row_scale=cvec).reshape(B, H, W_, Otot)
+                              row_scale=cvec, head=head).reshape(B, H, W_, Otot)
         ctx.cfg = dict(cfg, has_bias=bias is not None)
         ctx.save_for_backward(xa, xs, wb, out if cfg["act"] else None, cvec, wt)
         outs = [out]
@@ -354,6 +368,11 @@ class _ModGemmPrepared(Function):
             part = sq[0][:sq[1].value] if (sq is not None and sq[1].value > 0) else sum_squares(out)
             ctx.mark_non_differentiable(part)
             outs.append(part)
+        if head_w is not None:
+            hd = head[1].reshape(B, H, W_, 2) if (xs is None and pre_d is None and head[1] is not None) else \
+                torch.empty(0, device=dev, dtype=torch.float32)
+            ctx.mark_non_differentiable(hd)
+            outs.append(hd)
         if cfg["fork"]:   # hand the input on to a sibling consumer: its gradient then arrives HERE and is added in
             outs.append(xa.view_as(xa))   # the epilogue of this layer's data-gradient GEMM (no fork-point add)
         return outs[0] if len(outs) == 1 else tuple(outs)
@@ -363,7 +382,7 @@ class _ModGemmPrepared(Function):
         cfg = ctx.cfg
         g_sib = rest[-1] if cfg["fork"] else None
         if gy is None:
-            return (None, g_sib) + (None,) * 6
+            return (None, g_sib) + (None,) * 8
         xa, xs, wb, out, cvec, wt = ctx.saved_tensors
         B, Otot, I = wb.shape
         dt = wb.dtype
@@ -375,7 +394,7 @@ class _ModGemmPrepared(Function):
             fused = _head_bwd_fused(gy, cvec, wt, g_sib, xa, cfg["upstream"])
             if fused is not None:
                 gxa, gwb, gbh = fused
-                return None, gxa, None, (gbh if cfg["has_bias"] else None), gwb, None, None, None
+                return None, gxa, None, (gbh if cfg["has_bias"] else None), gwb, None, None, None, None, None
         H, W_ = gy.shape[1:3]
         P = H * W_
         dev = gy.device
@@ -431,7 +450,7 @@ class _ModGemmPrepared(Function):
         gwb = None
         if ctx.needs_input_grad[4]:
             gwb = _mod_wgrad(g3, xa, xs, B, H, W_, I, Otot, dt)
-        return None, gxa, None, gb, gwb, None, None, None
+        return None, gxa, None, gb, gwb, None, None, None, None, None
 
 
 # the positional-encoding part on the own streaming engine (shared-x mode): measured SLOWER than the library's batched

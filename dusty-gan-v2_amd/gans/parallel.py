@@ -80,6 +80,8 @@ class FlatGradSync:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
         self._sync = True
+        # all_reduce_captured: the reductions of the step as hipGraphs on a side stream (see there)
+        self._cg, self._cg_warm, self._side = {}, {}, None
 
     def zero(self):
         self.flat.zero_()
@@ -187,6 +189,11 @@ class FlatGradSync:
         if not (self._sync and is_dist()):
             return None
         avg = _avg_supported(self.flat.device)
+        if dist.get_world_size() == 1:
+            # (DGV2_DIST_WORLD1) the mean over one rank is the identity: plain SUM, which RCCL completes without a kernel
+            # for an in-place buffer -- its one-rank AVG runs a pre-multiply copy over the whole 154 MB (oneRankReduce,
+            # 0.3 ms per iteration: profiles/round5_one_rank_rccl_listing.txt) that no multi-rank run has
+            avg = False
         _, (lo, hi) = self._part(part)
         carry = bool(carry and self._carry and hi == self.flat.numel() and self._carry_valid())
         if carry:
@@ -219,10 +226,64 @@ class FlatGradSync:
         self._finish(avg, lo, hi, carry)
         return None
 
+    def all_reduce_captured(self, part=None, carry=False):
+        """all_reduce(async_op=True, ...) whose device work -- the packing of the carried buffers, the RCCL collective, the
+        scaling / unpacking behind it -- is captured ONCE as a hipGraph and replayed on a side stream: per iteration the
+        host issues one graph launch per reduction instead of c10d's eager sequence (work object, event record / wait,
+        kernel launches), which with ONE rank already cost 3.8 % of the step (round 4: 4 475 vs 4 650 img/s) before a byte
+        crossed xGMI.  The overlap of the asynchronous form is kept: the replay runs on the side stream, wait() joins it.
+        The first two calls run eagerly (RCCL's lazy communicator set-up must not fall into a capture); a failed capture
+        falls back to the eager asynchronous form for good.  CPU / gloo: the eager form."""
+        if not (self._sync and is_dist()):
+            return None
+        if (not self.flat.is_cuda or dist.get_backend() != "nccl" or os.environ.get("DGV2_NO_CAPTURED_COLLECTIVES")
+                or self.payload_dtype is not None):
+            return self.all_reduce(async_op=True, part=part, carry=carry)
+        key = (part, bool(carry))
+        if self._cg.get(key, "") is None:
+            return self.all_reduce(async_op=True, part=part, carry=carry)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.flat.device)
+        cur = torch.cuda.current_stream(self.flat.device)
+        side = self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            if key not in self._cg:
+                if self._cg_warm.get(key, 0) < 2:
+                    self._cg_warm[key] = self._cg_warm.get(key, 0) + 1
+                    self.all_reduce(async_op=False, part=part, carry=carry)
+                    return ("side", side)
+                import gc
+                import warnings
+                gc_on = gc.isenabled()
+                gc.disable()
+                try:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        self.all_reduce(async_op=False, part=part, carry=carry)
+                    self._cg[key] = g
+                except Exception as e:   # noqa: BLE001  (keep training: this reduction stays eager)
+                    torch.cuda.synchronize()
+                    warnings.warn(f"hipGraph capture of the gradient reduction {key} failed ({type(e).__name__}: {e}); "
+                                  "it runs eagerly")
+                    self._cg[key] = None
+                finally:
+                    if gc_on:
+                        gc.enable()
+                if self._cg[key] is None:
+                    return self.all_reduce(async_op=True, part=part, carry=carry)
+            self._cg[key].replay()
+        return ("side", side)
+
+    def captured(self):
+        """{(part, carry): True (replaying) / False (capture failed)} of the reductions all_reduce_captured has met."""
+        return {k: v is not None for k, v in self._cg.items()}
+
     def _finish(self, avg, lo, hi, carry=False):
         if self.payload_dtype is not None:
             self.flat[lo:hi].copy_(self._payload[lo:hi])
-        if not avg:
+        if not avg and dist.get_world_size() > 1:
             # (never the carried tail: it holds rank 0's values as they are)
             self._store[lo:min(hi, self.flat.numel())].mul_(1.0 / dist.get_world_size())
         if carry:
@@ -231,6 +292,9 @@ class FlatGradSync:
     def wait(self, handle):
         """Complete an all_reduce(async_op=True): the current stream waits for the reduction."""
         if handle is None:
+            return
+        if handle[0] == "side":   # all_reduce_captured: join the side stream
+            torch.cuda.current_stream(self.flat.device).wait_stream(handle[1])
             return
         work, avg, lo, hi, carry = handle
         work.wait()

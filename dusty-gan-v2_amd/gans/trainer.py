@@ -623,7 +623,7 @@ class Trainer:
                 log(self._run(self._acc_name("g_fb", j), self.g_fb, j))
         # G's 17.5 MB (+ rank 0's buffers) leave on the communication stream; the real batch of this iteration is
         # fetched / generated and converted meanwhile (the D step itself starts with a forward of the UPDATED G)
-        h = self.g_sync.all_reduce(async_op=True, carry=True)
+        h = self.g_sync.all_reduce_captured(carry=True)
         if late_reals:
             self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
         self.g_sync.wait(h)
@@ -635,7 +635,7 @@ class Trainer:
                 if j == 0 and not self._g_bufs_synced:
                     parallel.sync_buffers(self.G)
                 log(self._run(self._acc_name("pl_fb", j), self.pl_fb, j))
-            h = self.g_sync.all_reduce(async_op=True, carry=True)
+            h = self.g_sync.all_reduce_captured(carry=True)
             self.g_sync.wait(h)
             self._g_bufs_synced = h is not None and self.g_sync.carries_buffers()
             self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
@@ -649,14 +649,14 @@ class Trainer:
                 log(self._run(head, self.d_fb_head, real(j), j))
                 if j == nacc - 1:
                     # 134 of D's 154 MB leave now, on the communication stream, under the trunk's backward
-                    pending.append(self.d_sync.all_reduce(async_op=True, part="first"))
+                    pending.append(self.d_sync.all_reduce_captured(part="first"))
                 self._run(tail, self.d_fb_tail, j)
                 self._link_graphs(head, tail)
             else:
                 log(self._run(self._acc_name("d_fb", j), self.d_fb, real(j), j))
         # the (rest of the) gradient reduction of D runs on the communication stream while the EMA generator is updated
         # (G is final for this iteration: nothing below touches it)
-        pending.append(self.d_sync.all_reduce(async_op=True, part="rest" if self.split_d else None))
+        pending.append(self.d_sync.all_reduce_captured(part="rest" if self.split_d else None))
         decay = self.ema_decay(iteration)
         ema_inplace(self.G_ema, self.G, decay)
         for h in pending:
@@ -671,7 +671,7 @@ class Trainer:
             # R1's 154 MB leave asynchronously as well: the packing launches of the tail exchange run under them (the
             # exchange itself queues behind the reduction on the communication stream).  The optimizer step cannot move
             # past the next iteration's G step, whose D forward must see the regularised weights (trainer.py:419-451).
-            r1_pending = self.d_sync.all_reduce(async_op=True)
+            r1_pending = self.d_sync.all_reduce_captured()
 
         scalars = {k: (v[0] if len(v) == 1 else torch.stack([t.reshape(()) for t in v]).mean())
                    for k, v in per_chunk.items()}          # mean over the chunks (reference: trainer.py:471-476)

@@ -127,6 +127,12 @@ int dgv2_resample_tab(void* y, const void* x, const int* idx_h, const float* coe
 int dgv2_resample_tab_add(void* y, const void* x, const void* resid, const int* idx_h, const float* coef_h,
                           const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew,
                           int B, int C, int in_h, int in_w, int out_h, int out_w, int dtype, void* stream);
+/* ... with resid entering as rscale[c] * resid + rbias[c] (fp32 [C], both or neither): `c * heads(x) + bias` of Head.forward
+ * (dusty_v2.py:30-57) formed in the same store when the heads' contraction left conv2's epilogue (dgv2_modconv_pe_fwd_head). */
+int dgv2_resample_tab_add_affine(void* y, const void* x, const void* resid, const float* rscale, const float* rbias,
+                                 const int* idx_h, const float* coef_h, const int* cnt_h, int Eh, const int* idx_w,
+                                 const float* coef_w, const int* cnt_w, int Ew, int B, int C, int in_h, int in_w, int out_h,
+                                 int out_w, int dtype, void* stream);
 
 /* dgv2_resample_tab that can also leave the sum of squares of what it wrote (the next modulated conv's input
  * statistic, ModConv2d.forward style.py:98-103: x.square().mean() for the EMA) as per-block partials, saving a
@@ -330,6 +336,16 @@ int dgv2_modconv_pe_fwd(void* y, const void* xa, const void* xs, const void* w, 
 int dgv2_modconv_pe_fwd_sq(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
                            int O, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype, float* sumsq,
                            int sumsq_cap, int* sumsq_used, void* stream);
+/* ... and with the contraction of the level's two 1-channel output heads taken in this layer's epilogue instead of by a
+ * pass of their own over y: head_out[b,p,j] = sum_o y[b,p,o] head_w[b,j,o], j < 2 (on the stored bf16 values, fp32 sums;
+ * the heads' input-magnitude factor and bias are applied by the caller: they depend on the statistic of y this very launch
+ * produces).  head_w [B,2,O] bf16 (the heads' prepared weights), head_out fp32 [B,P,2]; both or neither.
+ * replaces: the ModConv2d contractions of Head.forward (gans/models/dusty_v2.py:30-57,171-178) behind conv2 of a
+ * SynthesisBlock (:161-170).  PE-free one-slab shapes (Ka, O) = (32, 32), (64, 64) (conv2 of levels 4 / 3); DGV2_ENOTSUP for
+ * any other shape when head_w is given. */
+int dgv2_modconv_pe_fwd_head(void* y, const void* xa, const void* xs, const void* w, int B, int P, int Ka, int Ks,
+                             int O, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype,
+                             float* sumsq, int sumsq_cap, int* sumsq_used, const void* head_w, float* head_out, void* stream);
 
 /* Per-sample weights of the modulated conv, written directly as the GEMM operand, and the exact
  * backward of that preparation (max-normalisations, modulation, demodulation, input-magnitude

@@ -1,0 +1,34 @@
+#!/bin/bash
+# round 5, call g: rng kernel fix, sample-walking kernel at levels 2 / 1, head affine in the skip store; one-rank RCCL
+# kernel trace; every step under its own timeout
+O=gpurun_out/r6g; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_full.py tests/test_gpu_trainer.py tests/test_gpu_dist.py -x -q -m gpu > $O/test_sel.txt 2>&1; echo "selected tests rc=$?"; tail -3 $O/test_sel.txt
+timeout 300 python scripts/mb_midgemm.py 2>&1 | grep -v amdgpu.ids | tee $O/mb_midgemm.txt
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_default.log 2> $O/bench_default.err; python - <<'PY'
+import json
+try:
+    d=json.loads([l for l in open('gpurun_out/r6g/bench_default.log') if l.startswith('{')][-1])
+    print('bench', round(d['value'],1), round(d['ms_per_step'],3), d['extra'].get('ms_plain_iteration'), d['extra'].get('ms_r1_iteration'))
+    print('modconv levels', {k: (round(v['frac'],3), round(v['avg_launch_us'],1)) for k, v in d['roofline_modconv']['levels'].items()})
+except Exception as e: print('bench ERR', e)
+PY
+tail -2 $O/bench_default.err
+DGV2_NO_PE_MID=1 DGV2_NO_HEAD_FWD=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_ab_old_routing.log 2>/dev/null; python -c "
+import json; d=json.loads([l for l in open('$O/bench_ab_old_routing.log') if l.startswith('{')][-1]); print('A/B round-4 routing of the mid GEMMs + heads as own GEMMs', round(d['value'],1), round(d['ms_per_step'],3))"
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_noextra.log 2>/dev/null; python -c "
+import json; d=json.loads([l for l in open('$O/bench_noextra.log') if l.startswith('{')][-1]); print('plain (no extra) line', round(d['value'],1), round(d['ms_per_step'],3))"
+timeout 300 python bench.py --workload gfwd --batch-per-gpu 32 --steps 50 --warmup 10 > $O/bench_gfwd.log 2>&1; python -c "
+import json; d=json.loads([l for l in open('$O/bench_gfwd.log') if l.startswith('{')][-1]); print('gfwd', round(d['value'],1), round(d['ms_per_step'],4))"
+DGV2_DIST_WORLD1=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_one_rank_rccl.log 2> $O/bench_one_rank_rccl.err; python -c "
+import json
+try:
+    d=json.loads([l for l in open('$O/bench_one_rank_rccl.log') if l.startswith('{')][-1]); print('one-rank rccl', round(d['value'],1), round(d['ms_per_step'],3), d['extra'].get('captured_collectives'))
+except Exception as e: print('rccl ERR', e)"
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
+export DGV2_DIST_WORLD1=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_rccl -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $GRAFT_REPO_ROOT/$O/prof_rccl.log 2>&1
+unset DGV2_DIST_WORLD1 RANK WORLD_SIZE LOCAL_RANK
+cd $GRAFT_REPO_ROOT
+f=$(find $O/prof -name "*kernel_trace.csv" | head -1); python scripts/step_listing.py $f --full --json $O/step_instances.json > $O/listing.txt; head -34 $O/listing.txt
+f=$(find $O/prof_rccl -name "*kernel_trace.csv" | head -1); python scripts/step_listing.py $f --full > $O/listing_rccl.txt; head -8 $O/listing_rccl.txt

@@ -197,7 +197,8 @@ def test_bmm_bf16_random_tolerance(nat):
 
 
 @pytest.mark.parametrize("Ka,Ks,O,P,B", [(64, 512, 32, 700, 5), (64, 512, 32, 256, 2), (128, 512, 64, 300, 3), (256, 512, 128, 200, 2), (64, 0, 32, 700, 3), (32, 0, 64, 300, 2),
-                                          (128, 0, 64, 300, 2), (64, 0, 128, 260, 2), (32, 0, 32, 300, 2), (64, 0, 64, 300, 2)])
+                                          (128, 0, 64, 300, 2), (64, 0, 128, 260, 2), (32, 0, 32, 300, 2), (64, 0, 64, 300, 2),
+                                          (128, 0, 128, 300, 3), (256, 0, 256, 200, 3), (256, 0, 128, 140, 2), (128, 0, 256, 260, 2)])
 def test_modconv_pe_fwd_matches_reference(nat, Ka, Ks, O, P, B):
     """dgv2_modconv_pe_fwd (pixel-tile blocks walking the samples, shared PE in registers) against the
     einsum of the reference's cat([h, pe]) + per-sample 1x1 conv + bias + lrelu (dusty_v2.py:153-162,
@@ -1868,3 +1869,31 @@ def test_head_backward_in_one_pass(nat, dtype, B, P, K, O, res):
     assert_rel(link["gb"].double().cpu(), v.to(dtype).double().sum((0, 1)).cpu(), 5e-3 if dtype == torch.bfloat16 else 1e-4, "gb_up")
     assert_rel(gw.double().cpu(), torch.einsum("bpo,bpk->bok", gq, x64).cpu(), 1e-4, "head weight gradient")
     assert_rel(gbh.double().cpu(), gy.double().sum((0, 1, 2)).cpu(), 1e-4, "head bias gradient")
+
+
+@pytest.mark.parametrize("C,P", [(32, 32768), (64, 8192), (32, 4096 + 48)])
+def test_heads_contraction_in_conv2_epilogue(nat, C, P):
+    """dgv2_modconv_pe_fwd_head: conv2 of a top generator level with the contraction of the level's two output heads taken in
+    its epilogue -- the layer's output is bit-identical to the launch without it, the head sums equal the contraction of the
+    STORED (bf16) output with the head weights."""
+    g = torch.Generator().manual_seed(C + P)
+    B = 3
+    x = torch.randn(B, P, C, generator=g).bfloat16().to(DEV)
+    wb = (torch.randn(B, C, C, generator=g) / C ** 0.5).bfloat16().to(DEV)
+    hw = (torch.randn(B, 2, C, generator=g) / C ** 0.5).bfloat16().to(DEV)
+    cvec = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    plain = nat._bmm_nn_raw(x, wb, torch.bfloat16, bias, 3, 0.2, 2.0 ** 0.5, sq=None, row_scale=cvec)
+    head = [hw, None]
+    fused = nat._bmm_nn_raw(x, wb, torch.bfloat16, bias, 3, 0.2, 2.0 ** 0.5, sq=None, row_scale=cvec, head=head)
+    assert head[1] is not None, "the kernel did not take the heads"
+    assert torch.equal(plain, fused)
+    want = torch.einsum("bpo,bjo->bpj", fused.double(), hw.double())
+    assert_rel(head[1].double().cpu(), want.cpu(), 1e-5, "head contraction")
+    # with the statistic partials as the training pass asks for them
+    sq = nat._sq_args(DEV)
+    head2 = [hw, None]
+    fused2 = nat._bmm_nn_raw(x, wb, torch.bfloat16, bias, 3, 0.2, 2.0 ** 0.5, sq=sq, row_scale=cvec, head=head2)
+    assert torch.equal(fused2, plain) and torch.equal(head2[1], head[1])
+    n = sq[1].value
+    assert n > 0 and abs(float(sq[0][:n].sum()) - float(plain.float().square().sum())) <= 1e-4 * float(plain.float().square().sum())
