@@ -42,7 +42,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint64_t key) {
 }
 
 // The argument block is read where it lies (the kernarg segment): a by-value struct indexed with a per-thread segment number
-// is otherwise copied to scratch memory first (measured: 59 us for the 2.1 M draws of a step body instead of 8).
+// is otherwise copied to scratch memory first.
 __global__ __launch_bounds__(256) void rng_fill_kernel(RngSegs s_by_value, unsigned long long* __restrict__ state) {
   const RngSegs& s = *(const RngSegs*)__builtin_amdgcn_kernarg_segment_ptr();
   const unsigned long long seed = state[0], offset = state[1];
@@ -86,19 +86,20 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(RngSegs s_by_value, unsig
         if (e + j < cnt) o[j] = v[j];
     }
   }
-  // the last block to arrive advances the stream (every block has read `offset` by then) and resets the ticket
+  // The last block to arrive advances the stream and resets the ticket.  No fence is needed: a block takes its ticket
+  // after all its threads have READ the offset (the barrier), so the block that draws the last ticket knows every block
+  // has; the new offset only has to be visible to the NEXT launch on this state (a kernel boundary).  (__threadfence()
+  // here cost 50 us per launch: on this part a device-scope release is an L2 write-back + invalidate, once per block.)
   __shared__ bool last;
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned long long t = atomicAdd(&state[2], 1ull);
+    const unsigned long long t = __hip_atomic_fetch_add(&state[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = t == (unsigned long long)gridDim.x - 1;
   }
   __syncthreads();
   if (last && threadIdx.x == 0) {
     state[1] = offset + (unsigned long long)total;
     state[2] = 0ull;
-    __threadfence();
   }
 }
 

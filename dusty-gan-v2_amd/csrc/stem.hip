@@ -80,13 +80,46 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(T* __restrict__ y, const 
   }
 }
 
-// partial[block][3*O]: gb[o], gw[o,0], gw[o,1];  gxb fp32 [B,H,W,2]
+// The stem's output feeds the first ResidualBlock twice: conv1, and the skip branch through a decimating blur
+// (dusty_v2.py:337-345: self.skip(self.resample(x)), evaluated at the even positions only).  SKIP: the gradient of that
+// blurred / decimated image, gsk [B, Hs, Ws, O], is gathered HERE through the ADJOINT tables of the blur (rows of the
+// full-resolution grid naming the <= E decimated positions they fed, as dgv2_resample_tab takes them) instead of being
+// scattered to a full-resolution tensor by a pass of its own, added to conv1's data gradient by another and read back
+// by this one: per iteration 2 x 268 MB of traffic and a launch less at 2B = 128.
 template <typename T>
+struct StemSkip {
+  const T* gsk;
+  const int* idx_h; const float* coef_h; const int* cnt_h; int Eh;
+  const int* idx_w; const float* coef_w; const int* cnt_w; int Ew;
+  int Hs, Ws;
+};
+
+// partial[block][3*O]: gb[o], gw[o,0], gw[o,1];  gxb fp32 [B,H,W,2]
+template <typename T, bool SKIP>
 __global__ __launch_bounds__(256) void stem_bwd_kernel(float* __restrict__ partial, float* __restrict__ gxb,
                                                        const T* __restrict__ gy, const T* __restrict__ y,
                                                        const float* __restrict__ x, const float* __restrict__ w,
-                                                       StemGeom g) {
+                                                       StemGeom g, StemSkip<T> sk) {
   __shared__ float red[4][8][24];
+  extern __shared__ __attribute__((aligned(16))) unsigned char stem_tabs[];   // SKIP: idx_h | coef_h | idx_w | coef_w
+  const int* t_ih = nullptr; const float* t_ch = nullptr; const int* t_iw = nullptr; const float* t_cw = nullptr;
+  if constexpr (SKIP) {
+    const int nh_ = g.H * sk.Eh, nw_ = g.W * sk.Ew;
+    int* a0 = reinterpret_cast<int*>(stem_tabs);
+    float* a1 = reinterpret_cast<float*>(a0 + nh_);
+    int* a2 = reinterpret_cast<int*>(a1 + nh_);
+    float* a3 = reinterpret_cast<float*>(a2 + nw_);
+    for (int t = threadIdx.x; t < nh_; t += 256) {
+      a0[t] = sk.idx_h[t];
+      a1[t] = sk.coef_h[t];
+    }
+    for (int t = threadIdx.x; t < nw_; t += 256) {
+      a2[t] = sk.idx_w[t];
+      a3[t] = sk.coef_w[t];
+    }
+    __syncthreads();
+    t_ih = a0; t_ch = a1; t_iw = a2; t_cw = a3;
+  }
   const int G = g.O / 8;                  // 1, 2, 4 or 8: a pixel's threads are adjacent lanes
   const int64_t items = (int64_t)g.B * g.H * g.W * G;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -110,18 +143,56 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(float* __restrict__ parti
     const int h = r / g.W, wc = r - h * g.W;
     float v, u;
     stem_blur(x + (int64_t)b * HW, h, wc, g, v, u);
-    float gp[8];
+    float gp[8], gs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gs[j] = 0.f;
+    if constexpr (SKIP) {   // blur_down^T(gsk) at this pixel: <= Eh x Ew decimated positions
+      // the tables sit in LDS (copied once per block: a global cnt -> idx -> data chain per pixel made this pass latency
+      // bound, 504 us instead of 136); the first 2 x 2 entries -- all there is away from the clamped border rows -- are
+      // requested together, unconditionally (unused entries carry coefficient 0 and index 0)
+      const T* sb = sk.gsk + (int64_t)b * sk.Hs * sk.Ws * g.O + grp * 8;
+      const int* ihp = t_ih + h * sk.Eh;
+      const float* chp = t_ch + h * sk.Eh;
+      const int* iwp = t_iw + wc * sk.Ew;
+      const float* cwp = t_cw + wc * sk.Ew;
+      const int e1h = sk.Eh > 1 ? 1 : 0, e1w = sk.Ew > 1 ? 1 : 0;
+      const float ch0 = chp[0], ch1 = sk.Eh > 1 ? chp[1] : 0.f, cw0 = cwp[0], cw1 = sk.Ew > 1 ? cwp[1] : 0.f;
+      const T* r0 = sb + (int64_t)ihp[0] * sk.Ws * g.O;
+      const T* r1 = sb + (int64_t)ihp[e1h] * sk.Ws * g.O;
+      const int64_t c0 = (int64_t)iwp[0] * g.O, c1 = (int64_t)iwp[e1w] * g.O;
+      auto acc8 = [&](const T* sp, float cf) {
+        if constexpr (sizeof(T) == 2) {
+          vec16<T> v8;
+          v8.load(sp);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gs[j] = fmaf(cf, v8.get(j), gs[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gs[j] = fmaf(cf, (float)sp[j], gs[j]);
+        }
+      };
+      acc8(r0 + c0, ch0 * cw0);
+      acc8(r0 + c1, ch0 * cw1);
+      acc8(r1 + c0, ch1 * cw0);
+      acc8(r1 + c1, ch1 * cw1);
+      for (int a = 0; a < sk.Eh; ++a)        // what the 2 x 2 block did not cover (border rows / longer tables)
+        for (int c = 0; c < sk.Ew; ++c) {
+          if (a < 2 && c < 2) continue;
+          const float cf = chp[a] * cwp[c];
+          if (cf != 0.f) acc8(sb + (int64_t)ihp[a] * sk.Ws * g.O + (int64_t)iwp[c] * g.O, cf);
+        }
+    }
     if constexpr (sizeof(T) == 2) {
       vec16<T> a, c;
       a.load(gy + px * g.O + grp * 8);
       c.load(y + px * g.O + grp * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gp[j] = a.get(j) * (c.get(j) > 0.f ? 1.f : g.alpha) * g.scale;
+      for (int j = 0; j < 8; ++j) gp[j] = (a.get(j) + gs[j]) * (c.get(j) > 0.f ? 1.f : g.alpha) * g.scale;
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float a = gy[px * g.O + grp * 8 + j], c = y[px * g.O + grp * 8 + j];
-        gp[j] = a * (c > 0.f ? 1.f : g.alpha) * g.scale;
+        gp[j] = (a + gs[j]) * (c > 0.f ? 1.f : g.alpha) * g.scale;
       }
     }
     float s0 = 0.f, s1 = 0.f;
@@ -236,8 +307,25 @@ extern "C" int dgv2_stem_bwd_scratch(int64_t* elems, int B, int H, int W, int O)
 extern "C" int dgv2_stem_bwd(float* gx, float* gw, float* gb, float* scratch, int64_t scratch_elems, const void* gy,
                              const void* y, const float* x, const float* w, int B, int H, int W, int O, int ring,
                              float alpha, float scale, int dtype, void* stream) {
+  return dgv2_stem_bwd_skip(gx, gw, gb, scratch, scratch_elems, gy, y, x, w, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                            nullptr, nullptr, 0, 0, 0, B, H, W, O, ring, alpha, scale, dtype, stream);
+}
+
+// ... with gsk [B, Hs, Ws, O] (dtype; NULL: none), the gradient of a decimating blur of y (the first ResidualBlock's skip
+// branch), gathered through the blur's ADJOINT tables (idx_h / coef_h / cnt_h: H rows of Eh entries naming rows of gsk;
+// idx_w ...: W rows of Ew entries): the gradient of y is then gy + blur^T(gsk), never materialised.
+extern "C" int dgv2_stem_bwd_skip(float* gx, float* gw, float* gb, float* scratch, int64_t scratch_elems, const void* gy,
+                                  const void* y, const float* x, const float* w, const void* gsk, const int* idx_h,
+                                  const float* coef_h, const int* cnt_h, int Eh, const int* idx_w, const float* coef_w,
+                                  const int* cnt_w, int Ew, int Hs, int Ws, int B, int H, int W, int O, int ring,
+                                  float alpha, float scale, int dtype, void* stream) {
   if (!gw || !gb || !scratch || !gy || !y || !x || !w || !stem_ok(B, H, W, O)) return DGV2_EINVAL;
   if (!aligned16(gy) || !aligned16(y) || !aligned16(scratch)) return DGV2_EINVAL;
+  if (gsk && (!idx_h || !coef_h || !cnt_h || !idx_w || !coef_w || !cnt_w || Eh < 1 || Ew < 1 || Hs < 1 || Ws < 1 ||
+              !aligned16(gsk)))
+    return DGV2_EINVAL;
+  const size_t tab_bytes = gsk ? 8 * ((size_t)H * Eh + (size_t)W * Ew) : 0;
+  if (tab_bytes > 48 * 1024) return DGV2_ENOTSUP;   // the tables ride in LDS (callers then run the separate passes)
   const int64_t need = (int64_t)STEM_BWD_BLOCKS * 3 * O + (int64_t)B * H * W * 2;
   if (scratch_elems < need) return DGV2_EINVAL;
   StemGeom g{B, H, W, O, ring, alpha, scale, 0};
@@ -246,12 +334,17 @@ extern "C" int dgv2_stem_bwd(float* gx, float* gw, float* gb, float* scratch, in
   float* partial = scratch;
   float* gxb = scratch + (int64_t)STEM_BWD_BLOCKS * 3 * O;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DGV2_BF16)
-    stem_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(partial, gxb, (const bf16_t*)gy, (const bf16_t*)y, x, w, g);
-  else if (dtype == DGV2_F32)
-    stem_bwd_kernel<float><<<grid, 256, 0, st>>>(partial, gxb, (const float*)gy, (const float*)y, x, w, g);
-  else
+  if (dtype == DGV2_BF16) {
+    StemSkip<bf16_t> sk{(const bf16_t*)gsk, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, Hs, Ws};
+    if (gsk) stem_bwd_kernel<bf16_t, true><<<grid, 256, tab_bytes, st>>>(partial, gxb, (const bf16_t*)gy, (const bf16_t*)y, x, w, g, sk);
+    else stem_bwd_kernel<bf16_t, false><<<grid, 256, 0, st>>>(partial, gxb, (const bf16_t*)gy, (const bf16_t*)y, x, w, g, sk);
+  } else if (dtype == DGV2_F32) {
+    StemSkip<float> sk{(const float*)gsk, idx_h, coef_h, cnt_h, Eh, idx_w, coef_w, cnt_w, Ew, Hs, Ws};
+    if (gsk) stem_bwd_kernel<float, true><<<grid, 256, tab_bytes, st>>>(partial, gxb, (const float*)gy, (const float*)y, x, w, g, sk);
+    else stem_bwd_kernel<float, false><<<grid, 256, 0, st>>>(partial, gxb, (const float*)gy, (const float*)y, x, w, g, sk);
+  } else {
     return DGV2_EINVAL;
+  }
   stem_reduce_kernel<<<3 * O, 256, 0, st>>>(gw, gb, partial, grid, O);
   if (gx) stem_blur_adj_kernel<<<grid_for((int64_t)B * H * W, 256, 4096), 256, 0, st>>>(gx, gxb, g);
   DGV2_RETURN_LAST();

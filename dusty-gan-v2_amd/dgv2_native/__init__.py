@@ -144,6 +144,8 @@ SIGNATURES = {
     "dgv2_stem_fwd": [_c_ptr] * 4 + [_c_int] * 5 + [_c_f32, _c_f32, _c_int, _c_ptr],
     "dgv2_stem_bwd_scratch": [_c_ptr] + [_c_int] * 4,
     "dgv2_stem_bwd": [_c_ptr] * 4 + [_c_i64] + [_c_ptr] * 4 + [_c_int] * 5 + [_c_f32, _c_f32, _c_int, _c_ptr],
+    "dgv2_stem_bwd_skip": [_c_ptr] * 4 + [_c_i64] + [_c_ptr] * 8 + [_c_int] + [_c_ptr] * 3 + [_c_int] * 8 + [_c_f32, _c_f32, _c_int,
+                                                                                                        _c_ptr],
     "dgv2_gen_tail_fwd": [_c_ptr] * 7 + [_c_int] * 3 + [_c_f32] * 3 + [_c_ptr],
     "dgv2_gen_tail_bwd": [_c_ptr] * 11 + [_c_int] * 3 + [_c_f32] * 3 + [_c_ptr],
     "dgv2_ada_apply": [_c_ptr] * 8 + [_c_int] * 5 + [_c_ptr],

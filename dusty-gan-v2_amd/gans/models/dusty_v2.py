@@ -72,6 +72,12 @@ class MappingNetwork(nn.Sequential):
 
 
 _BATCHED_PREP = os.environ.get("DGV2_NO_BATCHED_PREP") is None
+_R1_BANK = os.environ.get("DGV2_NO_R1_BANK") is None   # A/B switch: the weight bank in the twice-differentiable pass (bf16 mode)
+# opt-in (DGV2_STEM_SKIP=1): the first block's skip blur as an output of the stem, its gradient gathered inside the stem's
+# backward kernel.  Saves a scatter pass and the residual read of conv1's data gradient (-130 us) but the gather itself --
+# four 16-byte loads per pixel and channel group through the texture path -- costs the stem's backward +170 us at 2B = 128:
+# a net loss of 1 % until the kernel walks 2 x 2 pixel quads that share their four gathered neighbours
+_STEM_SKIP = os.environ.get("DGV2_STEM_SKIP") is not None
 
 
 class Head(nn.Module):
@@ -703,22 +709,25 @@ class ResidualBlock(nn.Module):
                                   fp8=fp8[self.conv2])
         return self.skip.forward_cl(xs, geom=self.skip_geom, resid=h, wscale=c, bank=bank, fp8=fp8[self.skip])
 
-    def forward_cl(self, x, bank=None, fp8=None):
-        if (fp8 is not None and self.conv2 in fp8 and bank is not None and bank.get(self.conv1) is not None
+    def forward_cl(self, x, bank=None, fp8=None, xs=None):
+        """xs: blur_down(x), when the producer of x made it already (Discriminator._fused_stem: its gradient then returns
+        to the stem's backward kernel instead of being scattered to x's resolution and joined in conv1's data gradient)."""
+        if (xs is None and fp8 is not None and self.conv2 in fp8 and bank is not None and bank.get(self.conv1) is not None
                 and isinstance(self.resample, ops.Resample) and native.fp8_ok(x, self.conv2.out_ch)):
             return self._forward_fp8(x, bank, fp8)
         hd = None   # conv1's activation after the blur/down
         if bank is not None and bank.get(self.conv1) is not None and isinstance(self.resample, ops.Resample):
             # conv1 -> act -> blur/down as one autograd node (one fused pass in backward); it also hands x on to the skip
             # branch: the two gradients of x then meet inside conv1's dgrad kernel
-            if x.requires_grad:
+            if x.requires_grad and xs is None:
                 hd, x = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank, fork=True, down=self.resample.spec)
             else:
                 hd = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank, down=self.resample.spec)
         else:
             h = self.conv1.forward_cl(x, act=self.bias_act1, bank=bank)
         c = 1.0 / math.sqrt(2)
-        xs = native.resample(x, self.blur_down)
+        if xs is None:
+            xs = native.resample(x, self.blur_down)
         if native.conv_resid_ok(xs, self.skip_geom) and self.skip._params_bias()[0] is None:
             # (act(z) * sqrt2 + skip) / sqrt2 == act(z) * 1 + skip / sqrt2: the residual scale folds into the
             # activation gain and the skip weights, the sum into the skip conv's epilogue
@@ -822,13 +831,14 @@ class Discriminator(nn.Module):
             raise ValueError(f"epilogue_dtype must be 'fp32' or 'bf16', got {self.epilogue_dtype!r}")
         return LOW if (self.epilogue_dtype == "bf16" and self.num_fp16_layers == -1) else torch.float32
 
-    def _fused_stem(self, h, layers):
-        """BlurVH -> 1x1 conv -> bias + lrelu of a one-channel input as ONE streaming kernel (dgv2_stem_fwd/bwd)."""
+    def _fused_stem(self, h, layers, down=None):
+        """BlurVH -> 1x1 conv -> bias + lrelu of a one-channel input as ONE streaming kernel (dgv2_stem_fwd/bwd).
+        down: the first ResidualBlock's decimating skip blur -> (x, down(x)) (native.stem)."""
         blur, conv, act = layers[0], layers[1], layers[2]
         w, b, _ = conv._params()
         low = self.num_fp16_layers > 1 or self.num_fp16_layers == -1
         return native.stem(h, w, act.bias, blur.blur_h.spec.ring, act.negative_slope, act.scale,
-                           LOW if low else torch.float32)
+                           LOW if low else torch.float32, down=down)
 
     _cut = None
 
@@ -844,7 +854,9 @@ class Discriminator(nn.Module):
         cut, self._cut = self._cut, None
         return cut
 
-    def forward(self, h, splits=1, double_backward=False, features_only=False, cut=False):
+    _bank_keep = None
+
+    def forward(self, h, splits=1, double_backward=False, features_only=False, cut=False, reuse_bank=False):
         """h [B,C,H,W] (C = 1 on the dusty_v2 path) -> logits [B,1]  (features_only: the trunk's output [B,H/16,W/16,C]
         channels-last, before the fp32 epilogue -- used by the precision tests).
         cut: detach the graph in front of the 65536 -> 512 Linear, so that the caller can run the backward in two
@@ -853,18 +865,40 @@ class Discriminator(nn.Module):
         sub-batches stacked along dim 0 (minibatch statistics are computed per sub-batch), so that
         D(real) and D(fake) of the discriminator step can share one pass over the weights.
         `double_backward`: the caller will differentiate the input gradient again (R1); the fused stem is
-        first-order only, so that pass runs the composable ops."""
+        first-order only, so that pass runs the composable ops.
+        `reuse_bank`: the weights have not changed since the previous call: its weight bank is used again."""
         layers = list(self.layers)
         i = 0
-        bank = None if (double_backward or not h.is_cuda) else self._weight_bank()
-        fp8 = self._fp8_bank() if (bank is not None and self.fp8_branches and self.num_fp16_layers == -1) else None
+        # reuse_bank: the caller's promise that the weights are what they were at the previous call (the D step's forward
+        # behind the G step's: only G moved in between, gans/trainer.py) -- the compute-dtype copies that call prepared
+        # (69 us of layout / cast launches at the timed configuration) serve this one too
+        keep = self._bank_keep if (reuse_bank and not double_backward and h.is_cuda) else None
+        if keep is not None and keep[0] == (self.num_fp16_layers, self._epilogue_dtype(), self.fp8_branches):
+            bank, fp8 = keep[1], keep[2]
+        else:
+            # the twice-differentiable pass (R1) takes the weight bank too in the reduced-precision mode (round 5: the
+            # handles are views of the parameters and reach the Functions of the double backward with their attributes;
+            # -0.35 ms per R1 iteration of per-use scaling / casting launches); the fp32 parity mode keeps its bank-less form
+            r1_bank = double_backward and _R1_BANK and self.num_fp16_layers == -1
+            bank = None if ((double_backward and not r1_bank) or not h.is_cuda) else self._weight_bank()
+            fp8 = self._fp8_bank() if (bank is not None and self.fp8_branches and self.num_fp16_layers == -1) else None
+            if bank is not None:
+                self._bank_keep = ((self.num_fp16_layers, self._epilogue_dtype(), self.fp8_branches), bank, fp8)
         fused = (not double_backward and h.is_cuda and h.shape[1] == 1 and len(layers) > 3
                  and isinstance(layers[0], ops.BlurVH) and isinstance(layers[1], ops.Conv2d)
                  and isinstance(layers[2], ops.FusedLeakyReLU) and layers[2].bias is not None
                  and layers[1]._params_bias()[0] is None and tuple(layers[1].raw_weight().shape[1:]) == (2, 1, 1)
                  and layers[1].raw_weight().shape[0] in (8, 16, 32, 64))
+        xs0 = None
         if fused:
-            x = self._fused_stem(h, layers)
+            # the first block's skip blur leaves the stem's node too (its gradient is gathered inside the stem's backward)
+            # in the passes that take gradients, unless that block runs its e4m3 form (which quantises its own blur)
+            blk0 = layers[3] if len(layers) > 3 and isinstance(layers[3], ResidualBlock) else None
+            want = (blk0 is not None and _STEM_SKIP and torch.is_grad_enabled() and fp8 is None
+                    and (self.num_fp16_layers == -1 or self.num_fp16_layers == 0))
+            x = self._fused_stem(h, layers, down=blk0.blur_down if want else None)
+            if want:
+                x, xs0 = x
             i = 3
         else:
             x = ops.to_cl(h.float())
@@ -877,7 +911,8 @@ class Discriminator(nn.Module):
                 x = layer.forward_cl(x, act=nxt)  # stem conv + its bias/lrelu in one kernel
                 i += 2
             elif isinstance(layer, ResidualBlock):
-                x = layer.forward_cl(x, bank=bank, fp8=fp8)
+                x = layer.forward_cl(x, bank=bank, fp8=fp8, xs=xs0)
+                xs0 = None
                 i += 1
             else:
                 x = layer.forward_cl(x)

@@ -20,10 +20,14 @@ from .conv import *  # noqa: F401,F403
 # (reference: dusty_v2.py:364-367, common.py:141-155,187-210, fused_act.py:20-129)
 # ---------------------------------------------------------------------------------------
 class _Stem(Function):
-    """First-order only (the R1 double backward runs the composable ops instead)."""
+    """First-order only (the R1 double backward runs the composable ops instead).
+    down (a ResampleSpec or None): also return down(y) -- the decimating blur in front of the first ResidualBlock's skip
+    conv (dusty_v2.py:337-345) -- as a SECOND output, so that its gradient comes back to this node and is gathered inside
+    the stem's backward kernel (dgv2_stem_bwd_skip) instead of being scattered to a full-resolution tensor, added to
+    conv1's data gradient and read back."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, ring, alpha, scale, out_dtype):
+    def forward(ctx, x, w, bias, ring, alpha, scale, out_dtype, down=None):
         H, W_ = ctx_hw = _stem_hw(x)
         B = x.shape[0]
         x3 = x.detach().float().reshape(B, -1).contiguous()
@@ -35,15 +39,20 @@ class _Stem(Function):
         N.call("dgv2_stem_fwd", N.ptr(y), N.ptr(x3), N.ptr(w32), N.ptr(b32), B, H, W_, O, int(ring), alpha, scale,
                _dt(y), N.stream())
         ctx.save_for_backward(x3, w32, y)
-        ctx.cfg = (ctx_hw, ring, alpha, scale, tuple(x.shape), w.shape)
-        return y
+        ctx.cfg = (ctx_hw, ring, alpha, scale, tuple(x.shape), w.shape, down)
+        if down is None:
+            return y
+        ctx.set_materialize_grads(False)
+        return y, _resample_raw(y, down, False, (H, W_))
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, gsk=None):
         x3, w32, y = ctx.saved_tensors
-        (H, W_), ring, alpha, scale, xshape, wshape = ctx.cfg
+        (H, W_), ring, alpha, scale, xshape, wshape, down = ctx.cfg
         B, O = x3.shape[0], w32.shape[0]
+        if gy is None:   # (only the skip branch reached the loss: not a case of the training path)
+            gy = torch.zeros_like(y)
         gy = gy.contiguous().to(y.dtype)
         key = (B, H, W_, O)
         if key not in _STEM_SCRATCH:
@@ -54,9 +63,18 @@ class _Stem(Function):
         gw = torch.empty((O, 2), device=gy.device, dtype=torch.float32)
         gb = torch.empty(O, device=gy.device, dtype=torch.float32)
         gx = torch.empty((B, H * W_), device=gy.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        N.call("dgv2_stem_bwd", N.ptr(gx), N.ptr(gw), N.ptr(gb), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(y),
-               N.ptr(x3), N.ptr(w32), B, H, W_, O, int(ring), alpha, scale, _dt(y), N.stream())
-        return (None if gx is None else gx.reshape(xshape)), gw.reshape(wshape), gb, None, None, None, None
+        if gsk is not None:
+            gsk = gsk.contiguous().to(y.dtype)
+            Hs, Ws = down.out_size(H, W_)
+            (ih, chh, nh, Eh), (iw, cw, nw, Ew) = down.tables(H, W_, True, gy.device)   # the blur's adjoint tables
+            N.check(gsk)
+            N.call("dgv2_stem_bwd_skip", N.ptr(gx), N.ptr(gw), N.ptr(gb), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(y),
+                   N.ptr(x3), N.ptr(w32), N.ptr(gsk), N.ptr(ih), N.ptr(chh), N.ptr(nh), Eh, N.ptr(iw), N.ptr(cw), N.ptr(nw), Ew,
+                   Hs, Ws, B, H, W_, O, int(ring), alpha, scale, _dt(y), N.stream())
+        else:
+            N.call("dgv2_stem_bwd", N.ptr(gx), N.ptr(gw), N.ptr(gb), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(y),
+                   N.ptr(x3), N.ptr(w32), B, H, W_, O, int(ring), alpha, scale, _dt(y), N.stream())
+        return (None if gx is None else gx.reshape(xshape)), gw.reshape(wshape), gb, None, None, None, None, None
 
 
 _STEM_SCRATCH = {}
@@ -69,9 +87,10 @@ def _stem_hw(x):
     return (x.shape[2], x.shape[3]) if x.shape[1] == 1 else (x.shape[1], x.shape[2])
 
 
-def stem(x, w, bias, ring=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=torch.float32):
-    """x one-channel images; w [O,2,1,1] or [O,2] effective conv weight; bias [O] -> [B,H,W,O] channels-last."""
-    return _Stem.apply(x, w, bias, bool(ring), float(alpha), float(scale), out_dtype)
+def stem(x, w, bias, ring=True, alpha=0.2, scale=math.sqrt(2.0), out_dtype=torch.float32, down=None):
+    """x one-channel images; w [O,2,1,1] or [O,2] effective conv weight; bias [O] -> [B,H,W,O] channels-last.
+    down: a ResampleSpec -> (y, down(y)), the second output's gradient folded into the stem's backward (see _Stem)."""
+    return _Stem.apply(x, w, bias, bool(ring), float(alpha), float(scale), out_dtype, down)
 
 
 # ---------------------------------------------------------------------------------------

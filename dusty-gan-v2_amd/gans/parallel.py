@@ -367,6 +367,12 @@ def tail_exchange(named, ada_stats=None, module=None):
     own all-reduce (adaptive_augment.py:372-384) + the buffer broadcast before the next iteration's first forward
     (DDP broadcast_buffers=True, reference trainer.py:77; nothing touches the buffers in between).
     Returns (scalars averaged over ranks, summed ADA statistics or None).  No host synchronisation."""
+    if not is_dist():   # one process: nothing to exchange -- one stack launch (the callers' scalars are static graph buffers:
+        #                 the returned values must survive the next replay)
+        ks = list(named.keys())
+        vec1 = torch.stack([named[k].detach().float().reshape(()) for k in ks]) if ks else None
+        return ({k: vec1[i] for i, k in enumerate(ks)},
+                None if ada_stats is None else ada_stats.detach().float().reshape(-1))
     keys = list(named.keys())
     parts = [torch.stack([named[k].detach().float().reshape(()) for k in keys])] if keys else []
     n_sc = len(keys)

@@ -177,6 +177,7 @@ class Trainer:
         if self.native_rng:
             _native.rng_state(self.device)
         self._body = None
+        self._d_bank_fresh = False   # True between the G step's D forward and the next D optimizer step
 
         # resume
         self.start_iteration = 0
@@ -349,6 +350,7 @@ class Trainer:
         z = self._z("g")
         x_fake = self.G(z, noise=self._g_noise("g"), **self.auxin)["image"]
         y_fake = self.D(self.A(self.warmup(x_fake, self._draw("g.keep")), draws=self._ada("g.ada")))
+        self._d_bank_fresh = True    # D's weight bank now matches D's weights (until the next D optimizer step)
         y_real = None
         if x_real is not None:   # relativistic objectives only (trainer.py:279-285: the augmented reals are detached)
             with torch.no_grad():
@@ -384,7 +386,9 @@ class Trainer:
             self.A(self.warmup(x_fake, self._draw("d.keep_fake")), draws=self._ada("d.ada_fake"), out=x_both[self.B:])
         # D(real) and D(fake) in ONE pass over the discriminator (minibatch-stddev per half), instead of
         # the reference's two calls (trainer.py:391-392): same result, half the launches / weight reads
-        y = self.D(x_both, splits=2, **({"cut": True} if cut else {}))
+        # (the G step's D forward prepared the weight bank of these very weights: only G has moved since)
+        reuse = {"reuse_bank": True} if (self._d_bank_fresh and hasattr(self.D, "_bank_keep")) else {}
+        y = self.D(x_both, splits=2, **reuse, **({"cut": True} if cut else {}))
         y_real, y_fake = y[:self.B], y[self.B:]
         if self.adversarial_loss.can_fuse(y):
             # objective, its weighted gradient, both output means and ADA's sign statistic from one launch
@@ -662,6 +666,7 @@ class Trainer:
         for h in pending:
             self.d_sync.wait(h)
         self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
+        self._d_bank_fresh = False
 
         self._g_bufs_synced = False   # the D step's G forward moved this rank's ema_var / w_avg again
         r1_pending = None
@@ -678,11 +683,22 @@ class Trainer:
         # ONE small collective closes the iteration: the logged scalars, ADA's statistic pair when its update is due
         # (adaptive_augment.py:372-384) and rank 0's G buffers for the next iteration's first forward
         ada_due = iteration % self.lazy_ada == 0
-        out, ada_stats = parallel.tail_exchange(scalars, self.A.stats() if ada_due else None, self.G)
+
+        def tail(sc):
+            res, ada_stats = parallel.tail_exchange(scalars, self.A.stats() if ada_due else None, self.G)
+            if ada_due:
+                res["stats/ada_rt"] = self.A.update_p(stats=ada_stats).reshape(())
+                res["stats/ada_p"] = self.A.p.detach().clone()
+            sc.update(res)
+
+        if parallel.is_dist() and nacc == 1:
+            # the packing, the collective and the unpacking replay as a hipGraph too (one variant per set of logged keys:
+            # with / without ADA's update, with / without the R1 scalar); its inputs are the bodies' static scalar buffers
+            out = dict(self._run("tail/" + "+".join(sorted(scalars)) + ("/ada" if ada_due else ""), tail))
+        else:
+            out = {}
+            tail(out)
         self._g_bufs_synced = parallel.is_dist()
-        if ada_due:
-            out["stats/ada_rt"] = self.A.update_p(stats=ada_stats).reshape(())
-            out["stats/ada_p"] = self.A.p.detach().clone()
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
             self.d_sync.wait(r1_pending)
             self._run("d_opt", lambda sc: self._opt_step(self.optim_D))

@@ -670,6 +670,16 @@ int dgv2_stem_bwd_scratch(int64_t* elems, int B, int H, int W, int O);
 int dgv2_stem_bwd(float* gx, float* gw, float* gb, float* scratch, int64_t scratch_elems, const void* gy,
                   const void* y, const float* x, const float* w, int B, int H, int W, int O, int ring,
                   float alpha, float scale, int dtype, void* stream);
+/* ... with the gradient of the first ResidualBlock's skip branch folded in: gsk [B,Hs,Ws,O] (dtype) = dL/d(blur_down(y)),
+ * the decimating blur in front of ResidualBlock.skip (gans/models/dusty_v2.py:337-345), gathered through the blur's ADJOINT
+ * tables (idx_h / coef_h / cnt_h: H rows of Eh entries naming rows of gsk; idx_w / coef_w / cnt_w: W rows of Ew entries,
+ * exactly the tables dgv2_resample_tab takes for the adjoint pass): dL/dy = gy + blur_down^T(gsk) is never materialised
+ * (it was scattered to a [B,H,W,O] tensor by one pass, added to conv1's data gradient by another and read back here).
+ * gsk NULL: dgv2_stem_bwd. */
+int dgv2_stem_bwd_skip(float* gx, float* gw, float* gb, float* scratch, int64_t scratch_elems, const void* gy, const void* y,
+                       const float* x, const float* w, const void* gsk, const int* idx_h, const float* coef_h,
+                       const int* cnt_h, int Eh, const int* idx_w, const float* coef_w, const int* cnt_w, int Ew, int Hs,
+                       int Ws, int B, int H, int W, int O, int ring, float alpha, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * generator output stage: cancel the azimuth shift (circular bilinear shift),

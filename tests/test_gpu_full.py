@@ -399,3 +399,61 @@ def test_r1_pass_with_the_epilogue_conv_on_the_matrix_cores_matches_the_exact_fp
         # piecewise-linear network has no other second-order dependence on its biases) and amplify it ten-fold
         assert all(v < 5e-4 for v, k in rel if k.endswith("weight")), [r for r in rel if r[1].endswith("weight")][:4]
         assert rel[0][0] < 5e-3, rel[:4]
+
+
+def test_fp32_epilogue_on_bf16_features_keeps_its_x_exact_promise_at_b64():
+    """The timed configuration's discriminator epilogue (dusty_v2.py:376-379 in the fp32 island of :394-395) at B = 64 behind
+    the bf16 trunk: minibatch-stddev -> 3x3 513 -> 512 conv -> bias + leaky ReLU on conv_x3.hip with the `x_exact = 512`
+    promise Discriminator.forward makes for the trunk's features (three of six plane products skipped) against the ORACLE's
+    float64 epilogue evaluated on the same bf16 features: fp32-equivalent (the exact-fp32 kernel's own distance from
+    float64 is the yardstick), and the kernels' status word stays clear (no value broke the promise)."""
+    import math
+    import recipe
+    import dgv2_native as N
+    from gans.models.ops import native
+    from oracle import ops as o_ops
+    B, H, W = 64, 64, 512
+    _, D = build_models(full_cfg(True), "cpu")
+    sd = recipe.fill_state_dict({k: v.clone() for k, v in D.state_dict().items()}, 4321)
+    D.load_state_dict(sd)
+    D = D.to(DEV).train()
+    t = torch.linspace(0, 6.28, W)[None, None, None, :] * torch.arange(1, B + 1)[:, None, None, None]
+    xin = (torch.sin(t + torch.linspace(0, 3, H)[None, None, :, None]) * 0.8).to(DEV)
+    N.status_read()
+    with torch.no_grad():
+        feats = D(xin, features_only=True)                              # bf16 [B, 4, 32, 512], channels-last
+        assert feats.dtype == torch.bfloat16
+        mb, conv, act1 = D.epilogue[0], D.epilogue[1], D.epilogue[2]
+        cin = feats.shape[3] + mb.features
+        cpad = (cin + 15) // 16 * 16
+        bank = D._weight_bank()
+
+        def epilogue(promise):
+            x = native.mbstd_cat(feats, mb.group, 1, cpad, out_dtype=torch.float32)
+            if promise:
+                x._dgv2_exact = int(feats.shape[3])
+            return conv.forward_cl(x, pad_in_to=cpad, act=act1, bank=bank)
+        got = epilogue(True)
+        full = epilogue(False)
+        assert N.status_read() == 0, "a trunk feature was not bf16-representable: the x_exact promise is broken"
+        assert torch.equal(got, full)                                    # the skipped products are products with zero
+        # the same epilogue on the exact-fp32 MFMA kernel (no plane images): the yardstick
+        from gans.models.ops.native import conv as cv
+        old = cv._CONV_X3
+        cv._CONV_X3 = False
+        try:
+            exact32 = epilogue(False)
+        finally:
+            cv._CONV_X3 = old
+    # float64 oracle on the same features
+    f64 = feats.float().permute(0, 3, 1, 2).double().cpu()
+    h = o_ops.minibatch_stddev(f64, mb.group, mb.features)
+    h = o_ops.equal_lr_conv2d(h, sd["epilogue.1.1.module.weight"].double(), 1, 1, True)
+    want = o_ops.fused_leaky_relu(h, sd["epilogue.2.bias"].double())
+    g = got.permute(0, 3, 1, 2).double().cpu()
+    e32 = exact32.permute(0, 3, 1, 2).double().cpu()
+    scale = float(want.abs().max())
+    err_x3 = float((g - want).abs().max()) / scale
+    err_32 = float((e32 - want).abs().max()) / scale
+    assert err_x3 <= max(2 * err_32, 2e-6), (err_x3, err_32)
+    assert err_x3 < 1e-5, err_x3

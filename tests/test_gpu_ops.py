@@ -1897,3 +1897,25 @@ def test_heads_contraction_in_conv2_epilogue(nat, C, P):
     assert torch.equal(fused2, plain) and torch.equal(head2[1], head[1])
     n = sq[1].value
     assert n > 0 and abs(float(sq[0][:n].sum()) - float(plain.float().square().sum())) <= 1e-4 * float(plain.float().square().sum())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_stem_with_the_skip_blur_as_second_output(nat, dtype, tol):
+    """native.stem(..., down=spec): (x, blur_down(x)) from one node whose backward gathers the second output's gradient
+    through the blur's adjoint tables inside the stem kernel (dgv2_stem_bwd_skip) -- against the two-node composition."""
+    g = torch.Generator().manual_seed(17)
+    B, H, W, O = 3, 16, 64, 32
+    img = torch.randn(B, 1, H, W, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(O, 2, 1, 1, generator=g) / 2).to(DEV).requires_grad_(True)
+    b = torch.randn(O, generator=g).to(DEV).requires_grad_(True)
+    spec = nat.ResampleSpec([1, 3, 3, 1], down=(2, 2), ring=True, pads=(2, 1))
+    gx = torch.randn(B, H, W, O, generator=g).to(dtype).to(DEV)
+    gs = torch.randn(B, H // 2, W // 2, O, generator=g).to(dtype).to(DEV)
+    x1, xs1 = nat.stem(img, w, b, True, 0.2, 2.0 ** 0.5, dtype, down=spec)
+    g1 = torch.autograd.grad([x1, xs1], [img, w, b], [gx, gs])
+    x2 = nat.stem(img, w, b, True, 0.2, 2.0 ** 0.5, dtype)
+    xs2 = nat.resample(x2, spec)
+    g2 = torch.autograd.grad([x2, xs2], [img, w, b], [gx, gs])
+    assert torch.equal(x1, x2) and torch.equal(xs1, xs2)
+    for a, c, what in zip(g1, g2, ("image", "weight", "bias")):
+        assert_rel(a.double().cpu(), c.double().cpu(), tol, what)
