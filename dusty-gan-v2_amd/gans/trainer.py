@@ -178,6 +178,7 @@ class Trainer:
             _native.rng_state(self.device)
         self._body = None
         self._d_bank_fresh = False   # True between the G step's D forward and the next D optimizer step
+        self._gp_scalar = torch.zeros((), device=self.device)   # the last R1 penalty (input of the captured tail exchange)
 
         # resume
         self.start_iteration = 0
@@ -691,10 +692,22 @@ class Trainer:
                 res["stats/ada_p"] = self.A.p.detach().clone()
             sc.update(res)
 
-        if parallel.is_dist() and nacc == 1:
-            # the packing, the collective and the unpacking replay as a hipGraph too (one variant per set of logged keys:
-            # with / without ADA's update, with / without the R1 scalar); its inputs are the bodies' static scalar buffers
-            out = dict(self._run("tail/" + "+".join(sorted(scalars)) + ("/ada" if ada_due else ""), tail))
+        gp_key = "loss/D/gradient_penalty"
+        captured_tail = (parallel.is_dist() and nacc == 1 and self.use_graphs and self.device.type == "cuda"
+                         and torch.distributed.get_backend() == "nccl")
+        if captured_tail:
+            # The packing, the collective and the unpacking replay as a hipGraph too; its inputs are the bodies' static
+            # scalar buffers.  Two variants only (ADA's update due or not): the R1 scalar, present every lazy.gp-th
+            # iteration, travels EVERY iteration from a buffer of its own, so that no new key set -- i.e. no capture --
+            # turns up deep into a run (a capture costs milliseconds; bench.py's timed region met one).
+            if gp_key in scalars:
+                self._gp_scalar.copy_(scalars[gp_key].reshape(()))
+            had_gp = gp_key in scalars
+            scalars = dict(scalars)
+            scalars[gp_key] = self._gp_scalar
+            out = dict(self._run("tail" + ("/ada" if ada_due else ""), tail))
+            if not had_gp:
+                out.pop(gp_key, None)
         else:
             out = {}
             tail(out)
