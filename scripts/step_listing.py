@@ -27,8 +27,10 @@ BUCKETS = collections.OrderedDict([
     ("modconv_pe", r"modconv_pe"), ("modconv_up", r"modconv_up|up2_lag"), ("pe_wgrad", r"pe_wgrad"), ("gemm_x3", r"gemm_x3"),
     ("stem", r"stem_"), ("adam/lerp", r"adam_|lerp_list"), ("ema/pack/bank", r"ema_scalar|pack2d|weight_bank"),
     ("glin/bmm/colsum", r"glin_|bmm_|colsum|transpose_list"), ("mbstd/loss", r"mbstd|loss|nsgan"),
-    ("zero", r"dgv2_zero"), ("rng", r"dgv2_rng|philox"), ("blas", r"Cijk|rocblas|hipblas"),
-    ("rccl", r"nccl|rccl"), ("memcpy", r"copyBuffer|fillBuffer"), ("aten", r"at::native|at_cuda|elementwise|reduce_kernel"),
+    ("zero", r"dgv2_zero"), ("rng", r"rng_fill|philox"), ("head_bwd", r"head_bwd_kernel"), ("mod_stats", r"mod_stats"),
+    ("scale_cast/shift", r"scale_cast|ring_shift"), ("blas", r"Cijk|rocblas|hipblas"),
+    ("rccl", r"nccl|rccl|oneRankReduce"), ("memcpy", r"copyBuffer|fillBuffer"), ("aten", r"at::native|at_cuda"),
+    ("reducers (own)", r"_reduce_kernel"),
     ("other", r".*")])
 
 
