@@ -8,7 +8,10 @@ args = argparse.Namespace(batch_per_gpu=64, dtype="bf16", ada_p=0.6, no_graph=Fa
 from gans.trainer import Trainer
 from gans.utils import init_random_seed
 init_random_seed(0, 0)
-tr = Trainer(bench.make_cfg(args, 0, 1), sync_scalars=False)
+cfg = bench.make_cfg(args, 0, 1)
+if os.environ.get("DGV2_TORCH_RNG"):   # A/B: torch's generator instead of the one-launch Philox draws
+    cfg.training.native_rng = False
+tr = Trainer(cfg, sync_scalars=False)
 hist = []
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 for it in range(1, N + 1):
