@@ -72,6 +72,9 @@ struct C8Cfg {
 // registers, one more pixel-fragment read (conv_pipe_kernel's F33 = 2 form).
 // WIMG: w is the staging image (C8::wimg); a template parameter because the two addressing forms together cost the
 // 256-register instances five spilled dwords
+#ifndef DGV2_C8_SPREAD
+#define DGV2_C8_SPREAD 1
+#endif
 template <typename T, typename TY, int S, int GM, int GN, int RW, int HZ, bool WIMG>
 __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict__ y, const T* __restrict__ x,
                                                                  const T* __restrict__ w, C8 p) {
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
   constexpr int ICOLS = Cf::ICOLS, NPIX = Cf::NPIX, PITCH = Cf::PITCH, LIVE = Cf::LIVE;
   constexpr int NI = Cf::NI, PIN = Cf::PIN, PW = Cf::PW, TS = Cf::TS, NW = Cf::NW;
   static_assert(GM * GN == 2, "two groups of four waves");
+  constexpr int SPREAD = DGV2_C8_SPREAD;
   static_assert(MF % NF == 0, "A fragments are re-read in equal shares behind the pixel-fragment groups");
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   __shared__ __attribute__((aligned(16))) float s_bias[GM * 64];
@@ -152,24 +156,28 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
 
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   u32x4 rin[NI], rwt[NW];
-  auto issue_in = [&](int c0) {
+  // loads [j0, j1) of a stage's input slots / weight slots (the whole stage in the prologue; one ninth per tap inside the
+  // MFMA loop: a wave that issues all of a stage's loads in one burst sits in front of the full memory queue until most
+  // of them have returned -- its MFMA loop then starts when the loads are nearly over, and the two phases add up)
+  auto issue_in = [&](int c0, int j0, int j1) {
     if (C8_ABL & 4) return;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) rin[j] = *reinterpret_cast<const u32x4*>(xb + c0 + (unsigned)goff[j]);
+    for (int j = 0; j < NI; ++j)
+      if (j >= j0 && j < j1) rin[j] = *reinterpret_cast<const u32x4*>(xb + c0 + (unsigned)goff[j]);
   };
-  auto issue_w = [&](int c0) {
+  auto issue_w = [&](int c0, int j0, int j1) {
     if (C8_ABL & 8) return;
     if constexpr (WIMG) {
       const u32x4* img = reinterpret_cast<const u32x4*>(w) + ((size_t)(o0 >> 6) * nchunks + c0 / kchunk) * (PW * 4) + uw;
 #pragma unroll
       for (int j = 0; j < NW; ++j)
-        if (TS * (NW - 1) + (TS - 1) < 9 || t0 + TS * j < 9) rwt[j] = img[UW * j];
+        if (j >= j0 && j < j1 && (TS * (NW - 1) + (TS - 1) < 9 || t0 + TS * j < 9)) rwt[j] = img[UW * j];
     } else {
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         const int t = t0 + TS * j;
         const T* wu = w + (p.widx0 + TS * j * p.wstep) * p.Cin + c0;
-        if (TS * (NW - 1) + (TS - 1) < 9 || t < 9) rwt[j] = *reinterpret_cast<const u32x4*>(wu + wlane);
+        if (j >= j0 && j < j1 && (TS * (NW - 1) + (TS - 1) < 9 || t < 9)) rwt[j] = *reinterpret_cast<const u32x4*>(wu + wlane);
       }
     }
   };
@@ -180,7 +188,10 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < NF; ++nf) {
+      acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+v"(acc[mf][nf]));   // written here, not between the first stage's MFMAs (see the epilogue)
+    }
 
   int bpix[NF];
 #pragma unroll
@@ -208,8 +219,8 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
   }
 
   tile_offsets(st0);
-  issue_in(0);
-  issue_w(0);
+  issue_in(0, 0, NI);
+  issue_w(0, 0, NW);
   int tile = 0, cc = 0;
   const int nstage = ntile * nchunks;
   for (int s = 0; s < nstage; ++s) {
@@ -225,10 +236,11 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
     }
     int ntile_i = tile, ncc = cc + 1;
     if (ncc == nchunks) { ncc = 0; ++ntile_i; }
-    if (s + 1 < nstage) {
-      if (ncc == 0) tile_offsets(st0 + ntile_i);
-      issue_in(ncc * kchunk);
-      if (nchunks > 1) issue_w(ncc * kchunk);
+    const bool more = s + 1 < nstage;
+    if (more && ncc == 0) tile_offsets(st0 + ntile_i);
+    if (more && (SPREAD == 0 || (C8_ABL & 2))) {
+      issue_in(ncc * kchunk, 0, NI);
+      if (nchunks > 1) issue_w(ncc * kchunk, 0, NW);
     }
     __syncthreads();                // stage s visible in LDS
 
@@ -258,7 +270,10 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
           __builtin_amdgcn_sched_barrier(0);
           if (!(HZ && ((dd[nf >> 1] >> t) & 1u))) {
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[mf][nf], a[t & 1][mf], bb[nf]);
+            for (int mf = 0; mf < MF; ++mf) {
+              if (mf < MF - 1) MfmaAsm<T>::run(acc[mf][nf], a[t & 1][mf], bb[nf]);
+              else MfmaAsm<T>::run_pad(acc[mf][nf], a[t & 1][mf], bb[nf]);
+            }
           }
           if constexpr (HZ != 0) {
             // replicate-row border term: this group's row has its MIRRORED tap dead (t - 6 at the first row, t + 6 at
@@ -269,16 +284,23 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
               if ((dd[nf >> 1] >> tm) & 1u) {
                 const uint4 bx = b_base[bpix[nf] + ICOLS + t % 3];
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[mf][nf], a[t & 1][mf], bx);
+                for (int mf = 0; mf < MF; ++mf) {
+                  if (mf < MF - 1) MfmaAsm<T>::run(acc[mf][nf], a[t & 1][mf], bx);
+                  else MfmaAsm<T>::run_pad(acc[mf][nf], a[t & 1][mf], bx);
+                }
               }
             }
             // The branches of this variant put compiler-generated VALU instructions (v_cndmask of the next group's
             // condition) right behind a group's last MFMA -- into a register that MFMA is still reading as its B operand
             // (found by scripts/audit_asm_mfma.py; the hazard recogniser does not see inside the asm).  Five wait states
-            // cover a 4-pass MFMA's source reads.
-            asm volatile("s_nop 4");
+            // cover a 4-pass MFMA's source reads: they are part of the group's last statement (run_pad).
           }
           __builtin_amdgcn_sched_barrier(0);
+          if (SPREAD != 0 && nf == NF - 1 && more) {   // this tap's ninth of the next stage's loads
+            issue_in(ncc * kchunk, t * NI / 9, (t + 1) * NI / 9);
+            if (nchunks > 1) issue_w(ncc * kchunk, t * NW / 9, (t + 1) * NW / 9);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if (t + 1 < 9) {
             const int ky = (t + 1) / 3, kx = (t + 1) % 3;
             const int tapoff = S == 2 ? (ky * 2 + (kx & 1)) * PITCH + (kx >> 1) : ky * ICOLS + kx;
@@ -336,7 +358,12 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
           }
         }
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mf = 0; mf < MF; ++mf) {
+          acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          // the zeros are written HERE: sunk into the next stage's tap loop they land between asm MFMAs, in registers
+          // one of them is still reading as an operand (scripts/audit_asm_mfma.py found exactly that)
+          asm volatile("" : "+v"(acc[mf][nf]));
+        }
       }
     }
     tile = ntile_i; cc = ncc;

@@ -63,6 +63,14 @@ template <> struct MfmaAsm<bf16_t> {
     ub.u = b;
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ua.v), "v"(ub.v));
   }
+  // the LAST MFMA of a group that compiler-generated code may follow (a branch condition, a merged register): its five
+  // wait states travel inside the statement, so nothing can be scheduled between the MFMA and them
+  __device__ static __forceinline__ void run_pad(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; bf16x8 v; } ua, ub;
+    ua.u = a;
+    ub.u = b;
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 4" : "+v"(acc) : "v"(ua.v), "v"(ub.v));
+  }
 };
 template <> struct MfmaAsm<fp8_t> {   // see Mfma16<fp8_t>
   __device__ static __forceinline__ void run(f32x4& acc, const uint4& a, const uint4& b) {
@@ -70,6 +78,12 @@ template <> struct MfmaAsm<fp8_t> {   // see Mfma16<fp8_t>
     const u32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
     asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a0), "v"(b0));
     asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a1), "v"(b1));
+  }
+  __device__ static __forceinline__ void run_pad(f32x4& acc, const uint4& a, const uint4& b) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc) : "v"(a0), "v"(b0));
+    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0\n\ts_nop 4" : "+v"(acc) : "v"(a1), "v"(b1));
   }
 };
 template <> struct MfmaAsm<float> {
