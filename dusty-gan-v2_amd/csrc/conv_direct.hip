@@ -139,6 +139,9 @@ __device__ __forceinline__ void store_frag(const DConv& p, T* __restrict__ row, 
 // because every tap that would read them is a dead tap of that output row and is skipped (the host checks that the
 // border extras read real rows).
 // TY: type of y / resid (= T, or bf16 for e4m3 operands T = fp8_t)
+#ifndef DGV2_CP_SPREAD
+#define DGV2_CP_SPREAD 1
+#endif
 template <typename T, typename TY, int TO, int RW, int NI, int NC, int F33>
 __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void conv_pipe_kernel(TY* __restrict__ y, const T* __restrict__ x,
                                                            const T* __restrict__ w, DConv p) {
@@ -254,10 +257,14 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
 
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   u32x4 rin[NI], rwt[NW];   // native vectors: as HIP's uint4 structs the unconditional F33 loads left both arrays in scratch
-  auto issue_in = [&](int c0) {
+  // slots [j0, j1) of a stage (F33: a ninth per tap inside the MFMA loop -- a wave that issues a whole stage in one burst
+  // waits at the full memory queue until most of it has returned, and its MFMA loop starts when the loads are nearly over;
+  // conv8.hip, measured there)
+  auto issue_in = [&](int c0, int j0 = 0, int j1 = 1 << 20) {
     if (CP_ABL & 4) return;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
+      if (j < j0 || j >= j1) continue;
       if constexpr (F33 != 0) {
         rin[j] = *reinterpret_cast<const u32x4*>(xb + c0 + (unsigned)goff[j]);
       } else {
@@ -266,10 +273,11 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
       }
     }
   };
-  auto issue_w = [&](int c0) {
+  auto issue_w = [&](int c0, int j0 = 0, int j1 = 1 << 20) {
     if (CP_ABL & 8) return;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
+      if (j < j0 || j >= j1) continue;
       if constexpr (F33 != 0) {   // uniform pointer of tap j's weights + this thread's 32-bit offset (TO = 64: slot j IS tap j)
         const T* wu = w + (p.widx[0] + j * (p.widx[1] - p.widx[0])) * p.Cin + c0;
         rwt[j] = *reinterpret_cast<const u32x4*>(wu + wlane);
@@ -352,8 +360,10 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
     // prefetch stage s+1
     int ntile_i = tile, ncc = cc + 1;
     if (ncc == nchunks) { ncc = 0; ++ntile_i; }
-    if (s + 1 < nstage) {
-      if (ncc == 0) tile_offsets(tw0 + ntile_i);
+    const bool more = s + 1 < nstage;
+    constexpr bool SPREAD = F33 != 0 && DGV2_CP_SPREAD != 0;
+    if (more && ncc == 0) tile_offsets(tw0 + ntile_i);
+    if (more && (!SPREAD || (CP_ABL & 2))) {
       issue_in(ncc * kchunk);
       if (!wres && nchunks > 1) issue_w(ncc * kchunk);
     }
@@ -387,7 +397,10 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
           __builtin_amdgcn_sched_barrier(0);
           if (!(F33 == 2 && ((dd[nf >> 1] >> t) & 1u))) {
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[0][mf][nf], a[t & 1][mf], bb[nf]);
+            for (int mf = 0; mf < MF; ++mf) {
+              if (mf < MF - 1) MfmaAsm<T>::run(acc[0][mf][nf], a[t & 1][mf], bb[nf]);
+              else MfmaAsm<T>::run_pad(acc[0][mf][nf], a[t & 1][mf], bb[nf]);   // compiler code may follow: wait states inside
+            }
           }
           if constexpr (F33 == 2 && NI <= 6) {   // (the image-pair instances, NI = 7, are at their register limit: extras)
             // replicate-row border term (p.border): the row this group belongs to has its MIRRORED tap dead (t - 6 at the
@@ -398,11 +411,19 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
               if (p.border && ((dd[nf >> 1] >> tm) & 1u)) {
                 const uint4 bx = b_base[bpix[nf] + COLS + t % 3];
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf) MfmaAsm<T>::run(acc[0][mf][nf], a[t & 1][mf], bx);
+                for (int mf = 0; mf < MF; ++mf) {
+                  if (mf < MF - 1) MfmaAsm<T>::run(acc[0][mf][nf], a[t & 1][mf], bx);
+                  else MfmaAsm<T>::run_pad(acc[0][mf][nf], a[t & 1][mf], bx);
+                }
               }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
+          if (SPREAD && nf == NF - 1 && more) {   // this tap's ninth of the next stage's loads
+            issue_in(ncc * kchunk, t * NI / 9, (t + 1) * NI / 9);
+            if (!wres && nchunks > 1) issue_w(ncc * kchunk, t * NW / 9, (t + 1) * NW / 9);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if (t + 1 < 9) {   // this group's pixel fragment is consumed: re-read it, and a share of the weights, for tap t+1
             bb[nf] = b_base[bpix[nf] + ((t + 1) / 3) * COLS + (t + 1) % 3];
 #pragma unroll

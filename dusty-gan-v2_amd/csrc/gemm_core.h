@@ -93,6 +93,12 @@ template <> struct MfmaAsm<float> {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.z), "v"(b.z));
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.w), "v"(b.w));
   }
+  __device__ static __forceinline__ void run_pad(f32x4& acc, const uint4& a, const uint4& b) {   // 8 passes: eleven wait states
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.x), "v"(b.x));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.y), "v"(b.y));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a.z), "v"(b.z));
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop 10" : "+v"(acc) : "v"(a.w), "v"(b.w));
+  }
 };
 // every MFMA issued so far has written its accumulator when this returns (the longest of the shapes used here takes
 // 8 passes = 32 cycles; the fences keep the scheduler from moving accumulator reads in front of the wait)
