@@ -296,6 +296,8 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
             // cover a 4-pass MFMA's source reads: they are part of the group's last statement (run_pad).
           }
           __builtin_amdgcn_sched_barrier(0);
+          // Measured against this form (gpurun_out/r7e): the same loads over the first 6 or 4 taps, input slots before
+          // weight slots, a share per pixel-fragment group -- each 1-6 % slower on the stride-2 layers.
           if (SPREAD != 0 && nf == NF - 1 && more) {   // this tap's ninth of the next stage's loads
             issue_in(ncc * kchunk, t * NI / 9, (t + 1) * NI / 9);
             if (nchunks > 1) issue_w(ncc * kchunk, t * NW / 9, (t + 1) * NW / 9);

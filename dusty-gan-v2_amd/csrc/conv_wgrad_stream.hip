@@ -243,6 +243,9 @@ __device__ __forceinline__ uint4 wz_tr_read(const char* p0, const char* p1) {
   return r.u;
 }
 
+#ifndef DGV2_WS_SPREAD
+#define DGV2_WS_SPREAD 1
+#endif
 template <int S, int MFN, int NFN, bool K3, int GO>
 __global__ __launch_bounds__(256 * GO, 2) void conv_wgrad_stream_bf16_kernel(float* __restrict__ part,
                                                                              const bf16_t* __restrict__ gy,
@@ -289,33 +292,47 @@ __global__ __launch_bounds__(256 * GO, 2) void conv_wgrad_stream_bf16_kernel(flo
 
   uint4 rg[NG], rx[NX];
   int tw_n, th_n, b_n;           // (column tile, row tile, image) of the NEXT tile to load
-  auto issue = [&]() {           // global loads of that tile into registers, then advance
-    const int h0 = th_n * WR, w0 = tw_n * 32;
-    const bf16_t* gyb = gy + (int64_t)b_n * g.Ho * g.Wo * g.O + o0;
-    const bf16_t* xb = x + (g.x_shared ? 0 : (int64_t)b_n * g.H * g.W * g.C) + c0;
+  int h0_l, w0_l;                // ... of the tile being loaded
+  const bf16_t *gyb_l, *xb_l;
+  auto issue_begin = [&]() {     // fix the tile the coming loads belong to, then advance
+    h0_l = th_n * WR; w0_l = tw_n * 32;
+    gyb_l = gy + (int64_t)b_n * g.Ho * g.Wo * g.O + o0;
+    xb_l = x + (g.x_shared ? 0 : (int64_t)b_n * g.H * g.W * g.C) + c0;
     if (++tw_n == g.tiles_w) {
       tw_n = 0;
       if (++th_n == g.tiles_h) { th_n = 0; ++b_n; }
     }
+  };
+  // slots [k0, k1) of the NG + NX loads of that tile (gy slots first).  The asm-MFMA instances issue them a share per
+  // (row, tap) of the MFMA loop: a wave that issues a whole tile in one burst waits at the full memory queue until most of
+  // it has returned, and its MFMA loop starts when the loads are nearly over (conv8.hip, measured there)
+  auto issue_part = [&](int k0, int k1) {
+    const int h0 = h0_l, w0 = w0_l;
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
+      if (j < k0 || j >= k1) continue;
       const int id = tid + j * NTHR;
       const int ho = h0 + (gpix[j] >> 8), wo = w0 + (gpix[j] & 255);
       rg[j] = make_uint4(0, 0, 0, 0);
       if (gpix[j] >= 0 && ho < g.Ho && wo < g.Wo)
-        rg[j] = *reinterpret_cast<const uint4*>(gyb + (ho * g.Wo + wo) * g.O + (id % GVT) * 8);
+        rg[j] = *reinterpret_cast<const uint4*>(gyb_l + (ho * g.Wo + wo) * g.O + (id % GVT) * 8);
     }
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
+      if (NG + j < k0 || NG + j >= k1) continue;
       const int id = tid + j * NTHR;
       int hi = h0 * S - off + (xpos[j] >> 16), wi = w0 * S - off + (xpos[j] & 0xffff);
       hi = hi < 0 ? 0 : (hi >= g.H ? g.H - 1 : hi);
       if (g.ring == 2) wi = wi < 0 ? wi + g.W : (wi >= g.W ? wi - g.W : wi);   // host-checked: one wrap suffices
       else wi = g.ring ? floormod(wi, g.W) : (wi < 0 ? 0 : (wi >= g.W ? g.W - 1 : wi));
       rx[j] = make_uint4(0, 0, 0, 0);
-      if (xpos[j] >= 0) rx[j] = *reinterpret_cast<const uint4*>(xb + (hi * g.W + wi) * g.C + (id % XV) * 8);
+      if (xpos[j] >= 0) rx[j] = *reinterpret_cast<const uint4*>(xb_l + (hi * g.W + wi) * g.C + (id % XV) * 8);
     }
   };
+  auto issue = [&]() { issue_begin(); issue_part(0, NG + NX); };
+  // measured (gpurun_out/r7d): the eight-wave stride-2 instances (one block per CU, its waves in lockstep) gain 3-4 %; the
+  // four-wave instances (two blocks per CU cover each other's load phase) lose 30-50 % to the predicated loads among the MFMAs
+  constexpr bool SPREAD = MFN == 4 && NFN == 4 && GO == 2 && DGV2_WS_SPREAD != 0;
 
   f32x4 acc[NT][MW];
 #pragma unroll
@@ -352,7 +369,9 @@ __global__ __launch_bounds__(256 * GO, 2) void conv_wgrad_stream_bf16_kernel(flo
 #pragma unroll
     for (int j = 0; j < NX; ++j)
       if (tid + j * NTHR < n_x) lds_x[xw_[j]] = rx[j];
-    if (t + 1 < t_end) issue();
+    const bool more = t + 1 < t_end;
+    if (more) issue_begin();
+    if (more && (!SPREAD || (WS_ABL & 2))) issue_part(0, NG + NX);
     __syncthreads();
     if (WS_ABL & 2) continue;
 #pragma unroll
@@ -381,9 +400,23 @@ __global__ __launch_bounds__(256 * GO, 2) void conv_wgrad_stream_bf16_kernel(flo
             union { uint4 u; bf16x8 v; } ua, ub;
             ua.u = a[mw];
             ub.u = bb;
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[tap][mw]) : "v"(ua.v), "v"(ub.v));
+            // (the last MFMA of a tap carries five wait states: the loads below bring compiler code -- zero fills,
+            // address arithmetic, exec masks -- right behind it; scripts/audit_asm_mfma.py)
+            if (mw < MW - 1 || !SPREAD)
+              asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[tap][mw]) : "v"(ua.v), "v"(ub.v));
+            else
+              asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 4" : "+v"(acc[tap][mw]) : "v"(ua.v), "v"(ub.v));
           } else {   // the smaller tiles have registers to spare and schedule better with the builtin
             Mfma16<bf16_t>::run(acc[tap][mw], a[mw], bb);
+          }
+        }
+        if constexpr (SPREAD) {
+          if (more) {
+            constexpr int NSLOT = WR * NT;
+            const int k = r * NT + tap;
+            __builtin_amdgcn_sched_barrier(0);
+            issue_part(k * (NG + NX) / NSLOT, (k + 1) * (NG + NX) / NSLOT);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
