@@ -361,6 +361,8 @@ __global__ __launch_bounds__(256, (TO <= 32 && NC == 1 && NI <= 6) ? 3 : 2) void
     int ntile_i = tile, ncc = cc + 1;
     if (ncc == nchunks) { ncc = 0; ++ntile_i; }
     const bool more = s + 1 < nstage;
+    // (not the four-class tap list of the stride-2 data gradient: with its predicated zero-fill loads among the builtin
+    // MFMAs that kernel spills and runs 90 -> 128 us, gpurun_out/r7g)
     constexpr bool SPREAD = F33 != 0 && DGV2_CP_SPREAD != 0;
     if (more && ncc == 0) tile_offsets(tw0 + ntile_i);
     if (more && (!SPREAD || (CP_ABL & 2))) {
