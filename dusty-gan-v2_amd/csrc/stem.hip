@@ -80,6 +80,62 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(T* __restrict__ y, const 
   }
 }
 
+// The same pass with one thread = FOUR pixels along W x 8 output channels (W % 4 == 0): three 16-byte loads and two
+// neighbours for four pixels instead of twenty scalar loads, one coordinate division per four stores -- the
+// one-pixel form wrote 268 MB in 75 us (3.6 TB/s), bound by its load latency and address arithmetic, not by the stores.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd4_kernel(T* __restrict__ y, const float* __restrict__ x,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        StemGeom g) {
+  const int G = g.O / 8, W4 = g.W >> 2;
+  const int64_t items = (int64_t)g.B * g.H * W4 * G;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;   // multiple of G (host-checked)
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = (int)(i % G);
+  float w0[8], w1[8], bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    w0[j] = w[(grp * 8 + j) * 2];
+    w1[j] = w[(grp * 8 + j) * 2 + 1];
+    bs[j] = bias ? bias[grp * 8 + j] : 0.f;
+  }
+  const int HW4 = g.H * W4;
+  for (; i < items; i += stride) {
+    const int64_t q = i / G;
+    const int b = (int)(q / HW4), r = (int)(q - (int64_t)b * HW4);
+    const int h = r / W4, wc = (r - h * W4) << 2;
+    const float* xb = x + ((int64_t)b * g.H) * g.W;
+    const float4 c4 = *reinterpret_cast<const float4*>(xb + h * g.W + wc);
+    const float4 u4 = *reinterpret_cast<const float4*>(xb + (h > 0 ? h - 1 : 0) * g.W + wc);
+    const float4 d4 = *reinterpret_cast<const float4*>(xb + (h + 1 < g.H ? h + 1 : g.H - 1) * g.W + wc);
+    const float lf = xb[h * g.W + stem_wcoord(wc - 1, g.W, g.ring)], rt = xb[h * g.W + stem_wcoord(wc + 4, g.W, g.ring)];
+    const float c[6] = {lf, c4.x, c4.y, c4.z, c4.w, rt};
+    const float up[4] = {u4.x, u4.y, u4.z, u4.w}, dn[4] = {d4.x, d4.y, d4.z, d4.w};
+    T* out = y + (((int64_t)b * g.H + h) * g.W + wc) * g.O + grp * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v = 0.25f * (up[k] + dn[k]) + 0.5f * c[k + 1];       // the operation order of stem_blur: same bits
+      const float u = 0.25f * (c[k] + c[k + 2]) + 0.5f * c[k + 1];
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = w0[j] * v + w1[j] * u + bs[j];
+        f[j] = (t > 0.f ? t : t * g.alpha) * g.scale;
+      }
+      if constexpr (sizeof(T) == 2) {
+        vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.set(j, f[j]);
+        if (g.nt) o.store_nt(out + k * g.O);
+        else o.store(out + k * g.O);
+      } else {
+        *reinterpret_cast<float4*>(out + k * g.O) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(out + k * g.O + 4) = make_float4(f[4], f[5], f[6], f[7]);
+      }
+    }
+  }
+}
+
 // The stem's output feeds the first ResidualBlock twice: conv1, and the skip branch through a decimating blur
 // (dusty_v2.py:337-345: self.skip(self.resample(x)), evaluated at the even positions only).  SKIP: the gradient of that
 // blurred / decimated image, gsk [B, Hs, Ws, O], is gathered HERE through the ADJOINT tables of the blur (rows of the
@@ -287,9 +343,18 @@ extern "C" int dgv2_stem_fwd(void* y, const float* x, const float* w, const floa
                              int ring, float alpha, float scale, int ydtype, void* stream) {
   if (!y || !x || !w || !stem_ok(B, H, W, O) || !aligned16(y)) return DGV2_EINVAL;
   StemGeom g{B, H, W, O, ring, alpha, scale, nt_output((int64_t)B * H * W * O * (ydtype == DGV2_BF16 ? 2 : 4)) ? 1 : 0};
+  hipStream_t st = (hipStream_t)stream;
+  static const bool no4 = getenv("DGV2_STEM_NO4") != nullptr;   // A/B switch for benchmarking
+  if (W % 4 == 0 && aligned16(x) && !no4) {
+    const int64_t items = (int64_t)B * H * (W / 4) * (O / 8);
+    const int grid = grid_for(items, 256, 256 * 32);
+    if (ydtype == DGV2_BF16) stem_fwd4_kernel<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)y, x, w, bias, g);
+    else if (ydtype == DGV2_F32) stem_fwd4_kernel<float><<<grid, 256, 0, st>>>((float*)y, x, w, bias, g);
+    else return DGV2_EINVAL;
+    DGV2_RETURN_LAST();
+  }
   const int64_t items = (int64_t)B * H * W * (O / 8);
   const int grid = grid_for(items, 256, 256 * 32);
-  hipStream_t st = (hipStream_t)stream;
   if (ydtype == DGV2_BF16) stem_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)y, x, w, bias, g);
   else if (ydtype == DGV2_F32) stem_fwd_kernel<float><<<grid, 256, 0, st>>>((float*)y, x, w, bias, g);
   else return DGV2_EINVAL;
