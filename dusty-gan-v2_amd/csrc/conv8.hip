@@ -319,6 +319,24 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
       mfma_drain();
       const int w0 = ((st0 + tile) * GN + gn) * 32;
       const TY* rbase = reinterpret_cast<const TY*>(p.resid);
+      // The residual (the data gradient's sibling branch) is fetched for the WHOLE tile before the first store: `y` and
+      // `resid` may alias as far as the compiler knows, so a load written next to its store stays behind every earlier
+      // store -- eight dependent round trips per tile, and a block walks up to eight tiles.
+      // (data-gradient instances only: the forward instances are at their register limit and run without a residual)
+      constexpr bool RPRE = HZ != 0;
+      vec16<TY> vres[RPRE ? NF : 1][MF / 2];
+      if (RPRE && rbase) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const int gh = h0 + wave4 * RW + (nf >> 1);
+          const int gw = w0 + (nf & 1) * 16 + lr;
+          const bool live = gh < p.Hg && gw < p.Wg;
+          const int64_t off = live ? (((int64_t)b * p.Hg + gh) * p.Wg + gw) * p.ldy + o0 : o0;   // dead lanes: a valid row
+#pragma unroll
+          for (int mf = 0; mf < MF; mf += 2)
+            vres[nf][mf / 2].load(rbase + off + mf * 16 + ((lc & 1) ? 16 + 4 * (lc - 1) : 4 * lc));   // pack_pair_bf16's channel offset
+        }
+      }
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
         const int gh = h0 + wave4 * RW + (nf >> 1);
@@ -346,7 +364,8 @@ __global__ __launch_bounds__(256 * GM * GN, 2) void conv8_kernel(TY* __restrict_
             if (rbase) {
               vec16<TY> va, vr;
               va.raw = pk;
-              vr.load(rbase + (q - y));
+              if constexpr (RPRE) vr = vres[RPRE ? nf : 0][mf / 2];
+              else vr.load(rbase + (q - y));
 #pragma unroll
               for (int j = 0; j < 8; ++j) va.set(j, va.get(j) + vr.get(j));
               pk = va.raw;
