@@ -130,6 +130,7 @@ SIGNATURES = {
                          _c_int, _c_ptr],
     "dgv2_glin_dweight": [_c_ptr] * 7 + [_c_int] * 3 + [_c_f32, _c_f32, _c_f32, _c_ptr, _c_ptr],
     "dgv2_conv3x3_dgrad8": [_c_ptr] * 3 + [_c_int] * 5 + [_c_ptr, _c_int, _c_ptr],
+    "dgv2_conv3x3_s2_dgrad8": [_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr],
     "dgv2_conv3x3_x3_wgrad_scratch": [_c_ptr] + [_c_int] * 6,
     "dgv2_conv3x3_x3_wgrad": [_c_ptr, _c_ptr, _c_i64] + [_c_ptr] * 2 + [_c_int] * 7 + [_c_f32, _c_int, _c_ptr, _c_ptr],
     "dgv2_conv_x3_images": [_c_ptr] * 3 + [_c_int] * 2 + [_c_ptr],

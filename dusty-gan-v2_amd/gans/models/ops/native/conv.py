@@ -47,6 +47,9 @@ def _conv_taps(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, ooff, taps, hzero,
 _FUSED_DGRAD = os.environ.get("DGV2_NO_FUSED_DGRAD") is None   # A/B switch for benchmarking
 
 
+_S2D8 = os.environ.get("DGV2_NO_S2D8") is None                 # A/B switch: stride-2 data gradients on conv8_s2d.hip
+
+
 def _conv_taps_ex(y, x, w3, Hg, Wg, in_stride, ioff, out_stride, classes, taps4, extras, hzero, resid=None, ch0=None):
     """dgv2_conv_taps_ex: output classes [(ooff_h, ooff_w)], taps [(dy, dx, widx, cls)] sorted by class, border
     extras [(dy, dx, widx, cls, row)].  Returns False when the engine asks for the per-class fallback.
@@ -205,6 +208,11 @@ def _conv_dgrad_direct(gy, wt3, g, xshape, resid=None):
         _conv_taps(gx, gy, wt3, 1, W, 1, (H - 1, 0), 1, (H - 1, 0), [(0, 1 - kx, 6 + kx) for kx in range(3)], True,
                    True)
         return gx
+    # stride 2, deeper blocks (C a multiple of 128): the eight-wave engine, one launch per output row parity
+    if _S2D8 and gy.dtype == torch.bfloat16 and g.ring and C % 128 == 0 and wt3.is_contiguous():
+        if N.try_call("dgv2_conv3x3_s2_dgrad8", N.ptr(gx), N.ptr(gy), N.ptr(wt3), B, H // 2, W // 2, C, gy.shape[3], _dt(gy),
+                      N.stream()):
+            return gx
     # stride 2: the four output parity classes (only the taps each class can see) and the top border in one launch
     classes, taps4, extras = [], [], []
     for ph in (0, 1):

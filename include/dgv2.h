@@ -554,6 +554,14 @@ int dgv2_conv3x3_fwd8(void* y, const void* x, const void* w8, int B, int Hin, in
  * W >= 32 / 64): callers then run dgv2_conv_taps_ex on wt. */
 int dgv2_conv3x3_dgrad8(void* gx, const void* gy, const void* w8t, int B, int H, int W, int C, int O, const void* resid,
                         int dtype, void* stream);
+/* The STRIDE-2 data gradient of the 3x3 ring conv (pad 1) on the eight-wave engine (conv8_s2d.hip), from the transposed row
+ * weights wt [C, 9, O] (dgv2_conv_weight_bank's wt): gx [B, 2 Hg, 2 Wg, C] (bf16) from gy [B, Hg, Wg, O], the replicate row of
+ * output row 0 included -- two launches, one per output row parity (three or six taps, two column classes each).
+ * replaces: the cuDNN data gradient autograd calls for ops.Conv2d (common.py:187-210) at ResidualBlock.conv2
+ * (dusty_v2.py:337-345).  DGV2_ENOTSUP where the engine does not cover the geometry (C % 128, O % 32, O >= 64, Hg % 4,
+ * Wg % 32, DGV2_BF16): callers then run dgv2_conv_taps_ex on wt. */
+int dgv2_conv3x3_s2_dgrad8(void* gx, const void* gy, const void* wt, int B, int Hg, int Wg, int C, int O, int dtype,
+                           void* stream);
 
 /* fp32 3x3 ring conv (stride 1, pad 1) on the bf16 matrix cores (conv_x3.hip): the fp32 operands as three bf16 planes
  * each (x = h + m + l), six bf16 products per multiply, fp32 accumulation -- fp32-equivalent (dropped terms < 2^-25 of a

@@ -5,6 +5,8 @@ tolerance.  Run with `-m gpu` on an MI355X."""
 import math
 
 import numpy as np
+import sys
+
 import pytest
 import torch
 
@@ -1026,6 +1028,42 @@ def test_conv8_data_gradient_exact_on_integers(nat, B, H, W, C, O):
     # same call without the image: the four-wave engine on wt
     ref = nat._conv_dgrad_raw(cl(gy).bfloat16(), None, geom, (B, H, W, C), wt=wt, resid=cl(resid).bfloat16())
     assert torch.equal(nchw(ref), want)
+
+
+@pytest.mark.parametrize("B,H,W,C,O", [(64, 16, 64, 128, 64), (22, 8, 128, 256, 96), (44, 24, 64, 128, 160), (256, 16, 64, 128, 64),
+                                       (130, 16, 128, 256, 64), (2, 16, 64, 128, 64)])
+def test_conv8_stride2_data_gradient_exact_on_integers(nat, B, H, W, C, O):
+    """dgv2_conv3x3_s2_dgrad8 (conv8_s2d.hip): the stride-2 3x3 ring data gradient of ResidualBlock.conv2's backward
+    (dusty_v2.py:337-345) as two launches, one per output row parity, on the eight-wave engine -- four-row tiles, eight-row
+    tiles (from 256 blocks up), two slab pairs (XCD-aware order), three chunks of gy, the replicate row of output row 0 and
+    the zero row below the last one.  Integers: exact, against autograd on the CPU and against the four-class kernel."""
+    g = torch.Generator().manual_seed(13)
+    x = torch.zeros(B, C, H, W, requires_grad=True)
+    w = torch.randint(-1, 2, (O, C, 3, 3), generator=g).float()
+    y = _conv_oracle(x, w, 2, 1, True)
+    gy = torch.randint(-1, 2, y.shape, generator=g).float()
+    (want,) = torch.autograd.grad(y, [x], gy)
+    assert float(want.abs().max()) < 256
+    wt = w.permute(1, 2, 3, 0).contiguous().to(DEV).bfloat16()            # [C, ky, kx, O]
+    geom = nat.ConvGeom(3, 3, 2, 1, True)
+    gyd = cl(gy).bfloat16()
+    nat_conv = sys.modules[nat._conv_dgrad_raw.__module__]
+    assert nat_conv._S2D8
+    got = nat._conv_dgrad_raw(gyd, None, geom, (B, H, W, C), wt=wt)
+    assert torch.equal(nchw(got), want)
+    nat_conv._S2D8 = False
+    try:
+        ref = nat._conv_dgrad_raw(gyd, None, geom, (B, H, W, C), wt=wt)
+    finally:
+        nat_conv._S2D8 = True
+    assert torch.equal(got, ref)
+    # the engine took the call where it fills the chip (>= 256 blocks of four-row tiles), the four-class kernel otherwise
+    gx = torch.empty(B, H, W, C, device=DEV, dtype=torch.bfloat16)
+    took = nat.N.try_call("dgv2_conv3x3_s2_dgrad8", nat.N.ptr(gx), nat.N.ptr(gyd), nat.N.ptr(wt), B, H // 2, W // 2, C, O,
+                          nat.N.BF16, nat.N.stream())
+    assert took == ((W // 64) * (H // 8) * B * (C // 128) >= 256)
+    if took:
+        assert torch.equal(gx, got)
 
 
 X3_CASES = [(4, 4, 32, 513, 512), (1, 4, 32, 72, 64), (3, 8, 64, 64, 128), (2, 6, 32, 130, 64), (5, 2, 96, 200, 192),
