@@ -17,7 +17,7 @@ import sys
 
 BUCKETS = collections.OrderedDict([
     ("conv_x3 (fp32 epilogue conv)", r"conv_x3_|x3_dgrad_tail|conv_wgrad_x3|x3_image"), ("conv_pipe", r"conv_pipe_kernel"),
-    ("conv8", r"conv8_kernel"), ("conv_strip", r"conv3x3_strip"), ("conv_deep", r"conv_deep|skip_fused"),
+    ("conv8", r"conv8_kernel|conv8_s2d_kernel"), ("conv_strip", r"conv3x3_strip"), ("conv_deep", r"conv_deep|skip_fused"),
     ("conv_direct_fallback", r"conv_direct_kernel"),
     ("conv_wgrad_stream", r"wgrad_stream|wgrad_reduce"), ("conv_wgrad_direct", r"wgrad_direct"),
     ("gemm_tn", r"gemm_tn_kernel"), ("gemm_nn(conv)", r"gemm_nn_kernel.*Im2col"), ("gemm_nn", r"gemm_nn_kernel"),
