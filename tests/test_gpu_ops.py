@@ -684,11 +684,12 @@ def test_producers_leave_sum_of_squares_partials(nat, g_ops):
 
 @pytest.mark.parametrize("ring", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_stem_matches_composed_reference(nat, ring, dtype):
+@pytest.mark.parametrize("W", [24, 26])   # the four-pixel forward kernel (W % 4 == 0) and the one-pixel form
+def test_stem_matches_composed_reference(nat, ring, dtype, W):
     """dgv2_stem_fwd/bwd (BlurVH + 1x1 conv + bias + lrelu in one pass) against the oracle's composition
     of the same reference ops (dusty_v2.py:364-367): outputs and all three gradients."""
     g = torch.Generator().manual_seed(5)
-    B, H, W, O = 3, 10, 24, 32
+    B, H, O = 3, 10, 32
     x = torch.randn(B, 1, H, W, generator=g)
     w = torch.randn(O, 2, 1, 1, generator=g)
     b = torch.randn(O, generator=g)
