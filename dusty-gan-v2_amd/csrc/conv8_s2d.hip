@@ -9,6 +9,8 @@
 //   T(0) = {(0, 1)}, T(1) = {(1, 0), (0, 2)}   (conv.py:_axis_taps_s2; gy rows past the last one are zero),
 //   + the replicate row of the forward padding: output row 0 sees gy row 0 once more through the ky = 0 weights.
 //
+// Two forms.  FOUR-ROW TILES, ALL FOUR CLASSES IN ONE LAUNCH (PY = 2: 128 accumulator registers fit; the border row's terms
+// reuse the ky = 0 weights of the odd rows' taps): the form for 4- and 8-row maps and small batches.  EIGHT-ROW TILES need
 // ONE LAUNCH PER OUTPUT ROW PARITY py: its two column classes (px = 0, 1) need 3 (py = 0: + 3 for the border row) or 6 taps,
 // two accumulator sets instead of four -- which is what lets a block be conv8.hip's: eight waves = two 64-channel slabs of
 // the gradient on one (4 RW) x 32 tile of gy pixels (+ one halo row and column), the tile staged once for 128 channels,
@@ -27,34 +29,47 @@ struct S2D {
   int gx_, gy_, gz_, xcd;
 };
 
-template <int RW>
+// tap j of mode PY: kernel index ky * 3 + kx of wt, output class, gy offsets (dy, dx).
+//   PY = 0 / 1: the two column classes of output row parity PY (class = px); PY = 0: taps 3..5 are the border row's (output
+//   row 0 only).  PY = 2: all four classes (class = py * 2 + px) in one launch, four-row tiles only (128 accumulator
+//   registers): the border row's terms share the ky = 0 weights of the odd rows' taps -- BCL[t] = the EVEN-row class that tap's
+//   weights also feed at output row 0 (through the gy pixel at dy = 0), or -1.
+template <int PY> struct S2DTaps;
+template <> struct S2DTaps<0> {
+  static constexpr int NTAP = 6, NCL = 2, NMAIN = 3;
+  static constexpr int W[6] = {4, 3, 5, 1, 0, 2}, CL[6] = {0, 1, 1, 0, 1, 1}, DY[6] = {0, 0, 0, 0, 0, 0}, DX[6] = {0, 1, 0, 0, 1, 0};
+  static constexpr int BCL[6] = {-1, -1, -1, -1, -1, -1};
+};
+template <> struct S2DTaps<1> {
+  static constexpr int NTAP = 6, NCL = 2, NMAIN = 6;
+  static constexpr int W[6] = {1, 7, 0, 2, 6, 8}, CL[6] = {0, 0, 1, 1, 1, 1}, DY[6] = {1, 0, 1, 1, 0, 0}, DX[6] = {0, 0, 1, 0, 1, 0};
+  static constexpr int BCL[6] = {-1, -1, -1, -1, -1, -1};
+};
+template <> struct S2DTaps<2> {
+  static constexpr int NTAP = 9, NCL = 4, NMAIN = 9;
+  static constexpr int W[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8}, CL[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+  static constexpr int DY[9] = {0, 0, 0, 1, 0, 1, 1, 0, 0}, DX[9] = {0, 1, 0, 0, 0, 1, 0, 1, 0};
+  static constexpr int BCL[9] = {-1, -1, -1, 0, -1, 1, 1, -1, -1};
+};
+
+template <int PY, int RW>
 struct S2DCfg {
   static constexpr int TH = 4 * RW, NF = 2 * RW, MF = 4;
   static constexpr int IROWS = TH + 1, ICOLS = 33, NPIX = IROWS * ICOLS;
   static constexpr int NI = (NPIX * 4 + 511) / 512;
   static constexpr int COVER = NI * 128;
   static constexpr int PIN = (NPIX + (COVER > NPIX ? COVER - NPIX : 0) + 15) / 16 * 16;   // dead slots land behind the image
-  static constexpr int NTAP = 6, PW = NTAP * 64;
+  static constexpr int NTAP = S2DTaps<PY>::NTAP, PW = NTAP * 64;
   static constexpr size_t LDS = sizeof(uint4) * 4 * ((size_t)PIN + 2 * PW);
-};
-
-// tap j of parity PY: kernel index ky * 3 + kx of wt, column class, gy offsets (dy, dx).  PY = 0: taps 3..5 are the border
-// row's (output row 0 only).
-template <int PY> struct S2DTaps;
-template <> struct S2DTaps<0> {
-  static constexpr int W[6] = {4, 3, 5, 1, 0, 2}, CL[6] = {0, 1, 1, 0, 1, 1}, DY[6] = {0, 0, 0, 0, 0, 0}, DX[6] = {0, 1, 0, 0, 1, 0};
-  static constexpr int NMAIN = 3;
-};
-template <> struct S2DTaps<1> {
-  static constexpr int W[6] = {1, 7, 0, 2, 6, 8}, CL[6] = {0, 0, 1, 1, 1, 1}, DY[6] = {1, 0, 1, 1, 0, 0}, DX[6] = {0, 0, 1, 0, 1, 0};
-  static constexpr int NMAIN = 6;
 };
 
 template <int PY, int RW>
 __global__ __launch_bounds__(512, 2) void conv8_s2d_kernel(bf16_t* __restrict__ gx, const bf16_t* __restrict__ gy,
                                                           const bf16_t* __restrict__ wt, S2D p) {
-  using Cf = S2DCfg<RW>;
+  using Cf = S2DCfg<PY, RW>;
   using Tp = S2DTaps<PY>;
+  constexpr int NCL = Tp::NCL;
+  static_assert(PY != 2 || RW == 1, "four classes: four-row tiles (128 accumulator registers)");
   constexpr int TH = Cf::TH, NF = Cf::NF, MF = Cf::MF, ICOLS = Cf::ICOLS, NPIX = Cf::NPIX, NI = Cf::NI, PIN = Cf::PIN;
   constexpr int NTAP = Cf::NTAP, PW = Cf::PW;
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -117,9 +132,9 @@ __global__ __launch_bounds__(512, 2) void conv8_s2d_kernel(bf16_t* __restrict__ 
   uint4* const st_in = lds_in + in_plane * PIN;
   uint4* const st_w = lds_w + w_plane * PW + w_row0;
 
-  f32x4 acc[2][MF][NF];
+  f32x4 acc[NCL][MF][NF];
 #pragma unroll
-  for (int cl = 0; cl < 2; ++cl)
+  for (int cl = 0; cl < NCL; ++cl)
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -143,9 +158,10 @@ __global__ __launch_bounds__(512, 2) void conv8_s2d_kernel(bf16_t* __restrict__ 
     unsigned m = 0;
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
-      if (PY == 1 && Tp::DY[t] == 1 && gi + 1 >= p.Hg) m |= 1u << t;
-      if (PY == 0 && t >= Tp::NMAIN && gi != 0) m |= 1u << t;
+      if (Tp::DY[t] == 1 && gi + 1 >= p.Hg) m |= 1u << t;
+      if (t >= Tp::NMAIN && gi != 0) m |= 1u << t;
     }
+    if (PY == 2 && gi == 0) m |= 1u << 16;   // bit 16: this row is output row 0 (the border terms of BCL apply)
     dead[rr] = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
   }
 
@@ -182,6 +198,19 @@ __global__ __launch_bounds__(512, 2) void conv8_s2d_kernel(bf16_t* __restrict__ 
             else MfmaAsm<bf16_t>::run_pad(acc[Tp::CL[t]][mf][nf], a[t & 1][mf], bb[nf]);   // compiler code may follow
           }
         }
+        // replicate-row border term (PY = 2): at output row 0 the even-row class BCL sees gy row 0 once more through THIS
+        // tap's weights (in registers right now) -- one more pixel-fragment read (dy = 0 instead of 1).  (t is a constant
+        // after unrolling: the taps without a border class lose this block.)
+        if (Tp::BCL[t] >= 0 && ((dd[nf >> 1] >> 16) & 1u)) {
+          constexpr int NCLm1 = NCL - 1;
+          const int bcl = Tp::BCL[t] >= 0 ? (Tp::BCL[t] < NCLm1 ? Tp::BCL[t] : NCLm1) : 0;
+          const uint4 bx = b_base[bpix[nf] + Tp::DX[t]];
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            if (mf < MF - 1) MfmaAsm<bf16_t>::run(acc[bcl][mf][nf], a[t & 1][mf], bx);
+            else MfmaAsm<bf16_t>::run_pad(acc[bcl][mf][nf], a[t & 1][mf], bx);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (nf == NF - 1 && more) {   // this tap's share of the next stage's loads (conv8.hip)
           issue((s + 1) * 32, t * (NI + NTAP) / NTAP, (t + 1) * (NI + NTAP) / NTAP);
@@ -205,8 +234,9 @@ __global__ __launch_bounds__(512, 2) void conv8_s2d_kernel(bf16_t* __restrict__ 
     const int gi = h0 + wave4 * RW + (nf >> 1);
     const int gj = w0 + (nf & 1) * 16 + lr;
 #pragma unroll
-    for (int cl = 0; cl < 2; ++cl) {
-      bf16_t* const row = gx + ((((int64_t)b * 2 * p.Hg + 2 * gi + PY) * 2 * p.Wg) + 2 * gj + cl) * p.C + c0;
+    for (int cl = 0; cl < NCL; ++cl) {
+      const int py = PY == 2 ? (cl >> 1) : PY, px = PY == 2 ? (cl & 1) : cl;
+      bf16_t* const row = gx + ((((int64_t)b * 2 * p.Hg + 2 * gi + py) * 2 * p.Wg) + 2 * gj + px) * p.C + c0;
 #pragma unroll
       for (int mf = 0; mf < MF; mf += 2) {
         float fa[4], fb[4];
@@ -225,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void conv8_s2d_kernel(bf16_t* __restrict__ 
 
 template <int PY, int RW>
 int launch_s2d(void* gx, const void* gy, const void* wt, S2D p, hipStream_t st) {
-  using Cf = S2DCfg<RW>;
+  using Cf = S2DCfg<PY, RW>;
   static_assert(Cf::LDS <= 160 * 1024 - 1024, "LDS image");
   static_assert(Cf::MF % Cf::NF == 0, "A fragments are re-read in equal shares behind the pixel-fragment groups");
   auto kern = conv8_s2d_kernel<PY, RW>;
@@ -267,11 +297,16 @@ extern "C" int dgv2_conv3x3_s2_dgrad8(void* gx, const void* gy, const void* wt, 
   // eight-row tiles while they still fill the chip, four-row tiles otherwise
   const int64_t blocks8 = Hg % 8 ? 0 : (int64_t)(Wg / 32) * (Hg / 8) * B * (C / 128);
   const int64_t blocks4 = (int64_t)(Wg / 32) * (Hg / 4) * B * (C / 128);
-  // measured (gpurun_out/r7j, B = 128 / 64): eight-row tiles on a full chip 92 -> 66 us; four-row tiles on a full chip
-  // level with the four-class kernel (87 -> 85, 48 -> 47 us); half a chip of blocks 43 -> 75 us: left to that kernel
+  // measured (profiles/round5_mb_s2d.txt, B = 128 / 64, against conv_pipe_kernel's four-class launch): two launches on
+  // eight-row tiles that fill the chip 91 -> 65 us; ONE four-class launch on four-row tiles 87 -> 61, 49 -> 33 us (two launches
+  // on four-row tiles: level with conv_pipe); half a chip of blocks 43 -> 75 us: left to conv_pipe
   if (blocks4 < 256) return DGV2_ENOTSUP;
+  static const int mode = getenv("DGV2_S2D8_MODE") ? atoi(getenv("DGV2_S2D8_MODE")) : 0;   // experiments: 1 two launches, 2 four classes
   int rc;
-  if (blocks8 >= 256) {
+  const bool four = mode == 2 || (mode == 0 && blocks8 < 256);
+  if (four) {
+    rc = launch_s2d<2, 1>(gx, gy, wt, p, st);
+  } else if (blocks8 >= 256) {
     rc = launch_s2d<0, 2>(gx, gy, wt, p, st);
     if (!rc) rc = launch_s2d<1, 2>(gx, gy, wt, p, st);
   } else {

@@ -556,7 +556,8 @@ int dgv2_conv3x3_dgrad8(void* gx, const void* gy, const void* w8t, int B, int H,
                         int dtype, void* stream);
 /* The STRIDE-2 data gradient of the 3x3 ring conv (pad 1) on the eight-wave engine (conv8_s2d.hip), from the transposed row
  * weights wt [C, 9, O] (dgv2_conv_weight_bank's wt): gx [B, 2 Hg, 2 Wg, C] (bf16) from gy [B, Hg, Wg, O], the replicate row of
- * output row 0 included -- two launches, one per output row parity (three or six taps, two column classes each).
+ * output row 0 included -- two launches, one per output row parity (three or six taps, two column classes each) on eight-row
+ * tiles where those fill the chip, one four-class launch on four-row tiles otherwise.
  * replaces: the cuDNN data gradient autograd calls for ops.Conv2d (common.py:187-210) at ResidualBlock.conv2
  * (dusty_v2.py:337-345).  DGV2_ENOTSUP where the engine does not cover the geometry (C % 128, O % 32, O >= 64, Hg % 4,
  * Wg % 32, DGV2_BF16): callers then run dgv2_conv_taps_ex on wt. */

@@ -1,5 +1,6 @@
-"""Stride-2 3x3 data gradients of D's residual blocks: the eight-wave engine (conv8_s2d.hip, two launches per gradient)
-against the four-class conv_pipe_kernel launch.  usage: mb_s2d.py"""
+"""Stride-2 3x3 data gradients of D's residual blocks: the eight-wave engine (conv8_s2d.hip; DGV2_S2D8_MODE=1: two launches
+per gradient, =2: one four-class launch on four-row tiles, unset: the shipped choice) against conv_pipe_kernel's four-class
+launch.  usage: mb_s2d.py"""
 import sys, torch
 sys.path[:0] = ["dusty-gan-v2_amd"]
 from gans.models.ops import native as nat
@@ -21,6 +22,6 @@ for B in (128, 64):
         for on in (True, False):
             conv._S2D8 = on
             us = t(lambda: nat._conv_dgrad_raw(gy, None, g, (B, H, W, C), wt=wt))
-            out.append(f"{'s2d8' if on else 'four-class'} {us:6.1f} us ({fl / us / 1e6:4.0f} TF/s)")
+            out.append(f"{'s2d8' if on else 'conv_pipe'} {us:6.1f} us ({fl / us / 1e6:4.0f} TF/s)")
         conv._S2D8 = True
         print(f"B={B} {H}x{W} C{C}<-O{O}: " + "   ".join(out), flush=True)
