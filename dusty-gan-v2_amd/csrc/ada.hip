@@ -116,23 +116,48 @@ __global__ __launch_bounds__(256) void ada_apply_lds_kernel(float* __restrict__ 
   const int qa = sg, qb = transpose ? -sg : 1;
   const int c0 = transpose ? sg * (j0 - of) : sg * j0 + of;
   const int qs = (qa < 0 ? ADA_TW - 1 : 0) + (qb < 0 ? K - 1 : 0);
-  const int nq = ADA_TW + K - 1;
-  for (int it = tid; it < H * nq; it += 256) {
-    const int h = it / nq, q = it - h * nq;
-    xt[h][q] = xb[(int64_t)h * W + floormod(c0 + q - qs, W)];
+  const int nq = ADA_TW + K - 1;   // <= 127
+  // staging: a thread owns ONE source column (its wrap computed once) and half of the rows -- no integer division in the
+  // loop, every load of a thread independent of the others (the element-per-iteration form with a division and a modulo per
+  // element was latency bound: 34 us per launch for 8 MB)
+  {
+    const int q = tid & 127, hh = tid >> 7;
+    if (q < nq) {
+      const float* src = xb + floormod(c0 + q - qs, W);
+      const int h0 = hh * (H / 2), h1 = hh ? H : H / 2;
+#pragma unroll 8
+      for (int h = h0; h < h1; ++h) xt[h][q] = src[(int64_t)h * W];
+    }
   }
+  // the operator: coalesced reads either way; the transpose is taken on the LDS side
   for (int it = tid; it < H * H; it += 256) {
-    const int i = it / H, h = it - i * H;
-    Al[i][h] = transpose ? Ab[h * H + i] : Ab[it];
+    const int r = it / H, cidx = it - r * H;   // H = 64 on the model's path: shifts
+    const float v = Ab[it];
+    if (transpose) Al[cidx][r] = v;
+    else Al[r][cidx] = v;
   }
   if (tid < K) kl[tid] = kx[(int64_t)b * K + tid];
   __syncthreads();
-  for (int it = tid; it < H * ADA_TW; it += 256) {
-    const int jl = it % ADA_TW, h = it / ADA_TW;
-    const int q0 = qa * jl + qs;
-    float acc = 0.f;
-    for (int t = 0; t < K; ++t) acc += kl[t] * xt[h][q0 + qb * t];
-    tmp[h][jl] = acc;
+  // phase 1, four consecutive outputs of a row per item: LDS column of (output o, tap t) = qa * (4 jg + o) + qs + qb * t
+  // = pb + o' + t' with o' = o or 3 - o and t' = t or K - 1 - t by the two signs -- a window that slides one source value and
+  // one tap per step: two LDS reads per four FMAs (the one-output form read two per FMA and was bound by the LDS issue rate)
+  for (int it = tid; it < H * (ADA_TW / 4); it += 256) {
+    const int jg = it % (ADA_TW / 4), h = it / (ADA_TW / 4);
+    const int pb = (qa > 0 ? 4 * jg : -4 * jg - 3) + qs + (qb > 0 ? 0 : -(K - 1));
+    const float* xr = &xt[h][pb];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
+    for (int u = 0; u < K + 3; ++u) {
+      const float xv = xr[u];
+      k3 = k2; k2 = k1; k1 = k0;
+      k0 = u < K ? kl[qb > 0 ? u : K - 1 - u] : 0.f;
+      a0 = fmaf(k0, xv, a0);
+      a1 = fmaf(k1, xv, a1);
+      a2 = fmaf(k2, xv, a2);
+      a3 = fmaf(k3, xv, a3);
+    }
+    float* tr = &tmp[h][4 * jg];
+    if (qa > 0) { tr[0] = a0; tr[1] = a1; tr[2] = a2; tr[3] = a3; }
+    else { tr[0] = a3; tr[1] = a2; tr[2] = a1; tr[3] = a0; }
   }
   __syncthreads();
   const int jl = tid % ADA_TW, ig = tid / ADA_TW;   // 4 row groups x 64 columns
