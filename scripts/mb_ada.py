@@ -22,3 +22,8 @@ for B in (64, 128):
         us = t(lambda: N.call("dgv2_ada_apply", N.ptr(y), N.ptr(x), N.ptr(Ay), N.ptr(kx), N.ptr(off), N.ptr(sgn), N.ptr(a), N.ptr(c), B, H, W, K, tr, N.stream()))
         out.append(f"{'transpose' if tr else 'forward'} {us:6.1f} us")
     print(f"B={B} 64x512 K={K}: " + "   ".join(out), flush=True)
+from gans.augment.adaptive_augment import AdaptiveAugment
+A = AdaptiveAugment(p_init=0.6, lr_flip=1, ud_flip=1, int_trans=1, iso_scale=1, frac_trans=1, brightness=1, contrast=1, luma_flip=1, hue=1, saturation=1).cuda()
+x = torch.randn(64, 1, 64, 512, device="cuda")
+with torch.no_grad():
+    print(f"AdaptiveAugment.forward, B = 64 (sample + build + apply): {t(lambda: A(x)):6.1f} us", flush=True)
