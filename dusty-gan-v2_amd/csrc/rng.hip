@@ -41,29 +41,19 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint64_t key) {
   }
 }
 
-__global__ __launch_bounds__(256) void rng_fill_kernel(RngSegs s, long long total, unsigned long long* __restrict__ state) {
-  // (every index into the by-value table below is a compile-time constant after unrolling: the fields come as scalar loads
-  // from the kernarg segment; a per-thread index would make the compiler copy the struct to scratch memory first)
+// The argument block is read where it lies (the kernarg segment): a by-value struct indexed with a per-thread segment number
+// is otherwise copied to scratch memory first.
+__global__ __launch_bounds__(256) void rng_fill_kernel(RngSegs s_by_value, unsigned long long* __restrict__ state) {
+  const RngSegs& s = *(const RngSegs*)__builtin_amdgcn_kernarg_segment_ptr();
   const unsigned long long seed = state[0], offset = state[1];
   const int nseg = s.nseg;
+  const long long total = s.begin[nseg];
   for (long long g = blockIdx.x * 256ll + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
-    // the group's segment: the LAST one whose start it has passed (segments are ordered).  Every field is picked by a select
-    // chain over the (uniform, scalar-loaded) table instead of an indexed load with the per-thread segment number: six
-    // dependent vector loads from the argument block per group were most of this kernel's 27 us
-    int kind = s.kind[0];
-    float a = s.a[0], b = s.b[0];
-    float* obase = s.out[0];
-    long long sbeg = s.begin[0], scnt = s.count[0];
+    int k = 0;
 #pragma unroll
-    for (int j = 1; j < RNG_MAX_SEG; ++j) {
-      const bool in = j < nseg && g >= s.begin[j];
-      kind = in ? s.kind[j] : kind;
-      a = in ? s.a[j] : a;
-      b = in ? s.b[j] : b;
-      obase = in ? s.out[j] : obase;
-      sbeg = in ? s.begin[j] : sbeg;
-      scnt = in ? s.count[j] : scnt;
-    }
+    for (int j = 1; j < RNG_MAX_SEG; ++j) k += (j < nseg && g >= s.begin[j]) ? 1 : 0;   // segments are ordered: count the starts passed
+    const int kind = s.kind[k];
+    const float a = s.a[k], b = s.b[k];
     const unsigned long long ctr = offset + (unsigned long long)g;
     uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
     philox4x32_10(c, seed);
@@ -86,8 +76,8 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(RngSegs s, long long tota
         v[j] = kind == 0 ? fmaf(b - a, u, a) : fminf(fmaxf(u, a), b);
       }
     }
-    const long long e = (g - sbeg) * 4, cnt = scnt;
-    float* o = obase + e;
+    const long long e = (g - s.begin[k]) * 4, cnt = s.count[k];
+    float* o = s.out[k] + e;
     if (e + 4 <= cnt && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
       *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
@@ -139,6 +129,6 @@ extern "C" int dgv2_rng_fill(float* const* out, const int64_t* count, const int*
   s.begin[nseg] = g;
   // (one block per CU at most: the arrival tickets are same-address atomics, ~15 ns each at the L2 -- 2048 blocks spent
   // 30 us queueing for theirs, 256 spend 4)
-  rng_fill_kernel<<<grid_for(g, 256, 256), 256, 0, (hipStream_t)stream>>>(s, g, (unsigned long long*)state);
+  rng_fill_kernel<<<grid_for(g, 256, 256), 256, 0, (hipStream_t)stream>>>(s, (unsigned long long*)state);
   DGV2_RETURN_LAST();
 }
