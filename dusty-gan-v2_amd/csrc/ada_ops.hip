@@ -175,10 +175,10 @@ __device__ __forceinline__ float interp_col(const float* __restrict__ M1, int n_
   return v;
 }
 
-// Ay[b, i, h] = sum_t k[t] * interp(M1y[:, h], pos_y(b, 2i + 1 + t));  grid (H, B), block >= H threads
-__global__ void ada_build_ay_kernel(float* __restrict__ Ay, const float* __restrict__ gaff,
-                                    const float* __restrict__ M1y, const float* __restrict__ taps, int H) {
-  const int i = blockIdx.x, b = blockIdx.y;
+// Ay[b, i, h] = sum_t k[t] * interp(M1y[:, h], pos_y(b, 2i + 1 + t));  one block per (i, b), >= H threads
+__device__ __forceinline__ void ada_build_ay_block(float* __restrict__ Ay, const float* __restrict__ gaff,
+                                                   const float* __restrict__ M1y, const float* __restrict__ taps, int H, int i,
+                                                   int b) {
   const float sy = gaff[b * 4 + 2], ty = gaff[b * 4 + 3];
   const int n_in = (H + 2 * (H - 1)) * 2, n_out = (H + 6) * 2;
   for (int h = threadIdx.x; h < H; h += blockDim.x) {
@@ -189,15 +189,12 @@ __global__ void ada_build_ay_kernel(float* __restrict__ Ay, const float* __restr
   }
 }
 
-// one reference row j_ref of the circulant x operator, its peak, and the K taps around the peak
-__global__ __launch_bounds__(256) void ada_build_kx_kernel(float* __restrict__ kx, int* __restrict__ off,
-                                                           int* __restrict__ sgn, const float* __restrict__ gaff,
-                                                           const float* __restrict__ M1x,
-                                                           const float* __restrict__ taps, int W, int K) {
-  extern __shared__ float row[];  // [W]
+// one reference row j_ref of the circulant x operator, its peak, and the K taps around the peak; one block of 256 threads per b
+__device__ __forceinline__ void ada_build_kx_block(float* __restrict__ kx, int* __restrict__ off, int* __restrict__ sgn,
+                                                   const float* __restrict__ gaff, const float* __restrict__ M1x,
+                                                   const float* __restrict__ taps, int W, int K, int b, float* row) {
   __shared__ float best_v[4];
   __shared__ int best_i[4];
-  const int b = blockIdx.x;
   const float sx = gaff[b * 4 + 0], tx = gaff[b * 4 + 1];
   const int n_in = (W + 2 * (W - 1)) * 2, n_out = (W + 6) * 2;
   const int j_ref = W / 2;
@@ -234,6 +231,17 @@ __global__ __launch_bounds__(256) void ada_build_kx_kernel(float* __restrict__ k
   }
 }
 
+// both operators of a sample batch from ONE launch: blocks (i < H, b) build row i of Ay[b], blocks (H, b) the x kernel of b
+// (two launches of 10 + 20 us, three times per iteration, ran one after the other for no reason: neither reads the other)
+__global__ __launch_bounds__(256) void ada_build_kernel(float* __restrict__ Ay, float* __restrict__ kx, int* __restrict__ off,
+                                                        int* __restrict__ sgn, const float* __restrict__ gaff,
+                                                        const float* __restrict__ M1y, const float* __restrict__ M1x,
+                                                        const float* __restrict__ taps, int H, int W, int K) {
+  extern __shared__ float row[];  // [W] (the x-kernel blocks)
+  if ((int)blockIdx.x < H) ada_build_ay_block(Ay, gaff, M1y, taps, H, blockIdx.x, blockIdx.y);
+  else ada_build_kx_block(kx, off, sgn, gaff, M1x, taps, W, K, blockIdx.y, row);
+}
+
 }  // namespace
 
 // u fp32 [B,16] uniforms in [0,1), n fp32 [B,8] standard normals, p fp32 [1] (device), policy fp32 [11] HOST
@@ -258,8 +266,7 @@ extern "C" int dgv2_ada_build(float* Ay, float* kx, int* off, int* sgn, const fl
   if (!Ay || !kx || !off || !sgn || !gaff || !M1y || !M1x || !taps || B <= 0 || H <= 0 || W <= 0 || K <= 0 || K > W)
     return DGV2_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(H, B);
-  ada_build_ay_kernel<<<grid, 64, 0, st>>>(Ay, gaff, M1y, taps, H);
-  ada_build_kx_kernel<<<B, 256, sizeof(float) * W, st>>>(kx, off, sgn, gaff, M1x, taps, W, K);
+  dim3 grid(H + 1, B);
+  ada_build_kernel<<<grid, 256, sizeof(float) * W, st>>>(Ay, kx, off, sgn, gaff, M1y, M1x, taps, H, W, K);
   DGV2_RETURN_LAST();
 }

@@ -21,7 +21,7 @@ BUCKETS = collections.OrderedDict([
     ("conv_direct_fallback", r"conv_direct_kernel"),
     ("conv_wgrad_stream", r"wgrad_stream|wgrad_reduce"), ("conv_wgrad_direct", r"wgrad_direct"),
     ("gemm_tn", r"gemm_tn_kernel"), ("gemm_nn(conv)", r"gemm_nn_kernel.*Im2col"), ("gemm_nn", r"gemm_nn_kernel"),
-    ("fir_mfma", r"fir_same_mfma"), ("resample", r"resample"), ("upfirdn/ada", r"upfirdn|ada_"), ("mod_prep", r"mod_prep"),
+    ("fir_mfma", r"fir_same_mfma"), ("resample", r"resample"), ("upfirdn/ada", r"ada_build_kernel|upfirdn|ada_"), ("mod_prep", r"mod_prep"),
     ("bias_act", r"bias_act|bias_grad"), ("sumsq", r"sum_squares"),
     ("tail/fourier/coords", r"gen_tail|fourier|coords|downsample_angle|fetch_reals|synth"),
     ("modconv_pe", r"modconv_pe"), ("modconv_up", r"modconv_up|up2_lag"), ("pe_wgrad", r"pe_wgrad"), ("gemm_x3", r"gemm_x3"),
