@@ -56,6 +56,11 @@ def parse():
                          "opt-in whose throughput is reported next to it as `extra.value_d_epilogue_bf16`")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurement points (ADA p = 0, bf16 "
                     "epilogue, separately timed R1 / plain iterations)")
+    ap.add_argument("--stamp", default=os.environ.get("DGV2_BENCH_STAMP"),
+                    help="write {src_sha16, lib_sha16, argv} of THIS process to the given file before anything is "
+                         "timed: a profiler-wrapped run leaves the identity of the kernels it traced next to its "
+                         "trace, and scripts/step_listing.py copies that stamp instead of hashing whatever tree it is "
+                         "later run in (scripts/refresh_profiles.sh)")
     return ap.parse_args()
 
 
@@ -160,13 +165,12 @@ def _pmc_traffic(kernel_key, batch_per_gpu=PMC_BATCH_PER_GPU):
 MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_*_f32, /opt/skills/guides/MI355X_MICROARCH.md
 # per-body launch listing of this command's kernel trace (scripts/step_listing.py --json; committed): every (kernel, grid)
 # instance with its time per TRAINING iteration = G body + D body + R1 body / 16
-STATS_FILE = "profiles/round5_step_instances.json"
+STATS_FILE = "profiles/round6_step_instances.json"
 
 
 def kernel_source_hash():
     """sha256 (16 hex digits) over the HIP sources the library is built from: stamps the committed statistics
-    (STATS_FILE's .meta.json sidecar, written by scripts/stats_meta.py when the file is refreshed) so that a bench line
-    says whether the ranking it selects `roofline` by was measured on THIS tree's kernels."""
+    (the profiled bench.py process writes it with --stamp, scripts/step_listing.py copies it) so that a bench line says whether the ranking it selects `roofline` by was measured on THIS tree's kernels."""
     import glob
     import hashlib
     h = hashlib.sha256()
@@ -175,6 +179,16 @@ def kernel_source_hash():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def write_stamp(path):
+    """The identity of the kernels this PROCESS runs: hash of the HIP sources beside it and of the library it loaded."""
+    import hashlib
+    import dgv2_native
+    lib = hashlib.sha256(open(dgv2_native.LIB_PATH, "rb").read()).hexdigest()[:16]
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    json.dump({"src_sha16": kernel_source_hash(), "lib_sha16": lib, "lib": os.path.relpath(dgv2_native.LIB_PATH, ROOT),
+               "argv": sys.argv[1:], "pid": os.getpid()}, open(path, "w"), indent=1)
 
 
 def stats_current():
@@ -297,6 +311,40 @@ def roofline_probe(args, reps=20):
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": sec * 1e6, "mfma_tflops": flops / sec / 1e12}
 
 
+_GUARDS = []
+_GUARD_WORDS = 4096          # int32 canary words behind every guarded buffer (16 KB: more than any kernel's tile row)
+_GUARD_PATTERN = 0x5A5AA5A5
+
+
+def guarded_empty(shape, device="cuda", dtype=torch.float32):
+    """torch.empty(shape) with canary words behind it.  The probes below hand raw pointers to C entries that take no
+    buffer sizes; round 5 lost a 45-minute profiler-wrapped call to `modconv_probe` allocating the T / W_s images without
+    their O // 16 and O // 32 dimensions (fixed in ce3c924 by the shapes of native.mod_up_prepare, now shared as
+    native.mod_up_image_shapes): dgv2_modconv_up_t wrote past both.  check_guards() raises when a canary changed."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    esz = torch.empty((), dtype=dtype).element_size()
+    nbytes = (n * esz + 15) // 16 * 16
+    flat = torch.empty(nbytes + 4 * _GUARD_WORDS, device=device, dtype=torch.uint8)
+    flat[nbytes:].view(torch.int32).fill_(_GUARD_PATTERN)
+    _GUARDS.append((flat, nbytes, tuple(shape)))
+    return flat[:n * esz].view(dtype).view(*shape)
+
+
+def check_guards(clear=True):
+    """Raises if a kernel wrote behind one of the guarded buffers; returns how many were checked."""
+    torch.cuda.synchronize()
+    bad = [shape for flat, nbytes, shape in _GUARDS
+           if not bool((flat[nbytes:].view(torch.int32) == _GUARD_PATTERN).all())]
+    n = len(_GUARDS)
+    if clear:
+        _GUARDS.clear()
+    if bad:
+        raise RuntimeError(f"a probe's kernel wrote past the end of its buffer(s) of shape {bad}")
+    return n
+
+
 def modconv_levels(args):
     """`roofline_modconv` at the three pyramid levels that run the commuted kernel in the training step: level 4 (the
     headline instance, full detail), level 3 and level 2 (own algorithmic FLOPs 2 B P Ks O over the kernel's launch time)."""
@@ -307,6 +355,7 @@ def modconv_levels(args):
     for lvl, (hl, wl, Ka, O) in (("3", (16, 128, 128, 64)), ("2", (8, 64, 256, 128))):
         r = modconv_probe(args, shape=(hl, wl, Ka, O), brief=True)
         out["levels"][lvl] = r
+    out["guarded_buffers_checked"] = check_guards()
     return out
 
 
@@ -336,9 +385,10 @@ def modconv_probe(args, reps=20, shape=(32, 256, 64, 32), brief=False):
     w = torch.randn(B, O, Ka + Ks, device="cuda", dtype=bf) / 16
     bias = torch.randn(O, device="cuda")
     cvec = torch.ones(O, device="cuda")
-    y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
-    t = torch.empty(B, hl, O // 16, wl // 8, 16, 8, device="cuda", dtype=bf)            # (native.mod_up_prepare's layouts)
-    wimg = torch.empty(B, O // 32, Ks // 32, 2, 4, 16, 8, device="cuda", dtype=bf)
+    # this probe calls C entries directly: every buffer a kernel WRITES is a guarded one (canary words behind it,
+    # checked by check_guards() below), and the operand images are sized by the product's own shape function
+    y = guarded_empty((B, H, W, O), device="cuda", dtype=bf)
+    t, wimg = native.mod_up_images(B, hl, wl, Ks, O, "cuda", bf, empty=guarded_empty)
 
     def lowres():
         N.call("dgv2_modconv_up_t", N.ptr(t), N.ptr(wimg), N.ptr(h), N.ptr(w), N.ptr(cvec), 2.0 ** 0.5 * 0.6, B, hl, wl, Ka, Ks, O, Ka + Ks, Ka, N.BF16, N.stream())
@@ -456,6 +506,8 @@ def main():
     from gans.utils import init_random_seed
 
     init_random_seed(0, rank)
+    if args.stamp and rank == 0:
+        write_stamp(args.stamp)
     cfg, trainer = build_trainer(args, rank, world)
 
     def barrier():

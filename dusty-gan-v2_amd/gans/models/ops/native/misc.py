@@ -278,6 +278,18 @@ def resample_sq_only(x, spec):
     return sq[0][:sq[1].value]
 
 
+def mod_up_image_shapes(B, hl, wl, Ks, O):
+    """Shapes of the two operand images dgv2_modconv_up_t / _t_lag WRITE and dgv2_modconv_up_fwd reads (include/dgv2.h):
+    T = W_a . h in 8-pixel units and W_s as the MFMA operand image.  The one place that knows them: the C entries take
+    plain pointers, so every caller (this module, bench.py's probes) sizes its buffers from here."""
+    return (B, hl, O // 16, wl // 8, 16, 8), (B, O // 32, Ks // 32, 2, 4, 16, 8)
+
+
+def mod_up_images(B, hl, wl, Ks, O, dev, dt, empty=torch.empty):
+    st, sw = mod_up_image_shapes(B, hl, wl, Ks, O)
+    return empty(st, device=dev, dtype=dt), empty(sw, device=dev, dtype=dt)
+
+
 def mod_up_prepare(h, xs, wb, spec, act=True, alpha=0.2, scale=math.sqrt(2.0), want_stat=False):
     """The low-resolution pass of the commuted level-input conv, AHEAD of the layer's EMA update (dgv2_modconv_up_t_lag):
     T = gain * W_a . h in 8-pixel units, the PE columns of the per-sample weights as the MFMA image, and -- with
@@ -293,8 +305,7 @@ def mod_up_prepare(h, xs, wb, spec, act=True, alpha=0.2, scale=math.sqrt(2.0), w
     if want_stat and gram is None:
         return None
     h = h.contiguous()
-    t = torch.empty((B, hl, Otot // 16, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
-    wimg = torch.empty((B, Otot // 32, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)   # W_s as the MFMA operand image
+    t, wimg = mod_up_images(B, hl, wl, Ks, Otot, dev, dt)
     gain = float(scale) * 0.5 * (1.0 + float(alpha)) if act else 1.0
     sq = _sq_args(dev) if want_stat else None
     N.check(h, wb)
@@ -325,8 +336,7 @@ class _ModUpPrepared(Function):
         if t is not None:
             in_scale = cvec          # T / the image from mod_up_prepare carry the gain only: c rides on the B operands
         else:
-            t = torch.empty((B, hl, Otot // 16, wl // 8, 16, 8), device=dev, dtype=dt)         # W_a . h in 8-pixel units
-            wimg = torch.empty((B, Otot // 32, Ks // 32, 2, 4, 16, 8), device=dev, dtype=dt)   # W_s as the MFMA operand image
+            t, wimg = mod_up_images(B, hl, wl, Ks, Otot, dev, dt)
             N.check(h, wb, cvec)
             # T and the image carry c[o] * gain, the kernel puts gain on the bias and runs the leaky ReLU as f' + k |f'|
             gain = cfg["scale"] * 0.5 * (1.0 + cfg["alpha"]) if cfg["act"] else 1.0

@@ -23,8 +23,7 @@ y = torch.empty(B, H, W, O, device="cuda", dtype=bf)
 t_rs = bench._time_launches(lambda: native._resample_raw(h, spec, False, (hl, wl), sq=native._sq_args(h.device)), 20)
 t_pe = bench._time_launches(lambda: N.call("dgv2_modconv_pe_fwd_sq", N.ptr(y), N.ptr(hup), N.ptr(pe), N.ptr(wb), B, H * W, Ka, Ks, O, N.ptr(cvec), N.ptr(bias), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream()), 20)
 y0 = y.clone()
-t = torch.empty(B, hl, 2, wl // 8, 16, 8, device="cuda", dtype=bf)
-wimg = torch.empty(B, Ks // 32, 2, 4, 16, 8, device="cuda", dtype=bf)
+t, wimg = native.mod_up_images(B, hl, wl, Ks, O, "cuda", bf, empty=bench.guarded_empty)   # sized by the product's shape function
 
 
 def lowres():
@@ -56,3 +55,4 @@ pre = native.mod_up_prepare(h, pe, wb, spec, True, 0.2, math.sqrt(2.0), want_sta
 print(f"  statistic rel diff {abs(pre[2].sum().item()-a)/a:.2e}")
 N.call("dgv2_modconv_up_fwd", N.ptr(y), N.ptr(pre[0]), N.ptr(pef), N.ptr(pre[1]), B, H, W, hl, wl, Ks, O, N.ptr(ih), N.ptr(ch), N.ptr(iw), N.ptr(cw), N.ptr(bias), N.ptr(cvec), 3, 0.2, math.sqrt(2.0), N.BF16, None, 0, None, N.stream())
 print("max |diff| vs cat path:", float((y.float() - y0.float()).abs().max()), "of", float(y0.float().abs().max()))
+print("guarded buffers checked:", bench.check_guards())

@@ -8,6 +8,9 @@ set -u
 OUT=${1:-refresh}
 R=$GRAFT_REPO_ROOT
 D=$R/gpurun_out/$OUT
+# a FRESH directory per refresh: the listing below is cut from the one trace this call writes, stamped by the traced
+# process itself (bench.py --stamp; step_listing.py checks the trace's pid against the stamp and copies its hashes)
+rm -rf $D
 mkdir -p $D
 cd $R
 line() { python -c "
@@ -24,13 +27,14 @@ timeout 600 python bench.py --res 128x1024 --batch-per-gpu 32 --steps 10 --warmu
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $D/bench_noextra.log 2>/dev/null; line bench_noextra
 DGV2_DIST_WORLD1=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $D/bench_one_rank_rccl.log 2> $D/bench_one_rank_rccl.err; line bench_one_rank_rccl
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $D/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $D/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --stamp $D/prof_stamp.json > $D/prof.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/pmc_f -- python3 $R/scripts/pmc_probe.py > $D/pmc_f.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/pmc_w -- python3 $R/scripts/pmc_probe.py > $D/pmc_w.log 2>&1
 export DGV2_DIST_WORLD1=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $D/prof_rccl -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $D/prof_rccl.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $D/prof_rccl -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra --stamp $D/prof_rccl_stamp.json > $D/prof_rccl.log 2>&1
 unset DGV2_DIST_WORLD1 RANK WORLD_SIZE LOCAL_RANK MASTER_ADDR MASTER_PORT
 cd $R
 python scripts/pmc_collect.py $D/pmc_f $D/pmc_w > $D/pmc.json 2> $D/pmc_collect.err
-f=$(find $D/prof -name "*kernel_trace.csv" | head -1); python scripts/step_listing.py $f --full --json $D/step_instances.json --kernel "conv_x3_kernelILi1|conv_pipe_kernel.*Li32ELi1ELi4ELi|conv3x3_strip|modconv_up_kernel" > $D/step_listing.txt; head -36 $D/step_listing.txt
-f=$(find $D/prof_rccl -name "*kernel_trace.csv" | head -1); python scripts/step_listing.py $f --full --kernel "nccl|rccl|oneRank|Reduce" > $D/one_rank_rccl_listing.txt; head -6 $D/one_rank_rccl_listing.txt
+f=$(ls -t $(find $D/prof -name "*kernel_trace.csv") | head -1); python scripts/step_listing.py $f --full --json $D/step_instances.json --stamp $D/prof_stamp.json --kernel "conv_x3_kernelILi1|conv_pipe_kernel.*Li32ELi1ELi4ELi|conv3x3_strip|modconv_up_kernel" > $D/step_listing.txt; head -36 $D/step_listing.txt
+f=$(ls -t $(find $D/prof -name "*kernel_stats.csv") | head -1); cp $f $D/bench_kernel_stats.csv   # same process as the listing
+f=$(ls -t $(find $D/prof_rccl -name "*kernel_trace.csv") | head -1); python scripts/step_listing.py $f --full --kernel "nccl|rccl|oneRank|Reduce" > $D/one_rank_rccl_listing.txt; head -6 $D/one_rank_rccl_listing.txt

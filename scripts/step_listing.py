@@ -3,12 +3,15 @@ of bench.py or scripts/prof_plain.py): which kernels one G body / D body / R1 bo
 duration averaged over the replays of that body.  The bodies are cut at the fused Adam launches (the G optimizer's is
 the short one, D's the long one; a D body that directly follows a D body is the lazy-R1 pass) and only the bodies with
 the modal launch count of their kind are averaged (the graph replays; eager warm-up bodies differ).
-usage: python scripts/step_listing.py <kernel_trace.csv> [--full] [--kernel REGEX] [--json OUT]
+usage: python scripts/step_listing.py <kernel_trace.csv> [--full] [--kernel REGEX] [--json OUT --stamp STAMP]
   default: per-body totals, bucket table per plain iteration (G + D body) and launch counts
   --full:  every launch of the three bodies (index, avg us, grid, workgroup, name)
   --kernel REGEX: per-launch durations (every replay) of the launches whose name matches, grouped by grid
   --json OUT: the (kernel, grid) instances of a TRAINING iteration (G body + D body + R1 body / 16) with their time, share
-              and launch count, largest first, stamped with the hash of the HIP sources (bench.py ranks `roofline` by it)"""
+              and launch count, largest first (bench.py ranks `roofline` by it).  The identity of the measured kernels
+              is COPIED from STAMP, the file the profiled `bench.py --stamp STAMP` process wrote next to its trace; this
+              script never hashes the tree it happens to run in (a listing cut later, on a changed tree, would otherwise
+              certify kernels it was not measured on), and refuses --json without a stamp"""
 import collections
 import csv
 import re
@@ -81,6 +84,11 @@ def main():
     full = "--full" in sys.argv
     pat = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else None
     rows = load(path)
+    if "--stamp" in sys.argv:
+        import json
+        st = json.load(open(sys.argv[sys.argv.index("--stamp") + 1]))
+        print(f"# trace {path.split('/')[-1]} of `bench.py {' '.join(st.get('argv') or [])}` (pid {st.get('pid')}); kernels: "
+              f"src_sha16 {st.get('src_sha16')}, {st.get('lib')} sha16 {st.get('lib_sha16')}")
     per = collections.defaultdict(list)
     for kind, b in bodies(rows):
         per[kind].append(b)
@@ -128,16 +136,17 @@ def main():
             for j, (l, a) in enumerate(zip(bs[0], avg)):
                 print(f"{j:4d} {a:9.1f} us  grid {str(l[3]):22s} wg {l[4][0]:4d}  {bucket(l[2]):14s} {l[2][:120]}")
     if "--json" in sys.argv:
-        import hashlib
-        import glob
         import json
         import os
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        h = hashlib.sha256()
-        for f in sorted(glob.glob(os.path.join(root, "dusty-gan-v2_amd", "csrc", "*.hip")) +
-                        glob.glob(os.path.join(root, "dusty-gan-v2_amd", "csrc", "*.h"))):
-            h.update(os.path.basename(f).encode())
-            h.update(open(f, "rb").read())
+        if "--stamp" not in sys.argv:
+            raise SystemExit("--json needs --stamp FILE (written by the profiled `bench.py --stamp FILE` process)")
+        stamp = json.load(open(sys.argv[sys.argv.index("--stamp") + 1]))
+        if not stamp.get("src_sha16"):
+            raise SystemExit("the stamp file carries no src_sha16")
+        # rocprofv3 names a trace <pid>_kernel_trace.csv: the stamp must come from the very process that was traced
+        m = re.match(r"(\d+)_", os.path.basename(path))
+        if m and stamp.get("pid") is not None and int(m.group(1)) != int(stamp["pid"]):
+            raise SystemExit(f"trace {os.path.basename(path)} was not written by the stamped process (pid {stamp['pid']})")
         inst = collections.defaultdict(lambda: [0.0, 0.0])
         weight = {"g": 1.0, "d": 1.0, "r1": 1.0 / 16.0}
         for kind, (bs, avg, _) in summary.items():
@@ -145,7 +154,8 @@ def main():
                 inst[(l[2], l[3])][0] += a * weight[kind]
                 inst[(l[2], l[3])][1] += weight[kind]
         tot = sum(v[0] for v in inst.values())
-        out = {"src_sha16": h.hexdigest()[:16], "source": os.path.basename(path),
+        out = {"src_sha16": stamp["src_sha16"], "lib_sha16": stamp.get("lib_sha16"), "bench_argv": stamp.get("argv"),
+               "source": os.path.basename(path),
                "us_per_training_iteration": tot, "launches_per_training_iteration": sum(v[1] for v in inst.values()),
                "bodies": {k: {"launches": len(v[1]), "kernel_us": sum(v[1]), "span_us": v[2], "replays": len(v[0])}
                           for k, v in summary.items()},
