@@ -44,6 +44,22 @@ def world_size():
     return dist.get_world_size() if is_dist() else 1
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """ONE side stream per device for every captured reduction of this process.  Invariant: all collectives of one RCCL
+    communicator are issued in one order on every rank AND never run unordered against each other -- two graph replays
+    on two streams, or a replay beside a c10d collective on c10d's own stream, have no ordering the communicator could
+    rely on.  Every FlatGradSync of a process (G's and D's) therefore replays on this one stream, and a caller that
+    follows a captured reduction with a collective issued elsewhere (parallel.tail_exchange on the main stream) joins
+    the side stream first (FlatGradSync.wait)."""
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class FlatGradSync:
     """Owns the gradients of `module`: p.grad are views of self.flat (fp32)."""
 
@@ -82,6 +98,8 @@ class FlatGradSync:
         self._sync = True
         # all_reduce_captured: the reductions of the step as hipGraphs on a side stream (see there)
         self._cg, self._cg_warm, self._side = {}, {}, None
+        self.capture = True         # Trainer sets this to its use_graphs: eager runs keep c10d's asynchronous form
+        self.last_carried = False   # did the most recent all_reduce(carry=True) actually carry rank 0's buffers?
 
     def zero(self):
         self.flat.zero_()
@@ -164,6 +182,15 @@ class FlatGradSync:
     def carries_buffers(self):
         return bool(self._carry)
 
+    def carry_ok(self):
+        """True when a reduction issued NOW with carry=True would carry (re-validated per call: cheap pointer compares).
+        A replayed graph froze the buffer addresses it captured: a module whose buffers were re-registered since must
+        not count as synchronised by the replay."""
+        if not self._carry:
+            return False
+        before = [b.data_ptr() for b in self._carry]
+        return self._carry_valid() and before == [b.data_ptr() for b in self._carry]
+
     def _carry_valid(self):
         """The carried buffer list was captured at construction; module.to(...), load_state_dict(assign=True) or a
         re-registered buffer replace the tensors.  Re-derive the list (as sync_buffers does) and re-point the views when
@@ -195,7 +222,12 @@ class FlatGradSync:
             # 0.3 ms per iteration: profiles/round5_one_rank_rccl_listing.txt) that no multi-rank run has
             avg = False
         _, (lo, hi) = self._part(part)
+        want_carry = bool(carry)
         carry = bool(carry and self._carry and hi == self.flat.numel() and self._carry_valid())
+        if want_carry:
+            # the caller (Trainer.step) decides from this whether its sync_buffers fallback has to run.  Inside a captured
+            # graph this line ran at capture time only: Trainer re-validates with carry_ok() outside the graph.
+            self.last_carried = carry
         if carry:
             # rank 0's values + zeros from everybody else: x + 0 + ... + 0 = x exactly, so the carried part must see a
             # plain SUM.  Where the reduction AVERAGES (RCCL), rank 0 pre-multiplies by W -- exact only for a power-of-two
@@ -236,14 +268,14 @@ class FlatGradSync:
         falls back to the eager asynchronous form for good.  CPU / gloo: the eager form."""
         if not (self._sync and is_dist()):
             return None
-        if (not self.flat.is_cuda or dist.get_backend() != "nccl" or os.environ.get("DGV2_NO_CAPTURED_COLLECTIVES")
-                or self.payload_dtype is not None):
+        if (not self.capture or not self.flat.is_cuda or dist.get_backend() != "nccl"
+                or os.environ.get("DGV2_NO_CAPTURED_COLLECTIVES") or self.payload_dtype is not None):
             return self.all_reduce(async_op=True, part=part, carry=carry)
         key = (part, bool(carry))
         if self._cg.get(key, "") is None:
             return self.all_reduce(async_op=True, part=part, carry=carry)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.flat.device)
+            self._side = _side_stream(self.flat.device)
         cur = torch.cuda.current_stream(self.flat.device)
         side = self._side
         side.wait_stream(cur)

@@ -158,6 +158,9 @@ class Trainer:
         # counters on the device
         self.use_graphs = bool(cfg.training.get("hip_graph", False))
         self._graphs, self._graph_warm = {}, {}
+        self.g_sync.capture = self.d_sync.capture = self.use_graphs   # eager runs keep c10d's asynchronous reductions
+        self.reuse_d_bank = os.environ.get("DGV2_NO_BANK_REUSE") is None
+        self._d_bank_captured = self.d_bank_reused = False
         self.optim_G = optim.Adam(self.G.parameters(), lr=lg.alpha * ratio_G, capturable=self.use_graphs, fused=self.device.type == "cuda",
                                   betas=(float(lg.beta1) ** ratio_G, float(lg.beta2) ** ratio_G))
         self.optim_D = optim.Adam(self.D.parameters(), lr=ld.alpha * ratio_D, capturable=self.use_graphs, fused=self.device.type == "cuda",
@@ -175,7 +178,12 @@ class Trainer:
         self.native_rng = (bool(cfg.training.get("native_rng", True)) and self.device.type == "cuda"
                            and isinstance(self.G, _v2.Generator))
         if self.native_rng:
-            _native.rng_state(self.device)
+            # (re)seeded from torch's seed of THIS moment and rewound, in place (captured bodies of an earlier Trainer keep
+            # reading the same device words): a run is reproducible from torch.manual_seed / init_random_seed like the
+            # reference's torch.randn path.  The STREAM is Philox4x32-10 with its own counter layout, not torch's
+            # generator: same distributions (moment-tested), different numbers -- "parity unpinned" for the draws
+            # themselves, which is why every parity test injects them.
+            _native.rng_state(self.device, seed=torch.initial_seed())
         self._body = None
         self._d_bank_fresh = False   # True between the G step's D forward and the next D optimizer step
         self._gp_scalar = torch.zeros((), device=self.device)   # the last R1 penalty (input of the captured tail exchange)
@@ -195,6 +203,8 @@ class Trainer:
                 self.pl_ema.copy_(sd["pl_ema"].to(self.device).reshape(()))
             self.optim_G.load_state_dict(sd["optim_G"])
             self.optim_D.load_state_dict(sd["optim_D"])
+            if self.native_rng and "rng_state" in sd:   # continue the Philox stream where the saved run stopped
+                _native.rng_state(self.device).copy_(sd["rng_state"].to(torch.int64))
             self.g_sync.rebind()
             self.d_sync.rebind()
 
@@ -351,7 +361,11 @@ class Trainer:
         z = self._z("g")
         x_fake = self.G(z, noise=self._g_noise("g"), **self.auxin)["image"]
         y_fake = self.D(self.A(self.warmup(x_fake, self._draw("g.keep")), draws=self._ada("g.ada")))
-        self._d_bank_fresh = True    # D's weight bank now matches D's weights (until the next D optimizer step)
+        # D's weight bank now matches D's weights (until the next D optimizer step).  WHERE it lives decides who may
+        # read it again: built inside a capture it sits in this body's graph pool and every replay rewrites it in place;
+        # built eagerly it is an ordinary allocation that the next eager G step replaces (and frees).
+        self._d_bank_fresh = True
+        self._d_bank_captured = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         y_real = None
         if x_real is not None:   # relativistic objectives only (trainer.py:279-285: the augmented reals are detached)
             with torch.no_grad():
@@ -388,7 +402,13 @@ class Trainer:
         # D(real) and D(fake) in ONE pass over the discriminator (minibatch-stddev per half), instead of
         # the reference's two calls (trainer.py:391-392): same result, half the launches / weight reads
         # (the G step's D forward prepared the weight bank of these very weights: only G has moved since)
-        reuse = {"reuse_bank": True} if (self._d_bank_fresh and hasattr(self.D, "_bank_keep")) else {}
+        # A captured D body bakes the bank's ADDRESSES in: it may reuse only a bank that a captured G body rewrites at
+        # those addresses before every replay; an eager D body only a bank an eager G body just built.  A G body that
+        # fell back to eager (failed capture, DGV2_GRAPHS) beside a captured D body -- or the reverse -- rebuilds.
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        reuse = {"reuse_bank": True} if (self.reuse_d_bank and self._d_bank_fresh and hasattr(self.D, "_bank_keep")
+                                         and capturing == self._d_bank_captured) else {}
+        self.d_bank_reused = bool(reuse)
         y = self.D(x_both, splits=2, **reuse, **({"cut": True} if cut else {}))
         y_real, y_fake = y[:self.B], y[self.B:]
         if self.adversarial_loss.can_fuse(y):
@@ -642,14 +662,17 @@ class Trainer:
         if fold:
             if late_reals:
                 self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
-            self._run("g_opt", g_reduce_opt)
-            self._g_bufs_synced = self.g_sync.carries_buffers()
+            # (its own body name: "g_opt" is the Adam-only graph of the non-folded form and of the path-length step)
+            ok = self.g_sync.carry_ok()   # outside the graph: a replay carries what it carried at capture time
+            self._run("g_red_opt", g_reduce_opt)
+            self._g_bufs_synced = ok and self.g_sync.last_carried
         else:
+            ok = self.g_sync.carry_ok()
             h = self.g_sync.all_reduce_captured(carry=True)
             if late_reals:
                 self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
             self.g_sync.wait(h)
-            self._g_bufs_synced = h is not None and self.g_sync.carries_buffers()
+            self._g_bufs_synced = h is not None and ok and self.g_sync.last_carried
             self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
 
         if self.pl_weight > 0.0 and iteration % self.lazy_pl == 0:
@@ -657,10 +680,11 @@ class Trainer:
                 if j == 0 and not self._g_bufs_synced:
                     parallel.sync_buffers(self.G)
                 log(self._run(self._acc_name("pl_fb", j), self.pl_fb, j))
+            ok = self.g_sync.carry_ok()
             h = self.g_sync.all_reduce_captured(carry=True)
             self.g_sync.wait(h)
-            self._g_bufs_synced = h is not None and self.g_sync.carries_buffers()
-            self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
+            self._g_bufs_synced = h is not None and ok and self.g_sync.last_carried
+            self._run("g_opt", lambda sc: self._opt_step(self.optim_G))   # Adam only: the reduction ran just above
 
         pending = []
         for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
@@ -703,9 +727,8 @@ class Trainer:
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
             for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
                 log(self._run(self._acc_name("r1_fb", j), self.r1_fb, real(j), j))
-            # R1's 154 MB leave asynchronously as well: the packing launches of the tail exchange run under them (the
-            # exchange itself queues behind the reduction on the communication stream).  The optimizer step cannot move
-            # past the next iteration's G step, whose D forward must see the regularised weights (trainer.py:419-451).
+            # R1's 154 MB leave asynchronously; the scalar bookkeeping below runs under them.  The optimizer step cannot
+            # move past the next iteration's G step, whose D forward must see the regularised weights (trainer.py:419-451).
             if not fold:
                 r1_pending = self.d_sync.all_reduce_captured()
 
@@ -722,6 +745,13 @@ class Trainer:
                 res["stats/ada_p"] = self.A.p.detach().clone()
             sc.update(res)
 
+        # One communicator, one order: the tail exchange below is a second collective of the SAME RCCL communicator,
+        # issued from the main stream (as a graph replay) or from c10d's stream (eager) -- neither is ordered against
+        # a reduction replaying on the side stream, and two unordered collectives of one communicator can interleave
+        # differently per rank (hang / corrupted buffers).  Join the reduction first (parallel._side_stream's invariant).
+        if r1_pending is not None:
+            self.d_sync.wait(r1_pending)
+            r1_pending = None
         gp_key = "loss/D/gradient_penalty"
         captured_tail = (parallel.is_dist() and nacc == 1 and self.use_graphs and self.device.type == "cuda"
                          and torch.distributed.get_backend() == "nccl")
@@ -746,7 +776,6 @@ class Trainer:
             if fold:   # (with the split D the plain step's optimizer graph reduces the "rest" segment only: another body)
                 self._run("d_opt" if rest is None else "d_all_opt", d_reduce_opt(None))
             else:
-                self.d_sync.wait(r1_pending)
                 self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
         set_requires_grad(self.D, False)
 
@@ -870,6 +899,11 @@ class Trainer:
         }
         if self.pl_weight > 0.0:
             ckpt["pl_ema"] = self.pl_ema.detach().cpu()
+        if self.native_rng:
+            # one key more than the reference writes (it restores no RNG state): (seed, offset, ticket, 0) of
+            # the device-side Philox stream, so that a resumed run does not replay the draws of its first iterations
+            from gans.models.ops import native as _native
+            ckpt["rng_state"] = _native.rng_state(self.device).detach().cpu()
         self.check_status()   # (state_dict -> file synchronises anyway) never write weights trained on a broken promise
         save_path.parent.mkdir(parents=True, exist_ok=True)
         torch.save(ckpt, save_path)

@@ -67,7 +67,10 @@ def test_checkpoint_roundtrip(tmp_path):
     assert type(raw["cfg"]) is dict and type(raw["cfg"]["model"]) is dict
     from gans.pretrained import load_checkpoint
     ck = load_checkpoint(path)
-    assert set(ck) == {"cfg", "step", "angle", "G", "D", "G_ema", "A", "optim_G", "optim_D"}  # reference keys
+    ref_keys = {"cfg", "step", "angle", "G", "D", "G_ema", "A", "optim_G", "optim_D"}  # reference keys
+    assert ref_keys <= set(ck) <= ref_keys | {"rng_state"}     # (+ the Philox stream state of the one-launch RNG)
+    if "rng_state" in ck:
+        assert ck["rng_state"].dtype == torch.int64 and ck["rng_state"].shape == (4,) and int(ck["rng_state"][1]) > 0
     assert ck["angle"].shape == (1, 2, 16, 64) and ck["step"] == 8
     from gans.models.builder import build_generator
     G = build_generator(ck["cfg"].model.generator)
@@ -481,3 +484,44 @@ def test_relativistic_objectives_use_the_reals_in_the_generator_step(objective):
     assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
     live = tg.graphs_live()
     assert "g_fb" in live and all(live.values()), live
+
+
+# ---------------------------------------------------------------------------- the D step on the G step's weight bank
+@pytest.mark.parametrize("mode", ["eager", "graph", "g_eager_d_graph"])
+def test_d_step_on_the_g_steps_weight_bank_equals_a_fresh_bank(mode, monkeypatch):
+    """Trainer.d_fb passes reuse_bank=True when the G step's D forward has just prepared the compute-dtype copies of these
+    very weights.  Bit for bit the same iterations with the reuse switched off (reuse_d_bank = False: every D forward
+    builds its bank), eagerly and as replayed hipGraphs.  Third case: the G body runs EAGERLY beside a captured D body
+    (DGV2_GRAPHS excludes it -- the same state a failed capture of g_fb leaves): the captured D body must then not have
+    baked in the addresses of a bank that the next eager G step frees; it rebuilds its own (d_bank_reused False)."""
+    d = _load_trainer_fixture()
+    tag = "t."
+    hip_graph = mode != "eager"
+    if mode == "g_eager_d_graph":
+        monkeypatch.setenv("DGV2_GRAPHS", "d_fb,d_opt,g_opt,r1_fb")   # (matched before the /inj suffix)
+    a, hp, sdG, sdD = _fixture_trainer(d, tag, hip_graph, low_precision=True)
+    b, _, _, _ = _fixture_trainer(d, tag, hip_graph, low_precision=True)
+    b.reuse_d_bank = False
+    n_its = hp["iterations"]
+    outs = []
+    for tr in (a, b):
+        _reset(tr, hp, sdG, sdD)
+        for it in range(1, 7):     # two eager warm runs + the captures (R1 on even iterations), then replays
+            _run_fixture_iteration(tr, d, tag, it, n_its)
+        # one more iteration from the fixture's initial state (in place: the graphs keep their addresses); an eager G
+        # step has replaced its bank several times by now, so a captured D body reading a baked-in address would read
+        # freed memory here
+        _reset(tr, hp, sdG, sdD)
+        out = _run_fixture_iteration(tr, d, tag, 1, n_its)
+        outs.append({k: float(v) for k, v in out.items() if torch.is_tensor(v)})
+    assert a.d_bank_reused == (mode != "g_eager_d_graph") and not b.d_bank_reused
+    if hip_graph:
+        live = a.graphs_live()
+        assert live.get("d_fb/inj") is True and (("g_fb/inj" in live) == (mode == "graph")), live
+    # same kernels on the same numbers whether the bank was rebuilt or kept; float atomics in the weight-gradient
+    # reductions are the only run-to-run noise (Adam with beta1 = 0 turns a flipped near-zero gradient entry into 2 lr)
+    for k in outs[0]:
+        assert abs(outs[0][k] - outs[1][k]) <= 1e-4 * (abs(outs[0][k]) + 1e-3), (k, outs[0][k], outs[1][k])
+    for name, ma, mb in (("G", a.G, b.G), ("D", a.D, b.D)):
+        frac = _state_mismatch(ma.state_dict(), mb.state_dict())
+        assert frac < 2e-3, (name, frac)
