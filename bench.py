@@ -143,7 +143,7 @@ def _time_launches(fn, reps):
     return s.elapsed_time(e) * 1e-3 / reps
 
 
-PMC_FILE = os.path.join("profiles", "round5_pmc.json")
+PMC_FILE = os.path.join("profiles", "round6_pmc.json")
 
 
 PMC_BATCH_PER_GPU = 64   # scripts/pmc_probe.py launches the probes at this --batch-per-gpu
