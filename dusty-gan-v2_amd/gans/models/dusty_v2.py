@@ -551,6 +551,14 @@ class SynthesisNetwork(nn.Module):
             a = layer.downsample_angle(a, None, None)
             pyr.insert(0, a)
         if _CONST_CACHE and not (angle.is_cuda and torch.cuda.is_current_stream_capturing()):
+            old = getattr(self, "_pyr", None)
+            if (old is not None and len(old) == len(pyr)
+                    and all(a.shape == b.shape and a.dtype == b.dtype and a.device == b.device for a, b in zip(old, pyr))):
+                # refreshed IN PLACE (FourierFeature.encoded explains why): graphs captured on the old pyramid keep
+                # reading these addresses.  Level -1 is the caller's own tensor.
+                for a, b in zip(old[:-1], pyr[:-1]):
+                    a.copy_(b)
+                pyr = old[:-1] + [angle]
             self._pyr_src, self._pyr_key, self._pyr = angle, key, pyr
         return pyr
 

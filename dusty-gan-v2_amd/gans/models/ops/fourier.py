@@ -17,6 +17,12 @@ import os as _os
 _CONST_CACHE = _os.environ.get("DGV2_NO_CONST_CACHE") is None
 
 
+def _refresh_in_place(old, shape, dtype, device):
+    """May a constant-cache entry be overwritten where it lies (same shape / dtype / device, and no capture running)?"""
+    return (old is not None and tuple(old.shape) == tuple(shape) and old.dtype == dtype and old.device == torch.device(device)
+            and not (old.is_cuda and torch.cuda.is_current_stream_capturing()))
+
+
 class FourierFeature(nn.Module):
     def __init__(self, resolution, basis_scale="random", num_freqs=512, L_offset=(3, -1), mapping=False,
                  mapping_ch=64):
@@ -59,7 +65,14 @@ class FourierFeature(nn.Module):
         cached, and rebuilt when the buffer changes (load_state_dict, .to())."""
         f = self.freqs
         if getattr(self, "_fw_src", None) is not f or self._fw_key != f._version:
-            self._fw_src, self._fw_key, self._fw = f, f._version, f.reshape(-1, 2)[:, 1].contiguous()
+            new = f.reshape(-1, 2)[:, 1]
+            old = getattr(self, "_fw", None)
+            if _refresh_in_place(old, new.shape, new.dtype, new.device):
+                old.copy_(new)           # same address: see encoded()
+                new = old
+            else:
+                new = new.contiguous()
+            self._fw_src, self._fw_key, self._fw = f, f._version, new
         return self._fw
 
     def encoded(self, angle, dtype):
@@ -68,15 +81,25 @@ class FourierFeature(nn.Module):
         on it.  The entry is valid for the very tensor OBJECTS it was computed from (held by the entry, so their storage
         cannot be recycled for another grid) at the versions they had; a fresh or modified angle tensor always misses.
         Nothing is cached while a hipGraph is being captured (a tensor born inside a capture belongs to that graph's
-        memory pool)."""
+        memory pool).  A miss that finds an entry of the same shape REFRESHES IT IN PLACE: a hipGraph captured while
+        the old entry was live has its address baked in, and an eager pass that replaced the tensor (after a
+        load_state_dict bumped the buffers' versions, say) would free it under that graph -- round 6 met exactly this
+        as NaNs from a captured D body beside an eager G body (tests/test_gpu_trainer.py, mode g_eager_d_graph)."""
         key = (angle._version, tuple(angle.shape), dtype, self.freqs._version, self.phase._version)
         src = getattr(self, "_enc_src", None)
         if src is not None and src[0] is angle and src[1] is self.freqs and src[2] is self.phase and self._enc_key == key:
             return self._enc
         H, W = angle.shape[2:]
-        pe0 = torch.empty((1, H, W, self.out_ch), device=angle.device, dtype=dtype)
-        self.encode_into(pe0, 0, angle)
-        if _CONST_CACHE and not (angle.is_cuda and torch.cuda.is_current_stream_capturing()):
+        capturing = angle.is_cuda and torch.cuda.is_current_stream_capturing()
+        old = getattr(self, "_enc", None)
+        if _CONST_CACHE and not capturing and _refresh_in_place(old, (1, H, W, self.out_ch), dtype, angle.device):
+            pe0 = old
+            self.encode_into(pe0, 0, angle)
+            native.pe_frag16(pe0, refresh=True)     # the operand image that rides on the table, in place as well
+        else:
+            pe0 = torch.empty((1, H, W, self.out_ch), device=angle.device, dtype=dtype)
+            self.encode_into(pe0, 0, angle)
+        if _CONST_CACHE and not capturing:
             self._enc_src, self._enc_key, self._enc = (angle, self.freqs, self.phase), key, pe0
         return pe0
 

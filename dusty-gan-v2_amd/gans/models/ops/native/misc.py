@@ -233,16 +233,25 @@ def up2_lag_sumsq(x, spec):
     return sq[0][:sq[1].value]
 
 
-def pe_frag16(xs):
+def pe_frag16(xs, refresh=False):
     """The batch-shared PE [1,H,W,Ks] as the B-fragment image of dgv2_modconv_up_fwd, [H*W/16][Ks/32][4][16][8]: element
     [p][k] at [p/16][k/32][(k%32)/8][p%16][k%8].  The PE is a constant of the run (FourierFeature.encoded caches it), so
     the image is built once per PE tensor and version and lives ON that tensor (captured graphs read it for as long as
-    the PE exists; a process-wide cache with eviction would free it under them).  Built inside a capture it is not kept."""
+    the PE exists; a process-wide cache with eviction would free it under them).  Built inside a capture it is not kept.
+    refresh: xs was rewritten in place by a native call (FourierFeature.encoded refreshing its table; no version bump):
+    an existing image is rebuilt IN PLACE, so that graphs which captured its address read the new table."""
     ent = getattr(xs, "_dgv2_frag16", None)
-    if ent is not None and ent[0] == xs._version:
+    if ent is not None and ent[0] == xs._version and not refresh:
         return ent[1]
     P, Ks = xs.shape[1] * xs.shape[2], xs.shape[3]
-    img = xs.reshape(P // 16, 16, Ks // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+    src = xs.reshape(P // 16, 16, Ks // 32, 4, 8).permute(0, 2, 3, 1, 4)
+    if ent is not None and not (xs.is_cuda and torch.cuda.is_current_stream_capturing()):
+        ent[1].copy_(src)
+        xs._dgv2_frag16 = (xs._version, ent[1])
+        return ent[1]
+    if refresh:
+        return None          # nothing to refresh yet
+    img = src.contiguous()
     if not (xs.is_cuda and torch.cuda.is_current_stream_capturing()):
         xs._dgv2_frag16 = (xs._version, img)
     return img

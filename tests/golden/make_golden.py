@@ -913,6 +913,107 @@ def golden_full_b4():
     save("model_full_b4.npz", out)
 
 
+def golden_128x1024():
+    """BASELINE configs[4]'s shape (128 x 1024, full widths: one level / one ResidualBlock more than 64 x 512) run by the
+    REFERENCE itself: G step through ADA and D, D step, lazy R1 -- at B = 4 (one whole minibatch-stddev group).  Every
+    large input is a recipe both sides evaluate (weights: recipe.fill_state_dict; sensor grid: recipe.angle_grid; z,
+    reals: seeded private generators; shifts / Gumbel uniforms: the reference's own global-generator draws under a
+    seed, recipe.g_noise) with its norm stored for the check that the recipe reproduced it; stored outright: the PE
+    tables (numpy RNG in the reference ctor), the ADA draws, and of the outputs three rows per map, per-sample norms,
+    logits, losses, the norm and the leading 32 entries of every gradient.  <= 1 MB."""
+    RES = (128, 1024)
+    B = 4
+    cfg = _refshim.load_cfg()
+    cfg.model.generator.synthesis_kwargs.resolution = list(RES)
+    cfg.model.discriminator.layer_kwargs.resolution = list(RES)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    G = build_generator(cfg.model.generator)
+    D = build_discriminator(cfg.model.discriminator)
+    recipe.fill_state_dict(G.state_dict(), 1234)
+    recipe.fill_state_dict(D.state_dict(), 4321)
+    out = {}
+    for k, v in G.state_dict().items():
+        if k.endswith(("pe.freqs", "pe.phase")):
+            out["G." + k] = v.clone()
+    H, W = RES
+    ang1 = recipe.angle_grid(H, W)
+    ang = ang1.repeat_interleave(B, dim=0)
+    A = AdaptiveAugment(p_init=0.6, p_target=0.6, kimg=500, **cfg.training.augment.policy)
+    z = torch.randn(B, 512, generator=torch.Generator().manual_seed(19))
+    x_real = recipe.uniform_reals(B, H, W, 29)
+    crit = GANLoss("nsgan")
+    rows = [0, 63, 127]
+    out.update(seed_z=19, seed_reals=29, seed_g=301, rows=np.asarray(rows), B=B,
+               check_angle_norm=ang1.double().norm(), check_z_norm=z.double().norm(), check_x_real_norm=x_real.double().norm())
+
+    # ---- G step (trainer.py:262-306)
+    G.train().requires_grad_(True)
+    D.requires_grad_(False)
+    shifts, u = recipe.g_noise(B, RES, 301)
+    s2, u2 = capture_g_noise(B, RES, 301)
+    assert torch.equal(shifts, s2) and torch.equal(u, u2)
+    torch.manual_seed(301)
+    o = G(z, angle=ang)
+    Gm, Cm = capture_ada(A, B, H, W, 302)
+    torch.manual_seed(302)
+    x_aug = A(o["image"])
+    y_fake = D(x_aug)
+    loss_G = crit(None, y_fake, "G")
+    params = dict(G.named_parameters())
+    grads = torch.autograd.grad(loss_G, list(params.values()), allow_unused=True)
+    out.update(check_u_norm=u.double().norm(), check_shifts=shifts, gs_adaG=Gm, gs_adaC=Cm, gs_y_fake=y_fake, gs_loss=loss_G)
+    for name in ("image_orig", "raydrop_logit", "image"):
+        v = o[name].detach()
+        out[f"gs_{name}_rows"] = v[:, 0, rows].clone()                       # [B, 3, 1024]
+        out[f"gs_{name}_norm"] = v.double().flatten(1).norm(dim=1)
+        out[f"gs_{name}_mean"] = v.double().mean(dim=[1, 2, 3])
+    out["gs_x_aug_rows"] = x_aug.detach()[:, 0, rows].clone()
+    out["gs_x_aug_norm"] = x_aug.detach().double().flatten(1).norm(dim=1)
+    for k, gv in zip(params.keys(), grads):
+        if gv is not None:
+            out[f"gs_gradnorm.{k}"] = gv.double().norm()
+            out[f"gs_gradslice.{k}"] = gv.flatten()[:32].clone()
+    for k, v in G.state_dict().items():
+        if k.endswith("ema_var") or k == "w_avg":
+            out["G1buf." + k] = v.clone()
+    print("128x1024: G step done", flush=True)
+
+    # ---- D step (trainer.py:367-417) on the fakes of the G step
+    G.requires_grad_(False)
+    D.requires_grad_(True)
+    Gr, Cr = capture_ada(A, B, H, W, 303)
+    torch.manual_seed(303)
+    xr = A(x_real).detach()
+    y_real = D(xr)
+    y_fake2 = D(x_aug.detach())
+    loss_D = crit(y_real, y_fake2, "D")
+    dparams = dict(D.named_parameters())
+    dgrads = torch.autograd.grad(loss_D, list(dparams.values()))
+    out.update(ds_adaG_real=Gr, ds_adaC_real=Cr, ds_y_real=y_real, ds_loss=loss_D)
+    for k, gv in zip(dparams.keys(), dgrads):
+        out[f"ds_gradnorm.{k}"] = gv.double().norm()
+        out[f"ds_gradslice.{k}"] = gv.flatten()[:32].clone()
+    print("128x1024: D step done", flush=True)
+
+    # ---- lazy R1 (trainer.py:419-451)
+    Gm, Cm = capture_ada(A, B, H, W, 304)
+    xin = x_real.detach().clone().requires_grad_(True)
+    torch.manual_seed(304)
+    y = D(A(xin))
+    (gx,) = torch.autograd.grad(y.sum(), xin, create_graph=True)
+    r1 = (gx ** 2).sum(dim=[1, 2, 3]).mean()
+    loss = (16.0 / 2) * r1 + 0.0 * y.squeeze()[0]
+    rgrads = torch.autograd.grad(loss, list(dparams.values()), allow_unused=True)
+    out.update(r1_adaG=Gm, r1_adaC=Cm, r1_gradx_rows=gx.detach()[:, 0, rows].clone(),
+               r1_gradx_norm=gx.detach().double().flatten(1).norm(dim=1), r1_penalty=r1.detach())
+    for k, gv in zip(dparams.keys(), rgrads):
+        if gv is not None:
+            out[f"r1_gradnorm.{k}"] = gv.double().norm()
+            out[f"r1_gradslice.{k}"] = gv.flatten()[:32].clone()
+    save("model_128x1024.npz", out)
+
+
 def chamfer_inputs():
     """Seeded cloud pairs for chamfer.npz: scan-like random clouds of ragged sizes, a batch, a single point, and integer
     lattices (many exactly tied distances: the first minimum must win)."""
@@ -946,11 +1047,13 @@ def golden_chamfer():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation", "metrics", "baselines", "chamfer", "full_b4"]
+    which = sys.argv[1:] or ["ops", "coords", "geometry", "small", "full", "trainer", "kitti", "validation", "metrics", "baselines", "chamfer", "full_b4", "128x1024"]
     if "chamfer" in which:
         golden_chamfer()
     if "full_b4" in which:
         golden_full_b4()
+    if "128x1024" in which:
+        golden_128x1024()
     if "ops" in which:
         golden_ops()
     if "coords" in which:

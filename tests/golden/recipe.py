@@ -107,3 +107,33 @@ def baseline_cfg(arch):
                measurement_kwargs=dict(raydrop_const=-1.0, gumbel_temperature=1.0))
     dis = dict(arch="vanilla", layer_kwargs=dict(in_ch=1, ch_base=4, ch_max=16, resolution=[32, 64], ring=True))
     return gen, dis
+
+
+def angle_grid(H, W):
+    """A sensor grid by formula for the fixtures whose resolution has no angle file (128 x 1024, BASELINE configs[4];
+    SURVEY 8d's synthetic grid): elevation +2 deg ... -24.8 deg top to bottom, azimuth pi ... -pi left to right, each
+    computed in float64 and rounded once.  Generator.forward takes any angle grid (base.py:26-63).  [1, 2, H, W]."""
+    elev = torch.linspace(2.0, -24.8, H, dtype=torch.float64).mul(3.141592653589793 / 180.0)
+    azim = 3.141592653589793 - 2.0 * 3.141592653589793 * (torch.arange(W, dtype=torch.float64) + 0.5) / W
+    return torch.stack([elev[:, None].expand(H, W), azim[None, :].expand(H, W)])[None].float().contiguous()
+
+
+def g_noise(B, hw, seed):
+    """The azimuth shifts and Gumbel uniforms a training forward of the reference generator draws from torch's GLOBAL
+    generator after torch.manual_seed(seed) (SynthesisNetwork.forward dusty_v2.py:268-273, RelaxedBernoulli.rsample) --
+    the call sequence of make_golden.capture_g_noise, replayed on a forked generator.  The CPU generator's stream is the
+    same on every machine for one torch version, so a fixture can name the SEED instead of storing a megabyte of draws
+    (it stores their norms: the test checks it regenerated what the reference consumed).  -> (shifts [B], u [B,1,H,W])"""
+    import math
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)
+        shifts = torch.zeros((B, 2))
+        shifts[:, 1].uniform_(0, 1)
+        shifts = shifts.mul(2 * math.pi)
+        u = torch.distributions.utils.clamp_probs(torch.rand(B, 1, *hw))
+    return shifts[:, 1].clone(), u
+
+
+def uniform_reals(B, H, W, seed):
+    """Real batch by recipe for the same fixtures: x ~ U(-1, 1) [B, 1, H, W] from a private generator."""
+    return torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(seed)) * 2.0 - 1.0

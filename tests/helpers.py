@@ -116,3 +116,31 @@ def oracle_f64_full(d, angle):
         return out
     finally:
         torch.set_default_dtype(old)
+
+
+def inputs_128x1024(d):
+    """Everything tests/golden/model_128x1024.npz names by RECIPE, rebuilt and checked against the norms the fixture
+    stores of what the reference consumed (tests/golden/make_golden.py::golden_128x1024): reference-layout state dicts
+    (weights by recipe, PE tables from the fixture), sensor grid [1,2,128,1024], z, the G step's shifts / Gumbel
+    uniforms (the reference's own global-generator draws under the fixture's seed), the real batch."""
+    import recipe
+    RES = (128, 1024)
+    B = int(d["B"])
+    cfg = full_cfg()
+    cfg.model.generator.synthesis_kwargs.resolution = list(RES)
+    cfg.model.discriminator.layer_kwargs.resolution = list(RES)
+    G, D = build_models(cfg, "cpu")
+    sdG = recipe.fill_state_dict({k: v.clone() for k, v in G.state_dict().items()}, 1234)
+    sdD = recipe.fill_state_dict({k: v.clone() for k, v in D.state_dict().items()}, 4321)
+    for k in d:
+        if k.startswith("G."):
+            assert sdG[k[2:]].shape == d[k].shape, k
+            sdG[k[2:]] = d[k].clone()
+    angle = recipe.angle_grid(*RES)
+    z = torch.randn(B, 512, generator=torch.Generator().manual_seed(int(d["seed_z"])))
+    shifts, u = recipe.g_noise(B, RES, int(d["seed_g"]))
+    x_real = recipe.uniform_reals(B, *RES, int(d["seed_reals"]))
+    same = lambda t, key: abs(float(t.double().norm()) - float(d[key])) <= 1e-9 * float(d[key])
+    assert same(angle, "check_angle_norm") and same(z, "check_z_norm") and same(x_real, "check_x_real_norm")
+    assert same(u, "check_u_norm") and torch.equal(shifts, d["check_shifts"]), "the recipe did not reproduce the draws"
+    return dict(cfg=cfg, sdG=sdG, sdD=sdD, angle=angle, z=z, shifts=shifts, u=u, x_real=x_real, B=B, rows=[int(r) for r in d["rows"]])

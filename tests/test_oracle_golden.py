@@ -318,12 +318,50 @@ def test_full_size_steps_match_reference(g_full, g_coords):
     close(lossd, d["ds_loss"], rtol=1e-4)
     keys = [k for k, v in D.items() if v.requires_grad]
     _slice_check(dict(zip(keys, torch.autograd.grad(lossd, [D[k] for k in keys]))), d, "ds_", 32)
+    # lazy R1 (double backward through D and ADA)
+    r1, rgrads, rex = step.r1_step(I["sdD"], I["x_real"], 16.0, ada={"G": d["r1_adaG"], "C": d["r1_adaC"]})
+    close(r1, d["r1_penalty"], rtol=1e-3)
+    close(rex["grad_x"][:, 0, rows], d["r1_gradx_rows"], rtol=1e-3, atol=1e-3 * float(d["r1_gradx_rows"].abs().max()))
+    top = max(float(v) for k, v in d.items() if k.startswith("r1_gradnorm."))
+    _slice_check({k: v for k, v in rgrads.items() if v is not None}, d, "r1_", 32, rtol_norm=2e-3, floor=1e-5 * top)
     # lazy R1
     r1, rgrads, rex = step.r1_step(sdD, d["x_real"], 16.0, ada={"G": d["r1_adaG"], "C": d["r1_adaC"]})
     close(r1, d["r1_penalty"], rtol=1e-3)
     close(rex["grad_x"][:, :, 31], d["r1_gradx_row"], rtol=1e-3, atol=1e-3 * float(d["r1_gradx_row"].abs().max()))
     top = max(float(v) for k, v in d.items() if k.startswith("r1_gradnorm."))
     _slice_check({k: v for k, v in rgrads.items() if v is not None}, d, "r1_", 32, rtol_norm=2e-3, floor=1e-5 * top)
+
+
+def test_steps_at_128x1024_match_reference():
+    """The oracle at BASELINE configs[4]'s shape against tests/golden/model_128x1024.npz, which the REFERENCE produced at
+    128 x 1024, full widths, B = 4 (one level / one ResidualBlock more than 64 x 512): G step through ADA and D (rows and
+    per-sample norms of every output map, logits, loss, norm and leading slice of every parameter gradient, the
+    buffers after the step) the D step and the lazy R1 pass (double backward).  This pins the oracle at the resolution the 128 x 1024 GPU tests lean
+    on it for."""
+    from helpers import inputs_128x1024
+    d = load_golden("model_128x1024.npz")
+    I = inputs_128x1024(d)
+    B, rows = I["B"], I["rows"]
+    ang = I["angle"].repeat_interleave(B, 0)
+    loss, grads, bufs, ex = step.g_step(I["sdG"], I["sdD"], I["z"], ang, I["shifts"], I["u"],
+                                        ada={"G": d["gs_adaG"], "C": d["gs_adaC"]})
+    close(loss, d["gs_loss"], rtol=1e-4)
+    close(ex["y_fake"], d["gs_y_fake"], rtol=1e-3, atol=1e-3 * float(d["gs_y_fake"].abs().max()))
+    for name, key in (("image", "gs_image"), ("x_aug", "gs_x_aug")):
+        close(ex[name][:, 0, rows], d[f"{key}_rows"], rtol=1e-3, atol=1e-3)      # values in [-1, 1]; north_star's 1e-3
+        norm = ex[name].double().flatten(1).norm(dim=1)
+        assert float(((norm - d[f"{key}_norm"]).abs() / d[f"{key}_norm"]).max()) < 1e-4, name
+    _slice_check(grads, d, "gs_", 32)
+    for k, v in sub_dict(d, "G1buf.").items():
+        close(bufs[k], v, rtol=1e-5, atol=1e-6)
+    D = step.with_grad(I["sdD"], step.D_BUFFER_SUFFIXES)
+    xr = augment.ada_forward(I["x_real"], d["ds_adaG_real"], d["ds_adaC_real"])
+    y_real, y_fake = model.discriminator(D, xr), model.discriminator(D, ex["x_aug"])
+    lossd = model.loss_d_nsgan(y_real, y_fake)
+    close(y_real, d["ds_y_real"], rtol=1e-3, atol=1e-3 * float(d["ds_y_real"].abs().max()))
+    close(lossd, d["ds_loss"], rtol=1e-4)
+    keys = [k for k, v in D.items() if v.requires_grad]
+    _slice_check(dict(zip(keys, torch.autograd.grad(lossd, [D[k] for k in keys]))), d, "ds_", 32)
 
 
 def test_full_width_discriminator_at_batch_4_matches_reference():
