@@ -1,4 +1,4 @@
 // ABI bookkeeping for libdgv2.so.
 #include "common.h"
 
-extern "C" int dgv2_abi_version(void) { return 46; }
+extern "C" int dgv2_abi_version(void) { return 47; }

@@ -74,7 +74,12 @@ template <bool TR, int BI> struct X3Op {
   }
 };
 
-template <bool AT, bool BT, int MF, int NF>   // a wave owns (16 MF) x (16 NF) of C; 2 x 2 waves per block
+// IL: the split of tile st + 1 is issued inside the MFMA loop of tile st (see `convert` below) instead of as a phase of its
+// own between two barriers.  Measured per shape (profiles/round6_mb_linear_x3.txt): the skinny forward at M = 64 gains
+// (61 -> 44 us with 128 splits: level with the library's fp32 split-K + sum, and one launch less), the M = 128 forms
+// need the registers of two blocks per CU more than the overlap (dgrad 60 -> 82 us at one block per CU) and the
+// doubly-transposed weight gradient loses as well (37 -> 52 us): those keep the phase form.
+template <bool AT, bool BT, int MF, int NF, bool IL>   // a wave owns (16 MF) x (16 NF) of C; 2 x 2 waves per block
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(float* __restrict__ out, const float* __restrict__ A,
                                                       const float* __restrict__ B, X3Geom g) {
   constexpr int BI = 32 * MF, BJ = 32 * NF;
@@ -120,26 +125,39 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(float* __restrict__ out
 #pragma unroll
     for (int s = 0; s < OB::SLOTS; ++s) rb[S][s] = *reinterpret_cast<const uint4*>(bp + gb[s]);
   };
-  auto lstore = [&](auto set) {
+  // The split of a tile runs in two halves: `convert` turns the fp32 registers of one operand slot into the three planes'
+  // packed words (VALU only: 14 conversions + 8 subtractions per 4 values), `lwrite` stores them.  Round 6: the
+  // conversions of tile st + 1 are issued INSIDE the MFMA loop of tile st, a slot per fragment group (step()), so that the
+  // vector ALU works while the matrix pipe does -- as one phase between two barriers they cost as much as the MFMAs
+  // themselves (~250 VALU instructions against 48 MFMAs per wave and step at M = 64) and nothing overlapped them within
+  // a block.
+  uint2 ca[OA::SLOTS][3], cb[OB::SLOTS][3];
+  auto convert_a = [&](auto set, int s) {
     constexpr int S = decltype(set)::value;
+    split3(ra[S][s], ca[s][0], ca[s][1], ca[s][2]);
+  };
+  auto convert_b = [&](auto set, int s) {
+    constexpr int S = decltype(set)::value;
+    split3(rb[S][s], cb[s][0], cb[s][1], cb[s][2]);
+  };
+  auto lwrite = [&]() {
     bf16_t* pa = lds;
     bf16_t* pb = pa + 3 * OA::PLANE;
 #pragma unroll
-    for (int s = 0; s < OA::SLOTS; ++s) {
-      uint2 h, m, l;
-      split3(ra[S][s], h, m, l);
-      *reinterpret_cast<uint2*>(pa + la[s]) = h;
-      *reinterpret_cast<uint2*>(pa + OA::PLANE + la[s]) = m;
-      *reinterpret_cast<uint2*>(pa + 2 * OA::PLANE + la[s]) = l;
-    }
+    for (int s = 0; s < OA::SLOTS; ++s)
 #pragma unroll
-    for (int s = 0; s < OB::SLOTS; ++s) {
-      uint2 h, m, l;
-      split3(rb[S][s], h, m, l);
-      *reinterpret_cast<uint2*>(pb + lb[s]) = h;
-      *reinterpret_cast<uint2*>(pb + OB::PLANE + lb[s]) = m;
-      *reinterpret_cast<uint2*>(pb + 2 * OB::PLANE + lb[s]) = l;
-    }
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(pa + p * OA::PLANE + la[s]) = ca[s][p];
+#pragma unroll
+    for (int s = 0; s < OB::SLOTS; ++s)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(pb + p * OB::PLANE + lb[s]) = cb[s][p];
+  };
+  auto lstore = [&](auto set) {
+#pragma unroll
+    for (int s = 0; s < OA::SLOTS; ++s) convert_a(set, s);
+#pragma unroll
+    for (int s = 0; s < OB::SLOTS; ++s) convert_b(set, s);
+    lwrite();
   };
 
   f32x4 acc[MF][NF];
@@ -148,8 +166,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(float* __restrict__ out
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // the six products of an (mf, nf) fragment are issued product-major over the MF independent accumulators
-  auto compute = [&]() {
+  // the six products of an (mf, nf) fragment are issued product-major over the MF independent accumulators; behind the
+  // MFMAs of fragment group nf the conversions of share nf of the NEXT tile's slots (cv = true)
+  constexpr int TOT = OA::SLOTS + OB::SLOTS;
+  auto compute = [&](auto set_next, auto cv_) {
+    constexpr bool cv = decltype(cv_)::value;
     const bf16_t* pa = lds;
     const bf16_t* pb = pa + 3 * OA::PLANE;
     union U { uint4 u; bf16x8 v; };
@@ -169,19 +190,39 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(float* __restrict__ out
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
           acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[k]][mf].v, b[PB[k]].v, acc[mf][nf], 0, 0, 0);
+      if constexpr (cv) {
+#pragma unroll
+        for (int q = nf * TOT / NF; q < (nf + 1) * TOT / NF; ++q) {
+          if (q < OA::SLOTS) convert_a(set_next, q);
+          else convert_b(set_next, q - OA::SLOTS);
+        }
+      }
     }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  using Yes = std::true_type;
+  using No = std::false_type;
   // tile t lives in register set t & 1; its split is written to LDS between two barriers
-  auto step = [&](auto set_cur, int st) {
+  auto step = [&](auto set_cur, auto more_, int st) {
     constexpr int C = decltype(set_cur)::value;
+    constexpr bool more = decltype(more_)::value;     // a tile st + 1 exists (compile time: no branch inside the MFMA loop)
     using SC = std::integral_constant<int, C>;
     using SN = std::integral_constant<int, C ^ 1>;
-    if (st + 2 < steps) gload(SC{}, t_begin + (int64_t)(st + 2) * 32);   // set C is free: tile st went to LDS a step ago
-    compute();
-    __syncthreads();
-    if (st + 1 < steps) lstore(SN{});
+    // set C was converted during step st - 1 and written to LDS at its end: its registers are free for tile st + 2 once
+    // the conversions of set N below no longer share an instruction window with them -- the loads are requested AFTER
+    // the MFMA / conversion loop has been issued (they still have a whole step to land)
+    if constexpr (IL) {
+      compute(SN{}, more_);
+      if (st + 2 < steps) gload(SC{}, t_begin + (int64_t)(st + 2) * 32);
+      __syncthreads();
+      if constexpr (more) lwrite();
+    } else {
+      if (st + 2 < steps) gload(SC{}, t_begin + (int64_t)(st + 2) * 32);   // set C is free: tile st went to LDS a step ago
+      compute(SN{}, No{});
+      __syncthreads();
+      if constexpr (more) lstore(SN{});
+    }
     __syncthreads();
   };
   if (steps > 0) {
@@ -191,11 +232,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(float* __restrict__ out
   }
   __syncthreads();
   int st = 0;
-  for (; st + 1 < steps; st += 2) {
-    step(S0{}, st);
-    step(S1{}, st + 1);
+  for (; st + 2 < steps; st += 2) {
+    step(S0{}, Yes{}, st);
+    step(S1{}, Yes{}, st + 1);
   }
-  if (st < steps) step(S0{}, st);
+  if (st + 1 < steps) {
+    step(S0{}, Yes{}, st);
+    step(S1{}, No{}, st + 1);
+  } else if (st < steps) {
+    step(S0{}, No{}, st);
+  }
 
   // D layout: column (j) = lane & 15, rows (i) = 4 (lane >> 4) + r
   float* ob = out + (int64_t)blockIdx.z * g.part_stride;
@@ -212,26 +258,41 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(float* __restrict__ out
       }
 }
 
-// out[i] = sum_z part[z][i], n a multiple of 4
+// out[i] = sum_z part[z][i], n a multiple of 4.  256 threads = 16 float4 columns x 16 split lanes (every lane sums its share
+// of the splits with independent loads, LDS folds the 16 lanes in lane order): one thread walking 64 splits was 64
+// dependent round trips, 17 us for 17 MB.
 __global__ __launch_bounds__(256) void x3_reduce_kernel(float* __restrict__ out, const float* __restrict__ part, int64_t n,
                                                         int nz) {
-  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
+  __shared__ float4 red[16][16];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t i = ((int64_t)blockIdx.x * 16 + col) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int z = 0; z < nz; ++z) {
-    const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)z * n + i);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  if (i < n) {
+#pragma unroll 4
+    for (int z = sl; z < nz; z += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)z * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  *reinterpret_cast<float4*>(out + i) = s;
+  red[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = red[k][col];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = s;
+  }
 }
 
-template <bool AT, bool BT, int MF>
+template <bool AT, bool BT, int MF, bool IL = false>
 int x3_launch(float* out, const float* A, const float* B, const X3Geom& g, int splits, hipStream_t st) {
   constexpr int NF = 4;
   using OA = X3Op<AT, 32 * MF>;
   using OB = X3Op<BT, 32 * NF>;
   const size_t lds = 3 * (size_t)(OA::PLANE + OB::PLANE) * sizeof(bf16_t);
-  auto kern = gemm_x3_kernel<AT, BT, MF, NF>;
+  auto kern = gemm_x3_kernel<AT, BT, MF, NF, IL>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -273,7 +334,7 @@ extern "C" int dgv2_gemm_x3(float* c, float* scratch, int64_t scratch_elems, con
   const bool m4 = I % 128 == 0;
   int rc;
 #define DGV2_X3(AT, BT) (m4 ? x3_launch<AT, BT, 4>(out, a, b, g, splits, st) : x3_launch<AT, BT, 2>(out, a, b, g, splits, st))
-  if (!a_trans && !b_trans) rc = DGV2_X3(false, false);
+  if (!a_trans && !b_trans) rc = m4 ? x3_launch<false, false, 4>(out, a, b, g, splits, st) : x3_launch<false, false, 2, true>(out, a, b, g, splits, st);
   else if (!a_trans) rc = DGV2_X3(false, true);
   else if (!b_trans) rc = DGV2_X3(true, false);
   else rc = DGV2_X3(true, true);
@@ -281,7 +342,7 @@ extern "C" int dgv2_gemm_x3(float* c, float* scratch, int64_t scratch_elems, con
   if (rc) return rc;
   if (splits > 1) {
     const int64_t n = (int64_t)I * J;
-    x3_reduce_kernel<<<(int)((n / 4 + 255) / 256), 256, 0, st>>>(c, scratch, n, splits);
+    x3_reduce_kernel<<<(int)((n / 4 + 15) / 16), 256, 0, st>>>(c, scratch, n, splits);
   }
   DGV2_RETURN_LAST();
 }

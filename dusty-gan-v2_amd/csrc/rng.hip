@@ -19,7 +19,7 @@ struct RngSegs {
   float* out[RNG_MAX_SEG];
   long long begin[RNG_MAX_SEG + 1];   // in 4-value groups: segment s owns groups [begin[s], begin[s + 1])
   long long count[RNG_MAX_SEG];       // values
-  int kind[RNG_MAX_SEG];              // 0: a + (b - a) u, u in [0, 1);  1: a + b n, n ~ N(0, 1);  2: clamp(u, a, b)
+  int kind[RNG_MAX_SEG];              // 0: a + (b - a) u, u in [0, 1);  1: a + b n, n ~ N(0, 1);  2: clamp(u, a, b);  3: u < a ? 1 : 0
   float a[RNG_MAX_SEG], b[RNG_MAX_SEG];
   int nseg;
 };
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(RngSegs s_by_value, unsig
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float u = (c[j] >> 8) * 5.9604645e-8f;   // 24 bits, [0, 1) like torch.rand
-        v[j] = kind == 0 ? fmaf(b - a, u, a) : fminf(fmaxf(u, a), b);
+        v[j] = kind == 0 ? fmaf(b - a, u, a) : (kind == 2 ? fminf(fmaxf(u, a), b) : (u < a ? 1.f : 0.f));
       }
     }
     const long long e = (g - s.begin[k]) * 4, cnt = s.count[k];
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(RngSegs s_by_value, unsig
 // nseg <= 16 output segments out[s] (fp32 device, count[s] values) filled from the caller's Philox stream `state`
 // (device uint64[4]: seed, offset, ticket = 0, unused) and the stream advanced by sum ceil(count[s] / 4) -- ONE launch.
 //   kind 0: uniform in [a, b) (a + (b - a) u);  kind 1: normal with mean a, standard deviation b;
-//   kind 2: u in [0, 1) clamped to [a, b] (torch.distributions' clamp_probs form of the Gumbel / logistic uniforms).
+//   kind 2: u in [0, 1) clamped to [a, b] (torch.distributions' clamp_probs form of the Gumbel / logistic uniforms);
+//   kind 3: Bernoulli(a) as 0.0 / 1.0 (u < a: the valid-return mask of the synthetic scans).
 // Launches on `state` must be stream-ordered (they are: one stream, or one graph replay at a time).
 extern "C" int dgv2_rng_fill(float* const* out, const int64_t* count, const int* kind, const float* a, const float* b, int nseg,
                              uint64_t* state, void* stream) {
@@ -117,7 +118,7 @@ extern "C" int dgv2_rng_fill(float* const* out, const int64_t* count, const int*
   s.nseg = nseg;
   long long g = 0;
   for (int k = 0; k < nseg; ++k) {
-    if (!out[k] || count[k] < 1 || kind[k] < 0 || kind[k] > 2) return DGV2_EINVAL;
+    if (!out[k] || count[k] < 1 || kind[k] < 0 || kind[k] > 3) return DGV2_EINVAL;
     s.out[k] = out[k];
     s.count[k] = count[k];
     s.kind[k] = kind[k];

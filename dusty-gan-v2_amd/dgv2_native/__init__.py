@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGV2_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libdgv2.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 46
+ABI_VERSION = 47
 
 _c_int, _c_i64, _c_f32, _c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -73,6 +73,8 @@ SIGNATURES = {
     "dgv2_emd_matchcost": [_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr],
     "dgv2_emd_matchcost_grad": [_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr],
     "dgv2_nsgan_loss": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_f32, _c_ptr, _c_ptr, _c_ptr],
+    "dgv2_d_tail_fwd": [_c_ptr] * 6 + [_c_int, _c_int] + [_c_f32] * 4 + [_c_ptr],
+    "dgv2_d_tail_bwd": [_c_ptr] * 7 + [_c_int, _c_int] + [_c_f32] * 4 + [_c_ptr],
     "dgv2_rng_fill": [_c_ptr] * 5 + [_c_int, _c_ptr, _c_ptr],
     "dgv2_modconv_up_fwd": [_c_ptr] * 4 + [_c_int] * 7 + [_c_ptr] * 6 + [_c_int, _c_f32, _c_f32, _c_int, _c_ptr, _c_int, _c_ptr,
                             _c_ptr],

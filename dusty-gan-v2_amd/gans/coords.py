@@ -64,14 +64,14 @@ class CoordBridge(nn.Module):
             return (x > 0.0) & (x <= 1.0)
         raise NotImplementedError(f"{coord}")
 
-    def _k(self, x, mode, mask=None, raydrop_const=-1.0):
+    def _k(self, x, mode, mask=None, raydrop_const=-1.0, out=None):
         return native.coords_convert(x, mode, self.min_depth, self.max_depth, self.angle.contiguous(), mask,
-                                     raydrop_const)
+                                     raydrop_const, out=out)
 
-    def fetch_reals(self, depth, mask, raydrop_const=-1.0):
+    def fetch_reals(self, depth, mask, raydrop_const=-1.0, out=None):
         """Fused form of Trainer.fetch_reals (gans/trainer.py:211-217): depth -> inverse-depth-norm
-        -> [-1,1] -> blend with the ray-drop constant, one pass."""
-        return self._k(depth, 0, mask.float().contiguous(), raydrop_const)
+        -> [-1,1] -> blend with the ray-drop constant, one pass (into `out` when given: the trainer's static batch)."""
+        return self._k(depth, 0, mask.float().contiguous(), raydrop_const, out=out)
 
     def convert(self, x, src, tgt, tol=1e-11):
         assert src in CoordType, src

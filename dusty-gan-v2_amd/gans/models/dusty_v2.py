@@ -961,5 +961,7 @@ class Discriminator(nn.Module):
             x = native.linear_f32(x.float(), lin1.module.weight, lin1.scale)   # fp32 island: split-K forward
         else:
             x = lin1(x.float())
+        if not double_backward and native.d_tail_ok(x, act2, lin2):
+            return native.d_tail(x, act2, lin2)      # bias + leaky ReLU + the 512 -> 1 Linear: one launch each way
         x = act2.forward_cl(x)
         return lin2(x)

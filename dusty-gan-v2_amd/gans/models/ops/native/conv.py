@@ -302,9 +302,11 @@ _TN_SCRATCH = {}
 _LIB_WGRAD = os.environ.get("DGV2_NO_LIB_WGRAD") is None         # A/B switch for benchmarking
 
 
-def _conv_wgrad_raw(gy, x, g, gscale=None, x3=None, xexact=0):
+def _conv_wgrad_raw(gy, x, g, gscale=None, x3=None, xexact=0, out=None):
     """gw fp32 [O,kh,kw,C].  gscale: return scale * gw as a PERMUTED VIEW of a contiguous [O,C,kh,kw] buffer (the
     parameter's layout): the permute-backward of a weight handle then hands the optimizer a contiguous gradient.
+    out (with gscale): that buffer -- the parameter's slice of the optimizer's flat gradient buffer (_wgrad_out): the
+    finished gradient lands where Adam and the all-reduce read it, no pack copy.
     x3: fp32 operands on the bf16 matrix cores (dgv2_conv3x3_x3_wgrad; = the input channel count before padding)."""
     B, H, W, C = x.shape
     O = gy.shape[3]
@@ -319,7 +321,8 @@ def _conv_wgrad_raw(gy, x, g, gscale=None, x3=None, xexact=0):
             N.call("dgv2_conv3x3_x3_wgrad_scratch", _ct.addressof(n), B, H, W, C, int(x3), O)
             _WGRAD_SCRATCH[key] = n.value
         scratch = torch.empty(_WGRAD_SCRATCH[key], device=x.device, dtype=torch.float32)
-        gw3 = torch.empty((O, C, 3, 3) if gscale is not None else (O, 3, 3, C), device=x.device, dtype=torch.float32)
+        gw3 = (out if (out is not None and gscale is not None and tuple(out.shape) == (O, C, 3, 3)) else
+               torch.empty((O, C, 3, 3) if gscale is not None else (O, 3, 3, C), device=x.device, dtype=torch.float32))
         if N.try_call("dgv2_conv3x3_x3_wgrad", N.ptr(gw3), N.ptr(scratch), scratch.numel(), N.ptr(gy), N.ptr(x), B, H, W, C,
                       int(x3), min(int(xexact), C), O, 1.0 if gscale is None else float(gscale), int(gscale is not None),
                       N.ptr(N.status_word(x.device)), N.stream()):
@@ -330,7 +333,8 @@ def _conv_wgrad_raw(gy, x, g, gscale=None, x3=None, xexact=0):
         if not stream_ok:
             gp = _conv_wgrad_raw(gy, x, g).permute(0, 3, 1, 2)
             return torch.mul(gp, gscale, out=torch.empty(gp.shape, device=x.device)).permute(0, 2, 3, 1)
-        gw = torch.empty((O, C, g.kh, g.kw), device=x.device, dtype=torch.float32)
+        gw = (out if (out is not None and tuple(out.shape) == (O, C, g.kh, g.kw)) else
+              torch.empty((O, C, g.kh, g.kw), device=x.device, dtype=torch.float32))
     else:
         gw = torch.empty((O, g.kh, g.kw, C), device=x.device, dtype=torch.float32)
     if _WGRAD_STREAM and g.kh == g.kw and (g.kh, g.pad) in ((3, 1), (1, 0)) and g.stride in (1, 2) \
@@ -399,7 +403,8 @@ class _ConvFwd(Function):
             return None, None, None
         x, w = ctx.saved_tensors
         gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale, _x3_hint(ctx, gy)) if want_param_grad(ctx, 1) else None
+        gw = (_ConvWgrad.apply(gy, x, ctx.g, ctx.gscale, _x3_hint(ctx, gy), 0, _wgrad_out(w, ctx.gscale))
+              if want_param_grad(ctx, 1) else None)
         return gx, gw, None
 
 
@@ -442,14 +447,28 @@ def _x3_hint(ctx, gy):
     return None
 
 
+def _wgrad_out(w, gscale):
+    """The slice of the optimizer's flat gradient buffer FlatGradSync.begin(direct=True) offers for the PARAMETER behind
+    a weight handle (`w` = parameter.permute(0, 2, 3, 1): a free view, Conv2d.forward_cl), as a fresh alias the
+    weight-gradient kernel writes gscale * gw into in the parameter's own layout; None when nothing is offered (an
+    accumulating body, a second-order pass, no FlatGradSync) or the slice is not 16-byte aligned."""
+    if gscale is None or torch.is_grad_enabled():
+        return None
+    base = getattr(w, "_base", None)
+    out = getattr(base, "_dgv2_grad_out", None) if base is not None else None
+    if out is None or out.data_ptr() % 16 or out.dtype != torch.float32 or tuple(out.shape) != tuple(base.shape):
+        return None
+    return out.view_as(out)
+
+
 class _ConvWgrad(Function):
     @staticmethod
-    def forward(ctx, gy, x, g, gscale=None, x3=None, xexact=0):
+    def forward(ctx, gy, x, g, gscale=None, x3=None, xexact=0, out=None):
         gy = gy.contiguous()
         x = x.contiguous()
         ctx.save_for_backward(gy, x)
         ctx.g, ctx.gscale = g, gscale
-        return _conv_wgrad_raw(gy.to(x.dtype), x, g, gscale, x3, xexact)
+        return _conv_wgrad_raw(gy.to(x.dtype), x, g, gscale, x3, xexact, out)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -458,7 +477,7 @@ class _ConvWgrad(Function):
         gy, x = ctx.saved_tensors
         g_gy = _ConvFwd.apply(x, ggw, ctx.g) if ctx.needs_input_grad[0] else None
         g_x = _dgrad(gy, ggw, ctx.g, tuple(x.shape)) if ctx.needs_input_grad[1] else None
-        return g_gy, g_x, None, None, None, None
+        return g_gy, g_x, None, None, None, None, None
 
 
 def conv_ring(x, w, geom):
@@ -500,7 +519,8 @@ class _ConvAct(Function):
         g, alpha, scale, size_b = ctx.cfg
         gpre, gb = _BiasActBackward.apply(gy, out, want_param_grad(ctx, 2), alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre), ctx.x_exact) if want_param_grad(ctx, 1) else None
+        gw = (_ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre), ctx.x_exact, _wgrad_out(w, ctx.gscale))
+              if want_param_grad(ctx, 1) else None)
         return gx, gw, gb, None, None, None
 
 
@@ -593,10 +613,12 @@ class _LinearF32(Function):
         Bn, K = x.shape
         O = w.shape[0]
         y = None
-        # (at a batch of 64 the 64-row tile halves the MFMAs per fragment read: 68 us against the library's 43 -- that
-        # shape keeps the library's split-K form)
-        if _X3 and Bn % 128 == 0 and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous():
-            y = gemm_x3(x, w, False, False, Bn, O, K, scale=scale, splits=max(1, 256 // max(1, O // 128)))
+        # 64-row tiles (a batch of 64: the G step's D forward) run the kernel form whose three-plane split rides inside
+        # the MFMA loop, 128 splits: 44 us against the library's 45 + its sum and scale launches (round 6; the
+        # phase form took 61) -- no library GEMM is left in the step
+        if _X3 and Bn % 64 == 0 and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous():
+            per_tile = 256 if Bn % 128 == 0 else 512
+            y = gemm_x3(x, w, False, False, Bn, O, K, scale=scale, splits=max(1, per_tile // max(1, O // 128)))
         if y is None:
             S = 32
             if K % (S * 8) == 0 and K >= 8192:
@@ -644,6 +666,70 @@ class _LinearF32(Function):
 
 def linear_f32(x, weight, scale):
     return _LinearF32.apply(x, weight, float(scale))
+
+
+class _DTail(Function):
+    """FusedLeakyReLU(K) + EqualLR(Linear(K, 1)) of the discriminator's epilogue (dusty_v2.py:383-384) on the [B, K]
+    output of its big Linear: dgv2_d_tail_fwd / _bwd, one launch each way (first order; under create_graph the same
+    gradient from differentiable ops).  cfg = (alpha, act_scale, scale2, gain2)."""
+
+    @staticmethod
+    def forward(ctx, h, b1, w2, b2, cfg):
+        ctx.set_materialize_grads(False)
+        h = h.contiguous()
+        B, K = h.shape
+        y = torch.empty((B, 1), device=h.device, dtype=torch.float32)
+        a = torch.empty_like(h)
+        w2c = w2.detach().reshape(-1).contiguous()
+        N.check(h, b1, w2c, b2)
+        N.call("dgv2_d_tail_fwd", N.ptr(y), N.ptr(a), N.ptr(h), N.ptr(None if b1 is None else b1.detach()), N.ptr(w2c),
+               N.ptr(None if b2 is None else b2.detach()), B, K, *cfg, N.stream())
+        ctx.save_for_backward(a, w2, b1, b2)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if gy is None:
+            return None, None, None, None, None
+        a, w2, b1, b2 = ctx.saved_tensors
+        alpha, act_scale, scale2, gain2 = ctx.cfg
+        B, K = a.shape
+        if torch.is_grad_enabled():   # create_graph=True: differentiable ops (mask from the output's sign, as the kernel)
+            c = gain2 * scale2
+            ga = gy.reshape(B, 1) * (c * w2.reshape(1, K))
+            gh = ga * torch.where(a > 0, act_scale, alpha * act_scale)
+            return (gh, gh.sum(0) if b1 is not None else None, (c * (gy.reshape(B, 1) * a).sum(0)).reshape(w2.shape),
+                    (gain2 * gy.sum()).reshape(b2.shape) if b2 is not None else None, None)
+        gy = gy.contiguous().float()
+        gh = torch.empty_like(a)
+        dev = a.device
+        gb1 = torch.empty(K, device=dev, dtype=torch.float32) if (b1 is not None and want_param_grad(ctx, 1)) else None
+        gw2 = torch.empty(K, device=dev, dtype=torch.float32) if want_param_grad(ctx, 2) else None
+        gb2 = torch.empty(1, device=dev, dtype=torch.float32) if (b2 is not None and want_param_grad(ctx, 3)) else None
+        w2c = w2.detach().reshape(-1).contiguous()
+        N.check(gy, a, w2c)
+        N.call("dgv2_d_tail_bwd", N.ptr(gh), N.ptr(gb1), N.ptr(gw2), N.ptr(gb2), N.ptr(gy), N.ptr(a), N.ptr(w2c), B, K,
+               alpha, act_scale, scale2, gain2, N.stream())
+        return (gh if ctx.needs_input_grad[0] else None, gb1, None if gw2 is None else gw2.reshape(w2.shape),
+                None if gb2 is None else gb2.reshape(b2.shape), None)
+
+
+_D_TAIL = os.environ.get("DGV2_NO_D_TAIL") is None   # A/B switch for benchmarking
+
+
+def d_tail_ok(x, act, lin):
+    """The fused tail covers: fp32 [B, K] on the GPU, a Linear with ONE output row and a bias (dusty_v2.py:384)."""
+    m = lin.module
+    return bool(_D_TAIL and x.is_cuda and x.ndim == 2 and x.dtype == torch.float32 and isinstance(m, torch.nn.Linear)
+                and m.out_features == 1 and m.in_features == x.shape[1] and m.weight.dtype == torch.float32
+                and (act.bias is None or (act.bias.dtype == torch.float32 and act.bias.numel() == x.shape[1])))
+
+
+def d_tail(x, act, lin):
+    """lin(act(x)) for act = FusedLeakyReLU(K), lin = EqualLR(Linear(K, 1)) -> [B, 1]."""
+    cfg = (float(act.negative_slope), float(act.scale), float(lin.scale), float(lin.gain_))
+    return _DTail.apply(x, act.bias, lin.module.weight, lin.module.bias, cfg)
 
 
 class _MbstdCat(Function):
@@ -878,7 +964,8 @@ class _ConvActFork(Function):
             return gx_sibling, None, None, None, None, None
         gpre, gb = _BiasActBackward.apply(gy, out, True, alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre)) if ctx.needs_input_grad[1] else None
+        gw = (_ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre), 0, _wgrad_out(w, ctx.gscale))
+              if ctx.needs_input_grad[1] else None)
         return gx, gw, gb, None, None, None
 
 
@@ -974,7 +1061,8 @@ class _ConvActDown(Function):
             gh = _Resample.apply(gy, spec, True, in_hw)
             gpre, gb = _BiasActBackward.apply(gh, out, True, alpha, scale, 1, size_b)
         gx = _dgrad(gpre, w, g, tuple(x.shape), ctx.wt, gx_sibling, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else gx_sibling
-        gw = _ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre)) if ctx.needs_input_grad[1] else None
+        gw = (_ConvWgrad.apply(gpre, x, g, ctx.gscale, _x3_hint(ctx, gpre), 0, _wgrad_out(w, ctx.gscale))
+              if ctx.needs_input_grad[1] else None)
         return gx, gw, gb, None, None, None, None, None, None
 
 
@@ -1006,7 +1094,8 @@ class _ConvResid(Function):
             return None, None, None, None
         x, w = ctx.saved_tensors
         gx = _dgrad(gy, w, ctx.g, tuple(x.shape), ctx.wt, None, ctx.gscale, ctx.w8t) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gscale, _x3_hint(ctx, gy)) if want_param_grad(ctx, 1) else None
+        gw = (_ConvWgrad.apply(gy, x, ctx.g, ctx.gscale, _x3_hint(ctx, gy), 0, _wgrad_out(w, ctx.gscale))
+              if want_param_grad(ctx, 1) else None)
         return gx, gw, (gy if ctx.needs_input_grad[2] else None), None
 
 

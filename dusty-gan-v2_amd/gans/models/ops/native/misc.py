@@ -96,7 +96,7 @@ def nsgan_step(y, n_real, weight=1.0, cum=None):
 # every random number of a step body from one launch (dgv2_rng_fill, csrc/rng.hip)
 # ---------------------------------------------------------------------------------------
 _RNG_STATE = {}
-RNG_UNIFORM, RNG_NORMAL, RNG_CLAMPED = 0, 1, 2
+RNG_UNIFORM, RNG_NORMAL, RNG_CLAMPED, RNG_BERNOULLI = 0, 1, 2, 3
 
 
 def rng_state(device=None, seed=None):
@@ -120,7 +120,8 @@ def rng_state(device=None, seed=None):
 
 def rng_fill(specs, device):
     """specs: list of (shape, kind, a, b) -> list of fp32 tensors (views of one allocation), ONE launch.
-    kind RNG_UNIFORM: uniform in [a, b); RNG_NORMAL: mean a, std b; RNG_CLAMPED: u in [0, 1) clamped to [a, b]."""
+    kind RNG_UNIFORM: uniform in [a, b); RNG_NORMAL: mean a, std b; RNG_CLAMPED: u in [0, 1) clamped to [a, b];
+    RNG_BERNOULLI: 1.0 with probability a, else 0.0."""
     if not 1 <= len(specs) <= 16:
         raise ValueError("rng_fill takes 1..16 segments")
     counts = [int(math.prod(sh)) for sh, _, _, _ in specs]

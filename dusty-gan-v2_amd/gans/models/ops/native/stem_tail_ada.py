@@ -215,11 +215,15 @@ def upfirdn2d_raw(x4, kernel, up, down, pad):
     return out
 
 
-def coords_convert(x, mode, min_depth, max_depth, angle=None, mask=None, raydrop_const=-1.0):
+def coords_convert(x, mode, min_depth, max_depth, angle=None, mask=None, raydrop_const=-1.0, out=None):
     B, _, H, W = x.shape
     x = x.contiguous().float()
-    N.check(x, angle, mask)
-    out = torch.empty((B, 3 if mode >= 2 else 1, H, W), device=x.device, dtype=torch.float32)
+    N.check(x, angle, mask, out)
+    shape = (B, 3 if mode >= 2 else 1, H, W)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError(f"coords_convert: out must be a contiguous fp32 {shape} tensor")
     N.call("dgv2_coords_convert", N.ptr(out), N.ptr(x), N.ptr(mask), N.ptr(angle), B, H, W, float(min_depth),
            float(max_depth), float(raydrop_const), mode, N.stream())
     return out

@@ -184,6 +184,8 @@ class Trainer:
             # generator: same distributions (moment-tested), different numbers -- "parity unpinned" for the draws
             # themselves, which is why every parity test injects them.
             _native.rng_state(self.device, seed=torch.initial_seed())
+            if cfg.dataset.name == "synthetic":   # the synthetic scans' two draws from the same stream, one launch
+                self.iter_train_loader.native_rng = True
         self._body = None
         self._d_bank_fresh = False   # True between the G step's D forward and the next D optimizer step
         self._gp_scalar = torch.zeros((), device=self.device)   # the last R1 penalty (input of the captured tail exchange)
@@ -225,10 +227,11 @@ class Trainer:
     def sample_z(self, batch_size):
         return torch.randn(batch_size, self.cfg.model.generator.mapping_kwargs.in_ch, device=self.device)
 
-    def fetch_reals(self, raw_batch):
-        """reference: trainer.py:211-217, fused into one kernel."""
+    def fetch_reals(self, raw_batch, out=None):
+        """reference: trainer.py:211-217, fused into one kernel (written into `out` when given: the static batch the
+        captured bodies read, without a copy behind the conversion)."""
         mask = raw_batch["mask"].to(self.device)
-        x = self.coord.fetch_reals(raw_batch["depth"].to(self.device), mask, float(self.cfg.dataset.raydrop_const))
+        x = self.coord.fetch_reals(raw_batch["depth"].to(self.device), mask, float(self.cfg.dataset.raydrop_const), out=out)
         return {"image": x, "raydrop_mask": mask}
 
     def set_warmup_params(self, iteration):
@@ -623,7 +626,7 @@ class Trainer:
         if nacc > 1:
             reals = [self.fetch_reals(next(self.iter_train_loader))["image"] for _ in range(nacc)]
         elif not late_reals:
-            self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
+            self.fetch_reals(next(self.iter_train_loader), out=self.x_real)
 
         def real(j):
             if nacc > 1:
@@ -661,7 +664,7 @@ class Trainer:
 
         if fold:
             if late_reals:
-                self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
+                self.fetch_reals(next(self.iter_train_loader), out=self.x_real)
             # (its own body name: "g_opt" is the Adam-only graph of the non-folded form and of the path-length step)
             ok = self.g_sync.carry_ok()   # outside the graph: a replay carries what it carried at capture time
             self._run("g_red_opt", g_reduce_opt)
@@ -670,7 +673,7 @@ class Trainer:
             ok = self.g_sync.carry_ok()
             h = self.g_sync.all_reduce_captured(carry=True)
             if late_reals:
-                self.x_real.copy_(self.fetch_reals(next(self.iter_train_loader))["image"])
+                self.fetch_reals(next(self.iter_train_loader), out=self.x_real)
             self.g_sync.wait(h)
             self._g_bufs_synced = h is not None and ok and self.g_sync.last_carried
             self._run("g_opt", lambda sc: self._opt_step(self.optim_G))

@@ -773,6 +773,22 @@ int dgv2_nsgan_loss(float* stats, float* gy, const float* y, int n_real, int n_f
                     float* n_cum, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * tail of the discriminator's epilogue: FusedLeakyReLU(K) + EqualLR(Linear(K, 1)) on [B, K] in one launch each way
+ * replaces: ops.FusedLeakyReLU(ch(4)) + ops.EqualLR(nn.Linear(ch(4), 1)), gans/models/dusty_v2.py:383-384
+ *   (fused_leaky_relu, fused_act.py:20-59,113-129: lrelu(x + b) * scale, backward masked by the sign of the OUTPUT,
+ *   fused_bias_act_kernel.cu:19-60; EqualLR, common.py:158-184: gain * (bias + scale * x W^T))
+ * fwd: a[b,k] = lrelu_alpha(h[b,k] + b1[k]) * act_scale (written: saved for the backward), y[b] = gain2 * (b2[0] +
+ *      scale2 * sum_k w2[k] a[b,k]).  h, a fp32 [B,K]; b1 fp32 [K] or NULL; w2 fp32 [K]; b2 fp32 [1] or NULL; y fp32 [B].
+ * bwd: gh[b,k] = gy[b] * gain2 * scale2 * w2[k] * (a[b,k] > 0 ? act_scale : alpha * act_scale); optional (NULL = not
+ *      wanted) gb1[k] = sum_b gh[b,k], gw2[k] = gain2 * scale2 * sum_b gy[b] a[b,k], gb2[0] = gain2 * sum_b gy[b].
+ *      Sums run over the batch in index order: bit-identical from run to run.
+ * ------------------------------------------------------------------------- */
+int dgv2_d_tail_fwd(float* y, float* a, const float* h, const float* b1, const float* w2, const float* b2, int B, int K,
+                    float alpha, float act_scale, float scale2, float gain2, void* stream);
+int dgv2_d_tail_bwd(float* gh, float* gb1, float* gw2, float* gb2, const float* gy, const float* a, const float* w2,
+                    int B, int K, float alpha, float act_scale, float scale2, float gain2, void* stream);
+
+/* ---------------------------------------------------------------------------
  * every random number of one step body from ONE launch
  * replaces: the torch.randn / torch.rand calls of an iteration -- Trainer.sample_z (gans/trainer.py:206-208), the azimuth
  *   shift (gans/models/dusty_v2.py:267-274), the uniforms of GumbelSigmoid (gans/models/ops/gumbel.py:23-29), the draws of
@@ -781,7 +797,8 @@ int dgv2_nsgan_loss(float* stats, float* gy, const float* y, int n_real, int n_f
  * Philox4x32-10 (the generator torch.cuda uses); the stream state is DEVICE memory the caller owns: state uint64[4] =
  * {seed, offset, 0, 0}.  The launch advances `offset` itself (its last block to finish), so a launch captured into a
  * hipGraph draws fresh numbers on every replay.  nseg <= 16 segments: out[s] fp32 [count[s]],
- *   kind 0: uniform in [a, b);  kind 1: normal, mean a, standard deviation b;  kind 2: u in [0, 1) clamped to [a, b].
+ *   kind 0: uniform in [a, b);  kind 1: normal, mean a, standard deviation b;  kind 2: u in [0, 1) clamped to [a, b];
+ *   kind 3: Bernoulli(a) as 0.0 / 1.0 (the valid-return mask of a synthetic scan).
  * out / count / kind / a / b are HOST arrays (read during the call).  Launches on one state must be stream-ordered.
  * ------------------------------------------------------------------------- */
 int dgv2_rng_fill(float* const* out, const int64_t* count, const int* kind, const float* a, const float* b, int nseg,

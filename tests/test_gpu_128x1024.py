@@ -176,10 +176,14 @@ def test_fp32_steps_match_the_reference_fixture_at_128x1024():
     xin = I["x_real"].to(DEV).clone().requires_grad_(True)
     yr = D(A(xin, draws={"G": d["r1_adaG"], "C": d["r1_adaC"]}), double_backward=True)
     (gx,) = torch.autograd.grad(yr.sum(), xin, create_graph=True)
-    # a unit next to a leaky-ReLU kink may land on the other side and move the patch of pixels below it (as at 64 x 512,
-    # tests/test_gpu_full.py): nearly every entry within 1e-3 of the maximum, none far off; the per-sample norms to 1e-3
+    # A unit next to a leaky-ReLU kink may land on the other side and move the patch of pixels below it (as at 64 x 512,
+    # tests/test_gpu_full.py).  Measured at this size against the oracle in float64 (scripts/dbg/r1_128.py, whole
+    # tensor): the REFERENCE's arithmetic in fp32 has 0.18 % of its entries beyond 1e-3 of the maximum (worst 4.6 %), the
+    # HIP path 0.14 % (worst 2.5 %), both relative L2 ~5e-3 and both concentrated in the 16 rows next to the replicate
+    # borders (1 %) -- where two of the fixture's three rows lie.  Hence: nearly every entry of those rows within 1e-3,
+    # none far off, and the per-sample norms to 1e-3.
     egx = (gx[:, 0, rows].detach().double().cpu() - d["r1_gradx_rows"].double()).abs() / float(d["r1_gradx_rows"].abs().max())
-    assert float((egx > 1e-3).double().mean()) < 3e-3 and float(egx.max()) < 5e-2, (float((egx > 1e-3).double().mean()), float(egx.max()))
+    assert float((egx > 1e-3).double().mean()) < 5e-2 and float(egx.max()) < 0.1, (float((egx > 1e-3).double().mean()), float(egx.max()))
     nrm = gx.detach().double().flatten(1).norm(dim=1).cpu()
     assert float(((nrm - d["r1_gradx_norm"]).abs() / d["r1_gradx_norm"]).max()) < 1e-3
     r1 = (gx ** 2).sum(dim=[1, 2, 3]).mean()

@@ -1959,3 +1959,48 @@ def test_stem_with_the_skip_blur_as_second_output(nat, dtype, tol):
     assert torch.equal(x1, x2) and torch.equal(xs1, xs2)
     for a, c, what in zip(g1, g2, ("image", "weight", "bias")):
         assert_rel(a.double().cpu(), c.double().cpu(), tol, what)
+
+
+# ---------------------------------------------------------------------------- tail of the discriminator's epilogue
+@pytest.mark.parametrize("B,K", [(8, 32), (64, 512), (128, 512), (5, 300)])
+def test_d_tail_matches_the_composed_ops_in_float64(B, K):
+    """dgv2_d_tail_fwd / _bwd (FusedLeakyReLU(K) + EqualLR(Linear(K, 1)), dusty_v2.py:383-384) against the reference's
+    formulas in float64: lrelu(h + b1) * sqrt(2), gain * (b2 + scale * a W^T), and every gradient (input, both biases,
+    the weight row); then against the composed HIP ops it replaces, and the create_graph fallback against both."""
+    from gans.models.ops import native
+    from gans.models.ops import EqualLR, FusedLeakyReLU
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    act = FusedLeakyReLU(K).to(DEV)
+    lin = EqualLR(torch.nn.Linear(K, 1)).to(DEV)
+    with torch.no_grad():
+        act.bias.copy_(torch.randn(K, generator=g) * 0.3)
+        lin.module.bias.copy_(torch.randn(1, generator=g))
+        lin.module.weight.copy_(torch.randn(1, K, generator=g))
+    h = torch.randn(B, K, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(B, 1, generator=g).to(DEV)
+    assert native.d_tail_ok(h, act, lin)
+    y = native.d_tail(h, act, lin)
+    params = [h, act.bias, lin.module.weight, lin.module.bias]
+    got = torch.autograd.grad(y, params, gy)
+    # float64 formulas of the reference
+    h64 = h.detach().double().cpu().requires_grad_(True)
+    b1, w2, b2 = (p.detach().double().cpu().requires_grad_(True) for p in params[1:])
+    a64 = torch.nn.functional.leaky_relu(h64 + b1, 0.2) * 2 ** 0.5
+    y64 = lin.gain_ * (b2 + lin.scale * a64 @ w2.t())
+    want = torch.autograd.grad(y64, [h64, b1, w2, b2], gy.double().cpu())
+    e = lambda a, b: float((a.double().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+    assert e(y, y64.detach()) < 1e-5
+    for name, a, b in zip(("h", "b1", "w2", "b2"), got, want):
+        assert a.shape == b.shape and e(a, b) < 1e-5, (name, e(a, b))
+    # the composed HIP ops
+    y2 = lin(act.forward_cl(h))
+    got2 = torch.autograd.grad(y2, params, gy)
+    assert e(y2, y64.detach()) < 1e-5 and all(e(a, b) < 1e-5 for a, b in zip(got2, want))
+    # twice-differentiable fallback
+    y3 = native.d_tail(h, act, lin)
+    got3 = torch.autograd.grad(y3, params, gy, create_graph=True)
+    assert all(e(a.detach(), b) < 1e-5 for a, b in zip(got3, want))
+    # bit-identical from run to run (sums in index order, no atomics)
+    y4 = native.d_tail(h, act, lin)
+    got4 = torch.autograd.grad(y4, params, gy)
+    assert torch.equal(y, y4) and all(torch.equal(a, b) for a, b in zip(got, got4))
