@@ -44,6 +44,13 @@ struct MPGeom {
   // leaves from this epilogue instead of a pass of its own over y (reference: Head.forward, dusty_v2.py:30-57,171-178)
   const bf16_t* hw;   // [B, 2, O] the heads' prepared per-sample weights
   float* hd;          // [B, P, 2]
+  // ACTBWD instances (this launch is a DATA GRADIENT whose result is the gradient of an upstream layer's activation
+  // output): that layer's activation backward rides in the epilogue --
+  //   t = (yref > 0 ? g : g * alpha) * scale on the bf16-rounded g,  gb[o] += bf16(t),  stored: bf16(t * up_scale[o])
+  // bit for bit what dgv2_bias_act_bwd_rs makes of the g this launch would have stored (csrc/bias_act.hip)
+  const bf16_t* yref;       // [B, P, O] the upstream layer's forward OUTPUT
+  const float* up_scale;    // [O] its input-magnitude factor c[o]
+  float* gbpart;            // [gridDim.y * tiles, O] per-block column sums of bf16(t): the upstream bias gradient's partials
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned mp_u32x4;
@@ -90,7 +97,7 @@ __device__ __forceinline__ float dot8_bf16(const uint4& a, const mp_u32x4& b) {
 }
 
 // MF = O / 16, NFW = 16-pixel fragments per wave, KA = Ka / 32, KS = Ks / 32 (compile-time: register arrays)
-template <int MF, int NFW, int KA, int KS, bool HEAD = false>
+template <int MF, int NFW, int KA, int KS, bool HEAD = false, bool ACTBWD = false>
 __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ xa,
                                                                 const bf16_t* __restrict__ xs,
                                                                 const bf16_t* __restrict__ w, MPGeom g) {
@@ -157,6 +164,34 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     if constexpr (HEAD) mp_issue_hw<MF>(hwr[decltype(slot)::value], g.hw, min(b, b1 - 1), O, lc);
   };
   const int aswz = lc ^ ((lr >> 2) & 3);
+  // ACTBWD: the upstream output at the 8 channels this lane stores per fragment pair (pack_pair_bf16's channel offset),
+  // requested with the same hand-issued loads at the start of the sample's step, consumed in its epilogue
+  const int co8 = (lc & 1) ? 16 + 4 * (lc - 1) : 4 * lc;
+  u32x4 yr[ACTBWD ? NFW : 1][ACTBWD ? MF / 2 : 1];
+  float gbs[ACTBWD ? MF / 2 : 1][8];
+  __shared__ float s_up[ACTBWD ? MF * 16 : 1];      // up_scale of this block's slab
+  __shared__ float s_gb[ACTBWD ? 8 * MF * 16 : 1];  // the waves' column sums
+  if constexpr (ACTBWD) {
+#pragma unroll
+    for (int pr = 0; pr < MF / 2; ++pr)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gbs[pr][j] = 0.f;
+    for (int c = tid; c < MF * 16; c += 512) s_up[c] = g.up_scale[o_base + c];
+    __syncthreads();
+  }
+  auto issue_yref = [&](int b) {
+    if constexpr (ACTBWD) {
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) {
+        const int px = min(p0 + nf * 16 + lr, g.P - 1);
+#pragma unroll
+        for (int pr = 0; pr < MF / 2; ++pr) {
+          const bf16_t* src = g.yref + ((int64_t)b * g.P + px) * g.O + o_base + pr * 32 + co8;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(yr[nf][pr]) : "v"(src) : "memory");
+        }
+      }
+    }
+  };
 
   float ss = 0.f;
   // Hand-issued LDS reads and counted waits.  With an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` before every
@@ -195,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     asm volatile("" ::: "memory");
     if (!(MP_ABL & 4)) dma_w(min(b + 1, b1 - 1), S ^ 1);
     if (!(MP_ABL & 8)) issue_x(std::integral_constant<int, S ^ 1>{}, b + 1);
+    issue_yref(b);   // (ACTBWD) youngest loads of the step: the epilogue drains everything before it reads them
 
     f32x4 acc[MF][NFW];
 #pragma unroll
@@ -238,6 +274,14 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     }
 
     // epilogue: lane holds o = mf*16 + lc*4 + r at pixel nf*16 + lr; fragment pairs leave as 16-byte stores
+    if constexpr (ACTBWD) {
+      // the upstream outputs of THIS sample (and, older than them, the next sample's weights and fragments) have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+        for (int pr = 0; pr < MF / 2; ++pr) asm volatile("" : "+v"(yr[nf][pr]));
+    }
 #pragma unroll
     for (int nf = 0; nf < NFW; ++nf) {
       const int px = p0 + nf * 16 + lr;
@@ -261,6 +305,29 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
         }
         uint4 pk;
         const int co = pack_pair_bf16(va, vb, lc, pk);   // all lanes take part in the exchange
+        if constexpr (ACTBWD) {
+          const unsigned gw_[4] = {pk.x, pk.y, pk.z, pk.w};
+          unsigned ow[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned yw = yr[nf][mf / 2][i];
+            float t[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float gv = __uint_as_float(h ? (gw_[i] & 0xffff0000u) : (gw_[i] << 16));
+              const float yv = __uint_as_float(h ? (yw & 0xffff0000u) : (yw << 16));
+              const float v = (yv > 0.f ? gv : gv * g.alpha) * g.scale;
+              const bf16_t vb16 = (bf16_t)v;
+              if (live) gbs[mf / 2][2 * i + h] += (float)vb16;      // the sum of what the separate pass stores unscaled
+              t[h] = v * s_up[mf * 16 + co + 2 * i + h];
+            }
+            union { bf16_t e[2]; unsigned u; } o2;
+            o2.e[0] = (bf16_t)t[0];
+            o2.e[1] = (bf16_t)t[1];
+            ow[i] = o2.u;
+          }
+          pk = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
         if (live) {
           *reinterpret_cast<uint4*>(row + mf * 16 + co) = pk;
           if (g.sumsq) ss += sumsq_bf16x8(pk);
@@ -315,11 +382,33 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     const float s = block_sum(ss, red);
     if (tid == 0) g.sumsq[blockIdx.y * gridDim.x + blockIdx.x] = s;
   }
+  if constexpr (ACTBWD) {
+    // fold the 16 pixel lanes (lr) of a wave, then the 8 waves: one row of partials per (sample split, pixel tile)
+#pragma unroll
+    for (int pr = 0; pr < MF / 2; ++pr)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = gbs[pr][j];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if (lr == 0) s_gb[wave * (MF * 16) + pr * 32 + co8 + j] = v;
+      }
+    __syncthreads();
+    const int tile = blockIdx.x / slabs, tiles = gridDim.x / slabs;
+    for (int c = tid; c < MF * 16; c += 512) {
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) v += s_gb[wv * (MF * 16) + c];
+      g.gbpart[((int64_t)blockIdx.y * tiles + tile) * g.O + o_base + c] = v;
+    }
+  }
 }
 
-template <int MF, int NFW, int KA, int KS, bool HEAD = false>
+template <int MF, int NFW, int KA, int KS, bool HEAD = false, bool ACTBWD = false>
 int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, hipStream_t st, int sumsq_cap,
-              int* sumsq_used) {
+              int* sumsq_used, int64_t* part_rows = nullptr, int64_t part_cap = 0) {
   constexpr int TP = 8 * 16 * NFW;
   const int tiles = (g.P + TP - 1) / TP;
   // one resident block per CU (the PE fragments fill the register file): one round of blocks, as few sample
@@ -338,10 +427,14 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
     nsplit = (g.B + g.samples_per_block - 1) / g.samples_per_block;
   }
   dim3 grid(tiles * slabs, nsplit);
+  if (ACTBWD) {   // rows of column-sum partials this launch writes; a query (part_cap == 0) launches nothing
+    if (part_rows) *part_rows = (int64_t)tiles * nsplit;
+    if (part_cap < (int64_t)tiles * nsplit) return part_cap == 0 ? 0 : DGV2_EINVAL;
+  }
   if (g.sumsq && sumsq_used && tiles * nsplit * slabs <= sumsq_cap) *sumsq_used = tiles * nsplit * slabs;
   else g.sumsq = nullptr;
   constexpr size_t lds = sizeof(uint4) * 2 * (size_t)(((MF * 16) * (KA + KS) * 4 + 511) / 512 * 512);
-  auto kern = modconv_pe_fwd_kernel<MF, NFW, KA, KS, HEAD>;
+  auto kern = modconv_pe_fwd_kernel<MF, NFW, KA, KS, HEAD, ACTBWD>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -351,7 +444,63 @@ int mp_launch(void* y, const void* xa, const void* xs, const void* w, MPGeom g, 
   return 0;
 }
 
+// gb[c] = sum_r part[r][c]: one block per channel, 256 threads split the rows
+__global__ __launch_bounds__(256) void mp_gb_reduce_kernel(float* __restrict__ gb, const float* __restrict__ part, int rows,
+                                                           int C) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  float s = 0.f;
+#pragma unroll 4
+  for (int k = threadIdx.x; k < rows; k += 256) s += part[(int64_t)k * C + c];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) gb[c] = s;
+}
+
 }  // namespace
+
+// Data gradient of a PE-free modulated 1x1 layer (conv2 of a generator level: K -> K channels) FUSED with the activation
+// backward of the layer that produced its input (conv1 of the level):
+//   g[b,p,k]    = sum_o gy[b,p,o] wt[b,k,o]                      (rounded to bf16: what dgv2_modconv_pe_fwd stores)
+//   t           = (yref[b,p,k] > 0 ? g : g * alpha) * scale
+//   gpre[b,p,k] = bf16(t * up_scale[k]),     gb[k] = sum_{b,p} bf16(t)
+// -- bit for bit the pair dgv2_modconv_pe_fwd (Ks = 0) + dgv2_bias_act_bwd_rs it replaces (one pass over the gradient
+// instead of three; reference: the autograd chain of ModConv2d -> FusedLeakyReLU, gans/models/ops/style.py:105-118,
+// fused_act.py:46-59).  gy [B,P,K], wt [B,K,K] (conv2's per-sample weights, transposed), yref [B,P,K] bf16; up_scale, gb
+// fp32 [K]; scratch fp32 [scratch_elems] >= *rows_needed * K (call with scratch == NULL to query rows_needed; nothing is
+// launched).  K in {32, 64, 128}; DGV2_ENOTSUP otherwise.
+extern "C" int dgv2_modconv_pe_dgrad_actbwd(void* gpre, float* gb, float* scratch, int64_t scratch_elems, int64_t* rows_needed,
+                                            const void* gy, const void* wt, const void* yref, const float* up_scale,
+                                            float alpha, float scale, int B, int P, int K, int dtype, void* stream) {
+  if (rows_needed) *rows_needed = 0;
+  // (K = 256, level 1: the two-slab instance has no registers left for the column sums -- 44 spills; that level keeps the
+  // two launches)
+  if (dtype != DGV2_BF16 || (K != 32 && K != 64 && K != 128)) return DGV2_ENOTSUP;
+  if (B <= 0 || P <= 0) return DGV2_EINVAL;
+  const bool query = scratch == nullptr;
+  if (!query && (!gpre || !gb || !gy || !wt || !yref || !up_scale || !aligned16(gpre) || !aligned16(gy) || !aligned16(wt) ||
+                 !aligned16(yref)))
+    return DGV2_EINVAL;
+#ifdef DGV2_ABLATE
+  MPGeom g{B, P, K, 0, K, K, 1, 0, nullptr, 0, alpha, scale, nullptr, nullptr, nullptr, nullptr};
+#else
+  MPGeom g{B, P, K, 0, K, K, 1, nullptr, 0, alpha, scale, nullptr, nullptr, nullptr, nullptr};
+#endif
+  g.yref = (const bf16_t*)yref;
+  g.up_scale = up_scale;
+  g.gbpart = scratch;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t rows = 0;
+  const int64_t cap = query ? 0 : scratch_elems / K;
+  if (!query && cap < 1) return DGV2_EINVAL;
+  int rc;
+  if (K == 32) rc = mp_launch<2, 2, 1, 0, false, true>(gpre, gy, gy, wt, g, st, 0, nullptr, &rows, cap);
+  else if (K == 64) rc = mp_launch<4, 2, 2, 0, false, true>(gpre, gy, gy, wt, g, st, 0, nullptr, &rows, cap);
+  else rc = mp_launch<8, 1, 4, 0, false, true>(gpre, gy, gy, wt, g, st, 0, nullptr, &rows, cap);
+  if (rows_needed) *rows_needed = rows;
+  if (rc || query) return rc;
+  mp_gb_reduce_kernel<<<K, 256, 0, st>>>(gb, scratch, (int)rows, K);
+  DGV2_RETURN_LAST();
+}
 
 // Same contract as dgv2_bmm_nn_cat (bf16 in / bf16 out) for the shapes of the two top generator levels:
 // (Ka, Ks, O) = (64, 512, 32) (level-4 conv1) and, with Ks = 0 (xs unused), the PE-free shapes

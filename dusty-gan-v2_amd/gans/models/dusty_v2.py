@@ -214,7 +214,7 @@ class SynthesisBlock(nn.Module):
         conv = self.conv1
         sumsq, pe_sq = None, 0.0
         hup = None
-        if (conv._prep is not None and hin is not None and isinstance(self.resample, ops.Resample) and link is None
+        if (conv._prep is not None and hin is not None and isinstance(self.resample, ops.Resample)
                 and native.mod_up_ok(hin, pe0, conv._prep[1], self.resample.spec)):
             # the up-sampling commutes with the 1x1 contraction: the xa columns run at this block's INPUT resolution
             # and up2(h) is never materialised (csrc/modconv_up.hip); its statistic sum up2(h)^2 is a quadratic form of
@@ -234,7 +234,7 @@ class SynthesisBlock(nn.Module):
             conv.update_ema(sumsq, B * H * W * (cin + self.pe.out_ch), pe_sq, cvec)
             want = want_sq and (self.head.training if self.is_first else self.conv2.training)
             return native.mod_up_layer(hin, pe0, self.resample.spec, handle, wb, cvec, bias=act.bias, act=True,
-                                       alpha=act.negative_slope, scale=act.scale, want_sq=want, wt=wt, pre=pre)
+                                       alpha=act.negative_slope, scale=act.scale, want_sq=want, wt=wt, pre=pre, defer=link)
         if hin is not None and conv.training and isinstance(self.resample, ops.Resample):
             hup, sumsq = native.resample_sq(hin, self.resample.spec)   # the statistic leaves the same kernel
         elif hin is not None:
@@ -282,10 +282,14 @@ class SynthesisBlock(nn.Module):
         if angle.shape[0] == 1 and not angle.requires_grad and (hin is None or hin.shape[3] % vec == 0):
             # the layer that feeds the head shares a link with it: the head's data-gradient kernel then also runs that
             # layer's activation backward (native._head_dgrad_actbwd)
-            h = self._conv1_shared_pe(hin, ws[0], angle, shift, B, dt, want_sq=True, link=link if self.is_first else None)
-            if self.is_first and self.conv1._prep is not None:
+            # (a level with two convs: conv1 shares a link of its own with conv2, whose data-gradient kernel then runs
+            # conv1's activation backward in its epilogue -- native._dgrad_actbwd)
+            link1 = {}
+            h = self._conv1_shared_pe(hin, ws[0], angle, shift, B, dt, want_sq=True, link=link if self.is_first else link1)
+            if self.conv1._prep is not None:
                 a1 = self.bias_act1
-                up = dict(link=link, alpha=float(a1.negative_slope), scale=float(a1.scale), cvec=self.conv1._prep[2])
+                up = dict(link=link if self.is_first else link1, alpha=float(a1.negative_slope), scale=float(a1.scale),
+                          cvec=self.conv1._prep[2])
         elif angle.requires_grad and torch.is_grad_enabled():
             # differentiable encoding (gradients w.r.t. the angles: inversion / demo consumers; not the training path)
             a = angle if shift is None else angle + torch.stack([torch.zeros_like(shift), shift], dim=1)[:, :, None, None]
@@ -309,7 +313,8 @@ class SynthesisBlock(nn.Module):
                 self.conv2.update_ema(sumsq, h.numel(), 0.0, cvec)
                 hw = self.head.fused_weights()
                 h = native.mod_gemm_layer(h, None, handle, wb, cvec, bias=a2.bias, act=True, alpha=a2.negative_slope,
-                                          scale=a2.scale, want_sq=self.head.training, wt=wt, defer=link, head_w=hw)
+                                          scale=a2.scale, want_sq=self.head.training, wt=wt, defer=link, head_w=hw,
+                                          upstream=up)
                 if hw is not None:   # the heads' contraction left conv2's epilogue (levels 4 / 3; empty where it did not)
                     pre_d = h[-1]
                     h = h[0] if len(h) == 2 else h[:-1]

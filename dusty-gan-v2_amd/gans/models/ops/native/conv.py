@@ -595,15 +595,20 @@ def gemm_x3(a, b, a_trans, b_trans, I, J, T, scale=1.0, splits=1, out=None):
     return out if ok else None
 
 
+def _x3_ok(*ts):
+    return _X3 and all(t.dtype == torch.float32 and t.is_cuda for t in ts)
+
+
 class _LinearF32(Function):
     """y = (x @ W^T) * scale in fp32 for the 65536 -> 512 Linear of the discriminator's fp32 epilogue
     (dusty_v2.py:381-383,394-395).  The three GEMMs run on the bf16 matrix cores through the three-plane split of
     dgv2_gemm_x3 (fp32-equivalent: its error is below what the library's fp32-MFMA GEMM leaves on the same operands),
-    the forward as split-K over the chip.  Measured (scripts/mb_linear_x3.py, M = 128): forward 84 us (library split-K
-    bmm + sum: 79), data gradient 61 (75), weight gradient 68 (90) -- six bf16 products at the ~1.5 GHz the part holds
-    under bf16 MFMA load cost about what one fp32 product costs at its higher fp32-MFMA clock, so the gain is modest.
+    the forward as split-K over the chip (128 splits; at a batch of 64 the kernel form whose split rides inside the MFMA
+    loop: profiles/round6_mb_linear_x3.txt).  The backward is composed of the two sibling Functions below, each of
+    whose own backward is again one of the three forms: the twice-differentiable pass of R1 (create_graph=True) runs
+    the same kernels -- round 5 ran it on library GEMMs, 0.35 ms per R1 iteration, the last ones of the step.
     The weight gradient is written straight into the parameter's slice of the flat gradient buffer when FlatGradSync
-    offers one (`_dgv2_grad_out`: no 268 MB pack copy), and D's step has no library GEMM."""
+    offers one (`_dgv2_grad_out`: no 268 MB pack copy)."""
 
     @staticmethod
     def forward(ctx, x, weight, scale):
@@ -613,12 +618,8 @@ class _LinearF32(Function):
         Bn, K = x.shape
         O = w.shape[0]
         y = None
-        # 64-row tiles (a batch of 64: the G step's D forward) run the kernel form whose three-plane split rides inside
-        # the MFMA loop, 128 splits: 44 us against the library's 45 + its sum and scale launches (round 6; the
-        # phase form took 61) -- no library GEMM is left in the step
-        if _X3 and Bn % 64 == 0 and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous():
-            per_tile = 256 if Bn % 128 == 0 else 512
-            y = gemm_x3(x, w, False, False, Bn, O, K, scale=scale, splits=max(1, per_tile // max(1, O // 128)))
+        if _x3_ok(x, w) and Bn % 64 == 0 and w.is_contiguous():
+            y = gemm_x3(x, w, False, False, Bn, O, K, scale=scale, splits=max(1, 512 // max(1, O // 128)))
         if y is None:
             S = 32
             if K % (S * 8) == 0 and K >= 8192:
@@ -637,31 +638,73 @@ class _LinearF32(Function):
         if gy is None:
             return None, None, None
         x, weight = ctx.saved_tensors
-        if torch.is_grad_enabled():   # create_graph=True (R1): differentiable ops
-            g = gy * ctx.scale
-            return g @ weight, (g.t() @ x if want_param_grad(ctx, 1) else None), None
-        Bn, K = x.shape
-        O = weight.shape[0]
-        gx = gw = None
-        g = gy.contiguous()
-        w = weight.detach()
-        use = _X3 and g.dtype == torch.float32 and w.is_contiguous()
-        if ctx.needs_input_grad[0]:
-            gx = gemm_x3(g, w, False, True, Bn, K, O, scale=ctx.scale) if use else None
-            if gx is None:
-                gx = torch.mm(g * ctx.scale, w)
-        if ctx.needs_input_grad[1]:
-            out = getattr(weight, "_dgv2_grad_out", None)
+        gx = _LinearF32Dgrad.apply(gy, weight, ctx.scale) if ctx.needs_input_grad[0] else None
+        gw = None
+        if want_param_grad(ctx, 1):      # (R1's first pass takes input gradients only: act_resample.input_grads_only)
+            out = None if torch.is_grad_enabled() else getattr(weight, "_dgv2_grad_out", None)
             if out is not None and out.data_ptr() % 16:
                 out = None               # dgv2_gemm_x3 stores 16-byte rows: an unaligned slice of the flat buffer (a layout
                                          # whose preceding parameters do not add up to a multiple of 4 elements) is not
                                          # offered to it -- the kernel allocates and collect() packs as for any other gradient
             if out is not None:
                 out = out.view_as(out)   # a fresh alias: autograd adopts a gradient tensor nobody else holds
-            gw = gemm_x3(g, x, True, True, O, K, Bn, scale=ctx.scale, out=out) if use else None
-            if gw is None:
-                gw = torch.mm((g * ctx.scale).t(), x)
+            gw = _LinearF32Wgrad.apply(gy, x, ctx.scale, out)
         return gx, gw, None
+
+
+class _LinearF32Dgrad(Function):
+    """gx [M, K] = scale * g [M, O] @ W [O, K]  (the data gradient of _LinearF32; its own backward: the forward form for
+    the cotangent, the weight-gradient form for W)."""
+
+    @staticmethod
+    def forward(ctx, g, weight, scale):
+        ctx.set_materialize_grads(False)
+        g = g.contiguous()
+        w = weight.detach()
+        M, O = g.shape
+        K = w.shape[1]
+        gx = gemm_x3(g, w, False, True, M, K, O, scale=scale) if (_x3_ok(g, w) and w.is_contiguous()) else None
+        if gx is None:
+            gx = torch.mm(g * scale, w)
+        ctx.save_for_backward(g, weight)
+        ctx.scale = scale
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        if ggx is None:
+            return None, None, None
+        g, weight = ctx.saved_tensors
+        g_g = _LinearF32.apply(ggx, weight, ctx.scale) if ctx.needs_input_grad[0] else None
+        g_w = _LinearF32Wgrad.apply(g, ggx, ctx.scale, None) if ctx.needs_input_grad[1] else None
+        return g_g, g_w, None
+
+
+class _LinearF32Wgrad(Function):
+    """gw [O, K] = scale * g [M, O]^T @ x [M, K]  (the weight gradient of _LinearF32, optionally written into `out`; its own
+    backward: the forward form with the cotangent as the weight for g, the data-gradient form for x)."""
+
+    @staticmethod
+    def forward(ctx, g, x, scale, out):
+        ctx.set_materialize_grads(False)
+        g, x = g.contiguous(), x.contiguous()
+        M, O = g.shape
+        K = x.shape[1]
+        gw = gemm_x3(g, x, True, True, O, K, M, scale=scale, out=out) if _x3_ok(g, x) else None
+        if gw is None:
+            gw = torch.mm((g * scale).t(), x)
+        ctx.save_for_backward(g, x)
+        ctx.scale = scale
+        return gw
+
+    @staticmethod
+    def backward(ctx, ggw):
+        if ggw is None:
+            return None, None, None, None
+        g, x = ctx.saved_tensors
+        g_g = _LinearF32.apply(x, ggw, ctx.scale) if ctx.needs_input_grad[0] else None       # scale * x ggw^T  [M, O]
+        g_x = _LinearF32Dgrad.apply(g, ggw, ctx.scale) if ctx.needs_input_grad[1] else None  # scale * g ggw    [M, K]
+        return g_g, g_x, None, None
 
 
 def linear_f32(x, weight, scale):

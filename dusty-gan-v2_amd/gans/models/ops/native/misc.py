@@ -387,8 +387,15 @@ class _ModUpPrepared(Function):
         gb = None
         vn = 8 if gy.dtype == torch.bfloat16 else 4
         rows = gy.numel() // Otot
-        gpre = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
-        if cfg["act"] and gy.dtype == dt and Otot % vn == 0 and 256 % (Otot // vn) == 0:
+        link = cfg.get("defer")
+        if link is not None and bool(link.get("done")):
+            # the layer that consumed this output (conv2 of the level) already ran THIS layer's activation backward in
+            # the epilogue of its data-gradient kernel (modlayer._dgrad_actbwd): gy is the accumulator gradient, the
+            # bias gradient waits in `link`
+            gpre, gb = gy.to(dt), (link.get("gb") if cfg["has_bias"] else None)
+            link.clear()
+        elif cfg["act"] and gy.dtype == dt and Otot % vn == 0 and 256 % (Otot // vn) == 0:
+            gpre = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
             gb = torch.empty(Otot, device=dev, dtype=torch.float32)
             scratch = torch.empty(2048 * Otot, device=dev, dtype=torch.float32) if rows >= 65536 else None
             N.call("dgv2_bias_act_bwd_rs", N.ptr(gpre), N.ptr(gb), N.ptr(gy), N.ptr(out), rows, Otot, cfg["alpha"],
@@ -397,6 +404,7 @@ class _ModUpPrepared(Function):
             if not cfg["has_bias"]:
                 gb = None
         else:
+            gpre = torch.empty((B, H, W_, Otot), device=dev, dtype=dt)
             g0 = gy
             if cfg["act"]:
                 g0 = _bias_act_raw(gy, None, out, 1, cfg["alpha"], cfg["scale"], 1, Otot)
@@ -439,12 +447,13 @@ class _ModUpPrepared(Function):
 
 
 def mod_up_layer(h, xs, spec, handle, wb, cvec, bias=None, act=True, alpha=0.2, scale=math.sqrt(2.0), want_sq=False,
-                 wt=None, pre=None):
+                 wt=None, pre=None, defer=None):
     """conv1 of a generator level on the batch-shared PE, taking the level's LOW-resolution input h and the block's
     up-2 Resample spec (see _ModUpPrepared); same result as mod_gemm_layer(resample(h), xs, ...).
     pre: (t, wimg, ...) of mod_up_prepare(h, xs, wb, spec, act, alpha, scale) -- the low-resolution pass already done
     (ahead of the EMA update that produced cvec, whose common value is then applied inside the kernel)."""
-    cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0, want_sq=bool(want_sq), spec=spec)
+    cfg = dict(act=bool(act), alpha=float(alpha), scale=float(scale) if act else 1.0, want_sq=bool(want_sq), spec=spec,
+               defer=defer)   # defer: see mod_gemm_layer
     t, wimg = (None, None) if pre is None else pre[:2]
     return _ModUpPrepared.apply(cfg, h, xs, bias, handle, wb, cvec, wt, t, wimg)
 

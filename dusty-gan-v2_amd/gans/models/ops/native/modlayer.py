@@ -441,6 +441,8 @@ class _ModGemmPrepared(Function):
             fused = None
             if up is not None and cfg["fork"] and not torch.is_grad_enabled():
                 fused = _head_dgrad_actbwd(g3, wt, resid, xa, up)
+            elif up is not None and resid is None and not torch.is_grad_enabled():
+                fused = _dgrad_actbwd(g3, wt, xa, up)      # conv2 of a level: conv1's activation backward in the epilogue
             if fused is not None:
                 gxa = fused.reshape(xa.shape)
             else:
@@ -536,6 +538,44 @@ _HEAD_ACT_BLOCKS = {}
 
 
 _HEAD_ACTBWD = os.environ.get("DGV2_NO_HEAD_ACTBWD") is None   # A/B switch for benchmarking
+
+
+_DGRAD_ACTBWD = os.environ.get("DGV2_NO_DGRAD_ACTBWD") is None   # A/B switch for benchmarking
+_DGRAD_ACT_ROWS = {}
+
+
+def _dgrad_actbwd(g3, wt, xa, up):
+    """Data gradient of a PE-free K -> K modulated layer (conv2 of a generator level) fused with the activation backward
+    of the layer that produced its input xa (conv1 of the level): dgv2_modconv_pe_dgrad_actbwd, bit for bit the pair
+    dgv2_modconv_pe_fwd + dgv2_bias_act_bwd_rs.  up = dict(link, alpha, scale, cvec) as for _head_dgrad_actbwd; the
+    upstream layer's backward finds link["done"] and the bias gradient in link["gb"].  None where it does not apply."""
+    B, P, O = g3.shape
+    K = wt.shape[1]
+    if (not _DGRAD_ACTBWD or g3.dtype != torch.bfloat16 or xa.dtype != torch.bfloat16 or wt.dtype != torch.bfloat16
+            or K != O or K not in (32, 64, 128) or tuple(wt.shape) != (B, K, O)
+            or P < _PE_FREE_MINP.get((O, K), 1 << 30) or up.get("link") is None):
+        return None
+    key = (B, P, K)
+    if key not in _DGRAD_ACT_ROWS:
+        nr = _ct.c_int64(0)
+        ok = N.try_call("dgv2_modconv_pe_dgrad_actbwd", None, None, None, 0, _ct.addressof(nr), None, None, None, None,
+                        1.0, 1.0, B, P, K, N.BF16, N.stream())
+        _DGRAD_ACT_ROWS[key] = nr.value if ok else 0
+    rows = _DGRAD_ACT_ROWS[key]
+    if rows == 0:
+        return None
+    g3 = g3.contiguous()
+    xr = xa.contiguous()
+    gpre = torch.empty((B, P, K), device=xa.device, dtype=xa.dtype)
+    gb = torch.empty(K, device=xa.device, dtype=torch.float32)
+    scratch = torch.empty(rows * K, device=xa.device, dtype=torch.float32)
+    N.check(g3, wt, xr, up["cvec"])
+    if not N.try_call("dgv2_modconv_pe_dgrad_actbwd", N.ptr(gpre), N.ptr(gb), N.ptr(scratch), scratch.numel(), None, N.ptr(g3),
+                      N.ptr(wt), N.ptr(xr), N.ptr(up["cvec"]), up["alpha"], up["scale"], B, P, K, N.BF16, N.stream()):
+        return None
+    up["link"]["done"] = True
+    up["link"]["gb"] = gb
+    return gpre
 
 
 def _head_dgrad_actbwd(g3, wt, resid, xa, up):

@@ -347,6 +347,21 @@ int dgv2_modconv_pe_fwd_head(void* y, const void* xa, const void* xs, const void
                              int O, const float* row_scale, const float* bias, int act, float alpha, float scale, int dtype,
                              float* sumsq, int sumsq_cap, int* sumsq_used, const void* head_w, float* head_out, void* stream);
 
+/* Data gradient of a PE-free K -> K modulated 1x1 layer (conv2 of a generator level) FUSED with the activation backward
+ * of the layer that produced its input (conv1 of the level): one pass over the gradient instead of three.
+ * replaces: the autograd chain ModConv2d (data gradient, gans/models/ops/style.py:105-118) -> FusedLeakyReLU backward
+ *   (fused_act.py:46-59, fused_bias_act_kernel.cu:19-60) between the two convs of a SynthesisBlock (dusty_v2.py:160-170)
+ *   g[b,p,k]    = sum_o gy[b,p,o] wt[b,k,o]                    (rounded to bf16)
+ *   t           = (yref[b,p,k] > 0 ? g : g * alpha) * scale
+ *   gpre[b,p,k] = bf16(t * up_scale[k]),   gb[k] = sum_{b,p} bf16(t)
+ * -- bit for bit what dgv2_modconv_pe_fwd (Ks = 0) followed by dgv2_bias_act_bwd_rs produce.
+ * gy [B,P,K], wt [B,K,K], yref [B,P,K] (the upstream layer's forward output), gpre [B,P,K]: bf16; up_scale, gb fp32 [K];
+ * scratch fp32 [scratch_elems] >= *rows_needed * K.  scratch == NULL: only *rows_needed is written, nothing is launched.
+ * K in {32, 64, 128}, dtype DGV2_BF16; DGV2_ENOTSUP otherwise. */
+int dgv2_modconv_pe_dgrad_actbwd(void* gpre, float* gb, float* scratch, int64_t scratch_elems, int64_t* rows_needed,
+                                 const void* gy, const void* wt, const void* yref, const float* up_scale, float alpha,
+                                 float scale, int B, int P, int K, int dtype, void* stream);
+
 /* Per-sample weights of the modulated conv, written directly as the GEMM operand, and the exact
  * backward of that preparation (max-normalisations, modulation, demodulation, input-magnitude
  * scaling, optional rotation of the positional-encoding columns by shift_b * fw).

@@ -524,6 +524,33 @@ def test_linear_f32_matches_float64(nat):
     assert_rel(gw.cpu(), (gd.t() @ xd * scale).cpu(), 2e-6, "gw")
 
 
+def test_linear_f32_double_backward_matches_float64(nat):
+    """The R1 pattern through native.linear_f32: an input gradient taken with create_graph=True, a penalty on it, and the
+    penalty's gradients w.r.t. the weight AND the upstream cotangent -- every GEMM of both passes is one of the three
+    dgv2_gemm_x3 forms (_LinearF32 / _LinearF32Dgrad / _LinearF32Wgrad are each other's backward) -- against the same
+    computation in float64."""
+    g = torch.Generator().manual_seed(9)
+    Bn, K, O = 64, 4096, 128
+    scale = 1.0 / math.sqrt(K)
+    x0 = torch.randn(Bn, K, generator=g)
+    w0 = torch.randn(O, K, generator=g)
+    v0 = torch.randn(O, generator=g)
+
+    def run(dt, dev, fn):
+        x = x0.to(dev, dt).requires_grad_(True)
+        w = w0.to(dev, dt).requires_grad_(True)
+        v = v0.to(dev, dt).requires_grad_(True)
+        y = fn(x, w)
+        (gx,) = torch.autograd.grad((torch.tanh(y) * v).sum(), x, create_graph=True)
+        pen = (gx ** 2).sum()
+        gw, gv = torch.autograd.grad(pen, (w, v))
+        return y.detach(), gx.detach(), gw, gv
+    got = run(torch.float32, DEV, lambda x, w: nat.linear_f32(x, w, scale))
+    want = run(torch.float64, "cpu", lambda x, w: x @ w.t() * scale)
+    for name, a, b in zip(("y", "gx", "d pen / d w", "d pen / d v"), got, want):
+        assert_rel(a.cpu(), b, 1e-5, name)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_adjoint_resample_fused_with_activation_backward(nat, dtype):
     """dgv2_resample_tab_actbwd (adjoint blur/down + bias/leaky-ReLU backward + bias gradient in one pass) against the
@@ -2004,3 +2031,36 @@ def test_d_tail_matches_the_composed_ops_in_float64(B, K):
     y4 = native.d_tail(h, act, lin)
     got4 = torch.autograd.grad(y4, params, gy)
     assert torch.equal(y, y4) and all(torch.equal(a, b) for a, b in zip(got, got4))
+
+
+@pytest.mark.parametrize("B,P,K", [(3, 4096, 32), (2, 4096 + 200, 64), (5, 2048, 128), (64, 32768, 32)])
+def test_dgrad_with_upstream_activation_backward_is_bit_identical_to_the_two_launches(nat, B, P, K):
+    """dgv2_modconv_pe_dgrad_actbwd (conv2's data gradient of a generator level with conv1's activation backward in its
+    epilogue) against the two launches it replaces -- dgv2_modconv_pe_fwd (the same sample-walking kernel, Ks = 0) and
+    dgv2_bias_act_bwd_rs: the stored accumulator gradient BIT for bit (the epilogue masks / scales the bf16-rounded
+    gradient exactly as the separate pass reads it), the bias gradient to summation order.  Partial pixel tiles, odd
+    batches, all three channel counts; the last case is level 4 at the benchmark's batch."""
+    import dgv2_native as N
+    g = torch.Generator().manual_seed(B * 7 + K)
+    bf = torch.bfloat16
+    gy = torch.randn(B, P, K, generator=g).to(DEV).to(bf)
+    wt = (torch.randn(B, K, K, generator=g) / K ** 0.5).to(DEV).to(bf)
+    yref = torch.randn(B, P, K, generator=g).to(DEV).to(bf)
+    yref[0, :7, :5] = 0.0                                     # exact zeros take the negative branch (out > 0 is false)
+    cvec = (torch.rand(K, generator=g) + 0.5).to(DEV)
+    alpha, scale = 0.2, math.sqrt(2.0)
+    gd = nat._bmm_nn_raw(gy, wt, bf)
+    want = torch.empty_like(gd)
+    want_b = torch.empty(K, device=DEV)
+    rows = B * P
+    scratch = torch.empty(2048 * K, device=DEV) if rows >= 65536 else None
+    N.call("dgv2_bias_act_bwd_rs", N.ptr(want), N.ptr(want_b), N.ptr(gd), N.ptr(yref), rows, K, alpha, scale, N.ptr(cvec),
+           N.ptr(scratch), 0 if scratch is None else scratch.numel(), N.BF16, N.stream())
+    link = {}
+    got = nat._dgrad_actbwd(gy, wt, yref, dict(link=link, alpha=alpha, scale=scale, cvec=cvec))
+    if P < nat._PE_FREE_MINP[(K, K)]:
+        assert got is None
+        return
+    assert got is not None and link.get("done") is True
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert_rel(link["gb"].cpu(), want_b.cpu(), 1e-5, "bias gradient")
