@@ -85,6 +85,21 @@ __device__ __forceinline__ void mp_issue_hw(mp_u32x4 (&dst)[MF / 2][2], const bf
     }
 }
 
+// (ACTBWD) the upstream layer's output at the 8 channels a lane stores per fragment pair, one sample
+template <int NFW, int MF>
+__device__ __forceinline__ void mp_issue_yref(mp_u32x4 (&dst)[NFW][MF / 2], const bf16_t* __restrict__ yref, int b, int P,
+                                              int O, int p0, int lr, int ch0) {
+#pragma unroll
+  for (int nf = 0; nf < NFW; ++nf) {
+    const int px = min(p0 + nf * 16 + lr, P - 1);
+#pragma unroll
+    for (int pr = 0; pr < MF / 2; ++pr) {
+      const bf16_t* src = yref + ((int64_t)b * P + px) * O + ch0 + pr * 32;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[nf][pr]) : "v"(src) : "memory");
+    }
+  }
+}
+
 __device__ __forceinline__ float dot8_bf16(const uint4& a, const mp_u32x4& b) {
   const unsigned aw[4] = {a.x, a.y, a.z, a.w};
   float s = 0.f;
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   // ACTBWD: the upstream output at the 8 channels this lane stores per fragment pair (pack_pair_bf16's channel offset),
   // requested with the same hand-issued loads at the start of the sample's step, consumed in its epilogue
   const int co8 = (lc & 1) ? 16 + 4 * (lc - 1) : 4 * lc;
-  u32x4 yr[ACTBWD ? NFW : 1][ACTBWD ? MF / 2 : 1];
+  u32x4 yr[2][ACTBWD ? NFW : 1][ACTBWD ? MF / 2 : 1];   // samples b, b + 1: prefetched one sample ahead like the xa fragments
   float gbs[ACTBWD ? MF / 2 : 1][8];
   __shared__ float s_up[ACTBWD ? MF * 16 : 1];      // up_scale of this block's slab
   __shared__ float s_gb[ACTBWD ? 8 * MF * 16 : 1];  // the waves' column sums
@@ -179,18 +194,9 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     for (int c = tid; c < MF * 16; c += 512) s_up[c] = g.up_scale[o_base + c];
     __syncthreads();
   }
-  auto issue_yref = [&](int b) {
-    if constexpr (ACTBWD) {
-#pragma unroll
-      for (int nf = 0; nf < NFW; ++nf) {
-        const int px = min(p0 + nf * 16 + lr, g.P - 1);
-#pragma unroll
-        for (int pr = 0; pr < MF / 2; ++pr) {
-          const bf16_t* src = g.yref + ((int64_t)b * g.P + px) * g.O + o_base + pr * 32 + co8;
-          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(yr[nf][pr]) : "v"(src) : "memory");
-        }
-      }
-    }
+  auto issue_yref = [&](auto slot, int b) {
+    if constexpr (ACTBWD)   // tail: re-reads the last sample (as issue_x does)
+      mp_issue_yref<NFW, MF>(yr[decltype(slot)::value], g.yref, min(b, b1 - 1), g.P, g.O, p0, lr, o_base + co8);
   };
 
   float ss = 0.f;
@@ -226,11 +232,17 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(hwr[S][pr][j]));
     }
+    if constexpr (ACTBWD) {
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+        for (int pr = 0; pr < MF / 2; ++pr) asm volatile("" : "+v"(yr[S][nf][pr]));
+    }
     __builtin_amdgcn_s_barrier();   // all pieces landed; every wave is done with the other buffer
     asm volatile("" ::: "memory");
     if (!(MP_ABL & 4)) dma_w(min(b + 1, b1 - 1), S ^ 1);
     if (!(MP_ABL & 8)) issue_x(std::integral_constant<int, S ^ 1>{}, b + 1);
-    issue_yref(b);   // (ACTBWD) youngest loads of the step: the epilogue drains everything before it reads them
+    issue_yref(std::integral_constant<int, S ^ 1>{}, b + 1);   // (ACTBWD) with the next sample's fragments: landed by its step
 
     f32x4 acc[MF][NFW];
 #pragma unroll
@@ -274,14 +286,6 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
     }
 
     // epilogue: lane holds o = mf*16 + lc*4 + r at pixel nf*16 + lr; fragment pairs leave as 16-byte stores
-    if constexpr (ACTBWD) {
-      // the upstream outputs of THIS sample (and, older than them, the next sample's weights and fragments) have landed
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int nf = 0; nf < NFW; ++nf)
-#pragma unroll
-        for (int pr = 0; pr < MF / 2; ++pr) asm volatile("" : "+v"(yr[nf][pr]));
-    }
 #pragma unroll
     for (int nf = 0; nf < NFW; ++nf) {
       const int px = p0 + nf * 16 + lr;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
           unsigned ow[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const unsigned yw = yr[nf][mf / 2][i];
+            const unsigned yw = yr[S][nf][mf / 2][i];
             float t[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -351,6 +355,7 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
   if (b0 < b1) {
     dma_w(b0, 0);
     issue_x(std::integral_constant<int, 0>{}, b0);
+    issue_yref(std::integral_constant<int, 0>{}, b0);
   }
   for (int b = b0; b < b1; b += 2) {
     step(std::integral_constant<int, 0>{}, b);
@@ -376,6 +381,14 @@ __global__ __launch_bounds__(512, 2) void modconv_pe_fwd_kernel(bf16_t* __restri
       for (int pr = 0; pr < MF / 2; ++pr)
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(hwr[s2][pr][j]));
+  }
+  if constexpr (ACTBWD) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf)
+#pragma unroll
+        for (int pr = 0; pr < MF / 2; ++pr) asm volatile("" : "+v"(yr[s2][nf][pr]));
   }
   if (g.sumsq) {
     __shared__ float red[16];
@@ -467,14 +480,14 @@ __global__ __launch_bounds__(256) void mp_gb_reduce_kernel(float* __restrict__ g
 // instead of three; reference: the autograd chain of ModConv2d -> FusedLeakyReLU, gans/models/ops/style.py:105-118,
 // fused_act.py:46-59).  gy [B,P,K], wt [B,K,K] (conv2's per-sample weights, transposed), yref [B,P,K] bf16; up_scale, gb
 // fp32 [K]; scratch fp32 [scratch_elems] >= *rows_needed * K (call with scratch == NULL to query rows_needed; nothing is
-// launched).  K in {32, 64, 128}; DGV2_ENOTSUP otherwise.
+// launched).  K in {32, 64} (generator levels 4 / 3); DGV2_ENOTSUP otherwise.
 extern "C" int dgv2_modconv_pe_dgrad_actbwd(void* gpre, float* gb, float* scratch, int64_t scratch_elems, int64_t* rows_needed,
                                             const void* gy, const void* wt, const void* yref, const float* up_scale,
                                             float alpha, float scale, int B, int P, int K, int dtype, void* stream) {
   if (rows_needed) *rows_needed = 0;
-  // (K = 256, level 1: the two-slab instance has no registers left for the column sums -- 44 spills; that level keeps the
-  // two launches)
-  if (dtype != DGV2_BF16 || (K != 32 && K != 64 && K != 128)) return DGV2_ENOTSUP;
+  // (K = 128 / 256, levels 2 / 1: their instances have no registers left for the prefetched upstream outputs and the
+  // column sums -- 27 / 44 spills; they gained 6 us as a single-buffered form and keep the two launches)
+  if (dtype != DGV2_BF16 || (K != 32 && K != 64)) return DGV2_ENOTSUP;
   if (B <= 0 || P <= 0) return DGV2_EINVAL;
   const bool query = scratch == nullptr;
   if (!query && (!gpre || !gb || !gy || !wt || !yref || !up_scale || !aligned16(gpre) || !aligned16(gy) || !aligned16(wt) ||
@@ -494,8 +507,7 @@ extern "C" int dgv2_modconv_pe_dgrad_actbwd(void* gpre, float* gb, float* scratc
   if (!query && cap < 1) return DGV2_EINVAL;
   int rc;
   if (K == 32) rc = mp_launch<2, 2, 1, 0, false, true>(gpre, gy, gy, wt, g, st, 0, nullptr, &rows, cap);
-  else if (K == 64) rc = mp_launch<4, 2, 2, 0, false, true>(gpre, gy, gy, wt, g, st, 0, nullptr, &rows, cap);
-  else rc = mp_launch<8, 1, 4, 0, false, true>(gpre, gy, gy, wt, g, st, 0, nullptr, &rows, cap);
+  else rc = mp_launch<4, 2, 2, 0, false, true>(gpre, gy, gy, wt, g, st, 0, nullptr, &rows, cap);
   if (rows_needed) *rows_needed = rows;
   if (rc || query) return rc;
   mp_gb_reduce_kernel<<<K, 256, 0, st>>>(gb, scratch, (int)rows, K);

@@ -552,7 +552,7 @@ def _dgrad_actbwd(g3, wt, xa, up):
     B, P, O = g3.shape
     K = wt.shape[1]
     if (not _DGRAD_ACTBWD or g3.dtype != torch.bfloat16 or xa.dtype != torch.bfloat16 or wt.dtype != torch.bfloat16
-            or K != O or K not in (32, 64, 128) or tuple(wt.shape) != (B, K, O)
+            or K != O or K not in (32, 64) or tuple(wt.shape) != (B, K, O)
             or P < _PE_FREE_MINP.get((O, K), 1 << 30) or up.get("link") is None):
         return None
     key = (B, P, K)

@@ -357,7 +357,7 @@ int dgv2_modconv_pe_fwd_head(void* y, const void* xa, const void* xs, const void
  * -- bit for bit what dgv2_modconv_pe_fwd (Ks = 0) followed by dgv2_bias_act_bwd_rs produce.
  * gy [B,P,K], wt [B,K,K], yref [B,P,K] (the upstream layer's forward output), gpre [B,P,K]: bf16; up_scale, gb fp32 [K];
  * scratch fp32 [scratch_elems] >= *rows_needed * K.  scratch == NULL: only *rows_needed is written, nothing is launched.
- * K in {32, 64, 128}, dtype DGV2_BF16; DGV2_ENOTSUP otherwise. */
+ * K in {32, 64} (generator levels 4 / 3), dtype DGV2_BF16; DGV2_ENOTSUP otherwise. */
 int dgv2_modconv_pe_dgrad_actbwd(void* gpre, float* gb, float* scratch, int64_t scratch_elems, int64_t* rows_needed,
                                  const void* gy, const void* wt, const void* yref, const float* up_scale, float alpha,
                                  float scale, int B, int P, int K, int dtype, void* stream);
