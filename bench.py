@@ -124,10 +124,37 @@ def cpu_baseline(batch, steps=4):
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
-    dt = (time.perf_counter() - t0) / steps
+    dt_gd = (time.perf_counter() - t0) / steps
+    # the rest of an iteration: lazy R1 every 16th iteration (double backward through D and ADA),
+    # the two Adam steps, the EMA generator -- each timed on the same host and added at its share
+    ada1 = {"G": A.sample_affine(batch, H, W), "C": A.sample_color(batch)}
+    o_step.r1_step(sdD, x_real, 16.0, ada=ada1)   # warm-up
+    t0 = time.perf_counter()
+    o_step.r1_step(sdD, x_real, 16.0, ada=ada1)
+    dt_r1 = time.perf_counter() - t0
+
+    def params(sd, skip):
+        ps = [v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.endswith(skip)]
+        for q in ps:
+            q.grad = torch.randn_like(q)
+        return ps
+    pG, pD = params(sdG, o_step.G_BUFFER_SUFFIXES), params(sdD, o_step.D_BUFFER_SUFFIXES)
+    optG = torch.optim.Adam(pG, lr=0.002, betas=(0.0, 0.99))
+    optD = torch.optim.Adam(pD, lr=0.002 * 16 / 17, betas=(0.0, 0.99 ** (16 / 17)))
+    ema = [q.detach().clone() for q in pG]
+    for _ in range(2):   # the first step allocates the moments
+        t0 = time.perf_counter()
+        optG.step()
+        optD.step()
+        with torch.no_grad():
+            torch._foreach_lerp_(ema, [q.detach() for q in pG], 1.0 - 0.9995)
+        dt_opt = time.perf_counter() - t0
+    dt = dt_gd + dt_r1 / 16.0 + dt_opt
     return {"value": batch / dt, "unit": "range-images/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} iterations (G step + D step, fp32, B={batch}, ADA p=0.6, full-size dusty_v2 64x512) "
-                      f"of oracle/step.py after 1 warm-up; {dt:.2f} s/iteration"}
+            "sample": f"{steps} iterations (G step + D step, fp32, B={batch}, ADA p=0.6, full-size dusty_v2 64x512) of "
+                      f"oracle/step.py after 1 warm-up: {dt_gd:.2f} s; + one lazy-R1 pass at its 1/16 share ({dt_r1:.2f} s "
+                      f"each), + the two Adam steps and the EMA update of torch on the same tensors ({dt_opt:.3f} s); "
+                      f"{dt:.2f} s/iteration"}
 
 
 def _time_launches(fn, reps):

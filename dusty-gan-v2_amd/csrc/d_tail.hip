@@ -61,7 +61,27 @@ __global__ __launch_bounds__(256) void d_tail_bwd_kernel(float* __restrict__ gh,
   }
 }
 
+// dst[k] <- lerp(dst[k], mean_b src[b * ld + k], w): the running mean of the mapped latents (base.py:89-97), one launch
+__global__ __launch_bounds__(256) void colmean_lerp_kernel(float* __restrict__ dst, const float* __restrict__ src, int B,
+                                                           int K, int64_t ld, float w) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+#pragma unroll 8
+  for (int b = 0; b < B; ++b) s += src[(int64_t)b * ld + k];
+  const float d = dst[k];
+  dst[k] = d + w * (s / (float)B - d);
+}
+
 }  // namespace
+
+// dst fp32 [K] <- lerp(dst, mean over the B rows of src (fp32, row pitch ld >= K), w)
+// replaces: Generator.moving_average_w (gans/models/base.py:89-97: w.mean(0) + lerp) -- a reduction and a lerp launch
+extern "C" int dgv2_colmean_lerp(float* dst, const float* src, int B, int K, int64_t ld, float w, void* stream) {
+  if (!dst || !src || B < 1 || K < 1 || ld < K) return DGV2_EINVAL;
+  colmean_lerp_kernel<<<(K + 255) / 256, 256, 0, (hipStream_t)stream>>>(dst, src, B, K, ld, w);
+  DGV2_RETURN_LAST();
+}
 
 extern "C" int dgv2_d_tail_fwd(float* y, float* a, const float* h, const float* b1, const float* w2, const float* b2, int B,
                                int K, float alpha, float act_scale, float scale2, float gain2, void* stream) {

@@ -74,6 +74,7 @@ SIGNATURES = {
     "dgv2_emd_matchcost_grad": [_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr],
     "dgv2_nsgan_loss": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_f32, _c_ptr, _c_ptr, _c_ptr],
     "dgv2_modconv_pe_dgrad_actbwd": [_c_ptr, _c_ptr, _c_ptr, _c_i64] + [_c_ptr] * 5 + [_c_f32, _c_f32] + [_c_int] * 4 + [_c_ptr],
+    "dgv2_colmean_lerp": [_c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_f32, _c_ptr],
     "dgv2_d_tail_fwd": [_c_ptr] * 6 + [_c_int, _c_int] + [_c_f32] * 4 + [_c_ptr],
     "dgv2_d_tail_bwd": [_c_ptr] * 7 + [_c_int, _c_int] + [_c_f32] * 4 + [_c_ptr],
     "dgv2_rng_fill": [_c_ptr] * 5 + [_c_int, _c_ptr, _c_ptr],

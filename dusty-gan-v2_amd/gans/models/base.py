@@ -40,7 +40,13 @@ class Generator(nn.Module):
     @torch.no_grad()
     def moving_average_w(self, w):
         # in place (hipGraph-safe) form of base.py:89-97
-        batch_mean = w[:, 0].mean(dim=0, keepdim=True).to(self.w_avg)
+        w0 = w[:, 0]
+        if w0.is_cuda and w0.dtype == torch.float32 and self.w_avg.dtype == torch.float32 and w0.stride(-1) == 1:
+            import dgv2_native as N   # mean over the batch + lerp in ONE launch (was a reduction and a lerp)
+            N.call("dgv2_colmean_lerp", N.ptr(self.w_avg), N.ptr(w0), w0.shape[0], w0.shape[1], w0.stride(0),
+                   1 - self.w_avg_decay, N.stream())
+            return
+        batch_mean = w0.mean(dim=0, keepdim=True).to(self.w_avg)
         self.w_avg.lerp_(batch_mean, 1 - self.w_avg_decay)
 
     def truncation_trick(self, w, psi=1.0):

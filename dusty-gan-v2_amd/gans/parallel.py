@@ -133,12 +133,25 @@ class FlatGradSync:
             return (self.n_first_params, n), (self.n_first, ne)
         raise ValueError(part)
 
-    def collect(self, accumulate=False, scale=1.0, part=None):
+    def collect(self, accumulate=False, scale=1.0, part=None, pack=True):
         """End of the body: pack the fresh gradients into the flat buffer with one multi-tensor copy and
         re-attach the views (stable addresses for the captured optimizer graphs and the all-reduce).
         Gradient accumulation (reference: trainer.py:255-257,296): the chunk's gradients are scaled by
         `scale` = 1 / num_accumulation (the reference divides the loss) and, from the second chunk on
-        (`accumulate`), ADDED to what the buffer holds.  part: only that segment's parameters."""
+        (`accumulate`), ADDED to what the buffer holds.  part: only that segment's parameters.
+        pack=False (one process, one chunk, the optimizer step in the SAME body -- Trainer.step): nobody needs the flat
+        buffer: the gradients stay where the backward left them (inside a capture: in that graph's own pool, the addresses
+        the optimizer kernels of the same graph read); a parameter the backward did not reach gets its zeroed slice, as
+        the packed form gives it."""
+        if not pack:
+            if accumulate or scale != 1.0 or part is not None:
+                raise RuntimeError("collect(pack=False) is the one-chunk, whole-module form")
+            for v, p in zip(self._views(), self.params):
+                if p.grad is None:
+                    v.zero_()
+                    p.grad = v
+                p._dgv2_grad_out = None
+            return
         (lo, hi), _ = self._part(part)
         views = self._views()[lo:hi]
         params = self.params[lo:hi]

@@ -357,7 +357,7 @@ class Trainer:
     # Each sub-step is split into a forward/backward body (`*_fb`), the gradient all-reduce (eager,
     # RCCL) and the optimizer body, so that the bodies can be replayed as hipGraphs while the
     # collectives stay ordinary stream work between them.
-    def g_fb(self, j, scalars, x_real=None):
+    def g_fb(self, j, scalars, x_real=None, pack=True):
         set_requires_grad(self.G, True)
         self.g_sync.begin(direct=j == 0)
         self._begin_body("g")
@@ -383,15 +383,34 @@ class Trainer:
         else:
             loss_gan = self.adversarial_loss(y_real, y_fake, "G")
             (self.cfg.training.loss.gan * loss_gan).backward()
-        self.g_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
+        self.g_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation, pack=pack)
         set_requires_grad(self.G, False)
         scalars["loss/G/adversarial"] = loss_gan.detach()
+
+    # One process, one chunk: nothing happens between a body's backward and its optimizer step (no exchange, no second
+    # chunk), so both are ONE body -- one graph launch instead of two, and Adam reads the gradients where the backward
+    # left them (FlatGradSync.collect(pack=False): no pack copy, 40 us of multi-tensor launches for G's 140 tensors).
+    def g_fb_opt(self, j, scalars):
+        self.g_fb(j, scalars, pack=False)
+        self._opt_step(self.optim_G)
+
+    def g_fb_rel_opt(self, x_real, j, scalars):
+        self.g_fb(j, scalars, x_real, pack=False)
+        self._opt_step(self.optim_G)
+
+    def d_fb_opt(self, x_real, j, scalars):
+        self.d_fb(x_real, j, scalars, pack=False)
+        self._opt_step(self.optim_D)
+
+    def r1_fb_opt(self, x_real, j, scalars):
+        self.r1_fb(x_real, j, scalars, pack=False)
+        self._opt_step(self.optim_D)
 
     def g_fb_rel(self, x_real, j, scalars):
         """G step of a relativistic objective: also D(A(real)) (argument order of the other bodies that take reals)."""
         self.g_fb(j, scalars, x_real)
 
-    def d_fb(self, x_real, j, scalars, cut=False):
+    def d_fb(self, x_real, j, scalars, cut=False, pack=True):
         set_requires_grad(self.D, True)
         self.d_sync.begin(direct=j == 0)
         self._begin_body("d")
@@ -431,7 +450,7 @@ class Trainer:
             self._d_cut = self.D.take_cut()
             self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation, part="first")
         else:
-            self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
+            self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation, pack=pack)
         scalars["loss/D/output/real"] = out_real
         scalars["loss/D/output/fake"] = out_fake
         scalars["loss/D/adversarial"] = loss_gan.detach()
@@ -449,7 +468,7 @@ class Trainer:
         feat.backward(leaf.grad)
         self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation, part="rest")
 
-    def r1_fb(self, x_real, j, scalars):
+    def r1_fb(self, x_real, j, scalars, pack=True):
         """lazy R1 (reference: trainer.py:419-451): double backward through D and ADA."""
         set_requires_grad(self.D, True)
         self.d_sync.begin(direct=False)
@@ -460,9 +479,9 @@ class Trainer:
         conv = self.D.epilogue[1] if hasattr(self.D, "epilogue") else None
         live = {(conv.in_ch + 15) // 16 * 16: conv.in_ch} if conv is not None and hasattr(conv, "in_ch") else None
         with x3_auto(getattr(self.D, "num_fp16_layers", 0) == -1, live):
-            return self._r1_body(x, j, scalars)
+            return self._r1_body(x, j, scalars, pack)
 
-    def _r1_body(self, x, j, scalars):
+    def _r1_body(self, x, j, scalars, pack=True):
         y_real = self.D(self.A(self.warmup(x, self._draw("r1.keep")), draws=self._ada("r1.ada")), double_backward=True)
         # (only the gradient w.r.t. the input is taken here: the Functions skip their weight / bias gradients, which
         # ctx.needs_input_grad alone would make them compute and discard)
@@ -479,7 +498,7 @@ class Trainer:
         if os.environ.get("DGV2_R1_ZERO_TERM"):
             loss = loss + 0.0 * y_real.squeeze()[0]
         loss.backward()
-        self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation)
+        self.d_sync.collect(accumulate=j > 0, scale=1.0 / self.num_accumulation, pack=pack)
         scalars["loss/D/gradient_penalty"] = r1.detach()
 
     def pl_fb(self, j, scalars):
@@ -605,6 +624,48 @@ class Trainer:
         # chunk 0 overwrites the flat gradient buffer, later chunks add to it: two different captured bodies
         return name if j == 0 else name + "/acc"
 
+    def _fold(self):
+        # fold: the small reductions ride INSIDE the optimizer graphs (G's 17.5 MB, D's 20 MB "rest", R1's) -- every graph
+        # launch and every cross-stream join costs the GPU a dependency bubble (one rank on RCCL: 8 graphs + 3 joins per
+        # iteration ran 3.6 % behind the 4-graph plain step); only D's head reduction (134 MB under the trunk's backward)
+        # keeps its side stream.  Eager / gloo runs keep the asynchronous form.
+        return (parallel.is_dist() and self.use_graphs and self.device.type == "cuda"
+                and torch.distributed.get_backend() == "nccl" and os.environ.get("DGV2_NO_FOLDED_REDUCE") is None)
+
+    def _g_substep(self, iteration, nacc, late_reals, log, real):
+        """The G step in its exchanging / accumulating form: bodies, gradient reduction, optimizer step."""
+        for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
+            if j == 0 and not self._g_bufs_synced:
+                parallel.sync_buffers(self.G)
+            if self.use_real_in_g:
+                log(self._run(self._acc_name("g_fb", j), self.g_fb_rel, real(j), j))
+            else:
+                log(self._run(self._acc_name("g_fb", j), self.g_fb, j))
+        # G's 17.5 MB (+ rank 0's buffers) leave on the communication stream; the real batch of this iteration is
+        # fetched / generated and converted meanwhile (the D step itself starts with a forward of the UPDATED G)
+        fold = self._fold()
+
+        def g_reduce_opt(sc):
+            self.g_sync.all_reduce(carry=True)
+            self._opt_step(self.optim_G)
+
+        if fold:
+            if late_reals:
+                self.fetch_reals(next(self.iter_train_loader), out=self.x_real)
+            # (its own body name: "g_opt" is the Adam-only graph of the non-folded form and of the path-length step)
+            ok = self.g_sync.carry_ok()   # outside the graph: a replay carries what it carried at capture time
+            self._run("g_red_opt", g_reduce_opt)
+            self._g_bufs_synced = ok and self.g_sync.last_carried
+        else:
+            ok = self.g_sync.carry_ok()
+            h = self.g_sync.all_reduce_captured(carry=True)
+            if late_reals:
+                self.fetch_reals(next(self.iter_train_loader), out=self.x_real)
+            self.g_sync.wait(h)
+            self._g_bufs_synced = h is not None and ok and self.g_sync.last_carried
+            self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
+
+
     def step(self, iteration):
         self.G.train()
         self.set_warmup_params(iteration)
@@ -642,41 +703,18 @@ class Trainer:
         # Where the broadcast travels: the one before the G step rode in the previous iteration's tail exchange
         # (_g_bufs_synced), the one before the D step rides behind G's gradients; the stand-alone sync_buffers remains
         # for the first iteration and around the path-length step.
-        for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
-            if j == 0 and not self._g_bufs_synced:
-                parallel.sync_buffers(self.G)
+        # one process, one chunk: forward / backward and optimizer step of a sub-step are ONE body (see g_fb_opt)
+        fuse_opt = (not parallel.is_dist()) and nacc == 1 and os.environ.get("DGV2_NO_FUSED_OPT") is None
+        if fuse_opt:
             if self.use_real_in_g:
-                log(self._run(self._acc_name("g_fb", j), self.g_fb_rel, real(j), j))
+                log(self._run("g_step", self.g_fb_rel_opt, real(0), 0))
             else:
-                log(self._run(self._acc_name("g_fb", j), self.g_fb, j))
-        # G's 17.5 MB (+ rank 0's buffers) leave on the communication stream; the real batch of this iteration is
-        # fetched / generated and converted meanwhile (the D step itself starts with a forward of the UPDATED G)
-        # fold: the small reductions ride INSIDE the optimizer graphs (G's 17.5 MB, D's 20 MB "rest", R1's) -- every graph
-        # launch and every cross-stream join costs the GPU a dependency bubble (one rank on RCCL: 8 graphs + 3 joins per
-        # iteration ran 3.6 % behind the 4-graph plain step); only D's head reduction (134 MB under the trunk's backward)
-        # keeps its side stream.  Eager / gloo runs keep the asynchronous form.
-        fold = (parallel.is_dist() and self.use_graphs and self.device.type == "cuda"
-                and torch.distributed.get_backend() == "nccl" and os.environ.get("DGV2_NO_FOLDED_REDUCE") is None)
-
-        def g_reduce_opt(sc):
-            self.g_sync.all_reduce(carry=True)
-            self._opt_step(self.optim_G)
-
-        if fold:
-            if late_reals:
+                log(self._run("g_step", self.g_fb_opt, 0))
                 self.fetch_reals(next(self.iter_train_loader), out=self.x_real)
-            # (its own body name: "g_opt" is the Adam-only graph of the non-folded form and of the path-length step)
-            ok = self.g_sync.carry_ok()   # outside the graph: a replay carries what it carried at capture time
-            self._run("g_red_opt", g_reduce_opt)
-            self._g_bufs_synced = ok and self.g_sync.last_carried
+            fold = False
         else:
-            ok = self.g_sync.carry_ok()
-            h = self.g_sync.all_reduce_captured(carry=True)
-            if late_reals:
-                self.fetch_reals(next(self.iter_train_loader), out=self.x_real)
-            self.g_sync.wait(h)
-            self._g_bufs_synced = h is not None and ok and self.g_sync.last_carried
-            self._run("g_opt", lambda sc: self._opt_step(self.optim_G))
+            self._g_substep(iteration, nacc, late_reals, log, real)
+            fold = self._fold()
 
         if self.pl_weight > 0.0 and iteration % self.lazy_pl == 0:
             for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
@@ -689,8 +727,12 @@ class Trainer:
             self._g_bufs_synced = h is not None and ok and self.g_sync.last_carried
             self._run("g_opt", lambda sc: self._opt_step(self.optim_G))   # Adam only: the reduction ran just above
 
+        fuse_d = fuse_opt and not self.split_d
         pending = []
         for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
+            if fuse_d:
+                log(self._run("d_step", self.d_fb_opt, real(j), j))
+                continue
             if j == 0 and not self._g_bufs_synced:
                 parallel.sync_buffers(self.G)
             if self.split_d:
@@ -706,7 +748,7 @@ class Trainer:
         # the (rest of the) gradient reduction of D runs on the communication stream while the EMA generator is updated
         # (G is final for this iteration: nothing below touches it)
         rest = "rest" if self.split_d else None
-        if not fold:
+        if not fold and not fuse_d:
             pending.append(self.d_sync.all_reduce_captured(part=rest))
         decay = self.ema_decay(iteration)
         ema_inplace(self.G_ema, self.G, decay)
@@ -719,7 +761,9 @@ class Trainer:
                 self._opt_step(self.optim_D)
             return body
 
-        if fold:
+        if fuse_d:
+            pass                               # the optimizer step rode in the body
+        elif fold:
             self._run("d_opt", d_reduce_opt(rest))
         else:
             self._run("d_opt", lambda sc: self._opt_step(self.optim_D))
@@ -729,10 +773,13 @@ class Trainer:
         r1_pending = None
         if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
             for j in gradient_accumulation(nacc, parallel.is_dist(), self.ddp_models):
-                log(self._run(self._acc_name("r1_fb", j), self.r1_fb, real(j), j))
+                if fuse_d:
+                    log(self._run("r1_step", self.r1_fb_opt, real(j), j))
+                else:
+                    log(self._run(self._acc_name("r1_fb", j), self.r1_fb, real(j), j))
             # R1's 154 MB leave asynchronously; the scalar bookkeeping below runs under them.  The optimizer step cannot
             # move past the next iteration's G step, whose D forward must see the regularised weights (trainer.py:419-451).
-            if not fold:
+            if not fold and not fuse_d:
                 r1_pending = self.d_sync.all_reduce_captured()
 
         scalars = {k: (v[0] if len(v) == 1 else torch.stack([t.reshape(()) for t in v]).mean())
@@ -775,7 +822,7 @@ class Trainer:
             out = {}
             tail(out)
         self._g_bufs_synced = parallel.is_dist()
-        if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0:
+        if self.gp_weight > 0.0 and iteration % self.lazy_gp == 0 and not fuse_d:
             if fold:   # (with the split D the plain step's optimizer graph reduces the "rest" segment only: another body)
                 self._run("d_opt" if rest is None else "d_all_opt", d_reduce_opt(None))
             else:

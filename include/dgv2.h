@@ -803,6 +803,10 @@ int dgv2_d_tail_fwd(float* y, float* a, const float* h, const float* b1, const f
 int dgv2_d_tail_bwd(float* gh, float* gb1, float* gw2, float* gb2, const float* gy, const float* a, const float* w2,
                     int B, int K, float alpha, float act_scale, float scale2, float gain2, void* stream);
 
+/* dst fp32 [K] <- lerp(dst, mean over the B rows of src (fp32 [B, ld], ld >= K), w) in one launch.
+ * replaces: Generator.moving_average_w, gans/models/base.py:89-97 (w[:, 0].mean(0) and the lerp into w_avg). */
+int dgv2_colmean_lerp(float* dst, const float* src, int B, int K, int64_t ld, float w, void* stream);
+
 /* ---------------------------------------------------------------------------
  * every random number of one step body from ONE launch
  * replaces: the torch.randn / torch.rand calls of an iteration -- Trainer.sample_z (gans/trainer.py:206-208), the azimuth

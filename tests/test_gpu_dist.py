@@ -82,8 +82,8 @@ def test_one_rank_on_rccl_equals_the_plain_run(tmp_path, graph):
     (tmp_path / "plain").mkdir()
     (r,) = _run(tmp_path / "rccl", 1, iters, graph, {"DGV2_DIST_WORLD1": "1"})
     assert r["backend"] == "nccl" and r["split_d"]
-    if graph:
-        assert {"g_fb/inj", "g_opt", "d_fb_head/inj", "d_fb_tail/inj", "d_opt", "r1_fb/inj"} <= set(r["graphs"]), r["graphs"]
+    if graph:   # (RCCL + graphs: the small reductions ride inside the optimizer bodies -- "g_red_opt" = G's reduction + Adam)
+        assert {"g_fb/inj", "g_red_opt", "d_fb_head/inj", "d_fb_tail/inj", "d_opt", "r1_fb/inj"} <= set(r["graphs"]), r["graphs"]
     (one,) = _run(tmp_path / "plain", 1, iters, graph)
     assert one["backend"] is None
     for k in one["scalars"][0]:

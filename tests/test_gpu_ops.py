@@ -2065,3 +2065,25 @@ def test_dgrad_with_upstream_activation_backward_is_bit_identical_to_the_two_lau
     assert got is not None and link.get("done") is True
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
     assert_rel(link["gb"].cpu(), want_b.cpu(), 1e-5, "bias gradient")
+
+
+def test_w_avg_update_is_one_launch_and_matches_torch():
+    """Generator.moving_average_w (base.py:89-97) through dgv2_colmean_lerp against torch's mean + lerp, on the expanded
+    [B, n_styles, D] view the mapping network returns (row pitch = D) and on a stacked style-mixing tensor (row pitch =
+    n_styles * D)."""
+    from gans.models.base import Generator
+
+    class _G(Generator):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.register_buffer("w_avg", torch.zeros(1, 96))
+            self.w_avg_decay = 0.995
+    for stacked in (False, True):
+        g = _G().to(DEV)
+        base = torch.randn(7, 96, device=DEV)
+        w = torch.stack([base, base * 2, base * 3], dim=1) if stacked else base[:, None, :].expand(-1, 5, -1)
+        with torch.no_grad():
+            g.w_avg.copy_(torch.randn(1, 96))
+        want = torch.lerp(g.w_avg.clone(), w[:, 0].mean(0, keepdim=True), 1 - 0.995)
+        g.moving_average_w(w)
+        assert float((g.w_avg - want).abs().max()) < 1e-6

@@ -36,7 +36,7 @@ def test_iterations_run_and_train(hip_graph):
         assert all(torch.isfinite(torch.tensor(list(vals.values())))), vals
         seen.append(vals)
     if hip_graph:
-        assert set(tr._graphs) == {"g_fb", "g_opt", "d_fb", "d_opt", "r1_fb"}
+        assert set(tr._graphs) == {"g_step", "d_step", "r1_step"}   # one process: body + optimizer step are one graph
     # scalars are live (not stale copies) and the losses move
     assert len({round(s["loss/D/adversarial"], 6) for s in seen}) > 4
     assert "loss/D/gradient_penalty" in seen[1] and "stats/ada_p" in seen[1]
@@ -159,7 +159,7 @@ def test_iterations_match_reference_trainer(tag, hip_graph):
         for it in range(1, 7):     # two eager warm runs + capture of every body (R1 runs on even iterations)
             _run_fixture_iteration(tr, d, tag, it, n)
         suffix = ("/warmup" if tag == "w." else "") + "/inj"    # bodies reading injected draws are their own graphs
-        assert {"g_fb" + suffix, "d_fb" + suffix, "r1_fb" + suffix, "g_opt", "d_opt"} <= set(tr._graphs)
+        assert {"g_step" + suffix, "d_step" + suffix, "r1_step" + suffix} <= set(tr._graphs)
         assert all(v is not None for v in tr._graphs.values()), "a body fell back to eager"
         _reset(tr, hp, sdG, sdD)
     mods = (("G", tr.G), ("D", tr.D), ("Gema", tr.G_ema))
@@ -271,7 +271,7 @@ def graph_vs_eager_runs(B=64, H=64, W=512, n_it=4):
         return outs
 
     run(graph, range(1, 7))   # pre-roll: warm runs + captures
-    assert all(v is not None for v in graph._graphs.values()) and len(graph._graphs) == 5, graph._graphs.keys()
+    assert all(v is not None for v in graph._graphs.values()) and len(graph._graphs) == 3, graph._graphs.keys()   # g / d / r1 step
     reset(eager)
     first = run(eager, range(1, n_it + 1))
     state_first = {n: copy.deepcopy(m.state_dict()) for n, m in (("G", eager.G), ("D", eager.D), ("Gema", eager.G_ema))}
@@ -430,7 +430,7 @@ def test_split_d_backward_equals_the_single_pass(hip_graph):
     assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
     live = two.graphs_live()
     if hip_graph:
-        assert {"d_fb_head", "d_fb_tail", "g_fb"} <= set(live) and all(live.values()), live
+        assert {"d_fb_head", "d_fb_tail", "g_step"} <= set(live) and all(live.values()), live
 
 
 # ---------------------------------------------------------------------------- relativistic objectives
@@ -483,7 +483,7 @@ def test_relativistic_objectives_use_the_reals_in_the_generator_step(objective):
         out = tg.step(it)
     assert all(torch.isfinite(v).all() for v in out.values() if torch.is_tensor(v))
     live = tg.graphs_live()
-    assert "g_fb" in live and all(live.values()), live
+    assert "g_step" in live and all(live.values()), live
 
 
 # ---------------------------------------------------------------------------- the D step on the G step's weight bank
@@ -498,7 +498,7 @@ def test_d_step_on_the_g_steps_weight_bank_equals_a_fresh_bank(mode, monkeypatch
     tag = "t."
     hip_graph = mode != "eager"
     if mode == "g_eager_d_graph":
-        monkeypatch.setenv("DGV2_GRAPHS", "d_fb,d_opt,g_opt,r1_fb")   # (matched before the /inj suffix)
+        monkeypatch.setenv("DGV2_GRAPHS", "d_step,r1_step")   # (matched before the /inj suffix)
     a, hp, sdG, sdD = _fixture_trainer(d, tag, hip_graph, low_precision=True)
     b, _, _, _ = _fixture_trainer(d, tag, hip_graph, low_precision=True)
     b.reuse_d_bank = False
@@ -517,7 +517,7 @@ def test_d_step_on_the_g_steps_weight_bank_equals_a_fresh_bank(mode, monkeypatch
     assert a.d_bank_reused == (mode != "g_eager_d_graph") and not b.d_bank_reused
     if hip_graph:
         live = a.graphs_live()
-        assert live.get("d_fb/inj") is True and (("g_fb/inj" in live) == (mode == "graph")), live
+        assert live.get("d_step/inj") is True and (("g_step/inj" in live) == (mode == "graph")), live
     # same kernels on the same numbers whether the bank was rebuilt or kept; float atomics in the weight-gradient
     # reductions are the only run-to-run noise (Adam with beta1 = 0 turns a flipped near-zero gradient entry into 2 lr)
     for k in outs[0]:
