@@ -22,7 +22,7 @@ timeout 900 python bench.py --steps 20 --warmup 5 > $D/bench_default.log 2> $D/b
 timeout 300 python bench.py --workload gfwd --batch-per-gpu 32 --steps 50 --warmup 10 > $D/bench_gfwd.log 2>&1; line bench_gfwd
 timeout 600 python bench.py --res 128x1024 --batch-per-gpu 32 --steps 10 --warmup 4 --no-cpu-baseline > $D/bench_128x1024_bf16.log 2>&1; line bench_128x1024_bf16
 timeout 600 python bench.py --res 128x1024 --batch-per-gpu 32 --steps 10 --warmup 4 --no-cpu-baseline --dtype fp8 > $D/bench_128x1024_fp8.log 2>&1; line bench_128x1024_fp8
-(for s in mb_modup mb_conv_fp8 mb_linear_x3 mb_pewgrad2 mb_conv mb_conv_s2 mb_conv_x3 mb_conv8 mb_s2d mb_midgemm mb_rng; do timeout 300 python scripts/$s.py; done) 2>&1 | grep -v amdgpu.ids > $D/microbench_tables.txt
+(for s in mb_modup mb_conv_fp8 mb_linear_x3 mb_dgrad_actbwd mb_pewgrad2 mb_conv mb_conv_s2 mb_conv_x3 mb_conv8 mb_s2d mb_midgemm mb_rng; do timeout 300 python scripts/$s.py; done) 2>&1 | grep -v amdgpu.ids > $D/microbench_tables.txt
 # one rank on RCCL: the collectives of the N > 1 path (captured reductions on a side stream, the tail exchange) with nobody to wait for
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $D/bench_noextra.log 2>/dev/null; line bench_noextra
 DGV2_DIST_WORLD1=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $D/bench_one_rank_rccl.log 2> $D/bench_one_rank_rccl.err; line bench_one_rank_rccl
