@@ -7,7 +7,7 @@ import bench
 args = argparse.Namespace(batch_per_gpu=64, dtype="bf16", ada_p=0.6, no_graph=False, res="64x512")
 from gans.trainer import Trainer
 from gans.utils import init_random_seed
-init_random_seed(0, 0)
+init_random_seed(int(os.environ.get("DGV2_SEED", "0")), 0)
 cfg = bench.make_cfg(args, 0, 1)
 if os.environ.get("DGV2_TORCH_RNG"):   # A/B: torch's generator instead of the one-launch Philox draws
     cfg.training.native_rng = False
