@@ -88,7 +88,8 @@ def make_cfg(args, rank, world):
 
 def cpu_baseline(batch, steps=4):
     """The CPU oracle (oracle/step.py, a port of the reference's CPU path pinned by golden vectors)
-    timed on this host: full-size dusty_v2, fp32, one iteration = G step + D step, ADA at p=0.6."""
+    timed on this host: full-size dusty_v2, fp32, ADA at p=0.6; one iteration = G step + D step + the lazy-R1 pass at its
+    1/16 share + both Adam steps + the EMA update."""
     import numpy as np
     from helpers import ada_from_cfg, build_models, full_cfg
     from oracle import coords as o_coords
