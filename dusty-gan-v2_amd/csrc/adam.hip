@@ -3,6 +3,8 @@
 // all-reduce buffer) and the moment tensors of torch's own optimizer state stay separate tensors; their addresses
 // travel by value in the kernel arguments, so the launch is hipGraph-capturable and the optimizer's state_dict keeps
 // torch's layout.  Seven fp32 streams per element (p, g, m, v read; p, m, v written): a pure HBM kernel.
+// beta1 == 0 (both optimizers of the reference's config, dusty_v2.yaml lr.*.beta1 = 0.0): the first moment IS the gradient
+// (torch's lerp(m, g, 1) returns g exactly), so m is written but never read -- six streams (B1ZERO instance).
 //   m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 // The step counter lives on the device (graph replay): dgv2_adam_prep advances it and leaves the two bias
 // corrections of that step in a 4-float scratch that the update kernel reads.
@@ -28,6 +30,7 @@ __global__ void adam_prep_kernel(float* __restrict__ sc, float* __restrict__ ste
   sc[2] = sqrtf(1.f - powf(b2, s));   // sqrt(bias_correction2)
 }
 
+template <bool B1ZERO>
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, const float* __restrict__ sc, float lr, float b1,
                                                         float b2, float eps) {
   const int l = blockIdx.y;
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, const float*
   float* __restrict__ v = a.v[l];
   const float step_size = lr / sc[1], bc2s = sc[2];
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {
-    mm = mm + (1.f - b1) * (gg - mm);
+    mm = B1ZERO ? gg : mm + (1.f - b1) * (gg - mm);
     vv = b2 * vv + (1.f - b2) * gg * gg;
     pp -= step_size * mm / (sqrtf(vv) / bc2s + eps);
   };
@@ -48,14 +51,24 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a, const float*
   if (vec) {
     const int n4 = n >> 2;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-      float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+      float4 pp = reinterpret_cast<float4*>(p)[i], vv = reinterpret_cast<float4*>(v)[i];
       const float4 gg = reinterpret_cast<const float4*>(g)[i];
+      float4 mm = gg;
+      if constexpr (!B1ZERO) mm = reinterpret_cast<float4*>(m)[i];
       upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
       reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
     }
-    for (int i = (n4 << 2) + blockIdx.x * 256 + threadIdx.x; i < n; i += stride) upd(p[i], g[i], m[i], v[i]);
+    for (int i = (n4 << 2) + blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      float mm = B1ZERO ? 0.f : m[i];
+      upd(p[i], g[i], mm, v[i]);
+      m[i] = mm;
+    }
   } else {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) upd(p[i], g[i], m[i], v[i]);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      float mm = B1ZERO ? 0.f : m[i];
+      upd(p[i], g[i], mm, v[i]);
+      m[i] = mm;
+    }
   }
 }
 
@@ -110,6 +123,7 @@ extern "C" int dgv2_adam_step(float* const* p, const float* const* g, float* con
     nmax = n[l] > nmax ? n[l] : nmax;
   }
   dim3 grid(grid_for(nmax / 4 + 1, 256, 1024), L);
-  adam_step_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, sc, lr, b1, b2, eps);
+  if (b1 == 0.f) adam_step_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(a, sc, lr, b1, b2, eps);
+  else adam_step_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(a, sc, lr, b1, b2, eps);
   DGV2_RETURN_LAST();
 }

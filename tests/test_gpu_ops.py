@@ -898,6 +898,11 @@ def test_fused_adam_matches_torch_adam(nat):
         sd = o_dev.state_dict()["state"]
         assert float(sd[0]["step"]) == 3.0 and sd[1]["exp_avg"].shape == shapes[1]
         assert_rel(sd[2]["exp_avg_sq"].cpu(), o_ref.state_dict()["state"][2]["exp_avg_sq"], 1e-5)
+        for i in range(len(shapes)):    # first moments too: with beta1 = 0 the kernel never READS them, and they are the gradient
+            want = o_ref.state_dict()["state"][i]["exp_avg"]
+            assert_rel(sd[i]["exp_avg"].cpu(), want, 1e-6)
+            if b1 == 0.0:
+                assert torch.equal(sd[i]["exp_avg"].cpu(), grads[i])
 
 
 # ---------------------------------------------------------------------------------------
